@@ -1,0 +1,231 @@
+/*
+ * tredgpu.h -- C ABI of libtredgpu.so, the MI355X (gfx950) STR-genotyping hot path.
+ *
+ * This is the drop-in boundary for the two compute steps of humanlongevity/tredparse
+ * (reference paths relative to /root/reference):
+ *
+ *   (1) per-read Smith-Waterman against the template ladder + read tagging
+ *       replaces   src/ssw.h:72-182 (ssw_init / ssw_align / init_destroy / align_destroy),
+ *                  bound one alignment at a time by src/ssw_wrap.py:69-83,177-227, and the loop
+ *                  around it in tredparse/bam_parser.py:84-182 (_buildDB, get_hangs, _parseReadSW)
+ *                  and :256-268 (tally_counts, rept).
+ *   (2) the (h1,h2) allele-pair likelihood grid
+ *       replaces   tredparse/models.py:149-302 (pdf_spanning .. evaluate), :319-368 (calc_CI,
+ *                  calc_PP) and :426-473 (PEMaxLikModel incl. the gaussian_kde call).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every buffer is caller-owned; the library allocates only inside
+ *     the opaque context.  No function calls exit() or throws (contrast ssw.c:584-587).
+ *   - every function returns 0 on success, <0 on error; tredgpu_last_error() gives the text.
+ *   - mem: TREDGPU_MEM_HOST -> array arguments are host pointers (the call copies in, runs,
+ *     copies out and synchronises); TREDGPU_MEM_DEVICE -> they are device pointers valid on the
+ *     context's GPU (e.g. torch tensors' data_ptr()); the call only enqueues work on the context's
+ *     stream and returns; use tredgpu_sync() or stream-ordered consumers.
+ *   - a context is bound to one GPU and one HIP stream; calls on one context are serialised on that
+ *     stream; different contexts are independent (one process per GPU).
+ *   - "unit" = one sample x locus group (one runBam call, tredparse/tred.py:153-169).
+ *   - "ladder" = the template set of one locus at one READLEN: prefix + repeat*u + suffix and its
+ *     reverse complement for u = 1..max_units (bam_parser.py:84-100).
+ */
+#ifndef TREDGPU_H
+#define TREDGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TREDGPU_MEM_HOST 0
+#define TREDGPU_MEM_DEVICE 1
+
+/* read tags, bam_parser.py:157-168 (POST shares PREF's histogram, bam_parser.py:77) */
+#define TREDGPU_TAG_NONE 0
+#define TREDGPU_TAG_FULL 1
+#define TREDGPU_TAG_PREF 2
+#define TREDGPU_TAG_POST 3
+#define TREDGPU_TAG_REPT 4
+#define TREDGPU_TAG_HANG 5
+#define TREDGPU_TAG_INVALID 255 /* read longer than the instantiated kernel handles */
+
+#define TREDGPU_MAX_READ_LEN 256   /* rows per alignment the kernels are instantiated for */
+#define TREDGPU_MAX_TEMPLATE_LEN 511
+#define TREDGPU_SPAN 1000          /* SPAN, bam_parser.py:29 / models.py pdf length */
+
+typedef struct tredgpu_ctx tredgpu_ctx;
+
+/* scoring + tagging constants: bam_parser.py:95-98 (1/5/7/2), :30 (FLANKMATCH 9), :154-155 (clip) */
+typedef struct tredgpu_sw_params {
+    int32_t match;      /* +match on the diagonal                (ssw_wrap.py:154-167) */
+    int32_t mismatch;   /* -mismatch off the diagonal, N scores 0                       */
+    int32_t gap_open;   /* first gap base costs gap_open          (ssw.c:225-232)        */
+    int32_t gap_extend; /* every further gap base costs gap_extend                      */
+    int32_t flank;      /* FLANKMATCH                                                   */
+    int32_t clip;       /* --useclippedreads: REPT cut-off from the read's own length   */
+    int32_t max_read_len; /* upper bound of read_len[] in the call (selects the kernel
+                             instantiation: 64/112/160/256 rows); 0 = scan read_len (HOST
+                             memory) or assume TREDGPU_MAX_READ_LEN (DEVICE memory).  A read
+                             longer than the bound gets out_tag TREDGPU_TAG_INVALID.      */
+    int32_t reserved;
+} tredgpu_sw_params;
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+int tredgpu_create(int device_id, tredgpu_ctx** out);
+void tredgpu_destroy(tredgpu_ctx* ctx);
+const char* tredgpu_last_error(const tredgpu_ctx* ctx);  /* ctx may be NULL: last create error */
+int tredgpu_sync(tredgpu_ctx* ctx);
+/* the HIP stream (hipStream_t) all work of this context is enqueued on */
+void* tredgpu_get_stream(tredgpu_ctx* ctx);
+const char* tredgpu_version(void);
+
+/* ---- static tables ------------------------------------------------------------------------ */
+/*
+ * Register the template ladders (replaces BamParser._buildDB, bam_parser.py:84-100, which the
+ * reference rebuilds for every sample x locus).  Ladder i = (prefix[i], repeat[i], suffix[i],
+ * max_units[i]); sequences are ASCII, N allowed (motifs such as GCN), case-insensitive.
+ * max_units[i] = ceil(READLEN / len(repeat)) (bam_parser.py:73); 0 registers a plain reference
+ * sequence (prefix only) for tredgpu_sw_dump-style single alignments (Aligner.align).
+ * Replaces any previously registered set.
+ */
+int tredgpu_set_ladders(tredgpu_ctx* ctx, int32_t n_ladders, const char* const* prefix,
+                        const char* const* repeat, const char* const* suffix,
+                        const int32_t* max_units);
+
+/*
+ * Stutter / step-size model constants (replaces StepModel / NoiseModel, models.py:42-84).
+ *   step_pdf: 6 x 37 doubles, row p-1 = "Period<p>Model" (index 18 = offset 0);
+ *             periods 7..17 reuse row 6 (models.py:59-60); period >= 18 is an error as in the
+ *             reference (KeyError).
+ *   stutter_w: 5 doubles: bias, w_period, w_units, w_gc, w_score (models.py:79-84).
+ */
+int tredgpu_set_model(tredgpu_ctx* ctx, const double* step_pdf, const double* stutter_w,
+                      double gc, double score);
+
+/* ---- host-side packing helper ------------------------------------------------------------- */
+/*
+ * 2-bit + N-mask packing of reads (replaces Aligner._DNA_to_int_mat, ssw_wrap.py:229-244).
+ * seqs: concatenated ASCII reads, seq_off[n_reads+1] byte offsets.  For read r of length L the
+ * packed record is ceil(L/16) words of 2-bit codes (A0 C1 G2 T3, base i at bits 2*(i%16) of word
+ * i/16) followed by ceil(L/32) words of N flags (bit i%32 of word i/32; any non-ACGT letter).
+ * word_off_out[n_reads+1] receives the record offsets (in 32-bit words), len_out[n_reads] the
+ * lengths.  Returns the total number of words, or <0; call with packed_out == NULL to size.
+ */
+int64_t tredgpu_pack_reads(const char* seqs, const int64_t* seq_off, int64_t n_reads,
+                           uint32_t* packed_out, int64_t* word_off_out, int32_t* len_out);
+
+/* ---- (1) template Smith-Waterman + tagging ------------------------------------------------- */
+/*
+ * For every read: align against all 2*max_units templates of its unit's ladder, filter
+ * (ssw_wrap.py:214-220 with min_len/min_score of bam_parser.py:133-134), tag (bam_parser.py:139-168)
+ * and keep max(key=(score,-units)) (bam_parser.py:174).
+ *
+ *   packed, read_off[n_reads+1], read_len[n_reads]   as produced by tredgpu_pack_reads
+ *   unit_read_off[n_units+1]   reads of unit g are [unit_read_off[g], unit_read_off[g+1])
+ *   unit_ladder[n_units]       ladder index of each unit
+ *   out_tag[n_reads] (TREDGPU_TAG_*), out_h[n_reads] (repeat units), out_score[n_reads]
+ *   out_dump: optional (NULL to skip), int16 [n_reads][dump_templates][6] =
+ *             {score, ref_begin, ref_end, read_begin, read_end, tag-before-argmax} per template in
+ *             the reference's db order (u=1 fwd, u=1 rc, u=2 fwd, ...), i.e. field-for-field the
+ *             s_align members ssw_wrap.py:302-310 copies; -1 rows for templates a ladder lacks.
+ */
+int tredgpu_sw_classify(tredgpu_ctx* ctx, int mem, const uint32_t* packed, const int64_t* read_off,
+                        const int32_t* read_len, int64_t n_reads, const int32_t* unit_read_off,
+                        const int32_t* unit_ladder, int32_t n_units,
+                        const tredgpu_sw_params* params, uint8_t* out_tag, int16_t* out_h,
+                        int16_t* out_score, int16_t* out_dump, int32_t dump_templates);
+
+/*
+ * Histograms of one batch (replaces tally_counts + rept, bam_parser.py:256-268):
+ *   full_cnt[n_units][hist_stride], pref_cnt[...] (PREF and POST together, bam_parser.py:77),
+ *   rept_cnt[...]; bin = repeat units h (< hist_stride).  All int32.
+ * If read_pair_id != NULL (int32 per read, equal for the two mates of a pair, <0 = none) pairs whose
+ * reads are both REPT are dropped first (remove_pairs_of_rept, bam_parser.py:270-287; --norepeatpairs).
+ */
+int tredgpu_tally(tredgpu_ctx* ctx, int mem, const uint8_t* tag, const int16_t* h, int64_t n_reads,
+                  const int32_t* unit_read_off, int32_t n_units, const int32_t* read_pair_id,
+                  int32_t hist_stride, int32_t* full_cnt, int32_t* pref_cnt, int32_t* rept_cnt);
+
+/* ---- (2) likelihood grid -------------------------------------------------------------------- */
+/* per-unit inputs of IntegratedCaller (models.py:106-147) that are not histograms */
+typedef struct tredgpu_unit_params {
+    int32_t period;        /* len(repeat)                                  models.py:113   */
+    int32_t readlen;       /* READLEN                                      models.py:112   */
+    int32_t ploidy;        /* 1 or 2                                       models.py:122   */
+    int32_t maxinsert;     /* --maxinsert (300)                            models.py:124   */
+    int32_t fullsearch;    /* --fullsearch                                 models.py:125   */
+    int32_t ref_len;       /* repeat_end - repeat_start + 1                bam_parser.py:68 */
+    int32_t minpe;         /* end - start + 2*FLANKMATCH + 2               bam_parser.py:361 */
+    int32_t cutoff_risk;   /* tred.cutoff_risk                             models.py:342-368 */
+    int32_t is_expansion;  /* mutation_nature == 'increase'                meta.py:125     */
+    int32_t is_recessive;  /* inheritance[-1] == 'R'                       meta.py:124     */
+    int32_t pe_off;        /* this unit's slice of global_lens: [pe_off, pe_off+n_global) */
+    int32_t n_global;      /* len(pe.global_lens)                          bam_parser.py:342-359 */
+    int32_t tl_off;        /* this unit's slice of target_lens                             */
+    int32_t n_target;      /* len(pe.target_lens)                                          */
+    double half_depth;     /* depth / 2                                    models.py:123   */
+} tredgpu_unit_params;
+
+/* per-unit outputs of IntegratedCaller.evaluate (models.py:223-302) */
+typedef struct tredgpu_call {
+    int32_t status;     /* 0 ok; 1 no evidence (alleles -1,-1; models.py:244-245,406-408);
+                           <0 error that the reference would raise for this unit (the locus is
+                           dropped by tred.py:245-249): -2 singular KDE, -3 observation >= SPAN */
+    int32_t n_pairs;    /* size of the evaluated grid                                    */
+    int32_t h1, h2;     /* arg-max pair in bp (key (ml, -h1), first in enumeration; models.py:299) */
+    int32_t ci[4];      /* h1_lo, h1_hi, h2_lo, h2_hi in repeat units (models.py:287-290) */
+    int32_t run_pe;     /* models.py:234-236                                             */
+    int32_t pad;
+    double lik;         /* max log-likelihood                                            */
+    double pp;          /* calc_PP, models.py:342-368                                    */
+} tredgpu_call;
+
+/*
+ * Evaluate the grid of every unit.
+ *   full_cnt / pref_cnt / rept_cnt: as produced by tredgpu_tally (rept = sum of a unit's REPT bins)
+ *   global_lens / target_lens: int32 pools indexed through pe_off/tl_off (PEextractor output)
+ *   calls[n_units]
+ *   dump (optional): grid_off[n_units+1] (int64, caller-computed capacity offsets) and
+ *   grid_dump = doubles [total][6] = {h1, h2, ml1, ml2, ml3, ml4} in enumeration order
+ *   (models.py:260-273); pass NULL/NULL to skip.  A unit whose grid exceeds its capacity sets
+ *   status -4 and dumps nothing.
+ *   marg (optional): doubles [n_units][2][marg_stride]: un-normalised marginals P_h1 / P_h2
+ *   (models.py:277-285) indexed by position in the unit's h-axis (see tredgpu_grid_axis).
+ */
+int tredgpu_likelihood_grid(tredgpu_ctx* ctx, int mem, const tredgpu_unit_params* units,
+                            int32_t n_units, int32_t hist_stride, const int32_t* full_cnt,
+                            const int32_t* pref_cnt, const int32_t* rept_cnt,
+                            const int32_t* global_lens, int64_t n_global_total,
+                            const int32_t* target_lens, int64_t n_target_total,
+                            tredgpu_call* calls, const int64_t* grid_off, double* grid_dump,
+                            double* marg, int32_t marg_stride);
+
+/*
+ * The fused path: SW + tagging -> histograms -> grid for a whole batch, nothing leaves the GPU
+ * in between.  Arguments are the union of the three calls above; histograms are written to the
+ * caller's buffers as well (they are the FR/PR/RR strings of the JSON, tred.py:254-256).
+ */
+int tredgpu_genotype_batch(tredgpu_ctx* ctx, int mem, const uint32_t* packed,
+                           const int64_t* read_off, const int32_t* read_len, int64_t n_reads,
+                           const int32_t* unit_read_off, const int32_t* unit_ladder,
+                           const tredgpu_unit_params* units, int32_t n_units,
+                           const tredgpu_sw_params* params, const int32_t* read_pair_id,
+                           const int32_t* global_lens, int64_t n_global_total,
+                           const int32_t* target_lens, int64_t n_target_total,
+                           uint8_t* out_tag, int16_t* out_h, int16_t* out_score,
+                           int32_t hist_stride, int32_t* full_cnt, int32_t* pref_cnt,
+                           int32_t* rept_cnt, tredgpu_call* calls);
+
+/*
+ * KDE of the paired-end model alone (replaces gaussian_kde(global_lens).evaluate(arange(1000))
+ * normalised to sum 1, models.py:428-435): pdf_out[n_units][1000]; units with fewer than 2
+ * lengths or zero variance get status -2 in status_out.
+ */
+int tredgpu_pe_kde(tredgpu_ctx* ctx, int mem, const tredgpu_unit_params* units, int32_t n_units,
+                   const int32_t* global_lens, int64_t n_global_total, double* pdf_out,
+                   int32_t* status_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TREDGPU_H */

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One libtredgpu context on cuda:0 for the whole GPU session."""
+    from tredparse_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def loci():
+    from tredparse_amd import synth
+    return synth.load_loci()

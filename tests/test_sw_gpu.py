@@ -1,0 +1,132 @@
+"""GPU parity: HIP template-ladder SW + tagging vs the CPU oracle (bit-exact, integer work).
+
+Every call goes through the C ABI (libtredgpu.so).  The oracle (oracle/sw_oracle.c) is the plain
+restatement of ssw.c / bam_parser.py pinned against the compiled reference in test_oracle_sw.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tredparse_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gpu(ctx, ladders, reads, unit_read_off, unit_ladder, dump=True, clip=False):
+    ctx.set_ladders(ladders)
+    packed, woff, rlen = _lib.pack_reads(reads)
+    n = len(reads)
+    nt = max(2 * l[3] for l in ladders)
+    tag = np.zeros(n, np.uint8)
+    h = np.zeros(n, np.int16)
+    score = np.zeros(n, np.int16)
+    dumpa = np.zeros((n, nt, 6), np.int16) if dump else None
+    uro = np.asarray(unit_read_off, np.int32)
+    ul = np.asarray(unit_ladder, np.int32)
+    ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, uro, ul, len(ul), _lib.default_sw_params(clip=clip),
+                    tag, h, score, dumpa, nt if dump else 0)
+    return tag, h, score, dumpa
+
+
+def _oracle(ladders, reads, unit_read_off, unit_ladder, clip=False):
+    ls = po.LocusSet(ladders)
+    read_locus = np.zeros(len(reads), np.int32)
+    for g, lad in enumerate(unit_ladder):
+        read_locus[unit_read_off[g]:unit_read_off[g + 1]] = lad
+    cls = po.classify(reads, read_locus, ls, clip=clip, threads=8)
+    return cls, ls, read_locus
+
+
+@pytest.mark.parametrize("readlen,names", [(150, ["HD", "DM1", "SCA10", "ULD", "OPMD", "ALS"]),
+                                            (100, ["HD", "DM2", "BPES"]), (250, ["SCA36", "FRDA"]),
+                                            (36, ["HD"])])
+def test_ladder_dump_matches_oracle(ctx, loci, readlen, names):
+    rng = np.random.default_rng(7 + readlen)
+    p = synth.SynthParams(coverage=12, readlen=readlen, sub=0.02, indel=0.004, nrate=0.01,
+                          min_units=1, max_units=max(3, readlen // 3 + 8))
+    sel = [l for l in loci if l["name"] in names]
+    ladders, reads, uro, ul = [], [], [0], []
+    for li, locus in enumerate(sel):
+        lb = synth.simulate_locus(rng, locus, 3, p)
+        ladders.append((locus["prefix"], locus["repeat"], locus["suffix"], -(-readlen // len(locus["repeat"]))))
+        for g in range(3):
+            rr = [synth.decode(r) for r in lb.reads[lb.unit_read_off[g]:lb.unit_read_off[g + 1]]]
+            rr += ["N" * readlen, synth.decode(rng.integers(0, 4, readlen).astype(np.uint8))]
+            reads += rr
+            uro.append(len(reads))
+            ul.append(li)
+    tag, h, score, dump = _run_gpu(ctx, ladders, reads, uro, ul)
+    cls, ls, read_locus = _oracle(ladders, reads, uro, ul)
+    # field-by-field per template against the restated ssw_align
+    n_bad = 0
+    for r, read in enumerate(reads):
+        g = read_locus[r]
+        t0, t1 = ls.lad_off[g], ls.lad_off[g + 1]
+        refs = ls.templates[t0:t1]
+        want = po.sw_pairs([read], refs, [0] * len(refs), list(range(len(refs))))
+        got = dump[r, :len(refs), :5].astype(np.int32)
+        if not np.array_equal(got, want):
+            n_bad += 1
+            if n_bad < 5:
+                k = np.nonzero((got != want).any(axis=1))[0][0]
+                print("read", r, "template", k, "gpu", got[k], "oracle", want[k])
+    assert n_bad == 0
+    assert np.array_equal(tag, cls[:, 0].astype(np.uint8))
+    assert np.array_equal(h, cls[:, 1].astype(np.int16))
+    assert np.array_equal(score, cls[:, 2].astype(np.int16))
+    assert (tag != 0).sum() > 0
+
+
+def test_ragged_units_and_lengths(ctx, loci):
+    """Empty units, units of 1..9 reads (partial quads), mixed read lengths in one launch."""
+    rng = np.random.default_rng(3)
+    hd = [l for l in loci if l["name"] == "HD"][0]
+    ladders = [(hd["prefix"], hd["repeat"], hd["suffix"], 50)]
+    p = synth.SynthParams(coverage=40, readlen=150)
+    lb = synth.simulate_locus(rng, hd, 1, p, h_pairs=[[17, 42]])
+    pool = [synth.decode(r) for r in lb.reads]
+    reads, uro, ul = [], [0], []
+    for n in (0, 1, 2, 3, 4, 5, 9, 0, 7):
+        for k in range(n):
+            s = pool[int(rng.integers(0, len(pool)))]
+            cut = int(rng.integers(0, 60))
+            reads.append(s[cut:] if rng.random() < 0.5 else s[:150 - cut])
+        uro.append(len(reads))
+        ul.append(0)
+    tag, h, score, _ = _run_gpu(ctx, ladders, reads, uro, ul, dump=False)
+    cls, _, _ = _oracle(ladders, reads, uro, ul)
+    assert np.array_equal(tag, cls[:, 0].astype(np.uint8))
+    assert np.array_equal(h, cls[:, 1].astype(np.int16))
+    assert np.array_equal(score, cls[:, 2].astype(np.int16))
+    # clip mode: REPT cut-off from the read's own length (bam_parser.py:154-155)
+    tag2, h2, score2, _ = _run_gpu(ctx, ladders, reads, uro, ul, dump=False, clip=True)
+    cls2, _, _ = _oracle(ladders, reads, uro, ul, clip=True)
+    assert np.array_equal(tag2, cls2[:, 0].astype(np.uint8))
+    assert np.array_equal(h2, cls2[:, 1].astype(np.int16))
+
+
+def test_plain_reference_alignment(ctx):
+    """max_units = 0 ladders: one arbitrary reference per unit (the Aligner.align use case)."""
+    rng = np.random.default_rng(11)
+    refs = [synth.decode(rng.integers(0, 4, n).astype(np.uint8)) for n in (40, 120, 300, 511)]
+    reads, uro, ul = [], [0], []
+    for i, ref in enumerate(refs):
+        for k in range(5):
+            a = int(rng.integers(0, max(1, len(ref) - 30)))
+            frag = ref[a:a + 150]
+            frag = frag[:len(frag) // 2] + "ACGTNACG" + frag[len(frag) // 2:]
+            reads.append(frag[:150] if len(frag) > 30 else frag + "ACGT" * 10)
+        uro.append(len(reads))
+        ul.append(i)
+    ladders = [(r, "A", "", 0) for r in refs]
+    ctx.set_ladders(ladders)
+    packed, woff, rlen = _lib.pack_reads(reads)
+    n = len(reads)
+    tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
+    dump = np.zeros((n, 1, 6), np.int16)
+    ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, np.asarray(uro, np.int32), np.asarray(ul, np.int32),
+                    len(ul), _lib.default_sw_params(), tag, h, sc, dump, 1)
+    pr = list(range(n))
+    pt = [u for u in range(len(refs)) for _ in range(5)]
+    want = po.sw_pairs(reads, refs, pr, pt)
+    assert np.array_equal(dump[:, 0, :5].astype(np.int32), want)

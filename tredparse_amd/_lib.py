@@ -1,0 +1,252 @@
+"""ctypes binding of libtredgpu.so (include/tredgpu.h).
+
+The library is the product path: there is no Python/CPU fallback.  Loading needs the in-tree
+``tredparse_amd/libtredgpu.so`` (built by ``__graft_entry__.build()`` / ``make -C tredparse_amd/csrc``);
+creating a context needs a HIP device and fails loudly otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtredgpu.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+TAG_NONE, TAG_FULL, TAG_PREF, TAG_POST, TAG_REPT, TAG_HANG, TAG_INVALID = 0, 1, 2, 3, 4, 5, 255
+TAG_NAMES = {TAG_FULL: "FULL", TAG_PREF: "PREF", TAG_POST: "POST", TAG_REPT: "REPT", TAG_HANG: "HANG"}
+SPAN = 1000
+
+
+class TredGpuError(RuntimeError):
+    pass
+
+
+class SwParams(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32),
+                ("gap_extend", C.c_int32), ("flank", C.c_int32), ("clip", C.c_int32),
+                ("max_read_len", C.c_int32), ("reserved", C.c_int32)]
+
+
+class UnitParams(C.Structure):
+    _fields_ = [("period", C.c_int32), ("readlen", C.c_int32), ("ploidy", C.c_int32),
+                ("maxinsert", C.c_int32), ("fullsearch", C.c_int32), ("ref_len", C.c_int32),
+                ("minpe", C.c_int32), ("cutoff_risk", C.c_int32), ("is_expansion", C.c_int32),
+                ("is_recessive", C.c_int32), ("pe_off", C.c_int32), ("n_global", C.c_int32),
+                ("tl_off", C.c_int32), ("n_target", C.c_int32), ("half_depth", C.c_double)]
+
+
+class Call(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_pairs", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32),
+                ("ci", C.c_int32 * 4), ("run_pe", C.c_int32), ("pad", C.c_int32),
+                ("lik", C.c_double), ("pp", C.c_double)]
+
+
+UNIT_DTYPE = np.dtype([("period", "<i4"), ("readlen", "<i4"), ("ploidy", "<i4"), ("maxinsert", "<i4"),
+                       ("fullsearch", "<i4"), ("ref_len", "<i4"), ("minpe", "<i4"), ("cutoff_risk", "<i4"),
+                       ("is_expansion", "<i4"), ("is_recessive", "<i4"), ("pe_off", "<i4"),
+                       ("n_global", "<i4"), ("tl_off", "<i4"), ("n_target", "<i4"), ("half_depth", "<f8")])
+CALL_DTYPE = np.dtype([("status", "<i4"), ("n_pairs", "<i4"), ("h1", "<i4"), ("h2", "<i4"),
+                       ("ci", "<i4", (4,)), ("run_pe", "<i4"), ("pad", "<i4"), ("lik", "<f8"), ("pp", "<f8")])
+assert UNIT_DTYPE.itemsize == C.sizeof(UnitParams) == 64
+assert CALL_DTYPE.itemsize == C.sizeof(Call) == 56
+
+# every symbol include/tredgpu.h declares (tests check the .so exports them all)
+EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_sync", "tredgpu_get_stream",
+           "tredgpu_version", "tredgpu_set_ladders", "tredgpu_set_model", "tredgpu_pack_reads",
+           "tredgpu_sw_classify", "tredgpu_tally", "tredgpu_likelihood_grid", "tredgpu_genotype_batch",
+           "tredgpu_pe_kde")
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TredGpuError("{} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)".format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.tredgpu_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.tredgpu_destroy.argtypes = [vp]
+    lib.tredgpu_destroy.restype = None
+    lib.tredgpu_last_error.argtypes = [vp]
+    lib.tredgpu_last_error.restype = C.c_char_p
+    lib.tredgpu_sync.argtypes = [vp]
+    lib.tredgpu_get_stream.argtypes = [vp]
+    lib.tredgpu_get_stream.restype = vp
+    lib.tredgpu_version.restype = C.c_char_p
+    lib.tredgpu_set_ladders.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                        C.POINTER(C.c_char_p), vp]
+    lib.tredgpu_set_model.argtypes = [vp, vp, vp, C.c_double, C.c_double]
+    lib.tredgpu_pack_reads.argtypes = [vp, vp, i64, vp, vp, vp]
+    lib.tredgpu_pack_reads.restype = i64
+    lib.tredgpu_sw_classify.argtypes = [vp, C.c_int, vp, vp, vp, i64, vp, vp, i32, C.POINTER(SwParams),
+                                        vp, vp, vp, vp, i32]
+    lib.tredgpu_tally.argtypes = [vp, C.c_int, vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]
+    lib.tredgpu_likelihood_grid.argtypes = [vp, C.c_int, vp, i32, i32, vp, vp, vp, vp, i64, vp, i64, vp,
+                                            vp, vp, vp, i32]
+    lib.tredgpu_genotype_batch.argtypes = [vp, C.c_int, vp, vp, vp, i64, vp, vp, vp, i32,
+                                           C.POINTER(SwParams), vp, vp, i64, vp, i64, vp, vp, vp, i32,
+                                           vp, vp, vp, vp]
+    lib.tredgpu_pe_kde.argtypes = [vp, C.c_int, vp, i32, vp, i64, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    """Raw pointer of a numpy array, a torch tensor, an int address or None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return a.data_ptr()
+    raise TypeError("unsupported buffer type {}".format(type(a)))
+
+
+def pack_reads(seqs):
+    """2-bit + N-mask packing (tredgpu_pack_reads).  seqs: list of str/bytes.
+    Returns (packed uint32[], word_off int64[n+1], read_len int32[n])."""
+    lib = load()
+    bs = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in seqs]
+    n = len(bs)
+    off = np.zeros(n + 1, np.int64)
+    if n:
+        off[1:] = np.cumsum([len(b) for b in bs])
+    blob = b"".join(bs)
+    buf = np.frombuffer(blob, np.uint8) if blob else np.zeros(1, np.uint8)
+    woff = np.zeros(n + 1, np.int64)
+    rlen = np.zeros(max(n, 1), np.int32)
+    total = lib.tredgpu_pack_reads(buf.ctypes.data, off.ctypes.data, n, None, woff.ctypes.data, rlen.ctypes.data)
+    if total < 0:
+        raise TredGpuError("tredgpu_pack_reads failed ({})".format(total))
+    packed = np.zeros(max(int(total), 1), np.uint32)
+    lib.tredgpu_pack_reads(buf.ctypes.data, off.ctypes.data, n, packed.ctypes.data, woff.ctypes.data, rlen.ctypes.data)
+    return packed, woff, rlen[:n]
+
+
+def pack_codes(codes, lengths=None):
+    """Vectorised packer for a 2-D uint8 array of base codes (0..3, 4 = N), all reads the same
+    length (rows) -- same record layout as tredgpu_pack_reads; used by the synthetic generator."""
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n, L = codes.shape
+    nb, nm = (L + 15) // 16, (L + 31) // 32
+    padb = np.zeros((n, nb * 16), np.uint32)
+    padb[:, :L] = np.where(codes < 4, codes, 0)
+    sh = (2 * (np.arange(nb * 16) % 16)).astype(np.uint32)
+    words = (padb << sh).reshape(n, nb, 16).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+    padm = np.zeros((n, nm * 32), np.uint32)
+    padm[:, :L] = codes >= 4
+    shm = (np.arange(nm * 32) % 32).astype(np.uint32)
+    masks = (padm << shm).reshape(n, nm, 32).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+    packed = np.ascontiguousarray(np.concatenate([words, masks], axis=1).reshape(-1))
+    woff = (np.arange(n + 1, dtype=np.int64) * (nb + nm))
+    rlen = np.full(n, L, np.int32)
+    return packed, woff, rlen
+
+
+class Context:
+    """One GPU + one HIP stream (tredgpu_ctx)."""
+
+    def __init__(self, device_id=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.tredgpu_create(device_id, C.byref(h))
+        if rc != 0:
+            raise TredGpuError("tredgpu_create({}) failed: {}".format(
+                device_id, self.lib.tredgpu_last_error(None).decode()))
+        self.h = h
+        self.n_ladders = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tredgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise TredGpuError("{} failed ({}): {}".format(what, rc, self.lib.tredgpu_last_error(self.h).decode()))
+
+    def sync(self):
+        self._chk(self.lib.tredgpu_sync(self.h), "tredgpu_sync")
+
+    @property
+    def stream(self):
+        return self.lib.tredgpu_get_stream(self.h)
+
+    def set_ladders(self, ladders):
+        """ladders: list of (prefix, repeat, suffix, max_units)."""
+        n = len(ladders)
+        arr = lambda k: (C.c_char_p * max(n, 1))(*[l[k].encode() for l in ladders])
+        mu = np.asarray([l[3] for l in ladders] or [0], np.int32)
+        self._chk(self.lib.tredgpu_set_ladders(self.h, n, arr(0), arr(1), arr(2), mu.ctypes.data),
+                  "tredgpu_set_ladders")
+        self.n_ladders = n
+        self.ladders = list(ladders)
+
+    def set_model(self, step_pdf, stutter_w, gc=.68, score=1.0):
+        step = np.ascontiguousarray(step_pdf, np.float64)
+        w = np.ascontiguousarray(stutter_w, np.float64)
+        assert step.shape == (6, 37) and w.shape == (5,)
+        self._chk(self.lib.tredgpu_set_model(self.h, step.ctypes.data, w.ctypes.data, gc, score),
+                  "tredgpu_set_model")
+
+    def sw_classify(self, mem, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, n_units,
+                    params, out_tag, out_h, out_score, out_dump=None, dump_templates=0):
+        self._chk(self.lib.tredgpu_sw_classify(self.h, mem, _ptr(packed), _ptr(read_off), _ptr(read_len),
+                                               n_reads, _ptr(unit_read_off), _ptr(unit_ladder), n_units,
+                                               C.byref(params), _ptr(out_tag), _ptr(out_h), _ptr(out_score),
+                                               _ptr(out_dump), dump_templates), "tredgpu_sw_classify")
+
+    def tally(self, mem, tag, h, n_reads, unit_read_off, n_units, read_pair_id, hist_stride, full_cnt,
+              pref_cnt, rept_cnt):
+        self._chk(self.lib.tredgpu_tally(self.h, mem, _ptr(tag), _ptr(h), n_reads, _ptr(unit_read_off),
+                                         n_units, _ptr(read_pair_id), hist_stride, _ptr(full_cnt),
+                                         _ptr(pref_cnt), _ptr(rept_cnt)), "tredgpu_tally")
+
+    def likelihood_grid(self, mem, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens,
+                        n_global_total, target_lens, n_target_total, calls, grid_off=None, grid_dump=None,
+                        marg=None, marg_stride=0):
+        self._chk(self.lib.tredgpu_likelihood_grid(self.h, mem, _ptr(units), n_units, hist_stride,
+                                                   _ptr(full_cnt), _ptr(pref_cnt), _ptr(rept_cnt),
+                                                   _ptr(global_lens), n_global_total, _ptr(target_lens),
+                                                   n_target_total, _ptr(calls), _ptr(grid_off),
+                                                   _ptr(grid_dump), _ptr(marg), marg_stride),
+                  "tredgpu_likelihood_grid")
+
+    def genotype_batch(self, mem, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, units,
+                       n_units, params, read_pair_id, global_lens, n_global_total, target_lens,
+                       n_target_total, out_tag, out_h, out_score, hist_stride, full_cnt, pref_cnt, rept_cnt,
+                       calls):
+        self._chk(self.lib.tredgpu_genotype_batch(self.h, mem, _ptr(packed), _ptr(read_off), _ptr(read_len),
+                                                  n_reads, _ptr(unit_read_off), _ptr(unit_ladder), _ptr(units),
+                                                  n_units, C.byref(params), _ptr(read_pair_id),
+                                                  _ptr(global_lens), n_global_total, _ptr(target_lens),
+                                                  n_target_total, _ptr(out_tag), _ptr(out_h), _ptr(out_score),
+                                                  hist_stride, _ptr(full_cnt), _ptr(pref_cnt), _ptr(rept_cnt),
+                                                  _ptr(calls)), "tredgpu_genotype_batch")
+
+    def pe_kde(self, mem, units, n_units, global_lens, n_global_total, pdf_out, status_out):
+        self._chk(self.lib.tredgpu_pe_kde(self.h, mem, _ptr(units), n_units, _ptr(global_lens),
+                                          n_global_total, _ptr(pdf_out), _ptr(status_out)), "tredgpu_pe_kde")
+
+
+def default_sw_params(clip=False, max_read_len=0):
+    """bam_parser.py:95-98 scoring (1/5/7/2), FLANKMATCH 9 (bam_parser.py:30)."""
+    return SwParams(1, 5, 7, 2, 9, int(bool(clip)), int(max_read_len), 0)

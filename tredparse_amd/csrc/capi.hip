@@ -1,0 +1,602 @@
+// capi.hip -- the extern "C" surface of libtredgpu.so (declared in include/tredgpu.h).
+// Host-side glue only: argument checks, ladder tables, staging of host buffers, kernel launches.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tredgpu_internal.h"
+
+using namespace tredgpu;
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+std::string g_create_error;
+
+}  // namespace
+
+struct tredgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // ladders
+    std::vector<LadderDesc> h_ladders;
+    Buf d_ladders, d_seq;
+    int max_templates = 0;  // max over ladders of 2*max_units (or 1)
+    int max_ladder_units = 0;
+    // model
+    Buf d_model;
+    bool have_model = false;
+    // workspaces (grow-only, reused across calls)
+    Buf ws_quads, ws_counter, ws_drop, ws_grid;
+    Buf st[24];  // staging for HOST-memory calls
+    // intermediates of the fused path
+    Buf ws_tag, ws_h, ws_score;
+};
+
+namespace {
+
+int fail(tredgpu_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                    \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail((c), -10, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(tredgpu_ctx* c, Buf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return 0;
+    if (b.p) {
+        // the buffer may still be in use by enqueued work
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+void release(Buf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int base_code(char ch) {
+    switch (ch) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+
+void encode(const char* s, std::vector<int8_t>& out) {
+    for (; *s; ++s) out.push_back((int8_t)base_code(*s));
+}
+
+// reverse complement on codes (N stays N): bam_parser.py:448-450
+std::vector<int8_t> revcomp(const std::vector<int8_t>& v) {
+    std::vector<int8_t> o(v.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+        int c = v[v.size() - 1 - i];
+        o[i] = (int8_t)(c == 4 ? 4 : 3 - c);
+    }
+    return o;
+}
+
+int check_sw_params(tredgpu_ctx* c, const tredgpu_sw_params* p) {
+    if (!p) return fail(c, -2, "params is NULL");
+    if (p->match < 1 || p->match > 8 || p->mismatch < 0 || p->mismatch > 16 || p->gap_open < 1 ||
+        p->gap_open > 16 || p->gap_extend < 1 || p->gap_extend > 16 || p->gap_extend > p->gap_open)
+        return fail(c, -2, "scoring out of the supported range (match 1..8, mismatch 0..16, "
+                           "1 <= gap_extend <= gap_open <= 16)");
+    if (p->flank < 0 || p->flank > 255) return fail(c, -2, "flank out of range");
+    return 0;
+}
+
+int rows_for(int max_len) {
+    if (max_len <= 64) return 4;
+    if (max_len <= 112) return 7;
+    if (max_len <= 160) return 10;
+    return 16;
+}
+
+// copy a host array to a staging buffer; returns device pointer through out
+template <typename T>
+int stage_in(tredgpu_ctx* c, Buf& b, const T* host, size_t n, const T** out) {
+    int rc = ensure(c, b, n * sizeof(T));
+    if (rc) return rc;
+    if (n) HIPCHK(c, hipMemcpyAsync(b.p, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *out = (const T*)b.p;
+    return 0;
+}
+
+template <typename T>
+int stage_out(tredgpu_ctx* c, Buf& b, size_t n, T** out) {
+    int rc = ensure(c, b, n * sizeof(T));
+    if (rc) return rc;
+    *out = (T*)b.p;
+    return 0;
+}
+
+template <typename T>
+int copy_back(tredgpu_ctx* c, T* host, const T* dev, size_t n) {
+    if (n && host) HIPCHK(c, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tredgpu_version(void) { return "tredgpu 0.1 (gfx950)"; }
+
+int tredgpu_create(int device_id, tredgpu_ctx** out) {
+    if (!out) return fail(nullptr, -2, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, -3, "no HIP device available (%s); libtredgpu has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, -2, "device %d out of range [0,%d)", device_id, n);
+    tredgpu_ctx* c = new tredgpu_ctx();
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, -10, "cannot initialise device %d: %s", device_id, hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+void tredgpu_destroy(tredgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (Buf* b : {&c->d_ladders, &c->d_seq, &c->d_model, &c->ws_quads, &c->ws_counter, &c->ws_drop,
+                   &c->ws_grid, &c->ws_tag, &c->ws_h, &c->ws_score})
+        release(*b);
+    for (Buf& b : c->st) release(b);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* tredgpu_last_error(const tredgpu_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int tredgpu_sync(tredgpu_ctx* c) {
+    if (!c) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void* tredgpu_get_stream(tredgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, const char* const* repeat,
+                        const char* const* suffix, const int32_t* max_units) {
+    if (!c) return -2;
+    if (n < 0 || (n > 0 && (!prefix || !repeat || !suffix || !max_units))) return fail(c, -2, "bad ladder arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int8_t> seq;
+    std::vector<LadderDesc> lad((size_t)n);
+    int max_t = 1, max_u = 0;
+    for (int i = 0; i < n; ++i) {
+        std::vector<int8_t> P, Rp, S;
+        encode(prefix[i], P);
+        encode(repeat[i], Rp);
+        encode(suffix[i], S);
+        const int mu = max_units[i];
+        LadderDesc& d = lad[i];
+        memset(&d, 0, sizeof d);
+        if (mu < 0) return fail(c, -2, "ladder %d: negative max_units", i);
+        if (mu == 0) {
+            if (P.empty() || P.size() > TREDGPU_MAX_TEMPLATE_LEN)
+                return fail(c, -2, "ladder %d: reference length %zu not in [1,%d]", i, P.size(), TREDGPU_MAX_TEMPLATE_LEN);
+            d.alen[0] = (int)P.size();
+            d.trunk_off[0] = (int)seq.size();
+            seq.insert(seq.end(), P.begin(), P.end());
+            d.branch_off[0] = (int)seq.size();
+            d.period = 1;
+            d.max_units = 0;
+            d.n_strands = 1;
+            continue;
+        }
+        if (Rp.empty()) return fail(c, -2, "ladder %d: empty repeat", i);
+        const size_t T = P.size() + S.size() + Rp.size() * (size_t)mu;
+        if (T > TREDGPU_MAX_TEMPLATE_LEN)
+            return fail(c, -2, "ladder %d: longest template %zu exceeds %d", i, T, TREDGPU_MAX_TEMPLATE_LEN);
+        const std::vector<int8_t> Pr = revcomp(P), Rr = revcomp(Rp), Sr = revcomp(S);
+        const std::vector<int8_t>* A[2] = {&P, &Sr};
+        const std::vector<int8_t>* Rep[2] = {&Rp, &Rr};
+        const std::vector<int8_t>* B[2] = {&S, &Pr};
+        for (int s = 0; s < 2; ++s) {
+            d.alen[s] = (int)A[s]->size();
+            d.blen[s] = (int)B[s]->size();
+            d.trunk_off[s] = (int)seq.size();
+            seq.insert(seq.end(), A[s]->begin(), A[s]->end());
+            for (int k = 0; k < mu; ++k) seq.insert(seq.end(), Rep[s]->begin(), Rep[s]->end());
+            d.branch_off[s] = (int)seq.size();
+            seq.insert(seq.end(), B[s]->begin(), B[s]->end());
+        }
+        d.period = (int)Rp.size();
+        d.max_units = mu;
+        d.n_strands = 2;
+        max_t = std::max(max_t, 2 * mu);
+        max_u = std::max(max_u, mu);
+    }
+    seq.resize(seq.size() + 16, 4);
+    int rc;
+    if ((rc = ensure(c, c->d_ladders, lad.size() * sizeof(LadderDesc)))) return rc;
+    if ((rc = ensure(c, c->d_seq, seq.size()))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCHK(c, hipMemcpy(c->d_ladders.p, lad.data(), lad.size() * sizeof(LadderDesc), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_seq.p, seq.data(), seq.size(), hipMemcpyHostToDevice));
+    c->h_ladders.swap(lad);
+    c->max_templates = max_t;
+    c->max_ladder_units = max_u;
+    return 0;
+}
+
+int tredgpu_set_model(tredgpu_ctx* c, const double* step_pdf, const double* stutter_w, double gc, double score) {
+    if (!c) return -2;
+    if (!step_pdf || !stutter_w) return fail(c, -2, "model arrays are NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    ModelConst m;
+    memcpy(m.step, step_pdf, sizeof m.step);
+    memcpy(m.w, stutter_w, sizeof m.w);
+    m.gc = gc;
+    m.score = score;
+    m.small = std::exp(-10.0);
+    m.really_small = std::exp(-100.0);
+    int rc;
+    if ((rc = ensure(c, c->d_model, sizeof m))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->d_model.p, &m, sizeof m, hipMemcpyHostToDevice));
+    c->have_model = true;
+    return 0;
+}
+
+int64_t tredgpu_pack_reads(const char* seqs, const int64_t* seq_off, int64_t n_reads, uint32_t* packed_out,
+                           int64_t* word_off_out, int32_t* len_out) {
+    if (n_reads < 0 || (n_reads > 0 && (!seqs || !seq_off))) return -2;
+    int64_t w = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const int64_t L = seq_off[r + 1] - seq_off[r];
+        if (L < 0 || L > 0x7fffffff) return -2;
+        const int64_t nb = (L + 15) >> 4, nm = (L + 31) >> 5;
+        if (word_off_out) word_off_out[r] = w;
+        if (len_out) len_out[r] = (int32_t)L;
+        if (packed_out) {
+            uint32_t* rec = packed_out + w;
+            for (int64_t k = 0; k < nb + nm; ++k) rec[k] = 0;
+            const char* s = seqs + seq_off[r];
+            for (int64_t i = 0; i < L; ++i) {
+                const int code = base_code(s[i]);
+                if (code == 4) rec[nb + (i >> 5)] |= 1u << (i & 31);
+                else rec[i >> 4] |= (uint32_t)code << ((i & 15) * 2);
+            }
+        }
+        w += nb + nm;
+    }
+    if (word_off_out) word_off_out[n_reads] = w;
+    return w;
+}
+
+// ---- SW ------------------------------------------------------------------------------------------
+
+static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* read_off, const int32_t* read_len,
+                         int64_t n_reads, const int32_t* unit_read_off, const int32_t* unit_ladder,
+                         int32_t n_units, const tredgpu_sw_params* p, int max_len, uint8_t* out_tag,
+                         int16_t* out_h, int16_t* out_score, int16_t* out_dump, int32_t dump_templates) {
+    if (n_reads == 0 || n_units == 0) return 0;
+    const int64_t max_quads = n_reads / 4 + n_units + 1;
+    int rc;
+    if ((rc = ensure(c, c->ws_quads, (size_t)max_quads * sizeof(Quad)))) return rc;
+    if ((rc = ensure(c, c->ws_counter, 64))) return rc;
+    HIPCHK(c, launch_build_quads(unit_read_off, n_units, (Quad*)c->ws_quads.p, (int32_t*)c->ws_counter.p, c->stream));
+    SwArgs a;
+    a.packed = packed;
+    a.read_off = read_off;
+    a.read_len = read_len;
+    a.unit_read_off = unit_read_off;
+    a.unit_ladder = unit_ladder;
+    a.ladders = (const LadderDesc*)c->d_ladders.p;
+    a.seq = (const int8_t*)c->d_seq.p;
+    a.quads = (const Quad*)c->ws_quads.p;
+    a.n_quads = (const int32_t*)c->ws_counter.p;
+    a.out_tag = out_tag;
+    a.out_h = out_h;
+    a.out_score = out_score;
+    a.out_dump = out_dump;
+    a.dump_templates = dump_templates;
+    a.n_units = n_units;
+    a.p = *p;
+    HIPCHK(c, launch_sw_ladder(a, rows_for(max_len), max_quads, c->stream));
+    return 0;
+}
+
+int tredgpu_sw_classify(tredgpu_ctx* c, int mem, const uint32_t* packed, const int64_t* read_off,
+                        const int32_t* read_len, int64_t n_reads, const int32_t* unit_read_off,
+                        const int32_t* unit_ladder, int32_t n_units, const tredgpu_sw_params* params,
+                        uint8_t* out_tag, int16_t* out_h, int16_t* out_score, int16_t* out_dump,
+                        int32_t dump_templates) {
+    if (!c) return -2;
+    int rc;
+    if ((rc = check_sw_params(c, params))) return rc;
+    if (n_reads < 0 || n_units < 0) return fail(c, -2, "negative sizes");
+    if (n_reads > 0 && (!packed || !read_off || !read_len || !unit_read_off || !unit_ladder || !out_tag || !out_h || !out_score))
+        return fail(c, -2, "NULL array argument");
+    if (c->h_ladders.empty()) return fail(c, -4, "no ladders registered (tredgpu_set_ladders)");
+    if (out_dump && dump_templates <= 0) return fail(c, -2, "dump_templates must be > 0 with out_dump");
+    HIPCHK(c, hipSetDevice(c->device));
+    int max_len = params->max_read_len;
+    if (mem == TREDGPU_MEM_DEVICE) {
+        if (max_len <= 0) max_len = TREDGPU_MAX_READ_LEN;
+        if (out_dump) HIPCHK(c, hipMemsetAsync(out_dump, 0xFF, (size_t)n_reads * dump_templates * 6 * sizeof(int16_t), c->stream));
+        return run_sw_device(c, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, n_units, params,
+                             max_len, out_tag, out_h, out_score, out_dump, dump_templates);
+    }
+    if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "mem must be TREDGPU_MEM_HOST or TREDGPU_MEM_DEVICE");
+    if (n_reads == 0) return 0;
+    // validate the host metadata (the device path trusts its caller)
+    if (unit_read_off[0] != 0 || unit_read_off[n_units] != n_reads) return fail(c, -2, "unit_read_off must span [0,n_reads]");
+    for (int g = 0; g < n_units; ++g) {
+        if (unit_read_off[g + 1] < unit_read_off[g]) return fail(c, -2, "unit_read_off not monotone at %d", g);
+        if (unit_ladder[g] < 0 || unit_ladder[g] >= (int)c->h_ladders.size()) return fail(c, -2, "unit %d: ladder %d not registered", g, unit_ladder[g]);
+    }
+    int seen = 0;
+    for (int64_t r = 0; r < n_reads; ++r) seen = std::max(seen, read_len[r]);
+    if (max_len <= 0) max_len = seen;
+    if (seen > TREDGPU_MAX_READ_LEN) return fail(c, -5, "read of %d bp exceeds TREDGPU_MAX_READ_LEN=%d", seen, TREDGPU_MAX_READ_LEN);
+    const uint32_t* d_packed; const int64_t* d_off; const int32_t* d_len; const int32_t* d_uoff; const int32_t* d_ulad;
+    uint8_t* d_tag; int16_t* d_h; int16_t* d_score; int16_t* d_dump = nullptr;
+    const size_t words = (size_t)read_off[n_reads];
+    if ((rc = stage_in(c, c->st[0], packed, words, &d_packed))) return rc;
+    if ((rc = stage_in(c, c->st[1], read_off, (size_t)n_reads + 1, &d_off))) return rc;
+    if ((rc = stage_in(c, c->st[2], read_len, (size_t)n_reads, &d_len))) return rc;
+    if ((rc = stage_in(c, c->st[3], unit_read_off, (size_t)n_units + 1, &d_uoff))) return rc;
+    if ((rc = stage_in(c, c->st[4], unit_ladder, (size_t)n_units, &d_ulad))) return rc;
+    if ((rc = stage_out(c, c->st[5], (size_t)n_reads, &d_tag))) return rc;
+    if ((rc = stage_out(c, c->st[6], (size_t)n_reads, &d_h))) return rc;
+    if ((rc = stage_out(c, c->st[7], (size_t)n_reads, &d_score))) return rc;
+    const size_t dump_n = out_dump ? (size_t)n_reads * dump_templates * 6 : 0;
+    if (out_dump) {
+        if ((rc = stage_out(c, c->st[8], dump_n, &d_dump))) return rc;
+        HIPCHK(c, hipMemsetAsync(d_dump, 0xFF, dump_n * sizeof(int16_t), c->stream));
+    }
+    if ((rc = run_sw_device(c, d_packed, d_off, d_len, n_reads, d_uoff, d_ulad, n_units, params, max_len, d_tag,
+                            d_h, d_score, d_dump, dump_templates)))
+        return rc;
+    if ((rc = copy_back(c, out_tag, (const uint8_t*)d_tag, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, out_h, (const int16_t*)d_h, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, out_score, (const int16_t*)d_score, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, out_dump, (const int16_t*)d_dump, dump_n))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tredgpu_tally(tredgpu_ctx* c, int mem, const uint8_t* tag, const int16_t* h, int64_t n_reads,
+                  const int32_t* unit_read_off, int32_t n_units, const int32_t* read_pair_id, int32_t hist_stride,
+                  int32_t* full_cnt, int32_t* pref_cnt, int32_t* rept_cnt) {
+    if (!c) return -2;
+    if (n_reads < 0 || n_units < 0 || hist_stride <= 0) return fail(c, -2, "bad sizes");
+    if (n_units > 0 && (!unit_read_off || !full_cnt || !pref_cnt || !rept_cnt)) return fail(c, -2, "NULL array argument");
+    if (n_reads > 0 && (!tag || !h)) return fail(c, -2, "NULL array argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if (read_pair_id && (rc = ensure(c, c->ws_drop, (size_t)n_reads))) return rc;
+    if (mem == TREDGPU_MEM_DEVICE) {
+        HIPCHK(c, launch_tally(tag, h, n_reads, unit_read_off, n_units, read_pair_id, hist_stride, full_cnt, pref_cnt,
+                               rept_cnt, (uint8_t*)c->ws_drop.p, c->stream));
+        return 0;
+    }
+    if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
+    const uint8_t* d_tag; const int16_t* d_h; const int32_t* d_uoff; const int32_t* d_pid = nullptr;
+    int32_t *d_f, *d_p, *d_r;
+    const size_t hn = (size_t)n_units * hist_stride;
+    if ((rc = stage_in(c, c->st[0], tag, (size_t)n_reads, &d_tag))) return rc;
+    if ((rc = stage_in(c, c->st[1], h, (size_t)n_reads, &d_h))) return rc;
+    if ((rc = stage_in(c, c->st[2], unit_read_off, (size_t)n_units + 1, &d_uoff))) return rc;
+    if (read_pair_id && (rc = stage_in(c, c->st[3], read_pair_id, (size_t)n_reads, &d_pid))) return rc;
+    if ((rc = stage_out(c, c->st[4], hn, &d_f))) return rc;
+    if ((rc = stage_out(c, c->st[5], hn, &d_p))) return rc;
+    if ((rc = stage_out(c, c->st[6], hn, &d_r))) return rc;
+    HIPCHK(c, launch_tally(d_tag, d_h, n_reads, d_uoff, n_units, d_pid, hist_stride, d_f, d_p, d_r,
+                           (uint8_t*)c->ws_drop.p, c->stream));
+    if ((rc = copy_back(c, full_cnt, (const int32_t*)d_f, hn))) return rc;
+    if ((rc = copy_back(c, pref_cnt, (const int32_t*)d_p, hn))) return rc;
+    if ((rc = copy_back(c, rept_cnt, (const int32_t*)d_r, hn))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- likelihood grid -------------------------------------------------------------------------------
+
+static int check_grid_common(tredgpu_ctx* c, const tredgpu_unit_params* units, int32_t n_units) {
+    if (!c->have_model) return fail(c, -4, "model constants not set (tredgpu_set_model)");
+    if (n_units < 0) return fail(c, -2, "negative n_units");
+    if (n_units > 0 && !units) return fail(c, -2, "units is NULL");
+    return 0;
+}
+
+static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int32_t n_units, int32_t hist_stride,
+                           const int32_t* full_cnt, const int32_t* pref_cnt, const int32_t* rept_cnt,
+                           const int32_t* global_lens, const int32_t* target_lens, tredgpu_call* calls,
+                           const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride) {
+    if (n_units == 0) return 0;
+    int rc;
+    if ((rc = ensure(c, c->ws_grid, grid_scratch_bytes(n_units)))) return rc;
+    GridArgs a;
+    a.units = units;
+    a.n_units = n_units;
+    a.hist_stride = hist_stride;
+    a.full_cnt = full_cnt;
+    a.pref_cnt = pref_cnt;
+    a.rept_cnt = rept_cnt;
+    a.global_lens = global_lens;
+    a.target_lens = target_lens;
+    a.calls = calls;
+    a.grid_off = grid_off;
+    a.grid_dump = grid_dump;
+    a.marg = marg;
+    a.marg_stride = marg_stride;
+    a.model = (const ModelConst*)c->d_model.p;
+    a.kde_pdf = nullptr;
+    a.kde_status = nullptr;
+    HIPCHK(c, launch_grid(a, (double*)c->ws_grid.p, c->stream));
+    return 0;
+}
+
+int tredgpu_likelihood_grid(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, int32_t n_units,
+                            int32_t hist_stride, const int32_t* full_cnt, const int32_t* pref_cnt,
+                            const int32_t* rept_cnt, const int32_t* global_lens, int64_t n_global_total,
+                            const int32_t* target_lens, int64_t n_target_total, tredgpu_call* calls,
+                            const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride) {
+    if (!c) return -2;
+    int rc;
+    if ((rc = check_grid_common(c, units, n_units))) return rc;
+    if (hist_stride <= 0) return fail(c, -2, "hist_stride must be > 0");
+    if (n_units > 0 && (!full_cnt || !pref_cnt || !rept_cnt || !calls)) return fail(c, -2, "NULL array argument");
+    if ((grid_off == nullptr) != (grid_dump == nullptr)) return fail(c, -2, "grid_off and grid_dump go together");
+    if (marg && marg_stride <= 0) return fail(c, -2, "marg_stride must be > 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (mem == TREDGPU_MEM_DEVICE)
+        return run_grid_device(c, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens, target_lens,
+                               calls, grid_off, grid_dump, marg, marg_stride);
+    if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
+    if (n_units == 0) return 0;
+    for (int g = 0; g < n_units; ++g) {
+        const tredgpu_unit_params& u = units[g];
+        if (u.n_global < 0 || u.n_target < 0 || u.pe_off < 0 || u.tl_off < 0 || (int64_t)u.pe_off + u.n_global > n_global_total ||
+            (int64_t)u.tl_off + u.n_target > n_target_total)
+            return fail(c, -2, "unit %d: paired-end slices out of range", g);
+        if (marg && marg_stride <= std::max(u.maxinsert, hist_stride)) return fail(c, -2, "marg_stride must exceed max(maxinsert, hist_stride)");
+    }
+    const tredgpu_unit_params* d_units; const int32_t *d_f, *d_p, *d_r, *d_gl = nullptr, *d_tl = nullptr;
+    const int64_t* d_goff = nullptr; tredgpu_call* d_calls; double* d_dump = nullptr; double* d_marg = nullptr;
+    const size_t hn = (size_t)n_units * hist_stride;
+    if ((rc = stage_in(c, c->st[0], units, (size_t)n_units, &d_units))) return rc;
+    if ((rc = stage_in(c, c->st[1], full_cnt, hn, &d_f))) return rc;
+    if ((rc = stage_in(c, c->st[2], pref_cnt, hn, &d_p))) return rc;
+    if ((rc = stage_in(c, c->st[3], rept_cnt, hn, &d_r))) return rc;
+    if ((rc = stage_in(c, c->st[4], global_lens, (size_t)n_global_total, &d_gl))) return rc;
+    if ((rc = stage_in(c, c->st[5], target_lens, (size_t)n_target_total, &d_tl))) return rc;
+    if ((rc = stage_out(c, c->st[6], (size_t)n_units, &d_calls))) return rc;
+    size_t dump_n = 0;
+    if (grid_off) {
+        dump_n = (size_t)grid_off[n_units] * 6;
+        if ((rc = stage_in(c, c->st[7], grid_off, (size_t)n_units + 1, &d_goff))) return rc;
+        if ((rc = stage_out(c, c->st[8], dump_n, &d_dump))) return rc;
+    }
+    const size_t marg_n = marg ? (size_t)n_units * 2 * marg_stride : 0;
+    if (marg && (rc = stage_out(c, c->st[9], marg_n, &d_marg))) return rc;
+    if ((rc = run_grid_device(c, d_units, n_units, hist_stride, d_f, d_p, d_r, d_gl, d_tl, d_calls, d_goff, d_dump,
+                              d_marg, marg_stride)))
+        return rc;
+    if ((rc = copy_back(c, calls, (const tredgpu_call*)d_calls, (size_t)n_units))) return rc;
+    if ((rc = copy_back(c, grid_dump, (const double*)d_dump, dump_n))) return rc;
+    if ((rc = copy_back(c, marg, (const double*)d_marg, marg_n))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tredgpu_pe_kde(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, int32_t n_units,
+                   const int32_t* global_lens, int64_t n_global_total, double* pdf_out, int32_t* status_out) {
+    if (!c) return -2;
+    if (n_units < 0 || (n_units > 0 && (!units || !pdf_out || !status_out))) return fail(c, -2, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n_units == 0) return 0;
+    GridArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_units = n_units;
+    int rc;
+    if (mem == TREDGPU_MEM_DEVICE) {
+        a.units = units;
+        a.global_lens = global_lens;
+        a.kde_pdf = pdf_out;
+        a.kde_status = status_out;
+        HIPCHK(c, launch_pe_kde(a, c->stream));
+        return 0;
+    }
+    if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
+    const tredgpu_unit_params* d_units; const int32_t* d_gl; double* d_pdf; int32_t* d_st;
+    if ((rc = stage_in(c, c->st[0], units, (size_t)n_units, &d_units))) return rc;
+    if ((rc = stage_in(c, c->st[1], global_lens, (size_t)n_global_total, &d_gl))) return rc;
+    if ((rc = stage_out(c, c->st[2], (size_t)n_units * TREDGPU_SPAN, &d_pdf))) return rc;
+    if ((rc = stage_out(c, c->st[3], (size_t)n_units, &d_st))) return rc;
+    a.units = d_units;
+    a.global_lens = d_gl;
+    a.kde_pdf = d_pdf;
+    a.kde_status = d_st;
+    HIPCHK(c, launch_pe_kde(a, c->stream));
+    if ((rc = copy_back(c, pdf_out, (const double*)d_pdf, (size_t)n_units * TREDGPU_SPAN))) return rc;
+    if ((rc = copy_back(c, status_out, (const int32_t*)d_st, (size_t)n_units))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tredgpu_genotype_batch(tredgpu_ctx* c, int mem, const uint32_t* packed, const int64_t* read_off,
+                           const int32_t* read_len, int64_t n_reads, const int32_t* unit_read_off,
+                           const int32_t* unit_ladder, const tredgpu_unit_params* units, int32_t n_units,
+                           const tredgpu_sw_params* params, const int32_t* read_pair_id,
+                           const int32_t* global_lens, int64_t n_global_total, const int32_t* target_lens,
+                           int64_t n_target_total, uint8_t* out_tag, int16_t* out_h, int16_t* out_score,
+                           int32_t hist_stride, int32_t* full_cnt, int32_t* pref_cnt, int32_t* rept_cnt,
+                           tredgpu_call* calls) {
+    if (!c) return -2;
+    int rc;
+    if ((rc = check_sw_params(c, params))) return rc;
+    if ((rc = check_grid_common(c, units, n_units))) return rc;
+    if (c->h_ladders.empty()) return fail(c, -4, "no ladders registered (tredgpu_set_ladders)");
+    if (hist_stride <= c->max_ladder_units) return fail(c, -2, "hist_stride %d must exceed the largest max_units %d", hist_stride, c->max_ladder_units);
+    if (n_reads < 0) return fail(c, -2, "negative n_reads");
+    if (n_units > 0 && (!unit_read_off || !unit_ladder || !full_cnt || !pref_cnt || !rept_cnt || !calls)) return fail(c, -2, "NULL array argument");
+    if (n_reads > 0 && (!packed || !read_off || !read_len || !out_tag || !out_h || !out_score)) return fail(c, -2, "NULL array argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (mem == TREDGPU_MEM_DEVICE) {
+        int max_len = params->max_read_len > 0 ? params->max_read_len : TREDGPU_MAX_READ_LEN;
+        if (read_pair_id && (rc = ensure(c, c->ws_drop, (size_t)n_reads))) return rc;
+        if ((rc = run_sw_device(c, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, n_units, params,
+                                max_len, out_tag, out_h, out_score, nullptr, 0)))
+            return rc;
+        HIPCHK(c, launch_tally(out_tag, out_h, n_reads, unit_read_off, n_units, read_pair_id, hist_stride, full_cnt,
+                               pref_cnt, rept_cnt, (uint8_t*)c->ws_drop.p, c->stream));
+        return run_grid_device(c, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens, target_lens,
+                               calls, nullptr, nullptr, nullptr, 0);
+    }
+    if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
+    // HOST memory: compose the three host-memory calls (each validates and stages its own arguments)
+    if ((rc = tredgpu_sw_classify(c, mem, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, n_units,
+                                  params, out_tag, out_h, out_score, nullptr, 0)))
+        return rc;
+    if ((rc = tredgpu_tally(c, mem, out_tag, out_h, n_reads, unit_read_off, n_units, read_pair_id, hist_stride,
+                            full_cnt, pref_cnt, rept_cnt)))
+        return rc;
+    return tredgpu_likelihood_grid(c, mem, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens,
+                                   n_global_total, target_lens, n_target_total, calls, nullptr, nullptr, nullptr, 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Internal declarations shared by the HIP translation units of libtredgpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tredgpu.h"
+
+namespace tredgpu {
+
+// One template ladder on the device.  Sequences are base codes 0..4 (N = 4) in `seq`:
+//   strand 0: trunk = prefix + repeat*max_units, branch = suffix              (bam_parser.py:92)
+//   strand 1: trunk = rc(suffix) + rc(repeat)*max_units, branch = rc(prefix)  (bam_parser.py:93)
+// max_units == 0: a plain reference (trunk = the sequence, no branch, strand 0 only).
+struct LadderDesc {
+    int32_t alen[2];       // trunk head length per strand (|prefix| / |suffix|)
+    int32_t blen[2];       // branch length per strand     (|suffix| / |prefix|)
+    int32_t trunk_off[2];  // offsets into the sequence pool
+    int32_t branch_off[2];
+    int32_t period;
+    int32_t max_units;
+    int32_t n_strands;
+    int32_t pad;
+};
+
+// A quad = up to four reads of one unit that share a wavefront (16 lanes each).
+struct Quad {
+    int32_t unit;
+    int32_t read0;
+    int32_t count;
+    int32_t pad;
+};
+
+struct SwArgs {
+    const uint32_t* packed;
+    const int64_t* read_off;
+    const int32_t* read_len;
+    const int32_t* unit_read_off;
+    const int32_t* unit_ladder;
+    const LadderDesc* ladders;
+    const int8_t* seq;
+    const Quad* quads;
+    const int32_t* n_quads;  // device counter written by build_quads
+    uint8_t* out_tag;
+    int16_t* out_h;
+    int16_t* out_score;
+    int16_t* out_dump;
+    int32_t dump_templates;
+    int32_t n_units;
+    tredgpu_sw_params p;
+};
+
+// sw_ladder.hip
+hipError_t launch_build_quads(const int32_t* unit_read_off, int32_t n_units, Quad* quads,
+                              int32_t* n_quads, hipStream_t s);
+hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s);
+hipError_t launch_tally(const uint8_t* tag, const int16_t* h, int64_t n_reads,
+                        const int32_t* unit_read_off, int32_t n_units, const int32_t* read_pair_id,
+                        int32_t hist_stride, int32_t* full_cnt, int32_t* pref_cnt,
+                        int32_t* rept_cnt, uint8_t* scratch_drop, hipStream_t s);
+
+// grid.hip
+struct ModelConst {
+    double step[6][37];
+    double w[5];
+    double gc, score;
+    double small;         // SMALL_VALUE = exp(-10), models.py:34 (host libm value)
+    double really_small;  // REALLY_SMALL_VALUE = exp(-100), models.py:35
+};
+
+struct GridArgs {
+    const tredgpu_unit_params* units;
+    int32_t n_units;
+    int32_t hist_stride;
+    const int32_t* full_cnt;
+    const int32_t* pref_cnt;
+    const int32_t* rept_cnt;
+    const int32_t* global_lens;
+    const int32_t* target_lens;
+    tredgpu_call* calls;
+    const int64_t* grid_off;
+    double* grid_dump;
+    double* marg;
+    int32_t marg_stride;
+    const ModelConst* model;
+    double* kde_pdf;      // tredgpu_pe_kde only: [n_units][1000] output
+    int32_t* kde_status;  // tredgpu_pe_kde only: [n_units]
+};
+constexpr int GRID_MAX_ROWS = 512;   // |h1range| a workgroup can hold
+constexpr int GRID_MAX_COLS = 1024;  // |h2range|
+constexpr int GRID_MAX_BLOCKS = 512;
+inline size_t grid_scratch_bytes(int n_units) {
+    const size_t blocks = n_units < GRID_MAX_BLOCKS ? n_units : GRID_MAX_BLOCKS;
+    return blocks * (size_t)GRID_MAX_ROWS * GRID_MAX_COLS * sizeof(double);
+}
+hipError_t launch_pe_kde(const GridArgs& a, hipStream_t s);
+hipError_t launch_grid(const GridArgs& a, double* scratch, hipStream_t s);
+
+}  // namespace tredgpu
