@@ -1,0 +1,153 @@
+"""GPU parity: HIP likelihood grid / KDE / fused genotyping path vs the reference goldens and the
+CPU oracle.  Tolerances: per-term log-likelihoods 1e-6 absolute (BASELINE.json north_star; observed
+~1e-12), (h1,h2) calls, CI and grid enumeration bit-identical."""
+import numpy as np
+import pytest
+
+from oracle import lik_oracle as lo
+from oracle import pyoracle as po
+from tests.gridcases import load_cases, oracle_caller
+from tredparse_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+CASES = load_cases()
+ML_TOL = 1e-6
+
+
+def _set_model(ctx):
+    step, w = lo.load_model()
+    ctx.set_model(np.array([step[p] for p in range(1, 7)]), np.array(w))
+
+
+def _case_inputs(cases, hist_stride):
+    n = len(cases)
+    units = np.zeros(n, _lib.UNIT_DTYPE)
+    full = np.zeros((n, hist_stride), np.int32)
+    pref = np.zeros((n, hist_stride), np.int32)
+    rept = np.zeros((n, hist_stride), np.int32)
+    gl, tl = [], []
+    for i, c in enumerate(cases):
+        u = synth.unit_params_for(c["locus_rec"], c["readlen"], c["depth"], len(c["global_lens"]),
+                                  len(c["target_lens"]), len(gl), len(tl), ploidy=c["ploidy"],
+                                  maxinsert=c["maxinsert"], fullsearch=c["fullsearch"])
+        u["ref_len"], u["minpe"] = c["ref_len"], c["minpe"]
+        units[i] = u
+        for k, v in c["full"].items():
+            full[i, int(k)] = v
+        for k, v in c["partial"].items():
+            pref[i, int(k)] = v
+        rept[i, 0] = c["rept"]
+        gl += c["global_lens"]
+        tl += c["target_lens"]
+    return units, full, pref, rept, np.asarray(gl, np.int32), np.asarray(tl, np.int32)
+
+
+def test_grid_matches_reference_goldens(ctx):
+    _set_model(ctx)
+    hs = 128
+    units, full, pref, rept, gl, tl = _case_inputs(CASES, hs)
+    n = len(CASES)
+    cap = np.array([max(c["expected"].get("n_pairs", 0), 1) for c in CASES], np.int64)
+    goff = np.zeros(n + 1, np.int64)
+    goff[1:] = np.cumsum(cap)
+    dump = np.zeros((int(goff[-1]), 6), np.float64)
+    ms = 512
+    marg = np.zeros((n, 2, ms), np.float64)
+    calls = np.zeros(n, _lib.CALL_DTYPE)
+    ctx.likelihood_grid(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls, goff, dump,
+                        marg, ms)
+    for i, c in enumerate(CASES):
+        exp, call = c["expected"], calls[i]
+        period = len(c["locus_rec"]["repeat"])
+        if exp["raised"]:
+            assert call["status"] == -2, c["name"]           # singular KDE -> LinAlgError in the reference
+            continue
+        if exp["alleles"] == [-1, -1]:
+            assert call["status"] == 1, c["name"]
+            continue
+        assert call["status"] == 0, (c["name"], call)
+        assert call["n_pairs"] == exp["n_pairs"], c["name"]
+        got = dump[goff[i]:goff[i] + call["n_pairs"]]
+        want = c["mls"]
+        assert np.array_equal(got[:, :2], want[:, :2]), c["name"]            # enumeration order (models.py:260-264)
+        assert np.abs(got[:, 2:] - want[:, 2:]).max() <= ML_TOL, c["name"]
+        assert sorted([call["h1"] // period, call["h2"] // period]) == exp["alleles"], c["name"]
+        assert "{}-{}|{}-{}".format(*call["ci"]) == exp["CI"], c["name"]
+        assert abs(call["pp"] - exp["PP"]) <= 1e-9, c["name"]
+        tot = want[:, 2:].sum(axis=1)
+        assert abs(call["lik"] - tot.max()) <= ML_TOL
+        # marginals (un-normalised) -> the reference's sparsified P_h1 / P_h2 (models.py:304-317)
+        for which, name in enumerate(("P_h1", "P_h2")):
+            m = marg[i, which]
+            z = {str(k): m[k] / m.sum() for k in np.nonzero(m >= lo.SMALL_VALUE)[0]}
+            assert set(z) == set(exp[name]), (c["name"], name)
+            for k in z:
+                assert abs(z[k] - exp[name][k]) <= 1e-9
+
+
+def test_kde_matches_reference(ctx):
+    _set_model(ctx)
+    cs = [c for c in CASES if c["kde"] is not None]
+    units, _, _, _, gl, _ = _case_inputs(cs, 128)
+    pdf = np.zeros((len(cs), 1000))
+    st = np.zeros(len(cs), np.int32)
+    ctx.pe_kde(_lib.MEM_HOST, units, len(cs), gl, len(gl), pdf, st)
+    assert (st == 0).all()
+    for i, c in enumerate(cs):
+        assert np.abs(pdf[i] - c["kde"]).max() <= 1e-12
+        assert abs(pdf[i].sum() - 1) < 1e-12
+
+
+def test_fused_batch_matches_oracle_chain(ctx, loci):
+    """SW -> tally -> grid on the GPU vs oracle classification + numpy likelihood, unit by unit."""
+    _set_model(ctx)
+    rng = np.random.default_rng(99)
+    sel = [l for l in loci if l["name"] in ("HD", "DM1", "SCA10", "ULD", "FRDA", "AR", "OPMD")]
+    p = synth.SynthParams(coverage=30, expanded_max=120, expanded_frac=0.3)
+    b = synth.build_batch(rng, sel, 6, p, maxinsert=150)
+    ctx.set_ladders(b.ladders)
+    n, g = b.n_reads, b.n_units
+    tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
+    hs = b.hist_stride
+    full = np.zeros((g, hs), np.int32); pref = np.zeros((g, hs), np.int32); rept = np.zeros((g, hs), np.int32)
+    calls = np.zeros(g, _lib.CALL_DTYPE)
+    ctx.genotype_batch(_lib.MEM_HOST, b.packed, b.read_off, b.read_len, n, b.unit_read_off, b.unit_ladder, b.units,
+                       g, _lib.default_sw_params(max_read_len=150), None, b.global_lens, len(b.global_lens),
+                       b.target_lens, len(b.target_lens), tag, h, sc, hs, full, pref, rept, calls)
+    reads = [synth.decode(r) for r in b.codes]
+    ls = po.LocusSet(b.ladders)
+    read_locus = np.repeat(b.unit_ladder, np.diff(b.unit_read_off))
+    cls = po.classify(reads, read_locus, ls, threads=8)
+    assert np.array_equal(tag, cls[:, 0].astype(np.uint8))
+    assert np.array_equal(h, cls[:, 1].astype(np.int16))
+    n_called = 0
+    for u in range(g):
+        r0, r1 = b.unit_read_off[u], b.unit_read_off[u + 1]
+        f, pp, rr = {}, {}, 0
+        for t, hh, _ in cls[r0:r1]:
+            if t == 1: f[int(hh)] = f.get(int(hh), 0) + 1
+            elif t in (2, 3): pp[int(hh)] = pp.get(int(hh), 0) + 1
+            elif t == 4: rr += 1
+        assert {k: v for k, v in enumerate(full[u]) if v} == f
+        assert {k: v for k, v in enumerate(pref[u]) if v} == pp
+        assert rept[u].sum() == rr
+        up = b.units[u]
+        locus = sel[b.unit_ladder[u]]
+        caller = lo.Caller(int(up["period"]), int(up["readlen"]), int(up["ploidy"]), 2 * float(up["half_depth"]), f, pp,
+                           rr, b.global_lens[up["pe_off"]:up["pe_off"] + up["n_global"]],
+                           b.target_lens[up["tl_off"]:up["tl_off"] + up["n_target"]], int(up["ref_len"]),
+                           int(up["minpe"]), maxinsert=int(up["maxinsert"]))
+        res = caller.evaluate()
+        if res["status"] == 1:
+            assert calls[u]["status"] == 1
+            continue
+        assert calls[u]["status"] == 0
+        assert (calls[u]["h1"], calls[u]["h2"]) == tuple(res["alleles"]), (u, locus["name"])
+        assert abs(calls[u]["lik"] - res["lik"]) <= ML_TOL
+        assert tuple(calls[u]["ci"]) == tuple(res["CI"])
+        ppv = lo.calc_PP(res["tot"], res["lik"], int(up["period"]), locus["cutoff_risk"],
+                         locus["mutation_nature"] == "increase", locus["inheritance"][-1] == "R")
+        assert abs(calls[u]["pp"] - ppv) <= 1e-9
+        assert calls[u]["n_pairs"] == len(res["mls"])
+        n_called += 1
+    assert n_called >= g - 2

@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ from the REFERENCE ITSELF.
+
+BUILD-CONTAINER ONLY (reads /root/reference through tools/refshim.py and oracle/_ref/libssw.so).
+The outputs are plain data (inputs + expected outputs); no reference source is stored.
+
+  sw_pairs.npz     (read, template) -> (score, ref_begin, ref_end, read_begin, read_end) from the
+                   compiled reference ssw.c driven exactly as ssw_wrap.Aligner.align does
+  classify.json    reads -> (tag, h) from the reference's BamParser._parseReadSW + tally_counts
+  grid.npz/json    IntegratedCaller inputs -> ordered [(h1,h2,ml1..ml4)], alleles, lik, PP, CI,
+                   P_h1/P_h2/P_h1h2, label from the reference's models.py
+  kde.npz          global_lens -> PEMaxLikModel.pdf
+"""
+import json
+import logging
+import os
+import sys
+import types
+from collections import defaultdict
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import refshim  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from tredparse_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def locus_by_name(loci, name):
+    return [l for l in loci if l["name"] == name][0]
+
+
+def make_reads(rng, loci, names, readlen, n_units, **kw):
+    """[(locus, reads[str])] drawn from the synthetic generator (+ a few adversarial reads)."""
+    out = []
+    p = synth.SynthParams(readlen=readlen, **kw)
+    for nm in names:
+        locus = locus_by_name(loci, nm)
+        lb = synth.simulate_locus(rng, locus, n_units, p)
+        reads = [synth.decode(r) for r in lb.reads]
+        reads.append("N" * readlen)
+        reads.append(synth.decode(rng.integers(0, 4, readlen).astype(np.uint8)))
+        rep = locus["repeat"].replace("N", "C")
+        reads.append((rep * (readlen // len(rep) + 1))[:readlen])          # pure repeat
+        reads.append(po.rc((rep * (readlen // len(rep) + 1))[:readlen]))    # pure repeat, other strand
+        out.append((locus, reads))
+    return out
+
+
+def gen_sw(loci):
+    rng = np.random.default_rng(20260101)
+    reads_all, refs_all, pr, pt, meta = [], [], [], [], []
+    plan = [(150, ["HD", "DM1", "SCA10", "ULD", "OPMD", "BPES", "ALS", "DM2", "FRDA", "SCA8"], 2, 10),
+            (100, ["HD", "SCA36", "CCD"], 2, 8), (250, ["HD", "DM2"], 1, 8), (36, ["SCA3"], 1, 20)]
+    for readlen, names, n_units, cov in plan:
+        for locus, reads in make_reads(rng, loci, names, readlen, n_units, coverage=cov, sub=0.02,
+                                       indel=0.004, nrate=0.01, min_units=1,
+                                       max_units=max(4, readlen // len("CAG") + 10)):
+            mu = -(-readlen // len(locus["repeat"]))
+            if 36 + len(locus["repeat"]) * mu > 511:
+                continue
+            refs = [t for _, t in po.build_ladder(locus["prefix"], locus["repeat"], locus["suffix"], mu)]
+            # subsample reads so the file stays small
+            keep = rng.permutation(len(reads))[:40]
+            r0, t0 = len(reads_all), len(refs_all)
+            reads_all += [reads[i] for i in keep]
+            refs_all += refs
+            for i in range(len(keep)):
+                for j in range(len(refs)):
+                    pr.append(r0 + i)
+                    pt.append(t0 + j)
+            meta.append((locus["name"], readlen, len(keep), len(refs)))
+    res = po.ref_sw_pairs(reads_all, refs_all, pr, pt, threads=8)
+    np.savez_compressed(os.path.join(GOLD, "sw_pairs.npz"), reads=np.array(reads_all), refs=np.array(refs_all),
+                        pair_read=np.asarray(pr, np.int32), pair_ref=np.asarray(pt, np.int32),
+                        result=res.astype(np.int16), scoring=np.asarray([1, 5, 7, 2], np.int32))
+    print("sw_pairs:", len(pr), "pairs", meta)
+
+
+class FakeRead:
+    def __init__(self, name, seq):
+        self.query_name, self.query_sequence = name, seq
+
+
+def fake_input_params(ref, locus, readlen, clip=False, depth=30.0, ploidy_gender="Unknown"):
+    tred = types.SimpleNamespace(
+        repeat=locus["repeat"], chr="chrT", repeat_start=10000, alt=[],
+        repeat_end=10000 + int(locus["repeat_location"].split(":")[1].split("-")[1]) -
+        int(locus["repeat_location"].split(":")[1].split("-")[0]),
+        prefix=locus["prefix"], suffix=locus["suffix"], is_xlinked=locus["inheritance"][0] == "X", ploidy=2,
+        inheritance=locus["inheritance"], cutoff_risk=locus["cutoff_risk"], cutoff_prerisk=locus["cutoff_prerisk"],
+        is_recessive=locus["inheritance"][-1] == "R", is_expansion=locus["mutation_nature"] == "increase",
+        name=locus["name"])
+    ip = types.SimpleNamespace(bam="none.bam", gender=ploidy_gender, depth=depth, READLEN=readlen, clip=clip,
+                               alts=False, repeatpairs=True, ref="hg38", tred=tred,
+                               getLogLevel=lambda *a: logging.INFO, kwargs={})
+    return ip
+
+
+def gen_classify(ref, loci):
+    rng = np.random.default_rng(20260102)
+    cases = []
+    plan = [(150, ["HD", "DM1", "SCA10", "ULD", "OPMD", "XLMR"], False), (100, ["SCA2", "DM2"], False),
+            (150, ["HD"], True)]
+    for readlen, names, clip in plan:
+        for locus, reads in make_reads(rng, loci, names, readlen, 1, coverage=25, min_units=3,
+                                       max_units=readlen // 3 + 20):
+            if clip:  # ragged lengths exercise the per-read REPT cut-off
+                reads = [r[int(rng.integers(0, 40)):] for r in reads]
+            bp = ref.bam_parser.BamParser(fake_input_params(ref, locus, readlen, clip=clip))
+            db = bp._buildDB()
+            per_read = []
+            for i, seq in enumerate(reads):
+                n_before = len(bp.details)
+                hang_before = dict(bp.counts["HANG"])
+                bp._parseReadSW("chrT", FakeRead("r{}".format(i), seq), db)
+                tag, h = "", 0
+                if len(bp.details) > n_before:
+                    tag, h = bp.details[-1]["tag"], bp.details[-1]["h"]
+                else:
+                    for k, v in bp.counts["HANG"].items():
+                        if v != hang_before.get(k, 0):
+                            tag, h = "HANG", k
+                per_read.append([tag, int(h)])
+            bp.tally_counts()
+            rept = sum(bp.counts["REPT"].values()) if bp.counts["REPT"] else 0
+            cases.append({"locus": locus["name"], "readlen": readlen, "clip": clip, "max_units": bp.max_units,
+                          "reads": reads, "expected": per_read,
+                          "FULL": {str(k): v for k, v in sorted(bp.counts["FULL"].items())},
+                          "PREF": {str(k): v for k, v in sorted(bp.counts["PREF"].items())},
+                          "REPT": {str(k): v for k, v in sorted(bp.counts["REPT"].items())}, "rept": rept})
+            print("classify:", locus["name"], readlen, clip, len(reads), "reads",
+                  sum(1 for t, _ in per_read if t), "tagged")
+    with open(os.path.join(GOLD, "classify.json"), "w") as fp:
+        json.dump({"generator": "tools/gen_golden.py (reference bam_parser._parseReadSW)", "cases": cases}, fp)
+
+
+def ref_caller(ref, locus, case):
+    """Drive the reference's IntegratedCaller on plain inputs."""
+    ip = fake_input_params(ref, locus, case["readlen"], depth=case["depth"])
+    counts = {}
+    counts["PREF"] = counts["POST"] = defaultdict(int)
+    for tag in ("FULL", "REPT", "HANG"):
+        counts[tag] = defaultdict(int)
+    for k, v in sorted(case["full"].items(), key=lambda kv: int(kv[0])):
+        counts["FULL"][int(k)] = v
+    for k, v in sorted(case["partial"].items(), key=lambda kv: int(kv[0])):
+        counts["PREF"][int(k)] = v
+    bp = types.SimpleNamespace(tred=ip.tred, READLEN=case["readlen"], repeatSize=len(locus["repeat"]),
+                               counts=counts, rept=case["rept"], ploidy=case["ploidy"], depth=case["depth"],
+                               inputParams=ip)
+    pe = types.SimpleNamespace(global_lens=list(case["global_lens"]), target_lens=list(case["target_lens"]),
+                               ref=case["ref_len"], MINPE=case["minpe"])
+    ref.models.PEextractor = lambda _bp: pe
+    caller = ref.models.IntegratedCaller(bp, maxinsert=case["maxinsert"], fullsearch=case["fullsearch"])
+    # capture the per-pair terms (the reference only logs them): wrap the four evaluators
+    rec = []
+    ev = {n: getattr(caller, n) for n in ("evaluate_spanning", "evaluate_partial", "evaluate_rept")}
+    return caller, rec, ev
+
+
+def gen_grid(ref, loci):
+    rng = np.random.default_rng(20260103)
+    cases = []
+
+    def add(name, locus_name, readlen=150, ploidy=2, maxinsert=100, fullsearch=False, h=None, coverage=30,
+            full=None, partial=None, rept=None, n_global=None, tweak=None, **kw):
+        locus = locus_by_name(loci, locus_name)
+        p = synth.SynthParams(coverage=coverage, readlen=readlen, **kw)
+        lb = synth.simulate_locus(rng, locus, 1, p, h_pairs=[h] if h else None)
+        reads = [synth.decode(r) for r in lb.reads]
+        mu = -(-readlen // len(locus["repeat"]))
+        ls = po.LocusSet([(locus["prefix"], locus["repeat"], locus["suffix"], mu)])
+        cls = po.classify(reads, np.zeros(len(reads), np.int32), ls, threads=8)
+        f, pp, r = defaultdict(int), defaultdict(int), 0
+        for t, hh, _ in cls:
+            if t == 1: f[int(hh)] += 1
+            elif t in (2, 3): pp[int(hh)] += 1
+            elif t == 4: r += 1
+        span = locus["repeat_location"].split(":")[1].split("-")
+        ref_len = int(span[1]) - int(span[0]) + 1
+        gl = lb.global_lens if n_global is None else lb.global_lens[:n_global]
+        case = {"name": name, "locus": locus_name, "readlen": readlen, "ploidy": ploidy, "maxinsert": maxinsert,
+                "fullsearch": fullsearch, "depth": float(lb.depth[0]),
+                "full": {str(k): v for k, v in sorted((full if full is not None else f).items())},
+                "partial": {str(k): v for k, v in sorted((partial if partial is not None else pp).items())},
+                "rept": r if rept is None else rept, "global_lens": [int(x) for x in gl],
+                "target_lens": [int(x) for x in lb.target_lens], "ref_len": ref_len, "minpe": ref_len - 1 + 20,
+                "h_true": [int(x) for x in lb.h_true[0]]}
+        if tweak:
+            tweak(case)
+        cases.append(case)
+
+    add("hd_typical", "HD", h=[15, 41], maxinsert=300)
+    add("hd_close", "HD", h=[17, 19])
+    add("hd_homo", "HD", h=[30, 30])
+    add("hd_expanded_rept_pe", "HD", h=[20, 90], maxinsert=300)
+    add("dm1_expanded_big", "DM1", h=[5, 200], maxinsert=300, coverage=40)
+    add("hd_haploid", "HD", h=[22, 22], ploidy=1)
+    add("hd_fullsearch", "HD", h=[15, 41], fullsearch=True, maxinsert=60)
+    add("hd_no_full", "HD", h=[70, 80], maxinsert=120)
+    add("hd_no_pe_model", "HD", h=[20, 90], n_global=50)
+    add("ar_decrease", "AR", h=[6, 21])
+    add("frda_recessive", "FRDA", h=[70, 80], maxinsert=120)
+    add("uld_period12", "ULD", h=[2, 3])
+    add("uld_period12_big", "ULD", h=[3, 40], maxinsert=80)
+    add("sca10_period5", "SCA10", h=[12, 14])
+    add("sca36_period6_rl100", "SCA36", readlen=100, h=[5, 9])
+    add("dm2_period4_rl250", "DM2", readlen=250, h=[20, 75], maxinsert=120)
+    add("opmd_nmotif", "OPMD", h=[10, 13])
+    add("hd_dup_axis", "HD", h=[20, 90], full={"15": 3, "41": 2}, partial={"20": 2, "30": 1}, rept=3)
+    add("hd_partial_only", "HD", full={}, partial={"12": 2, "33": 1}, rept=0, h=[15, 41])
+    add("hd_rept_only_extended", "HD", full={}, partial={"45": 3, "47": 2}, rept=4, h=[20, 90], maxinsert=150)
+    add("hd_empty", "HD", full={}, partial={}, rept=0, h=[15, 41])
+    add("hd_low_cov", "HD", h=[15, 41], coverage=6)
+    add("hd_100x", "HD", h=[18, 150], coverage=100, maxinsert=200)
+
+    def singular(case):
+        case["global_lens"] = [350] * 150
+    add("hd_singular_kde", "HD", h=[20, 90], tweak=singular)
+
+    out_arrays, out_cases = {}, []
+    for ci, case in enumerate(cases):
+        locus = locus_by_name(loci, case["locus"])
+        exp = {}
+        try:
+            caller, rec, ev = ref_caller(ref, locus, case)
+            terms = []
+            orig_sp, orig_pa, orig_re = caller.evaluate_spanning, caller.evaluate_partial, caller.evaluate_rept
+            pem = caller.pemodel
+            state = {}
+
+            def sp(obs, h1, h2): state["ml1"] = orig_sp(obs, h1, h2); return state["ml1"]
+            def pa(obs, h1, h2): state["ml2"] = orig_pa(obs, h1, h2); return state["ml2"]
+
+            def re_(n, h1, h2):
+                state["ml3"] = orig_re(n, h1, h2)
+                terms.append([h1, h2, state.get("ml1", 0), state.get("ml2", 0), state["ml3"], 0.0])
+                state.pop("ml1", None); state.pop("ml2", None)
+                return state["ml3"]
+            caller.evaluate_spanning, caller.evaluate_partial, caller.evaluate_rept = sp, pa, re_
+            if pem is not None:
+                orig_pe = pem.evaluate
+
+                def pev(h1, h2):
+                    v = orig_pe(h1, h2)
+                    terms[-1][5] = v
+                    return v
+                pem.evaluate = pev
+            caller.call()
+            exp["raised"] = ""
+            exp["alleles"] = [int(x) for x in caller.alleles]
+            exp["label"] = caller.label
+            exp["CI"] = caller.CI
+            exp["PP"] = float(caller.PP)
+            exp["P_h1"] = caller.P_h1 if caller.P_h1 else {}
+            exp["P_h2"] = caller.P_h2 if caller.P_h2 else {}
+            exp["P_h1h2"] = caller.P_h1h2 if caller.P_h1h2 else {}
+            exp["PEDP"], exp["PEG"], exp["PET"] = caller.PEDP, caller.PEG, caller.PET
+            exp["P_PEG"], exp["P_PET"] = caller.P_PEG, caller.P_PET
+            exp["n_pairs"] = len(terms)
+            exp["pe_model"] = pem is not None
+            out_arrays["mls_{}".format(ci)] = np.asarray(terms, np.float64).reshape(-1, 6)
+            if pem is not None:
+                out_arrays["kde_{}".format(ci)] = np.asarray(pem.pdf, np.float64)
+        except Exception as e:  # the reference drops such a locus (tred.py:245-249)
+            exp = {"raised": type(e).__name__}
+        case["expected"] = exp
+        out_cases.append(case)
+        print("grid:", case["name"], exp.get("alleles"), exp.get("CI"), exp.get("PP"), exp.get("label"),
+              exp.get("n_pairs"), exp.get("raised"))
+    np.savez_compressed(os.path.join(GOLD, "grid.npz"), **out_arrays)
+    with open(os.path.join(GOLD, "grid.json"), "w") as fp:
+        json.dump({"generator": "tools/gen_golden.py (reference models.IntegratedCaller.call)",
+                   "cases": out_cases}, fp)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    loci = synth.load_loci()
+    what = sys.argv[1:] or ["sw", "classify", "grid"]
+    if "sw" in what:
+        gen_sw(loci)
+    if "classify" in what or "grid" in what:
+        ref = refshim.load_reference()
+        logging.disable(logging.CRITICAL)
+        if "classify" in what:
+            gen_classify(ref, loci)
+        if "grid" in what:
+            gen_grid(ref, loci)
+
+
+if __name__ == "__main__":
+    main()
