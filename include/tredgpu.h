@@ -225,6 +225,20 @@ int tredgpu_pe_kde(tredgpu_ctx* ctx, int mem, const tredgpu_unit_params* units, 
                    const int32_t* global_lens, int64_t n_global_total, double* pdf_out,
                    int32_t* status_out);
 
+/* ---- measurement ------------------------------------------------------------------------------ */
+/*
+ * Every launch of the three main kernels is bracketed by HIP events on the context's stream.
+ * tredgpu_get_timing synchronises the stream and returns, for kernel `which`
+ * (TREDGPU_KERNEL_*), the number of launches since the last tredgpu_reset_timing and their summed
+ * device time in milliseconds.  (No reference counterpart: the reference only prints wall time,
+ * tredparse/tred.py:534-535.)
+ */
+#define TREDGPU_KERNEL_SW 0
+#define TREDGPU_KERNEL_TALLY 1
+#define TREDGPU_KERNEL_GRID 2
+int tredgpu_reset_timing(tredgpu_ctx* ctx);
+int tredgpu_get_timing(tredgpu_ctx* ctx, int which, int64_t* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

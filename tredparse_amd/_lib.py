@@ -55,7 +55,7 @@ assert CALL_DTYPE.itemsize == C.sizeof(Call) == 56
 EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_sync", "tredgpu_get_stream",
            "tredgpu_version", "tredgpu_set_ladders", "tredgpu_set_model", "tredgpu_pack_reads",
            "tredgpu_sw_classify", "tredgpu_tally", "tredgpu_likelihood_grid", "tredgpu_genotype_batch",
-           "tredgpu_pe_kde")
+           "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing")
 
 _lib = None
 
@@ -93,6 +93,8 @@ def load():
                                            C.POINTER(SwParams), vp, vp, i64, vp, i64, vp, vp, vp, i32,
                                            vp, vp, vp, vp]
     lib.tredgpu_pe_kde.argtypes = [vp, C.c_int, vp, i32, vp, i64, vp, vp]
+    lib.tredgpu_reset_timing.argtypes = [vp]
+    lib.tredgpu_get_timing.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -141,14 +143,15 @@ def pack_codes(codes, lengths=None):
     codes = np.ascontiguousarray(codes, np.uint8)
     n, L = codes.shape
     nb, nm = (L + 15) // 16, (L + 31) // 32
-    padb = np.zeros((n, nb * 16), np.uint32)
-    padb[:, :L] = np.where(codes < 4, codes, 0)
-    sh = (2 * (np.arange(nb * 16) % 16)).astype(np.uint32)
-    words = (padb << sh).reshape(n, nb, 16).sum(axis=2, dtype=np.uint64).astype(np.uint32)
-    padm = np.zeros((n, nm * 32), np.uint32)
-    padm[:, :L] = codes >= 4
-    shm = (np.arange(nm * 32) % 32).astype(np.uint32)
-    masks = (padm << shm).reshape(n, nm, 32).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+    isn = codes >= 4
+    c = np.where(isn, 0, codes).astype(np.uint8)
+    bits = np.zeros((n, nb * 32), np.uint8)          # bit 2k = low bit of base k, bit 2k+1 = high bit
+    bits[:, 0:2 * L:2] = c & 1
+    bits[:, 1:2 * L:2] = c >> 1
+    words = np.packbits(bits, axis=1, bitorder="little").view("<u4")
+    mbits = np.zeros((n, nm * 32), np.uint8)
+    mbits[:, :L] = isn
+    masks = np.packbits(mbits, axis=1, bitorder="little").view("<u4")
     packed = np.ascontiguousarray(np.concatenate([words, masks], axis=1).reshape(-1))
     woff = (np.arange(n + 1, dtype=np.int64) * (nb + nm))
     rlen = np.full(n, L, np.int32)
@@ -242,9 +245,21 @@ class Context:
                                                   hist_stride, _ptr(full_cnt), _ptr(pref_cnt), _ptr(rept_cnt),
                                                   _ptr(calls)), "tredgpu_genotype_batch")
 
+    def reset_timing(self):
+        self._chk(self.lib.tredgpu_reset_timing(self.h), "tredgpu_reset_timing")
+
+    def get_timing(self, which):
+        """(launches, total device ms) of kernel `which` since reset_timing (HIP events)."""
+        n, ms = C.c_int64(0), C.c_double(0)
+        self._chk(self.lib.tredgpu_get_timing(self.h, which, C.byref(n), C.byref(ms)), "tredgpu_get_timing")
+        return n.value, ms.value
+
     def pe_kde(self, mem, units, n_units, global_lens, n_global_total, pdf_out, status_out):
         self._chk(self.lib.tredgpu_pe_kde(self.h, mem, _ptr(units), n_units, _ptr(global_lens),
                                           n_global_total, _ptr(pdf_out), _ptr(status_out)), "tredgpu_pe_kde")
+
+
+KERNEL_SW, KERNEL_TALLY, KERNEL_GRID = 0, 1, 2
 
 
 def default_sw_params(clip=False, max_read_len=0):

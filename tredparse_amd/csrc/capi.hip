@@ -40,6 +40,13 @@ struct tredgpu_ctx {
     Buf st[24];  // staging for HOST-memory calls
     // intermediates of the fused path
     Buf ws_tag, ws_h, ws_score;
+    // HIP-event timing of the three main kernels
+    struct Timer {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;  // reusable event pairs
+        size_t used = 0;
+        int64_t launches = 0;
+        double total_ms = 0;
+    } timers[3];
 };
 
 namespace {
@@ -59,6 +66,43 @@ int fail(tredgpu_ctx* c, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                            \
         if (e_ != hipSuccess) return fail((c), -10, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// resolve the recorded event pairs of one timer into (launches, total_ms); stream must be idle
+void timer_flush(tredgpu_ctx::Timer& t) {
+    for (size_t i = 0; i < t.used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.pool[i].first, t.pool[i].second) == hipSuccess) {
+            t.total_ms += ms;
+            t.launches += 1;
+        }
+    }
+    t.used = 0;
+}
+
+struct ScopedTimer {
+    tredgpu_ctx* c;
+    tredgpu_ctx::Timer& t;
+    hipEvent_t stop = nullptr;
+    ScopedTimer(tredgpu_ctx* c_, int which) : c(c_), t(c_->timers[which]) {
+        if (t.used >= 256) {  // bounded pool: fold what is already finished
+            (void)hipStreamSynchronize(c->stream);
+            timer_flush(t);
+        }
+        if (t.used == t.pool.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            t.pool.emplace_back(a, b);
+        }
+        (void)hipEventRecord(t.pool[t.used].first, c->stream);
+        stop = t.pool[t.used].second;
+    }
+    ~ScopedTimer() {
+        if (stop) {
+            (void)hipEventRecord(stop, c->stream);
+            t.used += 1;
+        }
+    }
+};
 
 int ensure(tredgpu_ctx* c, Buf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -180,6 +224,8 @@ void tredgpu_destroy(tredgpu_ctx* c) {
                    &c->ws_grid, &c->ws_tag, &c->ws_h, &c->ws_score})
         release(*b);
     for (Buf& b : c->st) release(b);
+    for (auto& t : c->timers)
+        for (auto& ev : t.pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -194,6 +240,25 @@ int tredgpu_sync(tredgpu_ctx* c) {
 }
 
 void* tredgpu_get_stream(tredgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int tredgpu_reset_timing(tredgpu_ctx* c) {
+    if (!c) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& t : c->timers) { t.used = 0; t.launches = 0; t.total_ms = 0; }
+    return 0;
+}
+
+int tredgpu_get_timing(tredgpu_ctx* c, int which, int64_t* launches, double* total_ms) {
+    if (!c) return -2;
+    if (which < 0 || which > 2) return fail(c, -2, "which must be TREDGPU_KERNEL_SW/TALLY/GRID");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timer_flush(c->timers[which]);
+    if (launches) *launches = c->timers[which].launches;
+    if (total_ms) *total_ms = c->timers[which].total_ms;
+    return 0;
+}
 
 int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, const char* const* repeat,
                         const char* const* suffix, const int32_t* max_units) {
@@ -334,7 +399,10 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     a.dump_templates = dump_templates;
     a.n_units = n_units;
     a.p = *p;
-    HIPCHK(c, launch_sw_ladder(a, rows_for(max_len), max_quads, c->stream));
+    {
+        ScopedTimer tm(c, TREDGPU_KERNEL_SW);
+        HIPCHK(c, launch_sw_ladder(a, rows_for(max_len), max_quads, c->stream));
+    }
     return 0;
 }
 
@@ -409,6 +477,7 @@ int tredgpu_tally(tredgpu_ctx* c, int mem, const uint8_t* tag, const int16_t* h,
     int rc;
     if (read_pair_id && (rc = ensure(c, c->ws_drop, (size_t)n_reads))) return rc;
     if (mem == TREDGPU_MEM_DEVICE) {
+        ScopedTimer tm(c, TREDGPU_KERNEL_TALLY);
         HIPCHK(c, launch_tally(tag, h, n_reads, unit_read_off, n_units, read_pair_id, hist_stride, full_cnt, pref_cnt,
                                rept_cnt, (uint8_t*)c->ws_drop.p, c->stream));
         return 0;
@@ -424,8 +493,11 @@ int tredgpu_tally(tredgpu_ctx* c, int mem, const uint8_t* tag, const int16_t* h,
     if ((rc = stage_out(c, c->st[4], hn, &d_f))) return rc;
     if ((rc = stage_out(c, c->st[5], hn, &d_p))) return rc;
     if ((rc = stage_out(c, c->st[6], hn, &d_r))) return rc;
-    HIPCHK(c, launch_tally(d_tag, d_h, n_reads, d_uoff, n_units, d_pid, hist_stride, d_f, d_p, d_r,
-                           (uint8_t*)c->ws_drop.p, c->stream));
+    {
+        ScopedTimer tm(c, TREDGPU_KERNEL_TALLY);
+        HIPCHK(c, launch_tally(d_tag, d_h, n_reads, d_uoff, n_units, d_pid, hist_stride, d_f, d_p, d_r,
+                               (uint8_t*)c->ws_drop.p, c->stream));
+    }
     if ((rc = copy_back(c, full_cnt, (const int32_t*)d_f, hn))) return rc;
     if ((rc = copy_back(c, pref_cnt, (const int32_t*)d_p, hn))) return rc;
     if ((rc = copy_back(c, rept_cnt, (const int32_t*)d_r, hn))) return rc;
@@ -466,7 +538,10 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     a.model = (const ModelConst*)c->d_model.p;
     a.kde_pdf = nullptr;
     a.kde_status = nullptr;
-    HIPCHK(c, launch_grid(a, (double*)c->ws_grid.p, c->stream));
+    {
+        ScopedTimer tm(c, TREDGPU_KERNEL_GRID);
+        HIPCHK(c, launch_grid(a, (double*)c->ws_grid.p, c->stream));
+    }
     return 0;
 }
 
@@ -582,8 +657,11 @@ int tredgpu_genotype_batch(tredgpu_ctx* c, int mem, const uint32_t* packed, cons
         if ((rc = run_sw_device(c, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, n_units, params,
                                 max_len, out_tag, out_h, out_score, nullptr, 0)))
             return rc;
-        HIPCHK(c, launch_tally(out_tag, out_h, n_reads, unit_read_off, n_units, read_pair_id, hist_stride, full_cnt,
-                               pref_cnt, rept_cnt, (uint8_t*)c->ws_drop.p, c->stream));
+        {
+            ScopedTimer tm(c, TREDGPU_KERNEL_TALLY);
+            HIPCHK(c, launch_tally(out_tag, out_h, n_reads, unit_read_off, n_units, read_pair_id, hist_stride, full_cnt,
+                                   pref_cnt, rept_cnt, (uint8_t*)c->ws_drop.p, c->stream));
+        }
         return run_grid_device(c, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens, target_lens,
                                calls, nullptr, nullptr, nullptr, 0);
     }

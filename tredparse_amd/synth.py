@@ -79,10 +79,11 @@ class LocusBatch:
 def _mutate(rng, reads, p):
     """In-place substitutions / N; indels applied per affected read (rare)."""
     n, L = reads.shape
-    r = rng.random(reads.shape)
-    sub = r < p.sub
+    r = rng.integers(0, 65536, reads.shape, dtype=np.uint16)
+    t_sub, t_n = int(p.sub * 65536), int((p.sub + p.nrate) * 65536)
+    sub = r < t_sub
     reads[sub] = (reads[sub] + rng.integers(1, 4, int(sub.sum()), dtype=np.uint8)) % 4
-    isn = (r >= p.sub) & (r < p.sub + p.nrate)
+    isn = (r >= t_sub) & (r < t_n)
     reads[isn] = 4
     if p.indel > 0:
         hit = np.nonzero(rng.random(n) < 1 - (1 - 2 * p.indel) ** L)[0]
@@ -145,19 +146,16 @@ def simulate_locus(rng, locus, n_units, p, h_pairs=None):
             if len(idx) == 0:
                 continue
             # materialise the read bases from the haplotype (flanks are random per unit and position)
-            pos = s[idx, None] + np.arange(L)[None, :]
-            rel = pos - p.flank
-            hl = hlen[unit[idx], None]
-            bases = rng.integers(0, 4, pos.shape, dtype=np.uint8)     # flank bases (i.i.d.)
-            in_pre = (rel >= 0) & (rel < len(prefix))
-            bases[in_pre] = prefix[rel[in_pre]]
-            rrel = rel - len(prefix)
-            in_rep = (rrel >= 0) & (rrel < hl)
+            rel = (s[idx, None] - p.flank + np.arange(L, dtype=np.int32)[None, :]).astype(np.int32)
+            hl = hlen[unit[idx], None].astype(np.int32)
+            bases = rng.integers(0, 4, rel.shape, dtype=np.uint8)     # flank bases (i.i.d.)
             rep = encode(locus["repeat"].replace("N", "ACGT"[int(rng.integers(0, 4))]))
-            bases[in_rep] = rep[rrel[in_rep] % period]
+            # one lookup table: [prefix | repeat * many | suffix] indexed by position class
+            rrel = rel - len(prefix)
             srel = rrel - hl
-            in_suf = (srel >= 0) & (srel < len(suffix))
-            bases[in_suf] = suffix[np.clip(srel, 0, len(suffix) - 1)[in_suf]]
+            np.copyto(bases, prefix[np.clip(rel, 0, len(prefix) - 1)], where=(rel >= 0) & (rel < len(prefix)))
+            np.copyto(bases, rep[np.remainder(rrel, period)], where=(rrel >= 0) & (srel < 0))
+            np.copyto(bases, suffix[np.clip(srel, 0, len(suffix) - 1)], where=(srel >= 0) & (srel < len(suffix)))
             # unmapped reads come in sequencing orientation: reverse-complement half of them
             flip = inside[idx] & (rng.random(len(idx)) < 0.5)
             bases[flip] = _COMP[bases[flip][:, ::-1]]
@@ -219,34 +217,60 @@ class Batch:
         self.hist_stride = max(l[3] for l in self.ladders) + 2
 
 
-def build_batch(rng, loci, n_samples, p, maxinsert=300, fullsearch=False):
-    """n_samples x len(loci) units; unit index = locus_index * n_samples + sample."""
+def _sim_task(args):
+    seed, li, locus, n_samples, p = args
+    lb = simulate_locus(np.random.default_rng([seed, li]), locus, n_samples, p)
+    lb.packed, lb.read_off, lb.read_len = _lib.pack_codes(lb.reads)  # pack in the worker
+    return lb
+
+
+def build_batch(rng, loci, n_samples, p, maxinsert=300, fullsearch=False, workers=0):
+    """n_samples x len(loci) units; unit index = locus_index * n_samples + sample.
+    rng: numpy Generator or an int seed; workers > 1 simulates loci in a process pool (call it
+    before the process touches the GPU)."""
     b = Batch(loci, p.readlen)
-    parts, units = [], []
+    seed = int(rng.integers(0, 2 ** 31)) if hasattr(rng, "integers") else int(rng)
+    tasks = [(seed, li, locus, n_samples, p) for li, locus in enumerate(loci)]
+    if workers and workers > 1 and len(tasks) > 1:
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=min(workers, len(tasks))) as ex:
+            sims = list(ex.map(_sim_task, tasks))
+    else:
+        sims = [_sim_task(t) for t in tasks]
+    parts = []
     read_base, gl_base, tl_base = 0, 0, 0
-    gls, tls, uoffs, ulad, htrue = [], [], [np.zeros(1, np.int64)], [], []
-    for li, locus in enumerate(loci):
-        lb = simulate_locus(rng, locus, n_samples, p)
+    gls, tls, uoffs, ulad, htrue, unit_blocks = [], [], [np.zeros(1, np.int64)], [], [], []
+    for li, (locus, lb) in enumerate(zip(loci, sims)):
         parts.append(lb.reads)
         uoffs.append(lb.unit_read_off[1:] + read_base)
         read_base += len(lb.reads)
         ulad.append(np.full(n_samples, li, np.int32))
         htrue.append(lb.h_true)
-        for g in range(n_samples):
-            units.append(unit_params_for(locus, p.readlen, lb.depth[g], int(lb.gl_off[g + 1] - lb.gl_off[g]),
-                                         int(lb.tl_off[g + 1] - lb.tl_off[g]), int(lb.gl_off[g] + gl_base),
-                                         int(lb.tl_off[g] + tl_base), maxinsert=maxinsert, fullsearch=fullsearch))
+        blk = np.zeros(n_samples, _lib.UNIT_DTYPE)
+        blk[:] = unit_params_for(locus, p.readlen, 0.0, 0, 0, 0, 0, maxinsert=maxinsert, fullsearch=fullsearch)
+        blk["half_depth"] = lb.depth / 2
+        blk["pe_off"] = lb.gl_off[:-1] + gl_base
+        blk["n_global"] = np.diff(lb.gl_off)
+        blk["tl_off"] = lb.tl_off[:-1] + tl_base
+        blk["n_target"] = np.diff(lb.tl_off)
+        unit_blocks.append(blk)
         gls.append(lb.global_lens)
         tls.append(lb.target_lens)
         gl_base += len(lb.global_lens)
         tl_base += len(lb.target_lens)
     b.codes = np.concatenate(parts)
     b.n_reads = len(b.codes)
-    b.packed, b.read_off, b.read_len = _lib.pack_codes(b.codes)
+    b.packed = np.concatenate([lb.packed for lb in sims])
+    woffs, wbase = [np.zeros(1, np.int64)], 0
+    for lb in sims:
+        woffs.append(lb.read_off[1:] + wbase)
+        wbase += int(lb.read_off[-1])
+    b.read_off = np.concatenate(woffs)
+    b.read_len = np.concatenate([lb.read_len for lb in sims])
     b.unit_read_off = np.concatenate(uoffs).astype(np.int32)
     b.unit_ladder = np.concatenate(ulad)
     b.n_units = len(b.unit_ladder)
-    b.units = np.array(units, _lib.UNIT_DTYPE)
+    b.units = np.concatenate(unit_blocks)
     b.global_lens = np.concatenate(gls).astype(np.int32) if gls else np.zeros(0, np.int32)
     b.target_lens = np.concatenate(tls).astype(np.int32) if tls else np.zeros(0, np.int32)
     b.h_true = np.concatenate(htrue)
