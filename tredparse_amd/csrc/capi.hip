@@ -265,7 +265,16 @@ int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, co
     if (!c) return -2;
     if (n < 0 || (n > 0 && (!prefix || !repeat || !suffix || !max_units))) return fail(c, -2, "bad ladder arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<int8_t> seq;
+    std::vector<uint32_t> seq;  // letters, 8 per word; every segment starts on a word boundary
+    auto append = [&seq](const std::vector<int8_t>& v) {
+        const int off = (int)seq.size();
+        seq.resize(seq.size() + (v.size() + 7) / 8 + 1, 0x44444444u);
+        for (size_t i = 0; i < v.size(); ++i) {
+            uint32_t& w = seq[off + i / 8];
+            w = (w & ~(0xFu << ((i % 8) * 4))) | ((uint32_t)v[i] << ((i % 8) * 4));
+        }
+        return off;
+    };
     std::vector<LadderDesc> lad((size_t)n);
     int max_t = 1, max_u = 0;
     for (int i = 0; i < n; ++i) {
@@ -281,9 +290,8 @@ int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, co
             if (P.empty() || P.size() > TREDGPU_MAX_TEMPLATE_LEN)
                 return fail(c, -2, "ladder %d: reference length %zu not in [1,%d]", i, P.size(), TREDGPU_MAX_TEMPLATE_LEN);
             d.alen[0] = (int)P.size();
-            d.trunk_off[0] = (int)seq.size();
-            seq.insert(seq.end(), P.begin(), P.end());
-            d.branch_off[0] = (int)seq.size();
+            d.trunk_off[0] = append(P);
+            d.branch_off[0] = append(std::vector<int8_t>());
             d.period = 1;
             d.max_units = 0;
             d.n_strands = 1;
@@ -300,11 +308,10 @@ int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, co
         for (int s = 0; s < 2; ++s) {
             d.alen[s] = (int)A[s]->size();
             d.blen[s] = (int)B[s]->size();
-            d.trunk_off[s] = (int)seq.size();
-            seq.insert(seq.end(), A[s]->begin(), A[s]->end());
-            for (int k = 0; k < mu; ++k) seq.insert(seq.end(), Rep[s]->begin(), Rep[s]->end());
-            d.branch_off[s] = (int)seq.size();
-            seq.insert(seq.end(), B[s]->begin(), B[s]->end());
+            std::vector<int8_t> trunk(*A[s]);
+            for (int k = 0; k < mu; ++k) trunk.insert(trunk.end(), Rep[s]->begin(), Rep[s]->end());
+            d.trunk_off[s] = append(trunk);
+            d.branch_off[s] = append(*B[s]);
         }
         d.period = (int)Rp.size();
         d.max_units = mu;
@@ -312,13 +319,13 @@ int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, co
         max_t = std::max(max_t, 2 * mu);
         max_u = std::max(max_u, mu);
     }
-    seq.resize(seq.size() + 16, 4);
+    seq.resize(seq.size() + 4, 0x44444444u);
     int rc;
     if ((rc = ensure(c, c->d_ladders, lad.size() * sizeof(LadderDesc)))) return rc;
-    if ((rc = ensure(c, c->d_seq, seq.size()))) return rc;
+    if ((rc = ensure(c, c->d_seq, seq.size() * sizeof(uint32_t)))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (n) HIPCHK(c, hipMemcpy(c->d_ladders.p, lad.data(), lad.size() * sizeof(LadderDesc), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_seq.p, seq.data(), seq.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_seq.p, seq.data(), seq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->h_ladders.swap(lad);
     c->max_templates = max_t;
     c->max_ladder_units = max_u;
@@ -389,7 +396,7 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     a.unit_read_off = unit_read_off;
     a.unit_ladder = unit_ladder;
     a.ladders = (const LadderDesc*)c->d_ladders.p;
-    a.seq = (const int8_t*)c->d_seq.p;
+    a.seqw = (const uint32_t*)c->d_seq.p;
     a.quads = (const Quad*)c->ws_quads.p;
     a.n_quads = (const int32_t*)c->ws_counter.p;
     a.out_tag = out_tag;

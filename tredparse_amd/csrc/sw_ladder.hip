@@ -39,75 +39,122 @@ __device__ __forceinline__ int dpp_row_shr(int old, int x) {
     return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, 0xF, false);
 }
 
-// inclusive max scan over the 16 lanes of a DPP row
+// v_add3_u32 with the wave-uniform column term in an SGPR.  Written as asm so that the compiler cannot
+// re-associate max(diag + S, fresh + S) into max(diag, fresh) + S (one more VALU op per cell).
+__device__ __forceinline__ int add3_vsv(int v0, int s1, int v2) {
+    int d;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(v0), "s"(s1), "v"(v2));
+    return d;
+}
+__device__ __forceinline__ int max3(int a, int b, int c) { return max(max(a, b), c); }
+
+// inclusive max scan over the 16 lanes of a DPP row (old = x: lanes without a source keep x)
 __device__ __forceinline__ int row_scan_max(int x) {
-    x = max(x, dpp_row_shr<0x111>(NEG, x));
-    x = max(x, dpp_row_shr<0x112>(NEG, x));
-    x = max(x, dpp_row_shr<0x114>(NEG, x));
-    x = max(x, dpp_row_shr<0x118>(NEG, x));
+    x = max(x, dpp_row_shr<0x111>(x, x));
+    x = max(x, dpp_row_shr<0x112>(x, x));
+    x = max(x, dpp_row_shr<0x114>(x, x));
+    x = max(x, dpp_row_shr<0x118>(x, x));
     return x;
 }
 
 template <int CTRL>
 __device__ __forceinline__ void pair_step(int& k, int& s) {
-    int tk = dpp_row_shr<CTRL>(0, k);
-    int ts = dpp_row_shr<CTRL>(0, s);
-    bool c = tk > k;
+    const int tk = dpp_row_shr<CTRL>(k, k);
+    const int ts = dpp_row_shr<CTRL>(s, s);
+    const bool c = tk > k;
     k = c ? tk : k;
     s = c ? ts : s;
 }
 
+// Per-lane constants of one read ("job").  All DP values live in the anti-diagonal-scaled domain
+//   X~[i][c] = X[i][c] + (i + c) * ge * K
+// in which the three recurrences lose their per-cell gap-extension subtractions:
+//   F~[i]   = max(F~[i-1], H~[i-1] - c0)          c0 = (go - ge) * K
+//   E~[c+1] = max(E~[c],   H~[c]   - c0)
+//   H~t     = max(D~ + s + 2geK, fresh~ + s, E~)
+// so F~ inside a lane is a plain prefix max and across lanes a plain DPP max scan.
 template <int R>
 struct Rows {
-    int bc[R];  // base code compared with the template letter: 0..3, 4 = N, 5 = padding row
-    int xk[R];  // addend when the letter differs: -mismatch*K, 0 for N rows, PADNEG for padding
-    int zk[R];  // addend in an N template column: 0, PADNEG for padding
-    int rr[R];  // 511 - row index
+    int S[4][R];  // (score vs template letter 0..3) * K + 2*ge*K; PADNEG for padding rows
+    int rowc[R];  // i + i*ge*K: the row part of a fresh start in the scaled domain
 };
 
-// One DP column for all rows of the four alignments in this wave.
-//   H: packed H of the previous column (in) / this column (out);  E: packed E for this column (in) /
-//   the next column (out).  letter is wave-uniform.
-template <int R>
-__device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int (&E)[R],
-                                             int& bestkey, int& beststart, int letter, int col,
-                                             int row0, int mK, int goK, int geK, int shl,
-                                             int geRK) {
-    // diagonal input of this lane's first row: last row of the lane above, previous column
-    const int hup = dpp_row_shr<0x111>(0, H[R - 1]);
-    const int colbits = col << 9;
-    const bool ncol = letter == 4;
-    int ht[R], u[R];
+struct Track {
+    int bestkey;    // score<<18 | (511-col)<<9 | (511-row), true (unscaled) score
+    int beststart;  // packed value of that cell (start col/row in the low 18 bits)
+    int ceil;       // bestkey | PAYMASK: what a cell must exceed to be a new best
+};
+
+// One DP column for all rows of the four alignments in this wave; LET = template letter (4 = N).
+//   s_fresh = (col<<9) + col*geK - 2*geK   (wave-uniform)      s_scale = col*geK
+template <int R, int LET>
+__device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int (&E)[R], Track& T,
+                                             int col, int row0, int s_fresh, int s_scale, int geK,
+                                             int c0, int row0g) {
+    const int hup = dpp_row_shr<0x111>(NEG, H[R - 1]);  // last row of the lane above, previous column
+    int ht[R], pl[R];
     int diag = hup;
+    int run = NEG;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int s = ncol ? J.zk[r] : (J.bc[r] == letter ? mK : J.xk[r]);
-        const int t1 = diag + s;                    // extend the alignment ending at (row-1, col-1)
-        const int t2 = (row0 + r) + colbits + s;    // or start a new one here
-        const int v = max(max(t1, t2), E[r]);
+        int S;
+        if (LET < 4) S = J.S[LET][r];
+        else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;  // N column: 0 against every real row
+        const int t1 = diag + S;                      // extend the alignment ending at (row-1, col-1)
+        const int t2 = add3_vsv(J.rowc[r], s_fresh, S);  // or start a new one here
+        const int v = max3(t1, t2, E[r]);
         diag = H[r];
         ht[r] = v;
-        u[r] = v - goK;
+        pl[r] = run;                                  // F~ from this lane's rows above
+        run = max(run, v - c0);
     }
-    // F entering the row below this lane, from this lane's rows only
-    int a = u[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r) a = max(a - geK, u[r]);
-    // exclusive max-plus scan across the 16 lanes: F entering this lane's first row
-    const int p = row_scan_max(a + shl);
-    int f = dpp_row_shr<0x111>(NEG, p) - shl + geRK;
-    const int revcol = (511 - col) << 9;
+    // exclusive max scan across the 16 lanes: F~ entering this lane from the lanes above
+    const int p = row_scan_max(run);
+    const int fin = dpp_row_shr<0x111>(NEG, p);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int h = max(ht[r], f);
-        f = max(f - geK, u[r]);
+        const int h = max3(ht[r], pl[r], fin);
         H[r] = h;
-        E[r] = max(E[r] - geK, h - goK);
-        const int cand = (h & ~PAYMASK) | revcol | J.rr[r];
-        const bool c = cand > bestkey;
-        bestkey = c ? cand : bestkey;
-        beststart = c ? h : beststart;
+        E[r] = max(E[r], h - c0);
     }
+    // running best: only columns in which some lane could beat its best take the exact path.
+    // run + c0 = max over this lane's rows of H~ without the vertical-gap term (a best cell never ends
+    // in a gap); minus (row0 + col)*geK it over-estimates every row's true value by <= (R-1)*geK.
+    const bool trig = run + c0 - (row0g + s_scale) > T.ceil;
+    if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+        const int revcol = (511 - col) << 9;
+        int scale = row0g + s_scale;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int tr = H[r] - scale;  // true packed value
+            scale += geK;
+            const int cand = (tr & ~PAYMASK) | revcol | (511 - (row0 + r));
+            const bool c = cand > T.bestkey;
+            T.bestkey = c ? cand : T.bestkey;
+            T.beststart = c ? tr : T.beststart;
+        }
+        T.ceil = T.bestkey | PAYMASK;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (&H)[R], int (&E)[R], Track& T,
+                                             int col, int row0, int geK, int c0, int row0g) {
+    const int s_scale = col * geK;
+    const int s_fresh = (col << 9) + s_scale - 2 * geK;
+    switch (letter) {
+        case 0: sweep_column<R, 0>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+        case 1: sweep_column<R, 1>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+        case 2: sweep_column<R, 2>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+        case 3: sweep_column<R, 3>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+        default: sweep_column<R, 4>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+    }
+}
+
+// letters are packed 8 per 32-bit word (4 bits each) so that they are fetched with scalar loads
+__device__ __forceinline__ int letter_at(const uint32_t* seqw, int word_off, int c) {
+    const uint32_t w = seqw[word_off + (c >> 3)];
+    return (int)((w >> ((c & 7) * 4)) & 7u);
 }
 
 template <int R>
@@ -136,10 +183,9 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
 
     const int mK = a.p.match * KONE;
     const int xK = -a.p.mismatch * KONE;
-    const int goK = a.p.gap_open * KONE;
     const int geK = a.p.gap_extend * KONE;
-    const int geRK = geK * R;
-    const int shl = geRK * jl;
+    const int c0 = (a.p.gap_open - a.p.gap_extend) * KONE;
+    const int row0g = row0 * geK;
     const int flank = a.p.flank;
 
     Rows<R> J;
@@ -148,19 +194,16 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = row0 + r;
-            J.rr[r] = 511 - i;
+            J.rowc[r] = i + i * geK;
+            int code = 5;  // padding
             if (i < L) {
                 const uint32_t w = a.packed[off + (i >> 4)];
                 const uint32_t m = a.packed[off + nb + (i >> 5)];
-                const bool isn = (m >> (i & 31)) & 1u;
-                J.bc[r] = isn ? 4 : (int)((w >> ((i & 15) * 2)) & 3u);
-                J.xk[r] = isn ? 0 : xK;
-                J.zk[r] = 0;
-            } else {
-                J.bc[r] = 5;
-                J.xk[r] = PADNEG;
-                J.zk[r] = PADNEG;
+                code = ((m >> (i & 31)) & 1u) ? 4 : (int)((w >> ((i & 15) * 2)) & 3u);
             }
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                J.S[l][r] = code == 5 ? PADNEG : (code == 4 ? 0 : (code == l ? mK : xK)) + 2 * geK;
         }
     }
     // REPT cut-off: per-read ceil(L/period) with --useclippedreads, else the ladder's (bam_parser.py:154-155)
@@ -170,30 +213,52 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
     int16_t* dump = nullptr;
     if (a.out_dump != nullptr && valid) dump = a.out_dump + rd * (int64_t)a.dump_templates * 6;
 
+    // Only cells that can survive the score filter are tracked: min_score >= 30 (bam_parser.py:134), so a
+    // floor of 29 is exact for tagging; the per-template dump (parity/debug) tracks every positive score.
+    const int floor_key = ((dump != nullptr || a.out_dump != nullptr) ? 0 : 29) << KSH | PAYMASK;
+
     for (int s = 0; s < n_strands; ++s) {
-        const int8_t* trunk = a.seq + __builtin_amdgcn_readfirstlane(ld->trunk_off[s]);
-        const int8_t* branch = a.seq + __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
+        const int trunk_w = __builtin_amdgcn_readfirstlane(ld->trunk_off[s]);
+        const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
         const int alen = __builtin_amdgcn_readfirstlane(ld->alen[s]);
         const int blen = __builtin_amdgcn_readfirstlane(ld->blen[s]);
         const int ncols = alen + period * max_units;
-        int H[R], E[R];
+        int H[R], E[R], Hs[R], Es[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
-        int bestkey = 0, beststart = 0;
+        for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; Hs[r] = NEG; Es[r] = NEG; }
+        Track T, Ts;
+        T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
+        Ts = T;
         int next_branch = max_units > 0 ? alen + period - 1 : alen - 1;
         int u = max_units > 0 ? 1 : 0;
-        for (int c = 0; c < ncols; ++c) {
-            const int letter = trunk[c];
-            sweep_column<R>(J, H, E, bestkey, beststart, letter, c, row0, mK, goK, geK, shl, geRK);
-            if (c != next_branch) continue;
-            // ---- template u ends here on the trunk: run its branch from a copy of the state ----
-            int Hb[R], Eb[R];
+        // One sweep site for trunk and branch columns: tc = next trunk column, bk_left = branch columns
+        // still to sweep for template u (state of the trunk parked in Hs/Es/Ts meanwhile).
+        int tc = 0, b_left = 0, b_col = 0, b_idx = 0;
+        bool in_branch = false;
+        while (tc < ncols || in_branch) {
+            int letter, col;
+            if (in_branch) { letter = letter_at(a.seqw, branch_w, b_idx); col = b_col; }
+            else { letter = letter_at(a.seqw, trunk_w, tc); col = tc; }
+            sweep_letter<R>(letter, J, H, E, T, col, row0, geK, c0, row0g);
+            bool emit = false;
+            if (in_branch) {
+                ++b_idx; ++b_col; --b_left;
+                emit = b_left == 0;
+            } else {
+                ++tc;
+                if (col == next_branch) {
+                    // template u ends here on the trunk: park the trunk state, continue into its branch
 #pragma unroll
-            for (int r = 0; r < R; ++r) { Hb[r] = H[r]; Eb[r] = E[r]; }
-            int bk = bestkey, bs = beststart;
-            for (int k = 0; k < blen; ++k)
-                sweep_column<R>(J, Hb, Eb, bk, bs, branch[k], c + 1 + k, row0, mK, goK, geK, shl, geRK);
-            // best cell of the alignment -> lane 15 of the read's DPP row
+                    for (int r = 0; r < R; ++r) { Hs[r] = H[r]; Es[r] = E[r]; }
+                    Ts = T;
+                    in_branch = true;
+                    b_left = blen; b_col = col + 1; b_idx = 0;
+                    emit = blen == 0;
+                }
+            }
+            if (!emit) continue;
+            // ---- template u complete: best cell of the alignment -> lane 15 of the read's DPP row ----
+            int bk = T.bestkey, bs = T.beststart;
             pair_step<0x111>(bk, bs);
             pair_step<0x112>(bk, bs);
             pair_step<0x114>(bk, bs);
@@ -201,14 +266,14 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
             const int score = bk >> KSH;
             const int ref_end = 511 - ((bk >> 9) & 511), read_end = 511 - (bk & 511);
             const int ref_begin = (bs >> 9) & 511, read_begin = bs & 511;
-            const int T = alen + period * u + blen;
-            const int min_len = min(L, T) >> 1;                 // bam_parser.py:133
+            const int Tlen = alen + period * u + blen;
+            const int min_len = min(L, Tlen) >> 1;              // bam_parser.py:133
             const int min_score = max(min_len, 30);             // :134
             const bool pass = score >= min_score && (read_end - read_begin + 1) >= min_len;  // ssw_wrap.py:217
-            const int aL = ref_begin, aR = T - ref_end - 1, bL = read_begin, bR = L - read_end - 1;
+            const int aL = ref_begin, aR = Tlen - ref_end - 1, bL = read_begin, bR = L - read_end - 1;
             const int hang = min(min(aR + bL, aL + bR), min(aL + aR, bL + bR));  // bam_parser.py:113-121
             const bool prefix_read = ref_begin < flank;                           // :139
-            const bool suffix_read = ref_end > T - flank - 1;                     // :140
+            const bool suffix_read = ref_end > Tlen - flank - 1;                  // :140
             int tag;
             if (hang >= flank) tag = TREDGPU_TAG_HANG;
             else if (prefix_read) tag = suffix_read ? TREDGPU_TAG_FULL : TREDGPU_TAG_PREF;
@@ -225,7 +290,7 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
                 const int k = max_units > 0 ? 2 * (u - 1) + s : 0;
                 if (k < a.dump_templates) {
                     int16_t* d = dump + k * 6;
-                    const bool hit = score > 0;
+                    const bool hit = score > 0 && bk != floor_key;
                     d[0] = (int16_t)(hit ? score : 0);
                     d[1] = (int16_t)(hit ? ref_begin : -1);
                     d[2] = (int16_t)(hit ? ref_end : -1);
@@ -234,6 +299,11 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
                     d[5] = (int16_t)tag;
                 }
             }
+            // back to the trunk
+#pragma unroll
+            for (int r = 0; r < R; ++r) { H[r] = Hs[r]; E[r] = Es[r]; }
+            T = Ts;
+            in_branch = false;
             next_branch += period;
             ++u;
         }

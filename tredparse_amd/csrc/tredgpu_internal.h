@@ -13,7 +13,7 @@ namespace tredgpu {
 struct LadderDesc {
     int32_t alen[2];       // trunk head length per strand (|prefix| / |suffix|)
     int32_t blen[2];       // branch length per strand     (|suffix| / |prefix|)
-    int32_t trunk_off[2];  // offsets into the sequence pool
+    int32_t trunk_off[2];  // WORD offsets into the letter pool (8 letters per 32-bit word)
     int32_t branch_off[2];
     int32_t period;
     int32_t max_units;
@@ -36,7 +36,7 @@ struct SwArgs {
     const int32_t* unit_read_off;
     const int32_t* unit_ladder;
     const LadderDesc* ladders;
-    const int8_t* seq;
+    const uint32_t* seqw;  // ladder letters, 8 per word (4 bits each)
     const Quad* quads;
     const int32_t* n_quads;  // device counter written by build_quads
     uint8_t* out_tag;
