@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
 
     // Only cells that can survive the score filter are tracked: min_score >= 30 (bam_parser.py:134), so a
     // floor of 29 is exact for tagging; the per-template dump (parity/debug) tracks every positive score.
-    const int floor_key = ((dump != nullptr || a.out_dump != nullptr) ? 0 : 29) << KSH | PAYMASK;
+    const bool full_dump = a.out_dump != nullptr;  // wave-uniform
+    const int floor_key = (full_dump ? 0 : 29) << KSH | PAYMASK;
 
     for (int s = 0; s < n_strands; ++s) {
         const int trunk_w = __builtin_amdgcn_readfirstlane(ld->trunk_off[s]);
@@ -247,13 +248,39 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
             } else {
                 ++tc;
                 if (col == next_branch) {
-                    // template u ends here on the trunk: park the trunk state, continue into its branch
+                    // Template u ends here on the trunk.  Exact pruning: no cell of its branch can score
+                    // more than max(trunk best, column max + |branch| * match); if that cannot reach the
+                    // score filter (bam_parser.py:134) or beat this read's current arg-max key
+                    // (score, -units) for ANY of the four reads, the branch is not swept at all.
+                    bool need = true;
+                    if (!full_dump && blen > 0) {
+                        int cmx = NEG;
+                        int scale = row0g + col * geK;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) { Hs[r] = H[r]; Es[r] = E[r]; }
-                    Ts = T;
-                    in_branch = true;
-                    b_left = blen; b_col = col + 1; b_idx = 0;
-                    emit = blen == 0;
+                        for (int r = 0; r < R; ++r) { cmx = max(cmx, H[r] - scale); scale += geK; }
+                        int bk0 = T.bestkey;
+                        cmx = max(cmx, dpp_row_shr<0x111>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x111>(bk0, bk0));
+                        cmx = max(cmx, dpp_row_shr<0x112>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x112>(bk0, bk0));
+                        cmx = max(cmx, dpp_row_shr<0x114>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x114>(bk0, bk0));
+                        cmx = max(cmx, dpp_row_shr<0x118>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x118>(bk0, bk0));
+                        const int bound = max(bk0 >> KSH, max(cmx >> KSH, 0) + blen * a.p.match);
+                        const int Tlen = alen + period * u + blen;
+                        const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
+                        const bool want = valid && jl == 15 && bound >= need_score;
+                        need = __builtin_amdgcn_ballot_w64(want) != 0;
+                    }
+                    if (need) {
+                        // park the trunk state, continue into the branch
+#pragma unroll
+                        for (int r = 0; r < R; ++r) { Hs[r] = H[r]; Es[r] = E[r]; }
+                        Ts = T;
+                        in_branch = true;
+                        b_left = blen; b_col = col + 1; b_idx = 0;
+                        emit = blen == 0;
+                    } else {
+                        next_branch += period;
+                        ++u;
+                    }
                 }
             }
             if (!emit) continue;
