@@ -228,7 +228,9 @@ def main():
                                  "frac": alg_bytes / sw_s / 1e9 / HBM_PEAK_GBS}},
             "kernels_ms_per_step": {"sw_ladder": sw_ms / max(sw_n, 1), "tally": ta_ms / max(ta_n, 1),
                                     "grid": gr_ms / max(gr_n, 1)},
-            "check": {"units_ok": ok, "units": g, "short_allele_exact_frac": short_ok},
+            "check": {"units_ok": ok, "units": g, "short_allele_exact_frac": short_ok,
+                      "mean_grid_pairs": float(calls["n_pairs"].mean()), "max_grid_pairs": int(calls["n_pairs"].max()),
+                      "run_pe_frac": float(calls["run_pe"].mean())},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, loci, args.cpu_budget)

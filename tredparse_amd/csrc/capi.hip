@@ -528,6 +528,7 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     if (n_units == 0) return 0;
     int rc;
     if ((rc = ensure(c, c->ws_grid, grid_scratch_bytes(n_units)))) return rc;
+    if ((rc = ensure(c, c->ws_counter, 64))) return rc;
     GridArgs a;
     a.units = units;
     a.n_units = n_units;
@@ -547,7 +548,7 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     a.kde_status = nullptr;
     {
         ScopedTimer tm(c, TREDGPU_KERNEL_GRID);
-        HIPCHK(c, launch_grid(a, (double*)c->ws_grid.p, c->stream));
+        HIPCHK(c, launch_grid(a, (double*)c->ws_grid.p, (int32_t*)c->ws_counter.p + 4, c->stream));
     }
     return 0;
 }

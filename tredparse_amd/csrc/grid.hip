@@ -21,8 +21,8 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int SPAN = TREDGPU_SPAN;
-constexpr int MAXOBS = GRID_MAX_ROWS;  // distinct FULL / PREF sizes per unit; also the row limit
-constexpr int MAXM = 1024;   // marginal bins (repeat units)
+constexpr int MAXOBS = 256;  // distinct FULL / PREF sizes per unit
+constexpr int MAXM = 768;    // marginal bins (repeat units)
 
 struct Axis {
     int nb;      // entries taken from the sorted base list
@@ -95,26 +95,31 @@ struct PairCtx {
     int n_target;
     int period, readlen, t1, t2, mp_eff, ref_len, minpe, n_rept;
     bool run_pe;
-    double half_depth, lgam_rept, small, really_small;
+    double half_depth, lgam_rept, small, really_small, logsmall;
 };
 
-__device__ void eval_pair(const PairCtx& C, int h1, int h2, double out[4]) {
+// log(max(p, SMALL_VALUE)) (safe_log, models.py:418-423); log(SMALL_VALUE) itself is evaluated once
+// per unit with the same device log, so clamped terms cost no transcendental.
+__device__ __forceinline__ double safe_log(const PairCtx& C, double p) {
+    if (p < C.small) return C.logsmall;
+    return log(p);
+}
+
+// spanning + partial terms (models.py:192-207)
+__device__ void eval_reads(const PairCtx& C, int h1, int h2, double& ml1, double& ml2) {
     const Obs& O = *C.obs;
-    // spanning reads, models.py:192-198
-    double ml1 = 0;
+    ml1 = 0;
     if (O.nF > 0) {
         const double pi1 = stutter_prob(*C.M, C.period, h1), pi2 = stutter_prob(*C.M, C.period, h2);
         const int s1 = max(0, C.t2 - h1), s2 = max(0, C.t2 - h2);
         const double alpha = (s1 + s2) ? s1 * 1. / (s1 + s2) : .5;
         for (int i = 0; i < O.nF; ++i) {
             const int k = O.fullK[i];
-            double p = alpha * spanning_at(C.step, pi1, h1, k) + (1 - alpha) * spanning_at(C.step, pi2, h2, k);
-            if (p < C.small) p = C.small;
-            ml1 += log(p) * O.fullC[i];
+            const double p = alpha * spanning_at(C.step, pi1, h1, k) + (1 - alpha) * spanning_at(C.step, pi2, h2, k);
+            ml1 += safe_log(C, p) * O.fullC[i];
         }
     }
-    // partial reads, models.py:200-207
-    double ml2 = 0;
+    ml2 = 0;
     if (O.nP > 0) {
         const int hp1 = min(h1, C.mp_eff), hp2 = min(h2, C.mp_eff);
         const double pi1 = stutter_prob(*C.M, C.period, hp1), pi2 = stutter_prob(*C.M, C.period, hp2);
@@ -122,32 +127,32 @@ __device__ void eval_pair(const PairCtx& C, int h1, int h2, double out[4]) {
         const double alpha = (s1 + s2) ? s1 * 1. / (s1 + s2) : .5;
         for (int i = 0; i < O.nP; ++i) {
             const int k = O.partK[i];
-            double p = alpha * partial_at(C.step, pi1, hp1, k) + (1 - alpha) * partial_at(C.step, pi2, hp2, k);
-            if (p < C.small) p = C.small;
-            ml2 += log(p) * O.partC[i];
+            const double p = alpha * partial_at(C.step, pi1, hp1, k) + (1 - alpha) * partial_at(C.step, pi2, hp2, k);
+            ml2 += safe_log(C, p) * O.partC[i];
         }
     }
-    // repeat-only reads, models.py:209-221 (scipy poisson.pmf = exp(xlogy(k,mu) - gammaln(k+1) - mu))
+}
+
+// repeat-only + paired-end terms (models.py:209-221, 460-473)
+__device__ void eval_rept_pe(const PairCtx& C, int h1, int h2, double& ml3, double& ml4) {
+    // scipy poisson.pmf = exp(xlogy(k,mu) - gammaln(k+1) - mu)
     const int d1 = max(h1 - C.readlen, 1), d2 = max(h2 - C.readlen, 1);
     const double mu = (d1 + d2) * C.half_depth / C.readlen;
     const double xl = C.n_rept == 0 ? 0.0 : C.n_rept * log(mu);
     double prob = exp(xl - C.lgam_rept - mu);
     if (!(prob > C.really_small)) prob = C.really_small;
-    const double ml3 = log(prob);
-    // paired-end distances, models.py:460-473
-    double ml4 = 0;
+    ml3 = log(prob);
+    ml4 = 0;
     if (C.run_pe) {
         for (int i = 0; i < C.n_target; ++i) {
             int x = C.tl[i];
             if (x < 0) x += SPAN;
             const double p1 = roll_at(C.pdf, C.ref_len, C.minpe, h1, x, C.small);
             const double p2 = roll_at(C.pdf, C.ref_len, C.minpe, h2, x, C.small);
-            double p = .5 * p1 + (1 - .5) * p2;
-            if (p < C.small) p = C.small;
-            ml4 += log(p);
+            const double p = .5 * p1 + (1 - .5) * p2;
+            ml4 += safe_log(C, p);
         }
     }
-    out[0] = ml1; out[1] = ml2; out[2] = ml3; out[3] = ml4;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -242,20 +247,26 @@ __device__ __forceinline__ bool better(const Best& x, const Best& y) {  // is x 
     return x.pos < y.pos;                   // python max keeps the first maximal element
 }
 
+constexpr int OBSMAX = MAXOBS;
+
 struct GridShared {
     Obs obs;
-    int hist[SPAN];     // KDE scratch
-    double kern[SPAN];  // KDE scratch
-    double pdf[SPAN];   // normalised KDE
+    union {
+        int hist[SPAN];               // KDE scratch / raw histograms while loading
+        int row_off[GRID_MAX_ROWS + 1];
+    };
+    double kern[SPAN];                // KDE scratch
+    double pdf[SPAN];                 // normalised KDE
+    double far1[GRID_MAX_ROWS], far2[GRID_MAX_ROWS];  // per-row ml1 / ml2 against any "far" h2
     double ph1[MAXM], ph2[MAXM];
     double red[NT / 64];
     Best bred[NT / 64];
-    int row_off[MAXOBS + 1];
     int flag;
     int status;
+    int unit;
 };
 
-__global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
+__global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, int* next_unit) {
     constexpr size_t scratch_per_block = (size_t)GRID_MAX_ROWS * GRID_MAX_COLS;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     GridShared& S = *reinterpret_cast<GridShared*>(smem_raw);
@@ -263,8 +274,13 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
     double* mlbuf = scratch + (size_t)blockIdx.x * scratch_per_block;
     const ModelConst& M = *a.model;
 
-    for (int g = blockIdx.x; g < a.n_units; g += gridDim.x) {
+    while (true) {
+        // dynamic unit scheduling: grids differ by three orders of magnitude in size
         __syncthreads();
+        if (tid == 0) S.unit = atomicAdd(next_unit, 1);
+        __syncthreads();
+        const int g = S.unit;
+        if (g >= a.n_units) break;
         const tredgpu_unit_params u = a.units[g];
         const int period = u.period, readlen = u.readlen;
         const int t1 = readlen - 9, t2 = readlen - 18, t3 = readlen - 27;  // models.py:114-116
@@ -274,20 +290,29 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
         call.run_pe = 0; call.pad = 0; call.lik = -1; call.pp = -1;
 
         // ---- observations (models.py:399-403): sparse lists in bp, ascending ----
+        const bool staged = 3 * a.hist_stride <= SPAN;
+        if (staged) {
+            for (int h = tid; h < a.hist_stride; h += NT) {
+                S.hist[h] = a.full_cnt[(size_t)g * a.hist_stride + h];
+                S.hist[a.hist_stride + h] = a.pref_cnt[(size_t)g * a.hist_stride + h];
+                S.hist[2 * a.hist_stride + h] = a.rept_cnt[(size_t)g * a.hist_stride + h];
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
             int nF = 0, nP = 0, rept = 0, st = 0;
-            const int32_t* fc = a.full_cnt + (size_t)g * a.hist_stride;
-            const int32_t* pc = a.pref_cnt + (size_t)g * a.hist_stride;
-            const int32_t* rc = a.rept_cnt + (size_t)g * a.hist_stride;
+            const int32_t* fc = staged ? S.hist : a.full_cnt + (size_t)g * a.hist_stride;
+            const int32_t* pc = staged ? S.hist + a.hist_stride : a.pref_cnt + (size_t)g * a.hist_stride;
+            const int32_t* rc = staged ? S.hist + 2 * a.hist_stride : a.rept_cnt + (size_t)g * a.hist_stride;
             for (int h = 0; h < a.hist_stride; ++h) {
-                if (fc[h] > 0) { if (nF < MAXOBS) { S.obs.fullK[nF] = h * period; S.obs.fullC[nF] = fc[h]; } ++nF; }
-                if (pc[h] > 0) { if (nP < MAXOBS) { S.obs.partK[nP] = h * period; S.obs.partC[nP] = pc[h]; } ++nP; }
+                if (fc[h] > 0) { if (nF < OBSMAX) { S.obs.fullK[nF] = h * period; S.obs.fullC[nF] = fc[h]; } ++nF; }
+                if (pc[h] > 0) { if (nP < OBSMAX) { S.obs.partK[nP] = h * period; S.obs.partC[nP] = pc[h]; } ++nP; }
                 rept += rc[h];
             }
-            if (nF > MAXOBS || nP > MAXOBS) st = -9;
+            if (nF > OBSMAX || nP > OBSMAX) st = -9;
             if (period < 1 || period >= 18) st = -7;  // step_size_by_period KeyError, models.py:157
-            S.obs.nF = min(nF, MAXOBS);
-            S.obs.nP = min(nP, MAXOBS);
+            S.obs.nF = min(nF, OBSMAX);
+            S.obs.nP = min(nP, OBSMAX);
             S.flag = rept;
             S.status = st;
         }
@@ -301,6 +326,7 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
             if (S.obs.partK[i] > max_full + period) reads_above_full += S.obs.partC[i];
         // observation sizes index the 1000-vectors (models.py:198,206): IndexError past the end
         if (status == 0 && (max_full >= SPAN || max_partial >= SPAN)) status = -3;
+        __syncthreads();  // S.hist is reused by the KDE below
 
         // ---- paired-end model (models.py:131-132, 428-439) ----
         const bool have_pe = u.n_global >= 100 && u.n_target >= 5;
@@ -382,14 +408,20 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
         C.half_depth = u.half_depth;
         C.lgam_rept = lgamma((double)n_rept + 1);
         C.small = M.small; C.really_small = M.really_small;
+        C.logsmall = log(M.small);
 
-        // ---- rows: count of valid h2 per h1 (h1 <= h2), dump offsets ----
+        // ---- rows: count of valid h2 per h1 (h1 <= h2), dump offsets; per-row "far" terms ----
+        // For h2 >= h_far the spanning and partial terms no longer depend on h2 (S(k|h2) = 0 for every
+        // observed size, alpha is pinned, pdf_partial is clipped at max_partial): bit-identical values,
+        // evaluated once per row instead of once per pair.
+        const int h_far = max(max(max_full + 19, mp_eff), t1);
         for (int i = tid; i < nrow; i += NT) {
             const int h1 = axis_value(ax1, S.obs.base, period, i);
             int cnt = 0;
             if (u.ploidy == 1) cnt = 1;
             else for (int j = 0; j < ncol; ++j) cnt += axis_value(ax2, S.obs.base, period, j) >= h1;
             S.row_off[i] = cnt;
+            eval_reads(C, h1, max(h_far, h1), S.far1[i], S.far2[i]);
         }
         __syncthreads();
         if (tid == 0) {
@@ -414,7 +446,9 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
             const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
             if (h1 > h2) { mlbuf[pos] = 0; continue; }
             double ml4[4];
-            eval_pair(C, h1, h2, ml4);
+            if (h2 >= h_far) { ml4[0] = S.far1[i]; ml4[1] = S.far2[i]; }
+            else eval_reads(C, h1, h2, ml4[0], ml4[1]);
+            eval_rept_pe(C, h1, h2, ml4[2], ml4[3]);
             const double ml = ml4[0] + ml4[1] + ml4[2] + ml4[3];  // models.py:269
             mlbuf[pos] = ml;
             Best b; b.ml = ml; b.h1 = h1; b.pos = pos;
@@ -439,67 +473,16 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
         Best top = S.bred[0];
         for (int w = 1; w < NT / 64; ++w) if (better(S.bred[w], top)) top = S.bred[w];
         const double max_ml = top.ml;
-        __threadfence_block();
-        __syncthreads();
 
-        // ---- pass B: marginals in the reference's enumeration order (models.py:277-285) ----
-        const int nm = min(MAXM, a.marg != nullptr ? a.marg_stride : MAXM);
-        for (int m = tid; m < MAXM; m += NT) { S.ph1[m] = 0; S.ph2[m] = 0; }
-        __syncthreads();
-        // P_h1: one thread per row (rows with equal h1 cannot occur twice on the h1 axis unless the
-        // axis is the extended one with duplicated base values; they are then merged below in row order)
-        for (int i = tid; i < nrow; i += NT) {
-            const int h1 = axis_value(ax1, S.obs.base, period, i);
-            double acc = 0;
-            for (int j = 0; j < ncol; ++j) {
-                const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
-                if (h1 > h2) continue;
-                acc += exp(mlbuf[i * ncol + j] - max_ml);
-            }
-            S.kern[i] = acc;  // row sums (kern is free after the KDE)
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 0; i < nrow; ++i) {
-                const int m = axis_value(ax1, S.obs.base, period, i) / period;
-                if (m < MAXM) S.ph1[m] += S.kern[i];
-            }
-        }
-        // P_h2: one thread per distinct h2 value, rows outermost as in the reference
-        for (int j = tid; j < ncol; j += NT) {
-            if (u.ploidy == 1) break;
-            const int h2 = axis_value(ax2, S.obs.base, period, j);
-            // the extended axis can list a value twice (once in the base part, once in the arithmetic
-            // part, models.py:251-252); the first occurrence owns the sum
-            int twin = -1;
-            bool owner = true;
-            for (int jj = 0; jj < ncol; ++jj) {
-                if (jj == j) continue;
-                if (axis_value(ax2, S.obs.base, period, jj) == h2) { if (jj < j) owner = false; else twin = jj; }
-            }
-            if (!owner) continue;
-            double acc = 0;
-            for (int i = 0; i < nrow; ++i) {
-                const int h1 = axis_value(ax1, S.obs.base, period, i);
-                if (h1 > h2) continue;
-                acc += exp(mlbuf[i * ncol + j] - max_ml);
-                if (twin >= 0) acc += exp(mlbuf[i * ncol + twin] - max_ml);
-            }
-            const int m = h2 / period;
-            if (m < MAXM) S.ph2[m] = acc;
-        }
-        if (u.ploidy == 1) {
-            __syncthreads();
-            for (int m = tid; m < MAXM; m += NT) S.ph2[m] = S.ph1[m];  // h2 == h1 for every pair
-        }
-        // PP sums (models.py:342-368)
+        // ---- pass B: exp(ml - max) once per pair (models.py:280-285) + the PP sums (:342-368) ----
         double all = 0, path = 0;
         for (int pos = tid; pos < rect; pos += NT) {
             const int i = pos / ncol, j = pos - i * ncol;
             const int h1 = axis_value(ax1, S.obs.base, period, i);
             const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
-            if (h1 > h2) continue;
+            if (h1 > h2) continue;   // mlbuf[pos] stays 0: contributes nothing to the sums below
             const double e = exp(mlbuf[pos] - max_ml);
+            mlbuf[pos] = e;
             all += e;
             const int lo = h1 / period, hi = h2 / period;
             bool p;
@@ -509,18 +492,66 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
         }
         all = block_sum(all, S.red);
         path = block_sum(path, S.red);
+        const int last1 = axis_value(ax1, S.obs.base, period, nrow - 1), last2 = u.ploidy == 1 ? last1 : axis_value(ax2, S.obs.base, period, ncol - 1);
+        int hmaxv = max(last1, last2);
+        if (nb > 0) hmaxv = max(hmaxv, S.obs.base[nb - 1]);
+        const int mlim = min(MAXM, hmaxv / period + 1);
+        for (int m = tid; m < mlim; m += NT) { S.ph1[m] = 0; S.ph2[m] = 0; }
+        __syncthreads();  // also orders the mlbuf writes above before the reads below
+        // marginal P_h1: one wave per row (fixed shuffle tree), rows merged by key in row order
+        for (int i = tid >> 6; i < nrow; i += NT / 64) {
+            double acc = 0;
+            for (int j = tid & 63; j < ncol; j += 64) acc += mlbuf[i * ncol + j];
+            acc = wave_sum(acc);
+            if ((tid & 63) == 0) S.far1[i] = acc;  // far1 is free now: row sums
+        }
         __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < nrow; ++i) {
+                const int m = axis_value(ax1, S.obs.base, period, i) / period;
+                if (m < MAXM) S.ph1[m] += S.far1[i];
+            }
+        }
+        // marginal P_h2: one thread per distinct h2 value, rows outermost as in the reference.  The
+        // extended axis can list a value twice (base part + arithmetic part, models.py:251-252): the
+        // first occurrence owns the sum.
+        if (u.ploidy != 1) {
+            for (int j = tid; j < ncol; j += NT) {
+                const int h2 = axis_value(ax2, S.obs.base, period, j);
+                int twin = -1;
+                if (j < ax2.nb) {
+                    const int d = h2 - ax2.start;
+                    if (ax2.n > 0 && d >= 0 && d % period == 0 && d / period < ax2.n) twin = ax2.nb + d / period;
+                } else {
+                    bool dup = false;
+                    for (int k = 0; k < ax2.nb; ++k) dup |= S.obs.base[k] == h2;
+                    if (dup) continue;  // owned by the base occurrence
+                }
+                double acc = 0;
+                for (int i = 0; i < nrow; ++i) {
+                    acc += mlbuf[i * ncol + j];
+                    if (twin >= 0) acc += mlbuf[i * ncol + twin];
+                }
+                const int m = h2 / period;
+                if (m < MAXM) S.ph2[m] = acc;
+            }
+        }
+        __syncthreads();
+        if (u.ploidy == 1) {
+            for (int m = tid; m < mlim; m += NT) S.ph2[m] = S.ph1[m];  // h2 == h1 for every pair
+            __syncthreads();
+        }
 
         if (tid == 0) {
             // calc_CI, models.py:319-340 on each marginal
             for (int which = 0; which < 2; ++which) {
                 const double* P = which ? S.ph2 : S.ph1;
                 double total = 0;
-                for (int m = 0; m < MAXM; ++m) total += P[m];
+                for (int m = 0; m < mlim; ++m) total += P[m];
                 double cum = 0;
                 int lo = 0, hi = 0, last = 0;
                 bool in_range = false, broke = false;
-                for (int m = 0; m < MAXM && !broke; ++m) {
+                for (int m = 0; m < mlim && !broke; ++m) {
                     if (P[m] == 0) continue;
                     last = m;
                     cum += P[m];
@@ -544,8 +575,8 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch) {
         }
         if (a.marg != nullptr) {
             for (int m = tid; m < a.marg_stride; m += NT) {
-                a.marg[((size_t)g * 2 + 0) * a.marg_stride + m] = m < nm ? S.ph1[m] : 0;
-                a.marg[((size_t)g * 2 + 1) * a.marg_stride + m] = m < nm ? S.ph2[m] : 0;
+                a.marg[((size_t)g * 2 + 0) * a.marg_stride + m] = m < mlim ? S.ph1[m] : 0;
+                a.marg[((size_t)g * 2 + 1) * a.marg_stride + m] = m < mlim ? S.ph2[m] : 0;
             }
         }
     }
@@ -559,13 +590,15 @@ hipError_t launch_pe_kde(const GridArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_grid(const GridArgs& a, double* scratch, hipStream_t s) {
+hipError_t launch_grid(const GridArgs& a, double* scratch, int* next_unit, hipStream_t s) {
     if (a.n_units <= 0) return hipSuccess;
+    hipError_t e0 = hipMemsetAsync(next_unit, 0, sizeof(int), s);
+    if (e0 != hipSuccess) return e0;
     const int blocks = a.n_units < GRID_MAX_BLOCKS ? a.n_units : GRID_MAX_BLOCKS;
     const size_t smem = sizeof(GridShared);
     hipError_t e = hipFuncSetAttribute((const void*)grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    grid_kernel<<<blocks, NT, smem, s>>>(a, scratch);
+    grid_kernel<<<blocks, NT, smem, s>>>(a, scratch, next_unit);
     return hipGetLastError();
 }
 

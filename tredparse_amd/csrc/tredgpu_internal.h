@@ -86,12 +86,12 @@ struct GridArgs {
 };
 constexpr int GRID_MAX_ROWS = 512;   // |h1range| a workgroup can hold
 constexpr int GRID_MAX_COLS = 1024;  // |h2range|
-constexpr int GRID_MAX_BLOCKS = 512;
+constexpr int GRID_MAX_BLOCKS = 1024;
 inline size_t grid_scratch_bytes(int n_units) {
     const size_t blocks = n_units < GRID_MAX_BLOCKS ? n_units : GRID_MAX_BLOCKS;
     return blocks * (size_t)GRID_MAX_ROWS * GRID_MAX_COLS * sizeof(double);
 }
 hipError_t launch_pe_kde(const GridArgs& a, hipStream_t s);
-hipError_t launch_grid(const GridArgs& a, double* scratch, hipStream_t s);
+hipError_t launch_grid(const GridArgs& a, double* scratch, int* next_unit, hipStream_t s);
 
 }  // namespace tredgpu
