@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,7 +37,7 @@ struct tredgpu_ctx {
     Buf d_model;
     bool have_model = false;
     // workspaces (grow-only, reused across calls)
-    Buf ws_quads, ws_counter, ws_drop, ws_grid;
+    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats;
     Buf st[24];  // staging for HOST-memory calls
     // intermediates of the fused path
     Buf ws_tag, ws_h, ws_score;
@@ -221,7 +222,7 @@ void tredgpu_destroy(tredgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (Buf* b : {&c->d_ladders, &c->d_seq, &c->d_model, &c->ws_quads, &c->ws_counter, &c->ws_drop,
-                   &c->ws_grid, &c->ws_tag, &c->ws_h, &c->ws_score})
+                   &c->ws_grid, &c->ws_stats, &c->ws_tag, &c->ws_h, &c->ws_score})
         release(*b);
     for (Buf& b : c->st) release(b);
     for (auto& t : c->timers)
@@ -406,9 +407,23 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     a.dump_templates = dump_templates;
     a.n_units = n_units;
     a.p = *p;
+    a.stats = nullptr;
+    static const bool want_stats = getenv("TREDGPU_SW_STATS") != nullptr;
+    if (want_stats) {
+        if ((rc = ensure(c, c->ws_stats, 8 * sizeof(unsigned long long)))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
+        a.stats = (unsigned long long*)c->ws_stats.p;
+    }
     {
         ScopedTimer tm(c, TREDGPU_KERNEL_SW);
         HIPCHK(c, launch_sw_ladder(a, rows_for(max_len), max_quads, c->stream));
+    }
+    if (want_stats) {
+        unsigned long long h[8];
+        HIPCHK(c, hipMemcpyAsync(h, c->ws_stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        fprintf(stderr, "[tredgpu sw stats] quads<=%lld trunk_cols=%llu branch_cols=%llu branches_run=%llu branches_skipped=%llu\n",
+                (long long)max_quads, h[0], h[1], h[2], h[3]);
     }
     return 0;
 }

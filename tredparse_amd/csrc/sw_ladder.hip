@@ -85,6 +85,23 @@ struct Track {
     int ceil;       // bestkey | PAYMASK: what a cell must exceed to be a new best
 };
 
+// inclusive max scan over the 16 lanes of a DPP row fused with the exclusive shift, as one asm block:
+// v_max_i32_dpp reads its own and the neighbour's value (lanes without a source are disabled and keep
+// theirs); s_nop 1 covers the VALU-write -> DPP-read hazard.  in: x = lane value; out: fin = max over
+// the lanes above (NEG for the first lane of the row).
+__device__ __forceinline__ int row_excl_scan_max(int x) {
+    int fin = NEG;
+    asm volatile(
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x), "+v"(fin));
+    return fin;
+}
+
 // One DP column for all rows of the four alignments in this wave; LET = template letter (4 = N).
 //   s_fresh = (col<<9) + col*geK - 2*geK   (wave-uniform)      s_scale = col*geK
 template <int R, int LET>
@@ -100,40 +117,50 @@ __device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int 
         int S;
         if (LET < 4) S = J.S[LET][r];
         else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;  // N column: 0 against every real row
-        const int t1 = diag + S;                      // extend the alignment ending at (row-1, col-1)
-        const int t2 = add3_vsv(J.rowc[r], s_fresh, S);  // or start a new one here
+        const int t1 = diag + S;                          // extend the alignment ending at (row-1, col-1)
+        const int t2 = add3_vsv(J.rowc[r], s_fresh, S);   // or start a new one here
         const int v = max3(t1, t2, E[r]);
         diag = H[r];
         ht[r] = v;
-        pl[r] = run;                                  // F~ from this lane's rows above
-        run = max(run, v - c0);
+        pl[r] = run;                                      // F~ from this lane's rows above
+        const int q = v - c0;
+        run = max(run, q);
+        // E~ for the next column.  Fed from H without the vertical-gap term: a vertical gap followed by
+        // a horizontal one has an equal-score twin (horizontal, then vertical) with the same end points
+        // that the F recurrence does admit, so nothing is lost (ssw.c:238 makes the same choice).
+        E[r] = max(E[r], q);
     }
     // exclusive max scan across the 16 lanes: F~ entering this lane from the lanes above
-    const int p = row_scan_max(run);
-    const int fin = dpp_row_shr<0x111>(NEG, p);
+    const int fin = row_excl_scan_max(run);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int h = max3(ht[r], pl[r], fin);
-        H[r] = h;
-        E[r] = max(E[r], h - c0);
-    }
+    for (int r = 0; r < R; ++r) H[r] = max3(ht[r], pl[r], fin);
     // running best: only columns in which some lane could beat its best take the exact path.
     // run + c0 = max over this lane's rows of H~ without the vertical-gap term (a best cell never ends
     // in a gap); minus (row0 + col)*geK it over-estimates every row's true value by <= (R-1)*geK.
-    const bool trig = run + c0 - (row0g + s_scale) > T.ceil;
+    const int lane_scale = row0g + s_scale;
+    const bool trig = run + c0 - lane_scale > T.ceil;
     if (__builtin_amdgcn_ballot_w64(trig) != 0) {
-        const int revcol = (511 - col) << 9;
-        int scale = row0g + s_scale;
+        // exact lane maximum of score<<18 | (R-1-r): the row part is a compile-time constant per row
+        int tr[R];
+        int m = NEG;
+        int rs = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int tr = H[r] - scale;  // true packed value
-            scale += geK;
-            const int cand = (tr & ~PAYMASK) | revcol | (511 - (row0 + r));
-            const bool c = cand > T.bestkey;
-            T.bestkey = c ? cand : T.bestkey;
-            T.beststart = c ? tr : T.beststart;
+            tr[r] = H[r] - rs;  // still carries the lane's scale, a multiple of K
+            rs += geK;
+            m = max(m, (tr[r] & ~PAYMASK) | (R - 1 - r));
         }
-        T.ceil = T.bestkey | PAYMASK;
+        // -> score<<18 | (511-col)<<9 | (511-row)
+        const int cand = m - lane_scale + (((511 - col) << 9) + (511 - (R - 1)) - row0);
+        const bool imp = cand > T.bestkey;
+        if (__builtin_amdgcn_ballot_w64(imp) != 0) {
+            int st = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) st = ((tr[r] & ~PAYMASK) | (R - 1 - r)) == m ? tr[r] : st;
+            T.bestkey = imp ? cand : T.bestkey;
+            T.beststart = imp ? st - lane_scale : T.beststart;
+            T.ceil = T.bestkey | PAYMASK;
+        }
     }
 }
 
@@ -157,8 +184,11 @@ __device__ __forceinline__ int letter_at(const uint32_t* seqw, int word_off, int
     return (int)((w >> ((c & 7) * 4)) & 7u);
 }
 
-template <int R>
-__global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
+template <int R, int W>
+__global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
+    // trunk state parked while a branch is swept: [2R+3][256] ints, one column per thread (conflict-free)
+    __shared__ int park[(2 * R + 3) * 256];
+    int* const mypark = park + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -224,12 +254,11 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
         const int alen = __builtin_amdgcn_readfirstlane(ld->alen[s]);
         const int blen = __builtin_amdgcn_readfirstlane(ld->blen[s]);
         const int ncols = alen + period * max_units;
-        int H[R], E[R], Hs[R], Es[R];
+        int H[R], E[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; Hs[r] = NEG; Es[r] = NEG; }
-        Track T, Ts;
+        for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+        Track T;
         T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
-        Ts = T;
         int next_branch = max_units > 0 ? alen + period - 1 : alen - 1;
         int u = max_units > 0 ? 1 : 0;
         // One sweep site for trunk and branch columns: tc = next trunk column, bk_left = branch columns
@@ -241,6 +270,7 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
             if (in_branch) { letter = letter_at(a.seqw, branch_w, b_idx); col = b_col; }
             else { letter = letter_at(a.seqw, trunk_w, tc); col = tc; }
             sweep_letter<R>(letter, J, H, E, T, col, row0, geK, c0, row0g);
+            if (a.stats != nullptr && lane == 0) atomicAdd(a.stats + (in_branch ? 1 : 0), 1ull);
             bool emit = false;
             if (in_branch) {
                 ++b_idx; ++b_col; --b_left;
@@ -269,11 +299,14 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
                         const bool want = valid && jl == 15 && bound >= need_score;
                         need = __builtin_amdgcn_ballot_w64(want) != 0;
                     }
+                    if (a.stats != nullptr && lane == 0) atomicAdd(a.stats + (need ? 2 : 3), 1ull);
                     if (need) {
                         // park the trunk state, continue into the branch
 #pragma unroll
-                        for (int r = 0; r < R; ++r) { Hs[r] = H[r]; Es[r] = E[r]; }
-                        Ts = T;
+                        for (int r = 0; r < R; ++r) { mypark[r * 256] = H[r]; mypark[(R + r) * 256] = E[r]; }
+                        mypark[(2 * R) * 256] = T.bestkey;
+                        mypark[(2 * R + 1) * 256] = T.beststart;
+                        mypark[(2 * R + 2) * 256] = T.ceil;
                         in_branch = true;
                         b_left = blen; b_col = col + 1; b_idx = 0;
                         emit = blen == 0;
@@ -328,8 +361,10 @@ __global__ __launch_bounds__(256) void sw_ladder_kernel(SwArgs a) {
             }
             // back to the trunk
 #pragma unroll
-            for (int r = 0; r < R; ++r) { H[r] = Hs[r]; E[r] = Es[r]; }
-            T = Ts;
+            for (int r = 0; r < R; ++r) { H[r] = mypark[r * 256]; E[r] = mypark[(R + r) * 256]; }
+            T.bestkey = mypark[(2 * R) * 256];
+            T.beststart = mypark[(2 * R + 1) * 256];
+            T.ceil = mypark[(2 * R + 2) * 256];
             in_branch = false;
             next_branch += period;
             ++u;
@@ -411,10 +446,14 @@ hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quad
     if (max_quads <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((max_quads + 3) / 4);
     switch (rows_per_lane) {
-        case 4: sw_ladder_kernel<4><<<blocks, 256, 0, s>>>(a); break;
-        case 7: sw_ladder_kernel<7><<<blocks, 256, 0, s>>>(a); break;
-        case 10: sw_ladder_kernel<10><<<blocks, 256, 0, s>>>(a); break;
-        case 16: sw_ladder_kernel<16><<<blocks, 256, 0, s>>>(a); break;
+#ifndef SW_W10
+#define SW_W10 4
+#endif
+        // second parameter = waves per SIMD the register allocation is held to
+        case 4: sw_ladder_kernel<4, 6><<<blocks, 256, 0, s>>>(a); break;
+        case 7: sw_ladder_kernel<7, 4><<<blocks, 256, 0, s>>>(a); break;
+        case 10: sw_ladder_kernel<10, SW_W10><<<blocks, 256, 0, s>>>(a); break;
+        case 16: sw_ladder_kernel<16, 2><<<blocks, 256, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -46,6 +46,7 @@ struct SwArgs {
     int32_t dump_templates;
     int32_t n_units;
     tredgpu_sw_params p;
+    unsigned long long* stats;  // optional debug counters (TREDGPU_SW_STATS=1), else nullptr
 };
 
 // sw_ladder.hip
