@@ -133,26 +133,41 @@ __device__ void eval_reads(const PairCtx& C, int h1, int h2, double& ml1, double
     }
 }
 
-// repeat-only + paired-end terms (models.py:209-221, 460-473)
-__device__ void eval_rept_pe(const PairCtx& C, int h1, int h2, double& ml3, double& ml4) {
-    // scipy poisson.pmf = exp(xlogy(k,mu) - gammaln(k+1) - mu)
-    const int d1 = max(h1 - C.readlen, 1), d2 = max(h2 - C.readlen, 1);
-    const double mu = (d1 + d2) * C.half_depth / C.readlen;
+// repeat-only term (models.py:209-221); a function of dsum = max(h1-L,1) + max(h2-L,1) only.
+// scipy poisson.pmf = exp(xlogy(k,mu) - gammaln(k+1) - mu)
+__device__ double rept_term(const PairCtx& C, int dsum) {
+    const double mu = dsum * C.half_depth / C.readlen;
     const double xl = C.n_rept == 0 ? 0.0 : C.n_rept * log(mu);
     double prob = exp(xl - C.lgam_rept - mu);
     if (!(prob > C.really_small)) prob = C.really_small;
-    ml3 = log(prob);
-    ml4 = 0;
-    if (C.run_pe) {
-        for (int i = 0; i < C.n_target; ++i) {
+    return log(prob);
+}
+
+// paired-end term (models.py:460-473).  r1/r2: roll(h1)[x_t], roll(h2)[x_t] for the unit's spanning
+// pairs, either from the per-axis tables or evaluated on the fly (same expression, same bits).
+// Sum of log(max(p, SMALL)) evaluated as the log of a running product that is flushed before it can
+// leave the normal range (every factor is in [e^-10, 1], so 32 factors stay above e^-320): one log per
+// 32 pairs.  Differs from the reference's term-by-term sum by O(1e-14), far inside the 1e-6 contract.
+template <bool TABLES>
+__device__ double pe_term(const PairCtx& C, int h1, int h2, const double* r1, const double* r2) {
+    double ml4 = 0, prod = 1.0;
+    int k = 0;
+    for (int i = 0; i < C.n_target; ++i) {
+        double p1, p2;
+        if (TABLES) { p1 = r1[i]; p2 = r2[i]; }
+        else {
             int x = C.tl[i];
             if (x < 0) x += SPAN;
-            const double p1 = roll_at(C.pdf, C.ref_len, C.minpe, h1, x, C.small);
-            const double p2 = roll_at(C.pdf, C.ref_len, C.minpe, h2, x, C.small);
-            const double p = .5 * p1 + (1 - .5) * p2;
-            ml4 += safe_log(C, p);
+            p1 = roll_at(C.pdf, C.ref_len, C.minpe, h1, x, C.small);
+            p2 = roll_at(C.pdf, C.ref_len, C.minpe, h2, x, C.small);
         }
+        double p = .5 * p1 + (1 - .5) * p2;
+        if (p < C.small) p = C.small;
+        prod *= p;
+        if (++k == 32) { ml4 += log(prod); prod = 1.0; k = 0; }
     }
+    if (k) ml4 += log(prod);
+    return ml4;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -267,11 +282,15 @@ struct GridShared {
 };
 
 __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, int* next_unit) {
-    constexpr size_t scratch_per_block = (size_t)GRID_MAX_ROWS * GRID_MAX_COLS;
+    constexpr size_t scratch_per_block = GRID_SCRATCH_DOUBLES;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     GridShared& S = *reinterpret_cast<GridShared*>(smem_raw);
     const int tid = threadIdx.x;
-    double* mlbuf = scratch + (size_t)blockIdx.x * scratch_per_block;
+    // per-workgroup scratch (global, L2-resident): [rept table][roll table rows][roll table cols][ml grid]
+    double* const rept_tab = scratch + (size_t)blockIdx.x * scratch_per_block;
+    double* const roll1 = rept_tab + GRID_REPT_TAB;
+    double* const roll2 = roll1 + (size_t)GRID_MAX_ROWS * GRID_TMAX;
+    double* const mlbuf = roll2 + (size_t)GRID_MAX_COLS * GRID_TMAX;
     const ModelConst& M = *a.model;
 
     while (true) {
@@ -437,28 +456,67 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
             if (n_pairs <= cap) dump_base = a.grid_off[g];
         }
 
+        // ---- tables for big grids: the repeat-only term depends on dsum only, the paired-end term on
+        //      roll(h)[x_t] per axis value; both are filled with the very expressions the direct path uses
+        const int rect = nrow * ncol;
+        const int last1 = axis_value(ax1, S.obs.base, period, nrow - 1);
+        const int last2 = u.ploidy == 1 ? last1 : axis_value(ax2, S.obs.base, period, ncol - 1);
+        int hmaxv = max(last1, last2);
+        if (nb > 0) hmaxv = max(hmaxv, S.obs.base[nb - 1]);
+        const int dmax = 2 * max(hmaxv - readlen, 1);
+        const bool use_rept_tab = rect >= 1024 && dmax < GRID_REPT_TAB;
+        const bool use_roll_tab = run_pe && rect >= 1024 && u.n_target <= GRID_TMAX;
+        if (use_rept_tab)
+            for (int d = 2 + tid; d <= dmax; d += NT) rept_tab[d] = rept_term(C, d);
+        if (use_roll_tab) {
+            const int nt = u.n_target;
+            for (int k = tid; k < (nrow + ncol) * nt; k += NT) {
+                const bool isrow = k < nrow * nt;
+                const int kk = isrow ? k : k - nrow * nt;
+                const int ai = kk / nt, t = kk - ai * nt;
+                const int h = isrow ? axis_value(ax1, S.obs.base, period, ai)
+                                    : (u.ploidy == 1 ? 0 : axis_value(ax2, S.obs.base, period, ai));
+                int x = C.tl[t];
+                if (x < 0) x += SPAN;
+                (isrow ? roll1 : roll2)[(size_t)ai * nt + t] = roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);
+            }
+        }
+        __syncthreads();
+
         // ---- pass A: log-likelihood of every pair, arg-max ----
         Best mine; mine.ml = 0; mine.h1 = 0; mine.pos = -1;
-        const int rect = nrow * ncol;
-        for (int pos = tid; pos < rect; pos += NT) {
-            const int i = pos / ncol, j = pos - i * ncol;
-            const int h1 = axis_value(ax1, S.obs.base, period, i);
-            const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
-            if (h1 > h2) { mlbuf[pos] = 0; continue; }
-            double ml4[4];
-            if (h2 >= h_far) { ml4[0] = S.far1[i]; ml4[1] = S.far2[i]; }
-            else eval_reads(C, h1, h2, ml4[0], ml4[1]);
-            eval_rept_pe(C, h1, h2, ml4[2], ml4[3]);
-            const double ml = ml4[0] + ml4[1] + ml4[2] + ml4[3];  // models.py:269
-            mlbuf[pos] = ml;
-            Best b; b.ml = ml; b.h1 = h1; b.pos = pos;
-            if (better(b, mine)) mine = b;
-            if (dump_base >= 0) {
-                int within = 0;  // valid columns before j in this row
-                if (u.ploidy != 1)
-                    for (int jj = 0; jj < j; ++jj) within += axis_value(ax2, S.obs.base, period, jj) >= h1;
-                double* d = a.grid_dump + (dump_base + S.row_off[i] + within) * 6;
-                d[0] = h1; d[1] = h2; d[2] = ml4[0]; d[3] = ml4[1]; d[4] = ml4[2]; d[5] = ml4[3];
+        {
+            int i = tid / ncol, j = tid - i * ncol;   // (row, column) of pos, advanced incrementally
+            for (int pos = tid; pos < rect; pos += NT) {
+                const int h1 = axis_value(ax1, S.obs.base, period, i);
+                const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
+                if (h1 > h2) mlbuf[pos] = 0;
+                else {
+                    double ml4[4];
+                    if (h2 >= h_far) { ml4[0] = S.far1[i]; ml4[1] = S.far2[i]; }
+                    else eval_reads(C, h1, h2, ml4[0], ml4[1]);
+                    const int dsum = max(h1 - readlen, 1) + max(h2 - readlen, 1);
+                    ml4[2] = use_rept_tab ? rept_tab[dsum] : rept_term(C, dsum);
+                    ml4[3] = 0;
+                    if (run_pe) {
+                        if (use_roll_tab && u.ploidy != 1)
+                            ml4[3] = pe_term<true>(C, h1, h2, roll1 + (size_t)i * u.n_target, roll2 + (size_t)j * u.n_target);
+                        else ml4[3] = pe_term<false>(C, h1, h2, nullptr, nullptr);
+                    }
+                    const double ml = ml4[0] + ml4[1] + ml4[2] + ml4[3];  // models.py:269
+                    mlbuf[pos] = ml;
+                    Best b; b.ml = ml; b.h1 = h1; b.pos = pos;
+                    if (better(b, mine)) mine = b;
+                    if (dump_base >= 0) {
+                        int within = 0;  // valid columns before j in this row
+                        if (u.ploidy != 1)
+                            for (int jj = 0; jj < j; ++jj) within += axis_value(ax2, S.obs.base, period, jj) >= h1;
+                        double* d = a.grid_dump + (dump_base + S.row_off[i] + within) * 6;
+                        d[0] = h1; d[1] = h2; d[2] = ml4[0]; d[3] = ml4[1]; d[4] = ml4[2]; d[5] = ml4[3];
+                    }
+                }
+                j += NT;
+                while (j >= ncol) { j -= ncol; ++i; }
             }
         }
         for (int o = 32; o > 0; o >>= 1) {
@@ -476,25 +534,27 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
 
         // ---- pass B: exp(ml - max) once per pair (models.py:280-285) + the PP sums (:342-368) ----
         double all = 0, path = 0;
-        for (int pos = tid; pos < rect; pos += NT) {
-            const int i = pos / ncol, j = pos - i * ncol;
-            const int h1 = axis_value(ax1, S.obs.base, period, i);
-            const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
-            if (h1 > h2) continue;   // mlbuf[pos] stays 0: contributes nothing to the sums below
-            const double e = exp(mlbuf[pos] - max_ml);
-            mlbuf[pos] = e;
-            all += e;
-            const int lo = h1 / period, hi = h2 / period;
-            bool p;
-            if (u.is_expansion) p = (u.is_recessive ? lo : hi) >= u.cutoff_risk;
-            else p = (u.is_recessive ? hi : lo) <= u.cutoff_risk;
-            if (p) path += e;
+        {
+            int i = tid / ncol, j = tid - i * ncol;
+            for (int pos = tid; pos < rect; pos += NT) {
+                const int h1 = axis_value(ax1, S.obs.base, period, i);
+                const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
+                if (h1 <= h2) {   // else mlbuf[pos] stays 0: contributes nothing to the sums below
+                    const double e = exp(mlbuf[pos] - max_ml);
+                    mlbuf[pos] = e;
+                    all += e;
+                    const int lo = h1 / period, hi = h2 / period;
+                    bool p;
+                    if (u.is_expansion) p = (u.is_recessive ? lo : hi) >= u.cutoff_risk;
+                    else p = (u.is_recessive ? hi : lo) <= u.cutoff_risk;
+                    if (p) path += e;
+                }
+                j += NT;
+                while (j >= ncol) { j -= ncol; ++i; }
+            }
         }
         all = block_sum(all, S.red);
         path = block_sum(path, S.red);
-        const int last1 = axis_value(ax1, S.obs.base, period, nrow - 1), last2 = u.ploidy == 1 ? last1 : axis_value(ax2, S.obs.base, period, ncol - 1);
-        int hmaxv = max(last1, last2);
-        if (nb > 0) hmaxv = max(hmaxv, S.obs.base[nb - 1]);
         const int mlim = min(MAXM, hmaxv / period + 1);
         for (int m = tid; m < mlim; m += NT) { S.ph1[m] = 0; S.ph2[m] = 0; }
         __syncthreads();  // also orders the mlbuf writes above before the reads below

@@ -178,10 +178,12 @@ __device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (
     }
 }
 
-// letters are packed 8 per 32-bit word (4 bits each) so that they are fetched with scalar loads
-__device__ __forceinline__ int letter_at(const uint32_t* seqw, int word_off, int c) {
-    const uint32_t w = seqw[word_off + (c >> 3)];
-    return (int)((w >> ((c & 7) * 4)) & 7u);
+// Letters are packed 8 per 32-bit word (4 bits each).  A strand's trunk (<= 64 words) and branch words
+// are loaded once into one VGPR each, word k in lane k, and fetched per column with v_readlane (no
+// memory access in the column loop).
+__device__ __forceinline__ int letter_from(int words_vgpr, int idx) {
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(words_vgpr, idx >> 3);
+    return (int)((w >> ((idx & 7) * 4)) & 7u);
 }
 
 template <int R, int W>
@@ -254,6 +256,8 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
         const int alen = __builtin_amdgcn_readfirstlane(ld->alen[s]);
         const int blen = __builtin_amdgcn_readfirstlane(ld->blen[s]);
         const int ncols = alen + period * max_units;
+        const int tw = lane < ((ncols + 7) >> 3) ? (int)a.seqw[trunk_w + lane] : 0;
+        const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
         int H[R], E[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
         bool in_branch = false;
         while (tc < ncols || in_branch) {
             int letter, col;
-            if (in_branch) { letter = letter_at(a.seqw, branch_w, b_idx); col = b_col; }
-            else { letter = letter_at(a.seqw, trunk_w, tc); col = tc; }
+            if (in_branch) { letter = letter_from(bw, b_idx); col = b_col; }
+            else { letter = letter_from(tw, tc); col = tc; }
             sweep_letter<R>(letter, J, H, E, T, col, row0, geK, c0, row0g);
             if (a.stats != nullptr && lane == 0) atomicAdd(a.stats + (in_branch ? 1 : 0), 1ull);
             bool emit = false;
