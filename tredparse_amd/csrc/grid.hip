@@ -203,7 +203,7 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, do
         s += (double)v;
     }
     const double total = block_sum(s, red);
-    if (*flag) return -6;
+    if (*flag || n >= 65536) return -6;
     if (n < 2) return -2;
     const double mean = total / n;
     double q = 0;
@@ -223,12 +223,30 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, do
         kern[d] = exp(-(r * r) / 2) * norm;
     }
     __syncthreads();
+    // compact the non-empty bins in place (ascending v, as the dense walk would visit them):
+    // hist[k] = v<<16 | count for k < nnz.  One wave, ballot + prefix popcount, 64 bins per step.
+    if (tid < 64) {
+        int nnz = 0;
+        for (int base = 0; base < SPAN; base += 64) {
+            const int v = base + tid;
+            const int c = v < SPAN ? hist[v] : 0;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(c > 0);
+            const int before = __builtin_popcountll(mask & ((1ull << tid) - 1ull));
+            // all reads of this 64-bin group happened above; writes go to indices <= base + tid
+            if (c > 0) hist[nnz + before] = (v << 16) | c;
+            nnz += __builtin_popcountll(mask);
+        }
+        if (tid == 0) *flag = nnz;
+    }
+    __syncthreads();
+    const int nnz = *flag;
     double part = 0;
     for (int x = tid; x < SPAN; x += NT) {
         double acc = 0;
-        for (int v = 0; v < SPAN; ++v) {
-            const int c = hist[v];
-            if (c) acc += (c * w) * kern[x > v ? x - v : v - x];
+        for (int k = 0; k < nnz; ++k) {
+            const int e = hist[k];
+            const int v = e >> 16, c = e & 0xFFFF;
+            acc += (c * w) * kern[x > v ? x - v : v - x];
         }
         pdf[x] = acc;
         part += acc;
