@@ -317,6 +317,28 @@ int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, co
         d.period = (int)Rp.size();
         d.max_units = mu;
         d.n_strands = 2;
+        // 6-mer presence bitmaps over ALL templates of each strand (exact strand filter in the kernel)
+        d.kmer_ok = 1;
+        for (int s = 0; s < 2; ++s) {
+            std::vector<uint32_t> bits(128, 0u);
+            for (int u = 1; u <= mu; ++u) {
+                std::vector<int8_t> t(*A[s]);
+                for (int k = 0; k < u; ++k) t.insert(t.end(), Rep[s]->begin(), Rep[s]->end());
+                t.insert(t.end(), B[s]->begin(), B[s]->end());
+                for (size_t i = 0; i + 6 <= t.size(); ++i) {
+                    uint32_t code = 0;
+                    bool wild = false;
+                    for (int k = 0; k < 6; ++k) {
+                        if (t[i + k] > 3) wild = true;
+                        code |= (uint32_t)(t[i + k] & 3) << (2 * k);
+                    }
+                    if (wild) d.kmer_ok = 0;
+                    else bits[code >> 5] |= 1u << (code & 31);
+                }
+            }
+            d.kmer_off[s] = (int)seq.size();
+            seq.insert(seq.end(), bits.begin(), bits.end());
+        }
         max_t = std::max(max_t, 2 * mu);
         max_u = std::max(max_u, mu);
     }

@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
     const int flank = a.p.flank;
 
     Rows<R> J;
+    uint32_t pk = 0, nk = 0;  // this lane's rows: 2-bit codes / N-or-padding flags (for the 6-mer filter)
     {
         const int nb = (L + 15) >> 4;
 #pragma unroll
@@ -232,6 +233,10 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
                 const uint32_t w = a.packed[off + (i >> 4)];
                 const uint32_t m = a.packed[off + nb + (i >> 5)];
                 code = ((m >> (i & 31)) & 1u) ? 4 : (int)((w >> ((i & 15) * 2)) & 3u);
+            }
+            if (2 * R + 10 <= 32) {
+                pk |= (uint32_t)(code & 3) << (2 * r);
+                nk |= (uint32_t)(code > 3) << r;
             }
 #pragma unroll
             for (int l = 0; l < 4; ++l)
@@ -248,6 +253,8 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
     // Only cells that can survive the score filter are tracked: min_score >= 30 (bam_parser.py:134), so a
     // floor of 29 is exact for tagging; the per-template dump (parity/debug) tracks every positive score.
     const bool full_dump = a.out_dump != nullptr;  // wave-uniform
+    // 6-mer filter premise: every run break costs >= 5 matches
+    const int kmer_thr = min(a.p.mismatch, a.p.gap_open) >= 5 * a.p.match ? (30 + a.p.match - 1) / a.p.match - 5 : 0;
     const int floor_key = (full_dump ? 0 : 29) << KSH | PAYMASK;
 
     for (int s = 0; s < n_strands; ++s) {
@@ -256,6 +263,35 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
         const int alen = __builtin_amdgcn_readfirstlane(ld->alen[s]);
         const int blen = __builtin_amdgcn_readfirstlane(ld->blen[s]);
         const int ncols = alen + period * max_units;
+        // ---- exact strand filter.  An alignment scoring s with m matches has <= (m - s)/P run breaks
+        // (P = min(mismatch, gap_open) >= 5*match), so at least m - 5*(breaks+1) >= s/match - 5 of its
+        // 6-mers are exact; no template of this strand can reach the score filter (>= 30,
+        // bam_parser.py:134) unless that many read 6-mers occur somewhere in the strand's templates.
+        // Windows containing N count as present.  Skipped for the dump (all positive scores wanted),
+        // for N-containing motifs and for scorings outside the bound's premise.
+        int kcap = 1 << 20;  // per read: upper bound of any score on this strand
+        if (2 * R + 10 <= 32 && !full_dump && kmer_thr > 0 && __builtin_amdgcn_readfirstlane(ld->kmer_ok) != 0) {
+            const uint32_t* bm = a.seqw + __builtin_amdgcn_readfirstlane(ld->kmer_off[s]);
+            const uint32_t pk_n = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x101, 0xF, 0xF, false);        // row_shl:1
+            const uint32_t nk_n = (uint32_t)__builtin_amdgcn_update_dpp(0x3FF, (int)nk, 0x101, 0xF, 0xF, false);
+            const uint32_t comb = pk | ((pk_n & 0x3FFu) << (2 * R));
+            const uint32_t ncomb = nk | ((nk_n & 0x1Fu) << R);
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t win = (comb >> (2 * r)) & 0xFFFu;
+                const bool has_n = ((ncomb >> r) & 0x3Fu) != 0;
+                const bool in_read = row0 + r + 5 < L;
+                const uint32_t word = bm[win >> 5];
+                cnt += in_read && (has_n || ((word >> (win & 31)) & 1u));
+            }
+            cnt += dpp_row_shr<0x111>(0, cnt);
+            cnt += dpp_row_shr<0x112>(0, cnt);
+            cnt += dpp_row_shr<0x114>(0, cnt);
+            cnt += dpp_row_shr<0x118>(0, cnt);
+            kcap = (cnt + 5) * a.p.match;  // lane 15 of each read holds the read's total
+            if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && cnt >= kmer_thr) == 0) continue;
+        }
         const int tw = lane < ((ncols + 7) >> 3) ? (int)a.seqw[trunk_w + lane] : 0;
         const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
         int H[R], E[R];
@@ -297,7 +333,7 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
                         cmx = max(cmx, dpp_row_shr<0x112>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x112>(bk0, bk0));
                         cmx = max(cmx, dpp_row_shr<0x114>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x114>(bk0, bk0));
                         cmx = max(cmx, dpp_row_shr<0x118>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x118>(bk0, bk0));
-                        const int bound = max(bk0 >> KSH, max(cmx >> KSH, 0) + blen * a.p.match);
+                        const int bound = min(kcap, max(bk0 >> KSH, max(cmx >> KSH, 0) + blen * a.p.match));
                         const int Tlen = alen + period * u + blen;
                         const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
                         const bool want = valid && jl == 15 && bound >= need_score;
