@@ -178,6 +178,25 @@ __device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (
     }
 }
 
+// Per read (valid in lane 15 of its DPP row): true score of the best cell so far and of the current
+// column's maximum.  lane_scale = (row0 + col) * geK of the column held in H.
+struct ReadBound { int best, colmax; };
+template <int R>
+__device__ __forceinline__ ReadBound read_bound(const int (&H)[R], const Track& T, int lane_scale, int geK) {
+    int cmx = NEG, scale = lane_scale;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { cmx = max(cmx, H[r] - scale); scale += geK; }
+    int bk = T.bestkey;
+    cmx = max(cmx, dpp_row_shr<0x111>(cmx, cmx)); bk = max(bk, dpp_row_shr<0x111>(bk, bk));
+    cmx = max(cmx, dpp_row_shr<0x112>(cmx, cmx)); bk = max(bk, dpp_row_shr<0x112>(bk, bk));
+    cmx = max(cmx, dpp_row_shr<0x114>(cmx, cmx)); bk = max(bk, dpp_row_shr<0x114>(bk, bk));
+    cmx = max(cmx, dpp_row_shr<0x118>(cmx, cmx)); bk = max(bk, dpp_row_shr<0x118>(bk, bk));
+    ReadBound rb;
+    rb.best = bk >> KSH;
+    rb.colmax = cmx >> KSH;
+    return rb;
+}
+
 // Letters are packed 8 per 32-bit word (4 bits each).  A strand's trunk (<= 64 words) and branch words
 // are loaded once into one VGPR each, word k in lane k, and fetched per column with v_readlane (no
 // memory access in the column loop).
@@ -303,8 +322,8 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
         int u = max_units > 0 ? 1 : 0;
         // One sweep site for trunk and branch columns: tc = next trunk column, bk_left = branch columns
         // still to sweep for template u (state of the trunk parked in Hs/Es/Ts meanwhile).
-        int tc = 0, b_left = 0, b_col = 0, b_idx = 0;
-        bool in_branch = false;
+        int tc = 0, b_left = 0, b_col = 0, b_idx = 0, need_score = 0;
+        bool in_branch = false, parked = false;
         while (tc < ncols || in_branch) {
             int letter, col;
             if (in_branch) { letter = letter_from(bw, b_idx); col = b_col; }
@@ -315,32 +334,39 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
             if (in_branch) {
                 ++b_idx; ++b_col; --b_left;
                 emit = b_left == 0;
+                if (!emit && !full_dump && (b_idx & 3) == 0) {
+                    // Early exit from a branch (exact): once, for every read of the wave, no remaining
+                    // column can either raise this template's best cell (strictly greater needed: the first
+                    // column reaching the maximum wins) or matter for the read's arg-max, the template's
+                    // result is already final.
+                    const ReadBound rb = read_bound<R>(H, T, row0g + (col) * geK, geK);
+                    const int top = max(rb.colmax, 0) + b_left * a.p.match;
+                    const bool may_improve = top > rb.best;
+                    const bool relevant = min(kcap, max(rb.best, top)) >= need_score;
+                    if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && may_improve && relevant) == 0) emit = true;
+                }
             } else {
                 ++tc;
                 if (col == next_branch) {
                     // Template u ends here on the trunk.  Exact pruning: no cell of its branch can score
-                    // more than max(trunk best, column max + |branch| * match); if that cannot reach the
-                    // score filter (bam_parser.py:134) or beat this read's current arg-max key
-                    // (score, -units) for ANY of the four reads, the branch is not swept at all.
-                    bool need = true;
+                    // more than max(trunk best, column max + |branch| * match).  If that cannot reach the
+                    // score filter (bam_parser.py:134) or beat the read's current arg-max key
+                    // (score, -units) for ANY of the four reads, the template is dropped; if it can matter
+                    // but the branch cannot raise the trunk's best cell, the result is emitted from the
+                    // trunk state without sweeping the branch.
+                    bool need = true, sweep = blen > 0;
+                    const int Tlen = alen + period * u + blen;
+                    need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
                     if (!full_dump && blen > 0) {
-                        int cmx = NEG;
-                        int scale = row0g + col * geK;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) { cmx = max(cmx, H[r] - scale); scale += geK; }
-                        int bk0 = T.bestkey;
-                        cmx = max(cmx, dpp_row_shr<0x111>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x111>(bk0, bk0));
-                        cmx = max(cmx, dpp_row_shr<0x112>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x112>(bk0, bk0));
-                        cmx = max(cmx, dpp_row_shr<0x114>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x114>(bk0, bk0));
-                        cmx = max(cmx, dpp_row_shr<0x118>(cmx, cmx)); bk0 = max(bk0, dpp_row_shr<0x118>(bk0, bk0));
-                        const int bound = min(kcap, max(bk0 >> KSH, max(cmx >> KSH, 0) + blen * a.p.match));
-                        const int Tlen = alen + period * u + blen;
-                        const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
-                        const bool want = valid && jl == 15 && bound >= need_score;
-                        need = __builtin_amdgcn_ballot_w64(want) != 0;
+                        const ReadBound rb = read_bound<R>(H, T, row0g + col * geK, geK);
+                        const int top = max(rb.colmax, 0) + blen * a.p.match;
+                        const bool relevant = min(kcap, max(rb.best, top)) >= need_score;
+                        const bool may_improve = top > rb.best;
+                        need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant) != 0;
+                        sweep = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant && may_improve) != 0;
                     }
-                    if (a.stats != nullptr && lane == 0) atomicAdd(a.stats + (need ? 2 : 3), 1ull);
-                    if (need) {
+                    if (a.stats != nullptr && lane == 0) atomicAdd(a.stats + (need ? (sweep ? 2 : 4) : 3), 1ull);
+                    if (need && sweep) {
                         // park the trunk state, continue into the branch
 #pragma unroll
                         for (int r = 0; r < R; ++r) { mypark[r * 256] = H[r]; mypark[(R + r) * 256] = E[r]; }
@@ -348,8 +374,11 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
                         mypark[(2 * R + 1) * 256] = T.beststart;
                         mypark[(2 * R + 2) * 256] = T.ceil;
                         in_branch = true;
+                        parked = true;
                         b_left = blen; b_col = col + 1; b_idx = 0;
-                        emit = blen == 0;
+                    } else if (need) {
+                        emit = true;       // result = trunk state; nothing parked
+                        parked = false;
                     } else {
                         next_branch += period;
                         ++u;
@@ -400,11 +429,13 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
                 }
             }
             // back to the trunk
+            if (parked) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) { H[r] = mypark[r * 256]; E[r] = mypark[(R + r) * 256]; }
-            T.bestkey = mypark[(2 * R) * 256];
-            T.beststart = mypark[(2 * R + 1) * 256];
-            T.ceil = mypark[(2 * R + 2) * 256];
+                for (int r = 0; r < R; ++r) { H[r] = mypark[r * 256]; E[r] = mypark[(R + r) * 256]; }
+                T.bestkey = mypark[(2 * R) * 256];
+                T.beststart = mypark[(2 * R + 1) * 256];
+                T.ceil = mypark[(2 * R + 2) * 256];
+            }
             in_branch = false;
             next_branch += period;
             ++u;
