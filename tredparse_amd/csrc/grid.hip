@@ -190,7 +190,8 @@ __device__ double block_sum(double v, double* red) {
 // n^(-1/5), covariance with ddof=1, kernel exp(-((l-x)/sigma)^2/2) / (sigma*sqrt(2*pi)) / n).
 // hist/kern are LDS scratch of SPAN ints / SPAN doubles; pdf receives the result (LDS or global).
 // Returns 0, or -2 (singular / too few points), -6 (length outside [0,1000)).
-__device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, double* pdf, double* red, int* flag) {
+__device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, double* pdf, double* red, int* flag,
+                         double* wgt) {
     const int tid = threadIdx.x;
     for (int i = tid; i < SPAN; i += NT) hist[i] = 0;
     if (tid == 0) *flag = 0;
@@ -240,16 +241,25 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, do
     }
     __syncthreads();
     const int nnz = *flag;
-    double part = 0;
-    for (int x = tid; x < SPAN; x += NT) {
-        double acc = 0;
-        for (int k = 0; k < nnz; ++k) {
-            const int e = hist[k];
-            const int v = e >> 16, c = e & 0xFFFF;
-            acc += (c * w) * kern[x > v ? x - v : v - x];
+    // per-bin weights (count * 1/n), evaluated once; wgt is caller-provided LDS scratch of >= 1000 doubles
+    for (int k = tid; k < nnz; k += NT) wgt[k] = ((hist[k] & 0xFFFF) * w);
+    __syncthreads();
+    // every thread owns x = tid, tid+256, tid+512, tid+768: the bin list is walked once for all four
+    double acc[4] = {0, 0, 0, 0};
+    for (int k = 0; k < nnz; ++k) {
+        const int v = hist[k] >> 16;
+        const double wk = wgt[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int x = tid + q * NT;
+            if (x < SPAN) acc[q] += wk * kern[x > v ? x - v : v - x];
         }
-        pdf[x] = acc;
-        part += acc;
+    }
+    double part = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int x = tid + q * NT;
+        if (x < SPAN) { pdf[x] = acc[q]; part += acc[q]; }
     }
     const double tot = block_sum(part, red);
     for (int x = tid; x < SPAN; x += NT) pdf[x] = pdf[x] / tot;
@@ -261,10 +271,11 @@ __global__ __launch_bounds__(NT) void pe_kde_kernel(GridArgs a) {
     __shared__ int hist[SPAN];
     __shared__ double kern[SPAN];
     __shared__ double red[NT / 64];
+    __shared__ double wgt[SPAN];
     __shared__ int flag;
     const int g = blockIdx.x;
     const tredgpu_unit_params u = a.units[g];
-    const int rc = kde_block(a.global_lens + u.pe_off, u.n_global, hist, kern, a.kde_pdf + (size_t)g * SPAN, red, &flag);
+    const int rc = kde_block(a.global_lens + u.pe_off, u.n_global, hist, kern, a.kde_pdf + (size_t)g * SPAN, red, &flag, wgt);
     if (threadIdx.x == 0) a.kde_status[g] = rc;
 }
 
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
                 for (int i = tid; i < u.n_global; i += NT) { const double d = gl[i] - mean; q += d * d; }
                 rc = block_sum(q, S.red) > 0 ? 0 : -2;
             } else {
-                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag);
+                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag, S.far1);
             }
             if (rc) status = rc;
         }
@@ -484,8 +495,22 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
         const int dmax = 2 * max(hmaxv - readlen, 1);
         const bool use_rept_tab = rect >= 1024 && dmax < GRID_REPT_TAB;
         const bool use_roll_tab = run_pe && rect >= 1024 && u.n_target <= GRID_TMAX;
-        if (use_rept_tab)
-            for (int d = 2 + tid; d <= dmax; d += NT) rept_tab[d] = rept_term(C, d);
+        if (use_rept_tab) {
+            // only the dsum values that occur: {2} U {1 + d} U {d + d'} for d, d' in D = {h - L > 0}
+            for (int d = 2 + tid; d <= dmax; d += NT) rept_tab[d] = 1.0;   // 1.0 = unset (terms are <= 0)
+            __syncthreads();
+            int i = tid / ncol, j = tid - i * ncol;
+            for (int pos = tid; pos < rect; pos += NT) {
+                const int h1 = axis_value(ax1, S.obs.base, period, i);
+                const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
+                if (h1 <= h2) rept_tab[max(h1 - readlen, 1) + max(h2 - readlen, 1)] = 2.0;  // needed
+                j += NT;
+                while (j >= ncol) { j -= ncol; ++i; }
+            }
+            __syncthreads();
+            for (int d = 2 + tid; d <= dmax; d += NT)
+                if (rept_tab[d] == 2.0) rept_tab[d] = rept_term(C, d);
+        }
         if (use_roll_tab) {
             const int nt = u.n_target;
             for (int k = tid; k < (nrow + ncol) * nt; k += NT) {
