@@ -149,12 +149,12 @@ __device__ double rept_term(const PairCtx& C, int dsum) {
 // leave the normal range (every factor is in [e^-10, 1], so 32 factors stay above e^-320): one log per
 // 32 pairs.  Differs from the reference's term-by-term sum by O(1e-14), far inside the 1e-6 contract.
 template <bool TABLES>
-__device__ double pe_term(const PairCtx& C, int h1, int h2, const double* r1, const double* r2) {
+__device__ double pe_term(const PairCtx& C, int h1, int h2, const double* r1, const double* r2, int r2_stride) {
     double ml4 = 0, prod = 1.0;
     int k = 0;
     for (int i = 0; i < C.n_target; ++i) {
         double p1, p2;
-        if (TABLES) { p1 = r1[i]; p2 = r2[i]; }
+        if (TABLES) { p1 = r1[i]; p2 = r2[(size_t)i * r2_stride]; }
         else {
             int x = C.tl[i];
             if (x < 0) x += SPAN;
@@ -310,7 +310,7 @@ struct GridShared {
     int unit;
 };
 
-__global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, int* next_unit) {
+__global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch, int* next_unit) {
     constexpr size_t scratch_per_block = GRID_SCRATCH_DOUBLES;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     GridShared& S = *reinterpret_cast<GridShared*>(smem_raw);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
                 for (int i = tid; i < u.n_global; i += NT) { const double d = gl[i] - mean; q += d * d; }
                 rc = block_sum(q, S.red) > 0 ? 0 : -2;
             } else {
-                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag, S.far1);
+                rc = (a.debug_skip & 1) ? 0 : kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag, S.far1);
             }
             if (rc) status = rc;
         }
@@ -469,6 +469,7 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
             if (u.ploidy == 1) cnt = 1;
             else for (int j = 0; j < ncol; ++j) cnt += axis_value(ax2, S.obs.base, period, j) >= h1;
             S.row_off[i] = cnt;
+            if (a.debug_skip & 32) { S.far1[i] = 0; S.far2[i] = 0; } else
             eval_reads(C, h1, max(h_far, h1), S.far1[i], S.far2[i]);
         }
         __syncthreads();
@@ -521,7 +522,9 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
                                     : (u.ploidy == 1 ? 0 : axis_value(ax2, S.obs.base, period, ai));
                 int x = C.tl[t];
                 if (x < 0) x += SPAN;
-                (isrow ? roll1 : roll2)[(size_t)ai * nt + t] = roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);
+                const double rv = roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);
+                if (isrow) roll1[(size_t)ai * nt + t] = rv;
+                else roll2[(size_t)t * ncol + ai] = rv;   // transposed: coalesced across columns in pass A
             }
         }
         __syncthreads();
@@ -537,14 +540,15 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
                 else {
                     double ml4[4];
                     if (h2 >= h_far) { ml4[0] = S.far1[i]; ml4[1] = S.far2[i]; }
+                    else if (a.debug_skip & 64) { ml4[0] = 0; ml4[1] = 0; }
                     else eval_reads(C, h1, h2, ml4[0], ml4[1]);
                     const int dsum = max(h1 - readlen, 1) + max(h2 - readlen, 1);
-                    ml4[2] = use_rept_tab ? rept_tab[dsum] : rept_term(C, dsum);
+                    ml4[2] = (a.debug_skip & 4) ? 0.0 : (use_rept_tab ? rept_tab[dsum] : rept_term(C, dsum));
                     ml4[3] = 0;
-                    if (run_pe) {
+                    if (run_pe && !(a.debug_skip & 2)) {
                         if (use_roll_tab && u.ploidy != 1)
-                            ml4[3] = pe_term<true>(C, h1, h2, roll1 + (size_t)i * u.n_target, roll2 + (size_t)j * u.n_target);
-                        else ml4[3] = pe_term<false>(C, h1, h2, nullptr, nullptr);
+                            ml4[3] = pe_term<true>(C, h1, h2, roll1 + (size_t)i * u.n_target, roll2 + j, ncol);
+                        else ml4[3] = pe_term<false>(C, h1, h2, nullptr, nullptr, 0);
                     }
                     const double ml = ml4[0] + ml4[1] + ml4[2] + ml4[3];  // models.py:269
                     mlbuf[pos] = ml;
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
                 const int h1 = axis_value(ax1, S.obs.base, period, i);
                 const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
                 if (h1 <= h2) {   // else mlbuf[pos] stays 0: contributes nothing to the sums below
-                    const double e = exp(mlbuf[pos] - max_ml);
+                    const double e = (a.debug_skip & 8) ? mlbuf[pos] : exp(mlbuf[pos] - max_ml);
                     mlbuf[pos] = e;
                     all += e;
                     const int lo = h1 / period, hi = h2 / period;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
         for (int m = tid; m < mlim; m += NT) { S.ph1[m] = 0; S.ph2[m] = 0; }
         __syncthreads();  // also orders the mlbuf writes above before the reads below
         // marginal P_h1: one wave per row (fixed shuffle tree), rows merged by key in row order
-        for (int i = tid >> 6; i < nrow; i += NT / 64) {
+        for (int i = tid >> 6; i < ((a.debug_skip & 16) ? 0 : nrow); i += NT / 64) {
             double acc = 0;
             for (int j = tid & 63; j < ncol; j += 64) acc += mlbuf[i * ncol + j];
             acc = wave_sum(acc);
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(NT) void grid_kernel(GridArgs a, double* scratch, i
         // marginal P_h2: one thread per distinct h2 value, rows outermost as in the reference.  The
         // extended axis can list a value twice (base part + arithmetic part, models.py:251-252): the
         // first occurrence owns the sum.
-        if (u.ploidy != 1) {
+        if (u.ploidy != 1 && !(a.debug_skip & 16)) {
             for (int j = tid; j < ncol; j += NT) {
                 const int h2 = axis_value(ax2, S.obs.base, period, j);
                 int twin = -1;
