@@ -55,7 +55,7 @@ assert CALL_DTYPE.itemsize == C.sizeof(Call) == 56
 EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_sync", "tredgpu_get_stream",
            "tredgpu_version", "tredgpu_set_ladders", "tredgpu_set_model", "tredgpu_pack_reads",
            "tredgpu_sw_classify", "tredgpu_tally", "tredgpu_likelihood_grid", "tredgpu_genotype_batch",
-           "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing")
+           "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing", "tredgpu_get_sw_counters")
 
 _lib = None
 
@@ -95,6 +95,7 @@ def load():
     lib.tredgpu_pe_kde.argtypes = [vp, C.c_int, vp, i32, vp, i64, vp, vp]
     lib.tredgpu_reset_timing.argtypes = [vp]
     lib.tredgpu_get_timing.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
+    lib.tredgpu_get_sw_counters.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -253,6 +254,13 @@ class Context:
         n, ms = C.c_int64(0), C.c_double(0)
         self._chk(self.lib.tredgpu_get_timing(self.h, which, C.byref(n), C.byref(ms)), "tredgpu_get_timing")
         return n.value, ms.value
+
+    def get_sw_counters(self):
+        """dict of the SW kernel's work counters since reset_timing (tredgpu_get_sw_counters)."""
+        out = np.zeros(8, np.uint64)
+        self._chk(self.lib.tredgpu_get_sw_counters(self.h, out.ctypes.data), "tredgpu_get_sw_counters")
+        keys = ("trunk_cols", "branch_cols", "branches_swept", "templates_dropped", "emitted_from_trunk", "waves")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def pe_kde(self, mem, units, n_units, global_lens, n_global_total, pdf_out, status_out):
         self._chk(self.lib.tredgpu_pe_kde(self.h, mem, _ptr(units), n_units, _ptr(global_lens),

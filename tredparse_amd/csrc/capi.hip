@@ -247,6 +247,18 @@ int tredgpu_reset_timing(tredgpu_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto& t : c->timers) { t.used = 0; t.launches = 0; t.total_ms = 0; }
+    if (c->ws_stats.p) HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    return 0;
+}
+
+int tredgpu_get_sw_counters(tredgpu_ctx* c, uint64_t out[8]) {
+    if (!c || !out) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (c->ws_stats.p) {
+        HIPCHK(c, hipMemcpyAsync(out, c->ws_stats.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -429,23 +441,14 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     a.dump_templates = dump_templates;
     a.n_units = n_units;
     a.p = *p;
-    a.stats = nullptr;
-    static const bool want_stats = getenv("TREDGPU_SW_STATS") != nullptr;
-    if (want_stats) {
+    if (c->ws_stats.p == nullptr) {
         if ((rc = ensure(c, c->ws_stats, 8 * sizeof(unsigned long long)))) return rc;
         HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
-        a.stats = (unsigned long long*)c->ws_stats.p;
     }
+    a.stats = (unsigned long long*)c->ws_stats.p;
     {
         ScopedTimer tm(c, TREDGPU_KERNEL_SW);
         HIPCHK(c, launch_sw_ladder(a, rows_for(max_len), max_quads, c->stream));
-    }
-    if (want_stats) {
-        unsigned long long h[8];
-        HIPCHK(c, hipMemcpyAsync(h, c->ws_stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        fprintf(stderr, "[tredgpu sw stats] quads<=%lld trunk_cols=%llu branch_cols=%llu branches_run=%llu branches_skipped=%llu\n",
-                (long long)max_quads, h[0], h[1], h[2], h[3]);
     }
     return 0;
 }

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
     const int mu_rept = a.p.clip ? (L + period - 1) / period : max_units;
 
     int bestS = -1, bestU = 0, bestTag = TREDGPU_TAG_NONE;
+    int n_trunk_cols = 0, n_branch_cols = 0, n_swept = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
     int16_t* dump = nullptr;
     if (a.out_dump != nullptr && valid) dump = a.out_dump + rd * (int64_t)a.dump_templates * 6;
 
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
             if (in_branch) { letter = letter_from(bw, b_idx); col = b_col; }
             else { letter = letter_from(tw, tc); col = tc; }
             sweep_letter<R>(letter, J, H, E, T, col, row0, geK, c0, row0g);
-            if (a.stats != nullptr && lane == 0) atomicAdd(a.stats + (in_branch ? 1 : 0), 1ull);
+            if (in_branch) ++n_branch_cols; else ++n_trunk_cols;
             bool emit = false;
             if (in_branch) {
                 ++b_idx; ++b_col; --b_left;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
                         need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant) != 0;
                         sweep = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant && may_improve) != 0;
                     }
-                    if (a.stats != nullptr && lane == 0) atomicAdd(a.stats + (need ? (sweep ? 2 : 4) : 3), 1ull);
+                    if (need && sweep) ++n_swept; else if (need) ++n_emit_trunk; else ++n_dropped;
                     if (need && sweep) {
                         // park the trunk state, continue into the branch
 #pragma unroll
@@ -440,6 +441,15 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
             next_branch += period;
             ++u;
         }
+    }
+    if (a.stats != nullptr && lane == 0) {
+        // one set of atomics per wave: what the exact shortcuts left to sweep
+        atomicAdd(a.stats + 0, (unsigned long long)n_trunk_cols);
+        atomicAdd(a.stats + 1, (unsigned long long)n_branch_cols);
+        atomicAdd(a.stats + 2, (unsigned long long)n_swept);
+        atomicAdd(a.stats + 3, (unsigned long long)n_dropped);
+        atomicAdd(a.stats + 4, (unsigned long long)n_emit_trunk);
+        atomicAdd(a.stats + 5, 1ull);
     }
     if (valid && jl == 15) {
         if (too_long) bestTag = TREDGPU_TAG_INVALID, bestU = 0, bestS = 0;

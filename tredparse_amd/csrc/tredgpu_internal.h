@@ -47,7 +47,7 @@ struct SwArgs {
     int32_t dump_templates;
     int32_t n_units;
     tredgpu_sw_params p;
-    unsigned long long* stats;  // optional debug counters (TREDGPU_SW_STATS=1), else nullptr
+    unsigned long long* stats;  // work counters: trunk cols, branch cols, branches swept/dropped/emitted-from-trunk, waves
 };
 
 // sw_ladder.hip
