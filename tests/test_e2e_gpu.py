@@ -1,0 +1,72 @@
+"""GPU, BASELINE configs[0]/[1]: the drop-in CLI path on the reference's own test BAMs (tests/t001.bam,
+tests/t002.bam; all 32 loci) against the reference's run() output captured in
+tests/golden/run_t001_t002.json (tools/gen_golden.py).  Everything the reference prints in its JSON is
+compared: integers and strings exactly, floats to 1e-9."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tredparse_amd import tred as tredmod
+from tredparse_amd.engine import Engine
+from tredparse_amd.meta import TREDsRepo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _close(a, b, tol=1e-9):
+    if isinstance(a, float) or isinstance(b, float):
+        return abs(float(a) - float(b)) <= tol * max(1.0, abs(float(b)))
+    return a == b
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("sample,headline", [("t001", ("HD", 15, 41)), ("t002", ("DM1", 5, 66))])
+def test_run_matches_reference(engine, sample, headline):
+    want = json.load(open(os.path.join(GOLD, "run_t001_t002.json")))["samples"][sample]
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    bam = os.path.join(GOLD, "bam", sample + ".bam")
+    res = tredmod.run((sample, bam, repo, list(repo.names), 300, False, False, True, True, "INFO"), engine=engine)
+    got = res["tredCalls"]
+    name, a1, a2 = headline
+    assert (got[name + ".1"], got[name + ".2"]) == (a1, a2)          # README.md:76-86 / SURVEY 9.4
+    assert set(got) == set(want)
+    for k in sorted(want):
+        w, g = want[k], got[k]
+        if k.endswith(".details"):
+            assert g == w, k                                          # tag, h, read id and sequence per read
+        elif isinstance(w, dict):
+            assert set(g) == set(w), k
+            for kk in w:
+                assert _close(g[kk], w[kk]), (k, kk, g[kk], w[kk])
+        else:
+            assert _close(g, w), (k, g, w)
+
+
+def test_cli_main_writes_json_and_vcf(engine, tmp_path, monkeypatch):
+    """tests.py:8-12 of the reference: main(["tests/samples.csv", "--workdir", "work"])."""
+    csv = tmp_path / "samples.csv"
+    csv.write_text("#SampleKey,BAM,TRED\nt001,{0}/t001.bam,HD\nt002,{0}/t002.bam,DM1\n".format(os.path.join(GOLD, "bam")))
+    work = tmp_path / "work"
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr("tredparse_amd.engine.Engine", lambda *a, **k: engine)
+    tredmod.main([str(csv), "--workdir", str(work)], quiet=True)
+    js = json.load(open(work / "t001.json"))
+    assert js["samplekey"] == "t001" and js["tredCalls"]["HD.2"] == 41 and js["tredCalls"]["HD.label"] == "risk"
+    # json.dumps(sort_keys=True, indent=4, separators=(',', ': ')), tred.py:305-306
+    assert open(work / "t001.json").read().startswith('{\n    "bam": ')
+    vcf = gzip.open(work / "t002.tred.vcf.gz", "rt").read().splitlines()
+    assert vcf[0] == "##fileformat=VCFv4.1"
+    line = [l for l in vcf if not l.startswith("#")][0].split("\t")
+    assert line[0] == "chr19" and line[2] == "DM1" and line[8] == "GT:GB:FR:PR:RR:DP:FDP:PDP:RDP:PEDP:CI:PP:LABEL"
+    assert line[9].startswith("1/2:5/66:5|24:")
+    assert "RPA=5,66" in line[7]

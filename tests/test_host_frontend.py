@@ -1,0 +1,75 @@
+"""CPU: the host front end (BAM reader, read selection, pair extraction, locus table, CLI plumbing) against
+numbers pinned by the reference run (SURVEY 9.4 / tests/golden/run_t001_t002.json).  No GPU needed."""
+import json
+import os
+import types
+
+import pytest
+
+from tredparse_amd import bamio, tred as tredmod
+from tredparse_amd.bam_parser import BamDepth, BamParser, BamReadLen, PEextractor, rc
+from tredparse_amd.meta import TREDsRepo
+from tredparse_amd.models import calc_label, histogram, mean_std
+from tredparse_amd.utils import InputParams
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BAM1 = os.path.join(GOLD, "bam", "t001.bam")
+BAM2 = os.path.join(GOLD, "bam", "t002.bam")
+WANT = json.load(open(os.path.join(GOLD, "run_t001_t002.json")))["samples"]
+
+
+def test_bam_reader_counts():
+    f = bamio.AlignmentFile(BAM1)
+    assert sum(1 for _ in f.fetch()) == 12309
+    reads = list(f.fetch("chr4", 3074877 - 1000, 3074933 + 1000))
+    assert len(reads) == 455 and sum(r.is_unmapped for r in reads) == 17   # SURVEY 3.2 probe numbers
+    with pytest.raises(ValueError):
+        list(f.fetch("chrNope", 1, 2))
+    assert BamReadLen(BAM1, None).readlen == 150
+
+
+def test_depth_and_pairs_match_reference_run():
+    repo = TREDsRepo()
+    for bam, name, sample in ((BAM1, "HD", "t001"), (BAM2, "DM1", "t002")):
+        t = repo[name]
+        depth = BamDepth(bam, "hg38", None).region_depth(t.chr, t.repeat_start - 1000, t.repeat_end + 1000)
+        assert depth == WANT[sample][name + ".DP"]
+        ip = InputParams(bam=bam, READLEN=150, tredName=name, repo=repo, depth=depth, alts=True, repeatpairs=True)
+        bp = BamParser(ip)
+        reads = bp.collect()
+        assert len(reads) == {"HD": 68, "DM1": 177}[name]
+        pe = PEextractor(bp)
+        assert len(pe.target_lens) == WANT[sample][name + ".PEDP"]
+        assert mean_std(pe.global_lens) == WANT[sample][name + ".PEG"]
+        assert mean_std(pe.target_lens) == WANT[sample][name + ".PET"]
+        assert histogram(pe.global_lens) == WANT[sample][name + ".P_PEG"]
+        assert histogram(pe.target_lens) == WANT[sample][name + ".P_PET"]
+        assert pe.MINPE == t.repeat_end - t.repeat_start + 20 and pe.ref == t.repeat_end - t.repeat_start + 1
+
+
+def test_locus_table_and_labels():
+    repo = TREDsRepo()
+    assert len(repo.names) == 32 and repo["HD"].ref_copy == 19 and repo["DM1"].ref_copy == 20
+    assert repo["AR"].is_expansion is False and repo["FRDA"].is_recessive and repo["FXS"].is_xlinked
+    assert TREDsRepo(ref="hg19_nochr")["HD"].chr == "4"
+    assert calc_label(repo["HD"], [15, 41]) == "risk" and calc_label(repo["HD"], [15, 37]) == "prerisk"
+    assert calc_label(repo["HD"], [-1, -1]) == "missing" and calc_label(repo["AR"], [6, 21]) == "risk"
+    assert calc_label(repo["FRDA"], [20, 80]) == "ok" and calc_label(repo["FRDA"], [70, 80]) == "risk"
+    assert rc("ACGTNacgtn") == "nacgtNACGT"
+    repo.set_ploidy(["chrX"])
+    assert repo["FXS"].ploidy == 1 and repo["HD"].ploidy == 2
+
+
+def test_read_csv_modes(tmp_path):
+    args = types.SimpleNamespace(workflow_execution_id=None, sample_id=None)
+    assert tredmod.read_csv(BAM1, args) == [("t001", BAM1, None)]
+    lst = tmp_path / "bams.txt"
+    lst.write_text(BAM1 + "\n" + BAM2 + "\n")
+    assert [x[0] for x in tredmod.read_csv(str(lst), args)] == ["t001", "t002"]
+    csv = tmp_path / "s.csv"
+    csv.write_text("#SampleKey,BAM,TRED\nA,{},HD\nB,{}\n".format(BAM1, BAM2))
+    assert tredmod.read_csv(str(csv), args) == [("A", BAM1, "HD"), ("B", BAM2, None)]
+    assert tredmod.counter_s({15: 4, 6: 1}) == "6|1;15|4"
+    p = tredmod.set_argparse()
+    a = p.parse_args([BAM1, "--tred", "HD", "--maxinsert", "100", "--norepeatpairs"])
+    assert a.tred == ["HD"] and a.maxinsert == 100 and a.norepeatpairs and not a.fullsearch

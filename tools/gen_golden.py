@@ -280,10 +280,70 @@ def gen_grid(ref, loci):
                    "cases": out_cases}, fp)
 
 
+class _Col(object):
+    __slots__ = ("n",)
+
+    def __init__(self, n):
+        self.n = n
+
+
+class PysamStandin(types.ModuleType):
+    """pysam.AlignmentFile on top of tredparse_amd.bamio (pysam is not installable here)."""
+
+    def __init__(self):
+        types.ModuleType.__init__(self, "pysam")
+        from tredparse_amd import bamio
+
+        class AlignmentFile(bamio.AlignmentFile):
+            def pileup(self, chrom, start, end):
+                # htslib default pileup: every column covered by a read overlapping the region
+                cov = {}
+                for r in self.fetch(chrom, start, end):
+                    if r.flag & (bamio.FUNMAP | bamio.FSECONDARY | bamio.FQCFAIL | bamio.FDUP):
+                        continue
+                    if r.reference_end is None:
+                        continue
+                    for p in range(r.pos, r.reference_end):
+                        cov[p] = cov.get(p, 0) + 1
+                for p in sorted(cov):
+                    yield _Col(cov[p])
+        self.AlignmentFile = AlignmentFile
+
+
+def gen_e2e(loci):
+    """The reference's own run() on its two test BAMs (tests/samples.csv), all 32 loci each."""
+    import tempfile
+    ref = refshim.load_reference(pysam_standin=PysamStandin(), full=True)
+    logging.disable(logging.CRITICAL)
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)      # a cwd without sites/ (SURVEY 9.3)
+    try:
+        repo = ref.meta.TREDsRepo(ref="hg38", toy=False, sites=os.path.join(tmp, "sites"))
+        for samplekey, bam, treds in (("t001", "t001.bam", None), ("t002", "t002.bam", None)):
+            bampath = os.path.join(refshim.REF, "tests", bam)
+            names = treds or list(repo.names)
+            res = ref.tred.run((samplekey, bampath, repo, names, 300, False, False, True, True, "INFO"))
+            calls = res["tredCalls"]
+            for k, v in list(calls.items()):
+                if isinstance(v, (np.floating, np.integer)):
+                    calls[k] = v.item()
+            out[samplekey] = calls
+            print("e2e:", samplekey, {k: calls[k] for k in calls if k.endswith((".1", ".2", ".label"))
+                                      and calls[k] not in (-1, "missing")})
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(GOLD, "run_t001_t002.json"), "w") as fp:
+        json.dump({"generator": "tools/gen_golden.py: the reference's tredparse.tred.run() (v0.7.8, via "
+                                "tools/refshim.py) on its own tests/t001.bam and tests/t002.bam, all 32 loci, "
+                                "default flags; pysam replaced by tredparse_amd.bamio", "samples": out}, fp)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     loci = synth.load_loci()
-    what = sys.argv[1:] or ["sw", "classify", "grid"]
+    what = sys.argv[1:] or ["sw", "classify", "grid", "e2e"]
     if "sw" in what:
         gen_sw(loci)
     if "classify" in what or "grid" in what:
@@ -293,6 +353,8 @@ def main():
             gen_classify(ref, loci)
         if "grid" in what:
             gen_grid(ref, loci)
+    if "e2e" in what:
+        gen_e2e(loci)
 
 
 if __name__ == "__main__":

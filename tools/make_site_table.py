@@ -75,3 +75,17 @@ def main():
 
 if __name__ == "__main__":
     sys.exit(main())
+
+
+def chr_y_regions():
+    """First 25 rows of chrY.<ref>.unique_ccn.gc (bam_parser.py:413-429 reads at most row 19)."""
+    data = os.path.join(REF, "tredparse", "data")
+    for ref in ("hg38", "hg19"):
+        rows = open(os.path.join(data, "chrY.{}.unique_ccn.gc".format(ref))).read().splitlines()[:25]
+        with open(os.path.join(OUT, "chrY.{}.unique_ccn.tsv".format(ref)), "w") as fp:
+            for r in rows:
+                fp.write("\t".join(r.split()[:4]) + "\n")
+
+
+if __name__ == "__main__":
+    chr_y_regions()

@@ -66,6 +66,8 @@ def _load(relpath, modname, aliases=(), extra=None):
         src = fp.read()
     mod = types.ModuleType(modname)
     mod.__file__ = path
+    if "." in modname:
+        mod.__package__ = modname.rsplit(".", 1)[0]
     mod.__dict__["_py2div"] = _py2div
     mod.__dict__["xrange"] = builtins.range
     mod.__dict__["range"] = lambda *a: list(builtins.range(*a))
@@ -78,8 +80,9 @@ def _load(relpath, modname, aliases=(), extra=None):
     return mod
 
 
-def load_reference(pysam_standin=None, libssw_dir=None):
-    """Returns a namespace with .ssw (ssw_wrap), .utils, .bam_parser, .models of the reference."""
+def load_reference(pysam_standin=None, libssw_dir=None, full=False):
+    """Returns a namespace with .ssw (ssw_wrap), .utils, .bam_parser, .models of the reference
+    (+ .meta and .tred with full=True)."""
     libssw_dir = libssw_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref")
     # ssw_wrap.load_ssw_library falls back to the bare soname (ssw_wrap.py:24-31): preload it
     import ctypes
@@ -96,6 +99,7 @@ def load_reference(pysam_standin=None, libssw_dir=None):
     try:
         pkg = types.ModuleType("tredparse")
         pkg.__path__ = []
+        pkg.__version__ = "0.7.8"
         sys.modules["tredparse"] = pkg
         sys.modules["pysam"] = pysam_standin if pysam_standin is not None else types.ModuleType("pysam")
         ssw = _load("src/ssw_wrap.py", "ssw", aliases=("ssw_wrap",))
@@ -105,6 +109,16 @@ def load_reference(pysam_standin=None, libssw_dir=None):
     finally:
         ctypes.cdll.LoadLibrary = real_cdll_load
     ns = types.SimpleNamespace(ssw=ssw, utils=utils, bam_parser=bam_parser, models=models)
+    if full:
+        import pandas as pd
+        real_read_csv = pd.read_csv
+
+        def read_csv_latin1(*a, **k):   # TREDs.meta.csv is not valid UTF-8 (py2 never decoded it)
+            k.setdefault("encoding", "latin-1")
+            return real_read_csv(*a, **k)
+        pd.read_csv = read_csv_latin1
+        ns.meta = _load("tredparse/meta.py", "tredparse.meta", aliases=("meta",))
+        ns.tred = _load("tredparse/tred.py", "tredparse.tred")
     return ns
 
 

@@ -1,0 +1,178 @@
+"""Batching engine: turns lists of sample x locus units into calls of the C ABI (libtredgpu.so).
+
+The reference calls its kernels one alignment / one locus at a time (bam_parser.py:132-135,
+tred.py:165-167); here the host mirrors (bam_parser.BamParser, models.IntegratedCaller, tred.run)
+collect units and hand them to one Engine, which packs reads, registers the template ladders and
+launches the SW, tally and grid kernels once per batch.  No CPU fallback: constructing an Engine
+needs a GPU.
+"""
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SMALL_VALUE = float(np.exp(-10))  # models.py:34
+
+
+def load_model():
+    """Step-size pdfs (6 x 37) and stutter weights (5) from the package data (models.py:42-84)."""
+    with open(os.path.join(HERE, "data", "model.json")) as fp:
+        m = json.load(fp)
+    step = np.array([m["step_size_by_period"][str(p)] for p in range(1, 7)], np.float64)
+    return step, np.array(m["stutter_weights"], np.float64)
+
+
+class Unit(object):
+    """Everything the hot path needs for one sample x locus (one runBam, tred.py:153-169)."""
+
+    def __init__(self, tred, readlen, reads, depth, ploidy, global_lens, target_lens, maxinsert=300,
+                 fullsearch=False, clip=False, read_pair_ids=None):
+        self.tred = tred
+        self.readlen = int(readlen)
+        self.reads = list(reads)
+        self.depth = float(depth)
+        self.ploidy = int(ploidy)
+        self.global_lens = list(global_lens)
+        self.target_lens = list(target_lens)
+        self.maxinsert = int(maxinsert)
+        self.fullsearch = bool(fullsearch)
+        self.clip = bool(clip)
+        self.read_pair_ids = read_pair_ids  # only for --norepeatpairs
+        period = len(tred.repeat)
+        self.max_units = -(-self.readlen // period)          # bam_parser.py:73
+        self.ref_len = tred.repeat_end - tred.repeat_start + 1  # bam_parser.py:68
+        self.minpe = tred.repeat_end - tred.repeat_start + 2 * 9 + 2   # bam_parser.py:361
+
+
+class UnitResult(object):
+    __slots__ = ("tags", "hs", "scores", "full", "pref", "rept_hist", "rept", "call", "grid", "P_h1", "P_h2")
+
+
+class Engine(object):
+    def __init__(self, device_id=0, ctx=None):
+        self.ctx = ctx or _lib.Context(device_id)
+        step, w = load_model()
+        self.ctx.set_model(step, w)       # gc=.68, score=1.0 (models.py:106)
+        self._ladders = None
+
+    def close(self):
+        self.ctx.close()
+
+    # ---- (1) SW + tagging only -----------------------------------------------------------------------
+    def classify(self, units, want_dump=False):
+        """Per unit: (tags u8[], h i16[], score i16[]) [+ dump].  units: list of Unit."""
+        ladders, lad_index, unit_ladder = [], {}, []
+        for u in units:
+            key = (u.tred.prefix, u.tred.repeat, u.tred.suffix, u.max_units)
+            if key not in lad_index:
+                lad_index[key] = len(ladders)
+                ladders.append(key)
+            unit_ladder.append(lad_index[key])
+        if self._ladders != ladders:
+            self.ctx.set_ladders(ladders)
+            self._ladders = ladders
+        reads = [r for u in units for r in u.reads]
+        packed, woff, rlen = _lib.pack_reads(reads)
+        n = len(reads)
+        uro = np.zeros(len(units) + 1, np.int32)
+        uro[1:] = np.cumsum([len(u.reads) for u in units])
+        tag = np.zeros(max(n, 1), np.uint8)
+        h = np.zeros(max(n, 1), np.int16)
+        sc = np.zeros(max(n, 1), np.int16)
+        nt = max([2 * l[3] for l in ladders] + [1])
+        dump = np.zeros((max(n, 1), nt, 6), np.int16) if want_dump else None
+        clips = set(u.clip for u in units)
+        if len(clips) > 1:
+            raise ValueError("all units of one batch must share the clip setting")
+        params = _lib.default_sw_params(clip=clips.pop() if clips else False)
+        if n:
+            self.ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, uro, np.asarray(unit_ladder, np.int32),
+                                 len(units), params, tag, h, sc, dump, nt if want_dump else 0)
+        if (tag[:n] == _lib.TAG_INVALID).any():
+            raise _lib.TredGpuError("a read exceeds TREDGPU_MAX_READ_LEN")
+        return tag[:n], h[:n], sc[:n], uro, (dump[:n] if want_dump else None)
+
+    # ---- the whole path ------------------------------------------------------------------------------
+    def genotype(self, units, want_grid=True):
+        """SW + tagging -> histograms -> likelihood grid for a batch of units; returns [UnitResult]."""
+        if not units:
+            return []
+        tag, h, sc, uro, _ = self.classify(units)
+        n, g = len(tag), len(units)
+        hs = max(u.max_units for u in units) + 2
+        full = np.zeros((g, hs), np.int32)
+        pref = np.zeros((g, hs), np.int32)
+        rept = np.zeros((g, hs), np.int32)
+        pair_ids = None
+        if any(u.read_pair_ids is not None for u in units):
+            pair_ids = np.concatenate([np.asarray(u.read_pair_ids if u.read_pair_ids is not None
+                                                  else -np.ones(len(u.reads)), np.int32) for u in units])
+        self.ctx.tally(_lib.MEM_HOST, tag if n else np.zeros(1, np.uint8), h if n else np.zeros(1, np.int16), n, uro,
+                       g, pair_ids, hs, full, pref, rept)
+        calls, marg, dump, goff = self._grid(units, hs, full, pref, rept, want_grid)
+        out = []
+        for i, u in enumerate(units):
+            r = UnitResult()
+            r.tags, r.hs, r.scores = tag[uro[i]:uro[i + 1]], h[uro[i]:uro[i + 1]], sc[uro[i]:uro[i + 1]]
+            r.full = {int(k): int(v) for k, v in enumerate(full[i]) if v}
+            r.pref = {int(k): int(v) for k, v in enumerate(pref[i]) if v}
+            r.rept_hist = {int(k): int(v) for k, v in enumerate(rept[i]) if v}
+            r.rept = int(rept[i].sum())
+            r.call = calls[i]
+            r.grid = dump[goff[i]:goff[i] + calls[i]["n_pairs"]] if want_grid and calls[i]["status"] == 0 else None
+            r.P_h1, r.P_h2 = marg[i, 0], marg[i, 1]
+            out.append(r)
+        return out
+
+    def _grid(self, units, hs, full, pref, rept, want_grid):
+        g = len(units)
+        up = np.zeros(g, _lib.UNIT_DTYPE)
+        gl, tl = [], []
+        for i, u in enumerate(units):
+            t = u.tred
+            up[i] = (len(t.repeat), u.readlen, u.ploidy, u.maxinsert, int(u.fullsearch), u.ref_len, u.minpe,
+                     int(t.cutoff_risk), int(t.is_expansion), int(t.is_recessive), len(gl), len(u.global_lens),
+                     len(tl), len(u.target_lens), u.depth / 2)
+            gl += u.global_lens
+            tl += u.target_lens
+        ngl, ntl = len(gl), len(tl)
+        gl = np.asarray(gl or [0], np.int32)
+        tl = np.asarray(tl or [0], np.int32)
+        calls = np.zeros(g, _lib.CALL_DTYPE)
+        ms = max(max(u.maxinsert for u in units), hs) + 2
+        marg = np.zeros((g, 2, ms), np.float64)
+        self.ctx.likelihood_grid(_lib.MEM_HOST, up, g, hs, full, pref, rept, gl, ngl, tl, ntl, calls, None, None,
+                                 marg, ms)
+        dump = goff = None
+        if want_grid:
+            goff = np.zeros(g + 1, np.int64)
+            goff[1:] = np.cumsum(np.maximum(calls["n_pairs"], 1))
+            dump = np.zeros((int(goff[-1]), 6), np.float64)
+            calls2 = np.zeros(g, _lib.CALL_DTYPE)
+            self.ctx.likelihood_grid(_lib.MEM_HOST, up, g, hs, full, pref, rept, gl, ngl, tl, ntl, calls2, goff, dump,
+                                     None, 0)
+        return calls, marg, dump, goff
+
+    def grid_from_counts(self, unit, full, pref, rept):
+        """Likelihood grid of one unit from explicit histograms {units: count} (IntegratedCaller.call)."""
+        keys = list(full) + list(pref) + [unit.max_units]
+        hs = max(keys) + 2
+        f = np.zeros((1, hs), np.int32)
+        p = np.zeros((1, hs), np.int32)
+        r = np.zeros((1, hs), np.int32)
+        for k, v in full.items():
+            f[0, k] = v
+        for k, v in pref.items():
+            p[0, k] = v
+        r[0, 0] = rept
+        calls, marg, dump, goff = self._grid([unit], hs, f, p, r, True)
+        res = UnitResult()
+        res.tags = res.hs = res.scores = None
+        res.full, res.pref, res.rept_hist, res.rept = dict(full), dict(pref), {}, rept
+        res.call = calls[0]
+        res.grid = dump[goff[0]:goff[0] + calls[0]["n_pairs"]] if calls[0]["status"] == 0 else None
+        res.P_h1, res.P_h2 = marg[0, 0], marg[0, 1]
+        return res
