@@ -53,7 +53,7 @@ def test_locus_table_and_labels():
     assert repo["AR"].is_expansion is False and repo["FRDA"].is_recessive and repo["FXS"].is_xlinked
     assert TREDsRepo(ref="hg19_nochr")["HD"].chr == "4"
     assert calc_label(repo["HD"], [15, 41]) == "risk" and calc_label(repo["HD"], [15, 37]) == "prerisk"
-    assert calc_label(repo["HD"], [-1, -1]) == "missing" and calc_label(repo["AR"], [6, 21]) == "risk"
+    assert calc_label(repo["HD"], [-1, -1]) == "missing" and calc_label(repo["AR"], [6, 21]) == "ok" and calc_label(repo["AR"], [6, 7]) == "risk"
     assert calc_label(repo["FRDA"], [20, 80]) == "ok" and calc_label(repo["FRDA"], [70, 80]) == "risk"
     assert rc("ACGTNacgtn") == "nacgtNACGT"
     repo.set_ploidy(["chrX"])
