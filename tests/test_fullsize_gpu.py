@@ -1,0 +1,131 @@
+"""GPU, BASELINE-size batches: properties that do not need the (slow) CPU oracle for every unit --
+idempotence, unit-order invariance, histogram/tag consistency, device-memory vs host-memory paths --
+plus an oracle spot check on a random subset and a full oracle check of the tags on a mid-size batch
+spanning all 32 loci (the non-dump path, i.e. with every exact shortcut of the kernel active)."""
+import numpy as np
+import pytest
+
+from oracle import lik_oracle as lo
+from oracle import pyoracle as po
+from tredparse_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(ctx):
+    step, w = lo.load_model()
+    ctx.set_model(np.array([step[p] for p in range(1, 7)]), np.array(w))
+
+
+def _run(ctx, b, order=None):
+    """Fused path on host buffers; order = permutation of units (reads are re-laid out accordingly)."""
+    g = b.n_units
+    order = np.arange(g) if order is None else np.asarray(order)
+    sizes = np.diff(b.unit_read_off)[order]
+    uro = np.zeros(g + 1, np.int32)
+    uro[1:] = np.cumsum(sizes)
+    ridx = np.concatenate([np.arange(b.unit_read_off[u], b.unit_read_off[u + 1]) for u in order])
+    W = int(b.read_off[1] - b.read_off[0])
+    packed = b.packed.reshape(-1, W)[ridx].reshape(-1).copy()
+    roff = (np.arange(len(ridx) + 1, dtype=np.int64) * W)
+    rlen = b.read_len[ridx].copy()
+    n = len(ridx)
+    tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
+    hs = b.hist_stride
+    full = np.zeros((g, hs), np.int32); pref = np.zeros((g, hs), np.int32); rept = np.zeros((g, hs), np.int32)
+    calls = np.zeros(g, _lib.CALL_DTYPE)
+    ctx.genotype_batch(_lib.MEM_HOST, packed, roff, rlen, n, uro, b.unit_ladder[order].copy(), b.units[order].copy(), g,
+                       _lib.default_sw_params(max_read_len=150), None, b.global_lens, len(b.global_lens),
+                       b.target_lens, len(b.target_lens), tag, h, sc, hs, full, pref, rept, calls)
+    return dict(tag=tag, h=h, sc=sc, full=full, pref=pref, rept=rept, calls=calls, uro=uro, ridx=ridx)
+
+
+def test_full_size_properties(ctx, loci):
+    _model(ctx)
+    sel = [l for l in loci if l["name"] not in ("FXTAS", "AR")]
+    b = synth.build_batch(20260101, sel, 200, synth.SynthParams(coverage=30), workers=16)   # 6 000 units, ~580 k reads
+    ctx.set_ladders(b.ladders)
+    r1 = _run(ctx, b)
+    r2 = _run(ctx, b)
+    for k in ("tag", "h", "sc", "full", "pref", "rept"):
+        assert np.array_equal(r1[k], r2[k]), k                           # idempotent, bit for bit
+    assert r1["calls"].tobytes() == r2["calls"].tobytes()
+    # unit order must not matter (units are independent; quads never mix units)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(b.n_units)
+    r3 = _run(ctx, b, perm)
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    assert r3["calls"][inv].tobytes() == r1["calls"].tobytes()
+    back = np.empty(len(r3["ridx"]), np.int64); back[r3["ridx"]] = np.arange(len(r3["ridx"]))
+    assert np.array_equal(r3["tag"][back], r1["tag"]) and np.array_equal(r3["h"][back], r1["h"])
+    # histograms == recount of the tags (bam_parser.py:259-268; POST lands in PREF's bins)
+    unit_of = np.repeat(np.arange(b.n_units), np.diff(b.unit_read_off))
+    for name, tags in (("full", (1,)), ("pref", (2, 3)), ("rept", (4,))):
+        m = np.isin(r1["tag"], tags)
+        want = np.zeros_like(r1[name])
+        np.add.at(want, (unit_of[m], r1["h"][m].astype(np.int64)), 1)
+        assert np.array_equal(want, r1[name]), name
+    # every unit got a call; the short allele is recovered exactly most of the time
+    assert (r1["calls"]["status"] == 0).all()
+    ok = (r1["calls"]["h1"] // b.units["period"]) == b.h_true[:, 0]
+    assert ok.mean() > 0.75
+    # oracle spot check (classification + likelihood) on 24 random units
+    ls = po.LocusSet(b.ladders)
+    for u in rng.choice(b.n_units, 24, replace=False):
+        r0, r1_ = b.unit_read_off[u], b.unit_read_off[u + 1]
+        reads = [synth.decode(x) for x in b.codes[r0:r1_]]
+        cls = po.classify(reads, np.full(len(reads), b.unit_ladder[u], np.int32), ls, threads=0)
+        assert np.array_equal(r1["tag"][r0:r1_], cls[:, 0].astype(np.uint8)), u
+        assert np.array_equal(r1["h"][r0:r1_], cls[:, 1].astype(np.int16)), u
+        up = b.units[u]
+        f = {k: int(v) for k, v in enumerate(r1["full"][u]) if v}
+        pp = {k: int(v) for k, v in enumerate(r1["pref"][u]) if v}
+        res = lo.Caller(int(up["period"]), 150, 2, 2 * float(up["half_depth"]), f, pp, int(r1["rept"][u].sum()),
+                        b.global_lens[up["pe_off"]:up["pe_off"] + up["n_global"]],
+                        b.target_lens[up["tl_off"]:up["tl_off"] + up["n_target"]], int(up["ref_len"]),
+                        int(up["minpe"])).evaluate()
+        c = r1["calls"][u]
+        assert (c["h1"], c["h2"]) == tuple(res["alleles"]), u
+        assert abs(c["lik"] - res["lik"]) <= 1e-6 and tuple(c["ci"]) == tuple(res["CI"])
+
+
+def test_all_loci_tags_against_oracle(ctx, loci):
+    """Every read of a 32-locus batch through the pruned (non-dump) kernel path vs the oracle."""
+    b = synth.build_batch(77, loci, 6, synth.SynthParams(coverage=30, expanded_max=150, expanded_frac=0.3), workers=8)
+    ctx.set_ladders(b.ladders)
+    n = b.n_reads
+    tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
+    ctx.sw_classify(_lib.MEM_HOST, b.packed, b.read_off, b.read_len, n, b.unit_read_off, b.unit_ladder, b.n_units,
+                    _lib.default_sw_params(max_read_len=150), tag, h, sc)
+    reads = [synth.decode(r) for r in b.codes]
+    cls = po.classify(reads, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), po.LocusSet(b.ladders), threads=0)
+    bad = np.nonzero((tag != cls[:, 0]) | (h != cls[:, 1]) | (sc != cls[:, 2]))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], tag[bad[:5]], cls[bad[:5]])
+    assert (tag == 4).sum() > 0 and (tag == 1).sum() > 0 and (tag == 5).sum() > 0
+
+
+def test_device_memory_path_matches_host_path(ctx, loci):
+    torch = pytest.importorskip("torch")
+    _model(ctx)
+    sel = [l for l in loci if l["name"] in ("HD", "DM1", "SCA10", "ULD")]
+    b = synth.build_batch(5, sel, 12, synth.SynthParams(coverage=30))
+    ctx.set_ladders(b.ladders)
+    ref = _run(ctx, b)
+    dev = torch.device("cuda", 0)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    n, g, hs = b.n_reads, b.n_units, b.hist_stride
+    d = dict(packed=dv(b.packed.view(np.int32)), roff=dv(b.read_off), rlen=dv(b.read_len), uoff=dv(b.unit_read_off),
+             ulad=dv(b.unit_ladder), units=dv(b.units.view(np.uint8)), gl=dv(b.global_lens), tl=dv(b.target_lens),
+             tag=torch.zeros(n, dtype=torch.uint8, device=dev), h=torch.zeros(n, dtype=torch.int16, device=dev),
+             sc=torch.zeros(n, dtype=torch.int16, device=dev),
+             full=torch.zeros((g, hs), dtype=torch.int32, device=dev), pref=torch.zeros((g, hs), dtype=torch.int32, device=dev),
+             rept=torch.zeros((g, hs), dtype=torch.int32, device=dev),
+             calls=torch.zeros(g * _lib.CALL_DTYPE.itemsize, dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize()
+    ctx.genotype_batch(_lib.MEM_DEVICE, d["packed"], d["roff"], d["rlen"], n, d["uoff"], d["ulad"], d["units"], g,
+                       _lib.default_sw_params(max_read_len=150), None, d["gl"], len(b.global_lens), d["tl"],
+                       len(b.target_lens), d["tag"], d["h"], d["sc"], hs, d["full"], d["pref"], d["rept"], d["calls"])
+    ctx.sync()
+    assert np.array_equal(d["tag"].cpu().numpy(), ref["tag"]) and np.array_equal(d["h"].cpu().numpy(), ref["h"])
+    assert np.array_equal(d["full"].cpu().numpy(), ref["full"]) and np.array_equal(d["rept"].cpu().numpy(), ref["rept"])
+    assert d["calls"].cpu().numpy().tobytes() == ref["calls"].tobytes()
