@@ -37,7 +37,7 @@ struct tredgpu_ctx {
     Buf d_model;
     bool have_model = false;
     // workspaces (grow-only, reused across calls)
-    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats;
+    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class;
     Buf st[24];  // staging for HOST-memory calls
     // intermediates of the fused path
     Buf ws_tag, ws_h, ws_score;
@@ -222,7 +222,7 @@ void tredgpu_destroy(tredgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (Buf* b : {&c->d_ladders, &c->d_seq, &c->d_model, &c->ws_quads, &c->ws_counter, &c->ws_drop,
-                   &c->ws_grid, &c->ws_stats, &c->ws_tag, &c->ws_h, &c->ws_score})
+                   &c->ws_grid, &c->ws_stats, &c->ws_perm, &c->ws_class, &c->ws_tag, &c->ws_h, &c->ws_score})
         release(*b);
     for (Buf& b : c->st) release(b);
     for (auto& t : c->timers)
@@ -419,11 +419,10 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
                          int32_t n_units, const tredgpu_sw_params* p, int max_len, uint8_t* out_tag,
                          int16_t* out_h, int16_t* out_score, int16_t* out_dump, int32_t dump_templates) {
     if (n_reads == 0 || n_units == 0) return 0;
-    const int64_t max_quads = n_reads / 4 + n_units + 1;
+    const int64_t max_quads = n_reads / 4 + 3 * (int64_t)n_units + 1;
     int rc;
     if ((rc = ensure(c, c->ws_quads, (size_t)max_quads * sizeof(Quad)))) return rc;
     if ((rc = ensure(c, c->ws_counter, 64))) return rc;
-    HIPCHK(c, launch_build_quads(unit_read_off, n_units, (Quad*)c->ws_quads.p, (int32_t*)c->ws_counter.p, c->stream));
     SwArgs a;
     a.packed = packed;
     a.read_off = read_off;
@@ -440,7 +439,14 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     a.out_dump = out_dump;
     a.dump_templates = dump_templates;
     a.n_units = n_units;
+    a.max_rows = 16 * rows_for(max_len);
     a.p = *p;
+    a.stats = nullptr;
+    if ((rc = ensure(c, c->ws_perm, (size_t)n_reads * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->ws_class, (size_t)n_reads))) return rc;
+    a.perm = (const int32_t*)c->ws_perm.p;
+    HIPCHK(c, launch_build_quads(a, (uint8_t*)c->ws_class.p, (int32_t*)c->ws_perm.p, (Quad*)c->ws_quads.p,
+                                 (int32_t*)c->ws_counter.p, c->stream));
     if (c->ws_stats.p == nullptr) {
         if ((rc = ensure(c, c->ws_stats, 8 * sizeof(unsigned long long)))) return rc;
         HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));

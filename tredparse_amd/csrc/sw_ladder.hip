@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
     const int nq = *a.n_quads;
     if (q >= nq) return;
     const int q_unit = __builtin_amdgcn_readfirstlane(a.quads[q].unit);
-    const int q_read0 = __builtin_amdgcn_readfirstlane(a.quads[q].read0);
+    const int q_first = __builtin_amdgcn_readfirstlane(a.quads[q].first);
+    const int q_strands = __builtin_amdgcn_readfirstlane(a.quads[q].strands);
     const int q_count = __builtin_amdgcn_readfirstlane(a.quads[q].count);
     const LadderDesc* ld = a.ladders + __builtin_amdgcn_readfirstlane(a.unit_ladder[q_unit]);
     const int period = __builtin_amdgcn_readfirstlane(ld->period);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
 
     const int job = lane >> 4, jl = lane & 15;
     const bool valid = job < q_count;
-    const int64_t rd = (int64_t)q_read0 + job;
+    const int64_t rd = valid ? (int64_t)a.perm[q_first + job] : 0;
     int L = valid ? a.read_len[rd] : 0;
     const bool too_long = L > 16 * R;  // not representable in this instantiation: flagged, not aligned
     if (too_long) L = 0;
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
     const int floor_key = (full_dump ? 0 : 29) << KSH | PAYMASK;
 
     for (int s = 0; s < n_strands; ++s) {
+        if (!((q_strands >> s) & 1)) continue;
         const int trunk_w = __builtin_amdgcn_readfirstlane(ld->trunk_off[s]);
         const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
         const int alen = __builtin_amdgcn_readfirstlane(ld->alen[s]);
@@ -459,21 +461,76 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
     }
 }
 
-__global__ void build_quads_kernel(const int32_t* unit_read_off, int32_t n_units, Quad* quads,
-                                   int32_t* n_quads) {
+// Strand classes for quad formation.  The exact 6-mer strand filter (see sw_ladder_kernel) is evaluated
+// per read here, once: bit s of the class = "strand s can reach the score filter for this read".  Reads
+// that need no strand at all are finished on the spot (no candidate: tag NONE); the others are grouped so
+// that the four reads of a wavefront need the same strands.
+__global__ void read_class_kernel(SwArgs a, uint8_t* read_class) {
+    const int g = blockIdx.x;
+    if (g >= a.n_units) return;
+    const LadderDesc* ld = a.ladders + a.unit_ladder[g];
+    const bool full_dump = a.out_dump != nullptr;
+    const int thr = min(a.p.mismatch, a.p.gap_open) >= 5 * a.p.match ? (30 + a.p.match - 1) / a.p.match - 5 : 0;
+    const bool filt = !full_dump && thr > 0 && ld->kmer_ok != 0 && ld->max_units > 0;
+    const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
+    for (int rd = r0 + (int)threadIdx.x; rd < r1; rd += (int)blockDim.x) {
+        int cls = ld->n_strands >= 2 ? 3 : 1;
+        const int L = a.read_len[rd];
+        if (filt && L <= a.max_rows) {   // over-long reads go to the SW kernel, which flags them
+            const int64_t off = a.read_off[rd];
+            const int nb = (L + 15) >> 4;
+            const uint32_t* bm0 = a.seqw + ld->kmer_off[0];
+            const uint32_t* bm1 = a.seqw + ld->kmer_off[1];
+            int cnt0 = 0, cnt1 = 0, since_n = 0;
+            uint32_t win = 0, w = 0, m = 0;
+            for (int i = 0; i < L; ++i) {
+                if ((i & 15) == 0) w = a.packed[off + (i >> 4)];
+                if ((i & 31) == 0) m = a.packed[off + nb + (i >> 5)];
+                const bool isn = (m >> (i & 31)) & 1u;
+                win = (win >> 2) | (((w >> ((i & 15) * 2)) & 3u) << 10);   // base i-5 ends up in the low bits
+                since_n = isn ? 0 : since_n + 1;
+                if (i >= 5) {
+                    const bool has_n = since_n < 6;
+                    cnt0 += has_n || ((bm0[win >> 5] >> (win & 31)) & 1u);
+                    cnt1 += has_n || ((bm1[win >> 5] >> (win & 31)) & 1u);
+                }
+            }
+            cls = (cnt0 >= thr ? 1 : 0) | (cnt1 >= thr ? 2 : 0);
+        }
+        read_class[rd] = (uint8_t)cls;
+        if (cls == 0) {   // no strand can produce a candidate: bam_parser.py:171-172 "if not res: return"
+            a.out_tag[rd] = TREDGPU_TAG_NONE;
+            a.out_h[rd] = 0;
+            a.out_score[rd] = 0;
+        }
+    }
+}
+
+__global__ void build_quads_kernel(SwArgs a, const uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_units) return;
-    const int r0 = unit_read_off[g], n = unit_read_off[g + 1] - r0;
-    const int nq = (n + 3) >> 2;
+    if (g >= a.n_units) return;
+    const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
+    int n_c[4] = {0, 0, 0, 0};
+    for (int r = r0; r < r1; ++r) ++n_c[read_class[r] & 3];
+    // layout inside the unit's slice of perm: class 1 | class 3 | class 2 | class 0 (stable within a class)
+    const int order[4] = {1, 3, 2, 0};
+    int start[4], pos = r0, nq = 0;
+    for (int k = 0; k < 4; ++k) { start[order[k]] = pos; pos += n_c[order[k]]; }
+    for (int c = 1; c < 4; ++c) nq += (n_c[c] + 3) >> 2;
+    int fill[4] = {start[0], start[1], start[2], start[3]};
+    for (int r = r0; r < r1; ++r) perm[fill[read_class[r] & 3]++] = r;
     if (nq == 0) return;
-    const int base = atomicAdd(n_quads, nq);
-    for (int k = 0; k < nq; ++k) {
-        Quad qd;
-        qd.unit = g;
-        qd.read0 = r0 + 4 * k;
-        qd.count = min(4, n - 4 * k);
-        qd.pad = 0;
-        quads[base + k] = qd;
+    int base = atomicAdd(n_quads, nq);
+    for (int k = 0; k < 3; ++k) {
+        const int c = order[k];
+        for (int j = 0; j < n_c[c]; j += 4) {
+            Quad qd;
+            qd.unit = g;
+            qd.first = start[c] + j;
+            qd.count = min(4, n_c[c] - j);
+            qd.strands = c;
+            quads[base++] = qd;
+        }
     }
 }
 
@@ -514,12 +571,13 @@ __global__ void tally_kernel(const uint8_t* tag, const int16_t* h, const int32_t
 
 }  // namespace
 
-hipError_t launch_build_quads(const int32_t* unit_read_off, int32_t n_units, Quad* quads,
-                              int32_t* n_quads, hipStream_t s) {
+hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads,
+                              hipStream_t s) {
     hipError_t e = hipMemsetAsync(n_quads, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return e;
-    if (n_units <= 0) return hipSuccess;
-    build_quads_kernel<<<(n_units + 255) / 256, 256, 0, s>>>(unit_read_off, n_units, quads, n_quads);
+    if (a.n_units <= 0) return hipSuccess;
+    read_class_kernel<<<a.n_units, 64, 0, s>>>(a, read_class);
+    build_quads_kernel<<<(a.n_units + 255) / 256, 256, 0, s>>>(a, read_class, perm, quads, n_quads);
     return hipGetLastError();
 }
 

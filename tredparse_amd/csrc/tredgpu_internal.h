@@ -25,9 +25,9 @@ struct LadderDesc {
 // A quad = up to four reads of one unit that share a wavefront (16 lanes each).
 struct Quad {
     int32_t unit;
-    int32_t read0;
+    int32_t first;    // index into the permutation array: reads perm[first .. first+count)
     int32_t count;
-    int32_t pad;
+    int32_t strands;  // bit s set: strand s has to be swept (all reads of a quad share the class)
 };
 
 struct SwArgs {
@@ -39,6 +39,7 @@ struct SwArgs {
     const LadderDesc* ladders;
     const uint32_t* seqw;  // ladder letters, 8 per word (4 bits each)
     const Quad* quads;
+    const int32_t* perm;     // class-sorted read order (see build_quads)
     const int32_t* n_quads;  // device counter written by build_quads
     uint8_t* out_tag;
     int16_t* out_h;
@@ -46,13 +47,14 @@ struct SwArgs {
     int16_t* out_dump;
     int32_t dump_templates;
     int32_t n_units;
+    int32_t max_rows;        // 16 * rows-per-lane of the instantiation that will run
     tredgpu_sw_params p;
     unsigned long long* stats;  // work counters: trunk cols, branch cols, branches swept/dropped/emitted-from-trunk, waves
 };
 
 // sw_ladder.hip
-hipError_t launch_build_quads(const int32_t* unit_read_off, int32_t n_units, Quad* quads,
-                              int32_t* n_quads, hipStream_t s);
+hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads,
+                              hipStream_t s);
 hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s);
 hipError_t launch_tally(const uint8_t* tag, const int16_t* h, int64_t n_reads,
                         const int32_t* unit_read_off, int32_t n_units, const int32_t* read_pair_id,
