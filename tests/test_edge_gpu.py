@@ -1,0 +1,131 @@
+"""GPU: edge cases of the C ABI -- empty and ragged inputs, degenerate reads, maximum sizes, other scorings,
+--norepeatpairs, error reporting (SURVEY section 5 failure semantics)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import lik_oracle as lo
+from oracle import pyoracle as po
+from tredparse_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+HD = ("GAGTCCCTCAAGTCCTTC", "CAG", "CAACAGCCGCCACCGCCG", 50)
+
+
+def _classify(ctx, ladders, reads, uro, ul, params=None, dump=False):
+    ctx.set_ladders(ladders)
+    packed, woff, rlen = _lib.pack_reads(reads)
+    n = len(reads)
+    tag = np.zeros(max(n, 1), np.uint8); h = np.zeros(max(n, 1), np.int16); sc = np.zeros(max(n, 1), np.int16)
+    nt = max(2 * l[3] for l in ladders) if dump else 0
+    d = np.zeros((max(n, 1), max(nt, 1), 6), np.int16) if dump else None
+    ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, np.asarray(uro, np.int32), np.asarray(ul, np.int32), len(ul),
+                    params or _lib.default_sw_params(), tag, h, sc, d, nt)
+    return tag[:n], h[:n], sc[:n], d
+
+
+def test_empty_and_zero_read_units(ctx):
+    step, w = lo.load_model()
+    ctx.set_model(np.array([step[p] for p in range(1, 7)]), np.array(w))
+    tag, h, sc, _ = _classify(ctx, [HD], [], [0], [])
+    assert len(tag) == 0
+    # three units, the middle one without reads; fused path gives "no evidence" for it
+    lb = synth.simulate_locus(np.random.default_rng(2), [l for l in synth.load_loci() if l["name"] == "HD"][0], 2,
+                              synth.SynthParams(coverage=20), h_pairs=[[15, 41], [17, 19]])
+    reads = [synth.decode(r) for r in lb.reads]
+    n0 = int(lb.unit_read_off[1])
+    uro = np.array([0, n0, n0, len(reads)], np.int32)
+    packed, woff, rlen = _lib.pack_reads(reads)
+    units = np.zeros(3, _lib.UNIT_DTYPE)
+    locus = [l for l in synth.load_loci() if l["name"] == "HD"][0]
+    for i in range(3):
+        units[i] = synth.unit_params_for(locus, 150, 30.0, 0, 0, 0, 0)
+    n, hs = len(reads), 52
+    tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
+    full = np.zeros((3, hs), np.int32); pref = np.zeros((3, hs), np.int32); rept = np.zeros((3, hs), np.int32)
+    calls = np.zeros(3, _lib.CALL_DTYPE)
+    ctx.set_ladders([HD])
+    ctx.genotype_batch(_lib.MEM_HOST, packed, woff, rlen, n, uro, np.zeros(3, np.int32), units, 3,
+                       _lib.default_sw_params(), None, np.zeros(1, np.int32), 0, np.zeros(1, np.int32), 0, tag, h, sc, hs,
+                       full, pref, rept, calls)
+    assert calls["status"].tolist() == [0, 1, 0]
+    assert (calls[0]["h1"] // 3, calls[2]["h1"] // 3) == (15, 17)
+    assert full[1].sum() == 0 and pref[1].sum() == 0
+
+
+def test_degenerate_reads_and_length_limits(ctx):
+    rng = np.random.default_rng(8)
+    tmpl = HD[0] + "CAG" * 30 + HD[2]
+    reads = ["A", "ACGTA", "N" * 150, "", tmpl[:160], tmpl[5:155], "CAG" * 50, "acgt" * 30 + "nnn", tmpl[:64], tmpl[3:115]]
+    tag, h, sc, dump = _classify(ctx, [HD], reads, [0, len(reads)], [0], dump=True)
+    ls = po.LocusSet([HD])
+    cls = po.classify(reads, np.zeros(len(reads), np.int32), ls)
+    assert np.array_equal(tag, cls[:, 0].astype(np.uint8)) and np.array_equal(h, cls[:, 1].astype(np.int16))
+    for r, read in enumerate(reads):
+        want = po.sw_pairs([read], ls.templates, [0] * 100, list(range(100)))
+        assert np.array_equal(dump[r, :, :5].astype(np.int32), want), r
+    # a read longer than the declared bound is flagged, never truncated
+    p = _lib.default_sw_params(max_read_len=150)
+    long_reads = [tmpl[:150], (tmpl * 2)[:200]]
+    t2, _, _, _ = _classify(ctx, [HD], long_reads, [0, 2], [0], params=p)
+    assert t2[1] == _lib.TAG_INVALID and t2[0] != _lib.TAG_INVALID
+    # 250 bp reads take the 16-rows-per-lane instantiation
+    mu = -(-250 // 3)
+    lad = (HD[0], "CAG", HD[2], mu)
+    r250 = [(HD[0] + "CAG" * 70 + HD[2] + "ACGT" * 30)[:250], po.rc((("TTGCA" * 10) + HD[0] + "CAG" * 40 + HD[2] + "GATTACA" * 20)[:250])]
+    t3, h3, s3, _ = _classify(ctx, [lad], r250, [0, 2], [0])
+    c3 = po.classify(r250, np.zeros(2, np.int32), po.LocusSet([lad]))
+    assert np.array_equal(t3, c3[:, 0]) and np.array_equal(h3, c3[:, 1]) and np.array_equal(s3, c3[:, 2])
+
+
+@pytest.mark.parametrize("scoring", [(2, 2, 3, 1), (1, 4, 6, 1), (1, 5, 7, 2)])
+def test_other_scorings_dump(ctx, scoring):
+    rng = np.random.default_rng(sum(scoring))
+    lad = ("GGCAGCCGCGGGCGGCGG", "CTG", "GGGCTTCAGCGACATGGT", 34)
+    hap = "".join("ACGT"[i] for i in rng.integers(0, 4, 200)) + lad[0] + "CTG" * 22 + lad[2] + "".join("ACGT"[i] for i in rng.integers(0, 4, 200))
+    reads = [hap[s:s + 100] for s in range(120, 300, 9)]
+    reads = [r if i % 3 else po.rc(r) for i, r in enumerate(reads)]
+    p = _lib.SwParams(scoring[0], scoring[1], scoring[2], scoring[3], 9, 0, 0, 0)
+    tag, h, sc, dump = _classify(ctx, [lad], reads, [0, len(reads)], [0], params=p, dump=True)
+    ls = po.LocusSet([lad])
+    for r, read in enumerate(reads):
+        want = po.sw_pairs([read], ls.templates, [0] * 68, list(range(68)), scoring=scoring)
+        assert np.array_equal(dump[r, :, :5].astype(np.int32), want), (scoring, r)
+    cls = po.classify(reads, np.zeros(len(reads), np.int32), ls, scoring=scoring)
+    t2, h2, s2, _ = _classify(ctx, [lad], reads, [0, len(reads)], [0], params=p)     # pruned path
+    assert np.array_equal(t2, cls[:, 0]) and np.array_equal(h2, cls[:, 1]) and np.array_equal(s2, cls[:, 2])
+
+
+def test_norepeatpairs_removes_rept_mates(ctx):
+    """remove_pairs_of_rept (bam_parser.py:270-287) on the device histograms."""
+    tag = np.array([4, 4, 4, 1, 4, 2, 4, 4], np.uint8)      # REPT REPT REPT FULL REPT PREF | REPT REPT
+    h = np.array([50, 49, 50, 20, 50, 12, 50, 50], np.int16)
+    pair = np.array([7, 7, 8, 8, 9, 9, 3, 4], np.int32)      # reads 0,1 are mates and both REPT -> dropped
+    uro = np.array([0, 6, 8], np.int32)
+    hs = 52
+    full = np.zeros((2, hs), np.int32); pref = np.zeros((2, hs), np.int32); rept = np.zeros((2, hs), np.int32)
+    ctx.tally(_lib.MEM_HOST, tag, h, 8, uro, 2, pair, hs, full, pref, rept)
+    assert rept[0].sum() == 2 and rept[0, 50] == 2 and full[0, 20] == 1 and pref[0, 12] == 1
+    assert rept[1].sum() == 2
+    ctx.tally(_lib.MEM_HOST, tag, h, 8, uro, 2, None, hs, full, pref, rept)
+    assert rept[0].sum() == 4
+
+
+def test_error_reporting(ctx):
+    lib = ctx.lib
+    p = _lib.default_sw_params()
+    one = np.zeros(4, np.int32)
+    rc = lib.tredgpu_sw_classify(ctx.h, 0, None, None, None, 5, None, None, 1, C.byref(p), None, None, None, None, 0)
+    assert rc < 0 and b"NULL" in lib.tredgpu_last_error(ctx.h)
+    bad = _lib.SwParams(1, 5, 2, 7, 9, 0, 0, 0)            # gap_extend > gap_open
+    rc = lib.tredgpu_sw_classify(ctx.h, 0, one.ctypes.data, one.ctypes.data, one.ctypes.data, 0, one.ctypes.data,
+                                 one.ctypes.data, 0, C.byref(bad), one.ctypes.data, one.ctypes.data, one.ctypes.data, None, 0)
+    assert rc < 0 and b"scoring" in lib.tredgpu_last_error(ctx.h)
+    with pytest.raises(_lib.TredGpuError):
+        ctx.set_ladders([("ACGT" * 5, "CAG", "ACGT" * 5, 200)])      # template longer than 511
+    ctx.set_ladders([HD])
+    packed, woff, rlen = _lib.pack_reads(["ACGT" * 30])
+    with pytest.raises(_lib.TredGpuError):                            # ladder index out of range
+        ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, 1, np.array([0, 1], np.int32), np.array([3], np.int32), 1, p,
+                        np.zeros(1, np.uint8), np.zeros(1, np.int16), np.zeros(1, np.int16))
