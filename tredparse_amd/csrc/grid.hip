@@ -151,16 +151,36 @@ __device__ double rept_term(const PairCtx& C, int dsum) {
 template <bool TABLES>
 __device__ double pe_term(const PairCtx& C, int h1, int h2, const double* r1, const double* r2, int r2_stride) {
     double ml4 = 0, prod = 1.0;
-    int k = 0;
-    for (int i = 0; i < C.n_target; ++i) {
-        double p1, p2;
-        if (TABLES) { p1 = r1[i]; p2 = r2[(size_t)i * r2_stride]; }
-        else {
-            int x = C.tl[i];
-            if (x < 0) x += SPAN;
-            p1 = roll_at(C.pdf, C.ref_len, C.minpe, h1, x, C.small);
-            p2 = roll_at(C.pdf, C.ref_len, C.minpe, h2, x, C.small);
+    const int n = C.n_target;
+    if (TABLES) {
+        // 8 factors per step with all 16 loads issued up front (the tables live in L2-resident scratch);
+        // same multiplication order as the plain loop, padding factors are exactly 1.0
+        for (int base = 0; base < n; base += 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = min(base + q, n - 1);
+                a[q] = r1[idx];
+                b[q] = r2[(size_t)idx * r2_stride];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double p = .5 * a[q] + (1 - .5) * b[q];
+                if (p < C.small) p = C.small;
+                if (base + q >= n) p = 1.0;
+                prod *= p;
+            }
+            if ((base & 31) == 24) { ml4 += log(prod); prod = 1.0; }
         }
+        if (n & 31) ml4 += log(prod);
+        return ml4;
+    }
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        int x = C.tl[i];
+        if (x < 0) x += SPAN;
+        const double p1 = roll_at(C.pdf, C.ref_len, C.minpe, h1, x, C.small);
+        const double p2 = roll_at(C.pdf, C.ref_len, C.minpe, h2, x, C.small);
         double p = .5 * p1 + (1 - .5) * p2;
         if (p < C.small) p = C.small;
         prod *= p;
