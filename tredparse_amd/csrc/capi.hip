@@ -593,10 +593,6 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     a.kde_pdf = nullptr;
     a.kde_status = nullptr;
     {
-        static const char* dbg = getenv("TREDGPU_GRID_SKIP");
-        a.debug_skip = dbg ? atoi(dbg) : 0;
-    }
-    {
         ScopedTimer tm(c, TREDGPU_KERNEL_GRID);
         HIPCHK(c, launch_grid(a, (double*)c->ws_grid.p, (int32_t*)c->ws_counter.p + 4, c->stream));
     }
@@ -665,7 +661,6 @@ int tredgpu_pe_kde(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, in
     GridArgs a;
     memset(&a, 0, sizeof a);
     a.n_units = n_units;
-    a.debug_skip = 0;
     int rc;
     if (mem == TREDGPU_MEM_DEVICE) {
         a.units = units;

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
                 for (int i = tid; i < u.n_global; i += NT) { const double d = gl[i] - mean; q += d * d; }
                 rc = block_sum(q, S.red) > 0 ? 0 : -2;
             } else {
-                rc = (a.debug_skip & 1) ? 0 : kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag, S.far1);
+                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag, S.far1);
             }
             if (rc) status = rc;
         }
@@ -489,7 +489,6 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
             if (u.ploidy == 1) cnt = 1;
             else for (int j = 0; j < ncol; ++j) cnt += axis_value(ax2, S.obs.base, period, j) >= h1;
             S.row_off[i] = cnt;
-            if (a.debug_skip & 32) { S.far1[i] = 0; S.far2[i] = 0; } else
             eval_reads(C, h1, max(h_far, h1), S.far1[i], S.far2[i]);
         }
         __syncthreads();
@@ -560,12 +559,11 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
                 else {
                     double ml4[4];
                     if (h2 >= h_far) { ml4[0] = S.far1[i]; ml4[1] = S.far2[i]; }
-                    else if (a.debug_skip & 64) { ml4[0] = 0; ml4[1] = 0; }
                     else eval_reads(C, h1, h2, ml4[0], ml4[1]);
                     const int dsum = max(h1 - readlen, 1) + max(h2 - readlen, 1);
-                    ml4[2] = (a.debug_skip & 4) ? 0.0 : (use_rept_tab ? rept_tab[dsum] : rept_term(C, dsum));
+                    ml4[2] = use_rept_tab ? rept_tab[dsum] : rept_term(C, dsum);
                     ml4[3] = 0;
-                    if (run_pe && !(a.debug_skip & 2)) {
+                    if (run_pe) {
                         if (use_roll_tab && u.ploidy != 1)
                             ml4[3] = pe_term<true>(C, h1, h2, roll1 + (size_t)i * u.n_target, roll2 + j, ncol);
                         else ml4[3] = pe_term<false>(C, h1, h2, nullptr, nullptr, 0);
@@ -607,7 +605,7 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
                 const int h1 = axis_value(ax1, S.obs.base, period, i);
                 const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
                 if (h1 <= h2) {   // else mlbuf[pos] stays 0: contributes nothing to the sums below
-                    const double e = (a.debug_skip & 8) ? mlbuf[pos] : exp(mlbuf[pos] - max_ml);
+                    const double e = exp(mlbuf[pos] - max_ml);
                     mlbuf[pos] = e;
                     all += e;
                     const int lo = h1 / period, hi = h2 / period;
@@ -626,7 +624,7 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
         for (int m = tid; m < mlim; m += NT) { S.ph1[m] = 0; S.ph2[m] = 0; }
         __syncthreads();  // also orders the mlbuf writes above before the reads below
         // marginal P_h1: one wave per row (fixed shuffle tree), rows merged by key in row order
-        for (int i = tid >> 6; i < ((a.debug_skip & 16) ? 0 : nrow); i += NT / 64) {
+        for (int i = tid >> 6; i < nrow; i += NT / 64) {
             double acc = 0;
             for (int j = tid & 63; j < ncol; j += 64) acc += mlbuf[i * ncol + j];
             acc = wave_sum(acc);
@@ -642,7 +640,7 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
         // marginal P_h2: one thread per distinct h2 value, rows outermost as in the reference.  The
         // extended axis can list a value twice (base part + arithmetic part, models.py:251-252): the
         // first occurrence owns the sum.
-        if (u.ploidy != 1 && !(a.debug_skip & 16)) {
+        if (u.ploidy != 1) {
             for (int j = tid; j < ncol; j += NT) {
                 const int h2 = axis_value(ax2, S.obs.base, period, j);
                 int twin = -1;

@@ -87,7 +87,6 @@ struct GridArgs {
     const ModelConst* model;
     double* kde_pdf;      // tredgpu_pe_kde only: [n_units][1000] output
     int32_t* kde_status;  // tredgpu_pe_kde only: [n_units]
-    int32_t debug_skip;   // timing experiments only (TREDGPU_GRID_SKIP bitmask); 0 in production
 };
 constexpr int GRID_MAX_ROWS = 512;   // |h1range| a workgroup can hold
 constexpr int GRID_MAX_COLS = 1024;  // |h2range|
