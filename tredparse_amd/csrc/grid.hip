@@ -456,6 +456,12 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
         const int ncol = u.ploidy == 1 ? 1 : ax2.size();
         if (status == 0 && (nrow > GRID_MAX_ROWS || ncol > GRID_MAX_COLS)) status = -5;
         if (status == 0 && (nrow == 0 || ncol == 0)) status = -8;
+        if (status == 0) {   // marginals are indexed by repeat units: every axis value must fit
+            int hm = axis_value(ax1, S.obs.base, period, nrow - 1);
+            if (u.ploidy != 1) hm = max(hm, axis_value(ax2, S.obs.base, period, ncol - 1));
+            if (nb > 0) hm = max(hm, S.obs.base[nb - 1]);
+            if (hm / period >= MAXM) status = -5;
+        }
 
         if (status != 0) {
             if (tid == 0) { call.status = status; call.run_pe = run_pe; a.calls[g] = call; }
