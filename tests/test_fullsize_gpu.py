@@ -129,3 +129,32 @@ def test_device_memory_path_matches_host_path(ctx, loci):
     assert np.array_equal(d["tag"].cpu().numpy(), ref["tag"]) and np.array_equal(d["h"].cpu().numpy(), ref["h"])
     assert np.array_equal(d["full"].cpu().numpy(), ref["full"]) and np.array_equal(d["rept"].cpu().numpy(), ref["rept"])
     assert d["calls"].cpu().numpy().tobytes() == ref["calls"].tobytes()
+
+
+def test_config5_high_coverage_expanded_alleles(ctx, loci):
+    """BASELINE configs[4]: 100x coverage, one allele expanded up to 200 repeats -- large (h1,h2) grids
+    (no spanning read for the long allele: extended h2 range, PE mode) and many repeat-only reads."""
+    _model(ctx)
+    sel = [l for l in loci if l["name"] in ("HD", "DM1", "SCA1")]
+    # both alleles beyond what a 150 bp read can span (no FULL read -> both axes extended), one up to 200
+    p = synth.SynthParams(coverage=100, min_units=42, max_units=60, expanded_max=200, expanded_frac=0.8)
+    b = synth.build_batch(55, sel, 2, p, maxinsert=300)
+    ctx.set_ladders(b.ladders)
+    r = _run(ctx, b)
+    assert (r["calls"]["status"] == 0).all()
+    assert r["calls"]["n_pairs"].max() > 20000 and (r["tag"] == 4).sum() > 50         # big grids, REPT reads
+    ls = po.LocusSet(b.ladders)
+    reads = [synth.decode(x) for x in b.codes]
+    cls = po.classify(reads, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), ls, threads=0)
+    assert np.array_equal(r["tag"], cls[:, 0].astype(np.uint8)) and np.array_equal(r["h"], cls[:, 1].astype(np.int16))
+    for u in range(b.n_units):
+        up = b.units[u]
+        f = {k: int(v) for k, v in enumerate(r["full"][u]) if v}
+        pp = {k: int(v) for k, v in enumerate(r["pref"][u]) if v}
+        res = lo.Caller(int(up["period"]), 150, 2, 2 * float(up["half_depth"]), f, pp, int(r["rept"][u].sum()),
+                        b.global_lens[up["pe_off"]:up["pe_off"] + up["n_global"]],
+                        b.target_lens[up["tl_off"]:up["tl_off"] + up["n_target"]], int(up["ref_len"]),
+                        int(up["minpe"])).evaluate()
+        c = r["calls"][u]
+        assert (c["h1"], c["h2"]) == tuple(res["alleles"]), u
+        assert abs(c["lik"] - res["lik"]) <= 1e-6 and tuple(c["ci"]) == tuple(res["CI"]) and c["n_pairs"] == len(res["mls"])
