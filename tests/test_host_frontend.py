@@ -73,3 +73,27 @@ def test_read_csv_modes(tmp_path):
     p = tredmod.set_argparse()
     a = p.parse_args([BAM1, "--tred", "HD", "--maxinsert", "100", "--norepeatpairs"])
     assert a.tred == ["HD"] and a.maxinsert == 100 and a.norepeatpairs and not a.fullsearch
+
+
+def test_tredreport_on_reference_results(tmp_path):
+    """tests.py:15-19 of the reference: tredreport on work/t001.json work/t002.json."""
+    from tredparse_amd import tredreport
+    files = []
+    for s in ("t001", "t002"):
+        f = tmp_path / (s + ".json")
+        f.write_text(json.dumps({"samplekey": s, "bam": s + ".bam", "tredCalls": WANT[s]}))
+        files.append(str(f))
+    tsv = str(tmp_path / "work.tsv")
+    total = tredreport.main(files + ["--tsv", tsv])
+    assert total["risk"] == 2 and total["loci"] == 2          # HD 15/41 and DM1 5/66 are at-risk calls
+    rows = open(tsv).read().splitlines()
+    hdr = rows[0].split("\t")
+    assert hdr[:2] == ["SampleKey", "inferredGender"] and "HD.calls" in hdr and "DM1.label" in hdr
+    r1 = dict(zip(hdr, rows[1].split("\t")))
+    assert r1["SampleKey"] == "t001" and r1["HD.calls"] == "15|41" and r1["HD.label"] == "risk"
+    cases = open(tsv + ".cases.txt").read()
+    assert "[HD] - Huntington" in cases and "[DM1]" in cases and "n_risk=1" in cases
+    det = open(tsv + ".details.txt").read().splitlines()
+    assert det[1].split("\t")[:5] == ["DM1", "AD", "t002", "Female", "5|66"]
+    rep = open(tsv + ".report.txt").read()
+    assert "{15:1,41:1}" in rep
