@@ -19,7 +19,8 @@
 namespace tredgpu {
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 128;   // threads per workgroup (one unit at a time); 6 workgroups per CU
+constexpr int XPER = (TREDGPU_SPAN + NT - 1) / NT;  // KDE x-values per thread
 constexpr int SPAN = TREDGPU_SPAN;
 constexpr int MAXOBS = 256;  // distinct FULL / PREF sizes per unit
 constexpr int MAXM = 768;    // marginal bins (repeat units)
@@ -210,8 +211,7 @@ __device__ double block_sum(double v, double* red) {
 // n^(-1/5), covariance with ddof=1, kernel exp(-((l-x)/sigma)^2/2) / (sigma*sqrt(2*pi)) / n).
 // hist/kern are LDS scratch of SPAN ints / SPAN doubles; pdf receives the result (LDS or global).
 // Returns 0, or -2 (singular / too few points), -6 (length outside [0,1000)).
-__device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, double* pdf, double* red, int* flag,
-                         double* wgt) {
+__device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, double* pdf, double* red, int* flag) {
     const int tid = threadIdx.x;
     for (int i = tid; i < SPAN; i += NT) hist[i] = 0;
     if (tid == 0) *flag = 0;
@@ -261,23 +261,23 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, do
     }
     __syncthreads();
     const int nnz = *flag;
-    // per-bin weights (count * 1/n), evaluated once; wgt is caller-provided LDS scratch of >= 1000 doubles
-    for (int k = tid; k < nnz; k += NT) wgt[k] = ((hist[k] & 0xFFFF) * w);
-    __syncthreads();
-    // every thread owns x = tid, tid+256, tid+512, tid+768: the bin list is walked once for all four
-    double acc[4] = {0, 0, 0, 0};
-    for (int k = 0; k < nnz; ++k) {
-        const int v = hist[k] >> 16;
-        const double wk = wgt[k];
+    // every thread owns x = tid, tid+NT, ...: the bin list is walked once for all of them
+    double acc[XPER];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < XPER; ++q) acc[q] = 0;
+    for (int k = 0; k < nnz; ++k) {
+        const int e = hist[k];
+        const int v = e >> 16;
+        const double wk = (e & 0xFFFF) * w;
+#pragma unroll
+        for (int q = 0; q < XPER; ++q) {
             const int x = tid + q * NT;
             if (x < SPAN) acc[q] += wk * kern[x > v ? x - v : v - x];
         }
     }
     double part = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < XPER; ++q) {
         const int x = tid + q * NT;
         if (x < SPAN) { pdf[x] = acc[q]; part += acc[q]; }
     }
@@ -291,11 +291,10 @@ __global__ __launch_bounds__(NT) void pe_kde_kernel(GridArgs a) {
     __shared__ int hist[SPAN];
     __shared__ double kern[SPAN];
     __shared__ double red[NT / 64];
-    __shared__ double wgt[SPAN];
     __shared__ int flag;
     const int g = blockIdx.x;
     const tredgpu_unit_params u = a.units[g];
-    const int rc = kde_block(a.global_lens + u.pe_off, u.n_global, hist, kern, a.kde_pdf + (size_t)g * SPAN, red, &flag, wgt);
+    const int rc = kde_block(a.global_lens + u.pe_off, u.n_global, hist, kern, a.kde_pdf + (size_t)g * SPAN, red, &flag);
     if (threadIdx.x == 0) a.kde_status[g] = rc;
 }
 
@@ -319,16 +318,21 @@ struct GridShared {
         int hist[SPAN];               // KDE scratch / raw histograms while loading
         int row_off[GRID_MAX_ROWS + 1];
     };
-    double kern[SPAN];                // KDE scratch
-    double pdf[SPAN];                 // normalised KDE
-    double far1[GRID_MAX_ROWS], far2[GRID_MAX_ROWS];  // per-row ml1 / ml2 against any "far" h2
-    double ph1[MAXM], ph2[MAXM];
+    union {
+        double kern[SPAN];            // KDE scratch ...
+        double ph1[MAXM];             // ... then the P_h1 marginal (after pass B)
+    };
+    union {
+        double pdf[SPAN];             // normalised KDE (read until the end of pass A) ...
+        double ph2[MAXM];             // ... then the P_h2 marginal
+    };
     double red[NT / 64];
     Best bred[NT / 64];
     int flag;
     int status;
     int unit;
 };
+static_assert(MAXM <= SPAN, "marginals alias the KDE arrays");
 
 __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch, int* next_unit) {
     constexpr size_t scratch_per_block = GRID_SCRATCH_DOUBLES;
@@ -339,7 +343,9 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
     double* const rept_tab = scratch + (size_t)blockIdx.x * scratch_per_block;
     double* const roll1 = rept_tab + GRID_REPT_TAB;
     double* const roll2 = roll1 + (size_t)GRID_MAX_ROWS * GRID_TMAX;
-    double* const mlbuf = roll2 + (size_t)GRID_MAX_COLS * GRID_TMAX;
+    double* const far1 = roll2 + (size_t)GRID_MAX_COLS * GRID_TMAX;   // per-row ml1 / ml2 against any "far" h2
+    double* const far2 = far1 + GRID_MAX_ROWS;
+    double* const mlbuf = far2 + GRID_MAX_ROWS;
     const ModelConst& M = *a.model;
 
     while (true) {
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
                 for (int i = tid; i < u.n_global; i += NT) { const double d = gl[i] - mean; q += d * d; }
                 rc = block_sum(q, S.red) > 0 ? 0 : -2;
             } else {
-                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag, S.far1);
+                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag);
             }
             if (rc) status = rc;
         }
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
             if (u.ploidy == 1) cnt = 1;
             else for (int j = 0; j < ncol; ++j) cnt += axis_value(ax2, S.obs.base, period, j) >= h1;
             S.row_off[i] = cnt;
-            eval_reads(C, h1, max(h_far, h1), S.far1[i], S.far2[i]);
+            eval_reads(C, h1, max(h_far, h1), far1[i], far2[i]);
         }
         __syncthreads();
         if (tid == 0) {
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
                 if (h1 > h2) mlbuf[pos] = 0;
                 else {
                     double ml4[4];
-                    if (h2 >= h_far) { ml4[0] = S.far1[i]; ml4[1] = S.far2[i]; }
+                    if (h2 >= h_far) { ml4[0] = far1[i]; ml4[1] = far2[i]; }
                     else eval_reads(C, h1, h2, ml4[0], ml4[1]);
                     const int dsum = max(h1 - readlen, 1) + max(h2 - readlen, 1);
                     ml4[2] = use_rept_tab ? rept_tab[dsum] : rept_term(C, dsum);
@@ -634,13 +640,13 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
             double acc = 0;
             for (int j = tid & 63; j < ncol; j += 64) acc += mlbuf[i * ncol + j];
             acc = wave_sum(acc);
-            if ((tid & 63) == 0) S.far1[i] = acc;  // far1 is free now: row sums
+            if ((tid & 63) == 0) far1[i] = acc;  // far1 is free now: row sums
         }
         __syncthreads();
         if (tid == 0) {
             for (int i = 0; i < nrow; ++i) {
                 const int m = axis_value(ax1, S.obs.base, period, i) / period;
-                if (m < MAXM) S.ph1[m] += S.far1[i];
+                if (m < MAXM) S.ph1[m] += far1[i];
             }
         }
         // marginal P_h2: one thread per distinct h2 value, rows outermost as in the reference.  The

@@ -90,11 +90,11 @@ struct GridArgs {
 };
 constexpr int GRID_MAX_ROWS = 512;   // |h1range| a workgroup can hold
 constexpr int GRID_MAX_COLS = 1024;  // |h2range|
-constexpr int GRID_MAX_BLOCKS = 768;  // 3 resident workgroups per CU (LDS-limited) x 256 CUs
+constexpr int GRID_MAX_BLOCKS = 1536;  // 6 resident 128-thread workgroups per CU x 256 CUs
 constexpr int GRID_REPT_TAB = 8192;   // entries of the per-unit repeat-only table (index dsum)
 constexpr int GRID_TMAX = 128;        // spanning pairs per unit the roll tables hold
 constexpr size_t GRID_SCRATCH_DOUBLES = (size_t)GRID_REPT_TAB + (size_t)(GRID_MAX_ROWS + GRID_MAX_COLS) * GRID_TMAX +
-                                        (size_t)GRID_MAX_ROWS * GRID_MAX_COLS;
+                                        2 * (size_t)GRID_MAX_ROWS + (size_t)GRID_MAX_ROWS * GRID_MAX_COLS;
 inline size_t grid_scratch_bytes(int n_units) {
     const size_t blocks = n_units < GRID_MAX_BLOCKS ? n_units : GRID_MAX_BLOCKS;
     return blocks * GRID_SCRATCH_DOUBLES * sizeof(double);
