@@ -130,3 +130,24 @@ def test_plain_reference_alignment(ctx):
     pt = [u for u in range(len(refs)) for _ in range(5)]
     want = po.sw_pairs(reads, refs, pr, pt)
     assert np.array_equal(dump[:, 0, :5].astype(np.int32), want)
+
+
+def test_aligner_mirror_matches_reference_goldens(ctx):
+    """tredparse_amd.ssw.Aligner (the reference's ssw.Aligner signature, src/ssw_wrap.py:110-143,177-227) on
+    pairs taken from the reference-generated golden file."""
+    import os
+    from tredparse_amd.ssw import Aligner
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sw_pairs.npz"))
+    reads, refs = [str(x) for x in z["reads"]], [str(x) for x in z["refs"]]
+    pr, pt, want = z["pair_read"], z["pair_ref"], z["result"].astype(np.int32)
+    rng = np.random.default_rng(0)
+    for k in rng.choice(len(pr), 60, replace=False):
+        ref = refs[pt[k]]
+        if len(ref) > 511:
+            continue
+        al = Aligner(ref_seq=ref, match=1, mismatch=5, gap_open=7, gap_extend=2, ctx=ctx)
+        res = al.align(reads[pr[k]], min_score=0, min_len=0)
+        got = (res.score, res.ref_begin, res.ref_end, res.query_begin, res.query_end)
+        assert got == tuple(int(x) for x in want[k]), k
+        # the min_score / min_len filter of Aligner.align (ssw_wrap.py:214-220)
+        assert al.align(reads[pr[k]], min_score=int(want[k][0]) + 1, min_len=0) is None
