@@ -158,3 +158,29 @@ def test_config5_high_coverage_expanded_alleles(ctx, loci):
         c = r["calls"][u]
         assert (c["h1"], c["h2"]) == tuple(res["alleles"]), u
         assert abs(c["lik"] - res["lik"]) <= 1e-6 and tuple(c["ci"]) == tuple(res["CI"]) and c["n_pairs"] == len(res["mls"])
+
+
+def test_small_scratch_pool_takes_several_passes(loci, monkeypatch):
+    """The grid kernels carve each unit's tables out of one scratch pool; units that find it full wait for
+    the next pass.  A 4 MiB pool (two or three of the big grids per pass) must give the same calls as the
+    default pool, which holds this batch at once."""
+    sel = [l for l in loci if l["name"] in ("HD", "DM1", "SCA1")]
+    p = synth.SynthParams(coverage=30, min_units=5, max_units=60)
+    b = synth.build_batch(60, sel, 11, p, maxinsert=300)
+    out = []
+    for mb in (None, "4"):
+        if mb is None:
+            monkeypatch.delenv("TREDGPU_GRID_POOL_MB", raising=False)
+        else:
+            monkeypatch.setenv("TREDGPU_GRID_POOL_MB", mb)
+        c = _lib.Context(0)
+        try:
+            _model(c)
+            c.set_ladders(b.ladders)
+            out.append(_run(c, b))
+        finally:
+            c.close()
+    a, s = out
+    assert (a["calls"]["status"] == 0).all()
+    assert (a["calls"]["n_pairs"] > 20000).sum() >= 4      # each of these needs > 0.5 MiB of the pool
+    assert np.array_equal(a["calls"], s["calls"])

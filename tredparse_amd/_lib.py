@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtredgpu.so")
+LIB_PATH = os.environ.get("TREDGPU_LIB") or os.path.join(HERE, "libtredgpu.so")   # override: kernel experiments
 
 MEM_HOST, MEM_DEVICE = 0, 1
 TAG_NONE, TAG_FULL, TAG_PREF, TAG_POST, TAG_REPT, TAG_HANG, TAG_INVALID = 0, 1, 2, 3, 4, 5, 255

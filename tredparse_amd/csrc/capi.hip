@@ -37,7 +37,9 @@ struct tredgpu_ctx {
     Buf d_model;
     bool have_model = false;
     // workspaces (grow-only, reused across calls)
-    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class;
+    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class, ws_gdesc, ws_gtile, ws_gctr;
+    int* h_pin = nullptr;  // pinned word for small read-backs
+    size_t grid_pool_bytes = GRID_POOL_BYTES;   // TREDGPU_GRID_POOL_MB overrides (tuning / tests of the multi-pass path)
     Buf st[24];  // staging for HOST-memory calls
     // intermediates of the fused path
     Buf ws_tag, ws_h, ws_score;
@@ -213,6 +215,10 @@ int tredgpu_create(int device_id, tredgpu_ctx** out) {
         delete c;
         return fail(nullptr, -10, "cannot initialise device %d: %s", device_id, hipGetErrorString(e));
     }
+    if (const char* mb = getenv("TREDGPU_GRID_POOL_MB")) {
+        const long v = atol(mb);
+        if (v > 0) c->grid_pool_bytes = (size_t)v << 20;
+    }
     *out = c;
     return 0;
 }
@@ -222,11 +228,12 @@ void tredgpu_destroy(tredgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (Buf* b : {&c->d_ladders, &c->d_seq, &c->d_model, &c->ws_quads, &c->ws_counter, &c->ws_drop,
-                   &c->ws_grid, &c->ws_stats, &c->ws_perm, &c->ws_class, &c->ws_tag, &c->ws_h, &c->ws_score})
+                   &c->ws_grid, &c->ws_stats, &c->ws_perm, &c->ws_class, &c->ws_gdesc, &c->ws_gtile, &c->ws_gctr, &c->ws_tag, &c->ws_h, &c->ws_score})
         release(*b);
     for (Buf& b : c->st) release(b);
     for (auto& t : c->timers)
         for (auto& ev : t.pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -567,14 +574,41 @@ static int check_grid_common(tredgpu_ctx* c, const tredgpu_unit_params* units, i
     return 0;
 }
 
+// Largest maxinsert over the units (device array): bounds the grid axes, hence the scratch slot of a unit.
+// One 4-byte read-back; the fused path asks before it launches the SW kernel, so the stream is idle.
+static int query_max_insert(tredgpu_ctx* c, const tredgpu_unit_params* units, int32_t n_units, int* out) {
+    int rc;
+    if ((rc = ensure(c, c->ws_counter, 64))) return rc;
+    if (!c->h_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_pin, 64, hipHostMallocDefault));
+    int* d = (int32_t*)c->ws_counter.p + 12;
+    HIPCHK(c, launch_unit_max(units, n_units, d, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = c->h_pin[0];
+    return 0;
+}
+
 static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int32_t n_units, int32_t hist_stride,
                            const int32_t* full_cnt, const int32_t* pref_cnt, const int32_t* rept_cnt,
                            const int32_t* global_lens, const int32_t* target_lens, tredgpu_call* calls,
-                           const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride) {
+                           const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride,
+                           int max_insert /* < 0: ask the device */) {
     if (n_units == 0) return 0;
     int rc;
-    if ((rc = ensure(c, c->ws_grid, grid_scratch_bytes(n_units)))) return rc;
-    if ((rc = ensure(c, c->ws_counter, 64))) return rc;
+    if (max_insert < 0 && (rc = query_max_insert(c, units, n_units, &max_insert))) return rc;
+    // every axis is a subset of {distinct sizes} U {max_partial} plus at most maxinsert arithmetic entries
+    const int cap = std::min(std::max(hist_stride + 1 + std::max(max_insert, 0), 8), GRID_MAX_ROWS);
+    const size_t slot_max = grid_slot_doubles_max(cap, cap) * sizeof(double);
+    // the pool: everything the batch can ask for if that is small, else GRID_POOL_BYTES and as many passes
+    // as it takes (units that find the pool full are deferred to the next pass)
+    const size_t pool_bytes = std::max(std::min((size_t)n_units * slot_max, c->grid_pool_bytes), slot_max);
+    const bool may_defer = (size_t)n_units * slot_max > pool_bytes;
+    const size_t item_cap = (size_t)n_units * grid_items_cap(cap, cap);
+    if ((rc = ensure(c, c->ws_grid, pool_bytes))) return rc;
+    if ((rc = ensure(c, c->ws_gdesc, (size_t)n_units * grid_desc_bytes()))) return rc;
+    if ((rc = ensure(c, c->ws_gtile, item_cap * grid_item_bytes() + 64))) return rc;
+    if ((rc = ensure(c, c->ws_gctr, grid_counter_bytes()))) return rc;
+    if (!c->h_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_pin, 64, hipHostMallocDefault));
     GridArgs a;
     a.units = units;
     a.n_units = n_units;
@@ -594,7 +628,16 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     a.kde_status = nullptr;
     {
         ScopedTimer tm(c, TREDGPU_KERNEL_GRID);
-        HIPCHK(c, launch_grid(a, (double*)c->ws_grid.p, (int32_t*)c->ws_counter.p + 4, c->stream));
+        for (int pass = 0;; ++pass) {
+            HIPCHK(c, launch_grid_pass(a, pass, c->ws_gdesc.p, (double*)c->ws_grid.p, pool_bytes / sizeof(double), cap, cap,
+                                       c->ws_gtile.p, item_cap, c->ws_gctr.p, c->stream));
+            if (!may_defer) break;
+            HIPCHK(c, hipMemcpyAsync(c->h_pin, (const char*)c->ws_gctr.p + grid_deferred_offset(), sizeof(int),
+                                     hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_pin[0] == 0) break;
+            if (pass >= 1000) return fail(c, -10, "likelihood grid: scratch pool passes do not converge");
+        }
     }
     return 0;
 }
@@ -614,9 +657,11 @@ int tredgpu_likelihood_grid(tredgpu_ctx* c, int mem, const tredgpu_unit_params* 
     HIPCHK(c, hipSetDevice(c->device));
     if (mem == TREDGPU_MEM_DEVICE)
         return run_grid_device(c, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens, target_lens,
-                               calls, grid_off, grid_dump, marg, marg_stride);
+                               calls, grid_off, grid_dump, marg, marg_stride, -1);
     if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
     if (n_units == 0) return 0;
+    int max_insert = 0;
+    for (int g = 0; g < n_units; ++g) max_insert = std::max(max_insert, units[g].maxinsert);
     for (int g = 0; g < n_units; ++g) {
         const tredgpu_unit_params& u = units[g];
         if (u.n_global < 0 || u.n_target < 0 || u.pe_off < 0 || u.tl_off < 0 || (int64_t)u.pe_off + u.n_global > n_global_total ||
@@ -643,7 +688,7 @@ int tredgpu_likelihood_grid(tredgpu_ctx* c, int mem, const tredgpu_unit_params* 
     const size_t marg_n = marg ? (size_t)n_units * 2 * marg_stride : 0;
     if (marg && (rc = stage_out(c, c->st[9], marg_n, &d_marg))) return rc;
     if ((rc = run_grid_device(c, d_units, n_units, hist_stride, d_f, d_p, d_r, d_gl, d_tl, d_calls, d_goff, d_dump,
-                              d_marg, marg_stride)))
+                              d_marg, marg_stride, max_insert)))
         return rc;
     if ((rc = copy_back(c, calls, (const tredgpu_call*)d_calls, (size_t)n_units))) return rc;
     if ((rc = copy_back(c, grid_dump, (const double*)d_dump, dump_n))) return rc;
@@ -707,6 +752,8 @@ int tredgpu_genotype_batch(tredgpu_ctx* c, int mem, const uint32_t* packed, cons
     HIPCHK(c, hipSetDevice(c->device));
     if (mem == TREDGPU_MEM_DEVICE) {
         int max_len = params->max_read_len > 0 ? params->max_read_len : TREDGPU_MAX_READ_LEN;
+        int max_insert = 0;
+        if (n_units > 0 && (rc = query_max_insert(c, units, n_units, &max_insert))) return rc;
         if (read_pair_id && (rc = ensure(c, c->ws_drop, (size_t)n_reads))) return rc;
         if ((rc = run_sw_device(c, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, n_units, params,
                                 max_len, out_tag, out_h, out_score, nullptr, 0)))
@@ -717,7 +764,7 @@ int tredgpu_genotype_batch(tredgpu_ctx* c, int mem, const uint32_t* packed, cons
                                    pref_cnt, rept_cnt, (uint8_t*)c->ws_drop.p, c->stream));
         }
         return run_grid_device(c, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens, target_lens,
-                               calls, nullptr, nullptr, nullptr, 0);
+                               calls, nullptr, nullptr, nullptr, 0, max_insert);
     }
     if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
     // HOST memory: compose the three host-memory calls (each validates and stages its own arguments)

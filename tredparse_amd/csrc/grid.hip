@@ -5,12 +5,17 @@
 //   evaluate_partial :200-207, evaluate_rept :209-221, evaluate :223-302, calc_CI :319-340,
 //   calc_PP :342-368, safe_log :418-423, PEMaxLikModel :426-473 (incl. scipy gaussian_kde).
 //
-// One 256-thread workgroup per sample x locus unit.  The grid rectangle h1range x h2range is walked
-// pair-per-thread; every pair's log-likelihood is a short sum over the unit's sparse observations
-// (distinct FULL sizes, distinct PREF/POST sizes, spanning-pair lengths), so only the entries of the
-// reference's dense 1000-vectors that are actually read are ever computed.  Reductions (arg-max
-// with the reference's tie-break, PP sums) go through wave shuffles + LDS partials; marginals are
-// accumulated in the reference's own enumeration order so the CI walk sees the same sums.
+// Three kernels per chunk of units, every unit owning one slot of a global scratch pool:
+//   grid_prepare_kernel  one workgroup per unit: sparse observation lists, grid axes, KDE (only when the
+//                        paired-end term is used), per-unit tables, per-row "far" terms -> UnitDesc + slot
+//   grid_pairs_kernel    flat over all pairs of all units (256-pair tiles handed out by an atomic counter):
+//                        the log-likelihood of each pair -- a short sum over the unit's sparse observations,
+//                        so only the entries of the reference's dense 1000-vectors that are actually read
+//                        are ever computed
+//   grid_reduce_kernel   one workgroup per unit: arg-max with the reference's tie-break, exp(ml - max),
+//                        PP sums, marginals in the reference's enumeration order, CI walk
+// (splitting keeps every kernel's register footprint small; the single-kernel version of this path
+// needed 168 VGPRs plus 400 B of spills per lane)
 //
 // Arithmetic mirrors the reference's operation order (compiled with -ffp-contract=off); the only
 // intended differences are libm-vs-ocml last-bit effects in log/exp/lgamma.
@@ -209,22 +214,39 @@ __device__ double block_sum(double v, double* red) {
 
 // gaussian_kde(global_lens).evaluate(arange(1000)) / sum  (models.py:428-435; scipy: Scott factor
 // n^(-1/5), covariance with ddof=1, kernel exp(-((l-x)/sigma)^2/2) / (sigma*sqrt(2*pi)) / n).
-// hist/kern are LDS scratch of SPAN ints / SPAN doubles; pdf receives the result (LDS or global).
+// hist: SPAN ints, kern2: KERN2 doubles of LDS scratch; pdf receives the result (LDS or global).
 // Returns 0, or -2 (singular / too few points), -6 (length outside [0,1000)).
-__device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, double* pdf, double* red, int* flag) {
+//
+// pdf[x] = sum_v count[v]/n * K(x - v) is a 1000 x (vmax - vmin + 1) convolution.  Every thread owns XPER
+// consecutive x and walks v upwards over the occupied range, so its window K(x0 - v .. x0 + XPER-1 - v)
+// slides by one entry per step: one LDS load of K and one broadcast load of the weight per XPER FMAs.
+// K is stored for d = -999 .. 1048 at index swz(d + 999); the swizzle i + i/8 turns the lanes' stride of
+// XPER doubles into 9, which keeps the 64 loads of a step off each other's banks.  Empty bins add
+// 0 * K = +0, so the sums carry the same bits as a walk over the occupied bins only.
+constexpr int KOFF = SPAN - 1;
+constexpr int KERN2_RAW = 2048 + 8;
+__device__ __forceinline__ int kswz(int i) { return i + (i >> 3); }
+constexpr int KERN2 = KERN2_RAW + KERN2_RAW / 8 + 1;
+static_assert(XPER == 8, "the sliding window below is unrolled for 8 x-values per thread");
+static_assert(NT * XPER >= SPAN && NT * XPER + KOFF < KERN2_RAW, "window indices stay inside kern2");
+
+__device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, double* pdf, double* red, int* flag) {
     const int tid = threadIdx.x;
     for (int i = tid; i < SPAN; i += NT) hist[i] = 0;
-    if (tid == 0) *flag = 0;
+    if (tid == 0) { flag[0] = 0; flag[1] = SPAN; flag[2] = -1; }
     __syncthreads();
     double s = 0;
+    int vlo = SPAN, vhi = -1;
     for (int i = tid; i < n; i += NT) {
         const int v = lens[i];
-        if (v < 0 || v >= SPAN) atomicOr(flag, 1);
-        else atomicAdd(&hist[v], 1);
+        if (v < 0 || v >= SPAN) atomicOr(&flag[0], 1);
+        else { atomicAdd(&hist[v], 1); vlo = min(vlo, v); vhi = max(vhi, v); }
         s += (double)v;
     }
+    for (int o = 32; o > 0; o >>= 1) { vlo = min(vlo, __shfl_down(vlo, o, 64)); vhi = max(vhi, __shfl_down(vhi, o, 64)); }
+    if ((tid & 63) == 0) { atomicMin(&flag[1], vlo); atomicMax(&flag[2], vhi); }
     const double total = block_sum(s, red);
-    if (*flag || n >= 65536) return -6;
+    if (flag[0] || n >= 65536) return -6;
     if (n < 2) return -2;
     const double mean = total / n;
     double q = 0;
@@ -238,63 +260,59 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern, do
     const double sigma = sqrt(var) * factor;       // cho_cov
     const double norm = 1.0 / sqrt(2 * M_PI) / sigma;  // (2*pi)^(-d/2) / cho_cov
     const double w = 1.0 / n;                      // uniform weights
-    // kern[d] = exp(-(d/sigma)^2 / 2) * norm, d = |l - x|
+    // K(d) = exp(-(d/sigma)^2 / 2) * norm for |d| < 1000 (both signs stored), 0 beyond
     for (int d = tid; d < SPAN; d += NT) {
         const double r = (double)d / sigma;
-        kern[d] = exp(-(r * r) / 2) * norm;
+        const double k = exp(-(r * r) / 2) * norm;
+        kern2[kswz(KOFF + d)] = k;
+        kern2[kswz(KOFF - d)] = k;
     }
+    for (int i = 2 * SPAN - 1 + tid; i < KERN2_RAW; i += NT) kern2[kswz(i)] = 0;
     __syncthreads();
-    // compact the non-empty bins in place (ascending v, as the dense walk would visit them):
-    // hist[k] = v<<16 | count for k < nnz.  One wave, ballot + prefix popcount, 64 bins per step.
-    if (tid < 64) {
-        int nnz = 0;
-        for (int base = 0; base < SPAN; base += 64) {
-            const int v = base + tid;
-            const int c = v < SPAN ? hist[v] : 0;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(c > 0);
-            const int before = __builtin_popcountll(mask & ((1ull << tid) - 1ull));
-            // all reads of this 64-bin group happened above; writes go to indices <= base + tid
-            if (c > 0) hist[nnz + before] = (v << 16) | c;
-            nnz += __builtin_popcountll(mask);
-        }
-        if (tid == 0) *flag = nnz;
+    const int vmin = flag[1], vmax = flag[2];
+    const int x0 = tid * XPER;
+    double acc[XPER], win[XPER];
+#pragma unroll
+    for (int qx = 0; qx < XPER; ++qx) {
+        acc[qx] = 0;
+        win[qx] = kern2[kswz(KOFF + x0 + qx - vmin)];   // K(x0 + qx - vmin)
     }
-    __syncthreads();
-    const int nnz = *flag;
-    // every thread owns x = tid, tid+NT, ...: the bin list is walked once for all of them
-    double acc[XPER];
+    // step s of a group handles v = vb + s with the window rotated by s: K(x0 + qx - v) sits in
+    // win[(qx - s) & 7]; afterwards the slot of qx = 7 is refilled with K(x0 - (v + 1))
+    for (int vb = vmin; vb <= vmax; vb += XPER) {
 #pragma unroll
-    for (int q = 0; q < XPER; ++q) acc[q] = 0;
-    for (int k = 0; k < nnz; ++k) {
-        const int e = hist[k];
-        const int v = e >> 16;
-        const double wk = (e & 0xFFFF) * w;
+        for (int st = 0; st < XPER; ++st) {
+            const int v = vb + st;
+            const double wk = (v <= vmax ? hist[v] : 0) * w;
 #pragma unroll
-        for (int q = 0; q < XPER; ++q) {
-            const int x = tid + q * NT;
-            if (x < SPAN) acc[q] += wk * kern[x > v ? x - v : v - x];
+            for (int qx = 0; qx < XPER; ++qx) acc[qx] += wk * win[(qx - st) & 7];
+            win[(7 - st) & 7] = kern2[kswz(max(KOFF + x0 - (v + 1), 0))];
         }
     }
     double part = 0;
 #pragma unroll
-    for (int q = 0; q < XPER; ++q) {
-        const int x = tid + q * NT;
-        if (x < SPAN) { pdf[x] = acc[q]; part += acc[q]; }
+    for (int qx = 0; qx < XPER; ++qx) {
+        const int x = x0 + qx;
+        if (x < SPAN) { pdf[x] = acc[qx]; part += acc[qx]; }
     }
     const double tot = block_sum(part, red);
-    for (int x = tid; x < SPAN; x += NT) pdf[x] = pdf[x] / tot;
+#pragma unroll
+    for (int qx = 0; qx < XPER; ++qx) {
+        const int x = x0 + qx;
+        if (x < SPAN) pdf[x] = pdf[x] / tot;
+    }
     __syncthreads();
     return 0;
 }
 
 __global__ __launch_bounds__(NT) void pe_kde_kernel(GridArgs a) {
     __shared__ int hist[SPAN];
-    __shared__ double kern[SPAN];
+    __shared__ double kern[KERN2];
     __shared__ double red[NT / 64];
-    __shared__ int flag;
+    __shared__ int flag[4];
     const int g = blockIdx.x;
     const tredgpu_unit_params u = a.units[g];
-    const int rc = kde_block(a.global_lens + u.pe_off, u.n_global, hist, kern, a.kde_pdf + (size_t)g * SPAN, red, &flag);
+    const int rc = kde_block(a.global_lens + u.pe_off, u.n_global, hist, kern, a.kde_pdf + (size_t)g * SPAN, red, flag);
     if (threadIdx.x == 0) a.kde_status[g] = rc;
 }
 
@@ -310,58 +328,116 @@ __device__ __forceinline__ bool better(const Best& x, const Best& y) {  // is x 
     return x.pos < y.pos;                   // python max keeps the first maximal element
 }
 
-constexpr int OBSMAX = MAXOBS;
+constexpr int NR = 256;     // threads per workgroup of grid_reduce_kernel
 
-struct GridShared {
-    Obs obs;
-    union {
-        int hist[SPAN];               // KDE scratch / raw histograms while loading
-        int row_off[GRID_MAX_ROWS + 1];
-    };
-    union {
-        double kern[SPAN];            // KDE scratch ...
-        double ph1[MAXM];             // ... then the P_h1 marginal (after pass B)
-    };
-    union {
-        double pdf[SPAN];             // normalised KDE (read until the end of pass A) ...
-        double ph2[MAXM];             // ... then the P_h2 marginal
-    };
-    double red[NT / 64];
-    Best bred[NT / 64];
-    int flag;
-    int status;
-    int unit;
+// Where one unit's tables live in the scratch pool (offsets in doubles from the unit's base)
+struct SlotLayout {
+    int32_t obs, rowoff, far1, far2, pdf, rept, roll1, roll2, ml, total;
 };
-static_assert(MAXM <= SPAN, "marginals alias the KDE arrays");
+__device__ inline SlotLayout unit_layout(int nrow, int ncol, int nt, bool want_pdf, bool use_rept, int dmax, bool use_roll) {
+    SlotLayout L;
+    int o = 0;
+    L.obs = o;    o += (int)((sizeof(Obs) + 7) / 8);
+    L.rowoff = o; o += (nrow + 2) / 2;
+    L.far1 = o;   o += nrow;
+    L.far2 = o;   o += nrow;
+    L.pdf = o;    o += want_pdf ? SPAN : 0;
+    L.rept = o;   o += use_rept ? dmax + 1 : 0;
+    L.roll1 = o;  o += use_roll ? nrow * nt : 0;
+    L.roll2 = o;  o += use_roll ? ncol * nt : 0;
+    L.ml = o;     o += nrow * ncol;
+    L.total = (o + 15) & ~15;   // slots start on 128-byte lines
+    return L;
+}
 
-__global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch, int* next_unit) {
-    constexpr size_t scratch_per_block = GRID_SCRATCH_DOUBLES;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    GridShared& S = *reinterpret_cast<GridShared*>(smem_raw);
+// Per-unit record handed from grid_prepare_kernel to the other two kernels.
+// status: the tredgpu_call status, or UNIT_DEFERRED (no room in the pool this pass), UNIT_SKIP (done in an
+// earlier pass)
+constexpr int UNIT_DEFERRED = 100;
+constexpr int UNIT_SKIP = 101;
+struct UnitDesc {
+    int32_t status, run_pe, n_rept, n_pairs;
+    int32_t period, readlen, ploidy, ref_len, minpe, n_target, tl_off, pad0;
+    int32_t t1, t2, mp_eff, h_far;
+    int32_t nrow, ncol, nb, hmaxv;
+    Axis ax1, ax2;
+    int32_t use_rept_tab, use_roll_tab;
+    int32_t cutoff_risk, is_expansion, is_recessive, pad1;
+    double half_depth, lgam_rept, logsmall;
+    int64_t slot_off;      // doubles from the start of the pool
+    SlotLayout lay;
+    int32_t item_base, n_items;
+};
+
+// Device-side counters of one pass (zeroed by the launch); the item ticket sits on its own cache line
+struct GridCounters {
+    unsigned long long pool_used;   // doubles handed out
+    int32_t n_items, next_prepare, next_reduce, n_deferred;
+    int32_t pad[26];
+    int32_t next_item;
+    int32_t pad2[31];
+};
+static_assert(sizeof(GridCounters) == 256, "counter block layout");
+
+constexpr int CB = 64;    // columns per work item of grid_pairs_kernel: one lane owns one h2 for all the item's rows
+constexpr int RG = 128;   // rows per item
+constexpr int TC = 32;    // spanning pairs per pass over the rows (the lane's roll(h2) values stay in registers)
+
+__device__ __forceinline__ int unit_items(int nrow, int ncol) { return ((ncol + CB - 1) / CB) * ((nrow + RG - 1) / RG); }
+
+struct PrepShared {
+    Obs obs;
+    int hist[SPAN];
+    double kern[KERN2];
+    double pdf[SPAN];
+    double red[NT / 64];
+    int row_off[GRID_MAX_ROWS + 1];
+    int kflag[4];
+    long long slot_off;
+    int flag, status, unit;
+};
+
+__device__ PairCtx make_ctx(const UnitDesc& d, const ModelConst& M, const Obs* obs, const double* pdf, const int32_t* tl) {
+    PairCtx C;
+    C.M = &M;
+    C.step = M.step[d.period <= 6 ? d.period - 1 : 5];  // models.py:54-60
+    C.obs = obs;
+    C.pdf = pdf;
+    C.tl = tl + d.tl_off;
+    C.n_target = d.n_target;
+    C.period = d.period; C.readlen = d.readlen; C.t1 = d.t1; C.t2 = d.t2; C.mp_eff = d.mp_eff;
+    C.ref_len = d.ref_len; C.minpe = d.minpe; C.n_rept = d.n_rept; C.run_pe = d.run_pe != 0;
+    C.half_depth = d.half_depth;
+    C.lgam_rept = d.lgam_rept;
+    C.small = M.small; C.really_small = M.really_small;
+    C.logsmall = d.logsmall;
+    return C;
+}
+
+// ---- kernel 1: per-unit preparation -------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, UnitDesc* descs, double* pool,
+                                                          unsigned long long pool_doubles, int rows_cap, int cols_cap,
+                                                          int* item_unit, GridCounters* ctr) {
+    __shared__ PrepShared S;
     const int tid = threadIdx.x;
-    // per-workgroup scratch (global, L2-resident): [rept table][roll table rows][roll table cols][ml grid]
-    double* const rept_tab = scratch + (size_t)blockIdx.x * scratch_per_block;
-    double* const roll1 = rept_tab + GRID_REPT_TAB;
-    double* const roll2 = roll1 + (size_t)GRID_MAX_ROWS * GRID_TMAX;
-    double* const far1 = roll2 + (size_t)GRID_MAX_COLS * GRID_TMAX;   // per-row ml1 / ml2 against any "far" h2
-    double* const far2 = far1 + GRID_MAX_ROWS;
-    double* const mlbuf = far2 + GRID_MAX_ROWS;
     const ModelConst& M = *a.model;
-
     while (true) {
-        // dynamic unit scheduling: grids differ by three orders of magnitude in size
         __syncthreads();
-        if (tid == 0) S.unit = atomicAdd(next_unit, 1);
+        if (tid == 0) {
+            S.unit = atomicAdd(&ctr->next_prepare, 1);
+            S.status = 0;
+            if (pass > 0 && S.unit < a.n_units && a.calls[S.unit].status != UNIT_DEFERRED) S.status = UNIT_SKIP;
+        }
         __syncthreads();
-        const int g = S.unit;
+        const int g = __builtin_amdgcn_readfirstlane(S.unit);
         if (g >= a.n_units) break;
+        if (S.status == UNIT_SKIP) {   // settled in an earlier pass
+            if (tid == 0) descs[g].status = UNIT_SKIP;
+            continue;
+        }
         const tredgpu_unit_params u = a.units[g];
         const int period = u.period, readlen = u.readlen;
         const int t1 = readlen - 9, t2 = readlen - 18, t3 = readlen - 27;  // models.py:114-116
-        tredgpu_call call;
-        call.status = 0; call.n_pairs = 0; call.h1 = call.h2 = -1;
-        call.ci[0] = call.ci[1] = call.ci[2] = call.ci[3] = 0;
-        call.run_pe = 0; call.pad = 0; call.lik = -1; call.pp = -1;
 
         // ---- observations (models.py:399-403): sparse lists in bp, ascending ----
         const bool staged = 3 * a.hist_stride <= SPAN;
@@ -373,20 +449,45 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
             }
             __syncthreads();
         }
-        if (tid == 0) {
+        if (staged) {
+            // wavefront 0 compacts the FULL sizes, wavefront 1 the PREF/POST sizes (ballot + prefix popcount)
+            if (tid == 0) { S.flag = 0; S.status = 0; }
+            __syncthreads();
+            const int wv = tid >> 6, ln = tid & 63;
+            const int32_t* cnt = S.hist + wv * a.hist_stride;
+            int* K = wv ? S.obs.partK : S.obs.fullK;
+            int* Cn = wv ? S.obs.partC : S.obs.fullC;
+            int nn = 0, rept = 0;
+            for (int base = 0; base < a.hist_stride; base += 64) {
+                const int h = base + ln;
+                const int c = h < a.hist_stride ? cnt[h] : 0;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(c > 0);
+                const int idx = nn + __builtin_popcountll(mask & ((1ull << ln) - 1ull));
+                if (c > 0 && idx < MAXOBS) { K[idx] = h * period; Cn[idx] = c; }
+                nn += __builtin_popcountll(mask);
+                if (wv == 0 && h < a.hist_stride) rept += S.hist[2 * a.hist_stride + h];
+            }
+            for (int o = 32; o > 0; o >>= 1) rept += __shfl_down(rept, o, 64);
+            if (ln == 0) {
+                if (wv) S.obs.nP = min(nn, MAXOBS); else { S.obs.nF = min(nn, MAXOBS); S.flag = rept; }
+                if (nn > MAXOBS) S.status = -9;
+            }
+            __syncthreads();
+            if (tid == 0 && (period < 1 || period >= 18)) S.status = -7;  // step_size_by_period KeyError, models.py:157
+        } else if (tid == 0) {
             int nF = 0, nP = 0, rept = 0, st = 0;
-            const int32_t* fc = staged ? S.hist : a.full_cnt + (size_t)g * a.hist_stride;
-            const int32_t* pc = staged ? S.hist + a.hist_stride : a.pref_cnt + (size_t)g * a.hist_stride;
-            const int32_t* rc = staged ? S.hist + 2 * a.hist_stride : a.rept_cnt + (size_t)g * a.hist_stride;
+            const int32_t* fc = a.full_cnt + (size_t)g * a.hist_stride;
+            const int32_t* pc = a.pref_cnt + (size_t)g * a.hist_stride;
+            const int32_t* rc = a.rept_cnt + (size_t)g * a.hist_stride;
             for (int h = 0; h < a.hist_stride; ++h) {
-                if (fc[h] > 0) { if (nF < OBSMAX) { S.obs.fullK[nF] = h * period; S.obs.fullC[nF] = fc[h]; } ++nF; }
-                if (pc[h] > 0) { if (nP < OBSMAX) { S.obs.partK[nP] = h * period; S.obs.partC[nP] = pc[h]; } ++nP; }
+                if (fc[h] > 0) { if (nF < MAXOBS) { S.obs.fullK[nF] = h * period; S.obs.fullC[nF] = fc[h]; } ++nF; }
+                if (pc[h] > 0) { if (nP < MAXOBS) { S.obs.partK[nP] = h * period; S.obs.partC[nP] = pc[h]; } ++nP; }
                 rept += rc[h];
             }
-            if (nF > OBSMAX || nP > OBSMAX) st = -9;
+            if (nF > MAXOBS || nP > MAXOBS) st = -9;
             if (period < 1 || period >= 18) st = -7;  // step_size_by_period KeyError, models.py:157
-            S.obs.nF = min(nF, OBSMAX);
-            S.obs.nP = min(nP, OBSMAX);
+            S.obs.nF = min(nF, MAXOBS);
+            S.obs.nP = min(nP, MAXOBS);
             S.flag = rept;
             S.status = st;
         }
@@ -418,7 +519,7 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
                 for (int i = tid; i < u.n_global; i += NT) { const double d = gl[i] - mean; q += d * d; }
                 rc = block_sum(q, S.red) > 0 ? 0 : -2;
             } else {
-                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, &S.flag);
+                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, S.kflag);
             }
             if (rc) status = rc;
         }
@@ -460,48 +561,92 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
         }
         const int nrow = ax1.size();
         const int ncol = u.ploidy == 1 ? 1 : ax2.size();
-        if (status == 0 && (nrow > GRID_MAX_ROWS || ncol > GRID_MAX_COLS)) status = -5;
+        if (status == 0 && (nrow > rows_cap || ncol > cols_cap)) status = -5;
         if (status == 0 && (nrow == 0 || ncol == 0)) status = -8;
+        int hmaxv = 0;
         if (status == 0) {   // marginals are indexed by repeat units: every axis value must fit
-            int hm = axis_value(ax1, S.obs.base, period, nrow - 1);
-            if (u.ploidy != 1) hm = max(hm, axis_value(ax2, S.obs.base, period, ncol - 1));
-            if (nb > 0) hm = max(hm, S.obs.base[nb - 1]);
-            if (hm / period >= MAXM) status = -5;
+            hmaxv = axis_value(ax1, S.obs.base, period, nrow - 1);
+            if (u.ploidy != 1) hmaxv = max(hmaxv, axis_value(ax2, S.obs.base, period, ncol - 1));
+            if (nb > 0) hmaxv = max(hmaxv, S.obs.base[nb - 1]);
+            if (hmaxv / period >= MAXM) status = -5;
         }
 
+        UnitDesc d;
+        d.status = status; d.run_pe = run_pe; d.n_rept = n_rept; d.n_pairs = 0;
+        d.period = period; d.readlen = readlen; d.ploidy = u.ploidy; d.ref_len = u.ref_len; d.minpe = u.minpe;
+        d.n_target = u.n_target; d.tl_off = u.tl_off; d.pad0 = 0;
+        d.t1 = t1; d.t2 = t2; d.mp_eff = mp_eff;
+        d.h_far = max(max(max_full + 19, mp_eff), t1);
+        d.nrow = nrow; d.ncol = ncol; d.nb = nb; d.hmaxv = hmaxv;
+        d.ax1 = ax1; d.ax2 = ax2;
+        d.use_rept_tab = 0; d.use_roll_tab = 0;
+        d.cutoff_risk = u.cutoff_risk; d.is_expansion = u.is_expansion; d.is_recessive = u.is_recessive; d.pad1 = 0;
+        d.half_depth = u.half_depth;
+        d.lgam_rept = lgamma((double)n_rept + 1);
+        d.logsmall = log(M.small);
+        d.slot_off = 0; d.item_base = 0; d.n_items = 0;
         if (status != 0) {
-            if (tid == 0) { call.status = status; call.run_pe = run_pe; a.calls[g] = call; }
-            if (a.marg != nullptr)
-                for (int m = tid; m < 2 * a.marg_stride; m += NT) a.marg[(size_t)g * 2 * a.marg_stride + m] = 0;
+            if (tid == 0) descs[g] = d;
             continue;
         }
 
-        PairCtx C;
-        C.M = &M;
-        C.step = M.step[period <= 6 ? period - 1 : 5];  // models.py:54-60
-        C.obs = &S.obs;
-        C.pdf = S.pdf;
-        C.tl = a.target_lens + u.tl_off;
-        C.n_target = u.n_target;
-        C.period = period; C.readlen = readlen; C.t1 = t1; C.t2 = t2; C.mp_eff = mp_eff;
-        C.ref_len = u.ref_len; C.minpe = u.minpe; C.n_rept = n_rept; C.run_pe = run_pe;
-        C.half_depth = u.half_depth;
-        C.lgam_rept = lgamma((double)n_rept + 1);
-        C.small = M.small; C.really_small = M.really_small;
-        C.logsmall = log(M.small);
+        // ---- tables for big grids (decided here, filled below): the repeat-only term depends on dsum only,
+        //      the paired-end term on roll(h)[x_t] per axis value
+        const int rect = nrow * ncol;
+        const int dmax = 2 * max(hmaxv - readlen, 1);
+        d.use_rept_tab = rect >= 1024 && dmax < GRID_REPT_TAB;
+        d.use_roll_tab = run_pe && rect >= 1024 && u.n_target <= GRID_TMAX && u.ploidy != 1;
+
+        // ---- room in the pool and a run of work items; a unit that finds the pool full waits for the next pass
+        d.lay = unit_layout(nrow, ncol, u.n_target, run_pe && !d.use_roll_tab, d.use_rept_tab, dmax, d.use_roll_tab);
+        d.n_items = unit_items(nrow, ncol);
+        if (tid == 0) {
+            const unsigned long long off = atomicAdd(&ctr->pool_used, (unsigned long long)d.lay.total);
+            S.flag = off + d.lay.total <= pool_doubles;
+            S.slot_off = (long long)off;
+            if (S.flag) S.status = atomicAdd(&ctr->n_items, d.n_items);
+            else atomicAdd(&ctr->n_deferred, 1);
+        }
+        __syncthreads();
+        if (!S.flag) {
+            if (tid == 0) { d.status = UNIT_DEFERRED; descs[g] = d; }
+            continue;
+        }
+        d.slot_off = S.slot_off;
+        d.item_base = S.status;
+        const SlotLayout L = d.lay;
+        double* slot = pool + d.slot_off;
+        for (int k = tid; k < d.n_items; k += NT) item_unit[d.item_base + k] = g;
+
+        // ---- hand the unit's lists and (when the pairs kernel evaluates roll() itself) its KDE to the slot ----
+        Obs* gobs = reinterpret_cast<Obs*>(slot + L.obs);
+        {
+            const int* src = reinterpret_cast<const int*>(&S.obs);
+            int* dst = reinterpret_cast<int*>(gobs);
+            for (int k = tid; k < (int)(sizeof(Obs) / sizeof(int)); k += NT) dst[k] = src[k];
+        }
+        if (run_pe && !d.use_roll_tab) for (int x = tid; x < SPAN; x += NT) slot[L.pdf + x] = S.pdf[x];
+        const PairCtx C = make_ctx(d, M, &S.obs, S.pdf, a.target_lens);
 
         // ---- rows: count of valid h2 per h1 (h1 <= h2), dump offsets; per-row "far" terms ----
         // For h2 >= h_far the spanning and partial terms no longer depend on h2 (S(k|h2) = 0 for every
         // observed size, alpha is pinned, pdf_partial is clipped at max_partial): bit-identical values,
         // evaluated once per row instead of once per pair.
-        const int h_far = max(max(max_full + 19, mp_eff), t1);
+        int* row_off = reinterpret_cast<int*>(slot + L.rowoff);
         for (int i = tid; i < nrow; i += NT) {
             const int h1 = axis_value(ax1, S.obs.base, period, i);
-            int cnt = 0;
+            int cnt = 0;   // columns with h2 >= h1: base entries one by one, the arithmetic part in closed form
             if (u.ploidy == 1) cnt = 1;
-            else for (int j = 0; j < ncol; ++j) cnt += axis_value(ax2, S.obs.base, period, j) >= h1;
+            else {
+                for (int k = 0; k < ax2.nb; ++k) cnt += S.obs.base[k] >= h1;
+                const int m0 = h1 <= ax2.start ? 0 : (h1 - ax2.start + period - 1) / period;
+                cnt += max(0, ax2.n - m0);
+            }
             S.row_off[i] = cnt;
-            eval_reads(C, h1, max(h_far, h1), far1[i], far2[i]);
+            double f1, f2;
+            eval_reads(C, h1, max(d.h_far, h1), f1, f2);
+            slot[L.far1 + i] = f1;
+            slot[L.far2 + i] = f2;
         }
         __syncthreads();
         if (tid == 0) {
@@ -510,91 +655,237 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
             S.row_off[nrow] = acc;
         }
         __syncthreads();
-        const int n_pairs = S.row_off[nrow];
-        int64_t dump_base = -1;
-        if (a.grid_dump != nullptr) {
-            const int64_t cap = a.grid_off[g + 1] - a.grid_off[g];
-            if (n_pairs <= cap) dump_base = a.grid_off[g];
-        }
+        d.n_pairs = S.row_off[nrow];
+        if (a.grid_dump != nullptr)
+            for (int i = tid; i <= nrow; i += NT) row_off[i] = S.row_off[i];
 
-        // ---- tables for big grids: the repeat-only term depends on dsum only, the paired-end term on
-        //      roll(h)[x_t] per axis value; both are filled with the very expressions the direct path uses
-        const int rect = nrow * ncol;
-        const int last1 = axis_value(ax1, S.obs.base, period, nrow - 1);
-        const int last2 = u.ploidy == 1 ? last1 : axis_value(ax2, S.obs.base, period, ncol - 1);
-        int hmaxv = max(last1, last2);
-        if (nb > 0) hmaxv = max(hmaxv, S.obs.base[nb - 1]);
-        const int dmax = 2 * max(hmaxv - readlen, 1);
-        const bool use_rept_tab = rect >= 1024 && dmax < GRID_REPT_TAB;
-        const bool use_roll_tab = run_pe && rect >= 1024 && u.n_target <= GRID_TMAX;
-        if (use_rept_tab) {
-            // only the dsum values that occur: {2} U {1 + d} U {d + d'} for d, d' in D = {h - L > 0}
-            for (int d = 2 + tid; d <= dmax; d += NT) rept_tab[d] = 1.0;   // 1.0 = unset (terms are <= 0)
-            __syncthreads();
-            int i = tid / ncol, j = tid - i * ncol;
-            for (int pos = tid; pos < rect; pos += NT) {
-                const int h1 = axis_value(ax1, S.obs.base, period, i);
-                const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
-                if (h1 <= h2) rept_tab[max(h1 - readlen, 1) + max(h2 - readlen, 1)] = 2.0;  // needed
-                j += NT;
-                while (j >= ncol) { j -= ncol; ++i; }
+        // ---- the tables, filled with the very expressions the direct path uses
+        if (d.use_rept_tab) {
+            double* rept_tab = slot + L.rept;
+            if (dmax < rect) {
+                // fewer table entries than pairs: fill every entry
+                for (int x = 2 + tid; x <= dmax; x += NT) rept_tab[x] = rept_term(C, x);
+            } else {
+                // only the dsum values that occur: {2} U {1 + d} U {d + d'} for d, d' in D = {h - L > 0}
+                for (int x = 2 + tid; x <= dmax; x += NT) rept_tab[x] = 1.0;   // 1.0 = unset (terms are <= 0)
+                __syncthreads();
+                int i = tid / ncol, j = tid - i * ncol;
+                for (int pos = tid; pos < rect; pos += NT) {
+                    const int h1 = axis_value(ax1, S.obs.base, period, i);
+                    const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
+                    if (h1 <= h2) rept_tab[max(h1 - readlen, 1) + max(h2 - readlen, 1)] = 2.0;  // needed
+                    j += NT;
+                    while (j >= ncol) { j -= ncol; ++i; }
+                }
+                __syncthreads();
+                for (int x = 2 + tid; x <= dmax; x += NT)
+                    if (rept_tab[x] == 2.0) rept_tab[x] = rept_term(C, x);
             }
-            __syncthreads();
-            for (int d = 2 + tid; d <= dmax; d += NT)
-                if (rept_tab[d] == 2.0) rept_tab[d] = rept_term(C, d);
         }
-        if (use_roll_tab) {
+        if (d.use_roll_tab) {
             const int nt = u.n_target;
             for (int k = tid; k < (nrow + ncol) * nt; k += NT) {
                 const bool isrow = k < nrow * nt;
                 const int kk = isrow ? k : k - nrow * nt;
                 const int ai = kk / nt, t = kk - ai * nt;
-                const int h = isrow ? axis_value(ax1, S.obs.base, period, ai)
-                                    : (u.ploidy == 1 ? 0 : axis_value(ax2, S.obs.base, period, ai));
+                const int h = isrow ? axis_value(ax1, S.obs.base, period, ai) : axis_value(ax2, S.obs.base, period, ai);
                 int x = C.tl[t];
                 if (x < 0) x += SPAN;
                 const double rv = roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);
-                if (isrow) roll1[(size_t)ai * nt + t] = rv;
-                else roll2[(size_t)t * ncol + ai] = rv;   // transposed: coalesced across columns in pass A
+                if (isrow) slot[L.roll1 + (size_t)ai * nt + t] = rv;
+                else slot[L.roll2 + (size_t)t * ncol + ai] = rv;   // transposed: coalesced across columns
             }
         }
-        __syncthreads();
+        if (tid == 0) descs[g] = d;
+    }
+}
 
-        // ---- pass A: log-likelihood of every pair, arg-max ----
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- kernel 2: every pair of every unit ------------------------------------------------------------------
+// One wavefront per work item = (unit, 64 columns, up to 128 rows); lane = column.  Everything that depends
+// on the column only (h2, roll(h2)[x_t] for 32 spanning pairs at a time) sits in registers while the rows
+// stream by; what depends on the row only (h1, the far terms, roll(h1)[x_t]) is fetched one row ahead, the
+// 32 roll(h1) values with one coalesced load that v_readlane then hands out.
+//
+// paired-end term (models.py:460-473) from the tables: log of the running product of
+// max(.5 * roll(h1)[x] + .5 * roll(h2)[x], SMALL), flushed every 32 factors as in pe_term; with more than
+// 32 spanning pairs the rows are walked once per 32 and the partial sums parked in the ml buffer.
+// (.5*a + .5*b is evaluated as (a + b) * .5: scaling by a power of two is exact.)
+struct RowIn {
+    int h1;
+    double f1, f2, r1v;
+};
+
+__global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitDesc* descs, double* pool,
+                                                         const int* item_unit, Best* item_best, GridCounters* ctr) {
+    const int lane = threadIdx.x & 63;
+    const ModelConst& M = *a.model;
+    const int total = ctr->n_items;
+    while (true) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&ctr->next_item, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= total) break;
+        const int g = __builtin_amdgcn_readfirstlane(item_unit[t]);
+        const UnitDesc d = descs[g];   // by value: stays in registers across the stores below
+        const SlotLayout L = d.lay;
+        double* slot = pool + d.slot_off;
+        const int nrow = d.nrow, ncol = d.ncol, period = d.period;
+        const Obs* obs = reinterpret_cast<const Obs*>(slot + L.obs);
+        double* mlbuf = slot + L.ml;
+        const PairCtx C = make_ctx(d, M, obs, slot + L.pdf, a.target_lens);
+        int64_t dump_base = -1;
+        if (a.grid_dump != nullptr && d.n_pairs <= a.grid_off[g + 1] - a.grid_off[g]) dump_base = a.grid_off[g];
+        const int* row_off = reinterpret_cast<const int*>(slot + L.rowoff);
+        const int ncb = (ncol + CB - 1) / CB;
+        const int k = t - d.item_base;
+        const int rg = k / ncb, cb = k - rg * ncb;
+        const int i_begin = rg * RG, i_end = min(nrow, i_begin + RG);
+        const int j = cb * CB + lane;
+        const bool jin = j < ncol;
+        const int jc = jin ? j : ncol - 1;
+        const int h2col = d.ploidy == 1 ? 0 : axis_value(d.ax2, obs->base, period, jc);
+        const bool tab = d.run_pe && d.use_roll_tab;
+        const int n = d.n_target;
+        const int npass = tab ? (n + TC - 1) / TC : 1;
+        const double* roll1 = slot + L.roll1;
         Best mine; mine.ml = 0; mine.h1 = 0; mine.pos = -1;
-        {
-            int i = tid / ncol, j = tid - i * ncol;   // (row, column) of pos, advanced incrementally
-            for (int pos = tid; pos < rect; pos += NT) {
-                const int h1 = axis_value(ax1, S.obs.base, period, i);
-                const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
-                if (h1 > h2) mlbuf[pos] = 0;
-                else {
-                    double ml4[4];
-                    if (h2 >= h_far) { ml4[0] = far1[i]; ml4[1] = far2[i]; }
-                    else eval_reads(C, h1, h2, ml4[0], ml4[1]);
-                    const int dsum = max(h1 - readlen, 1) + max(h2 - readlen, 1);
-                    ml4[2] = use_rept_tab ? rept_tab[dsum] : rept_term(C, dsum);
-                    ml4[3] = 0;
-                    if (run_pe) {
-                        if (use_roll_tab && u.ploidy != 1)
-                            ml4[3] = pe_term<true>(C, h1, h2, roll1 + (size_t)i * u.n_target, roll2 + j, ncol);
-                        else ml4[3] = pe_term<false>(C, h1, h2, nullptr, nullptr, 0);
+        for (int pass = 0; pass < npass; ++pass) {
+            const bool last = pass == npass - 1;
+            const int t0 = pass * TC;
+            double b[TC];
+            if (tab) {
+#pragma unroll
+                for (int q = 0; q < TC; ++q) b[q] = t0 + q < n ? slot[L.roll2 + (size_t)(t0 + q) * ncol + jc] : 1.0;
+            }
+            auto load_row = [&](int i) {
+                RowIn r;
+                r.h1 = axis_value(d.ax1, obs->base, period, i);
+                r.f1 = slot[L.far1 + i];
+                r.f2 = slot[L.far2 + i];
+                r.r1v = 1.0;
+                if (tab && t0 + (lane & (TC - 1)) < n) r.r1v = roll1[(size_t)i * n + t0 + (lane & (TC - 1))];
+                return r;
+            };
+            RowIn cur = load_row(i_begin);
+            for (int i = i_begin; i < i_end; ++i) {
+                RowIn nxt = cur;
+                if (i + 1 < i_end) nxt = load_row(i + 1);
+                const int h1r = __builtin_amdgcn_readfirstlane(cur.h1);
+                const int h2r = d.ploidy == 1 ? h1r : h2col;
+                const bool ok = jin && h1r <= h2r;
+                if (__builtin_amdgcn_ballot_w64(ok) != 0) {   // else: row entirely below the diagonal here
+                    double lp = 0;
+                    if (tab) {
+                        double prod = 1.0;
+#pragma unroll
+                        for (int q = 0; q < TC; ++q) {
+                            double p = (readlane_d(cur.r1v, q) + b[q]) * .5;
+                            p = fmax(p, C.small);
+                            prod *= p;
+                        }
+                        lp = log(prod);
                     }
-                    const double ml = ml4[0] + ml4[1] + ml4[2] + ml4[3];  // models.py:269
-                    mlbuf[pos] = ml;
-                    Best b; b.ml = ml; b.h1 = h1; b.pos = pos;
-                    if (better(b, mine)) mine = b;
-                    if (dump_base >= 0) {
-                        int within = 0;  // valid columns before j in this row
-                        if (u.ploidy != 1)
-                            for (int jj = 0; jj < j; ++jj) within += axis_value(ax2, S.obs.base, period, jj) >= h1;
-                        double* d = a.grid_dump + (dump_base + S.row_off[i] + within) * 6;
-                        d[0] = h1; d[1] = h2; d[2] = ml4[0]; d[3] = ml4[1]; d[4] = ml4[2]; d[5] = ml4[3];
+                    if (ok) {
+                        const int pos = i * ncol + j;
+                        double m3 = pass == 0 ? 0.0 : mlbuf[pos];
+                        if (tab) m3 += lp;
+                        if (!last) mlbuf[pos] = m3;
+                        else {
+                            double m0, m1;
+                            if (h2r >= d.h_far) { m0 = cur.f1; m1 = cur.f2; }
+                            else eval_reads(C, h1r, h2r, m0, m1);
+                            const int dsum = max(h1r - d.readlen, 1) + max(h2r - d.readlen, 1);
+                            const double m2 = d.use_rept_tab ? slot[L.rept + dsum] : rept_term(C, dsum);
+                            if (d.run_pe && !d.use_roll_tab) m3 = pe_term<false>(C, h1r, h2r, nullptr, nullptr, 0);
+                            const double ml = m0 + m1 + m2 + m3;  // models.py:269
+                            mlbuf[pos] = ml;
+                            Best bb; bb.ml = ml; bb.h1 = h1r; bb.pos = pos;
+                            if (better(bb, mine)) mine = bb;
+                            if (dump_base >= 0) {
+                                int within = 0;  // valid columns before j in this row
+                                if (d.ploidy != 1)
+                                    for (int jj = 0; jj < j; ++jj) within += axis_value(d.ax2, obs->base, period, jj) >= h1r;
+                                double* o = a.grid_dump + (dump_base + row_off[i] + within) * 6;
+                                o[0] = h1r; o[1] = h2r; o[2] = m0; o[3] = m1; o[4] = m2; o[5] = m3;
+                            }
+                        }
                     }
                 }
-                j += NT;
-                while (j >= ncol) { j -= ncol; ++i; }
+                cur = nxt;
             }
+        }
+        // arg-max of the item with key (ml, -h1), first in enumeration order (models.py:299)
+        for (int o = 32; o > 0; o >>= 1) {
+            Best other;
+            other.ml = __shfl_down(mine.ml, o, 64);
+            other.h1 = __shfl_down(mine.h1, o, 64);
+            other.pos = __shfl_down(mine.pos, o, 64);
+            if (better(other, mine)) mine = other;
+        }
+        if (lane == 0) item_best[t] = mine;
+    }
+}
+
+// ---- kernel 3: per-unit reductions --------------------------------------------------------------------------
+struct ReduceShared {
+    double ph1[MAXM], ph2[MAXM];
+    double cum1[GRID_MAX_ROWS];   // row sums first, then the running sum of P_h1
+    double cum2[MAXM];
+    double red[NR / 64];
+    Best bred[NR / 64];
+    int lo[2], brk[2], lastnz[2];
+    int unit;
+};
+
+__device__ double block_sum_r(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    for (int w = 0; w < NR / 64; ++w) t += red[w];
+    return t;
+}
+
+__global__ __launch_bounds__(NR) void grid_reduce_kernel(GridArgs a, const UnitDesc* descs, double* pool,
+                                                         const Best* item_best, GridCounters* ctr) {
+    __shared__ ReduceShared S;
+    const int tid = threadIdx.x;
+    while (true) {
+        __syncthreads();
+        if (tid == 0) S.unit = atomicAdd(&ctr->next_reduce, 1);
+        __syncthreads();
+        const int g = __builtin_amdgcn_readfirstlane(S.unit);
+        if (g >= a.n_units) break;
+        if (descs[g].status == UNIT_SKIP) continue;   // written in an earlier pass
+        const UnitDesc d = descs[g];
+        const SlotLayout L = d.lay;
+        tredgpu_call call;
+        call.status = d.status; call.n_pairs = 0; call.h1 = call.h2 = -1;
+        call.ci[0] = call.ci[1] = call.ci[2] = call.ci[3] = 0;
+        call.run_pe = d.run_pe; call.pad = 0; call.lik = -1; call.pp = -1;
+        if (d.status != 0) {
+            if (tid == 0) a.calls[g] = call;
+            if (a.marg != nullptr)
+                for (int m = tid; m < 2 * a.marg_stride; m += NR) a.marg[(size_t)g * 2 * a.marg_stride + m] = 0;
+            continue;
+        }
+        double* slot = pool + d.slot_off;
+        const double* mlbuf = slot + L.ml;
+        const Obs* obs = reinterpret_cast<const Obs*>(slot + L.obs);
+        const int nrow = d.nrow, ncol = d.ncol, period = d.period;
+
+        // ---- arg-max over the items' winners ----
+        Best mine; mine.ml = 0; mine.h1 = 0; mine.pos = -1;
+        for (int k = d.item_base + tid; k < d.item_base + d.n_items; k += NR) {
+            const Best b = item_best[k];
+            if (better(b, mine)) mine = b;
         }
         for (int o = 32; o > 0; o >>= 1) {
             Best other;
@@ -604,114 +895,115 @@ __global__ __launch_bounds__(NT, 3) void grid_kernel(GridArgs a, double* scratch
             if (better(other, mine)) mine = other;
         }
         if ((tid & 63) == 0) S.bred[tid >> 6] = mine;
+        const int mlim = min(MAXM, d.hmaxv / period + 1);
+        for (int m = tid; m < mlim; m += NR) { S.ph1[m] = 0; S.ph2[m] = 0; }
+        if (tid < 2) { S.lo[tid] = MAXM; S.brk[tid] = MAXM; S.lastnz[tid] = 0; }
         __syncthreads();
         Best top = S.bred[0];
-        for (int w = 1; w < NT / 64; ++w) if (better(S.bred[w], top)) top = S.bred[w];
+        for (int w = 1; w < NR / 64; ++w) if (better(S.bred[w], top)) top = S.bred[w];
         const double max_ml = top.ml;
 
-        // ---- pass B: exp(ml - max) once per pair (models.py:280-285) + the PP sums (:342-368) ----
+        // ---- exp(ml - max) (models.py:280-285), the PP sums (:342-368) and the row sums: one wave per row
+        //      (fixed shuffle tree); pairs below the diagonal were never written and count as 0 ----
         double all = 0, path = 0;
-        {
-            int i = tid / ncol, j = tid - i * ncol;
-            for (int pos = tid; pos < rect; pos += NT) {
-                const int h1 = axis_value(ax1, S.obs.base, period, i);
-                const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
-                if (h1 <= h2) {   // else mlbuf[pos] stays 0: contributes nothing to the sums below
-                    const double e = exp(mlbuf[pos] - max_ml);
-                    mlbuf[pos] = e;
-                    all += e;
-                    const int lo = h1 / period, hi = h2 / period;
+        for (int i = tid >> 6; i < nrow; i += NR / 64) {
+            const int h1 = axis_value(d.ax1, obs->base, period, i);
+            const int lo = h1 / period;
+            double acc = 0;
+            for (int j = tid & 63; j < ncol; j += 64) {
+                const int h2 = d.ploidy == 1 ? h1 : axis_value(d.ax2, obs->base, period, j);
+                if (h1 <= h2) {
+                    const double e = exp(mlbuf[i * ncol + j] - max_ml);
+                    acc += e;
+                    const int hi = h2 / period;
                     bool p;
-                    if (u.is_expansion) p = (u.is_recessive ? lo : hi) >= u.cutoff_risk;
-                    else p = (u.is_recessive ? hi : lo) <= u.cutoff_risk;
+                    if (d.is_expansion) p = (d.is_recessive ? lo : hi) >= d.cutoff_risk;
+                    else p = (d.is_recessive ? hi : lo) <= d.cutoff_risk;
                     if (p) path += e;
                 }
-                j += NT;
-                while (j >= ncol) { j -= ncol; ++i; }
             }
-        }
-        all = block_sum(all, S.red);
-        path = block_sum(path, S.red);
-        const int mlim = min(MAXM, hmaxv / period + 1);
-        for (int m = tid; m < mlim; m += NT) { S.ph1[m] = 0; S.ph2[m] = 0; }
-        __syncthreads();  // also orders the mlbuf writes above before the reads below
-        // marginal P_h1: one wave per row (fixed shuffle tree), rows merged by key in row order
-        for (int i = tid >> 6; i < nrow; i += NT / 64) {
-            double acc = 0;
-            for (int j = tid & 63; j < ncol; j += 64) acc += mlbuf[i * ncol + j];
+            all += acc;
             acc = wave_sum(acc);
-            if ((tid & 63) == 0) far1[i] = acc;  // far1 is free now: row sums
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 0; i < nrow; ++i) {
-                const int m = axis_value(ax1, S.obs.base, period, i) / period;
-                if (m < MAXM) S.ph1[m] += far1[i];
-            }
+            if ((tid & 63) == 0) S.cum1[i] = acc;
         }
         // marginal P_h2: one thread per distinct h2 value, rows outermost as in the reference.  The
         // extended axis can list a value twice (base part + arithmetic part, models.py:251-252): the
         // first occurrence owns the sum.
-        if (u.ploidy != 1) {
-            for (int j = tid; j < ncol; j += NT) {
-                const int h2 = axis_value(ax2, S.obs.base, period, j);
+        if (d.ploidy != 1) {
+            for (int j = tid; j < ncol; j += NR) {
+                const int h2 = axis_value(d.ax2, obs->base, period, j);
                 int twin = -1;
-                if (j < ax2.nb) {
-                    const int d = h2 - ax2.start;
-                    if (ax2.n > 0 && d >= 0 && d % period == 0 && d / period < ax2.n) twin = ax2.nb + d / period;
+                if (j < d.ax2.nb) {
+                    const int dd = h2 - d.ax2.start;
+                    if (d.ax2.n > 0 && dd >= 0 && dd % period == 0 && dd / period < d.ax2.n) twin = d.ax2.nb + dd / period;
                 } else {
                     bool dup = false;
-                    for (int k = 0; k < ax2.nb; ++k) dup |= S.obs.base[k] == h2;
+                    for (int k = 0; k < d.ax2.nb; ++k) dup |= obs->base[k] == h2;
                     if (dup) continue;  // owned by the base occurrence
                 }
                 double acc = 0;
+#pragma unroll 4
                 for (int i = 0; i < nrow; ++i) {
-                    acc += mlbuf[i * ncol + j];
-                    if (twin >= 0) acc += mlbuf[i * ncol + twin];
+                    if (axis_value(d.ax1, obs->base, period, i) > h2) continue;
+                    acc += exp(mlbuf[i * ncol + j] - max_ml);
+                    if (twin >= 0) acc += exp(mlbuf[i * ncol + twin] - max_ml);
                 }
                 const int m = h2 / period;
                 if (m < MAXM) S.ph2[m] = acc;
             }
         }
+        all = block_sum_r(all, S.red);
+        path = block_sum_r(path, S.red);   // (its barriers also publish the row sums and S.ph2)
+        if (tid == 0) {
+            for (int i = 0; i < nrow; ++i) {   // rows merged by key in row order
+                const int m = axis_value(d.ax1, obs->base, period, i) / period;
+                if (m < MAXM) S.ph1[m] += S.cum1[i];
+            }
+        }
         __syncthreads();
-        if (u.ploidy == 1) {
-            for (int m = tid; m < mlim; m += NT) S.ph2[m] = S.ph1[m];  // h2 == h1 for every pair
+        if (d.ploidy == 1) {
+            for (int m = tid; m < mlim; m += NR) S.ph2[m] = S.ph1[m];  // h2 == h1 for every pair
             __syncthreads();
         }
-
+        // ---- calc_CI, models.py:319-340 on each marginal: running sums by one lane each, then every
+        //      thread tests its own bins against the 2.5 % / 97.5 % marks ----
+        if (tid == 0 || tid == 64) {
+            const double* P = tid ? S.ph2 : S.ph1;
+            double* cum = tid ? S.cum2 : S.cum1;
+            double c = 0;
+            for (int m = 0; m < mlim; ++m) { c += P[m]; cum[m] = c; }
+        }
+        __syncthreads();
+        for (int which = 0; which < 2; ++which) {
+            const double* P = which ? S.ph2 : S.ph1;
+            const double* cum = which ? S.cum2 : S.cum1;
+            const double total = cum[mlim - 1];
+            for (int m = tid; m < mlim; m += NR) {
+                if (P[m] == 0) continue;
+                atomicMax(&S.lastnz[which], m);
+                if (cum[m] > .025 * total) atomicMin(&S.lo[which], m);
+                if (cum[m] > .975 * total) atomicMin(&S.brk[which], m);
+            }
+        }
+        __syncthreads();
         if (tid == 0) {
-            // calc_CI, models.py:319-340 on each marginal
             for (int which = 0; which < 2; ++which) {
-                const double* P = which ? S.ph2 : S.ph1;
-                double total = 0;
-                for (int m = 0; m < mlim; ++m) total += P[m];
-                double cum = 0;
-                int lo = 0, hi = 0, last = 0;
-                bool in_range = false, broke = false;
-                for (int m = 0; m < mlim && !broke; ++m) {
-                    if (P[m] == 0) continue;
-                    last = m;
-                    cum += P[m];
-                    if (!in_range && cum > .025 * total) { in_range = true; lo = m; }
-                    if (cum > .975 * total) broke = true;
-                }
-                hi = last;
-                call.ci[2 * which] = lo;
-                call.ci[2 * which + 1] = hi;
+                call.ci[2 * which] = S.lo[which] < MAXM ? S.lo[which] : 0;
+                call.ci[2 * which + 1] = S.brk[which] < MAXM ? S.brk[which] : S.lastnz[which];
             }
             const int bi = top.pos / ncol, bj = top.pos - bi * ncol;
-            call.h1 = axis_value(ax1, S.obs.base, period, bi);
-            call.h2 = u.ploidy == 1 ? call.h1 : axis_value(ax2, S.obs.base, period, bj);
+            call.h1 = axis_value(d.ax1, obs->base, period, bi);
+            call.h2 = d.ploidy == 1 ? call.h1 : axis_value(d.ax2, obs->base, period, bj);
             call.lik = max_ml;
             const double pp = path / all;
             call.pp = pp < 1 ? pp : 1;
-            call.n_pairs = n_pairs;
-            call.run_pe = run_pe;
-            call.status = (a.grid_dump != nullptr && dump_base < 0) ? -4 : 0;
+            call.n_pairs = d.n_pairs;
+            call.status = 0;
+            if (a.grid_dump != nullptr && d.n_pairs > a.grid_off[g + 1] - a.grid_off[g]) call.status = -4;
             a.calls[g] = call;
         }
         if (a.marg != nullptr) {
-            for (int m = tid; m < a.marg_stride; m += NT) {
+            for (int m = tid; m < a.marg_stride; m += NR) {
                 a.marg[((size_t)g * 2 + 0) * a.marg_stride + m] = m < mlim ? S.ph1[m] : 0;
                 a.marg[((size_t)g * 2 + 1) * a.marg_stride + m] = m < mlim ? S.ph2[m] : 0;
             }
@@ -727,16 +1019,59 @@ hipError_t launch_pe_kde(const GridArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_grid(const GridArgs& a, double* scratch, int* next_unit, hipStream_t s) {
-    if (a.n_units <= 0) return hipSuccess;
-    hipError_t e0 = hipMemsetAsync(next_unit, 0, sizeof(int), s);
-    if (e0 != hipSuccess) return e0;
-    const int blocks = a.n_units < GRID_MAX_BLOCKS ? a.n_units : GRID_MAX_BLOCKS;
-    const size_t smem = sizeof(GridShared);
-    hipError_t e = hipFuncSetAttribute((const void*)grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    grid_kernel<<<blocks, NT, smem, s>>>(a, scratch, next_unit);
+namespace {
+__global__ void unit_max_kernel(const tredgpu_unit_params* units, int n, int* out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int v = g < n ? units[g].maxinsert : 0;
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, 64));
+    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+}
+}  // namespace
+
+hipError_t launch_unit_max(const tredgpu_unit_params* units, int n_units, int* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(int), s);
+    if (e != hipSuccess || n_units <= 0) return e;
+    unit_max_kernel<<<(n_units + 255) / 256, 256, 0, s>>>(units, n_units, out);
     return hipGetLastError();
 }
+
+size_t grid_desc_bytes() { return sizeof(UnitDesc); }
+
+size_t grid_counter_bytes() { return sizeof(GridCounters); }
+
+size_t grid_items_cap(int rows_cap, int cols_cap) {   // most work items one unit can make
+    return (size_t)((cols_cap + CB - 1) / CB) * ((rows_cap + RG - 1) / RG);
+}
+
+size_t grid_item_bytes() { return sizeof(int) + sizeof(Best); }
+
+size_t grid_slot_doubles_max(int rows_cap, int cols_cap) {   // largest slot a unit within the caps can ask for
+    return (sizeof(Obs) + 7) / 8 + (size_t)rows_cap * 3 + 2 + SPAN + GRID_REPT_TAB + (size_t)(rows_cap + cols_cap) * GRID_TMAX +
+           (size_t)rows_cap * cols_cap + 16;
+}
+
+// One pass over all units: prepare (takes pool room per unit) -> pairs -> reduce, all on stream s.  Units that
+// found the pool full are marked UNIT_DEFERRED in calls[].status and counted in the counter block's
+// n_deferred; the caller runs further passes (pass > 0 touches only those) until none is left.
+// items: item_cap ints (item -> unit), then item_cap arg-max records
+hipError_t launch_grid_pass(const GridArgs& a, int pass, void* descs, double* pool, size_t pool_doubles, int rows_cap,
+                            int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s) {
+    if (a.n_units <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(counters, 0, sizeof(GridCounters), s);
+    if (e != hipSuccess) return e;
+    UnitDesc* d = (UnitDesc*)descs;
+    GridCounters* ctr = (GridCounters*)counters;
+    int* item_unit = (int*)items;
+    Best* item_best = (Best*)(item_unit + ((item_cap + 3) & ~(size_t)3));
+    const int pb = a.n_units < 1536 ? a.n_units : 1536;
+    grid_prepare_kernel<<<pb, NT, 0, s>>>(a, pass, d, pool, (unsigned long long)pool_doubles, rows_cap, cols_cap, item_unit,
+                                          ctr);
+    grid_pairs_kernel<<<2048, 256, 0, s>>>(a, d, pool, item_unit, item_best, ctr);
+    const int rb = a.n_units < 2048 ? a.n_units : 2048;
+    grid_reduce_kernel<<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
+    return hipGetLastError();
+}
+
+int grid_deferred_offset() { return (int)offsetof(GridCounters, n_deferred); }
 
 }  // namespace tredgpu

@@ -88,18 +88,24 @@ struct GridArgs {
     double* kde_pdf;      // tredgpu_pe_kde only: [n_units][1000] output
     int32_t* kde_status;  // tredgpu_pe_kde only: [n_units]
 };
-constexpr int GRID_MAX_ROWS = 512;   // |h1range| a workgroup can hold
-constexpr int GRID_MAX_COLS = 1024;  // |h2range|
-constexpr int GRID_MAX_BLOCKS = 1536;  // 6 resident 128-thread workgroups per CU x 256 CUs
+constexpr int GRID_MAX_ROWS = 1024;  // |h1range| / |h2range| the grid kernels accept (status -5 beyond)
+constexpr int GRID_MAX_COLS = 1024;
 constexpr int GRID_REPT_TAB = 8192;   // entries of the per-unit repeat-only table (index dsum)
 constexpr int GRID_TMAX = 128;        // spanning pairs per unit the roll tables hold
-constexpr size_t GRID_SCRATCH_DOUBLES = (size_t)GRID_REPT_TAB + (size_t)(GRID_MAX_ROWS + GRID_MAX_COLS) * GRID_TMAX +
-                                        2 * (size_t)GRID_MAX_ROWS + (size_t)GRID_MAX_ROWS * GRID_MAX_COLS;
-inline size_t grid_scratch_bytes(int n_units) {
-    const size_t blocks = n_units < GRID_MAX_BLOCKS ? n_units : GRID_MAX_BLOCKS;
-    return blocks * GRID_SCRATCH_DOUBLES * sizeof(double);
-}
+constexpr size_t GRID_POOL_BYTES = (size_t)12 << 30;  // scratch pool the units' tables are carved from
+constexpr int GRID_UNIT_DEFERRED = 100;               // calls[].status of a unit waiting for the next pass
+
 hipError_t launch_pe_kde(const GridArgs& a, hipStream_t s);
-hipError_t launch_grid(const GridArgs& a, double* scratch, int* next_unit, hipStream_t s);
+// max over units of maxinsert -> *out (device int, zeroed by the launch)
+hipError_t launch_unit_max(const tredgpu_unit_params* units, int n_units, int* out, hipStream_t s);
+size_t grid_desc_bytes();
+size_t grid_counter_bytes();
+int grid_deferred_offset();                          // byte offset of the deferred-unit count in the counter block
+size_t grid_slot_doubles_max(int rows_cap, int cols_cap);
+size_t grid_items_cap(int rows_cap, int cols_cap);   // work items one unit can make at most
+size_t grid_item_bytes();                            // bytes per work item in the items buffer
+// One pass over all units (prepare -> pairs -> reduce); see grid.hip
+hipError_t launch_grid_pass(const GridArgs& a, int pass, void* descs, double* pool, size_t pool_doubles, int rows_cap,
+                            int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s);
 
 }  // namespace tredgpu
