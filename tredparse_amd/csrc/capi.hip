@@ -378,13 +378,16 @@ int tredgpu_set_model(tredgpu_ctx* c, const double* step_pdf, const double* stut
     if (!c) return -2;
     if (!step_pdf || !stutter_w) return fail(c, -2, "model arrays are NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    ModelConst m;
+    std::vector<ModelConst> mbuf(1);   // 33 KB: not on the stack
+    ModelConst& m = mbuf[0];
     memcpy(m.step, step_pdf, sizeof m.step);
     memcpy(m.w, stutter_w, sizeof m.w);
     m.gc = gc;
     m.score = score;
     m.small = std::exp(-10.0);
     m.really_small = std::exp(-100.0);
+    m.logsmall = std::log(m.small);
+    for (int n = 0; n < GRID_LFACT; ++n) m.lfact[n] = std::lgamma((double)n + 1);
     int rc;
     if ((rc = ensure(c, c->d_model, sizeof m))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

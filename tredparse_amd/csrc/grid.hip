@@ -385,6 +385,17 @@ constexpr int TC = 32;    // spanning pairs per pass over the rows (the lane's r
 
 __device__ __forceinline__ int unit_items(int nrow, int ncol) { return ((ncol + CB - 1) / CB) * ((nrow + RG - 1) / RG); }
 
+// A unit's parameters as wave-uniform values: the loads go through the vector path (the kernels store to
+// memory the compiler cannot tell apart), readfirstlane moves every field to a scalar register.
+__device__ __forceinline__ tredgpu_unit_params uniform_unit(const tredgpu_unit_params* p) {
+    static_assert(sizeof(tredgpu_unit_params) == 16 * sizeof(int), "tredgpu_unit_params is 16 dwords");
+    union { tredgpu_unit_params u; int w[16]; } x;
+    x.u = *p;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x.w[k] = __builtin_amdgcn_readfirstlane(x.w[k]);
+    return x.u;
+}
+
 struct PrepShared {
     Obs obs;
     int hist[SPAN];
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
             if (tid == 0) descs[g].status = UNIT_SKIP;
             continue;
         }
-        const tredgpu_unit_params u = a.units[g];
+        const tredgpu_unit_params u = uniform_unit(a.units + g);
         const int period = u.period, readlen = u.readlen;
         const int t1 = readlen - 9, t2 = readlen - 18, t3 = readlen - 27;  // models.py:114-116
 
@@ -492,13 +503,16 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
             S.status = st;
         }
         __syncthreads();
-        const int nF = S.obs.nF, nP = S.obs.nP, n_rept = S.flag;
-        int status = S.status;
-        const int max_full = nF ? S.obs.fullK[nF - 1] : 0;
-        const int max_partial = nP ? S.obs.partK[nP - 1] : 0;
+        // (LDS reads land in VGPRs; these are the same for every lane and steer everything below)
+        const int nF = __builtin_amdgcn_readfirstlane(S.obs.nF), nP = __builtin_amdgcn_readfirstlane(S.obs.nP);
+        const int n_rept = __builtin_amdgcn_readfirstlane(S.flag);
+        int status = __builtin_amdgcn_readfirstlane(S.status);
+        const int max_full = __builtin_amdgcn_readfirstlane(nF ? S.obs.fullK[nF - 1] : 0);
+        const int max_partial = __builtin_amdgcn_readfirstlane(nP ? S.obs.partK[nP - 1] : 0);
         int reads_above_full = 0;
         for (int i = 0; i < nP; ++i)
             if (S.obs.partK[i] > max_full + period) reads_above_full += S.obs.partC[i];
+        reads_above_full = __builtin_amdgcn_readfirstlane(reads_above_full);
         // observation sizes index the 1000-vectors (models.py:198,206): IndexError past the end
         if (status == 0 && (max_full >= SPAN || max_partial >= SPAN)) status = -3;
         __syncthreads();  // S.hist is reused by the KDE below
@@ -521,6 +535,7 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
             } else {
                 rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, S.kflag);
             }
+            rc = __builtin_amdgcn_readfirstlane(rc);
             if (rc) status = rc;
         }
         if (status == 0 && run_pe) {
@@ -546,7 +561,7 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
             S.obs.nb = nb;
         }
         __syncthreads();
-        const int nb = S.obs.nb;
+        const int nb = __builtin_amdgcn_readfirstlane(S.obs.nb);
         if (status == 0 && nb == 0) status = 1;  // no evidence: alleles (-1,-1), models.py:244-245
         const int mp_eff = max(t2, max_partial);  // self.max_partial, models.py:117,241-242
         Axis ext, bas, ful, ax1, ax2;
@@ -582,8 +597,12 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
         d.use_rept_tab = 0; d.use_roll_tab = 0;
         d.cutoff_risk = u.cutoff_risk; d.is_expansion = u.is_expansion; d.is_recessive = u.is_recessive; d.pad1 = 0;
         d.half_depth = u.half_depth;
-        d.lgam_rept = lgamma((double)n_rept + 1);
-        d.logsmall = log(M.small);
+        if (n_rept < GRID_LFACT) d.lgam_rept = M.lfact[n_rept];
+        else {
+            const double x = (double)n_rept + 1, r = 1.0 / x, r2 = r * r;
+            d.lgam_rept = (x - .5) * log(x) - x + .91893853320467274178 + r * (1. / 12 - r2 * (1. / 360 - r2 * (1. / 1260)));
+        }
+        d.logsmall = M.logsmall;
         d.slot_off = 0; d.item_base = 0; d.n_items = 0;
         if (status != 0) {
             if (tid == 0) descs[g] = d;
@@ -608,12 +627,16 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
             else atomicAdd(&ctr->n_deferred, 1);
         }
         __syncthreads();
-        if (!S.flag) {
+        if (!__builtin_amdgcn_readfirstlane(S.flag)) {
             if (tid == 0) { d.status = UNIT_DEFERRED; descs[g] = d; }
             continue;
         }
-        d.slot_off = S.slot_off;
-        d.item_base = S.status;
+        {
+            const long long so = S.slot_off;
+            d.slot_off = ((long long)__builtin_amdgcn_readfirstlane((int)(so >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)so);
+        }
+        d.item_base = __builtin_amdgcn_readfirstlane(S.status);
         const SlotLayout L = d.lay;
         double* slot = pool + d.slot_off;
         for (int k = tid; k < d.n_items; k += NT) item_unit[d.item_base + k] = g;
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
             S.row_off[nrow] = acc;
         }
         __syncthreads();
-        d.n_pairs = S.row_off[nrow];
+        d.n_pairs = __builtin_amdgcn_readfirstlane(S.row_off[nrow]);
         if (a.grid_dump != nullptr)
             for (int i = tid; i <= nrow; i += NT) row_off[i] = S.row_off[i];
 

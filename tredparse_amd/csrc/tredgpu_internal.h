@@ -68,7 +68,12 @@ struct ModelConst {
     double gc, score;
     double small;         // SMALL_VALUE = exp(-10), models.py:34 (host libm value)
     double really_small;  // REALLY_SMALL_VALUE = exp(-100), models.py:35
+    double logsmall;      // log(SMALL_VALUE)
+    // gammaln(n + 1) for the repeat-only read counts (models.py:215, scipy poisson.pmf): host lgamma for
+    // n < GRID_LFACT, Stirling's series beyond (exact to the last bit there)
+    double lfact[4096];
 };
+constexpr int GRID_LFACT = 4096;
 
 struct GridArgs {
     const tredgpu_unit_params* units;
