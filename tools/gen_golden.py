@@ -55,9 +55,11 @@ def make_reads(rng, loci, names, readlen, n_units, **kw):
 def gen_sw(loci):
     rng = np.random.default_rng(20260101)
     reads_all, refs_all, pr, pt, meta = [], [], [], [], []
-    plan = [(150, ["HD", "DM1", "SCA10", "ULD", "OPMD", "BPES", "ALS", "DM2", "FRDA", "SCA8"], 2, 10),
-            (100, ["HD", "SCA36", "CCD"], 2, 8), (250, ["HD", "DM2"], 1, 8), (36, ["SCA3"], 1, 20)]
-    for readlen, names, n_units, cov in plan:
+    every = [l["name"] for l in loci]
+    plan = [(150, ["HD", "DM1", "SCA10", "ULD", "OPMD", "BPES", "ALS", "DM2", "FRDA", "SCA8"], 2, 10, 40),
+            (100, ["HD", "SCA36", "CCD"], 2, 8, 40), (250, ["HD", "DM2"], 1, 8, 40), (36, ["SCA3"], 1, 20, 40),
+            (150, every, 1, 10, 5)]      # every locus of the table, a few reads each
+    for readlen, names, n_units, cov, n_keep in plan:
         for locus, reads in make_reads(rng, loci, names, readlen, n_units, coverage=cov, sub=0.02,
                                        indel=0.004, nrate=0.01, min_units=1,
                                        max_units=max(4, readlen // len("CAG") + 10)):
@@ -66,7 +68,7 @@ def gen_sw(loci):
                 continue
             refs = [t for _, t in po.build_ladder(locus["prefix"], locus["repeat"], locus["suffix"], mu)]
             # subsample reads so the file stays small
-            keep = rng.permutation(len(reads))[:40]
+            keep = rng.permutation(len(reads))[:n_keep]
             r0, t0 = len(reads_all), len(refs_all)
             reads_all += [reads[i] for i in keep]
             refs_all += refs
