@@ -19,6 +19,8 @@
 //
 // Arithmetic mirrors the reference's operation order (compiled with -ffp-contract=off); the only
 // intended differences are libm-vs-ocml last-bit effects in log/exp/lgamma.
+#include <type_traits>
+
 #include "tredgpu_internal.h"
 
 namespace tredgpu {
@@ -860,6 +862,7 @@ struct ReduceShared {
     double ph1[MAXM], ph2[MAXM];
     double cum1[GRID_MAX_ROWS];   // row sums first, then the running sum of P_h1
     double cum2[MAXM];
+    double colsum[GRID_MAX_COLS];
     double red[NR / 64];
     Best bred[NR / 64];
     int lo[2], brk[2], lastnz[2];
@@ -926,32 +929,74 @@ __global__ __launch_bounds__(NR) void grid_reduce_kernel(GridArgs a, const UnitD
         for (int w = 1; w < NR / 64; ++w) if (better(S.bred[w], top)) top = S.bred[w];
         const double max_ml = top.ml;
 
-        // ---- exp(ml - max) (models.py:280-285), the PP sums (:342-368) and the row sums: one wave per row
-        //      (fixed shuffle tree); pairs below the diagonal were never written and count as 0 ----
+        // ---- one pass over the grid: exp(ml - max) (models.py:280-285), the PP sums (:342-368), row sums
+        //      (one wave per row, fixed shuffle tree) and per-wave column sums (lane = column, kept in
+        //      registers; the four waves' partial sums are added up in wave order below).  Pairs below the
+        //      diagonal were never written and count as 0.
+        const int lane = tid & 63, wv = tid >> 6;
+        const int nk = (ncol + 63) >> 6;
         double all = 0, path = 0;
-        for (int i = tid >> 6; i < nrow; i += NR / 64) {
-            const int h1 = axis_value(d.ax1, obs->base, period, i);
-            const int lo = h1 / period;
-            double acc = 0;
-            for (int j = tid & 63; j < ncol; j += 64) {
-                const int h2 = d.ploidy == 1 ? h1 : axis_value(d.ax2, obs->base, period, j);
-                if (h1 <= h2) {
-                    const double e = exp(mlbuf[i * ncol + j] - max_ml);
-                    acc += e;
-                    const int hi = h2 / period;
-                    bool p;
-                    if (d.is_expansion) p = (d.is_recessive ? lo : hi) >= d.cutoff_risk;
-                    else p = (d.is_recessive ? hi : lo) <= d.cutoff_risk;
-                    if (p) path += e;
-                }
+        // KC = column chunks a lane owns per sweep (4 for grids up to 256 columns wide, else 8; wider grids
+        // take a second sweep over the rows for chunks 8..15), k0 = first chunk of the sweep
+        auto sweep = [&](auto kc_tag, const int k0) {
+            constexpr int KC = decltype(kc_tag)::value;
+            int h2k[KC];
+            unsigned colpath = 0;   // bit k: the column's h2 decides "pathological" and says yes
+            const bool by_col = d.ploidy != 1 && ((d.is_expansion != 0) != (d.is_recessive != 0));   // hi decides
+    #pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int j = lane + 64 * (k0 + k);
+                h2k[k] = k0 + k < nk && j < ncol ? axis_value(d.ax2, obs->base, period, j) : -1;   // -1: no column
+                const int hi = h2k[k] / period;
+                if (by_col && h2k[k] >= 0 && (d.is_expansion ? hi >= d.cutoff_risk : hi <= d.cutoff_risk)) colpath |= 1u << k;
             }
-            all += acc;
-            acc = wave_sum(acc);
-            if ((tid & 63) == 0) S.cum1[i] = acc;
+            double colacc[KC];
+    #pragma unroll
+            for (int k = 0; k < KC; ++k) colacc[k] = 0;
+            for (int i = wv; i < nrow; i += NR / 64) {
+                const int h1 = axis_value(d.ax1, obs->base, period, i);
+                const int lo = h1 / period;
+                // ploidy 1: h2 = h1, one column; both alleles equal, so lo decides whatever the inheritance
+                const bool rowpath = !by_col && (d.is_expansion ? lo >= d.cutoff_risk : lo <= d.cutoff_risk);
+                double v[KC];
+    #pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const bool ok = k0 + k < nk && (d.ploidy == 1 ? lane == 0 && k == 0 : h2k[k] >= h1);
+                    v[k] = ok ? mlbuf[i * ncol + lane + 64 * (k0 + k)] : 0.0;
+                }
+                double acc = 0;
+    #pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    if (k0 + k >= nk) break;
+                    const bool ok = d.ploidy == 1 ? lane == 0 && k == 0 : h2k[k] >= h1;
+                    const double e = ok ? exp(v[k] - max_ml) : 0.0;
+                    acc += e;
+                    colacc[k] += e;
+                    if (rowpath || ((colpath >> k) & 1u)) path += e;
+                }
+                all += acc;
+                acc = wave_sum(acc);
+                if (lane == 0) S.cum1[i] = k0 == 0 ? acc : S.cum1[i] + acc;
+            }
+            // column sums: wave 0 stores, waves 1..3 add in turn
+            for (int w = 0; w < NR / 64; ++w) {
+                if (wv == w) {
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const int j = lane + 64 * (k0 + k);
+                        if (k0 + k < nk && j < ncol) S.colsum[j] = w == 0 ? colacc[k] : S.colsum[j] + colacc[k];
+                    }
+                }
+                __syncthreads();
+            }
+        };
+        if (nk <= 4) sweep(std::integral_constant<int, 4>(), 0);
+        else {
+            sweep(std::integral_constant<int, 8>(), 0);
+            if (nk > 8) sweep(std::integral_constant<int, 8>(), 8);
         }
-        // marginal P_h2: one thread per distinct h2 value, rows outermost as in the reference.  The
-        // extended axis can list a value twice (base part + arithmetic part, models.py:251-252): the
-        // first occurrence owns the sum.
+        // marginal P_h2 by distinct h2 value.  The extended axis can list a value twice (base part +
+        // arithmetic part, models.py:251-252): the first occurrence owns the sum of both columns.
         if (d.ploidy != 1) {
             for (int j = tid; j < ncol; j += NR) {
                 const int h2 = axis_value(d.ax2, obs->base, period, j);
@@ -964,15 +1009,8 @@ __global__ __launch_bounds__(NR) void grid_reduce_kernel(GridArgs a, const UnitD
                     for (int k = 0; k < d.ax2.nb; ++k) dup |= obs->base[k] == h2;
                     if (dup) continue;  // owned by the base occurrence
                 }
-                double acc = 0;
-#pragma unroll 4
-                for (int i = 0; i < nrow; ++i) {
-                    if (axis_value(d.ax1, obs->base, period, i) > h2) continue;
-                    acc += exp(mlbuf[i * ncol + j] - max_ml);
-                    if (twin >= 0) acc += exp(mlbuf[i * ncol + twin] - max_ml);
-                }
                 const int m = h2 / period;
-                if (m < MAXM) S.ph2[m] = acc;
+                if (m < MAXM) S.ph2[m] = twin >= 0 ? S.colsum[j] + S.colsum[twin] : S.colsum[j];
             }
         }
         all = block_sum_r(all, S.red);
