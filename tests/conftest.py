@@ -15,6 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def ctx():
     """One libtredgpu context on cuda:0 for the whole GPU session."""
+    # PyTorch-ROCm ships its own HIP runtime: a process that uses both must load torch first (INTEGRATION.md),
+    # whatever order the test files run in
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from tredparse_amd import _lib
     c = _lib.Context(0)
     yield c

@@ -345,7 +345,7 @@ __device__ inline SlotLayout unit_layout(int nrow, int ncol, int nt, bool want_p
     L.far2 = o;   o += nrow;
     L.pdf = o;    o += want_pdf ? SPAN : 0;
     L.rept = o;   o += use_rept ? dmax + 1 : 0;
-    L.roll1 = o;  o += use_roll ? nrow * nt : 0;
+    L.roll1 = o;  o += use_roll ? nrow * ((nt + 31) & ~31) : 0;   // rows padded to 32 entries
     L.roll2 = o;  o += use_roll ? ncol * nt : 0;
     L.ml = o;     o += nrow * ncol;
     L.total = (o + 15) & ~15;   // slots start on 128-byte lines
@@ -384,6 +384,7 @@ static_assert(sizeof(GridCounters) == 256, "counter block layout");
 constexpr int CB = 64;    // columns per work item of grid_pairs_kernel: one lane owns one h2 for all the item's rows
 constexpr int RG = 128;   // rows per item
 constexpr int TC = 32;    // spanning pairs per pass over the rows (the lane's roll(h2) values stay in registers)
+static_assert(TC == 32, "roll1 rows are padded to 32 entries (unit_layout)");
 
 __device__ __forceinline__ int unit_items(int nrow, int ncol) { return ((ncol + CB - 1) / CB) * ((nrow + RG - 1) / RG); }
 
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
             }
         }
         if (d.use_roll_tab) {
-            const int nt = u.n_target;
+            const int nt = u.n_target, ntp = (nt + 31) & ~31;
             for (int k = tid; k < (nrow + ncol) * nt; k += NT) {
                 const bool isrow = k < nrow * nt;
                 const int kk = isrow ? k : k - nrow * nt;
@@ -716,9 +717,14 @@ __global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, 
                 const int h = isrow ? axis_value(ax1, S.obs.base, period, ai) : axis_value(ax2, S.obs.base, period, ai);
                 int x = C.tl[t];
                 if (x < 0) x += SPAN;
-                const double rv = roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);
-                if (isrow) slot[L.roll1 + (size_t)ai * nt + t] = rv;
+                // the tables hold .5 * roll(h)[x]: the pair's factor is the plain sum of two entries (models.py:469)
+                const double rv = .5 * roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);
+                if (isrow) slot[L.roll1 + (size_t)ai * ntp + t] = rv;
                 else slot[L.roll2 + (size_t)t * ncol + ai] = rv;   // transposed: coalesced across columns
+            }
+            for (int k = tid; k < nrow * (ntp - nt); k += NT) {     // padding: .5 + .5 = a factor of 1
+                const int ai = k / (ntp - nt), t = nt + k - ai * (ntp - nt);
+                slot[L.roll1 + (size_t)ai * ntp + t] = .5;
             }
         }
         if (tid == 0) descs[g] = d;
@@ -740,7 +746,7 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // paired-end term (models.py:460-473) from the tables: log of the running product of
 // max(.5 * roll(h1)[x] + .5 * roll(h2)[x], SMALL), flushed every 32 factors as in pe_term; with more than
 // 32 spanning pairs the rows are walked once per 32 and the partial sums parked in the ml buffer.
-// (.5*a + .5*b is evaluated as (a + b) * .5: scaling by a power of two is exact.)
+// (the tables hold .5 * roll(h)[x], so a factor is max(entry + entry, SMALL).)
 struct RowIn {
     int h1;
     double f1, f2, r1v;
@@ -777,7 +783,8 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
         const int h2col = d.ploidy == 1 ? 0 : axis_value(d.ax2, obs->base, period, jc);
         const bool tab = d.run_pe && d.use_roll_tab;
         const int n = d.n_target;
-        const int npass = tab ? (n + TC - 1) / TC : 1;
+        const int ntp = (n + TC - 1) & ~(TC - 1);
+        const int npass = tab ? ntp / TC : 1;
         const double* roll1 = slot + L.roll1;
         Best mine; mine.ml = 0; mine.h1 = 0; mine.pos = -1;
         for (int pass = 0; pass < npass; ++pass) {
@@ -786,21 +793,32 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
             double b[TC];
             if (tab) {
 #pragma unroll
-                for (int q = 0; q < TC; ++q) b[q] = t0 + q < n ? slot[L.roll2 + (size_t)(t0 + q) * ncol + jc] : 1.0;
+                for (int q = 0; q < TC; ++q) b[q] = t0 + q < n ? slot[L.roll2 + (size_t)(t0 + q) * ncol + jc] : .5;
             }
             auto load_row = [&](int i) {
                 RowIn r;
                 r.h1 = axis_value(d.ax1, obs->base, period, i);
                 r.f1 = slot[L.far1 + i];
                 r.f2 = slot[L.far2 + i];
-                r.r1v = 1.0;
-                if (tab && t0 + (lane & (TC - 1)) < n) r.r1v = roll1[(size_t)i * n + t0 + (lane & (TC - 1))];
+                r.r1v = .5;
+                if (tab) r.r1v = roll1[(size_t)i * ntp + t0 + (lane & (TC - 1))];
                 return r;
             };
+            // software pipeline over the rows: row i+2's scalars and roll(h1) values are requested, row i+1's
+            // repeat-only term is gathered (its h1 arrived an iteration ago), row i is evaluated
+            const int d2col = max((d.ploidy == 1 ? 0 : h2col) - d.readlen, 1);
+            auto gather_rept = [&](int h1) {
+                const int d2 = d.ploidy == 1 ? max(h1 - d.readlen, 1) : d2col;
+                return slot[L.rept + max(h1 - d.readlen, 1) + d2];
+            };
+            const bool gather = last && d.use_rept_tab;
             RowIn cur = load_row(i_begin);
+            RowIn nxt = i_begin + 1 < i_end ? load_row(i_begin + 1) : cur;
+            double m2cur = gather ? gather_rept(cur.h1) : 0.0;
             for (int i = i_begin; i < i_end; ++i) {
-                RowIn nxt = cur;
-                if (i + 1 < i_end) nxt = load_row(i + 1);
+                RowIn nn = nxt;
+                if (i + 2 < i_end) nn = load_row(i + 2);
+                const double m2nxt = gather && i + 1 < i_end ? gather_rept(nxt.h1) : 0.0;
                 const int h1r = __builtin_amdgcn_readfirstlane(cur.h1);
                 const int h2r = d.ploidy == 1 ? h1r : h2col;
                 const bool ok = jin && h1r <= h2r;
@@ -810,9 +828,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                         double prod = 1.0;
 #pragma unroll
                         for (int q = 0; q < TC; ++q) {
-                            double p = (readlane_d(cur.r1v, q) + b[q]) * .5;
-                            p = fmax(p, C.small);
-                            prod *= p;
+                            prod *= fmax(readlane_d(cur.r1v, q) + b[q], C.small);
                         }
                         lp = log(prod);
                     }
@@ -826,7 +842,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                             if (h2r >= d.h_far) { m0 = cur.f1; m1 = cur.f2; }
                             else eval_reads(C, h1r, h2r, m0, m1);
                             const int dsum = max(h1r - d.readlen, 1) + max(h2r - d.readlen, 1);
-                            const double m2 = d.use_rept_tab ? slot[L.rept + dsum] : rept_term(C, dsum);
+                            const double m2 = d.use_rept_tab ? m2cur : rept_term(C, dsum);
                             if (d.run_pe && !d.use_roll_tab) m3 = pe_term<false>(C, h1r, h2r, nullptr, nullptr, 0);
                             const double ml = m0 + m1 + m2 + m3;  // models.py:269
                             mlbuf[pos] = ml;
@@ -842,7 +858,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                         }
                     }
                 }
-                cur = nxt;
+                cur = nxt; nxt = nn; m2cur = m2nxt;
             }
         }
         // arg-max of the item with key (ml, -h1), first in enumeration order (models.py:299)
