@@ -386,7 +386,11 @@ constexpr int RG = 128;   // rows per item
 constexpr int TC = 32;    // spanning pairs per pass over the rows (the lane's roll(h2) values stay in registers)
 static_assert(TC == 32, "roll1 rows are padded to 32 entries (unit_layout)");
 
-__device__ __forceinline__ int unit_items(int nrow, int ncol) { return ((ncol + CB - 1) / CB) * ((nrow + RG - 1) / RG); }
+// short grids (up to RS rows): one item takes all the column blocks, so the unit is looked up once
+constexpr int RS = 16;
+__device__ __forceinline__ int unit_items(int nrow, int ncol) {
+    return nrow <= RS ? 1 : ((ncol + CB - 1) / CB) * ((nrow + RG - 1) / RG);
+}
 
 // A unit's parameters as wave-uniform values: the loads go through the vector path (the kernels store to
 // memory the compiler cannot tell apart), readfirstlane moves every field to a scalar register.
@@ -775,8 +779,12 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
         const int* row_off = reinterpret_cast<const int*>(slot + L.rowoff);
         const int ncb = (ncol + CB - 1) / CB;
         const int k = t - d.item_base;
-        const int rg = k / ncb, cb = k - rg * ncb;
+        const bool short_grid = nrow <= RS;
+        const int rg = short_grid ? 0 : k / ncb;
+        const int cb_begin = short_grid ? 0 : k - rg * ncb, cb_end = short_grid ? ncb : cb_begin + 1;
         const int i_begin = rg * RG, i_end = min(nrow, i_begin + RG);
+        Best mine; mine.ml = 0; mine.h1 = 0; mine.pos = -1;
+        for (int cb = cb_begin; cb < cb_end; ++cb) {
         const int j = cb * CB + lane;
         const bool jin = j < ncol;
         const int jc = jin ? j : ncol - 1;
@@ -786,7 +794,6 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
         const int ntp = (n + TC - 1) & ~(TC - 1);
         const int npass = tab ? ntp / TC : 1;
         const double* roll1 = slot + L.roll1;
-        Best mine; mine.ml = 0; mine.h1 = 0; mine.pos = -1;
         for (int pass = 0; pass < npass; ++pass) {
             const bool last = pass == npass - 1;
             const int t0 = pass * TC;
@@ -861,6 +868,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                 cur = nxt; nxt = nn; m2cur = m2nxt;
             }
         }
+        }   // column blocks of the item
         // arg-max of the item with key (ml, -h1), first in enumeration order (models.py:299)
         for (int o = 32; o > 0; o >>= 1) {
             Best other;
