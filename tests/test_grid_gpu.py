@@ -151,3 +151,45 @@ def test_fused_batch_matches_oracle_chain(ctx, loci):
         assert calls[u]["n_pairs"] == len(res["mls"])
         n_called += 1
     assert n_called >= g - 2
+
+
+def test_wide_grids_beyond_512_columns(ctx):
+    """--maxinsert above ~510 makes the extended axis wider than 512 entries: several column blocks per row
+    group in the pairs kernel, a second column sweep in the reduce kernel, axis values beyond the 1000-bin
+    pdfs (numpy's empty-slice semantics in pdf_spanning, models.py:160-166).  Checked against the numpy oracle."""
+    _set_model(ctx)
+    by_name = {c["name"]: c for c in CASES}
+    cases = []
+    for name, maxinsert in (("hd_expanded_rept_pe", 700), ("hd_100x", 640), ("hd_no_full", 560)):
+        c = dict(by_name[name])
+        c["maxinsert"] = maxinsert
+        cases.append(c)
+    hs = 128
+    units, full, pref, rept, gl, tl = _case_inputs(cases, hs)
+    n = len(cases)
+    want = [oracle_caller(c).evaluate() for c in cases]
+    goff = np.zeros(n + 1, np.int64)
+    goff[1:] = np.cumsum([len(w["mls"]) for w in want])
+    dump = np.zeros((int(goff[-1]), 6), np.float64)
+    ms = 1024
+    marg = np.zeros((n, 2, ms), np.float64)
+    calls = np.zeros(n, _lib.CALL_DTYPE)
+    ctx.likelihood_grid(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls, goff, dump,
+                        marg, ms)
+    for i, (c, w) in enumerate(zip(cases, want)):
+        call = calls[i]
+        assert call["status"] == 0 and call["n_pairs"] == len(w["mls"]), (c["name"], call)
+        got, exp = dump[goff[i]:goff[i + 1]], np.asarray(w["mls"], np.float64)
+        assert np.array_equal(got[:, :2], exp[:, :2]), c["name"]
+        assert np.abs(got[:, 2:] - exp[:, 2:]).max() <= ML_TOL, c["name"]
+        assert (call["h1"], call["h2"]) == tuple(w["alleles"]), c["name"]
+        assert abs(call["lik"] - w["lik"]) <= ML_TOL and tuple(call["ci"]) == tuple(w["CI"]), c["name"]
+        l = c["locus_rec"]
+        pp = lo.calc_PP(w["tot"], w["lik"], len(l["repeat"]), l["cutoff_risk"], l["mutation_nature"] == "increase",
+                        l["inheritance"][-1] == "R")
+        assert abs(call["pp"] - pp) <= 1e-9, c["name"]
+        for which, name in enumerate(("P_h1", "P_h2")):     # un-normalised marginals, keyed by bp in the oracle
+            m = marg[i, which]
+            for h, v in w[name].items():
+                assert abs(m[h // len(l["repeat"])] - v) <= 1e-9 * max(1.0, v), (c["name"], name, h)
+    assert max(len(w["mls"]) for w in want) > 100000
