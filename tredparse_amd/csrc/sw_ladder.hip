@@ -206,13 +206,16 @@ __device__ __forceinline__ int letter_from(int words_vgpr, int idx) {
 }
 
 template <int R, int W>
-__global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
-    // trunk state parked while a branch is swept: [2R+3][256] ints, one column per thread (conflict-free)
-    __shared__ int park[(2 * R + 3) * 256];
+__global__ __launch_bounds__(64, W) void sw_ladder_kernel(SwArgs a) {
+    // One wavefront per workgroup: quads differ a lot in length (pruning), and a wave slot freed by a short
+    // quad is only refilled when a whole new workgroup fits -- with four quads per workgroup a quarter of the
+    // wave slots sat idle (80 -> 71.5 ms per launch).
+    // trunk state parked while a branch is swept: [2R+3][64] ints, one column per thread (conflict-free)
+    constexpr int PS = 64;
+    __shared__ int park[(2 * R + 3) * PS];
     int* const mypark = park + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    const int lane = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x;
     const int nq = *a.n_quads;
     if (q >= nq) return;
     const int q_unit = __builtin_amdgcn_readfirstlane(a.quads[q].unit);
@@ -372,10 +375,10 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
                     if (need && sweep) {
                         // park the trunk state, continue into the branch
 #pragma unroll
-                        for (int r = 0; r < R; ++r) { mypark[r * 256] = H[r]; mypark[(R + r) * 256] = E[r]; }
-                        mypark[(2 * R) * 256] = T.bestkey;
-                        mypark[(2 * R + 1) * 256] = T.beststart;
-                        mypark[(2 * R + 2) * 256] = T.ceil;
+                        for (int r = 0; r < R; ++r) { mypark[r * PS] = H[r]; mypark[(R + r) * PS] = E[r]; }
+                        mypark[(2 * R) * PS] = T.bestkey;
+                        mypark[(2 * R + 1) * PS] = T.beststart;
+                        mypark[(2 * R + 2) * PS] = T.ceil;
                         in_branch = true;
                         parked = true;
                         b_left = blen; b_col = col + 1; b_idx = 0;
@@ -434,10 +437,10 @@ __global__ __launch_bounds__(256, W) void sw_ladder_kernel(SwArgs a) {
             // back to the trunk
             if (parked) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) { H[r] = mypark[r * 256]; E[r] = mypark[(R + r) * 256]; }
-                T.bestkey = mypark[(2 * R) * 256];
-                T.beststart = mypark[(2 * R + 1) * 256];
-                T.ceil = mypark[(2 * R + 2) * 256];
+                for (int r = 0; r < R; ++r) { H[r] = mypark[r * PS]; E[r] = mypark[(R + r) * PS]; }
+                T.bestkey = mypark[(2 * R) * PS];
+                T.beststart = mypark[(2 * R + 1) * PS];
+                T.ceil = mypark[(2 * R + 2) * PS];
             }
             in_branch = false;
             next_branch += period;
@@ -583,16 +586,16 @@ hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* per
 
 hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s) {
     if (max_quads <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((max_quads + 3) / 4);
+    const unsigned blocks = (unsigned)max_quads;   // one quad = one wavefront = one workgroup
     switch (rows_per_lane) {
 #ifndef SW_W10
 #define SW_W10 4
 #endif
         // second parameter = waves per SIMD the register allocation is held to
-        case 4: sw_ladder_kernel<4, 6><<<blocks, 256, 0, s>>>(a); break;
-        case 7: sw_ladder_kernel<7, 4><<<blocks, 256, 0, s>>>(a); break;
-        case 10: sw_ladder_kernel<10, SW_W10><<<blocks, 256, 0, s>>>(a); break;
-        case 16: sw_ladder_kernel<16, 2><<<blocks, 256, 0, s>>>(a); break;
+        case 4: sw_ladder_kernel<4, 6><<<blocks, 64, 0, s>>>(a); break;
+        case 7: sw_ladder_kernel<7, 4><<<blocks, 64, 0, s>>>(a); break;
+        case 10: sw_ladder_kernel<10, SW_W10><<<blocks, 64, 0, s>>>(a); break;
+        case 16: sw_ladder_kernel<16, 2><<<blocks, 64, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
