@@ -31,6 +31,18 @@ def test_header_symbols_all_exported():
     assert exported == set(names)
 
 
+def test_bam_layer_header_symbols_all_exported():
+    """include/tredbam.h (host-only BAM file layer, libtredbam.so): every declared entry point is exported."""
+    from tredparse_amd import bamio
+    src = open(os.path.join(ROOT, "include", "tredbam.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(tredbam_[a-z_]+)\s*\(", src)))
+    assert len(names) == 10
+    out = subprocess.check_output(["nm", "-D", "--defined-only", bamio._LIB_PATH]).decode()
+    assert set(re.findall(r" T (tredbam_[a-z_]+)", out)) == set(names)
+    assert ctypes.sizeof(ctypes.c_int32) * 10 + 4 == bamio._REC.size == 44      # tredbam_rec
+
+
 def test_no_oracle_in_product_library():
     """The shipped library must not link or reference the oracle / reference build."""
     out = subprocess.check_output(["ldd", _lib.LIB_PATH]).decode()

@@ -97,3 +97,68 @@ def test_tredreport_on_reference_results(tmp_path):
     assert det[1].split("\t")[:5] == ["DM1", "AD", "t002", "Female", "5|66"]
     rep = open(tsv + ".report.txt").read()
     assert "{15:1,41:1}" in rep
+
+
+def test_native_bam_layer_matches_python_layer():
+    """libtredbam.so (csrc/bamread.cpp) against the pure-Python BGZF/BAM/BAI reader: same records in file order,
+    same records for region queries through the index (incl. placed-unmapped mates, regions without reads,
+    single-base regions), same pileup depth sums -- on both of the reference's test BAMs."""
+    import random
+    from tredparse_amd import bamio
+    assert bamio._native() is not None, "libtredbam.so is not built"
+    rng = random.Random(7)
+
+    def key(r):
+        return (r.tid, r.pos, r.mapq, r.flag, r.next_tid, r.next_pos, r.tlen, r.l_seq, r.query_name,
+                tuple(r.cigartuples), r.query_sequence, r.reference_end, r.query_alignment_start,
+                r.query_alignment_end, r.is_unmapped, r.is_reverse, r.query_length)
+
+    for name in ("t001.bam", "t002.bam"):
+        path = os.path.join(GOLD, "bam", name)
+        a, b = bamio.NativeAlignmentFile(path), bamio.PyAlignmentFile(path)
+        assert a.references == b.references and a.lengths == b.lengths
+        ra, rb = [key(r) for r in a.fetch()], [key(r) for r in b.fetch()]
+        assert ra == rb and len(ra) > 10000
+        assert [key(r) for _, r in zip(range(101), a.fetch())] == ra[:101]       # early stop (BamReadLen)
+        for tid in sorted(set(r[0] for r in ra if r[0] >= 0)):
+            chrom = a.references[tid]
+            starts = [r[1] for r in ra if r[0] == tid]
+            for _ in range(40):
+                s = max(0, rng.choice(starts) + rng.randint(-3000, 3000))
+                e = s + rng.choice([1, 50, 1000, 2000, 20000])
+                assert [key(r) for r in a.fetch(chrom, s, e)] == [key(r) for r in b.fetch(chrom, s, e)], (chrom, s, e)
+                assert a.pileup_depth_sum(chrom, s, e) == b.pileup_depth_sum(chrom, s, e)
+        with pytest.raises(ValueError):
+            list(a.fetch("no_such_contig", 0, 10))
+        a.close(); b.close()
+    with pytest.raises(IOError):
+        bamio.NativeAlignmentFile(os.path.join(GOLD, "bam", "missing.bam"))
+
+
+def test_native_pe_lengths_match_python_pe_extractor(monkeypatch):
+    """tredbam_pe_lengths (the whole PEextractor selection in one native call) against the Python loop over
+    fetched records (bam_parser.py:316-369), for every locus on both test BAMs: same lists, same order."""
+    from tredparse_amd import bam_parser as bpm
+    repo = TREDsRepo("hg38")
+    n_pairs = 0
+    for name in ("t001.bam", "t002.bam"):
+        path = os.path.join(GOLD, "bam", name)
+        for tred in repo.names:
+            ip = InputParams(bam=path, READLEN=150, tredName=tred, repo=repo, maxinsert=300, fullsearch=False,
+                             gender="Unknown", depth=30, clip=False, alts=False, repeatpairs=True, log="ERROR")
+            bp = BamParser(ip)
+            monkeypatch.delenv("TREDBAM_PURE_PYTHON", raising=False)
+            bamio._lib = None
+            bpm._open_files.clear()
+            nat = PEextractor(bp)
+            monkeypatch.setenv("TREDBAM_PURE_PYTHON", "1")
+            bamio._lib = None
+            bpm._open_files.clear()
+            py = PEextractor(bp)
+            assert nat.global_lens == py.global_lens and nat.target_lens == py.target_lens, (name, tred)
+            assert nat.MINPE == py.MINPE
+            n_pairs += len(nat.global_lens) + len(nat.target_lens)
+    monkeypatch.delenv("TREDBAM_PURE_PYTHON", raising=False)
+    bamio._lib = None
+    bpm._open_files.clear()
+    assert n_pairs > 4000

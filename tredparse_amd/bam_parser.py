@@ -28,15 +28,47 @@ def rc(s):
     return s.translate(_complement)[::-1]
 
 
+_open_files = {}   # path -> open AlignmentFile: one sample's 30-odd loci open its BAM about a hundred times
+
+
+class _SharedFile(object):
+    """What read_alignment hands out: the cached file with a close() that leaves it open."""
+
+    def __init__(self, f):
+        self._f = f
+        self.references, self.lengths = f.references, f.lengths
+        self.fetch, self.pileup_depth_sum, self.getrname = f.fetch, f.pileup_depth_sum, f.getrname
+        self.get_reference_name = f.getrname
+        if hasattr(f, "pe_lengths"):
+            self.pe_lengths, self.check_region = f.pe_lengths, f.check_region
+
+    def close(self):
+        pass
+
+
 def read_alignment(samfile):
     if samfile.endswith(".cram"):
         raise ValueError("CRAM input needs htslib; this front end reads BAM only")
-    return bamio.AlignmentFile(samfile, "rb")
+    try:
+        key = (samfile, os.path.getmtime(samfile))
+    except OSError:
+        key = None
+    f = _open_files.get(key) if key else None
+    if f is None:
+        f = bamio.AlignmentFile(samfile, "rb")
+        if key:
+            if len(_open_files) >= 8:
+                _open_files.pop(next(iter(_open_files))).close()
+            _open_files[key] = f
+    return _SharedFile(f) if key else f
 
 
 def test_fetch(samfile, chr, start, end, logger):
     try:
-        next(iter(samfile.fetch(chr, start, end)), None)
+        if hasattr(samfile, "check_region"):    # native file layer: same ValueErrors without reading the region
+            samfile.check_region(chr, start, end)
+        else:
+            next(iter(samfile.fetch(chr, start, end)), None)
         return True
     except ValueError:
         logger.error("No reads extracted for region {}:{}-{}".format(chr, start, end))
@@ -189,6 +221,15 @@ class PEextractor:
         self.ref = bp.referenceLen
         pstart = max(start - DNAPE_ELONGATE, 0)
         pend = end + DNAPE_ELONGATE
+        self.global_lens, self.target_lens = [], []
+        tstart = start - FLANKMATCH
+        tend = end + FLANKMATCH
+        self.MINPE = end - start + 2 * FLANKMATCH + 2
+        if hasattr(samfile, "pe_lengths"):   # native file layer: the whole selection in one call
+            if test_fetch(samfile, chr, pstart, pend, bp.logger):
+                self.global_lens, self.target_lens = samfile.pe_lengths(chr, pstart, pend, tstart, tend, SPAN)
+            samfile.close()
+            return
         cache = {}
         if test_fetch(samfile, chr, pstart, pend, bp.logger):
             cache = defaultdict(list)
@@ -200,9 +241,6 @@ class PEextractor:
                 if x.is_duplicate:
                     continue
                 cache[x.query_name].append(x)
-        self.global_lens, self.target_lens = [], []
-        tstart = start - FLANKMATCH
-        tend = end + FLANKMATCH
         for name, reads in cache.items():
             if len(reads) < 2:
                 continue
@@ -216,7 +254,6 @@ class PEextractor:
                 self.target_lens.append(tlen)
             else:
                 self.global_lens.append(tlen)
-        self.MINPE = end - start + 2 * FLANKMATCH + 2
         samfile.close()
 
     def get_target_length(self, a, b):
