@@ -52,6 +52,12 @@ typedef struct tredbam_rec {
 int64_t tredbam_fetch(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t limit, const uint8_t** buf,
                       int64_t* nbytes);
 
+/* The read selection of BamParser.parse (bam_parser.py:206-214): of the records overlapping [start, end), the
+ * unmapped ones (placed at their mate) and those with pos_lo <= pos <= pos_hi; same buffer layout as
+ * tredbam_fetch. */
+int64_t tredbam_fetch_reads(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t pos_lo, int64_t pos_hi,
+                            const uint8_t** buf, int64_t* nbytes);
+
 /* Sum over pileup columns of the number of reads covering them, for the reads that overlap [start, end):
  * every reference position such a read covers counts, also outside the region (pileup() without truncate,
  * bam_parser.py:404-407); unmapped / secondary / QC-fail / duplicate reads are skipped (htslib's default mask). */

@@ -37,7 +37,7 @@ def test_bam_layer_header_symbols_all_exported():
     src = open(os.path.join(ROOT, "include", "tredbam.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(tredbam_[a-z_]+)\s*\(", src)))
-    assert len(names) == 10
+    assert len(names) == 11
     out = subprocess.check_output(["nm", "-D", "--defined-only", bamio._LIB_PATH]).decode()
     assert set(re.findall(r" T (tredbam_[a-z_]+)", out)) == set(names)
     assert ctypes.sizeof(ctypes.c_int32) * 10 + 4 == bamio._REC.size == 44      # tredbam_rec

@@ -40,7 +40,7 @@ class _SharedFile(object):
         self.fetch, self.pileup_depth_sum, self.getrname = f.fetch, f.pileup_depth_sum, f.getrname
         self.get_reference_name = f.getrname
         if hasattr(f, "pe_lengths"):
-            self.pe_lengths, self.check_region = f.pe_lengths, f.check_region
+            self.pe_lengths, self.check_region, self.fetch_reads = f.pe_lengths, f.check_region, f.fetch_reads
 
     def close(self):
         pass
@@ -129,7 +129,11 @@ class BamParser:
         chr, start, end = self.chr, WINDOW_START, WINDOW_END
         self.reads = []
         if test_fetch(samfile, chr, start, end, self.logger):
-            for read in samfile.fetch(chr, start, end):
+            if hasattr(samfile, "fetch_reads"):    # native file layer: position filter applied before wrapping
+                window = samfile.fetch_reads(chr, start, end, READ_START, READ_END)
+            else:
+                window = samfile.fetch(chr, start, end)
+            for read in window:
                 if not read.is_unmapped:
                     if read.reference_start < READ_START:
                         continue

@@ -343,6 +343,9 @@ def _native():
             lib.tredbam_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
             lib.tredbam_fetch.restype = C.c_int64
+            lib.tredbam_fetch_reads.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+            lib.tredbam_fetch_reads.restype = C.c_int64
             lib.tredbam_pileup_depth_sum.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
             lib.tredbam_pileup_depth_sum.restype = C.c_int
             lib.tredbam_pe_lengths.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
@@ -419,9 +422,13 @@ class NativeAlignmentFile(object):
     def _err(self):
         return self._lib.tredbam_last_error(self._h).decode()
 
-    def _records(self, tid, start, end, limit=0):
+    def _records(self, tid, start, end, limit=0, pos_range=None):
         buf, nbytes = C.c_void_p(), C.c_int64()
-        n = self._lib.tredbam_fetch(self._h, tid, start, end, limit, C.byref(buf), C.byref(nbytes))
+        if pos_range is None:
+            n = self._lib.tredbam_fetch(self._h, tid, start, end, limit, C.byref(buf), C.byref(nbytes))
+        else:
+            n = self._lib.tredbam_fetch_reads(self._h, tid, start, end, pos_range[0], pos_range[1], C.byref(buf),
+                                              C.byref(nbytes))
         if n < 0:
             raise ValueError(self._err())
         data = C.string_at(buf, nbytes.value) if n else b""
@@ -466,6 +473,12 @@ class NativeAlignmentFile(object):
             raise ValueError(self._err())
         return int(total.value)
 
+
+    def fetch_reads(self, chrom, start, end, pos_lo, pos_hi):
+        """fetch(chrom, start, end) restricted to unmapped records and those with pos_lo <= pos <= pos_hi
+        (the read selection of bam_parser.py:206-214, filtered before anything is wrapped)."""
+        self.check_region(chrom, start, end)
+        return self._records(self._tid[chrom], max(0, int(start)), int(end), pos_range=(int(pos_lo), int(pos_hi)))
 
     def check_region(self, chrom, start, end):
         """The ValueErrors fetch(chrom, start, end) would raise, without reading anything."""

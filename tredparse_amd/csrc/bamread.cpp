@@ -304,7 +304,7 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
             if ((rc = emit_record(b, &rend, store)) < 0) return rc;
             int64_t e = rend;
             if (rend < 0 || rend <= rpos) e = (int64_t)rpos + 1;   // placed-unmapped / zero length: one base (bam_endpos)
-            if (e > start) { visit(rend, rpos, le16(b->rec.data() + 14), b->rec.data()); ++n; }
+            if (e > start && visit(rend, rpos, le16(b->rec.data() + 14), b->rec.data())) ++n;
             else b->out.resize(mark);
         }
     }
@@ -398,9 +398,22 @@ int64_t tredbam_fetch(tredbam* b, int32_t tid, int64_t start, int64_t end, int64
             ++n;
         }
     } else {
-        n = walk_region(b, tid, start, end, true, [](int32_t, int32_t, uint16_t, const uint8_t*) {});
+        n = walk_region(b, tid, start, end, true, [](int32_t, int32_t, uint16_t, const uint8_t*) { return true; });
         if (n < 0) return n;
     }
+    *buf = b->out.data();
+    *nbytes = (int64_t)b->out.size();
+    return n;
+}
+
+int64_t tredbam_fetch_reads(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t pos_lo, int64_t pos_hi,
+                            const uint8_t** buf, int64_t* nbytes) {
+    if (!b || !buf || !nbytes) return -2;
+    b->out.clear();
+    const int64_t n = walk_region(b, tid, start, end, true, [&](int32_t, int32_t rpos, uint16_t flag, const uint8_t*) {
+        return (flag & 0x4) != 0 || (rpos >= pos_lo && rpos <= pos_hi);
+    });
+    if (n < 0) return n;
     *buf = b->out.data();
     *nbytes = (int64_t)b->out.size();
     return n;
@@ -411,8 +424,9 @@ int tredbam_pileup_depth_sum(tredbam* b, int32_t tid, int64_t start, int64_t end
     b->out.clear();
     int64_t sum = 0;
     const int64_t n = walk_region(b, tid, start, end, false, [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t*) {
-        if (flag & (0x4 | 0x100 | 0x200 | 0x400)) return;   // unmapped, secondary, QC fail, duplicate
+        if (flag & (0x4 | 0x100 | 0x200 | 0x400)) return true;   // unmapped, secondary, QC fail, duplicate
         if (rend >= 0) sum += (int64_t)rend - rpos;
+        return true;
     });
     if (n < 0) return (int)n;
     *total = sum;
@@ -429,7 +443,7 @@ int tredbam_pe_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int6
     std::unordered_map<std::string, size_t> slot;
     std::vector<Pair> pairs;   // in order of first appearance (the reference walks a dict in that order)
     const int64_t n = walk_region(b, tid, start, end, false, [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
-        if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) return;   // paired, mapped, not a duplicate
+        if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) return true;   // paired, mapped, not a duplicate
         const int l_name = r[8];
         const int n_cigar = le16(r + 12);
         std::string name((const char*)r + 32, (size_t)std::max(l_name - 1, 0));
@@ -463,6 +477,7 @@ int tredbam_pe_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int6
             m.trail_clip = trail;
         }
         ++p.n;
+        return true;
     });
     if (n < 0) return (int)n;
     int64_t ng = 0, nt = 0;
