@@ -70,3 +70,18 @@ def test_cli_main_writes_json_and_vcf(engine, tmp_path, monkeypatch):
     assert line[0] == "chr19" and line[2] == "DM1" and line[8] == "GT:GB:FR:PR:RR:DP:FDP:PDP:RDP:PEDP:CI:PP:LABEL"
     assert line[9].startswith("1/2:5/66:5|24:")
     assert "RPA=5,66" in line[7]
+
+
+def test_run_many_batches_samples_into_one_gpu_call(engine):
+    """run_many (units of several samples in ONE GPU batch) gives what run() gives sample by sample."""
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    args = [(s, os.path.join(GOLD, "bam", s + ".bam"), repo, list(repo.names), 300, False, False, True, True, "INFO")
+            for s in ("t001", "t002", "t001")]
+    one_by_one = [tredmod.run(a, engine=engine) for a in args]
+    seen = []
+    assert tredmod.run_many(args, engine, batch=2, sink=seen.append) == []
+    batched = tredmod.run_many(args, engine, batch=8)
+    for got in (seen, batched):
+        assert [r["samplekey"] for r in got] == ["t001", "t002", "t001"]
+        for a, b in zip(got, one_by_one):
+            assert json.dumps(a["tredCalls"], sort_keys=True) == json.dumps(b["tredCalls"], sort_keys=True)

@@ -162,3 +162,27 @@ def test_native_pe_lengths_match_python_pe_extractor(monkeypatch):
     bamio._lib = None
     bpm._open_files.clear()
     assert n_pairs > 4000
+
+
+def test_host_pool_collects_samples_in_worker_processes():
+    """The host half of run() in forked workers (tred.host_pool, the reference's Pool over samples): what comes
+    back through pickling equals an in-process collect_sample -- reads, pair lengths, depth, the shared PREF/POST
+    dict -- and the workers never need a GPU."""
+    repo = TREDsRepo("hg38")
+    args = [(s, os.path.join(GOLD, "bam", s + ".bam"), repo, ["HD", "DM1", "SCA1"], 300, False, False, True, True, "ERROR")
+            for s in ("t001", "t002")]
+    pool = tredmod.host_pool(2, len(args))
+    try:
+        remote = pool.map(tredmod.collect_sample, args)
+    finally:
+        pool.close()
+        pool.join()
+    local = [tredmod.collect_sample(a) for a in args]
+    for (r1, p1), (r2, p2) in zip(remote, local):
+        assert r1 == r2 and len(p1) == len(p2) == 3
+        for u1, u2 in zip(p1, p2):
+            assert u1.tred == u2.tred and u1.depth == u2.depth and u1.bp.reads == u2.bp.reads
+            assert u1.caller.pe.global_lens == u2.caller.pe.global_lens
+            assert u1.caller.pe.target_lens == u2.caller.pe.target_lens
+            assert u1.bp.counts["PREF"] is u1.bp.counts["POST"]
+    assert tredmod.host_pool(1, 5) is None and tredmod.host_pool(4, 1) is None

@@ -17,41 +17,39 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    import torch  # noqa: F401  (load PyTorch's HIP runtime before libtredgpu, see INTEGRATION.md)
-    if torch.cuda.is_available():
-        torch.cuda.init()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=64, help="samples per repetition (the two BAMs, repeated)")
+    ap.add_argument("--cpus", type=int, default=1, help="host worker processes for the BAM half")
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
     from tredparse_amd import tred
-    from tredparse_amd.engine import Engine
     from tredparse_amd.meta import TREDsRepo
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     repo = TREDsRepo("hg38")
     names = list(repo.names)
     bams = [os.path.join(ROOT, "tests", "golden", "bam", b) for b in ("t001.bam", "t002.bam")]
+    tasks = [("s{:04d}".format(i), bams[i % 2], repo, names, 300, False, False, False, True, "ERROR")
+             for i in range(a.samples)]
+    pool = tred.host_pool(a.cpus, len(tasks))      # forked before the GPU runtime is initialised
+    import torch  # noqa: F401  (load PyTorch's HIP runtime before libtredgpu, see INTEGRATION.md)
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    from tredparse_amd.engine import Engine
     engine = Engine()
-    t_host = t_dev = 0.0
-    units = 0
-    for rep in range(reps + 1):
-        t0 = time.perf_counter()
-        collected = []
-        for bam in bams:
-            arg = (os.path.basename(bam)[:-4], bam, repo, names, 300, False, False, False, True, "ERROR")
-            collected.append(tred.collect_sample(arg))
-        t1 = time.perf_counter()
-        pend = [p for _, ps in collected for p in ps]
-        res = engine.genotype([p.caller.unit([sq for _, sq in p.bp.reads]) for p in pend], want_grid=True)
-        k = 0
-        for result, ps in collected:
-            tred.finish_sample(result, ps, res[k:k + len(ps)])
-            k += len(ps)
-        t2 = time.perf_counter()
-        if rep:   # first repetition warms caches / the HIP context
-            t_host += t1 - t0
-            t_dev += t2 - t1
-            units += len(pend)
-    print(json.dumps({"metric": "sample x TRED genotypes/sec end to end from BAM (one host process)",
-                      "value": units / (t_host + t_dev), "unit": "genotypes/s", "units": units, "reps": reps,
-                      "host_collect_s": t_host, "device_and_format_s": t_dev,
-                      "workload": "tests/golden/bam t001 + t002 x {} loci".format(len(names))}))
+    done = []
+    tred.run_many(tasks[:4], engine, pool=None, sink=done.append)      # warm-up: caches, HIP context
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        tred.run_many(tasks, engine, pool=pool, batch=64, sink=done.append)
+    dt = time.perf_counter() - t0
+    units = a.reps * len(tasks) * len(names)
+    if pool is not None:
+        pool.close()
+        pool.join()
+    print(json.dumps({"metric": "sample x TRED genotypes/sec end to end from BAM",
+                      "value": units / dt, "unit": "genotypes/s", "units": units, "seconds": dt,
+                      "host_workers": a.cpus, "samples_per_rep": len(tasks), "reps": a.reps,
+                      "workload": "tests/golden/bam t001 / t002 alternating x {} loci, 64 samples per GPU batch".format(len(names))}))
 
 
 if __name__ == "__main__":

@@ -207,25 +207,64 @@ def finish_sample(result, pending, unit_results):
     return result
 
 
+def units_of(arg, pending):
+    """The engine.Unit of every pending sample x locus of one sample (arg = the run() argument tuple)."""
+    clip, repeatpairs = arg[6], arg[8]
+    units = []
+    for u in pending:
+        unit = u.caller.unit([s for _, s in u.bp.reads])
+        if not (repeatpairs or clip):   # --norepeatpairs: mates share a query name (bam_parser.py:270-287)
+            ids = {}                    # (the device removes REPT/REPT pairs from the histograms; finish() on details)
+            unit.read_pair_ids = [ids.setdefault(name, len(ids)) for name, _ in u.bp.reads]
+        units.append(unit)
+    return units
+
+
 def run(arg, engine=None):
     """Run the TRED caller on one sample (same argument tuple and return value as tred.py:180-278)."""
     from .engine import Engine
     engine = engine or Engine()
     result, pending = collect_sample(arg)
-    clip = arg[6]
-    repeatpairs = arg[8]
-    units = []
-    for u in pending:
-        unit = u.caller.unit([s for _, s in u.bp.reads])
-        if not (repeatpairs or clip):   # --norepeatpairs: mates share a query name (bam_parser.py:270-287)
-            ids = {}
-            unit.read_pair_ids = [ids.setdefault(name, len(ids)) for name, _ in u.bp.reads]
-        units.append(unit)
+    units = units_of(arg, pending)
     res = engine.genotype(units) if units else []
-    if not (repeatpairs or clip):
-        # the device already removed REPT/REPT pairs from the histograms; finish() repeats it on details
-        pass
     return finish_sample(result, pending, res)
+
+
+def host_pool(cpus, n_tasks):
+    """Worker processes for the host half (the reference's Pool over samples, tred.py:521-532).  Create it BEFORE
+    the Engine: the workers are forked and must not inherit an initialised GPU runtime."""
+    if cpus > 1 and n_tasks > 1:
+        import multiprocessing
+        return multiprocessing.get_context("fork").Pool(min(cpus, n_tasks))
+    return None
+
+
+def run_many(task_args, engine, pool=None, batch=64, sink=None):
+    """run() over many samples: the host half of up to `batch` samples is collected (by the pool's workers, which
+    never touch the GPU), their units go to the GPU as ONE batch, and each finished result is handed to
+    sink(result) (or returned as a list)."""
+    out = []
+    try:
+        for i in range(0, len(task_args), batch):
+            chunk = task_args[i:i + batch]
+            collected = pool.map(collect_sample, chunk) if pool else [collect_sample(a) for a in chunk]
+            units, spans = [], []
+            for a, (_, pending) in zip(chunk, collected):
+                us = units_of(a, pending)
+                spans.append((len(units), len(units) + len(us)))
+                units += us
+            res = engine.genotype(units) if units else []
+            for (result, pending), (lo, hi) in zip(collected, spans):
+                r = finish_sample(result, pending, res[lo:hi])
+                if sink is not None:
+                    sink(r)
+                else:
+                    out.append(r)
+    finally:
+        if pool is not None:
+            pool.close()
+            pool.join()
+    return out
 
 
 def vcfstanza(sampleid, bam, tredCalls, ref):
@@ -367,11 +406,13 @@ def main(args, quiet=False):
         os.chdir(cwd)
         return
     from .engine import Engine
+    pool = host_pool(args.cpus, len(task_args))
     engine = Engine(args.gpu)
-    for ta in task_args:
-        results = run(ta, engine=engine)
+
+    def sink(results):
         if not args.no_output:
             write_vcf_json(results, ref, repo, treds, None, quiet=quiet)
+    run_many(task_args, engine, pool=pool, sink=sink)
     print("Elapsed time={}".format(timedelta(seconds=time.time() - start)), file=sys.stderr)
     os.chdir(cwd)
     if args.cleanup:
