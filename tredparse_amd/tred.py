@@ -242,28 +242,29 @@ def host_pool(cpus, n_tasks):
 def run_many(task_args, engine, pool=None, batch=64, sink=None):
     """run() over many samples: the host half of up to `batch` samples is collected (by the pool's workers, which
     never touch the GPU), their units go to the GPU as ONE batch, and each finished result is handed to
-    sink(result) (or returned as a list)."""
+    sink(result) (or returned as a list).  The pool stays the caller's (close and join it when done)."""
     out = []
-    try:
-        for i in range(0, len(task_args), batch):
-            chunk = task_args[i:i + batch]
-            collected = pool.map(collect_sample, chunk) if pool else [collect_sample(a) for a in chunk]
-            units, spans = [], []
-            for a, (_, pending) in zip(chunk, collected):
-                us = units_of(a, pending)
-                spans.append((len(units), len(units) + len(us)))
-                units += us
-            res = engine.genotype(units) if units else []
-            for (result, pending), (lo, hi) in zip(collected, spans):
-                r = finish_sample(result, pending, res[lo:hi])
-                if sink is not None:
-                    sink(r)
-                else:
-                    out.append(r)
-    finally:
-        if pool is not None:
-            pool.close()
-            pool.join()
+    chunks = [task_args[i:i + batch] for i in range(0, len(task_args), batch)]
+    ahead = pool.map_async(collect_sample, chunks[0]) if pool and chunks else None
+    for k, chunk in enumerate(chunks):
+        if pool:
+            collected = ahead.get()
+            # the workers read the next batch's BAMs while this one is on the GPU and being formatted
+            ahead = pool.map_async(collect_sample, chunks[k + 1]) if k + 1 < len(chunks) else None
+        else:
+            collected = [collect_sample(a) for a in chunk]
+        units, spans = [], []
+        for a, (_, pending) in zip(chunk, collected):
+            us = units_of(a, pending)
+            spans.append((len(units), len(units) + len(us)))
+            units += us
+        res = engine.genotype(units) if units else []
+        for (result, pending), (lo, hi) in zip(collected, spans):
+            r = finish_sample(result, pending, res[lo:hi])
+            if sink is not None:
+                sink(r)
+            else:
+                out.append(r)
     return out
 
 
@@ -412,7 +413,12 @@ def main(args, quiet=False):
     def sink(results):
         if not args.no_output:
             write_vcf_json(results, ref, repo, treds, None, quiet=quiet)
-    run_many(task_args, engine, pool=pool, sink=sink)
+    try:
+        run_many(task_args, engine, pool=pool, sink=sink)
+    finally:
+        if pool is not None:
+            pool.close()
+            pool.join()
     print("Elapsed time={}".format(timedelta(seconds=time.time() - start)), file=sys.stderr)
     os.chdir(cwd)
     if args.cleanup:
