@@ -905,7 +905,7 @@ __device__ double block_sum_r(double v, double* red) {
     return t;
 }
 
-__global__ __launch_bounds__(NR) void grid_reduce_kernel(GridArgs a, const UnitDesc* descs, double* pool,
+__global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const UnitDesc* descs, double* pool,
                                                          const Best* item_best, GridCounters* ctr) {
     __shared__ ReduceShared S;
     const int tid = threadIdx.x;
