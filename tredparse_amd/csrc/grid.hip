@@ -224,15 +224,14 @@ __device__ double block_sum(double v, double* red) {
 // pdf[x] = sum_v count[v]/n * K(x - v) is a 1000 x (vmax - vmin + 1) convolution.  Every thread owns XPER
 // consecutive x and walks v upwards over the occupied range, so its window K(x0 - v .. x0 + XPER-1 - v)
 // slides by one entry per step: one LDS load of K and one broadcast load of the weight per XPER FMAs.
-// K is stored for d = -999 .. 1048 at index swz(d + 999); the swizzle i + i/8 turns the lanes' stride of
+// K is even: it is stored for |d| = 0 .. 1039 at index swz(|d|); the swizzle i + i/8 turns the lanes' stride of
 // XPER doubles into 9, which keeps the 64 loads of a step off each other's banks.  Empty bins add
 // 0 * K = +0, so the sums carry the same bits as a walk over the occupied bins only.
-constexpr int KOFF = SPAN - 1;
-constexpr int KERN2_RAW = 2048 + 8;
+constexpr int KERN2_RAW = 1040;   // |d| <= NT * XPER - 1 + 7 = 1030 is the largest index a window touches
 __device__ __forceinline__ int kswz(int i) { return i + (i >> 3); }
 constexpr int KERN2 = KERN2_RAW + KERN2_RAW / 8 + 1;
 static_assert(XPER == 8, "the sliding window below is unrolled for 8 x-values per thread");
-static_assert(NT * XPER >= SPAN && NT * XPER + KOFF < KERN2_RAW, "window indices stay inside kern2");
+static_assert(NT * XPER >= SPAN && NT * XPER + XPER <= KERN2_RAW && SPAN + XPER <= KERN2_RAW, "window indices stay inside kern2");
 
 __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, double* pdf, double* red, int* flag) {
     const int tid = threadIdx.x;
@@ -264,14 +263,13 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
     const double sigma = sqrt(var) * factor;       // cho_cov
     const double norm = 1.0 / sqrt(2 * M_PI) / sigma;  // (2*pi)^(-d/2) / cho_cov
     const double w = 1.0 / n;                      // uniform weights
-    // K(d) = exp(-(d/sigma)^2 / 2) * norm for |d| < 1000 (both signs stored), 0 beyond
+    // K(d) = exp(-(d/sigma)^2 / 2) * norm for |d| < 1000, 0 beyond
     for (int d = tid; d < SPAN; d += NT) {
         const double r = (double)d / sigma;
         const double k = exp(-(r * r) / 2) * norm;
-        kern2[kswz(KOFF + d)] = k;
-        kern2[kswz(KOFF - d)] = k;
+        kern2[kswz(d)] = k;
     }
-    for (int i = 2 * SPAN - 1 + tid; i < KERN2_RAW; i += NT) kern2[kswz(i)] = 0;
+    for (int i = SPAN + tid; i < KERN2_RAW; i += NT) kern2[kswz(i)] = 0;
     __syncthreads();
     const int vmin = flag[1], vmax = flag[2];
     const int x0 = tid * XPER;
@@ -279,7 +277,7 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
 #pragma unroll
     for (int qx = 0; qx < XPER; ++qx) {
         acc[qx] = 0;
-        win[qx] = kern2[kswz(KOFF + x0 + qx - vmin)];   // K(x0 + qx - vmin)
+        win[qx] = kern2[kswz(abs(x0 + qx - vmin))];   // K(x0 + qx - vmin)
     }
     // step s of a group handles v = vb + s with the window rotated by s: K(x0 + qx - v) sits in
     // win[(qx - s) & 7]; afterwards the slot of qx = 7 is refilled with K(x0 - (v + 1))
@@ -290,7 +288,7 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
             const double wk = (v <= vmax ? hist[v] : 0) * w;
 #pragma unroll
             for (int qx = 0; qx < XPER; ++qx) acc[qx] += wk * win[(qx - st) & 7];
-            win[(7 - st) & 7] = kern2[kswz(max(KOFF + x0 - (v + 1), 0))];
+            win[(7 - st) & 7] = kern2[kswz(abs(x0 - (v + 1)))];
         }
     }
     double part = 0;
@@ -407,11 +405,13 @@ __device__ __forceinline__ tredgpu_unit_params uniform_unit(const tredgpu_unit_p
 
 struct PrepShared {
     Obs obs;
-    int hist[SPAN];
+    union {
+        int hist[SPAN];                    // raw histograms while the lists are built, then the KDE's bins ...
+        int row_off[GRID_MAX_ROWS + 1];    // ... then the per-row pair counts / dump offsets
+    };
     double kern[KERN2];
     double pdf[SPAN];
     double red[NT / 64];
-    int row_off[GRID_MAX_ROWS + 1];
     int kflag[4];
     long long slot_off;
     int flag, status, unit;
@@ -435,7 +435,7 @@ __device__ PairCtx make_ctx(const UnitDesc& d, const ModelConst& M, const Obs* o
 }
 
 // ---- kernel 1: per-unit preparation -------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void grid_prepare_kernel(GridArgs a, int pass, UnitDesc* descs, double* pool,
+__global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pass, UnitDesc* descs, double* pool,
                                                           unsigned long long pool_doubles, int rows_cap, int cols_cap,
                                                           int* item_unit, GridCounters* ctr) {
     __shared__ PrepShared S;
