@@ -193,3 +193,38 @@ def test_wide_grids_beyond_512_columns(ctx):
             for h, v in w[name].items():
                 assert abs(m[h // len(l["repeat"])] - v) <= 1e-9 * max(1.0, v), (c["name"], name, h)
     assert max(len(w["mls"]) for w in want) > 100000
+
+
+def test_many_spanning_pairs_and_haploid_paired_end(ctx):
+    """The paired-end term with more spanning pairs than one 32-wide register pass holds (40, 150: two and five
+    passes over the rows, partial sums parked in the ml buffer) and for one allele (h2 = h1: both factors of a
+    pair come from the row's own table entries), against the numpy oracle."""
+    _set_model(ctx)
+    base = next(c for c in CASES if c["name"] == "hd_expanded_rept_pe")
+    rng = np.random.default_rng(5)
+    cases = []
+    for n_target, ploidy in ((40, 2), (150, 2), (33, 1), (150, 1)):
+        c = dict(base)
+        c["target_lens"] = [int(x) for x in rng.choice(base["target_lens"], n_target) + rng.integers(-40, 40, n_target)]
+        c["ploidy"] = ploidy
+        c["name"] = "{}_nt{}_p{}".format(base["name"], n_target, ploidy)
+        cases.append(c)
+    hs = 128
+    units, full, pref, rept, gl, tl = _case_inputs(cases, hs)
+    n = len(cases)
+    want = [oracle_caller(c).evaluate() for c in cases]
+    assert all(w["run_pe"] for w in want)
+    goff = np.zeros(n + 1, np.int64)
+    goff[1:] = np.cumsum([len(w["mls"]) for w in want])
+    dump = np.zeros((int(goff[-1]), 6), np.float64)
+    calls = np.zeros(n, _lib.CALL_DTYPE)
+    ctx.likelihood_grid(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls, goff, dump,
+                        None, 0)
+    for i, (c, w) in enumerate(zip(cases, want)):
+        call = calls[i]
+        assert call["status"] == 0 and call["run_pe"] == 1 and call["n_pairs"] == len(w["mls"]), (c["name"], call)
+        got, exp = dump[goff[i]:goff[i + 1]], np.asarray(w["mls"], np.float64)
+        assert np.array_equal(got[:, :2], exp[:, :2]), c["name"]
+        assert np.abs(got[:, 2:] - exp[:, 2:]).max() <= ML_TOL, c["name"]
+        assert (call["h1"], call["h2"]) == tuple(w["alleles"]) and tuple(call["ci"]) == tuple(w["CI"]), c["name"]
+        assert abs(call["lik"] - w["lik"]) <= ML_TOL

@@ -577,17 +577,19 @@ static int check_grid_common(tredgpu_ctx* c, const tredgpu_unit_params* units, i
     return 0;
 }
 
-// Largest maxinsert over the units (device array): bounds the grid axes, hence the scratch slot of a unit.
+// Largest maxinsert and n_target over the units (device array): they bound the grid axes and the paired-end
+// tables, hence the scratch a unit can ask for.
 // One 4-byte read-back; the fused path asks before it launches the SW kernel, so the stream is idle.
-static int query_max_insert(tredgpu_ctx* c, const tredgpu_unit_params* units, int32_t n_units, int* out) {
+static int query_max_insert(tredgpu_ctx* c, const tredgpu_unit_params* units, int32_t n_units, int out[2]) {
     int rc;
     if ((rc = ensure(c, c->ws_counter, 64))) return rc;
     if (!c->h_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_pin, 64, hipHostMallocDefault));
     int* d = (int32_t*)c->ws_counter.p + 12;
     HIPCHK(c, launch_unit_max(units, n_units, d, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, d, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    *out = c->h_pin[0];
+    out[0] = c->h_pin[0];   // largest maxinsert
+    out[1] = c->h_pin[1];   // largest n_target
     return 0;
 }
 
@@ -595,13 +597,16 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
                            const int32_t* full_cnt, const int32_t* pref_cnt, const int32_t* rept_cnt,
                            const int32_t* global_lens, const int32_t* target_lens, tredgpu_call* calls,
                            const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride,
-                           int max_insert /* < 0: ask the device */) {
+                           const int* limits /* {max maxinsert, max n_target}; NULL: ask the device */) {
     if (n_units == 0) return 0;
     int rc;
-    if (max_insert < 0 && (rc = query_max_insert(c, units, n_units, &max_insert))) return rc;
+    int lim[2];
+    if (limits) { lim[0] = limits[0]; lim[1] = limits[1]; }
+    else if ((rc = query_max_insert(c, units, n_units, lim))) return rc;
+    const int max_insert = lim[0], max_target = lim[1];
     // every axis is a subset of {distinct sizes} U {max_partial} plus at most maxinsert arithmetic entries
     const int cap = std::min(std::max(hist_stride + 1 + std::max(max_insert, 0), 8), GRID_MAX_ROWS);
-    const size_t slot_max = grid_slot_doubles_max(cap, cap) * sizeof(double);
+    const size_t slot_max = grid_slot_doubles_max(cap, cap, max_target) * sizeof(double);
     // the pool: everything the batch can ask for if that is small, else GRID_POOL_BYTES and as many passes
     // as it takes (units that find the pool full are deferred to the next pass)
     const size_t pool_bytes = std::max(std::min((size_t)n_units * slot_max, c->grid_pool_bytes), slot_max);
@@ -660,11 +665,14 @@ int tredgpu_likelihood_grid(tredgpu_ctx* c, int mem, const tredgpu_unit_params* 
     HIPCHK(c, hipSetDevice(c->device));
     if (mem == TREDGPU_MEM_DEVICE)
         return run_grid_device(c, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens, target_lens,
-                               calls, grid_off, grid_dump, marg, marg_stride, -1);
+                               calls, grid_off, grid_dump, marg, marg_stride, nullptr);
     if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
     if (n_units == 0) return 0;
-    int max_insert = 0;
-    for (int g = 0; g < n_units; ++g) max_insert = std::max(max_insert, units[g].maxinsert);
+    int limits[2] = {0, 0};
+    for (int g = 0; g < n_units; ++g) {
+        limits[0] = std::max(limits[0], units[g].maxinsert);
+        limits[1] = std::max(limits[1], units[g].n_target);
+    }
     for (int g = 0; g < n_units; ++g) {
         const tredgpu_unit_params& u = units[g];
         if (u.n_global < 0 || u.n_target < 0 || u.pe_off < 0 || u.tl_off < 0 || (int64_t)u.pe_off + u.n_global > n_global_total ||
@@ -691,7 +699,7 @@ int tredgpu_likelihood_grid(tredgpu_ctx* c, int mem, const tredgpu_unit_params* 
     const size_t marg_n = marg ? (size_t)n_units * 2 * marg_stride : 0;
     if (marg && (rc = stage_out(c, c->st[9], marg_n, &d_marg))) return rc;
     if ((rc = run_grid_device(c, d_units, n_units, hist_stride, d_f, d_p, d_r, d_gl, d_tl, d_calls, d_goff, d_dump,
-                              d_marg, marg_stride, max_insert)))
+                              d_marg, marg_stride, limits)))
         return rc;
     if ((rc = copy_back(c, calls, (const tredgpu_call*)d_calls, (size_t)n_units))) return rc;
     if ((rc = copy_back(c, grid_dump, (const double*)d_dump, dump_n))) return rc;
@@ -755,8 +763,8 @@ int tredgpu_genotype_batch(tredgpu_ctx* c, int mem, const uint32_t* packed, cons
     HIPCHK(c, hipSetDevice(c->device));
     if (mem == TREDGPU_MEM_DEVICE) {
         int max_len = params->max_read_len > 0 ? params->max_read_len : TREDGPU_MAX_READ_LEN;
-        int max_insert = 0;
-        if (n_units > 0 && (rc = query_max_insert(c, units, n_units, &max_insert))) return rc;
+        int limits[2] = {0, 0};
+        if (n_units > 0 && (rc = query_max_insert(c, units, n_units, limits))) return rc;
         if (read_pair_id && (rc = ensure(c, c->ws_drop, (size_t)n_reads))) return rc;
         if ((rc = run_sw_device(c, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, n_units, params,
                                 max_len, out_tag, out_h, out_score, nullptr, 0)))
@@ -767,7 +775,7 @@ int tredgpu_genotype_batch(tredgpu_ctx* c, int mem, const uint32_t* packed, cons
                                    pref_cnt, rept_cnt, (uint8_t*)c->ws_drop.p, c->stream));
         }
         return run_grid_device(c, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens, target_lens,
-                               calls, nullptr, nullptr, nullptr, 0, max_insert);
+                               calls, nullptr, nullptr, nullptr, 0, limits);
     }
     if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
     // HOST memory: compose the three host-memory calls (each validates and stages its own arguments)

@@ -19,8 +19,9 @@
 // this path needed 168 VGPRs plus 400 B of spills per lane and ran at 15 ms against 9 ms per 30 000 units)
 //
 // Arithmetic mirrors the reference's operation order (compiled with -ffp-contract=off); the only
-// intended differences are libm-vs-ocml last-bit effects in log/exp, the paired-end product-log (pe_term) and
+// intended differences are libm-vs-ocml last-bit effects in log/exp, the paired-end product-log (pairs kernel) and
 // the summation order of the marginals.
+#include <algorithm>
 #include <type_traits>
 
 #include "tredgpu_internal.h"
@@ -151,53 +152,6 @@ __device__ double rept_term(const PairCtx& C, int dsum) {
     double prob = exp(xl - C.lgam_rept - mu);
     if (!(prob > C.really_small)) prob = C.really_small;
     return log(prob);
-}
-
-// paired-end term (models.py:460-473).  r1/r2: roll(h1)[x_t], roll(h2)[x_t] for the unit's spanning
-// pairs, either from the per-axis tables or evaluated on the fly (same expression, same bits).
-// Sum of log(max(p, SMALL)) evaluated as the log of a running product that is flushed before it can
-// leave the normal range (every factor is in [e^-10, 1], so 32 factors stay above e^-320): one log per
-// 32 pairs.  Differs from the reference's term-by-term sum by O(1e-14), far inside the 1e-6 contract.
-template <bool TABLES>
-__device__ double pe_term(const PairCtx& C, int h1, int h2, const double* r1, const double* r2, int r2_stride) {
-    double ml4 = 0, prod = 1.0;
-    const int n = C.n_target;
-    if (TABLES) {
-        // 8 factors per step with all 16 loads issued up front (the tables live in L2-resident scratch);
-        // same multiplication order as the plain loop, padding factors are exactly 1.0
-        for (int base = 0; base < n; base += 8) {
-            double a[8], b[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int idx = min(base + q, n - 1);
-                a[q] = r1[idx];
-                b[q] = r2[(size_t)idx * r2_stride];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                double p = .5 * a[q] + (1 - .5) * b[q];
-                if (p < C.small) p = C.small;
-                if (base + q >= n) p = 1.0;
-                prod *= p;
-            }
-            if ((base & 31) == 24) { ml4 += log(prod); prod = 1.0; }
-        }
-        if (n & 31) ml4 += log(prod);
-        return ml4;
-    }
-    int k = 0;
-    for (int i = 0; i < n; ++i) {
-        int x = C.tl[i];
-        if (x < 0) x += SPAN;
-        const double p1 = roll_at(C.pdf, C.ref_len, C.minpe, h1, x, C.small);
-        const double p2 = roll_at(C.pdf, C.ref_len, C.minpe, h2, x, C.small);
-        double p = .5 * p1 + (1 - .5) * p2;
-        if (p < C.small) p = C.small;
-        prod *= p;
-        if (++k == 32) { ml4 += log(prod); prod = 1.0; k = 0; }
-    }
-    if (k) ml4 += log(prod);
-    return ml4;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -334,19 +288,20 @@ constexpr int NR = 256;     // threads per workgroup of grid_reduce_kernel
 
 // Where one unit's tables live in the scratch pool (offsets in doubles from the unit's base)
 struct SlotLayout {
-    int32_t obs, rowoff, far1, far2, pdf, rept, roll1, roll2, ml, total;
+    int32_t obs, rowoff, far1, far2, near1, near2, rept, roll1, roll2, ml, total;
 };
-__device__ inline SlotLayout unit_layout(int nrow, int ncol, int nt, bool want_pdf, bool use_rept, int dmax, bool use_roll) {
+__device__ inline SlotLayout unit_layout(int nrow, int ncol, int nt, bool run_pe, bool haploid, int dmax, int n_near) {
     SlotLayout L;
     int o = 0;
     L.obs = o;    o += (int)((sizeof(Obs) + 7) / 8);
     L.rowoff = o; o += (nrow + 2) / 2;
     L.far1 = o;   o += nrow;
     L.far2 = o;   o += nrow;
-    L.pdf = o;    o += want_pdf ? SPAN : 0;
-    L.rept = o;   o += use_rept ? dmax + 1 : 0;
-    L.roll1 = o;  o += use_roll ? nrow * ((nt + 31) & ~31) : 0;   // rows padded to 32 entries
-    L.roll2 = o;  o += use_roll ? ncol * nt : 0;
+    L.near1 = o;  o += nrow * n_near;
+    L.near2 = o;  o += nrow * n_near;
+    L.rept = o;   o += dmax + 1;
+    L.roll1 = o;  o += run_pe ? nrow * ((nt + 31) & ~31) : 0;   // rows padded to 32 entries
+    L.roll2 = o;  o += run_pe && !haploid ? ncol * nt : 0;
     L.ml = o;     o += nrow * ncol;
     L.total = (o + 15) & ~15;   // slots start on 128-byte lines
     return L;
@@ -363,7 +318,7 @@ struct UnitDesc {
     int32_t t1, t2, mp_eff, h_far;
     int32_t nrow, ncol, nb, hmaxv;
     Axis ax1, ax2;
-    int32_t use_rept_tab, use_roll_tab;
+    int32_t nbn, n_near;   // near columns (h2 < h_far): the first nbn base entries + the first n_near - nbn arithmetic ones
     int32_t cutoff_risk, is_expansion, is_recessive, pad1;
     double half_depth, lgam_rept, logsmall;
     int64_t slot_off;      // doubles from the start of the pool
@@ -401,6 +356,17 @@ __device__ __forceinline__ tredgpu_unit_params uniform_unit(const tredgpu_unit_p
 #pragma unroll
     for (int k = 0; k < 16; ++k) x.w[k] = __builtin_amdgcn_readfirstlane(x.w[k]);
     return x.u;
+}
+
+// A unit descriptor as wave-uniform values (see uniform_unit): the pairs kernel keeps it live through its loops.
+__device__ __forceinline__ UnitDesc uniform_desc(const UnitDesc* p) {
+    static_assert(sizeof(UnitDesc) % sizeof(int) == 0, "UnitDesc is a whole number of dwords");
+    constexpr int NW = sizeof(UnitDesc) / sizeof(int);
+    union { UnitDesc d; int w[NW]; } x;
+    x.d = *p;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) x.w[k] = __builtin_amdgcn_readfirstlane(x.w[k]);
+    return x.d;
 }
 
 struct PrepShared {
@@ -603,7 +569,7 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         d.h_far = max(max(max_full + 19, mp_eff), t1);
         d.nrow = nrow; d.ncol = ncol; d.nb = nb; d.hmaxv = hmaxv;
         d.ax1 = ax1; d.ax2 = ax2;
-        d.use_rept_tab = 0; d.use_roll_tab = 0;
+        d.nbn = 0; d.n_near = 0;
         d.cutoff_risk = u.cutoff_risk; d.is_expansion = u.is_expansion; d.is_recessive = u.is_recessive; d.pad1 = 0;
         d.half_depth = u.half_depth;
         if (n_rept < GRID_LFACT) d.lgam_rept = M.lfact[n_rept];
@@ -618,15 +584,23 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             continue;
         }
 
-        // ---- tables for big grids (decided here, filled below): the repeat-only term depends on dsum only,
-        //      the paired-end term on roll(h)[x_t] per axis value
+        // ---- everything the pairs kernel adds up comes from tables filled below: the repeat-only term depends on
+        //      dsum = max(h1-L,1) + max(h2-L,1) only, the paired-end term on roll(h)[x_t] per axis value, the
+        //      spanning + partial terms on the row alone once h2 >= h_far ("far"), on (row, column) for the few
+        //      "near" columns below h_far -- a prefix of the base part and a prefix of the arithmetic part of
+        //      the h2 axis, both ascending
         const int rect = nrow * ncol;
         const int dmax = 2 * max(hmaxv - readlen, 1);
-        d.use_rept_tab = rect >= 1024 && dmax < GRID_REPT_TAB;
-        d.use_roll_tab = run_pe && rect >= 1024 && u.n_target <= GRID_TMAX && u.ploidy != 1;
+        const bool haploid = u.ploidy == 1;
+        if (!haploid) {
+            for (int k = 0; k < ax2.nb; ++k) d.nbn += S.obs.base[k] < d.h_far;
+            int nan = 0;
+            if (ax2.n > 0 && d.h_far > ax2.start) nan = min(ax2.n, (d.h_far - ax2.start + period - 1) / period);
+            d.n_near = d.nbn + nan;
+        }
 
         // ---- room in the pool and a run of work items; a unit that finds the pool full waits for the next pass
-        d.lay = unit_layout(nrow, ncol, u.n_target, run_pe && !d.use_roll_tab, d.use_rept_tab, dmax, d.use_roll_tab);
+        d.lay = unit_layout(nrow, ncol, u.n_target, run_pe, haploid, dmax, d.n_near);
         d.n_items = unit_items(nrow, ncol);
         if (tid == 0) {
             const unsigned long long off = atomicAdd(&ctr->pool_used, (unsigned long long)d.lay.total);
@@ -650,14 +624,13 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         double* slot = pool + d.slot_off;
         for (int k = tid; k < d.n_items; k += NT) item_unit[d.item_base + k] = g;
 
-        // ---- hand the unit's lists and (when the pairs kernel evaluates roll() itself) its KDE to the slot ----
+        // ---- hand the unit's lists to the slot ----
         Obs* gobs = reinterpret_cast<Obs*>(slot + L.obs);
         {
             const int* src = reinterpret_cast<const int*>(&S.obs);
             int* dst = reinterpret_cast<int*>(gobs);
             for (int k = tid; k < (int)(sizeof(Obs) / sizeof(int)); k += NT) dst[k] = src[k];
         }
-        if (run_pe && !d.use_roll_tab) for (int x = tid; x < SPAN; x += NT) slot[L.pdf + x] = S.pdf[x];
         const PairCtx C = make_ctx(d, M, &S.obs, S.pdf, a.target_lens);
 
         // ---- rows: count of valid h2 per h1 (h1 <= h2), dump offsets; per-row "far" terms ----
@@ -676,7 +649,7 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             }
             S.row_off[i] = cnt;
             double f1, f2;
-            eval_reads(C, h1, max(d.h_far, h1), f1, f2);
+            eval_reads(C, h1, haploid ? h1 : max(d.h_far, h1), f1, f2);   // (one allele: the only column is h2 = h1)
             slot[L.far1 + i] = f1;
             slot[L.far2 + i] = f2;
         }
@@ -691,8 +664,18 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         if (a.grid_dump != nullptr)
             for (int i = tid; i <= nrow; i += NT) row_off[i] = S.row_off[i];
 
-        // ---- the tables, filled with the very expressions the direct path uses
-        if (d.use_rept_tab) {
+        // ---- spanning + partial terms of the near columns
+        for (int k = tid; k < nrow * d.n_near; k += NT) {
+            const int i = k / d.n_near, c = k - i * d.n_near;
+            const int h1 = axis_value(ax1, S.obs.base, period, i);
+            const int h2 = c < d.nbn ? S.obs.base[c] : ax2.start + (c - d.nbn) * period;
+            double f1 = 0, f2 = 0;
+            if (h1 <= h2) eval_reads(C, h1, h2, f1, f2);
+            slot[L.near1 + k] = f1;
+            slot[L.near2 + k] = f2;
+        }
+        // ---- the repeat-only table
+        {
             double* rept_tab = slot + L.rept;
             if (dmax < rect) {
                 // fewer table entries than pairs: fill every entry
@@ -704,7 +687,7 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
                 int i = tid / ncol, j = tid - i * ncol;
                 for (int pos = tid; pos < rect; pos += NT) {
                     const int h1 = axis_value(ax1, S.obs.base, period, i);
-                    const int h2 = u.ploidy == 1 ? h1 : axis_value(ax2, S.obs.base, period, j);
+                    const int h2 = haploid ? h1 : axis_value(ax2, S.obs.base, period, j);
                     if (h1 <= h2) rept_tab[max(h1 - readlen, 1) + max(h2 - readlen, 1)] = 2.0;  // needed
                     j += NT;
                     while (j >= ncol) { j -= ncol; ++i; }
@@ -714,9 +697,11 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
                     if (rept_tab[x] == 2.0) rept_tab[x] = rept_term(C, x);
             }
         }
-        if (d.use_roll_tab) {
+        // ---- the paired-end tables: .5 * roll(h)[x_t] per row and (two alleles) per column
+        if (run_pe) {
             const int nt = u.n_target, ntp = (nt + 31) & ~31;
-            for (int k = tid; k < (nrow + ncol) * nt; k += NT) {
+            const int ncol_t = haploid ? 0 : ncol;
+            for (int k = tid; k < (nrow + ncol_t) * nt; k += NT) {
                 const bool isrow = k < nrow * nt;
                 const int kk = isrow ? k : k - nrow * nt;
                 const int ai = kk / nt, t = kk - ai * nt;
@@ -750,7 +735,9 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // 32 roll(h1) values with one coalesced load that v_readlane then hands out.
 //
 // paired-end term (models.py:460-473) from the tables: log of the running product of
-// max(.5 * roll(h1)[x] + .5 * roll(h2)[x], SMALL), flushed every 32 factors as in pe_term; with more than
+// max(.5 * roll(h1)[x] + .5 * roll(h2)[x], SMALL), flushed every 32 factors (every factor is in [e^-10, 1], so
+// 32 of them stay above e^-320: one log per 32 pairs instead of one per pair, O(1e-14) from the reference's
+// term-by-term sum, far inside the 1e-6 contract); with more than
 // 32 spanning pairs the rows are walked once per 32 and the partial sums parked in the ml buffer.
 // (the tables hold .5 * roll(h)[x], so a factor is max(entry + entry, SMALL).)
 struct RowIn {
@@ -761,7 +748,7 @@ struct RowIn {
 __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitDesc* descs, double* pool,
                                                          const int* item_unit, Best* item_best, GridCounters* ctr) {
     const int lane = threadIdx.x & 63;
-    const ModelConst& M = *a.model;
+    const double small = a.model->small;
     const int total = ctr->n_items;
     while (true) {
         int t = 0;
@@ -769,13 +756,13 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= total) break;
         const int g = __builtin_amdgcn_readfirstlane(item_unit[t]);
-        const UnitDesc d = descs[g];   // by value: stays in registers across the stores below
+        const UnitDesc d = uniform_desc(descs + g);   // by value, in scalar registers across the stores below
         const SlotLayout L = d.lay;
         double* slot = pool + d.slot_off;
         const int nrow = d.nrow, ncol = d.ncol, period = d.period;
+        const bool haploid = d.ploidy == 1;
         const Obs* obs = reinterpret_cast<const Obs*>(slot + L.obs);
         double* mlbuf = slot + L.ml;
-        const PairCtx C = make_ctx(d, M, obs, slot + L.pdf, a.target_lens);
         int64_t dump_base = -1;
         if (a.grid_dump != nullptr && d.n_pairs <= a.grid_off[g + 1] - a.grid_off[g]) dump_base = a.grid_off[g];
         const int* row_off = reinterpret_cast<const int*>(slot + L.rowoff);
@@ -790,8 +777,14 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
         const int j = cb * CB + lane;
         const bool jin = j < ncol;
         const int jc = jin ? j : ncol - 1;
-        const int h2col = d.ploidy == 1 ? 0 : axis_value(d.ax2, obs->base, period, jc);
-        const bool tab = d.run_pe && d.use_roll_tab;
+        const int h2col = haploid ? 0 : axis_value(d.ax2, obs->base, period, jc);
+        // near column (h2 < h_far): its index in the near tables, else -1 (the row's far terms apply)
+        int jn = -1;
+        if (!haploid) {
+            if (jc < d.ax2.nb) jn = jc < d.nbn ? jc : -1;
+            else jn = jc - d.ax2.nb < d.n_near - d.nbn ? d.nbn + jc - d.ax2.nb : -1;
+        }
+        const bool tab = d.run_pe != 0;
         const int n = d.n_target;
         const int ntp = (n + TC - 1) & ~(TC - 1);
         const int npass = tab ? ntp / TC : 1;
@@ -800,7 +793,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
             const bool last = pass == npass - 1;
             const int t0 = pass * TC;
             double b[TC];
-            if (tab) {
+            if (tab && !haploid) {
 #pragma unroll
                 for (int q = 0; q < TC; ++q) b[q] = t0 + q < n ? slot[L.roll2 + (size_t)(t0 + q) * ncol + jc] : .5;
             }
@@ -814,30 +807,39 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                 return r;
             };
             // software pipeline over the rows: row i+2's scalars and roll(h1) values are requested, row i+1's
-            // repeat-only term is gathered (its h1 arrived an iteration ago), row i is evaluated
-            const int d2col = max((d.ploidy == 1 ? 0 : h2col) - d.readlen, 1);
-            auto gather_rept = [&](int h1) {
-                const int d2 = d.ploidy == 1 ? max(h1 - d.readlen, 1) : d2col;
-                return slot[L.rept + max(h1 - d.readlen, 1) + d2];
+            // repeat-only term and near terms are gathered (its h1 arrived an iteration ago), row i is evaluated
+            const int d2col = max((haploid ? 0 : h2col) - d.readlen, 1);
+            struct Gathered { double m2, n1, n2; };
+            auto gather_row = [&](int i, int h1) {
+                Gathered v;
+                const int d2 = haploid ? max(h1 - d.readlen, 1) : d2col;
+                v.m2 = slot[L.rept + max(h1 - d.readlen, 1) + d2];
+                v.n1 = v.n2 = 0;
+                if (jn >= 0) { v.n1 = slot[L.near1 + i * d.n_near + jn]; v.n2 = slot[L.near2 + i * d.n_near + jn]; }
+                return v;
             };
-            const bool gather = last && d.use_rept_tab;
             RowIn cur = load_row(i_begin);
             RowIn nxt = i_begin + 1 < i_end ? load_row(i_begin + 1) : cur;
-            double m2cur = gather ? gather_rept(cur.h1) : 0.0;
+            Gathered gcur = {0, 0, 0};
+            if (last) gcur = gather_row(i_begin, cur.h1);
             for (int i = i_begin; i < i_end; ++i) {
                 RowIn nn = nxt;
                 if (i + 2 < i_end) nn = load_row(i + 2);
-                const double m2nxt = gather && i + 1 < i_end ? gather_rept(nxt.h1) : 0.0;
+                Gathered gnxt = {0, 0, 0};
+                if (last && i + 1 < i_end) gnxt = gather_row(i + 1, nxt.h1);
                 const int h1r = __builtin_amdgcn_readfirstlane(cur.h1);
-                const int h2r = d.ploidy == 1 ? h1r : h2col;
+                const int h2r = haploid ? h1r : h2col;
                 const bool ok = jin && h1r <= h2r;
                 if (__builtin_amdgcn_ballot_w64(ok) != 0) {   // else: row entirely below the diagonal here
                     double lp = 0;
                     if (tab) {
                         double prod = 1.0;
+                        if (haploid) {   // both alleles are the row's h1: .5 * roll + .5 * roll
 #pragma unroll
-                        for (int q = 0; q < TC; ++q) {
-                            prod *= fmax(readlane_d(cur.r1v, q) + b[q], C.small);
+                            for (int q = 0; q < TC; ++q) { const double av = readlane_d(cur.r1v, q); prod *= fmax(av + av, small); }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < TC; ++q) prod *= fmax(readlane_d(cur.r1v, q) + b[q], small);
                         }
                         lp = log(prod);
                     }
@@ -847,19 +849,16 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                         if (tab) m3 += lp;
                         if (!last) mlbuf[pos] = m3;
                         else {
-                            double m0, m1;
-                            if (h2r >= d.h_far) { m0 = cur.f1; m1 = cur.f2; }
-                            else eval_reads(C, h1r, h2r, m0, m1);
-                            const int dsum = max(h1r - d.readlen, 1) + max(h2r - d.readlen, 1);
-                            const double m2 = d.use_rept_tab ? m2cur : rept_term(C, dsum);
-                            if (d.run_pe && !d.use_roll_tab) m3 = pe_term<false>(C, h1r, h2r, nullptr, nullptr, 0);
+                            const double m0 = jn >= 0 ? gcur.n1 : cur.f1;
+                            const double m1 = jn >= 0 ? gcur.n2 : cur.f2;
+                            const double m2 = gcur.m2;
                             const double ml = m0 + m1 + m2 + m3;  // models.py:269
                             mlbuf[pos] = ml;
                             Best bb; bb.ml = ml; bb.h1 = h1r; bb.pos = pos;
                             if (better(bb, mine)) mine = bb;
                             if (dump_base >= 0) {
                                 int within = 0;  // valid columns before j in this row
-                                if (d.ploidy != 1)
+                                if (!haploid)
                                     for (int jj = 0; jj < j; ++jj) within += axis_value(d.ax2, obs->base, period, jj) >= h1r;
                                 double* o = a.grid_dump + (dump_base + row_off[i] + within) * 6;
                                 o[0] = h1r; o[1] = h2r; o[2] = m0; o[3] = m1; o[4] = m2; o[5] = m3;
@@ -867,7 +866,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                         }
                     }
                 }
-                cur = nxt; nxt = nn; m2cur = m2nxt;
+                cur = nxt; nxt = nn; gcur = gnxt;
             }
         }
         }   // column blocks of the item
@@ -1109,14 +1108,17 @@ hipError_t launch_pe_kde(const GridArgs& a, hipStream_t s) {
 namespace {
 __global__ void unit_max_kernel(const tredgpu_unit_params* units, int n, int* out) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    int v = g < n ? units[g].maxinsert : 0;
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, 64));
-    if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
+    int v = g < n ? units[g].maxinsert : 0, w = g < n ? units[g].n_target : 0;
+    for (int o = 32; o > 0; o >>= 1) { v = max(v, __shfl_down(v, o, 64)); w = max(w, __shfl_down(w, o, 64)); }
+    if ((threadIdx.x & 63) == 0) {
+        if (v > 0) atomicMax(out, v);
+        if (w > 0) atomicMax(out + 1, w);
+    }
 }
 }  // namespace
 
 hipError_t launch_unit_max(const tredgpu_unit_params* units, int n_units, int* out, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(int), s);
+    hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(int), s);
     if (e != hipSuccess || n_units <= 0) return e;
     unit_max_kernel<<<(n_units + 255) / 256, 256, 0, s>>>(units, n_units, out);
     return hipGetLastError();
@@ -1132,9 +1134,11 @@ size_t grid_items_cap(int rows_cap, int cols_cap) {   // most work items one uni
 
 size_t grid_item_bytes() { return sizeof(int) + sizeof(Best); }
 
-size_t grid_slot_doubles_max(int rows_cap, int cols_cap) {   // largest slot a unit within the caps can ask for
-    return (sizeof(Obs) + 7) / 8 + (size_t)rows_cap * 3 + 2 + SPAN + GRID_REPT_TAB + (size_t)(rows_cap + cols_cap) * GRID_TMAX +
-           (size_t)rows_cap * cols_cap + 16;
+// largest slot a unit within the caps can ask for (nt_max = most spanning pairs of any unit)
+size_t grid_slot_doubles_max(int rows_cap, int cols_cap, int nt_max) {
+    const size_t ntp = ((size_t)std::max(nt_max, 0) + 31) & ~(size_t)31;
+    return (sizeof(Obs) + 7) / 8 + (size_t)rows_cap * 3 + 2 + 2 * (size_t)18 * MAXM + 2 + (size_t)rows_cap * ntp +
+           (size_t)cols_cap * (size_t)std::max(nt_max, 0) + 3 * (size_t)rows_cap * cols_cap + 16;
 }
 
 // One pass over all units: prepare (takes pool room per unit) -> pairs -> reduce, all on stream s.  Units that

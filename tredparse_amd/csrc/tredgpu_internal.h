@@ -95,18 +95,16 @@ struct GridArgs {
 };
 constexpr int GRID_MAX_ROWS = 1024;  // |h1range| / |h2range| the grid kernels accept (status -5 beyond)
 constexpr int GRID_MAX_COLS = 1024;
-constexpr int GRID_REPT_TAB = 8192;   // entries of the per-unit repeat-only table (index dsum)
-constexpr int GRID_TMAX = 128;        // spanning pairs per unit the roll tables hold
 constexpr size_t GRID_POOL_BYTES = (size_t)12 << 30;  // scratch pool the units' tables are carved from
 constexpr int GRID_UNIT_DEFERRED = 100;               // calls[].status of a unit waiting for the next pass
 
 hipError_t launch_pe_kde(const GridArgs& a, hipStream_t s);
-// max over units of maxinsert -> *out (device int, zeroed by the launch)
+// max over units of maxinsert -> out[0], of n_target -> out[1] (device ints, zeroed by the launch)
 hipError_t launch_unit_max(const tredgpu_unit_params* units, int n_units, int* out, hipStream_t s);
 size_t grid_desc_bytes();
 size_t grid_counter_bytes();
 int grid_deferred_offset();                          // byte offset of the deferred-unit count in the counter block
-size_t grid_slot_doubles_max(int rows_cap, int cols_cap);
+size_t grid_slot_doubles_max(int rows_cap, int cols_cap, int nt_max);
 size_t grid_items_cap(int rows_cap, int cols_cap);   // work items one unit can make at most
 size_t grid_item_bytes();                            // bytes per work item in the items buffer
 // One pass over all units (prepare -> pairs -> reduce); see grid.hip
