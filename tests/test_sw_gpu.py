@@ -151,3 +151,23 @@ def test_aligner_mirror_matches_reference_goldens(ctx):
         assert got == tuple(int(x) for x in want[k]), k
         # the min_score / min_len filter of Aligner.align (ssw_wrap.py:214-220)
         assert al.align(reads[pr[k]], min_score=int(want[k][0]) + 1, min_len=0) is None
+
+
+@pytest.mark.parametrize("readlen", [36, 50, 64])
+def test_short_reads_through_the_pruned_path(ctx, loci, readlen):
+    """Reads of up to 64 bp use 4 rows per lane: a 6-mer window then spans three lanes, so the in-kernel 6-mer
+    bound must stay off there (it once capped scores too low and dropped the last templates of the ladder:
+    found by tools/fuzz_parity.py).  Non-dump path, every read against the reference's own ssw.c."""
+    sel = [l for l in loci if l["name"] in ("HD", "SCA3", "DM1", "FRDA", "SCA10")]
+    p = synth.SynthParams(coverage=40, readlen=readlen, min_units=1, max_units=30, sub=0.02, nrate=0.01)
+    b = synth.build_batch(900 + readlen, sel, 3, p, workers=4)
+    ctx.set_ladders(b.ladders)
+    n = b.n_reads
+    tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
+    ctx.sw_classify(_lib.MEM_HOST, b.packed, b.read_off, b.read_len, n, b.unit_read_off, b.unit_ladder, b.n_units,
+                    _lib.default_sw_params(max_read_len=readlen), tag, h, sc)
+    reads = [synth.decode(r) for r in b.codes]
+    cls = po.ref_classify(reads, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), po.LocusSet(b.ladders), threads=0)
+    bad = np.nonzero((tag != cls[:, 0]) | (h != cls[:, 1]) | (sc != cls[:, 2]))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], tag[bad[:5]], h[bad[:5]], cls[bad[:5]])
+    assert (tag == 4).sum() > 20      # REPT reads: the case that exposed it

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(64, W) void sw_ladder_kernel(SwArgs a) {
         // Windows containing N count as present.  Skipped for the dump (all positive scores wanted),
         // for N-containing motifs and for scorings outside the bound's premise.
         int kcap = 1 << 20;  // per read: upper bound of any score on this strand
-        if (2 * R + 10 <= 32 && !full_dump && kmer_thr > 0 && __builtin_amdgcn_readfirstlane(ld->kmer_ok) != 0) {
+        // (a 6-mer window starting in this lane ends at most 5 bases into the next lane's rows: needs R >= 5;
+        //  with fewer rows per lane the per-read classes of read_class_kernel already removed hopeless strands)
+        if (R >= 5 && 2 * R + 10 <= 32 && !full_dump && kmer_thr > 0 && __builtin_amdgcn_readfirstlane(ld->kmer_ok) != 0) {
             const uint32_t* bm = a.seqw + __builtin_amdgcn_readfirstlane(ld->kmer_off[s]);
             const uint32_t pk_n = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x101, 0xF, 0xF, false);        // row_shl:1
             const uint32_t nk_n = (uint32_t)__builtin_amdgcn_update_dpp(0x3FF, (int)nk, 0x101, 0xF, 0xF, false);
