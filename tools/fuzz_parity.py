@@ -46,20 +46,22 @@ def main():
         n = b.n_reads
         reads = [synth.decode(r) for r in b.codes]
         clip = bool(rng.random() < 0.3)
+        scoring = [(1, 5, 7, 2)] * 3 + [(2, 3, 5, 2), (1, 4, 6, 1), (1, 1, 2, 1), (3, 5, 7, 2), (1, 9, 12, 3)]
+        scoring = scoring[int(rng.integers(len(scoring)))]
         if clip:   # --useclippedreads: ragged lengths exercise the per-read REPT cut-off (bam_parser.py:154-155)
             reads = [r[int(rng.integers(0, max(1, len(r) // 3))):] for r in reads]
         packed, woff, rlen = _lib.pack_reads(reads)
         tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
         ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, b.unit_read_off, b.unit_ladder, b.n_units,
-                        _lib.default_sw_params(clip=clip, max_read_len=readlen), tag, h, sc)
+                        _lib.SwParams(scoring[0], scoring[1], scoring[2], scoring[3], 9, int(clip), readlen, 0), tag, h, sc)
         cls = po.ref_classify(reads, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), po.LocusSet(b.ladders), clip=clip,
-                              threads=0)
+                              scoring=scoring, threads=0)
         bad = np.nonzero((tag != cls[:, 0]) | (h != cls[:, 1]) | (sc != cls[:, 2]))[0]
         n_reads += n
         n_bad += len(bad)
         tags += np.bincount(tag, minlength=6)[:6]
         if len(bad):
-            print("MISMATCH round", k, "readlen", readlen, "clip", clip, bad[:5], tag[bad[:5]], h[bad[:5]], sc[bad[:5]], cls[bad[:5]],
+            print("MISMATCH round", k, "readlen", readlen, "clip", clip, "scoring", scoring, bad[:5], tag[bad[:5]], h[bad[:5]], sc[bad[:5]], cls[bad[:5]],
                   file=sys.stderr)
     print(json.dumps({"reads": int(n_reads), "mismatches": int(n_bad), "rounds": rounds, "seed": seed,
                       "tags_none_full_pref_post_rept_hang": [int(x) for x in tags], "seconds": round(time.time() - t0, 1)}))
