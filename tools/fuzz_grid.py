@@ -44,6 +44,7 @@ def main():
         b = synth.build_batch(int(rng.integers(1 << 30)), sel, int(rng.integers(1, 4)), p, maxinsert=maxinsert, workers=8)
         units = b.units.copy()
         units["ploidy"] = rng.choice([1, 2], len(units), p=[0.25, 0.75])
+        units["fullsearch"] = rng.random(len(units)) < 0.15
         ctx.set_ladders(b.ladders)
         n, g, hs = b.n_reads, b.n_units, b.hist_stride
         tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
@@ -63,7 +64,7 @@ def main():
             res = lo.Caller(int(up["period"]), 150, int(up["ploidy"]), 2 * float(up["half_depth"]), f, pp, int(rept[u].sum()),
                             b.global_lens[up["pe_off"]:up["pe_off"] + up["n_global"]],
                             b.target_lens[up["tl_off"]:up["tl_off"] + up["n_target"]], int(up["ref_len"]),
-                            int(up["minpe"]), maxinsert=int(up["maxinsert"])).evaluate()
+                            int(up["minpe"]), maxinsert=int(up["maxinsert"]), fullsearch=bool(up["fullsearch"])).evaluate()
             checked += 1
             if res["status"] == 1:
                 ok = c["status"] == 1
