@@ -42,9 +42,9 @@ def _case_inputs(cases, hist_stride):
     return units, full, pref, rept, np.asarray(gl, np.int32), np.asarray(tl, np.int32)
 
 
-def test_grid_matches_reference_goldens(ctx):
+@pytest.mark.parametrize("hs", [128, 400])   # 400: histograms too wide for the kernel's LDS staging (other code path)
+def test_grid_matches_reference_goldens(ctx, hs):
     _set_model(ctx)
-    hs = 128
     units, full, pref, rept, gl, tl = _case_inputs(CASES, hs)
     n = len(CASES)
     cap = np.array([max(c["expected"].get("n_pairs", 0), 1) for c in CASES], np.int64)
