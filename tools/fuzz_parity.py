@@ -29,7 +29,7 @@ def main():
     loci = synth.load_loci()
     rng = np.random.default_rng(seed)
     ctx = _lib.Context(0)
-    n_reads = n_bad = 0
+    n_reads = n_bad = n_pairs = n_bad_pairs = 0
     tags = np.zeros(6, np.int64)
     t0 = time.time()
     for k in range(rounds):
@@ -59,13 +59,44 @@ def main():
         bad = np.nonzero((tag != cls[:, 0]) | (h != cls[:, 1]) | (sc != cls[:, 2]))[0]
         n_reads += n
         n_bad += len(bad)
+        # per-template results (score, ref_begin, ref_end, read_begin, read_end) of the first units, dump path
+        gsub = 1
+        while gsub < b.n_units and b.unit_read_off[gsub] < 120:
+            gsub += 1
+        m = int(b.unit_read_off[gsub])
+        if m:
+            ls = po.LocusSet(b.ladders)
+            nt = max(2 * l[3] for l in b.ladders)
+            dump = np.zeros((m, nt, 6), np.int16)
+            packed2, woff2, rlen2 = _lib.pack_reads(reads[:m])
+            t2 = np.zeros(m, np.uint8); h2 = np.zeros(m, np.int16); s2 = np.zeros(m, np.int16)
+            ctx.sw_classify(_lib.MEM_HOST, packed2, woff2, rlen2, m, b.unit_read_off[:gsub + 1].copy(),
+                            b.unit_ladder[:gsub].copy(), gsub,
+                            _lib.SwParams(scoring[0], scoring[1], scoring[2], scoring[3], 9, int(clip), readlen, 0),
+                            t2, h2, s2, dump, nt)
+            pr, pt, where = [], [], []
+            for r in range(m):
+                lad = int(b.unit_ladder[np.searchsorted(b.unit_read_off, r, side="right") - 1])
+                for j, t in enumerate(range(ls.lad_off[lad], ls.lad_off[lad + 1])):
+                    pr.append(r); pt.append(t); where.append((r, j))
+            want = po.ref_sw_pairs(reads[:m], ls.templates, pr, pt, scoring=scoring, threads=0)
+            got = np.array([dump[r, j, :5] for r, j in where], np.int32)
+            nb = int((got != want).any(axis=1).sum())
+            n_pairs += len(pr)
+            n_bad_pairs += nb
+            if nb:
+                kk = int(np.nonzero((got != want).any(axis=1))[0][0])
+                print("PAIR MISMATCH round", k, "readlen", readlen, "scoring", scoring, where[kk], got[kk], want[kk], file=sys.stderr)
+            if not (np.array_equal(t2, tag[:m]) and np.array_equal(h2, h[:m]) and np.array_equal(s2, sc[:m])):
+                n_bad += 1
+                print("DUMP/NON-DUMP PATH DISAGREE round", k, file=sys.stderr)
         tags += np.bincount(tag, minlength=6)[:6]
         if len(bad):
             print("MISMATCH round", k, "readlen", readlen, "clip", clip, "scoring", scoring, bad[:5], tag[bad[:5]], h[bad[:5]], sc[bad[:5]], cls[bad[:5]],
                   file=sys.stderr)
-    print(json.dumps({"reads": int(n_reads), "mismatches": int(n_bad), "rounds": rounds, "seed": seed,
+    print(json.dumps({"reads": int(n_reads), "mismatches": int(n_bad), "template_pairs": int(n_pairs), "pair_mismatches": int(n_bad_pairs), "rounds": rounds, "seed": seed,
                       "tags_none_full_pref_post_rept_hang": [int(x) for x in tags], "seconds": round(time.time() - t0, 1)}))
-    return 1 if n_bad else 0
+    return 1 if (n_bad or n_bad_pairs) else 0
 
 
 if __name__ == "__main__":
