@@ -43,8 +43,45 @@ def main():
         sel = [sel[i] for i in rng.permutation(len(sel))[:int(rng.integers(4, len(sel) + 1))]]
         b = synth.build_batch(int(rng.integers(1 << 30)), sel, int(rng.integers(1, 4)), p, workers=8)
         ctx.set_ladders(b.ladders)
-        n = b.n_reads
         reads = [synth.decode(r) for r in b.codes]
+        uro, ulad = list(b.unit_read_off), list(b.unit_ladder)
+        # adversarial units: pure repeats in any phase / strand, exact template windows, chimeras, N runs, junk
+        for _ in range(4):
+            lad = int(rng.integers(len(b.ladders)))
+            prefix, rep, suffix, mu = b.ladders[lad]
+            rep_c = rep.replace("N", "C")
+            extra = []
+            for _ in range(25):
+                kind = int(rng.integers(7))
+                u = int(rng.integers(1, mu + 1))
+                tmpl = prefix + rep_c * u + suffix
+                if kind == 0:
+                    ph = int(rng.integers(len(rep_c)))
+                    r = (rep_c * (readlen // len(rep_c) + 2))[ph:ph + readlen]
+                elif kind == 1:
+                    o = int(rng.integers(0, max(1, len(tmpl) - 10)))
+                    r = tmpl[o:o + readlen]
+                elif kind == 2:
+                    other = b.ladders[int(rng.integers(len(b.ladders)))]
+                    r = (tmpl[:readlen // 2] + other[0] + other[1].replace("N", "A") * 4 + other[2])[:readlen]
+                elif kind == 3:
+                    r = "".join("ACGT"[i] for i in rng.integers(0, 4, readlen))
+                elif kind == 4:
+                    cut = int(rng.integers(1, readlen))
+                    r = (tmpl * 3)[:cut] + "N" * (readlen - cut)
+                elif kind == 5:
+                    r = (rep_c * u)[:readlen // 2] + "ACGT"[int(rng.integers(4))] + (rep_c * (mu + 2))[:readlen // 2]
+                else:
+                    r = "N" * int(rng.integers(1, readlen + 1))
+                if rng.random() < 0.5:
+                    r = po.rc(r)
+                if r:
+                    extra.append(r[:readlen])
+            reads += extra
+            uro.append(len(reads))
+            ulad.append(lad)
+        n = len(reads)
+        unit_read_off, unit_ladder = np.asarray(uro, np.int32), np.asarray(ulad, np.int32)
         clip = bool(rng.random() < 0.3)
         scoring = [(1, 5, 7, 2)] * 3 + [(2, 3, 5, 2), (1, 4, 6, 1), (1, 1, 2, 1), (3, 5, 7, 2), (1, 9, 12, 3)]
         scoring = scoring[int(rng.integers(len(scoring)))]
@@ -52,34 +89,35 @@ def main():
             reads = [r[int(rng.integers(0, max(1, len(r) // 3))):] for r in reads]
         packed, woff, rlen = _lib.pack_reads(reads)
         tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
-        ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, b.unit_read_off, b.unit_ladder, b.n_units,
+        ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, unit_read_off, unit_ladder, len(unit_ladder),
                         _lib.SwParams(scoring[0], scoring[1], scoring[2], scoring[3], 9, int(clip), readlen, 0), tag, h, sc)
-        cls = po.ref_classify(reads, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), po.LocusSet(b.ladders), clip=clip,
+        cls = po.ref_classify(reads, np.repeat(unit_ladder, np.diff(unit_read_off)), po.LocusSet(b.ladders), clip=clip,
                               scoring=scoring, threads=0)
         bad = np.nonzero((tag != cls[:, 0]) | (h != cls[:, 1]) | (sc != cls[:, 2]))[0]
         n_reads += n
         n_bad += len(bad)
         # per-template results (score, ref_begin, ref_end, read_begin, read_end) of the first units, dump path
-        gsub = 1
-        while gsub < b.n_units and b.unit_read_off[gsub] < 120:
-            gsub += 1
-        m = int(b.unit_read_off[gsub])
+        # (the adversarial units at the end of the batch)
+        g0 = len(unit_ladder) - 4
+        r0 = int(unit_read_off[g0])
+        sub_reads = reads[r0:]
+        m = len(sub_reads)
         if m:
             ls = po.LocusSet(b.ladders)
             nt = max(2 * l[3] for l in b.ladders)
             dump = np.zeros((m, nt, 6), np.int16)
-            packed2, woff2, rlen2 = _lib.pack_reads(reads[:m])
+            packed2, woff2, rlen2 = _lib.pack_reads(sub_reads)
+            sub_off = (unit_read_off[g0:] - r0).astype(np.int32)
             t2 = np.zeros(m, np.uint8); h2 = np.zeros(m, np.int16); s2 = np.zeros(m, np.int16)
-            ctx.sw_classify(_lib.MEM_HOST, packed2, woff2, rlen2, m, b.unit_read_off[:gsub + 1].copy(),
-                            b.unit_ladder[:gsub].copy(), gsub,
+            ctx.sw_classify(_lib.MEM_HOST, packed2, woff2, rlen2, m, sub_off, unit_ladder[g0:].copy(), 4,
                             _lib.SwParams(scoring[0], scoring[1], scoring[2], scoring[3], 9, int(clip), readlen, 0),
                             t2, h2, s2, dump, nt)
             pr, pt, where = [], [], []
             for r in range(m):
-                lad = int(b.unit_ladder[np.searchsorted(b.unit_read_off, r, side="right") - 1])
+                lad = int(unit_ladder[g0 + np.searchsorted(sub_off, r, side="right") - 1])
                 for j, t in enumerate(range(ls.lad_off[lad], ls.lad_off[lad + 1])):
                     pr.append(r); pt.append(t); where.append((r, j))
-            want = po.ref_sw_pairs(reads[:m], ls.templates, pr, pt, scoring=scoring, threads=0)
+            want = po.ref_sw_pairs(sub_reads, ls.templates, pr, pt, scoring=scoring, threads=0)
             got = np.array([dump[r, j, :5] for r, j in where], np.int32)
             nb = int((got != want).any(axis=1).sum())
             n_pairs += len(pr)
@@ -87,7 +125,7 @@ def main():
             if nb:
                 kk = int(np.nonzero((got != want).any(axis=1))[0][0])
                 print("PAIR MISMATCH round", k, "readlen", readlen, "scoring", scoring, where[kk], got[kk], want[kk], file=sys.stderr)
-            if not (np.array_equal(t2, tag[:m]) and np.array_equal(h2, h[:m]) and np.array_equal(s2, sc[:m])):
+            if not (np.array_equal(t2, tag[r0:]) and np.array_equal(h2, h[r0:]) and np.array_equal(s2, sc[r0:])):
                 n_bad += 1
                 print("DUMP/NON-DUMP PATH DISAGREE round", k, file=sys.stderr)
         tags += np.bincount(tag, minlength=6)[:6]
