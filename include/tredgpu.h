@@ -201,6 +201,25 @@ int tredgpu_likelihood_grid(tredgpu_ctx* ctx, int mem, const tredgpu_unit_params
                             double* marg, int32_t marg_stride);
 
 /*
+ * tredgpu_likelihood_grid plus the sparse joint distribution the reference reports as P_h1h2
+ * (models.py:279-285: P[(h1,h2)] = exp(ml - max); sparsify, :304-317: total = sum over the dict, keep v >= e^-10,
+ * print v / total): per unit the triples {h1, h2, exp(ml - max)} of the distinct (h1,h2) pairs with
+ * exp(ml - max) >= e^-10, in no particular order, and the sum over ALL distinct pairs.
+ *   joint_off[n_units+1] (int64): caller-chosen capacities, in triples; joint[3 * joint_off[n_units]] doubles
+ *   joint_n[n_units]: qualifying pairs of the unit -- when it exceeds the unit's capacity only the first
+ *   `capacity` found were stored (ask again with more room, or use the grid dump)
+ *   joint_total[n_units]: the normaliser
+ * Saves the dense grid dump (48 bytes per pair) for callers that only format the JSON.
+ */
+int tredgpu_likelihood_grid_joint(tredgpu_ctx* ctx, int mem, const tredgpu_unit_params* units,
+                                  int32_t n_units, int32_t hist_stride, const int32_t* full_cnt,
+                                  const int32_t* pref_cnt, const int32_t* rept_cnt,
+                                  const int32_t* global_lens, int64_t n_global_total,
+                                  const int32_t* target_lens, int64_t n_target_total,
+                                  tredgpu_call* calls, double* marg, int32_t marg_stride,
+                                  const int64_t* joint_off, double* joint, int32_t* joint_n, double* joint_total);
+
+/*
  * The fused path: SW + tagging -> histograms -> grid for a whole batch, nothing leaves the GPU
  * in between.  Arguments are the union of the three calls above; histograms are written to the
  * caller's buffers as well (they are the FR/PR/RR strings of the JSON, tred.py:254-256).

@@ -228,3 +228,32 @@ def test_many_spanning_pairs_and_haploid_paired_end(ctx):
         assert np.abs(got[:, 2:] - exp[:, 2:]).max() <= ML_TOL, c["name"]
         assert (call["h1"], call["h2"]) == tuple(w["alleles"]) and tuple(call["ci"]) == tuple(w["CI"]), c["name"]
         assert abs(call["lik"] - w["lik"]) <= ML_TOL
+
+
+def test_sparse_joint_matches_dense_dump(ctx):
+    """tredgpu_likelihood_grid_joint: the triples {h1, h2, exp(ml - max)} >= e^-10 and the normaliser against the
+    reference's P_h1h2 of the golden cases (and against the dense dump route), incl. a capacity that is too small."""
+    _set_model(ctx)
+    cases = [c for c in CASES if not c["expected"]["raised"] and c["expected"]["alleles"] != [-1, -1]]
+    hs = 128
+    units, full, pref, rept, gl, tl = _case_inputs(cases, hs)
+    n = len(cases)
+    for cap_each in (4096, 2):
+        joff = np.arange(n + 1, dtype=np.int64) * cap_each
+        trip = np.zeros((int(joff[-1]), 3), np.float64)
+        jn = np.zeros(n, np.int32); jt = np.zeros(n, np.float64)
+        calls = np.zeros(n, _lib.CALL_DTYPE)
+        ctx.likelihood_grid_joint(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls, None, 0,
+                                  joff, trip, jn, jt)
+        assert (calls["status"] == 0).all()
+        for i, c in enumerate(cases):
+            want = c["expected"]["P_h1h2"]
+            period = len(c["locus_rec"]["repeat"])
+            assert jn[i] == len(want), (c["name"], jn[i], len(want))          # count is reported even when truncated
+            got = trip[joff[i]:joff[i] + min(jn[i], cap_each)]
+            assert len(set((int(a), int(b)) for a, b, _ in got)) == len(got)  # distinct pairs
+            for h1, h2, v in got:
+                key = "{},{}".format(int(h1) // period, int(h2) // period)
+                assert key in want and abs(v / jt[i] - want[key]) <= 1e-9, (c["name"], key)
+            if cap_each >= jn[i]:
+                assert len(got) == len(want)

@@ -54,7 +54,8 @@ assert CALL_DTYPE.itemsize == C.sizeof(Call) == 56
 # every symbol include/tredgpu.h declares (tests check the .so exports them all)
 EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_sync", "tredgpu_get_stream",
            "tredgpu_version", "tredgpu_set_ladders", "tredgpu_set_model", "tredgpu_pack_reads",
-           "tredgpu_sw_classify", "tredgpu_tally", "tredgpu_likelihood_grid", "tredgpu_genotype_batch",
+           "tredgpu_sw_classify", "tredgpu_tally", "tredgpu_likelihood_grid", "tredgpu_likelihood_grid_joint",
+           "tredgpu_genotype_batch",
            "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing", "tredgpu_get_sw_counters")
 
 _lib = None
@@ -89,6 +90,8 @@ def load():
     lib.tredgpu_tally.argtypes = [vp, C.c_int, vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]
     lib.tredgpu_likelihood_grid.argtypes = [vp, C.c_int, vp, i32, i32, vp, vp, vp, vp, i64, vp, i64, vp,
                                             vp, vp, vp, i32]
+    lib.tredgpu_likelihood_grid_joint.argtypes = [vp, C.c_int, vp, i32, i32, vp, vp, vp, vp, i64, vp, i64, vp,
+                                                  vp, i32, vp, vp, vp, vp]
     lib.tredgpu_genotype_batch.argtypes = [vp, C.c_int, vp, vp, vp, i64, vp, vp, vp, i32,
                                            C.POINTER(SwParams), vp, vp, i64, vp, i64, vp, vp, vp, i32,
                                            vp, vp, vp, vp]
@@ -233,6 +236,16 @@ class Context:
                                                    n_target_total, _ptr(calls), _ptr(grid_off),
                                                    _ptr(grid_dump), _ptr(marg), marg_stride),
                   "tredgpu_likelihood_grid")
+
+    def likelihood_grid_joint(self, mem, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens,
+                              n_global_total, target_lens, n_target_total, calls, marg, marg_stride, joint_off, joint,
+                              joint_n, joint_total):
+        self._chk(self.lib.tredgpu_likelihood_grid_joint(self.h, mem, _ptr(units), n_units, hist_stride,
+                                                         _ptr(full_cnt), _ptr(pref_cnt), _ptr(rept_cnt),
+                                                         _ptr(global_lens), n_global_total, _ptr(target_lens),
+                                                         n_target_total, _ptr(calls), _ptr(marg), marg_stride,
+                                                         _ptr(joint_off), _ptr(joint), _ptr(joint_n), _ptr(joint_total)),
+                  "tredgpu_likelihood_grid_joint")
 
     def genotype_batch(self, mem, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, units,
                        n_units, params, read_pair_id, global_lens, n_global_total, target_lens,

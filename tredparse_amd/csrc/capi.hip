@@ -597,7 +597,9 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
                            const int32_t* full_cnt, const int32_t* pref_cnt, const int32_t* rept_cnt,
                            const int32_t* global_lens, const int32_t* target_lens, tredgpu_call* calls,
                            const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride,
-                           const int* limits /* {max maxinsert, max n_target}; NULL: ask the device */) {
+                           const int* limits /* {max maxinsert, max n_target}; NULL: ask the device */,
+                           const int64_t* joint_off = nullptr, double* joint = nullptr, int32_t* joint_n = nullptr,
+                           double* joint_total = nullptr) {
     if (n_units == 0) return 0;
     int rc;
     int lim[2];
@@ -632,6 +634,10 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     a.marg = marg;
     a.marg_stride = marg_stride;
     a.model = (const ModelConst*)c->d_model.p;
+    a.joint_off = joint_off;
+    a.joint = joint;
+    a.joint_n = joint_n;
+    a.joint_total = joint_total;
     a.kde_pdf = nullptr;
     a.kde_status = nullptr;
     {
@@ -650,22 +656,25 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     return 0;
 }
 
-int tredgpu_likelihood_grid(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, int32_t n_units,
+static int likelihood_grid_impl(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, int32_t n_units,
                             int32_t hist_stride, const int32_t* full_cnt, const int32_t* pref_cnt,
                             const int32_t* rept_cnt, const int32_t* global_lens, int64_t n_global_total,
                             const int32_t* target_lens, int64_t n_target_total, tredgpu_call* calls,
-                            const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride) {
+                            const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride,
+                            const int64_t* joint_off, double* joint, int32_t* joint_n, double* joint_total) {
     if (!c) return -2;
     int rc;
     if ((rc = check_grid_common(c, units, n_units))) return rc;
     if (hist_stride <= 0) return fail(c, -2, "hist_stride must be > 0");
     if (n_units > 0 && (!full_cnt || !pref_cnt || !rept_cnt || !calls)) return fail(c, -2, "NULL array argument");
     if ((grid_off == nullptr) != (grid_dump == nullptr)) return fail(c, -2, "grid_off and grid_dump go together");
+    if (joint_off && (!joint || !joint_n || !joint_total)) return fail(c, -2, "joint_off, joint, joint_n and joint_total go together");
     if (marg && marg_stride <= 0) return fail(c, -2, "marg_stride must be > 0");
     HIPCHK(c, hipSetDevice(c->device));
     if (mem == TREDGPU_MEM_DEVICE)
         return run_grid_device(c, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens, target_lens,
-                               calls, grid_off, grid_dump, marg, marg_stride, nullptr);
+                               calls, grid_off, grid_dump, marg, marg_stride, nullptr, joint_off, joint, joint_n,
+                               joint_total);
     if (mem != TREDGPU_MEM_HOST) return fail(c, -2, "bad mem");
     if (n_units == 0) return 0;
     int limits[2] = {0, 0};
@@ -698,14 +707,48 @@ int tredgpu_likelihood_grid(tredgpu_ctx* c, int mem, const tredgpu_unit_params* 
     }
     const size_t marg_n = marg ? (size_t)n_units * 2 * marg_stride : 0;
     if (marg && (rc = stage_out(c, c->st[9], marg_n, &d_marg))) return rc;
+    const int64_t* d_joff = nullptr; double* d_joint = nullptr; int32_t* d_jn = nullptr; double* d_jt = nullptr;
+    size_t joint_len = 0;
+    if (joint_off) {
+        joint_len = (size_t)joint_off[n_units] * 3;
+        if ((rc = stage_in(c, c->st[10], joint_off, (size_t)n_units + 1, &d_joff))) return rc;
+        if ((rc = stage_out(c, c->st[11], joint_len, &d_joint))) return rc;
+        if ((rc = stage_out(c, c->st[12], (size_t)n_units, &d_jn))) return rc;
+        if ((rc = stage_out(c, c->st[13], (size_t)n_units, &d_jt))) return rc;
+    }
     if ((rc = run_grid_device(c, d_units, n_units, hist_stride, d_f, d_p, d_r, d_gl, d_tl, d_calls, d_goff, d_dump,
-                              d_marg, marg_stride, limits)))
+                              d_marg, marg_stride, limits, d_joff, d_joint, d_jn, d_jt)))
         return rc;
+    if ((rc = copy_back(c, joint, (const double*)d_joint, joint_len))) return rc;
+    if ((rc = copy_back(c, joint_n, (const int32_t*)d_jn, joint_off ? (size_t)n_units : 0))) return rc;
+    if ((rc = copy_back(c, joint_total, (const double*)d_jt, joint_off ? (size_t)n_units : 0))) return rc;
     if ((rc = copy_back(c, calls, (const tredgpu_call*)d_calls, (size_t)n_units))) return rc;
     if ((rc = copy_back(c, grid_dump, (const double*)d_dump, dump_n))) return rc;
     if ((rc = copy_back(c, marg, (const double*)d_marg, marg_n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+int tredgpu_likelihood_grid(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, int32_t n_units,
+                            int32_t hist_stride, const int32_t* full_cnt, const int32_t* pref_cnt,
+                            const int32_t* rept_cnt, const int32_t* global_lens, int64_t n_global_total,
+                            const int32_t* target_lens, int64_t n_target_total, tredgpu_call* calls,
+                            const int64_t* grid_off, double* grid_dump, double* marg, int32_t marg_stride) {
+    return likelihood_grid_impl(c, mem, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens,
+                                n_global_total, target_lens, n_target_total, calls, grid_off, grid_dump, marg,
+                                marg_stride, nullptr, nullptr, nullptr, nullptr);
+}
+
+int tredgpu_likelihood_grid_joint(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, int32_t n_units,
+                                  int32_t hist_stride, const int32_t* full_cnt, const int32_t* pref_cnt,
+                                  const int32_t* rept_cnt, const int32_t* global_lens, int64_t n_global_total,
+                                  const int32_t* target_lens, int64_t n_target_total, tredgpu_call* calls,
+                                  double* marg, int32_t marg_stride, const int64_t* joint_off, double* joint,
+                                  int32_t* joint_n, double* joint_total) {
+    if (c && !joint_off) return fail(c, -2, "joint_off is NULL");
+    return likelihood_grid_impl(c, mem, units, n_units, hist_stride, full_cnt, pref_cnt, rept_cnt, global_lens,
+                                n_global_total, target_lens, n_target_total, calls, nullptr, nullptr, marg,
+                                marg_stride, joint_off, joint, joint_n, joint_total);
 }
 
 int tredgpu_pe_kde(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, int32_t n_units,

@@ -891,6 +891,7 @@ struct ReduceShared {
     double red[NR / 64];
     Best bred[NR / 64];
     int lo[2], brk[2], lastnz[2];
+    int jn;      // sparse joint entries found so far
     int unit;
 };
 
@@ -904,6 +905,7 @@ __device__ double block_sum_r(double v, double* red) {
     return t;
 }
 
+template <bool JOINT>   // JOINT: also the sparse joint distribution (tredgpu_likelihood_grid_joint)
 __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const UnitDesc* descs, double* pool,
                                                          const Best* item_best, GridCounters* ctr) {
     __shared__ ReduceShared S;
@@ -922,7 +924,10 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
         call.ci[0] = call.ci[1] = call.ci[2] = call.ci[3] = 0;
         call.run_pe = d.run_pe; call.pad = 0; call.lik = -1; call.pp = -1;
         if (d.status != 0) {
-            if (tid == 0) a.calls[g] = call;
+            if (tid == 0) {
+                a.calls[g] = call;
+                if (JOINT) { a.joint_n[g] = 0; a.joint_total[g] = 0; }
+            }
             if (a.marg != nullptr)
                 for (int m = tid; m < 2 * a.marg_stride; m += NR) a.marg[(size_t)g * 2 * a.marg_stride + m] = 0;
             continue;
@@ -949,6 +954,7 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
         const int mlim = min(MAXM, d.hmaxv / period + 1);
         for (int m = tid; m < mlim; m += NR) { S.ph1[m] = 0; S.ph2[m] = 0; }
         if (tid < 2) { S.lo[tid] = MAXM; S.brk[tid] = MAXM; S.lastnz[tid] = 0; }
+        if (tid == 0) S.jn = 0;
         __syncthreads();
         Best top = S.bred[0];
         for (int w = 1; w < NR / 64; ++w) if (better(S.bred[w], top)) top = S.bred[w];
@@ -960,7 +966,10 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
         //      diagonal were never written and count as 0.
         const int lane = tid & 63, wv = tid >> 6;
         const int nk = (ncol + 63) >> 6;
-        double all = 0, path = 0;
+        double all = 0, path = 0, uniq = 0;
+        constexpr bool want_joint = JOINT;
+        const double small = a.model->small;
+        const int jcap = want_joint ? (int)min((long long)(a.joint_off[g + 1] - a.joint_off[g]), 0x7fffffffLL) : 0;
         // KC = column chunks a lane owns per sweep (4 for grids up to 256 columns wide, else 8; wider grids
         // take a second sweep over the rows for chunks 8..15), k0 = first chunk of the sweep
         auto sweep = [&](auto kc_tag, const int k0) {
@@ -975,12 +984,26 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
                 const int hi = h2k[k] / period;
                 if (by_col && h2k[k] >= 0 && (d.is_expansion ? hi >= d.cutoff_risk : hi <= d.cutoff_risk)) colpath |= 1u << k;
             }
+            // sparse joint distribution: the extended axes can list a value twice (models.py:251-252); the pairs of
+            // the second occurrence repeat those of the first and the reference's dict keeps one of them
+            unsigned coldup = 0;
+            if (want_joint && d.ploidy != 1) {
+    #pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const int j = lane + 64 * (k0 + k);
+                    if (h2k[k] >= 0 && j >= d.ax2.nb)
+                        for (int q = 0; q < d.ax2.nb; ++q) if (obs->base[q] == h2k[k]) coldup |= 1u << k;
+                }
+            }
             double colacc[KC];
     #pragma unroll
             for (int k = 0; k < KC; ++k) colacc[k] = 0;
             for (int i = wv; i < nrow; i += NR / 64) {
                 const int h1 = axis_value(d.ax1, obs->base, period, i);
                 const int lo = h1 / period;
+                bool rowdup = false;
+                if (want_joint && i >= d.ax1.nb)
+                    for (int q = 0; q < d.ax1.nb; ++q) rowdup |= obs->base[q] == h1;
                 // ploidy 1: h2 = h1, one column; both alleles equal, so lo decides whatever the inheritance
                 const bool rowpath = !by_col && (d.is_expansion ? lo >= d.cutoff_risk : lo <= d.cutoff_risk);
                 double v[KC];
@@ -998,6 +1021,18 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
                     acc += e;
                     colacc[k] += e;
                     if (rowpath || ((colpath >> k) & 1u)) path += e;
+                    if (want_joint && ok && !rowdup && !((coldup >> k) & 1u)) {
+                        uniq += e;
+                        if (e >= small) {
+                            const int at = atomicAdd(&S.jn, 1);
+                            if (at < jcap) {
+                                double* o = a.joint + (a.joint_off[g] + at) * 3;
+                                o[0] = h1;
+                                o[1] = d.ploidy == 1 ? h1 : h2k[k];
+                                o[2] = e;
+                            }
+                        }
+                    }
                 }
                 all += acc;
                 acc = wave_sum(acc);
@@ -1040,6 +1075,10 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
         }
         all = block_sum_r(all, S.red);
         path = block_sum_r(path, S.red);   // (its barriers also publish the row sums and S.ph2)
+        if (want_joint) {
+            uniq = block_sum_r(uniq, S.red);
+            if (tid == 0) { a.joint_n[g] = S.jn; a.joint_total[g] = uniq; }
+        }
         if (tid == 0) {
             for (int i = 0; i < nrow; ++i) {   // rows merged by key in row order
                 const int m = axis_value(d.ax1, obs->base, period, i) / period;
@@ -1159,7 +1198,8 @@ hipError_t launch_grid_pass(const GridArgs& a, int pass, void* descs, double* po
                                           ctr);
     grid_pairs_kernel<<<2048, 256, 0, s>>>(a, d, pool, item_unit, item_best, ctr);
     const int rb = a.n_units < 2048 ? a.n_units : 2048;
-    grid_reduce_kernel<<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
+    if (a.joint != nullptr) grid_reduce_kernel<true><<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
+    else grid_reduce_kernel<false><<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
     return hipGetLastError();
 }
 

@@ -90,6 +90,10 @@ struct GridArgs {
     double* marg;
     int32_t marg_stride;
     const ModelConst* model;
+    const int64_t* joint_off;   // sparse joint distribution (optional): capacities, in triples
+    double* joint;              // {h1, h2, exp(ml - max)} per kept pair
+    int32_t* joint_n;           // qualifying pairs per unit
+    double* joint_total;        // sum over the unit's distinct pairs
     double* kde_pdf;      // tredgpu_pe_kde only: [n_units][1000] output
     int32_t* kde_status;  // tredgpu_pe_kde only: [n_units]
 };

@@ -47,8 +47,13 @@ class Unit(object):
         self.minpe = tred.repeat_end - tred.repeat_start + 2 * 9 + 2   # bam_parser.py:361
 
 
+JOINT_CAP = 512   # sparse joint entries per unit asked for first (pairs with exp(ml - max) >= e^-10)
+
+
 class UnitResult(object):
-    __slots__ = ("tags", "hs", "scores", "full", "pref", "rept_hist", "rept", "call", "grid", "P_h1", "P_h2")
+    """grid: the dense dump {h1, h2, ml1..ml4} per pair (only when asked for); joint: (triples {h1, h2, exp(ml - max)}
+    of the pairs >= e^-10, total over all distinct pairs) -- what P_h1h2 is printed from."""
+    __slots__ = ("tags", "hs", "scores", "full", "pref", "rept_hist", "rept", "call", "grid", "joint", "P_h1", "P_h2")
 
 
 class Engine(object):
@@ -112,7 +117,7 @@ class Engine(object):
                                                   else -np.ones(len(u.reads)), np.int32) for u in units])
         self.ctx.tally(_lib.MEM_HOST, tag if n else np.zeros(1, np.uint8), h if n else np.zeros(1, np.int16), n, uro,
                        g, pair_ids, hs, full, pref, rept)
-        calls, marg, dump, goff = self._grid(units, hs, full, pref, rept, want_grid)
+        calls, marg, dump, goff, joint = self._grid(units, hs, full, pref, rept, want_grid)
         out = []
         for i, u in enumerate(units):
             r = UnitResult()
@@ -122,12 +127,15 @@ class Engine(object):
             r.rept_hist = {int(k): int(v) for k, v in enumerate(rept[i]) if v}
             r.rept = int(rept[i].sum())
             r.call = calls[i]
-            r.grid = dump[goff[i]:goff[i] + calls[i]["n_pairs"]] if want_grid and calls[i]["status"] == 0 else None
+            r.grid = dump[goff[i]:goff[i] + calls[i]["n_pairs"]] if dump is not None and calls[i]["status"] == 0 else None
+            r.joint = joint[i] if joint is not None and calls[i]["status"] == 0 else None
             r.P_h1, r.P_h2 = marg[i, 0], marg[i, 1]
             out.append(r)
         return out
 
-    def _grid(self, units, hs, full, pref, rept, want_grid):
+    def _grid(self, units, hs, full, pref, rept, want_grid, dense=False):
+        """One grid call for the batch.  want_grid: also the joint distribution -- sparse (triples + total per
+        unit, tredgpu_likelihood_grid_joint) unless dense=True asks for the full dump of every pair."""
         g = len(units)
         up = np.zeros(g, _lib.UNIT_DTYPE)
         gl, tl = [], []
@@ -144,17 +152,32 @@ class Engine(object):
         calls = np.zeros(g, _lib.CALL_DTYPE)
         ms = max(max(u.maxinsert for u in units), hs) + 2
         marg = np.zeros((g, 2, ms), np.float64)
-        self.ctx.likelihood_grid(_lib.MEM_HOST, up, g, hs, full, pref, rept, gl, ngl, tl, ntl, calls, None, None,
-                                 marg, ms)
-        dump = goff = None
-        if want_grid:
+        dump = goff = joint = None
+        if want_grid and not dense:
+            cap = np.full(g, JOINT_CAP, np.int64)
+            while True:
+                joff = np.zeros(g + 1, np.int64)
+                joff[1:] = np.cumsum(cap)
+                trip = np.zeros((int(joff[-1]), 3), np.float64)
+                jn = np.zeros(g, np.int32)
+                jt = np.zeros(g, np.float64)
+                self.ctx.likelihood_grid_joint(_lib.MEM_HOST, up, g, hs, full, pref, rept, gl, ngl, tl, ntl, calls,
+                                               marg, ms, joff, trip, jn, jt)
+                if (jn <= cap).all():
+                    break
+                cap = np.maximum(cap, jn)     # a flat likelihood surface: ask again with room for every entry
+            joint = [(trip[joff[i]:joff[i] + jn[i]], float(jt[i])) for i in range(g)]
+        else:
+            self.ctx.likelihood_grid(_lib.MEM_HOST, up, g, hs, full, pref, rept, gl, ngl, tl, ntl, calls, None, None,
+                                     marg, ms)
+        if want_grid and dense:
             goff = np.zeros(g + 1, np.int64)
             goff[1:] = np.cumsum(np.maximum(calls["n_pairs"], 1))
             dump = np.zeros((int(goff[-1]), 6), np.float64)
             calls2 = np.zeros(g, _lib.CALL_DTYPE)
             self.ctx.likelihood_grid(_lib.MEM_HOST, up, g, hs, full, pref, rept, gl, ngl, tl, ntl, calls2, goff, dump,
                                      None, 0)
-        return calls, marg, dump, goff
+        return calls, marg, dump, goff, joint
 
     def grid_from_counts(self, unit, full, pref, rept):
         """Likelihood grid of one unit from explicit histograms {units: count} (IntegratedCaller.call)."""
@@ -168,11 +191,12 @@ class Engine(object):
         for k, v in pref.items():
             p[0, k] = v
         r[0, 0] = rept
-        calls, marg, dump, goff = self._grid([unit], hs, f, p, r, True)
+        calls, marg, dump, goff, _ = self._grid([unit], hs, f, p, r, True, dense=True)
         res = UnitResult()
         res.tags = res.hs = res.scores = None
         res.full, res.pref, res.rept_hist, res.rept = dict(full), dict(pref), {}, rept
         res.call = calls[0]
         res.grid = dump[goff[0]:goff[0] + calls[0]["n_pairs"]] if calls[0]["status"] == 0 else None
+        res.joint = None
         res.P_h1, res.P_h2 = marg[0, 0], marg[0, 1]
         return res

@@ -77,6 +77,12 @@ def sparsify_joint(grid, period, epsilon=SMALL_VALUE):
     return {"{},{}".format(h1 // period, h2 // period): v / total for (h1, h2), v in P.items() if v >= epsilon}
 
 
+def sparsify_joint_triples(triples, total, period):
+    """models.py:279-285 + 304-317 from the kernel's sparse joint output: triples {h1, h2, exp(ml - max)} of the
+    distinct pairs >= e^-10 and the sum over all distinct pairs."""
+    return {"{},{}".format(int(h1) // period, int(h2) // period): float(v) / total for h1, h2, v in triples}
+
+
 class IntegratedCaller:
     """Same constructor and result attributes as the reference's IntegratedCaller."""
 
@@ -125,7 +131,9 @@ class IntegratedCaller:
             self.CI = "{}-{}|{}-{}".format(*[int(x) for x in call["ci"]])
             self.P_h1 = sparsify_marginal(res.P_h1)
             self.P_h2 = sparsify_marginal(res.P_h2)
-            if res.grid is not None:
+            if getattr(res, "joint", None) is not None:
+                self.P_h1h2 = sparsify_joint_triples(res.joint[0], res.joint[1], self.period)
+            elif res.grid is not None:
                 self.P_h1h2 = sparsify_joint(res.grid, self.period)
         self.label = calc_label(self.tred, self.alleles)
 
