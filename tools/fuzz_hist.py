@@ -96,6 +96,13 @@ def main():
     calls = np.zeros(n, _lib.CALL_DTYPE)
     t0 = time.time()
     ctx.likelihood_grid(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls, goff, dump, None, 0)
+    # the sparse joint distribution (P_h1h2) through its own entry point
+    cap = np.array([max(len(w.get("P_h1h2", {})), 1) for w in want], np.int64)
+    joff = np.zeros(n + 1, np.int64); joff[1:] = np.cumsum(cap)
+    trip = np.zeros((int(joff[-1]), 3), np.float64); jn = np.zeros(n, np.int32); jt = np.zeros(n, np.float64)
+    calls_j = np.zeros(n, _lib.CALL_DTYPE)
+    ctx.likelihood_grid_joint(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls_j, None, 0,
+                              joff, trip, jn, jt)
     bad = singular = empty = 0
     worst = 0.0
     for i, (c, w) in enumerate(zip(cases, want)):
@@ -117,6 +124,13 @@ def main():
                 ok = (d <= 1e-6 and (call["h1"], call["h2"]) == tuple(w["alleles"]) and tuple(call["ci"]) == tuple(w["CI"])
                       and abs(call["lik"] - w["lik"]) <= 1e-6 and abs(call["pp"] - ppv) <= 1e-9
                       and bool(call["run_pe"]) == w["run_pe"])
+                if ok:   # joint: same kept pairs, same normalised values
+                    P = w["P_h1h2"]
+                    tot = sum(P.values())
+                    keep = {k: v / tot for k, v in P.items() if v >= lo.SMALL_VALUE}
+                    got_j = {(int(a), int(b)): v / jt[i] for a, b, v in trip[joff[i]:joff[i] + min(jn[i], cap[i])]}
+                    ok = (calls_j[i].tobytes() == call.tobytes() and jn[i] == len(keep) and set(got_j) == set(keep)
+                          and all(abs(got_j[k] - keep[k]) <= 1e-9 for k in keep))
         if not ok:
             bad += 1
             print("MISMATCH case", i, l["name"], {k: c[k] for k in ("readlen", "ploidy", "depth", "maxinsert", "fullsearch",
