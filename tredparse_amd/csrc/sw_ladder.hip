@@ -76,7 +76,8 @@ __device__ __forceinline__ void pair_step(int& k, int& s) {
 template <int R>
 struct Rows {
     int S[4][R];  // (score vs template letter 0..3) * K + 2*ge*K; PADNEG for padding rows
-    int rowc[R];  // i + i*ge*K: the row part of a fresh start in the scaled domain
+    int rowc0;    // i0 + i0*ge*K for the lane's first row i0: the row part of a fresh start in the scaled
+                  // domain; row r adds r*(1 + ge*K), folded into the wave-uniform column term (an SGPR per row)
 };
 
 struct Track {
@@ -118,7 +119,7 @@ __device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int 
         if (LET < 4) S = J.S[LET][r];
         else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;  // N column: 0 against every real row
         const int t1 = diag + S;                          // extend the alignment ending at (row-1, col-1)
-        const int t2 = add3_vsv(J.rowc[r], s_fresh, S);   // or start a new one here
+        const int t2 = add3_vsv(J.rowc0, s_fresh + r * (1 + geK), S);   // or start a new one here
         const int v = max3(t1, t2, E[r]);
         diag = H[r];
         ht[r] = v;
@@ -205,15 +206,119 @@ __device__ __forceinline__ int letter_from(int words_vgpr, int idx) {
     return (int)((w >> ((idx & 7) * 4)) & 7u);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Suffix continuation.  Every template prefix + repeat*u + suffix ends with the same |suffix| columns, so what
+// an alignment can still gain after leaving the trunk at read row i does not depend on u.  One reversed
+// alignment of the read against the reversed suffix (once per read and strand, |suffix| columns) yields, for
+// every row, the weight and the end cell of the best continuation
+//     WH[i]: the alignment leaves trunk cell (i, c) by a match at (i+1, c+1)
+//     WE[i]: it leaves inside a horizontal gap (trunk E[i][c+1], next match in row i+1)
+// and a template's result is max(trunk best, max_i H[i][c] + WH[i], max_i E[i][c+1] + WE[i], best alignment
+// inside the suffix alone) -- about one column's worth of work per template instead of |suffix| columns.
+// Packing makes the tie rules carry over: the reversed alignment's "start" payload (largest reversed column,
+// largest reversed row) is the forward end cell with the smallest column, then the smallest row; the start
+// coordinates travel in the trunk values' payload.  The reversed pass uses the unrestricted recurrences (E fed
+// from H including the vertical-gap term) and the junction admits H - go: every Gotoh path then has an
+// equal-score representative that is restricted (no vertical-then-horizontal gap) on the trunk side only.
+// tools/proto_continuation.py checks the formulation against the CPU oracle in plain integers.
+constexpr int NEGH = -(1 << 29);
+
+template <int R, int LET>
+__device__ __forceinline__ void sweep_column_free(const Rows<R>& J, int (&H)[R], int (&E)[R], int s_fresh,
+                                                  int geK, int c0) {
+    const int hup = dpp_row_shr<0x111>(NEG, H[R - 1]);
+    int ht[R], pl[R];
+    int diag = hup;
+    int run = NEG;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int S;
+        if (LET < 4) S = J.S[LET][r];
+        else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;
+        const int t1 = diag + S;
+        const int t2 = add3_vsv(J.rowc0, s_fresh + r * (1 + geK), S);
+        const int v = max3(t1, t2, E[r]);
+        diag = H[r];
+        ht[r] = v;
+        pl[r] = run;
+        run = max(run, v - c0);
+    }
+    const int fin = row_excl_scan_max(run);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        H[r] = max3(ht[r], pl[r], fin);
+        E[r] = max(E[r], H[r] - c0);   // unrestricted: a horizontal gap may follow a vertical one
+    }
+}
+
+// last reversed column: only the cells entered by a match (or started there) are needed
+template <int R, int LET>
+__device__ __forceinline__ void match_column(const Rows<R>& J, const int (&H)[R], int (&D)[R], int s_fresh, int geK) {
+    int diag = dpp_row_shr<0x111>(NEG, H[R - 1]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int S;
+        if (LET < 4) S = J.S[LET][r];
+        else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;
+        D[r] = max(diag + S, add3_vsv(J.rowc0, s_fresh + r * (1 + geK), S));
+        diag = H[r];
+    }
+}
+
+__device__ __forceinline__ int row_mirror(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false); }
+
+// reversed position x of this lane's register r  ->  forward row (i + 1) = 16R - 1 - x: the vector indexed by
+// forward row i is the mirrored one moved up by one row (NEGH for the last row: nothing left to match)
+template <int R>
+__device__ __forceinline__ void mirror_up(const int (&X)[R], int add, int* out, int stride) {
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) out[r * stride] = max(row_mirror(X[R - 2 - r]) + add, NEGH);
+    const int m0 = row_mirror(X[R - 1]);
+    const int nx = __builtin_amdgcn_update_dpp(NEGH, m0, 0x101, 0xF, 0xF, false);  // row_shl:1
+    out[(R - 1) * stride] = max(nx + add, NEGH);
+}
+
+template <int CTRL>
+__device__ __forceinline__ void pair_step_lex(int& k, int& s) {
+    const int tk = dpp_row_shr<CTRL>(k, k);
+    const int ts = dpp_row_shr<CTRL>(s, s);
+    const bool c = tk > k || (tk == k && ts > s);
+    k = c ? tk : k;
+    s = c ? ts : s;
+}
+
+// Match/mismatch profile of this lane's R rows.  reversed: position x of the lane layout holds read row
+// 16R-1-x (padding first), the layout of the continuation pass.
+template <int R>
+__device__ __forceinline__ void build_profile(Rows<R>& J, const SwArgs& a, int64_t off, int L, int row0, bool reversed,
+                                              int mK, int xK, int geK) {
+    // (the profile is the same for both strands; the empty asm keeps the compiler from hoisting it out of the
+    //  strand loop, where the forward and the reversed one would be live together: 2 x 4R registers)
+    asm volatile("" : "+v"(L));
+    const int nb = (L + 15) >> 4;
+    J.rowc0 = row0 + row0 * geK;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = reversed ? 16 * R - 1 - (row0 + r) : row0 + r;
+        int code = 5;  // padding
+        if (i < L) {
+            const uint32_t w = a.packed[off + (i >> 4)];
+            const uint32_t m = a.packed[off + nb + (i >> 5)];
+            code = ((m >> (i & 31)) & 1u) ? 4 : (int)((w >> ((i & 15) * 2)) & 3u);
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            J.S[l][r] = code == 5 ? PADNEG : (code == 4 ? 0 : (code == l ? mK : xK)) + 2 * geK;
+    }
+}
+
 template <int R, int W>
-__global__ __launch_bounds__(64, W) void sw_ladder_kernel(SwArgs a) {
+__global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     // One wavefront per workgroup: quads differ a lot in length (pruning), and a wave slot freed by a short
-    // quad is only refilled when a whole new workgroup fits -- with four quads per workgroup a quarter of the
-    // wave slots sat idle (80 -> 71.5 ms per launch).
-    // trunk state parked while a branch is swept: [2R+3][64] ints, one column per thread (conflict-free)
+    // quad is only refilled when a whole new workgroup fits.
+    // continuation vectors of the strand being swept: [WH rows | WE rows | suffix-only best: key, start][64 lanes]
     constexpr int PS = 64;
-    __shared__ int park[(2 * R + 3) * PS];
-    int* const mypark = park + threadIdx.x;
+    __shared__ int wbuf[(2 * R + 2) * PS];
     const int lane = threadIdx.x;
     const int64_t q = (int64_t)blockIdx.x;
     const int nq = *a.n_quads;
@@ -229,54 +334,52 @@ __global__ __launch_bounds__(64, W) void sw_ladder_kernel(SwArgs a) {
 
     const int job = lane >> 4, jl = lane & 15;
     const bool valid = job < q_count;
-    const int64_t rd = valid ? (int64_t)a.perm[q_first + job] : 0;
-    int L = valid ? a.read_len[rd] : 0;
-    const bool too_long = L > 16 * R;  // not representable in this instantiation: flagged, not aligned
-    if (too_long) L = 0;
-    const int64_t off = valid ? a.read_off[rd] : 0;
-    const int row0 = jl * R;
-
+    int L, row0;
+    int64_t off;
+    bool too_long;
+    {
+        const int64_t rd = valid ? (int64_t)a.perm[q_first + job] : 0;
+        L = valid ? a.read_len[rd] : 0;
+        too_long = L > 16 * R;  // not representable in this instantiation: flagged, not aligned
+        if (too_long) L = 0;
+        off = valid ? a.read_off[rd] : 0;
+        row0 = jl * R;
+    }
     const int mK = a.p.match * KONE;
     const int xK = -a.p.mismatch * KONE;
     const int geK = a.p.gap_extend * KONE;
     const int c0 = (a.p.gap_open - a.p.gap_extend) * KONE;
-    const int row0g = row0 * geK;
     const int flank = a.p.flank;
+    const bool full_dump = a.out_dump != nullptr;  // wave-uniform
+    int* const wb = wbuf + lane;
 
-    Rows<R> J;
-    uint32_t pk = 0, nk = 0;  // this lane's rows: 2-bit codes / N-or-padding flags (for the 6-mer filter)
-    {
+    // this lane's rows as 2-bit codes / N-or-padding flags, for the 6-mer filter
+    uint32_t pk = 0, nk = 0;
+    if (2 * R + 10 <= 32) {
         const int nb = (L + 15) >> 4;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = row0 + r;
-            J.rowc[r] = i + i * geK;
-            int code = 5;  // padding
+            int code = 5;
             if (i < L) {
                 const uint32_t w = a.packed[off + (i >> 4)];
                 const uint32_t m = a.packed[off + nb + (i >> 5)];
                 code = ((m >> (i & 31)) & 1u) ? 4 : (int)((w >> ((i & 15) * 2)) & 3u);
             }
-            if (2 * R + 10 <= 32) {
-                pk |= (uint32_t)(code & 3) << (2 * r);
-                nk |= (uint32_t)(code > 3) << r;
-            }
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-                J.S[l][r] = code == 5 ? PADNEG : (code == 4 ? 0 : (code == l ? mK : xK)) + 2 * geK;
+            pk |= (uint32_t)(code & 3) << (2 * r);
+            nk |= (uint32_t)(code > 3) << r;
         }
     }
     // REPT cut-off: per-read ceil(L/period) with --useclippedreads, else the ladder's (bam_parser.py:154-155)
     const int mu_rept = a.p.clip ? (L + period - 1) / period : max_units;
 
-    int bestS = -1, bestU = 0, bestTag = TREDGPU_TAG_NONE;
-    int n_trunk_cols = 0, n_branch_cols = 0, n_swept = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
-    int16_t* dump = nullptr;
-    if (a.out_dump != nullptr && valid) dump = a.out_dump + rd * (int64_t)a.dump_templates * 6;
+    // arg-max so far, one word: (score << 9 | 511 - units) << 3 | tag; -1 = nothing yet.  A candidate must beat
+    // it on (score, -units): max(res, key=(score, -units)), first maximal element in db order (bam_parser.py:174)
+    int best = -1;
+    int n_trunk_cols = 0, n_combined = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
 
     // Only cells that can survive the score filter are tracked: min_score >= 30 (bam_parser.py:134), so a
     // floor of 29 is exact for tagging; the per-template dump (parity/debug) tracks every positive score.
-    const bool full_dump = a.out_dump != nullptr;  // wave-uniform
     // 6-mer filter premise: every run break costs >= 5 matches
     const int kmer_thr = min(a.p.mismatch, a.p.gap_open) >= 5 * a.p.match ? (30 + a.p.match - 1) / a.p.match - 5 : 0;
     const int floor_key = (full_dump ? 0 : 29) << KSH | PAYMASK;
@@ -284,7 +387,6 @@ __global__ __launch_bounds__(64, W) void sw_ladder_kernel(SwArgs a) {
     for (int s = 0; s < n_strands; ++s) {
         if (!((q_strands >> s) & 1)) continue;
         const int trunk_w = __builtin_amdgcn_readfirstlane(ld->trunk_off[s]);
-        const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
         const int alen = __builtin_amdgcn_readfirstlane(ld->alen[s]);
         const int blen = __builtin_amdgcn_readfirstlane(ld->blen[s]);
         const int ncols = alen + period * max_units;
@@ -319,91 +421,143 @@ __global__ __launch_bounds__(64, W) void sw_ladder_kernel(SwArgs a) {
             kcap = (cnt + 5) * a.p.match;  // lane 15 of each read holds the read's total
             if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && cnt >= kmer_thr) == 0) continue;
         }
-        const int tw = lane < ((ncols + 7) >> 3) ? (int)a.seqw[trunk_w + lane] : 0;
-        const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
+        // No alignment scores more than cap; a template only matters if it passes the score filter and beats
+        // the read's arg-max so far, and at equal score the smaller unit count wins: once
+        // max(30, best score + 1) > cap for every read of the wave, the rest of this strand changes nothing.
+        const int cap = min(kcap, L * a.p.match);
+        if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && max(30, (best >> 12) + 1) <= cap) == 0) continue;
+
+        Rows<R> J;
         int H[R], E[R];
+        const bool has_suffix = max_units > 0 && blen > 0;
+        if (has_suffix) {
+            // ---- continuation vectors of this strand (see above) ----
+            build_profile<R>(J, a, off, L, row0, true, mK, xK, geK);
+            const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
+            const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
+            int D[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
-        Track T;
-        T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
-        int next_branch = max_units > 0 ? alen + period - 1 : alen - 1;
-        int u = max_units > 0 ? 1 : 0;
-        // One sweep site for trunk and branch columns: tc = next trunk column, bk_left = branch columns
-        // still to sweep for template u (state of the trunk parked in Hs/Es/Ts meanwhile).
-        int tc = 0, b_left = 0, b_col = 0, b_idx = 0, need_score = 0;
-        bool in_branch = false, parked = false;
-        while (tc < ncols || in_branch) {
-            int letter, col;
-            if (in_branch) { letter = letter_from(bw, b_idx); col = b_col; }
-            else { letter = letter_from(tw, tc); col = tc; }
-            sweep_letter<R>(letter, J, H, E, T, col, row0, geK, c0, row0g);
-            if (in_branch) ++n_branch_cols; else ++n_trunk_cols;
-            bool emit = false;
-            if (in_branch) {
-                ++b_idx; ++b_col; --b_left;
-                emit = b_left == 0;
-                if (!emit && !full_dump && (b_idx & 3) == 0) {
-                    // Early exit from a branch (exact): once, for every read of the wave, no remaining
-                    // column can either raise this template's best cell (strictly greater needed: the first
-                    // column reaching the maximum wins) or matter for the read's arg-max, the template's
-                    // result is already final.
-                    const ReadBound rb = read_bound<R>(H, T, row0g + (col) * geK, geK);
-                    const int top = max(rb.colmax, 0) + b_left * a.p.match;
-                    const bool may_improve = top > rb.best;
-                    const bool relevant = min(kcap, max(rb.best, top)) >= need_score;
-                    if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && may_improve && relevant) == 0) emit = true;
-                }
-            } else {
-                ++tc;
-                if (col == next_branch) {
-                    // Template u ends here on the trunk.  Exact pruning: no cell of its branch can score
-                    // more than max(trunk best, column max + |branch| * match).  If that cannot reach the
-                    // score filter (bam_parser.py:134) or beat the read's current arg-max key
-                    // (score, -units) for ANY of the four reads, the template is dropped; if it can matter
-                    // but the branch cannot raise the trunk's best cell, the result is emitted from the
-                    // trunk state without sweeping the branch.
-                    bool need = true, sweep = blen > 0;
-                    const int Tlen = alen + period * u + blen;
-                    need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
-                    if (!full_dump && blen > 0) {
-                        const ReadBound rb = read_bound<R>(H, T, row0g + col * geK, geK);
-                        const int top = max(rb.colmax, 0) + blen * a.p.match;
-                        const bool relevant = min(kcap, max(rb.best, top)) >= need_score;
-                        const bool may_improve = top > rb.best;
-                        need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant) != 0;
-                        sweep = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant && may_improve) != 0;
-                    }
-                    if (need && sweep) ++n_swept; else if (need) ++n_emit_trunk; else ++n_dropped;
-                    if (need && sweep) {
-                        // park the trunk state, continue into the branch
-#pragma unroll
-                        for (int r = 0; r < R; ++r) { mypark[r * PS] = H[r]; mypark[(R + r) * PS] = E[r]; }
-                        mypark[(2 * R) * PS] = T.bestkey;
-                        mypark[(2 * R + 1) * PS] = T.beststart;
-                        mypark[(2 * R + 2) * PS] = T.ceil;
-                        in_branch = true;
-                        parked = true;
-                        b_left = blen; b_col = col + 1; b_idx = 0;
-                    } else if (need) {
-                        emit = true;       // result = trunk state; nothing parked
-                        parked = false;
-                    } else {
-                        next_branch += period;
-                        ++u;
-                    }
+            for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+            for (int y = 0; y + 1 < blen; ++y) {
+                const int s_fresh = (y << 9) + y * geK - 2 * geK;
+                switch (letter_from(bw, blen - 1 - y)) {
+                    case 0: sweep_column_free<R, 0>(J, H, E, s_fresh, geK, c0); break;
+                    case 1: sweep_column_free<R, 1>(J, H, E, s_fresh, geK, c0); break;
+                    case 2: sweep_column_free<R, 2>(J, H, E, s_fresh, geK, c0); break;
+                    case 3: sweep_column_free<R, 3>(J, H, E, s_fresh, geK, c0); break;
+                    default: sweep_column_free<R, 4>(J, H, E, s_fresh, geK, c0); break;
                 }
             }
-            if (!emit) continue;
-            // ---- template u complete: best cell of the alignment -> lane 15 of the read's DPP row ----
+            {
+                const int y = blen - 1;
+                const int s_fresh = (y << 9) + y * geK - 2 * geK;
+                switch (letter_from(bw, 0)) {
+                    case 0: match_column<R, 0>(J, H, D, s_fresh, geK); break;
+                    case 1: match_column<R, 1>(J, H, D, s_fresh, geK); break;
+                    case 2: match_column<R, 2>(J, H, D, s_fresh, geK); break;
+                    case 3: match_column<R, 3>(J, H, D, s_fresh, geK); break;
+                    default: match_column<R, 4>(J, H, D, s_fresh, geK); break;
+                }
+            }
+            // E holds the horizontal-gap state of the last reversed column (= first suffix column); its opening
+            // cost was charged on the reversed side too: + go - ge in the scaled domain
+            mirror_up<R>(D, 0, wb, PS);
+            mirror_up<R>(E, c0, wb + R * PS, PS);
+        }
+        build_profile<R>(J, a, off, L, row0, false, mK, xK, geK);
+        const int row0g = row0 * geK;
+        Track T;
+        // best alignment inside the suffix alone (columns relative to the suffix); it cannot reach the score
+        // floor unless the suffix is long enough, so normally only the dump needs it
+        const bool with_sfx = has_suffix && (full_dump || blen * a.p.match >= 30);
+        if (with_sfx) {
+            const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
+            const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+            T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
+            for (int j = 0; j < blen; ++j) sweep_letter<R>(letter_from(bw, j), J, H, E, T, j, row0, geK, c0, row0g);
+            int sk = T.bestkey, ss = T.beststart;
+            pair_step<0x111>(sk, ss);
+            pair_step<0x112>(sk, ss);
+            pair_step<0x114>(sk, ss);
+            pair_step<0x118>(sk, ss);
+            wb[(2 * R) * PS] = sk;
+            wb[(2 * R + 1) * PS] = ss;
+        }
+        const int tw = lane < ((ncols + 7) >> 3) ? (int)a.seqw[trunk_w + lane] : 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+        T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
+        int next_end = max_units > 0 ? alen + period - 1 : alen - 1;
+        int u = max_units > 0 ? 1 : 0;
+        for (int col = 0; col < ncols; ++col) {
+            sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g);
+            ++n_trunk_cols;
+            if (col != next_end) continue;
+            // ---- template u ends here on the trunk ----
+            // Exact pruning: no cell of its suffix can score more than max(trunk best, column max + |suffix| *
+            // match).  If that cannot reach the score filter (bam_parser.py:134) or beat the read's current
+            // arg-max key (score, -units) for ANY of the four reads, the template is dropped; if it can matter
+            // but the suffix cannot raise the trunk's best cell, the result is the trunk state.
+            bool need = true, comb = blen > 0;
+            const int Tlen = alen + period * u + blen;
+            if (!full_dump && blen > 0) {
+                const int bestS = best >> 12, bestU = 511 - ((best >> 3) & 511);
+                const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
+                const ReadBound rb = read_bound<R>(H, T, row0g + col * geK, geK);
+                const int top = max(rb.colmax, 0) + blen * a.p.match;
+                const bool relevant = min(kcap, max(rb.best, top)) >= need_score;
+                const bool may_improve = top > rb.best;
+                need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant) != 0;
+                comb = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant && may_improve) != 0;
+            }
+            next_end += period;
+            if (!need) { ++n_dropped; ++u; continue; }
             int bk = T.bestkey, bs = T.beststart;
-            pair_step<0x111>(bk, bs);
-            pair_step<0x112>(bk, bs);
-            pair_step<0x114>(bk, bs);
-            pair_step<0x118>(bk, bs);
+            if (comb) {
+                ++n_combined;
+                // candidates entering the suffix: key = (H or E score field) + continuation (score | end cell)
+                int m = NEG;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int ef = max(E[r], H[r] - c0);   // the gap may also open from a cell reached by a vertical gap
+                    m = max3(m, (H[r] & ~PAYMASK) + wb[r * PS], (ef & ~PAYMASK) + wb[(R + r) * PS]);
+                }
+                int st = 0;   // start payload of the winner (largest among equal keys); recomputed, not kept
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int ef = max(E[r], H[r] - c0);
+                    st = max(st, (H[r] & ~PAYMASK) + wb[r * PS] == m ? (H[r] & PAYMASK) : 0);
+                    st = max(st, (ef & ~PAYMASK) + wb[(R + r) * PS] == m ? (ef & PAYMASK) : 0);
+                }
+                // scaled sum -> true score; reversed start cell -> 511 - end column | 511 - end row
+                const int cu = ((511 - col - blen) << 9) + (512 - 16 * R) - (col + 16 * R + blen - 3) * geK;
+                m += cu;
+                const bool c = m > bk;     // an equal key is impossible: trunk cells end at columns <= col
+                bk = c ? m : bk;
+                bs = c ? st : bs;
+                pair_step_lex<0x111>(bk, bs);
+                pair_step_lex<0x112>(bk, bs);
+                pair_step_lex<0x114>(bk, bs);
+                pair_step_lex<0x118>(bk, bs);
+                if (with_sfx) {
+                    const int sk = wb[(2 * R) * PS], ss = wb[(2 * R + 1) * PS];
+                    const int k3 = sk - ((col + 1) << 9), s3 = ss + ((col + 1) << 9);
+                    const bool c3 = sk != floor_key && (k3 > bk || (k3 == bk && s3 > bs));
+                    bk = c3 ? k3 : bk;
+                    bs = c3 ? s3 : bs;
+                }
+            } else {
+                ++n_emit_trunk;
+                pair_step<0x111>(bk, bs);
+                pair_step<0x112>(bk, bs);
+                pair_step<0x114>(bk, bs);
+                pair_step<0x118>(bk, bs);
+            }
             const int score = bk >> KSH;
             const int ref_end = 511 - ((bk >> 9) & 511), read_end = 511 - (bk & 511);
             const int ref_begin = (bs >> 9) & 511, read_begin = bs & 511;
-            const int Tlen = alen + period * u + blen;
             const int min_len = min(L, Tlen) >> 1;              // bam_parser.py:133
             const int min_score = max(min_len, 30);             // :134
             const bool pass = score >= min_score && (read_end - read_begin + 1) >= min_len;  // ssw_wrap.py:217
@@ -418,15 +572,12 @@ __global__ __launch_bounds__(64, W) void sw_ladder_kernel(SwArgs a) {
             else if (u >= mu_rept - 1 && u * period <= L) tag = TREDGPU_TAG_REPT;
             else tag = TREDGPU_TAG_NONE;
             if (!pass) tag = TREDGPU_TAG_NONE;
-            // max(res, key=(score, -units)), first maximal element in db order (bam_parser.py:174)
-            const bool better = tag != TREDGPU_TAG_NONE && (score > bestS || (score == bestS && u < bestU));
-            bestS = better ? score : bestS;
-            bestU = better ? u : bestU;
-            bestTag = better ? tag : bestTag;
-            if (dump != nullptr && jl == 15) {
+            const int cand = (score << 9 | (511 - u)) << 3;
+            best = tag != TREDGPU_TAG_NONE && cand > (best | 7) ? cand | tag : best;
+            if (full_dump && valid && jl == 15) {
                 const int k = max_units > 0 ? 2 * (u - 1) + s : 0;
                 if (k < a.dump_templates) {
-                    int16_t* d = dump + k * 6;
+                    int16_t* d = a.out_dump + ((int64_t)a.perm[q_first + job] * a.dump_templates + k) * 6;
                     const bool hit = score > 0 && bk != floor_key;
                     d[0] = (int16_t)(hit ? score : 0);
                     d[1] = (int16_t)(hit ? ref_begin : -1);
@@ -436,29 +587,22 @@ __global__ __launch_bounds__(64, W) void sw_ladder_kernel(SwArgs a) {
                     d[5] = (int16_t)tag;
                 }
             }
-            // back to the trunk
-            if (parked) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) { H[r] = mypark[r * PS]; E[r] = mypark[(R + r) * PS]; }
-                T.bestkey = mypark[(2 * R) * PS];
-                T.beststart = mypark[(2 * R + 1) * PS];
-                T.ceil = mypark[(2 * R + 2) * PS];
-            }
-            in_branch = false;
-            next_branch += period;
             ++u;
+            if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && max(30, (best >> 12) + 1) <= cap) == 0) break;
         }
     }
     if (a.stats != nullptr && lane == 0) {
-        // one set of atomics per wave: what the exact shortcuts left to sweep
+        // one set of atomics per wave: what the exact shortcuts left to do
         atomicAdd(a.stats + 0, (unsigned long long)n_trunk_cols);
-        atomicAdd(a.stats + 1, (unsigned long long)n_branch_cols);
-        atomicAdd(a.stats + 2, (unsigned long long)n_swept);
+        atomicAdd(a.stats + 2, (unsigned long long)n_combined);
         atomicAdd(a.stats + 3, (unsigned long long)n_dropped);
         atomicAdd(a.stats + 4, (unsigned long long)n_emit_trunk);
         atomicAdd(a.stats + 5, 1ull);
     }
     if (valid && jl == 15) {
+        const int64_t rd = (int64_t)a.perm[q_first + job];
+        int bestTag = best < 0 ? TREDGPU_TAG_NONE : best & 7;
+        int bestU = 511 - ((best >> 3) & 511), bestS = best >> 12;
         if (too_long) bestTag = TREDGPU_TAG_INVALID, bestU = 0, bestS = 0;
         a.out_tag[rd] = (uint8_t)bestTag;
         a.out_h[rd] = (int16_t)(bestTag == TREDGPU_TAG_NONE ? 0 : bestU);
@@ -590,14 +734,11 @@ hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quad
     if (max_quads <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)max_quads;   // one quad = one wavefront = one workgroup
     switch (rows_per_lane) {
-#ifndef SW_W10
-#define SW_W10 4
-#endif
         // second parameter = waves per SIMD the register allocation is held to
-        case 4: sw_ladder_kernel<4, 6><<<blocks, 64, 0, s>>>(a); break;
-        case 7: sw_ladder_kernel<7, 4><<<blocks, 64, 0, s>>>(a); break;
-        case 10: sw_ladder_kernel<10, SW_W10><<<blocks, 64, 0, s>>>(a); break;
-        case 16: sw_ladder_kernel<16, 2><<<blocks, 64, 0, s>>>(a); break;
+        case 4: sw_cont_kernel<4, 6><<<blocks, 64, 0, s>>>(a); break;
+        case 7: sw_cont_kernel<7, 4><<<blocks, 64, 0, s>>>(a); break;
+        case 10: sw_cont_kernel<10, 4><<<blocks, 64, 0, s>>>(a); break;
+        case 16: sw_cont_kernel<16, 2><<<blocks, 64, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
