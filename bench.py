@@ -205,7 +205,7 @@ def main():
         alg = algorithmic_cells(batch)
         sw_s = sw_ms / 1e3 / max(sw_n, 1)
         cnt = ctx.get_sw_counters()
-        cols_per_launch = (cnt["trunk_cols"] + cnt["branch_cols"]) / max(sw_n, 1)
+        cols_per_launch = (cnt["trunk_cols"] + cnt["continuation_cols"]) / max(sw_n, 1)
         swept = cols_per_launch * 4 * 160          # a column sweep = 4 reads x 16 lanes x 10 rows
         alg_bytes = int(batch.packed.nbytes + n * 12 + n * 5)  # packed reads + offsets/lengths in, tag/h/score out
         out = {
@@ -219,13 +219,15 @@ def main():
                        "units_per_step_per_gpu": g, "reads_per_step_per_gpu": n, "coverage": args.coverage,
                        "readlen": 150, "maxinsert": 300, "alleles": "uniform 5..60 units (SURVEY 8d)",
                        "parallelism": "sample-sharded x{} (no collective)".format(world)},
-            "roofline": {"kernel": "sw_ladder_kernel<10,4>", "bound": "valu", "achieved": alg / sw_s / 1e12,
+            "roofline": {"kernel": "sw_cont_kernel<10,4>", "bound": "valu", "achieved": alg / sw_s / 1e12,
                          "peak": PEAK_TCUPS, "unit": "TCUPS", "frac": alg / sw_s / 1e12 / PEAK_TCUPS,
                          "traffic": None,
                          "note": "achieved = brute-force forward cells of SURVEY 8(d) per launch / HIP-event launch "
                                  "time; peak = int32 VALU lane-ops/s / 10 ops per cell. frac > 1 is the effect of the "
-                                 "exact shortcuts (shared-prefix ladder, strand filter, score-bound pruning): the "
-                                 "kernel sweeps {:.1f}x fewer cells than the brute-force count; see swept_*"
+                                 "exact shortcuts (shared-prefix ladder, suffix continuation vectors, strand filter, "
+                                 "score-bound pruning): the kernel sweeps {:.1f}x fewer cells than the brute-force "
+                                 "count (trunk + continuation-pass columns; a combined template costs about one "
+                                 "more column); see swept_*"
                                  .format(alg / max(swept, 1)),
                          "avg_launch_ms": sw_s * 1e3, "algorithmic_cells_per_launch": alg,
                          "ladder_cells_per_launch": ladder_cells(batch),

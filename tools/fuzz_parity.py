@@ -52,7 +52,7 @@ def main():
             rep_c = rep.replace("N", "C")
             extra = []
             for _ in range(25):
-                kind = int(rng.integers(7))
+                kind = int(rng.integers(9))
                 u = int(rng.integers(1, mu + 1))
                 tmpl = prefix + rep_c * u + suffix
                 if kind == 0:
@@ -71,8 +71,19 @@ def main():
                     r = (tmpl * 3)[:cut] + "N" * (readlen - cut)
                 elif kind == 5:
                     r = (rep_c * u)[:readlen // 2] + "ACGT"[int(rng.integers(4))] + (rep_c * (mu + 2))[:readlen // 2]
-                else:
+                elif kind == 6:
                     r = "N" * int(rng.integers(1, readlen + 1))
+                else:
+                    # indels at the repeat / suffix junction (where an alignment leaves the trunk for the suffix
+                    # continuation vectors): deletion, insertion, or both back to back
+                    j = len(prefix) + len(rep_c) * u + int(rng.integers(-4, 5))
+                    a, c = tmpl[:max(j, 0)], tmpl[max(j, 0):]
+                    mode = int(rng.integers(3))
+                    if mode != 1:
+                        c = c[int(rng.integers(1, 7)):]
+                    if mode != 0:
+                        a = a + "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 7))))
+                    r = (a + c)[max(0, len(a) - readlen + int(rng.integers(4, 30))):]
                 if rng.random() < 0.5:
                     r = po.rc(r)
                 if r:
@@ -83,7 +94,8 @@ def main():
         n = len(reads)
         unit_read_off, unit_ladder = np.asarray(uro, np.int32), np.asarray(ulad, np.int32)
         clip = bool(rng.random() < 0.3)
-        scoring = [(1, 5, 7, 2)] * 3 + [(2, 3, 5, 2), (1, 4, 6, 1), (1, 1, 2, 1), (3, 5, 7, 2), (1, 9, 12, 3)]
+        scoring = [(1, 5, 7, 2)] * 3 + [(2, 3, 5, 2), (1, 4, 6, 1), (1, 1, 2, 1), (3, 5, 7, 2), (1, 9, 12, 3),
+                                          (2, 6, 3, 1), (1, 3, 2, 2), (3, 2, 4, 1)]
         scoring = scoring[int(rng.integers(len(scoring)))]
         if clip:   # --useclippedreads: ragged lengths exercise the per-read REPT cut-off (bam_parser.py:154-155)
             reads = [r[int(rng.integers(0, max(1, len(r) // 3))):] for r in reads]

@@ -141,23 +141,27 @@ __device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int 
     const int lane_scale = row0g + s_scale;
     const bool trig = run + c0 - lane_scale > T.ceil;
     if (__builtin_amdgcn_ballot_w64(trig) != 0) {
-        // exact lane maximum of score<<18 | (R-1-r): the row part is a compile-time constant per row
+        // exact: does some row of this lane score more than the lane's best?  (a later column never wins a tie)
         int tr[R];
-        int m = NEG;
+        int m0 = NEG;
         int rs = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             tr[r] = H[r] - rs;  // still carries the lane's scale, a multiple of K
             rs += geK;
-            m = max(m, (tr[r] & ~PAYMASK) | (R - 1 - r));
+            m0 = max(m0, tr[r]);
         }
-        // -> score<<18 | (511-col)<<9 | (511-row)
-        const int cand = m - lane_scale + (((511 - col) << 9) + (511 - (R - 1)) - row0);
-        const bool imp = cand > T.bestkey;
+        const bool imp = m0 - lane_scale > T.ceil;
         if (__builtin_amdgcn_ballot_w64(imp) != 0) {
+            // the row: maximum of score<<18 | (R-1-r) (smallest row among equal scores), then its packed value
+            int m = NEG;
+#pragma unroll
+            for (int r = 0; r < R; ++r) m = max(m, (tr[r] & ~PAYMASK) | (R - 1 - r));
             int st = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) st = ((tr[r] & ~PAYMASK) | (R - 1 - r)) == m ? tr[r] : st;
+            // -> score<<18 | (511-col)<<9 | (511-row)
+            const int cand = m - lane_scale + (((511 - col) << 9) + (511 - (R - 1)) - row0);
             T.bestkey = imp ? cand : T.bestkey;
             T.beststart = imp ? st - lane_scale : T.beststart;
             T.ceil = T.bestkey | PAYMASK;
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     // arg-max so far, one word: (score << 9 | 511 - units) << 3 | tag; -1 = nothing yet.  A candidate must beat
     // it on (score, -units): max(res, key=(score, -units)), first maximal element in db order (bam_parser.py:174)
     int best = -1;
-    int n_trunk_cols = 0, n_combined = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
+    int n_trunk_cols = 0, n_cont_cols = 0, n_combined = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
 
     // Only cells that can survive the score filter are tracked: min_score >= 30 (bam_parser.py:134), so a
     // floor of 29 is exact for tagging; the per-template dump (parity/debug) tracks every positive score.
@@ -463,6 +467,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             // cost was charged on the reversed side too: + go - ge in the scaled domain
             mirror_up<R>(D, 0, wb, PS);
             mirror_up<R>(E, c0, wb + R * PS, PS);
+            n_cont_cols += blen;
         }
         build_profile<R>(J, a, off, L, row0, false, mK, xK, geK);
         const int row0g = row0 * geK;
@@ -524,23 +529,32 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                     const int ef = max(E[r], H[r] - c0);   // the gap may also open from a cell reached by a vertical gap
                     m = max3(m, (H[r] & ~PAYMASK) + wb[r * PS], (ef & ~PAYMASK) + wb[(R + r) * PS]);
                 }
-                int st = 0;   // start payload of the winner (largest among equal keys); recomputed, not kept
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int ef = max(E[r], H[r] - c0);
-                    st = max(st, (H[r] & ~PAYMASK) + wb[r * PS] == m ? (H[r] & PAYMASK) : 0);
-                    st = max(st, (ef & ~PAYMASK) + wb[(R + r) * PS] == m ? (ef & PAYMASK) : 0);
-                }
                 // scaled sum -> true score; reversed start cell -> 511 - end column | 511 - end row
                 const int cu = ((511 - col - blen) << 9) + (512 - 16 * R) - (col + 16 * R + blen - 3) * geK;
                 m += cu;
                 const bool c = m > bk;     // an equal key is impossible: trunk cells end at columns <= col
-                bk = c ? m : bk;
-                bs = c ? st : bs;
-                pair_step_lex<0x111>(bk, bs);
-                pair_step_lex<0x112>(bk, bs);
-                pair_step_lex<0x114>(bk, bs);
-                pair_step_lex<0x118>(bk, bs);
+                if (__builtin_amdgcn_ballot_w64(c) != 0) {
+                    // start payload of the winner (largest among equal keys); the sums are recomputed, not kept
+                    const int mm = m - cu;
+                    int st = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int ef = max(E[r], H[r] - c0);
+                        st = max(st, (H[r] & ~PAYMASK) + wb[r * PS] == mm ? (H[r] & PAYMASK) : 0);
+                        st = max(st, (ef & ~PAYMASK) + wb[(R + r) * PS] == mm ? (ef & PAYMASK) : 0);
+                    }
+                    bk = c ? m : bk;
+                    bs = c ? st : bs;
+                    pair_step_lex<0x111>(bk, bs);
+                    pair_step_lex<0x112>(bk, bs);
+                    pair_step_lex<0x114>(bk, bs);
+                    pair_step_lex<0x118>(bk, bs);
+                } else {
+                    pair_step<0x111>(bk, bs);
+                    pair_step<0x112>(bk, bs);
+                    pair_step<0x114>(bk, bs);
+                    pair_step<0x118>(bk, bs);
+                }
                 if (with_sfx) {
                     const int sk = wb[(2 * R) * PS], ss = wb[(2 * R + 1) * PS];
                     const int k3 = sk - ((col + 1) << 9), s3 = ss + ((col + 1) << 9);
@@ -594,6 +608,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     if (a.stats != nullptr && lane == 0) {
         // one set of atomics per wave: what the exact shortcuts left to do
         atomicAdd(a.stats + 0, (unsigned long long)n_trunk_cols);
+        atomicAdd(a.stats + 1, (unsigned long long)n_cont_cols);
         atomicAdd(a.stats + 2, (unsigned long long)n_combined);
         atomicAdd(a.stats + 3, (unsigned long long)n_dropped);
         atomicAdd(a.stats + 4, (unsigned long long)n_emit_trunk);

@@ -49,7 +49,7 @@ struct SwArgs {
     int32_t n_units;
     int32_t max_rows;        // 16 * rows-per-lane of the instantiation that will run
     tredgpu_sw_params p;
-    unsigned long long* stats;  // work counters: trunk cols, branch cols, branches swept/dropped/emitted-from-trunk, waves
+    unsigned long long* stats;  // work counters: trunk cols, continuation-pass cols, templates combined/dropped/emitted-from-trunk, waves
 };
 
 // sw_ladder.hip
