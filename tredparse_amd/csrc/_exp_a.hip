@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     // arg-max so far, one word: (score << 9 | 511 - units) << 3 | tag; -1 = nothing yet.  A candidate must beat
     // it on (score, -units): max(res, key=(score, -units)), first maximal element in db order (bam_parser.py:174)
     int best = -1;
-    int n_trunk_cols = 0, n_cont_cols = 0, n_combined = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
+    int n_trunk_cols = 0, n_combined = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
 
     // Only cells that can survive the score filter are tracked: min_score >= 30 (bam_parser.py:134), so a
     // floor of 29 is exact for tagging; the per-template dump (parity/debug) tracks every positive score.
@@ -467,7 +467,6 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             // cost was charged on the reversed side too: + go - ge in the scaled domain
             mirror_up<R>(D, 0, wb, PS);
             mirror_up<R>(E, c0, wb + R * PS, PS);
-            n_cont_cols += blen;
         }
         build_profile<R>(J, a, off, L, row0, false, mK, xK, geK);
         const int row0g = row0 * geK;
@@ -596,13 +595,13 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && max(30, (best >> 12) + 1) <= cap) == 0) break;
         }
     }
-    if (a.stats != nullptr && lane < 6) {
-        // one atomic per counter and wave (lanes 0..5 of one instruction), spread over SW_STAT_SLOTS lines
-        const int vals[6] = {n_trunk_cols, n_cont_cols, n_combined, n_dropped, n_emit_trunk, 1};
-        int v = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v = lane == k ? vals[k] : v;
-        atomicAdd(a.stats + (size_t)(blockIdx.x & (SW_STAT_SLOTS - 1)) * 8 + lane, (unsigned long long)v);
+    if (a.stats != nullptr && lane == 0) {
+        // one set of atomics per wave: what the exact shortcuts left to do
+        atomicAdd(a.stats + 0, (unsigned long long)n_trunk_cols);
+        atomicAdd(a.stats + 2, (unsigned long long)n_combined);
+        atomicAdd(a.stats + 3, (unsigned long long)n_dropped);
+        atomicAdd(a.stats + 4, (unsigned long long)n_emit_trunk);
+        atomicAdd(a.stats + 5, 1ull);
     }
     if (valid && jl == 15) {
         const int64_t rd = (int64_t)a.perm[q_first + job];

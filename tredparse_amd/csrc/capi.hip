@@ -254,7 +254,7 @@ int tredgpu_reset_timing(tredgpu_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto& t : c->timers) { t.used = 0; t.launches = 0; t.total_ms = 0; }
-    if (c->ws_stats.p) HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    if (c->ws_stats.p) HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, SW_STAT_SLOTS * 8 * sizeof(unsigned long long), c->stream));
     return 0;
 }
 
@@ -263,7 +263,12 @@ int tredgpu_get_sw_counters(tredgpu_ctx* c, uint64_t out[8]) {
     HIPCHK(c, hipSetDevice(c->device));
     for (int i = 0; i < 8; ++i) out[i] = 0;
     if (c->ws_stats.p) {
-        HIPCHK(c, hipMemcpyAsync(out, c->ws_stats.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        // the kernel spreads its per-wave updates over SW_STAT_SLOTS cache lines (one line of 8 counters each)
+        std::vector<uint64_t> slots((size_t)SW_STAT_SLOTS * 8);
+        HIPCHK(c, hipMemcpyAsync(slots.data(), c->ws_stats.p, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < SW_STAT_SLOTS; ++k)
+            for (int i = 0; i < 8; ++i) out[i] += slots[(size_t)k * 8 + i];
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -458,8 +463,8 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     HIPCHK(c, launch_build_quads(a, (uint8_t*)c->ws_class.p, (int32_t*)c->ws_perm.p, (Quad*)c->ws_quads.p,
                                  (int32_t*)c->ws_counter.p, c->stream));
     if (c->ws_stats.p == nullptr) {
-        if ((rc = ensure(c, c->ws_stats, 8 * sizeof(unsigned long long)))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
+        if ((rc = ensure(c, c->ws_stats, SW_STAT_SLOTS * 8 * sizeof(unsigned long long)))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, SW_STAT_SLOTS * 8 * sizeof(unsigned long long), c->stream));
     }
     a.stats = (unsigned long long*)c->ws_stats.p;
     {

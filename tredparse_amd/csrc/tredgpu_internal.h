@@ -49,8 +49,12 @@ struct SwArgs {
     int32_t n_units;
     int32_t max_rows;        // 16 * rows-per-lane of the instantiation that will run
     tredgpu_sw_params p;
-    unsigned long long* stats;  // work counters: trunk cols, continuation-pass cols, templates combined/dropped/emitted-from-trunk, waves
+    unsigned long long* stats;  // [SW_STAT_SLOTS][8], slot = workgroup & (SW_STAT_SLOTS - 1): work counters: trunk cols, continuation-pass cols, templates combined/dropped/emitted-from-trunk, waves
 };
+
+// per-wave counter updates are spread over this many 64-byte lines: half a million waves adding to one line
+// serialise in L2 (measured: 6 atomics per wave on one line cost the SW kernel 15 % of its time)
+constexpr int SW_STAT_SLOTS = 1024;
 
 // sw_ladder.hip
 hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads,
