@@ -291,6 +291,20 @@ __device__ __forceinline__ void pair_step_lex(int& k, int& s) {
     s = c ? ts : s;
 }
 
+// Codes of R consecutive read rows i_lo .. i_lo+R-1 (R <= 16): they span at most two words of the 2-bit codes and
+// two words of the N mask (tredgpu.h read packing), so four loads fetch them all.  code2: 2 bits per row;
+// nmask: bit k = row i_lo+k is N.  Rows >= L hold garbage (the caller pads them).
+template <int R>
+__device__ __forceinline__ void load_rows(const SwArgs& a, int64_t off, int L, int i_lo, uint32_t& code2, uint32_t& nmask) {
+    const int nb = (L + 15) >> 4, nm = (L + 31) >> 5;
+    const int wl = max(nb - 1, 0), ml = max(nm - 1, 0);
+    const int wi = i_lo >> 4, mi = i_lo >> 5;
+    const uint32_t w0 = a.packed[off + min(wi, wl)], w1 = a.packed[off + min(wi + 1, wl)];
+    const uint32_t m0 = a.packed[off + nb + min(mi, ml)], m1 = a.packed[off + nb + min(mi + 1, ml)];
+    code2 = (uint32_t)((((uint64_t)w1 << 32) | w0) >> ((i_lo & 15) * 2));
+    nmask = (uint32_t)((((uint64_t)m1 << 32) | m0) >> (i_lo & 31));
+}
+
 // Match/mismatch profile of this lane's R rows.  reversed: position x of the lane layout holds read row
 // 16R-1-x (padding first), the layout of the continuation pass.
 template <int R>
@@ -299,17 +313,15 @@ __device__ __forceinline__ void build_profile(Rows<R>& J, const SwArgs& a, int64
     // (the profile is the same for both strands; the empty asm keeps the compiler from hoisting it out of the
     //  strand loop, where the forward and the reversed one would be live together: 2 x 4R registers)
     asm volatile("" : "+v"(L));
-    const int nb = (L + 15) >> 4;
     J.rowc0 = row0 + row0 * geK;
+    const int i_lo = reversed ? 16 * R - R - row0 : row0;
+    uint32_t code2, nmask;
+    load_rows<R>(a, off, L, i_lo, code2, nmask);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int i = reversed ? 16 * R - 1 - (row0 + r) : row0 + r;
-        int code = 5;  // padding
-        if (i < L) {
-            const uint32_t w = a.packed[off + (i >> 4)];
-            const uint32_t m = a.packed[off + nb + (i >> 5)];
-            code = ((m >> (i & 31)) & 1u) ? 4 : (int)((w >> ((i & 15) * 2)) & 3u);
-        }
+        const int k = reversed ? R - 1 - r : r;
+        const int i = i_lo + k;
+        const int code = i >= L ? 5 : (((nmask >> k) & 1u) ? 4 : (int)((code2 >> (2 * k)) & 3u));
 #pragma unroll
         for (int l = 0; l < 4; ++l)
             J.S[l][r] = code == 5 ? PADNEG : (code == 4 ? 0 : (code == l ? mK : xK)) + 2 * geK;
@@ -360,19 +372,11 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     // this lane's rows as 2-bit codes / N-or-padding flags, for the 6-mer filter
     uint32_t pk = 0, nk = 0;
     if (2 * R + 10 <= 32) {
-        const int nb = (L + 15) >> 4;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = row0 + r;
-            int code = 5;
-            if (i < L) {
-                const uint32_t w = a.packed[off + (i >> 4)];
-                const uint32_t m = a.packed[off + nb + (i >> 5)];
-                code = ((m >> (i & 31)) & 1u) ? 4 : (int)((w >> ((i & 15) * 2)) & 3u);
-            }
-            pk |= (uint32_t)(code & 3) << (2 * r);
-            nk |= (uint32_t)(code > 3) << r;
-        }
+        uint32_t code2, nmask;
+        load_rows<R>(a, off, L, row0, code2, nmask);
+        const int n_real = min(max(L - row0, 0), R);                       // rows of this lane inside the read
+        pk = code2 & ((1u << (2 * R)) - 1u);                               // (codes of N / padding rows are never
+        nk = (nmask | ~((1u << n_real) - 1u)) & ((1u << R) - 1u);          //  looked at: their windows count as present)
     }
     // REPT cut-off: per-read ceil(L/period) with --useclippedreads, else the ladder's (bam_parser.py:154-155)
     const int mu_rept = a.p.clip ? (L + period - 1) / period : max_units;
@@ -529,17 +533,21 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                     const int ef = max(E[r], H[r] - c0);   // the gap may also open from a cell reached by a vertical gap
                     m = max3(m, (H[r] & ~PAYMASK) + wb[r * PS], (ef & ~PAYMASK) + wb[(R + r) * PS]);
                 }
-                int st = 0;   // start payload of the winner (largest among equal keys); recomputed, not kept
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int ef = max(E[r], H[r] - c0);
-                    st = max(st, (H[r] & ~PAYMASK) + wb[r * PS] == m ? (H[r] & PAYMASK) : 0);
-                    st = max(st, (ef & ~PAYMASK) + wb[(R + r) * PS] == m ? (ef & PAYMASK) : 0);
-                }
                 // scaled sum -> true score; reversed start cell -> 511 - end column | 511 - end row
                 const int cu = ((511 - col - blen) << 9) + (512 - 16 * R) - (col + 16 * R + blen - 3) * geK;
                 m += cu;
                 const bool c = m > bk;     // an equal key is impossible: trunk cells end at columns <= col
+                int st = 0;
+                if (__builtin_amdgcn_ballot_w64(c) != 0) {
+                    // start payload of the winner (largest among equal keys); the sums are recomputed, not kept
+                    const int mm = m - cu;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int ef = max(E[r], H[r] - c0);
+                        st = max(st, (H[r] & ~PAYMASK) + wb[r * PS] == mm ? (H[r] & PAYMASK) : 0);
+                        st = max(st, (ef & ~PAYMASK) + wb[(R + r) * PS] == mm ? (ef & PAYMASK) : 0);
+                    }
+                }
                 bk = c ? m : bk;
                 bs = c ? st : bs;
                 pair_step_lex<0x111>(bk, bs);
