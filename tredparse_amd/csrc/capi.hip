@@ -341,7 +341,9 @@ int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, co
         d.period = (int)Rp.size();
         d.max_units = mu;
         d.n_strands = 2;
-        // 6-mer presence bitmaps over ALL templates of each strand (exact strand filter in the kernel)
+        // 6-mer presence bitmaps over ALL templates of each strand (exact strand filter in the kernel).  A template
+        // N scores 0 against every base: it neither breaks nor feeds a run of matches, so a window with N
+        // positions stands for all its fillings (the bound's run-length argument then holds unchanged).
         d.kmer_ok = 1;
         for (int s = 0; s < 2; ++s) {
             std::vector<uint32_t> bits(128, 0u);
@@ -351,13 +353,16 @@ int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, co
                 t.insert(t.end(), B[s]->begin(), B[s]->end());
                 for (size_t i = 0; i + 6 <= t.size(); ++i) {
                     uint32_t code = 0;
-                    bool wild = false;
+                    int wild[6], nw = 0;
                     for (int k = 0; k < 6; ++k) {
-                        if (t[i + k] > 3) wild = true;
-                        code |= (uint32_t)(t[i + k] & 3) << (2 * k);
+                        if (t[i + k] > 3) wild[nw++] = k;
+                        else code |= (uint32_t)(t[i + k] & 3) << (2 * k);
                     }
-                    if (wild) d.kmer_ok = 0;
-                    else bits[code >> 5] |= 1u << (code & 31);
+                    for (uint32_t f = 0; f < (1u << (2 * nw)); ++f) {
+                        uint32_t cf = code;
+                        for (int j = 0; j < nw; ++j) cf |= ((f >> (2 * j)) & 3u) << (2 * wild[j]);
+                        bits[cf >> 5] |= 1u << (cf & 31);
+                    }
                 }
             }
             d.kmer_off[s] = (int)seq.size();

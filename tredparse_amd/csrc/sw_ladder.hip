@@ -402,8 +402,9 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
         // (P = min(mismatch, gap_open) >= 5*match), so at least m - 5*(breaks+1) >= s/match - 5 of its
         // 6-mers are exact; no template of this strand can reach the score filter (>= 30,
         // bam_parser.py:134) unless that many read 6-mers occur somewhere in the strand's templates.
-        // Windows containing N count as present.  Skipped for the dump (all positive scores wanted),
-        // for N-containing motifs and for scorings outside the bound's premise.
+        // Read windows containing N count as present; a template N scores 0 against every base, so template
+        // windows with N stand for all their fillings (tredgpu_set_ladders).  Skipped for the dump (all positive
+        // scores wanted) and for scorings outside the bound's premise.
         int kcap = 1 << 20;  // per read: upper bound of any score on this strand
         // (a 6-mer window starting in this lane ends at most 5 bases into the next lane's rows: needs R >= 5;
         //  with fewer rows per lane the per-read classes of read_class_kernel already removed hopeless strands)

@@ -18,7 +18,7 @@ struct LadderDesc {
     int32_t period;
     int32_t max_units;
     int32_t n_strands;
-    int32_t kmer_ok;       // 1: kmer_off[] bitmaps usable (no N in any template, max_units > 0)
+    int32_t kmer_ok;       // 1: kmer_off[] bitmaps usable (max_units > 0)
     int32_t kmer_off[2];   // WORD offsets of the 4096-bit 6-mer presence bitmaps (128 words) per strand
 };
 
