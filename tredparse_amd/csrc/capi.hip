@@ -37,7 +37,7 @@ struct tredgpu_ctx {
     Buf d_model;
     bool have_model = false;
     // workspaces (grow-only, reused across calls)
-    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class, ws_gdesc, ws_gtile, ws_gctr;
+    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class, ws_gdesc, ws_gtile, ws_gctr, ws_ucnt, ws_bins;
     int* h_pin = nullptr;  // pinned word for small read-backs
     size_t grid_pool_bytes = GRID_POOL_BYTES;   // TREDGPU_GRID_POOL_MB overrides (tuning / tests of the multi-pass path)
     Buf st[24];  // staging for HOST-memory calls
@@ -228,7 +228,7 @@ void tredgpu_destroy(tredgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (Buf* b : {&c->d_ladders, &c->d_seq, &c->d_model, &c->ws_quads, &c->ws_counter, &c->ws_drop,
-                   &c->ws_grid, &c->ws_stats, &c->ws_perm, &c->ws_class, &c->ws_gdesc, &c->ws_gtile, &c->ws_gctr, &c->ws_tag, &c->ws_h, &c->ws_score})
+                   &c->ws_grid, &c->ws_stats, &c->ws_perm, &c->ws_class, &c->ws_gdesc, &c->ws_gtile, &c->ws_gctr, &c->ws_ucnt, &c->ws_bins, &c->ws_tag, &c->ws_h, &c->ws_score})
         release(*b);
     for (Buf& b : c->st) release(b);
     for (auto& t : c->timers)
@@ -439,7 +439,8 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
                          int32_t n_units, const tredgpu_sw_params* p, int max_len, uint8_t* out_tag,
                          int16_t* out_h, int16_t* out_score, int16_t* out_dump, int32_t dump_templates) {
     if (n_reads == 0 || n_units == 0) return 0;
-    const int64_t max_quads = n_reads / 4 + 3 * (int64_t)n_units + 1;
+    const int n_ladders = (int)c->h_ladders.size();
+    const int64_t max_quads = n_reads / 4 + 3 * (int64_t)n_ladders + 1;   // one partial quad per (ladder, class) bin
     int rc;
     if ((rc = ensure(c, c->ws_quads, (size_t)max_quads * sizeof(Quad)))) return rc;
     if ((rc = ensure(c, c->ws_counter, 64))) return rc;
@@ -465,8 +466,11 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     if ((rc = ensure(c, c->ws_perm, (size_t)n_reads * sizeof(int32_t)))) return rc;
     if ((rc = ensure(c, c->ws_class, (size_t)n_reads))) return rc;
     a.perm = (const int32_t*)c->ws_perm.p;
+    if ((rc = ensure(c, c->ws_ucnt, (size_t)n_units * 4 * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->ws_bins, sw_bin_bytes(n_ladders)))) return rc;
     HIPCHK(c, launch_build_quads(a, (uint8_t*)c->ws_class.p, (int32_t*)c->ws_perm.p, (Quad*)c->ws_quads.p,
-                                 (int32_t*)c->ws_counter.p, c->stream));
+                                 (int32_t*)c->ws_counter.p, (int32_t*)c->ws_ucnt.p, (int32_t*)c->ws_bins.p, n_ladders,
+                                 max_quads, c->stream));
     if (c->ws_stats.p == nullptr) {
         if ((rc = ensure(c, c->ws_stats, SW_STAT_SLOTS * 8 * sizeof(unsigned long long)))) return rc;
         HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, SW_STAT_SLOTS * 8 * sizeof(unsigned long long), c->stream));

@@ -339,11 +339,11 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     const int64_t q = (int64_t)blockIdx.x;
     const int nq = *a.n_quads;
     if (q >= nq) return;
-    const int q_unit = __builtin_amdgcn_readfirstlane(a.quads[q].unit);
+    const int q_ladder = __builtin_amdgcn_readfirstlane(a.quads[q].ladder);
     const int q_first = __builtin_amdgcn_readfirstlane(a.quads[q].first);
     const int q_strands = __builtin_amdgcn_readfirstlane(a.quads[q].strands);
     const int q_count = __builtin_amdgcn_readfirstlane(a.quads[q].count);
-    const LadderDesc* ld = a.ladders + __builtin_amdgcn_readfirstlane(a.unit_ladder[q_unit]);
+    const LadderDesc* ld = a.ladders + q_ladder;
     const int period = __builtin_amdgcn_readfirstlane(ld->period);
     const int max_units = __builtin_amdgcn_readfirstlane(ld->max_units);
     const int n_strands = __builtin_amdgcn_readfirstlane(ld->n_strands);
@@ -624,18 +624,29 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     }
 }
 
-// Strand classes for quad formation.  The exact 6-mer strand filter (see sw_ladder_kernel) is evaluated
-// per read here, once: bit s of the class = "strand s can reach the score filter for this read".  Reads
-// that need no strand at all are finished on the spot (no candidate: tag NONE); the others are grouped so
-// that the four reads of a wavefront need the same strands.
-__global__ void read_class_kernel(SwArgs a, uint8_t* read_class) {
+// Strand classes and quad formation.  The exact 6-mer strand filter (see sw_cont_kernel) is evaluated per read
+// here, once: bit s of the class = "strand s can reach the score filter for this read".  Reads that need no strand
+// at all are finished on the spot (no candidate: tag NONE).  The others are packed four to a wavefront by
+// (ladder, class) across the units of a batch -- a read's alignment does not depend on its wave-mates, so only
+// the last quad of each of the 3 x n_ladders bins can be partial (per-unit packing left 7 % of the read slots
+// of the bench batch empty).  Bin b = 3 * ladder + k holds class {1, 3, 2}[k].
+//   read_class_kernel   classes, per-unit class counts, bin totals (one atomic per unit and class)
+//   bin_scan_kernel     bin -> first slot in the permutation / first quad; the quad count of the launch
+//   scatter_kernel      each unit reserves its run inside its bins and writes its reads' indices there
+//   fill_quads_kernel   one thread per quad: its bin by binary search over the quad offsets
+constexpr int BIN_STRIDE = 16;   // ints: every bin counter on its own 64-byte line
+__device__ __forceinline__ int bin_of(int ladder, int cls) { return 3 * ladder + (cls == 1 ? 0 : (cls == 3 ? 1 : 2)); }
+
+__global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_class, int32_t* unit_cnt, int32_t* bin_total) {
     const int g = blockIdx.x;
     if (g >= a.n_units) return;
-    const LadderDesc* ld = a.ladders + a.unit_ladder[g];
+    const int lad = a.unit_ladder[g];
+    const LadderDesc* ld = a.ladders + lad;
     const bool full_dump = a.out_dump != nullptr;
     const int thr = min(a.p.mismatch, a.p.gap_open) >= 5 * a.p.match ? (30 + a.p.match - 1) / a.p.match - 5 : 0;
     const bool filt = !full_dump && thr > 0 && ld->kmer_ok != 0 && ld->max_units > 0;
     const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
+    int n1 = 0, n2 = 0, n3 = 0;
     for (int rd = r0 + (int)threadIdx.x; rd < r1; rd += (int)blockDim.x) {
         int cls = ld->n_strands >= 2 ? 3 : 1;
         const int L = a.read_len[rd];
@@ -661,40 +672,78 @@ __global__ void read_class_kernel(SwArgs a, uint8_t* read_class) {
             cls = (cnt0 >= thr ? 1 : 0) | (cnt1 >= thr ? 2 : 0);
         }
         read_class[rd] = (uint8_t)cls;
+        n1 += cls == 1; n2 += cls == 2; n3 += cls == 3;
         if (cls == 0) {   // no strand can produce a candidate: bam_parser.py:171-172 "if not res: return"
             a.out_tag[rd] = TREDGPU_TAG_NONE;
             a.out_h[rd] = 0;
             a.out_score[rd] = 0;
         }
     }
+    // one wavefront per unit: wave-wide sums by DPP-free ballots are not available for counts, use shuffles
+    for (int o = 32; o > 0; o >>= 1) {
+        n1 += __shfl_down(n1, o);
+        n2 += __shfl_down(n2, o);
+        n3 += __shfl_down(n3, o);
+    }
+    if (threadIdx.x == 0) {
+        unit_cnt[4 * g + 1] = n1; unit_cnt[4 * g + 2] = n2; unit_cnt[4 * g + 3] = n3;
+        if (n1) atomicAdd(bin_total + (size_t)bin_of(lad, 1) * BIN_STRIDE, n1);
+        if (n3) atomicAdd(bin_total + (size_t)bin_of(lad, 3) * BIN_STRIDE, n3);
+        if (n2) atomicAdd(bin_total + (size_t)bin_of(lad, 2) * BIN_STRIDE, n2);
+    }
 }
 
-__global__ void build_quads_kernel(SwArgs a, const uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads) {
+// bins[b * BIN_STRIDE + 0] total reads, +1 first permutation slot, +2 first quad, +3 fill cursor
+__global__ void bin_scan_kernel(int32_t* bins, int n_bins, int32_t* n_quads) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int slot = 0, quad = 0;
+    for (int b = 0; b < n_bins; ++b) {
+        int32_t* e = bins + (size_t)b * BIN_STRIDE;
+        e[1] = slot;
+        e[2] = quad;
+        e[3] = 0;
+        slot += e[0];
+        quad += (e[0] + 3) >> 2;
+    }
+    bins[(size_t)n_bins * BIN_STRIDE + 2] = quad;   // sentinel for the binary search
+    *n_quads = quad;
+}
+
+__global__ void scatter_kernel(SwArgs a, const uint8_t* read_class, const int32_t* unit_cnt, int32_t* bins, int32_t* perm) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n_units) return;
-    const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
-    int n_c[4] = {0, 0, 0, 0};
-    for (int r = r0; r < r1; ++r) ++n_c[read_class[r] & 3];
-    // layout inside the unit's slice of perm: class 1 | class 3 | class 2 | class 0 (stable within a class)
-    const int order[4] = {1, 3, 2, 0};
-    int start[4], pos = r0, nq = 0;
-    for (int k = 0; k < 4; ++k) { start[order[k]] = pos; pos += n_c[order[k]]; }
-    for (int c = 1; c < 4; ++c) nq += (n_c[c] + 3) >> 2;
-    int fill[4] = {start[0], start[1], start[2], start[3]};
-    for (int r = r0; r < r1; ++r) perm[fill[read_class[r] & 3]++] = r;
-    if (nq == 0) return;
-    int base = atomicAdd(n_quads, nq);
-    for (int k = 0; k < 3; ++k) {
-        const int c = order[k];
-        for (int j = 0; j < n_c[c]; j += 4) {
-            Quad qd;
-            qd.unit = g;
-            qd.first = start[c] + j;
-            qd.count = min(4, n_c[c] - j);
-            qd.strands = c;
-            quads[base++] = qd;
-        }
+    const int lad = a.unit_ladder[g];
+    int pos[4] = {0, 0, 0, 0};
+    for (int c = 1; c < 4; ++c) {
+        const int n = unit_cnt[4 * g + c];
+        if (n == 0) continue;
+        int32_t* e = bins + (size_t)bin_of(lad, c) * BIN_STRIDE;
+        pos[c] = e[1] + atomicAdd(e + 3, n);
     }
+    const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
+    for (int r = r0; r < r1; ++r) {
+        const int c = read_class[r] & 3;
+        if (c != 0) perm[pos[c]++] = r;
+    }
+}
+
+__global__ void fill_quads_kernel(const int32_t* bins, int n_bins, const int32_t* n_quads, Quad* quads) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= *n_quads) return;
+    int lo = 0, hi = n_bins;   // largest b with first_quad[b] <= q (empty bins share their successor's offset)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bins[(size_t)mid * BIN_STRIDE + 2] <= q) lo = mid; else hi = mid;
+    }
+    const int32_t* e = bins + (size_t)lo * BIN_STRIDE;
+    const int j = q - e[2];
+    const int cls[3] = {1, 3, 2};
+    Quad qd;
+    qd.ladder = lo / 3;
+    qd.first = e[1] + 4 * j;
+    qd.count = min(4, e[0] - 4 * j);
+    qd.strands = cls[lo % 3];
+    quads[q] = qd;
 }
 
 // bam_parser.py:256-287: histograms per unit; optional removal of REPT/REPT mate pairs.
@@ -735,14 +784,20 @@ __global__ void tally_kernel(const uint8_t* tag, const int16_t* h, const int32_t
 }  // namespace
 
 hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads,
-                              hipStream_t s) {
+                              int32_t* unit_cnt, int32_t* bins, int n_ladders, int64_t max_quads, hipStream_t s) {
     hipError_t e = hipMemsetAsync(n_quads, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return e;
     if (a.n_units <= 0) return hipSuccess;
-    read_class_kernel<<<a.n_units, 64, 0, s>>>(a, read_class);
-    build_quads_kernel<<<(a.n_units + 255) / 256, 256, 0, s>>>(a, read_class, perm, quads, n_quads);
+    const int n_bins = 3 * n_ladders;
+    if ((e = hipMemsetAsync(bins, 0, sw_bin_bytes(n_ladders), s)) != hipSuccess) return e;
+    read_class_kernel<<<a.n_units, 64, 0, s>>>(a, read_class, unit_cnt, bins);
+    bin_scan_kernel<<<1, 64, 0, s>>>(bins, n_bins, n_quads);
+    scatter_kernel<<<(a.n_units + 255) / 256, 256, 0, s>>>(a, read_class, unit_cnt, bins, perm);
+    fill_quads_kernel<<<(unsigned)((max_quads + 255) / 256), 256, 0, s>>>(bins, n_bins, n_quads, quads);
     return hipGetLastError();
 }
+
+size_t sw_bin_bytes(int n_ladders) { return ((size_t)3 * n_ladders + 1) * BIN_STRIDE * sizeof(int32_t); }
 
 hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s) {
     if (max_quads <= 0) return hipSuccess;

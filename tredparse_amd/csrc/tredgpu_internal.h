@@ -22,9 +22,9 @@ struct LadderDesc {
     int32_t kmer_off[2];   // WORD offsets of the 4096-bit 6-mer presence bitmaps (128 words) per strand
 };
 
-// A quad = up to four reads of one unit that share a wavefront (16 lanes each).
+// A quad = up to four reads of one ladder (any units) that share a wavefront (16 lanes each).
 struct Quad {
-    int32_t unit;
+    int32_t ladder;
     int32_t first;    // index into the permutation array: reads perm[first .. first+count)
     int32_t count;
     int32_t strands;  // bit s set: strand s has to be swept (all reads of a quad share the class)
@@ -58,7 +58,8 @@ constexpr int SW_STAT_SLOTS = 1024;
 
 // sw_ladder.hip
 hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads,
-                              hipStream_t s);
+                              int32_t* unit_cnt, int32_t* bins, int n_ladders, int64_t max_quads, hipStream_t s);
+size_t sw_bin_bytes(int n_ladders);
 hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s);
 hipError_t launch_tally(const uint8_t* tag, const int16_t* h, int64_t n_reads,
                         const int32_t* unit_read_off, int32_t n_units, const int32_t* read_pair_id,
