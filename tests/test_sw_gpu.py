@@ -171,3 +171,40 @@ def test_short_reads_through_the_pruned_path(ctx, loci, readlen):
     bad = np.nonzero((tag != cls[:, 0]) | (h != cls[:, 1]) | (sc != cls[:, 2]))[0]
     assert len(bad) == 0, (len(bad), bad[:5], tag[bad[:5]], h[bad[:5]], cls[bad[:5]])
     assert (tag == 4).sum() > 20      # REPT reads: the case that exposed it
+
+
+def test_quads_across_units_any_unit_order(ctx, loci):
+    """Quads are packed by (ladder, class) across units: a read's result must not depend on which units surround
+    it.  The same reads are classified with the units in locus order and interleaved at random (with empty units
+    in between); per read the outputs must be identical, and equal to the reference's."""
+    sel = [l for l in loci if l["name"] in ("HD", "DM1", "SCA10", "OPMD", "FRDA", "ULD", "BPES")]
+    p = synth.SynthParams(coverage=25, readlen=150, min_units=3, max_units=55)
+    b = synth.build_batch(4242, sel, 5, p, workers=4)
+    reads = [synth.decode(r) for r in b.codes]
+    uro = np.asarray(b.unit_read_off, np.int64)
+    ctx.set_ladders(b.ladders)
+
+    def run(order, empties):
+        rr, off, lad, src = [], [0], [], []
+        for k, g in enumerate(order):
+            if k in empties:
+                off.append(len(rr)); lad.append(int(b.unit_ladder[g]))
+            rr += reads[uro[g]:uro[g + 1]]
+            src += list(range(uro[g], uro[g + 1]))
+            off.append(len(rr)); lad.append(int(b.unit_ladder[g]))
+        packed, woff, rlen = _lib.pack_reads(rr)
+        n = len(rr)
+        tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
+        ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, np.asarray(off, np.int32), np.asarray(lad, np.int32),
+                        len(lad), _lib.default_sw_params(max_read_len=150), tag, h, sc)
+        out = np.zeros((len(reads), 3), np.int32)
+        out[np.asarray(src)] = np.stack([tag, h, sc], 1)
+        return out
+
+    rng = np.random.default_rng(5)
+    a = run(list(range(b.n_units)), set())
+    c = run(list(rng.permutation(b.n_units)), set(rng.integers(0, b.n_units, 6).tolist()))
+    assert np.array_equal(a, c)
+    cls = po.ref_classify(reads, np.repeat(b.unit_ladder, np.diff(uro)), po.LocusSet(b.ladders), threads=0)
+    assert np.array_equal(a, cls[:, :3].astype(np.int32))
+    assert len(set(a[:, 0])) >= 5      # all tags occur
