@@ -526,7 +526,6 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             if (!need) { ++n_dropped; ++u; continue; }
             int bk = T.bestkey, bs = T.beststart;
             if (comb) {
-                ++n_combined;
                 // candidates entering the suffix: key = (H or E score field) + continuation (score | end cell)
                 int m = NEG;
 #pragma unroll
@@ -538,6 +537,24 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 const int cu = ((511 - col - blen) << 9) + (512 - 16 * R) - (col + 16 * R + blen - 3) * geK;
                 m += cu;
                 const bool c = m > bk;     // an equal key is impossible: trunk cells end at columns <= col
+                if (!full_dump) {
+                    // the template's exact score is known now: drop it unless it can pass the score filter and
+                    // beat the arg-max of some read (the bound above only had column max + |suffix| * match)
+                    int ks = max(m, bk);
+                    ks = max(ks, dpp_row_shr<0x111>(ks, ks));
+                    ks = max(ks, dpp_row_shr<0x112>(ks, ks));
+                    ks = max(ks, dpp_row_shr<0x114>(ks, ks));
+                    ks = max(ks, dpp_row_shr<0x118>(ks, ks));
+                    if (with_sfx) ks = max(ks, wb[(2 * R) * PS]);   // (its column shift does not touch the score)
+                    const int bestS = best >> 12, bestU = 511 - ((best >> 3) & 511);
+                    const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
+                    if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && (ks >> KSH) >= need_score) == 0) {
+                        ++n_dropped;
+                        ++u;
+                        continue;
+                    }
+                }
+                ++n_combined;
                 int st = 0;
                 if (__builtin_amdgcn_ballot_w64(c) != 0) {
                     // start payload of the winner (largest among equal keys); the sums are recomputed, not kept
