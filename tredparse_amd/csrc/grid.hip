@@ -792,6 +792,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
         for (int pass = 0; pass < npass; ++pass) {
             const bool last = pass == npass - 1;
             const int t0 = pass * TC;
+            const int nq = min(TC, n - t0);   // spanning pairs of this pass (wave-uniform)
             double b[TC];
             if (tab && !haploid) {
 #pragma unroll
@@ -833,14 +834,17 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                 if (__builtin_amdgcn_ballot_w64(ok) != 0) {   // else: row entirely below the diagonal here
                     double lp = 0;
                     if (tab) {
+                        // (entries past the unit's n_target are .5 + .5 = 1: whole groups of eight of them are skipped,
+                        //  which leaves the product bit-identical -- the median unit has 16 spanning pairs, not 32)
                         double prod = 1.0;
-                        if (haploid) {   // both alleles are the row's h1: .5 * roll + .5 * roll
-#pragma unroll
-                            for (int q = 0; q < TC; ++q) { const double av = readlane_d(cur.r1v, q); prod *= fmax(av + av, small); }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < TC; ++q) prod *= fmax(readlane_d(cur.r1v, q) + b[q], small);
-                        }
+#define TRED_PROD8(Q0, OTHER) _Pragma("unroll") for (int q = (Q0); q < (Q0) + 8; ++q) { \
+                            const double av = readlane_d(cur.r1v, q); prod *= fmax(av + (OTHER), small); }
+#define TRED_PROD(OTHER) TRED_PROD8(0, OTHER) \
+                        if (nq > 8) { TRED_PROD8(8, OTHER) if (nq > 16) { TRED_PROD8(16, OTHER) if (nq > 24) { TRED_PROD8(24, OTHER) } } }
+                        if (haploid) { TRED_PROD(av) }   // both alleles are the row's h1: .5 * roll + .5 * roll
+                        else { TRED_PROD(b[q]) }
+#undef TRED_PROD
+#undef TRED_PROD8
                         lp = log(prod);
                     }
                     if (ok) {
