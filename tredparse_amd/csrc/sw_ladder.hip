@@ -91,16 +91,12 @@ struct Track {
 // theirs); s_nop 1 covers the VALU-write -> DPP-read hazard.  in: x = lane value; out: fin = max over
 // the lanes above (NEG for the first lane of the row).
 __device__ __forceinline__ int row_excl_scan_max(int x) {
-    int fin = NEG;
-    asm volatile(
-        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(x), "+v"(fin));
-    return fin;
+    constexpr int IMIN = -2147483647 - 1;
+    x = max(x, dpp_row_shr<0x111>(IMIN, x));
+    x = max(x, dpp_row_shr<0x112>(IMIN, x));
+    x = max(x, dpp_row_shr<0x114>(IMIN, x));
+    x = max(x, dpp_row_shr<0x118>(IMIN, x));
+    return dpp_row_shr<0x111>(NEG, x);
 }
 
 // One DP column for all rows of the four alignments in this wave; LET = template letter (4 = N).
@@ -663,6 +659,13 @@ __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_
     const int thr = min(a.p.mismatch, a.p.gap_open) >= 5 * a.p.match ? (30 + a.p.match - 1) / a.p.match - 5 : 0;
     const bool filt = !full_dump && thr > 0 && ld->kmer_ok != 0 && ld->max_units > 0;
     const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
+    // the two 4096-bit presence maps of the ladder, in LDS: every base of every read looks both up, and a
+    // lookup in global memory (even an L1 hit) stalled the loop for its whole latency
+    __shared__ uint32_t bm[2][128];
+    if (filt) {
+        for (int k = threadIdx.x; k < 256; k += (int)blockDim.x) bm[k >> 7][k & 127] = a.seqw[ld->kmer_off[k >> 7] + (k & 127)];
+    }
+    __syncthreads();
     int n1 = 0, n2 = 0, n3 = 0;
     for (int rd = r0 + (int)threadIdx.x; rd < r1; rd += (int)blockDim.x) {
         int cls = ld->n_strands >= 2 ? 3 : 1;
@@ -670,8 +673,8 @@ __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_
         if (filt && L <= a.max_rows) {   // over-long reads go to the SW kernel, which flags them
             const int64_t off = a.read_off[rd];
             const int nb = (L + 15) >> 4;
-            const uint32_t* bm0 = a.seqw + ld->kmer_off[0];
-            const uint32_t* bm1 = a.seqw + ld->kmer_off[1];
+            const uint32_t* bm0 = bm[0];
+            const uint32_t* bm1 = bm[1];
             int cnt0 = 0, cnt1 = 0, since_n = 0;
             uint32_t win = 0, w = 0, m = 0;
             for (int i = 0; i < L; ++i) {
