@@ -460,6 +460,7 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     a.out_dump = out_dump;
     a.dump_templates = dump_templates;
     a.n_units = n_units;
+    a.n_ladders = n_ladders;
     a.max_rows = 16 * rows_for(max_len);
     a.p = *p;
     a.stats = nullptr;

@@ -328,13 +328,19 @@ struct UnitDesc {
 
 // Device-side counters of one pass (zeroed by the launch); the item ticket sits on its own cache line
 struct GridCounters {
+    // every counter that many workgroups add to sits on its own 64-byte line (atomics on one line serialise)
     unsigned long long pool_used;   // doubles handed out
-    int32_t n_items, next_prepare, next_reduce, n_deferred;
-    int32_t pad[26];
+    int32_t pad0[14];
+    int32_t n_items;
+    int32_t pad1[15];
+    int32_t next_prepare;
+    int32_t pad2[15];
+    int32_t next_reduce, n_deferred;
+    int32_t pad3[14];
     int32_t next_item;
-    int32_t pad2[31];
+    int32_t pad4[15];
 };
-static_assert(sizeof(GridCounters) == 256, "counter block layout");
+static_assert(sizeof(GridCounters) == 320, "counter block layout");
 
 constexpr int CB = 64;    // columns per work item of grid_pairs_kernel: one lane owns one h2 for all the item's rows
 constexpr int RG = 128;   // rows per item

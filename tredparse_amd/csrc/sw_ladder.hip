@@ -653,7 +653,8 @@ __device__ __forceinline__ int bin_of(int ladder, int cls) { return 3 * ladder +
 __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_class, int32_t* unit_cnt, int32_t* bin_total) {
     const int g = blockIdx.x;
     if (g >= a.n_units) return;
-    const int lad = a.unit_ladder[g];
+    // (device-resident unit tables are not validated by the host: keep a bad index from leaving the tables)
+    const int lad = min(max(a.unit_ladder[g], 0), a.n_ladders - 1);
     const LadderDesc* ld = a.ladders + lad;
     const bool full_dump = a.out_dump != nullptr;
     const int thr = min(a.p.mismatch, a.p.gap_open) >= 5 * a.p.match ? (30 + a.p.match - 1) / a.p.match - 5 : 0;
@@ -732,7 +733,7 @@ __global__ void bin_scan_kernel(int32_t* bins, int n_bins, int32_t* n_quads) {
 __global__ void scatter_kernel(SwArgs a, const uint8_t* read_class, const int32_t* unit_cnt, int32_t* bins, int32_t* perm) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n_units) return;
-    const int lad = a.unit_ladder[g];
+    const int lad = min(max(a.unit_ladder[g], 0), a.n_ladders - 1);
     int pos[4] = {0, 0, 0, 0};
     for (int c = 1; c < 4; ++c) {
         const int n = unit_cnt[4 * g + c];

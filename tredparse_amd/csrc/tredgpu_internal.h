@@ -47,6 +47,7 @@ struct SwArgs {
     int16_t* out_dump;
     int32_t dump_templates;
     int32_t n_units;
+    int32_t n_ladders;       // registered ladders (unit_ladder values outside [0, n_ladders) are clamped on the device)
     int32_t max_rows;        // 16 * rows-per-lane of the instantiation that will run
     tredgpu_sw_params p;
     unsigned long long* stats;  // [SW_STAT_SLOTS][8], slot = workgroup & (SW_STAT_SLOTS - 1): work counters: trunk cols, continuation-pass cols, templates combined/dropped/emitted-from-trunk, waves
