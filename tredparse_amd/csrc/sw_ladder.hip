@@ -179,23 +179,21 @@ __device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (
     }
 }
 
-// Per read (valid in lane 15 of its DPP row): true score of the best cell so far and of the current
-// column's maximum.  lane_scale = (row0 + col) * geK of the column held in H.
-struct ReadBound { int best, colmax; };
+// Per read (valid in lane 15 of its DPP row): upper bound of the score template u can reach at its end column,
+// max(trunk best, column max + |suffix| * match), in one reduction.  lane_scale = (row0 + col) * geK of the
+// column held in H; gain = |suffix| * match * K.
 template <int R>
-__device__ __forceinline__ ReadBound read_bound(const int (&H)[R], const Track& T, int lane_scale, int geK) {
+__device__ __forceinline__ int reach_bound(const int (&H)[R], const Track& T, int lane_scale, int geK, int gain) {
     int cmx = NEG, scale = lane_scale;
 #pragma unroll
     for (int r = 0; r < R; ++r) { cmx = max(cmx, H[r] - scale); scale += geK; }
-    int bk = T.bestkey;
-    cmx = max(cmx, dpp_row_shr<0x111>(cmx, cmx)); bk = max(bk, dpp_row_shr<0x111>(bk, bk));
-    cmx = max(cmx, dpp_row_shr<0x112>(cmx, cmx)); bk = max(bk, dpp_row_shr<0x112>(bk, bk));
-    cmx = max(cmx, dpp_row_shr<0x114>(cmx, cmx)); bk = max(bk, dpp_row_shr<0x114>(bk, bk));
-    cmx = max(cmx, dpp_row_shr<0x118>(cmx, cmx)); bk = max(bk, dpp_row_shr<0x118>(bk, bk));
-    ReadBound rb;
-    rb.best = bk >> KSH;
-    rb.colmax = cmx >> KSH;
-    return rb;
+    constexpr int IMIN = -2147483647 - 1;
+    int v = max(max(cmx, 0) + gain, T.bestkey);
+    v = max(v, dpp_row_shr<0x111>(IMIN, v));
+    v = max(v, dpp_row_shr<0x112>(IMIN, v));
+    v = max(v, dpp_row_shr<0x114>(IMIN, v));
+    v = max(v, dpp_row_shr<0x118>(IMIN, v));
+    return v >> KSH;
 }
 
 // Letters are packed 8 per 32-bit word (4 bits each).  A strand's trunk (<= 64 words) and branch words
@@ -504,19 +502,15 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             // ---- template u ends here on the trunk ----
             // Exact pruning: no cell of its suffix can score more than max(trunk best, column max + |suffix| *
             // match).  If that cannot reach the score filter (bam_parser.py:134) or beat the read's current
-            // arg-max key (score, -units) for ANY of the four reads, the template is dropped; if it can matter
-            // but the suffix cannot raise the trunk's best cell, the result is the trunk state.
-            bool need = true, comb = blen > 0;
+            // arg-max key (score, -units) for ANY of the four reads, the template is dropped.
+            bool need = true;
+            const bool comb = blen > 0;
             const int Tlen = alen + period * u + blen;
             if (!full_dump && blen > 0) {
                 const int bestS = best >> 12, bestU = 511 - ((best >> 3) & 511);
                 const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
-                const ReadBound rb = read_bound<R>(H, T, row0g + col * geK, geK);
-                const int top = max(rb.colmax, 0) + blen * a.p.match;
-                const bool relevant = min(kcap, max(rb.best, top)) >= need_score;
-                const bool may_improve = top > rb.best;
-                need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant) != 0;
-                comb = __builtin_amdgcn_ballot_w64(valid && jl == 15 && relevant && may_improve) != 0;
+                const int reach = reach_bound<R>(H, T, row0g + col * geK, geK, blen * mK);
+                need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && min(kcap, reach) >= need_score) != 0;
             }
             next_end += period;
             if (!need) { ++n_dropped; ++u; continue; }
