@@ -6,16 +6,17 @@
 //   /root/reference/tredparse/bam_parser.py:123-182  _parseReadSW (hangs :102-121, tags :139-168, arg-max :174)
 //
 // Design (not a translation of the striped SSE2 code):
-//  * one wavefront = four reads of one sample x locus unit, 16 lanes per read, R consecutive read
+//  * one wavefront = four reads of one ladder (any units), 16 lanes per read, R consecutive read
 //    rows per lane (R = ceil(maxlen/16)); the DP column lives in registers, lanes talk through DPP
-//    row shifts only (no LDS, no barriers), so a DPP row (16 lanes) is exactly one alignment.
+//    row shifts only (no barriers), so a DPP row (16 lanes) is exactly one alignment.
 //  * the vertical-gap term F is an exclusive max-plus prefix scan over the 16 lanes (4 DPP steps)
 //    instead of Farrar's data-dependent lazy-F loop.
 //  * shared-prefix ladder: templates prefix+repeat*u+suffix (u=1..max_units) share the trunk
-//    prefix+repeat*max_units; the trunk is swept once and the |suffix| branch columns are swept per u
-//    from a register copy of the trunk state -- 5.3x fewer cells than 2*max_units independent
-//    alignments for period 3 / 150 bp, and bit-identical because a forward column depends only on
-//    the columns to its left.
+//    prefix+repeat*max_units, swept once; a forward column depends only on the columns to its left.
+//  * suffix continuation vectors: what an alignment can still gain in the |suffix| columns after leaving
+//    the trunk at read row i does not depend on u; one reversed alignment of the read against the
+//    reversed suffix per strand gives it for every row, and a template's result is the trunk state at
+//    its end column combined with those vectors (see the block comment before sweep_column_free).
 //  * begin coordinates without the reference's reverse pass: every DP value is one int32
 //    score<<18 | start_col<<9 | start_row; integer max then picks (score, largest start column,
 //    largest start row), which is what the reverse pass reports (first column walking left whose
@@ -196,7 +197,7 @@ __device__ __forceinline__ int reach_bound(const int (&H)[R], const Track& T, in
     return v >> KSH;
 }
 
-// Letters are packed 8 per 32-bit word (4 bits each).  A strand's trunk (<= 64 words) and branch words
+// Letters are packed 8 per 32-bit word (4 bits each).  A strand's trunk (<= 64 words) and suffix words
 // are loaded once into one VGPR each, word k in lane k, and fetched per column with v_readlane (no
 // memory access in the column loop).
 __device__ __forceinline__ int letter_from(int words_vgpr, int idx) {
