@@ -440,7 +440,7 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
                          int16_t* out_h, int16_t* out_score, int16_t* out_dump, int32_t dump_templates) {
     if (n_reads == 0 || n_units == 0) return 0;
     const int n_ladders = (int)c->h_ladders.size();
-    const int64_t max_quads = n_reads / 4 + 3 * (int64_t)n_ladders + 1;   // one partial quad per (ladder, class) bin
+    const int64_t max_quads = sw_max_quads(n_reads, n_ladders);
     int rc;
     if ((rc = ensure(c, c->ws_quads, (size_t)max_quads * sizeof(Quad)))) return rc;
     if ((rc = ensure(c, c->ws_counter, 64))) return rc;
@@ -467,7 +467,7 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     if ((rc = ensure(c, c->ws_perm, (size_t)n_reads * sizeof(int32_t)))) return rc;
     if ((rc = ensure(c, c->ws_class, (size_t)n_reads))) return rc;
     a.perm = (const int32_t*)c->ws_perm.p;
-    if ((rc = ensure(c, c->ws_ucnt, (size_t)n_units * 4 * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->ws_ucnt, sw_unit_cnt_bytes(n_units)))) return rc;
     if ((rc = ensure(c, c->ws_bins, sw_bin_bytes(n_ladders)))) return rc;
     HIPCHK(c, launch_build_quads(a, (uint8_t*)c->ws_class.p, (int32_t*)c->ws_perm.p, (Quad*)c->ws_quads.p,
                                  (int32_t*)c->ws_counter.p, (int32_t*)c->ws_ucnt.p, (int32_t*)c->ws_bins.p, n_ladders,

@@ -425,11 +425,18 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             kcap = (cnt + 5) * a.p.match;  // lane 15 of each read holds the read's total
             if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && cnt >= kmer_thr) == 0) continue;
         }
-        // No alignment scores more than cap; a template only matters if it passes the score filter and beats
-        // the read's arg-max so far, and at equal score the smaller unit count wins: once
-        // max(30, best score + 1) > cap for every read of the wave, the rest of this strand changes nothing.
+        // Strand exit.  No alignment scores more than cap; a template only matters if it passes its score filter
+        // and beats the read's arg-max so far, and at equal score the smaller unit count wins: once neither is
+        // possible any more for any read of the wave, the rest of this strand changes nothing.  Quads hold reads
+        // of one level of the 6-mer count (read_class_kernel), so the four reads get there together.
         const int cap = min(kcap, L * a.p.match);
-        if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && max(30, (best >> 12) + 1) <= cap) == 0) continue;
+        // template un can still matter for this read: its score filter max(min(L, T)/2, 30) (bam_parser.py:133-134,
+        // growing with un) and the arg-max so far are within reach of cap
+        auto still_open = [&](int un) {
+            const int min_score = max(min(L, alen + period * un + blen) >> 1, 30);
+            return max(min_score, (best >> 12) + 1) <= cap;
+        };
+        if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(max_units > 0 ? 1 : 0)) == 0) continue;
 
         Rows<R> J;
         int H[R], E[R];
@@ -514,7 +521,12 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && min(kcap, reach) >= need_score) != 0;
             }
             next_end += period;
-            if (!need) { ++n_dropped; ++u; continue; }
+            if (!need) {
+                ++n_dropped;
+                ++u;
+                if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
+                continue;
+            }
             int bk = T.bestkey, bs = T.beststart;
             if (comb) {
                 // candidates entering the suffix: key = (H or E score field) + continuation (score | end cell)
@@ -542,6 +554,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                     if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && (ks >> KSH) >= need_score) == 0) {
                         ++n_dropped;
                         ++u;
+                        if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
                         continue;
                     }
                 }
@@ -610,7 +623,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 }
             }
             ++u;
-            if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && max(30, (best >> 12) + 1) <= cap) == 0) break;
+            if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
         }
     }
     if (a.stats != nullptr && lane < 6) {
@@ -635,15 +648,20 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
 // Strand classes and quad formation.  The exact 6-mer strand filter (see sw_cont_kernel) is evaluated per read
 // here, once: bit s of the class = "strand s can reach the score filter for this read".  Reads that need no strand
 // at all are finished on the spot (no candidate: tag NONE).  The others are packed four to a wavefront by
-// (ladder, class) across the units of a batch -- a read's alignment does not depend on its wave-mates, so only
-// the last quad of each of the 3 x n_ladders bins can be partial (per-unit packing left 7 % of the read slots
-// of the bench batch empty).  Bin b = 3 * ladder + k holds class {1, 3, 2}[k].
-//   read_class_kernel   classes, per-unit class counts, bin totals (one atomic per unit and class)
+// (ladder, class, level) across the units of a batch -- a read's alignment does not depend on its wave-mates, so
+// only the last quad of each bin can be partial (per-unit packing left 7 % of the read slots of the bench batch
+// empty).  The level is the read's count of 6-mers present in the templates, in steps of 6: that count caps the
+// read's score, a template of length T needs a score of min(L, T)/2, so reads of one level stop needing the
+// trunk at about the same template and the wave can leave the strand together (strand exit in sw_cont_kernel).
+// Bin b = (3 * ladder + k) * SW_LEVELS + level holds class {1, 3, 2}[k].
+//   read_class_kernel   classes and levels, per-unit counts per bin, bin totals (one atomic per unit and bin)
 //   bin_scan_kernel     bin -> first slot in the permutation / first quad; the quad count of the launch
 //   scatter_kernel      each unit reserves its run inside its bins and writes its reads' indices there
 //   fill_quads_kernel   one thread per quad: its bin by binary search over the quad offsets
 constexpr int BIN_STRIDE = 16;   // ints: every bin counter on its own 64-byte line
-__device__ __forceinline__ int bin_of(int ladder, int cls) { return 3 * ladder + (cls == 1 ? 0 : (cls == 3 ? 1 : 2)); }
+constexpr int SW_LEVELS = 16;
+constexpr int UNIT_BINS = 3 * SW_LEVELS;   // bins one unit can feed
+__device__ __forceinline__ int class_slot(int cls) { return cls == 1 ? 0 : (cls == 3 ? 1 : 2); }
 
 __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_class, int32_t* unit_cnt, int32_t* bin_total) {
     const int g = blockIdx.x;
@@ -658,13 +676,15 @@ __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_
     // the two 4096-bit presence maps of the ladder, in LDS: every base of every read looks both up, and a
     // lookup in global memory (even an L1 hit) stalled the loop for its whole latency
     __shared__ uint32_t bm[2][128];
+    __shared__ int hist[UNIT_BINS];
     if (filt) {
         for (int k = threadIdx.x; k < 256; k += (int)blockDim.x) bm[k >> 7][k & 127] = a.seqw[ld->kmer_off[k >> 7] + (k & 127)];
     }
+    if (threadIdx.x < UNIT_BINS) hist[threadIdx.x] = 0;
     __syncthreads();
-    int n1 = 0, n2 = 0, n3 = 0;
     for (int rd = r0 + (int)threadIdx.x; rd < r1; rd += (int)blockDim.x) {
         int cls = ld->n_strands >= 2 ? 3 : 1;
+        int level = SW_LEVELS - 1;
         const int L = a.read_len[rd];
         if (filt && L <= a.max_rows) {   // over-long reads go to the SW kernel, which flags them
             const int64_t off = a.read_off[rd];
@@ -686,34 +706,49 @@ __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_
                 }
             }
             cls = (cnt0 >= thr ? 1 : 0) | (cnt1 >= thr ? 2 : 0);
+            level = min(SW_LEVELS - 1, max(cls & 1 ? cnt0 : 0, cls & 2 ? cnt1 : 0) / 6);
         }
-        read_class[rd] = (uint8_t)cls;
-        n1 += cls == 1; n2 += cls == 2; n3 += cls == 3;
+        read_class[rd] = (uint8_t)(cls | level << 2);
         if (cls == 0) {   // no strand can produce a candidate: bam_parser.py:171-172 "if not res: return"
             a.out_tag[rd] = TREDGPU_TAG_NONE;
             a.out_h[rd] = 0;
             a.out_score[rd] = 0;
+        } else {
+            atomicAdd(&hist[class_slot(cls) * SW_LEVELS + level], 1);
         }
     }
-    // one wavefront per unit: wave-wide sums by DPP-free ballots are not available for counts, use shuffles
-    for (int o = 32; o > 0; o >>= 1) {
-        n1 += __shfl_down(n1, o);
-        n2 += __shfl_down(n2, o);
-        n3 += __shfl_down(n3, o);
-    }
-    if (threadIdx.x == 0) {
-        unit_cnt[4 * g + 1] = n1; unit_cnt[4 * g + 2] = n2; unit_cnt[4 * g + 3] = n3;
-        if (n1) atomicAdd(bin_total + (size_t)bin_of(lad, 1) * BIN_STRIDE, n1);
-        if (n3) atomicAdd(bin_total + (size_t)bin_of(lad, 3) * BIN_STRIDE, n3);
-        if (n2) atomicAdd(bin_total + (size_t)bin_of(lad, 2) * BIN_STRIDE, n2);
+    __syncthreads();
+    if (threadIdx.x < UNIT_BINS) {
+        const int n = hist[threadIdx.x];
+        unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x] = n;
+        if (n) atomicAdd(bin_total + ((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE, n);
     }
 }
 
-// bins[b * BIN_STRIDE + 0] total reads, +1 first permutation slot, +2 first quad, +3 fill cursor
-__global__ void bin_scan_kernel(int32_t* bins, int n_bins, int32_t* n_quads) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int slot = 0, quad = 0;
-    for (int b = 0; b < n_bins; ++b) {
+// bins[b * BIN_STRIDE + 0] total reads, +1 first permutation slot, +2 first quad, +3 fill cursor.
+// One block: every thread sums a contiguous chunk of bins, the chunk totals are scanned in LDS.
+__global__ __launch_bounds__(1024) void bin_scan_kernel(int32_t* bins, int n_bins, int32_t* n_quads) {
+    __shared__ int cs[1024], cq[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n_bins + 1023) / 1024;
+    const int b0 = min(t * chunk, n_bins), b1 = min(b0 + chunk, n_bins);
+    int slots = 0, quads = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int n = bins[(size_t)b * BIN_STRIDE];
+        slots += n;
+        quads += (n + 3) >> 2;
+    }
+    cs[t] = slots; cq[t] = quads;
+    __syncthreads();
+    if (t == 0) {
+        int s = 0, q = 0;
+        for (int k = 0; k < 1024; ++k) { const int a_ = cs[k], b_ = cq[k]; cs[k] = s; cq[k] = q; s += a_; q += b_; }
+        bins[(size_t)n_bins * BIN_STRIDE + 2] = q;   // sentinel for the binary search
+        *n_quads = q;
+    }
+    __syncthreads();
+    int slot = cs[t], quad = cq[t];
+    for (int b = b0; b < b1; ++b) {
         int32_t* e = bins + (size_t)b * BIN_STRIDE;
         e[1] = slot;
         e[2] = quad;
@@ -721,25 +756,28 @@ __global__ void bin_scan_kernel(int32_t* bins, int n_bins, int32_t* n_quads) {
         slot += e[0];
         quad += (e[0] + 3) >> 2;
     }
-    bins[(size_t)n_bins * BIN_STRIDE + 2] = quad;   // sentinel for the binary search
-    *n_quads = quad;
 }
 
-__global__ void scatter_kernel(SwArgs a, const uint8_t* read_class, const int32_t* unit_cnt, int32_t* bins, int32_t* perm) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void scatter_kernel(SwArgs a, const uint8_t* read_class, const int32_t* unit_cnt, int32_t* bins,
+                                                       int32_t* perm) {
+    const int g = blockIdx.x;
     if (g >= a.n_units) return;
     const int lad = min(max(a.unit_ladder[g], 0), a.n_ladders - 1);
-    int pos[4] = {0, 0, 0, 0};
-    for (int c = 1; c < 4; ++c) {
-        const int n = unit_cnt[4 * g + c];
-        if (n == 0) continue;
-        int32_t* e = bins + (size_t)bin_of(lad, c) * BIN_STRIDE;
-        pos[c] = e[1] + atomicAdd(e + 3, n);
+    __shared__ int pos[UNIT_BINS];
+    if (threadIdx.x < UNIT_BINS) {
+        const int n = unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x];
+        int p = 0;
+        if (n) {
+            int32_t* e = bins + ((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE;
+            p = e[1] + atomicAdd(e + 3, n);
+        }
+        pos[threadIdx.x] = p;
     }
+    __syncthreads();
     const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
-    for (int r = r0; r < r1; ++r) {
-        const int c = read_class[r] & 3;
-        if (c != 0) perm[pos[c]++] = r;
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += (int)blockDim.x) {
+        const int c = read_class[r] & 3, level = read_class[r] >> 2;
+        if (c != 0) perm[atomicAdd(&pos[class_slot(c) * SW_LEVELS + level], 1)] = r;
     }
 }
 
@@ -755,10 +793,10 @@ __global__ void fill_quads_kernel(const int32_t* bins, int n_bins, const int32_t
     const int j = q - e[2];
     const int cls[3] = {1, 3, 2};
     Quad qd;
-    qd.ladder = lo / 3;
+    qd.ladder = lo / UNIT_BINS;
     qd.first = e[1] + 4 * j;
     qd.count = min(4, e[0] - 4 * j);
-    qd.strands = cls[lo % 3];
+    qd.strands = cls[(lo / SW_LEVELS) % 3];
     quads[q] = qd;
 }
 
@@ -804,16 +842,18 @@ hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* per
     hipError_t e = hipMemsetAsync(n_quads, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return e;
     if (a.n_units <= 0) return hipSuccess;
-    const int n_bins = 3 * n_ladders;
+    const int n_bins = UNIT_BINS * n_ladders;
     if ((e = hipMemsetAsync(bins, 0, sw_bin_bytes(n_ladders), s)) != hipSuccess) return e;
     read_class_kernel<<<a.n_units, 64, 0, s>>>(a, read_class, unit_cnt, bins);
-    bin_scan_kernel<<<1, 64, 0, s>>>(bins, n_bins, n_quads);
-    scatter_kernel<<<(a.n_units + 255) / 256, 256, 0, s>>>(a, read_class, unit_cnt, bins, perm);
+    bin_scan_kernel<<<1, 1024, 0, s>>>(bins, n_bins, n_quads);
+    scatter_kernel<<<a.n_units, 64, 0, s>>>(a, read_class, unit_cnt, bins, perm);
     fill_quads_kernel<<<(unsigned)((max_quads + 255) / 256), 256, 0, s>>>(bins, n_bins, n_quads, quads);
     return hipGetLastError();
 }
 
-size_t sw_bin_bytes(int n_ladders) { return ((size_t)3 * n_ladders + 1) * BIN_STRIDE * sizeof(int32_t); }
+size_t sw_unit_cnt_bytes(int n_units) { return (size_t)n_units * UNIT_BINS * sizeof(int32_t); }
+int64_t sw_max_quads(int64_t n_reads, int n_ladders) { return n_reads / 4 + (int64_t)UNIT_BINS * n_ladders + 1; }
+size_t sw_bin_bytes(int n_ladders) { return ((size_t)UNIT_BINS * n_ladders + 1) * BIN_STRIDE * sizeof(int32_t); }
 
 hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s) {
     if (max_quads <= 0) return hipSuccess;

@@ -61,6 +61,8 @@ constexpr int SW_STAT_SLOTS = 1024;
 hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads,
                               int32_t* unit_cnt, int32_t* bins, int n_ladders, int64_t max_quads, hipStream_t s);
 size_t sw_bin_bytes(int n_ladders);
+size_t sw_unit_cnt_bytes(int n_units);
+int64_t sw_max_quads(int64_t n_reads, int n_ladders);   // one partial quad per (ladder, class, level) bin
 hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s);
 hipError_t launch_tally(const uint8_t* tag, const int16_t* h, int64_t n_reads,
                         const int32_t* unit_read_off, int32_t n_units, const int32_t* read_pair_id,
