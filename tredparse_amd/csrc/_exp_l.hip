@@ -1,0 +1,893 @@
+// sw_ladder.hip -- template-ladder Smith-Waterman + read tagging for gfx950 (MI355X, CDNA4).
+//
+// Replaces, for a whole batch of reads in one launch:
+//   /root/reference/src/ssw.c:780-871        ssw_align (forward pass :123-345/:371-547, reverse pass :839-851)
+//   /root/reference/src/ssw_wrap.py:177-227  Aligner.align incl. the score / length filter :214-220
+//   /root/reference/tredparse/bam_parser.py:123-182  _parseReadSW (hangs :102-121, tags :139-168, arg-max :174)
+//
+// Design (not a translation of the striped SSE2 code):
+//  * one wavefront = four reads of one ladder (any units), 16 lanes per read, R consecutive read
+//    rows per lane (R = ceil(maxlen/16)); the DP column lives in registers, lanes talk through DPP
+//    row shifts only (no barriers), so a DPP row (16 lanes) is exactly one alignment.
+//  * the vertical-gap term F is an exclusive max-plus prefix scan over the 16 lanes (4 DPP steps)
+//    instead of Farrar's data-dependent lazy-F loop.
+//  * shared-prefix ladder: templates prefix+repeat*u+suffix (u=1..max_units) share the trunk
+//    prefix+repeat*max_units, swept once; a forward column depends only on the columns to its left.
+//  * suffix continuation vectors: what an alignment can still gain in the |suffix| columns after leaving
+//    the trunk at read row i does not depend on u; one reversed alignment of the read against the
+//    reversed suffix per strand gives it for every row, and a template's result is the trunk state at
+//    its end column combined with those vectors (see the block comment before sweep_column_free).
+//  * begin coordinates without the reference's reverse pass: every DP value is one int32
+//    score<<18 | start_col<<9 | start_row; integer max then picks (score, largest start column,
+//    largest start row), which is what the reverse pass reports (first column walking left whose
+//    max equals the score, smallest reversed row).  End coordinates use the key
+//    score<<18 | (511-col)<<9 | (511-row): its max is "first column reaching the max, smallest row".
+//    Both rules are validated against the compiled reference in oracle/ladder_model.c's tests.
+#include "tredgpu_internal.h"
+
+namespace tredgpu {
+namespace {
+
+constexpr int KSH = 18;
+constexpr int KONE = 1 << KSH;
+constexpr int PAYMASK = KONE - 1;
+constexpr int NEG = -(1 << 30);
+constexpr int PADNEG = -64 * KONE;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_row_shr(int old, int x) {
+    // row_shr:n inside a 16-lane DPP row; lanes without a source keep `old`
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, 0xF, false);
+}
+
+// v_add3_u32 with the wave-uniform column term in an SGPR.  Written as asm so that the compiler cannot
+// re-associate max(diag + S, fresh + S) into max(diag, fresh) + S (one more VALU op per cell).
+__device__ __forceinline__ int add3_vsv(int v0, int s1, int v2) {
+    int d;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(v0), "s"(s1), "v"(v2));
+    return d;
+}
+__device__ __forceinline__ int max3(int a, int b, int c) { return max(max(a, b), c); }
+
+// inclusive max scan over the 16 lanes of a DPP row (old = x: lanes without a source keep x)
+__device__ __forceinline__ int row_scan_max(int x) {
+    x = max(x, dpp_row_shr<0x111>(x, x));
+    x = max(x, dpp_row_shr<0x112>(x, x));
+    x = max(x, dpp_row_shr<0x114>(x, x));
+    x = max(x, dpp_row_shr<0x118>(x, x));
+    return x;
+}
+
+template <int CTRL>
+__device__ __forceinline__ void pair_step(int& k, int& s) {
+    const int tk = dpp_row_shr<CTRL>(k, k);
+    const int ts = dpp_row_shr<CTRL>(s, s);
+    const bool c = tk > k;
+    k = c ? tk : k;
+    s = c ? ts : s;
+}
+
+// Per-lane constants of one read ("job").  All DP values live in the anti-diagonal-scaled domain
+//   X~[i][c] = X[i][c] + (i + c) * ge * K
+// in which the three recurrences lose their per-cell gap-extension subtractions:
+//   F~[i]   = max(F~[i-1], H~[i-1] - c0)          c0 = (go - ge) * K
+//   E~[c+1] = max(E~[c],   H~[c]   - c0)
+//   H~t     = max(D~ + s + 2geK, fresh~ + s, E~)
+// so F~ inside a lane is a plain prefix max and across lanes a plain DPP max scan.
+template <int R>
+struct Rows {
+    int S[4][R];  // (score vs template letter 0..3) * K + 2*ge*K; PADNEG for padding rows
+    int rowc0;    // i0 + i0*ge*K for the lane's first row i0: the row part of a fresh start in the scaled
+                  // domain; row r adds r*(1 + ge*K), folded into the wave-uniform column term (an SGPR per row)
+};
+
+struct Track {
+    int bestkey;    // score<<18 | (511-col)<<9 | (511-row), true (unscaled) score
+    int beststart;  // packed value of that cell (start col/row in the low 18 bits)
+    int ceil;       // bestkey | PAYMASK: what a cell must exceed to be a new best
+};
+
+// inclusive max scan over the 16 lanes of a DPP row fused with the exclusive shift, as one asm block:
+// v_max_i32_dpp reads its own and the neighbour's value (lanes without a source are disabled and keep
+// theirs); s_nop 1 covers the VALU-write -> DPP-read hazard.  in: x = lane value; out: fin = max over
+// the lanes above (NEG for the first lane of the row).
+__device__ __forceinline__ int row_excl_scan_max(int x) {
+    constexpr int IMIN = -2147483647 - 1;
+    x = max(x, dpp_row_shr<0x111>(IMIN, x));
+    x = max(x, dpp_row_shr<0x112>(IMIN, x));
+    x = max(x, dpp_row_shr<0x114>(IMIN, x));
+    x = max(x, dpp_row_shr<0x118>(IMIN, x));
+    return dpp_row_shr<0x111>(NEG, x);
+}
+
+// One DP column for all rows of the four alignments in this wave; LET = template letter (4 = N).
+//   s_fresh = (col<<9) + col*geK - 2*geK   (wave-uniform)      s_scale = col*geK
+template <int R, int LET>
+__device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int (&E)[R], Track& T,
+                                             int col, int row0, int s_fresh, int s_scale, int geK,
+                                             int c0, int row0g) {
+    const int hup = dpp_row_shr<0x111>(NEG, H[R - 1]);  // last row of the lane above, previous column
+    int ht[R], pl[R];
+    int diag = hup;
+    int run = NEG;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int S;
+        if (LET < 4) S = J.S[LET][r];
+        else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;  // N column: 0 against every real row
+        const int t1 = diag + S;                          // extend the alignment ending at (row-1, col-1)
+        const int t2 = add3_vsv(J.rowc0, s_fresh + r * (1 + geK), S);   // or start a new one here
+        const int v = max3(t1, t2, E[r]);
+        diag = H[r];
+        ht[r] = v;
+        pl[r] = run;                                      // F~ from this lane's rows above
+        const int q = v - c0;
+        run = max(run, q);
+        // E~ for the next column.  Fed from H without the vertical-gap term: a vertical gap followed by
+        // a horizontal one has an equal-score twin (horizontal, then vertical) with the same end points
+        // that the F recurrence does admit, so nothing is lost (ssw.c:238 makes the same choice).
+        E[r] = max(E[r], q);
+    }
+    // exclusive max scan across the 16 lanes: F~ entering this lane from the lanes above
+    const int fin = row_excl_scan_max(run);
+#pragma unroll
+    for (int r = 0; r < R; ++r) H[r] = max3(ht[r], pl[r], fin);
+    // running best: only columns in which some lane could beat its best take the exact path.
+    // run + c0 = max over this lane's rows of H~ without the vertical-gap term (a best cell never ends
+    // in a gap); minus (row0 + col)*geK it over-estimates every row's true value by <= (R-1)*geK.
+    const int lane_scale = row0g + s_scale;
+    const bool trig = run + c0 - lane_scale > T.ceil;
+    if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+        // exact: does some row of this lane score more than the lane's best?  (a later column never wins a tie)
+        int tr[R];
+        int m0 = NEG;
+        int rs = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            tr[r] = H[r] - rs;  // still carries the lane's scale, a multiple of K
+            rs += geK;
+            m0 = max(m0, tr[r]);
+        }
+        const bool imp = m0 - lane_scale > T.ceil;
+        if (__builtin_amdgcn_ballot_w64(imp) != 0) {
+            // the row: maximum of score<<18 | (R-1-r) (smallest row among equal scores), then its packed value
+            int m = NEG;
+#pragma unroll
+            for (int r = 0; r < R; ++r) m = max(m, (tr[r] & ~PAYMASK) | (R - 1 - r));
+            int st = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) st = ((tr[r] & ~PAYMASK) | (R - 1 - r)) == m ? tr[r] : st;
+            // -> score<<18 | (511-col)<<9 | (511-row)
+            const int cand = m - lane_scale + (((511 - col) << 9) + (511 - (R - 1)) - row0);
+            T.bestkey = imp ? cand : T.bestkey;
+            T.beststart = imp ? st - lane_scale : T.beststart;
+            T.ceil = T.bestkey | PAYMASK;
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (&H)[R], int (&E)[R], Track& T,
+                                             int col, int row0, int geK, int c0, int row0g) {
+    const int s_scale = col * geK;
+    const int s_fresh = (col << 9) + s_scale - 2 * geK;
+    switch (letter) {
+        case 0: sweep_column<R, 0>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+        case 1: sweep_column<R, 1>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+        case 2: sweep_column<R, 2>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+        case 3: sweep_column<R, 3>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+        default: sweep_column<R, 4>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
+    }
+}
+
+// Per read (valid in lane 15 of its DPP row): upper bound of the score template u can reach at its end column,
+// max(trunk best, column max + |suffix| * match), in one reduction.  lane_scale = (row0 + col) * geK of the
+// column held in H; gain = |suffix| * match * K.
+template <int R>
+__device__ __forceinline__ int reach_bound(const int (&H)[R], const Track& T, int lane_scale, int geK, int gain) {
+    int cmx = NEG, scale = lane_scale;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { cmx = max(cmx, H[r] - scale); scale += geK; }
+    constexpr int IMIN = -2147483647 - 1;
+    int v = max(max(cmx, 0) + gain, T.bestkey);
+    v = max(v, dpp_row_shr<0x111>(IMIN, v));
+    v = max(v, dpp_row_shr<0x112>(IMIN, v));
+    v = max(v, dpp_row_shr<0x114>(IMIN, v));
+    v = max(v, dpp_row_shr<0x118>(IMIN, v));
+    return v >> KSH;
+}
+
+// Letters are packed 8 per 32-bit word (4 bits each).  A strand's trunk (<= 64 words) and suffix words
+// are loaded once into one VGPR each, word k in lane k, and fetched per column with v_readlane (no
+// memory access in the column loop).
+__device__ __forceinline__ int letter_from(int words_vgpr, int idx) {
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(words_vgpr, idx >> 3);
+    return (int)((w >> ((idx & 7) * 4)) & 7u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Suffix continuation.  Every template prefix + repeat*u + suffix ends with the same |suffix| columns, so what
+// an alignment can still gain after leaving the trunk at read row i does not depend on u.  One reversed
+// alignment of the read against the reversed suffix (once per read and strand, |suffix| columns) yields, for
+// every row, the weight and the end cell of the best continuation
+//     WH[i]: the alignment leaves trunk cell (i, c) by a match at (i+1, c+1)
+//     WE[i]: it leaves inside a horizontal gap (trunk E[i][c+1], next match in row i+1)
+// and a template's result is max(trunk best, max_i H[i][c] + WH[i], max_i E[i][c+1] + WE[i], best alignment
+// inside the suffix alone) -- about one column's worth of work per template instead of |suffix| columns.
+// Packing makes the tie rules carry over: the reversed alignment's "start" payload (largest reversed column,
+// largest reversed row) is the forward end cell with the smallest column, then the smallest row; the start
+// coordinates travel in the trunk values' payload.  The reversed pass uses the unrestricted recurrences (E fed
+// from H including the vertical-gap term) and the junction admits H - go: every Gotoh path then has an
+// equal-score representative that is restricted (no vertical-then-horizontal gap) on the trunk side only.
+// tools/proto_continuation.py checks the formulation against the CPU oracle in plain integers.
+constexpr int NEGH = -(1 << 29);
+
+template <int R, int LET>
+__device__ __forceinline__ void sweep_column_free(const Rows<R>& J, int (&H)[R], int (&E)[R], int s_fresh,
+                                                  int geK, int c0) {
+    const int hup = dpp_row_shr<0x111>(NEG, H[R - 1]);
+    int ht[R], pl[R];
+    int diag = hup;
+    int run = NEG;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int S;
+        if (LET < 4) S = J.S[LET][r];
+        else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;
+        const int t1 = diag + S;
+        const int t2 = add3_vsv(J.rowc0, s_fresh + r * (1 + geK), S);
+        const int v = max3(t1, t2, E[r]);
+        diag = H[r];
+        ht[r] = v;
+        pl[r] = run;
+        run = max(run, v - c0);
+    }
+    const int fin = row_excl_scan_max(run);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        H[r] = max3(ht[r], pl[r], fin);
+        E[r] = max(E[r], H[r] - c0);   // unrestricted: a horizontal gap may follow a vertical one
+    }
+}
+
+// last reversed column: only the cells entered by a match (or started there) are needed
+template <int R, int LET>
+__device__ __forceinline__ void match_column(const Rows<R>& J, const int (&H)[R], int (&D)[R], int s_fresh, int geK) {
+    int diag = dpp_row_shr<0x111>(NEG, H[R - 1]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int S;
+        if (LET < 4) S = J.S[LET][r];
+        else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;
+        D[r] = max(diag + S, add3_vsv(J.rowc0, s_fresh + r * (1 + geK), S));
+        diag = H[r];
+    }
+}
+
+__device__ __forceinline__ int row_mirror(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false); }
+
+// reversed position x of this lane's register r  ->  forward row (i + 1) = 16R - 1 - x: the vector indexed by
+// forward row i is the mirrored one moved up by one row (NEGH for the last row: nothing left to match)
+template <int R>
+__device__ __forceinline__ void mirror_up(const int (&X)[R], int add, int* out, int stride) {
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) out[r * stride] = max(row_mirror(X[R - 2 - r]) + add, NEGH);
+    const int m0 = row_mirror(X[R - 1]);
+    const int nx = __builtin_amdgcn_update_dpp(NEGH, m0, 0x101, 0xF, 0xF, false);  // row_shl:1
+    out[(R - 1) * stride] = max(nx + add, NEGH);
+}
+
+template <int CTRL>
+__device__ __forceinline__ void pair_step_lex(int& k, int& s) {
+    const int tk = dpp_row_shr<CTRL>(k, k);
+    const int ts = dpp_row_shr<CTRL>(s, s);
+    const bool c = tk > k || (tk == k && ts > s);
+    k = c ? tk : k;
+    s = c ? ts : s;
+}
+
+// Codes of R consecutive read rows i_lo .. i_lo+R-1 (R <= 16): they span at most two words of the 2-bit codes and
+// two words of the N mask (tredgpu.h read packing), so four loads fetch them all.  code2: 2 bits per row;
+// nmask: bit k = row i_lo+k is N.  Rows >= L hold garbage (the caller pads them).
+template <int R>
+__device__ __forceinline__ void load_rows(const SwArgs& a, int64_t off, int L, int i_lo, uint32_t& code2, uint32_t& nmask) {
+    const int nb = (L + 15) >> 4, nm = (L + 31) >> 5;
+    const int wl = max(nb - 1, 0), ml = max(nm - 1, 0);
+    const int wi = i_lo >> 4, mi = i_lo >> 5;
+    const uint32_t w0 = a.packed[off + min(wi, wl)], w1 = a.packed[off + min(wi + 1, wl)];
+    const uint32_t m0 = a.packed[off + nb + min(mi, ml)], m1 = a.packed[off + nb + min(mi + 1, ml)];
+    code2 = (uint32_t)((((uint64_t)w1 << 32) | w0) >> ((i_lo & 15) * 2));
+    nmask = (uint32_t)((((uint64_t)m1 << 32) | m0) >> (i_lo & 31));
+}
+
+// Match/mismatch profile of this lane's R rows.  reversed: position x of the lane layout holds read row
+// 16R-1-x (padding first), the layout of the continuation pass.
+template <int R>
+__device__ __forceinline__ void build_profile(Rows<R>& J, const SwArgs& a, int64_t off, int L, int row0, bool reversed,
+                                              int mK, int xK, int geK) {
+    // (the profile is the same for both strands; the empty asm keeps the compiler from hoisting it out of the
+    //  strand loop, where the forward and the reversed one would be live together: 2 x 4R registers)
+    asm volatile("" : "+v"(L));
+    J.rowc0 = row0 + row0 * geK;
+    const int i_lo = reversed ? 16 * R - R - row0 : row0;
+    uint32_t code2, nmask;
+    load_rows<R>(a, off, L, i_lo, code2, nmask);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = reversed ? R - 1 - r : r;
+        const int i = i_lo + k;
+        const int code = i >= L ? 5 : (((nmask >> k) & 1u) ? 4 : (int)((code2 >> (2 * k)) & 3u));
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            J.S[l][r] = code == 5 ? PADNEG : (code == 4 ? 0 : (code == l ? mK : xK)) + 2 * geK;
+    }
+}
+
+template <int R, int W>
+__global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
+    // One wavefront per workgroup: quads differ a lot in length (pruning), and a wave slot freed by a short
+    // quad is only refilled when a whole new workgroup fits.
+    // continuation vectors of the strand being swept: [WH rows | WE rows | suffix-only best: key, start][64 lanes]
+    constexpr int PS = 64;
+    __shared__ int wbuf[(2 * R + 2) * PS];
+    const int lane = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x;
+    const int nq = *a.n_quads;
+    if (q >= nq) return;
+    const int q_ladder = __builtin_amdgcn_readfirstlane(a.quads[q].ladder);
+    const int q_first = __builtin_amdgcn_readfirstlane(a.quads[q].first);
+    const int q_strands = __builtin_amdgcn_readfirstlane(a.quads[q].strands);
+    const int q_count = __builtin_amdgcn_readfirstlane(a.quads[q].count);
+    const LadderDesc* ld = a.ladders + q_ladder;
+    const int period = __builtin_amdgcn_readfirstlane(ld->period);
+    const int max_units = __builtin_amdgcn_readfirstlane(ld->max_units);
+    const int n_strands = __builtin_amdgcn_readfirstlane(ld->n_strands);
+
+    const int job = lane >> 4, jl = lane & 15;
+    const bool valid = job < q_count;
+    int L, row0;
+    int64_t off;
+    bool too_long;
+    {
+        const int64_t rd = valid ? (int64_t)a.perm[q_first + job] : 0;
+        L = valid ? a.read_len[rd] : 0;
+        too_long = L > 16 * R;  // not representable in this instantiation: flagged, not aligned
+        if (too_long) L = 0;
+        off = valid ? a.read_off[rd] : 0;
+        row0 = jl * R;
+    }
+    const int mK = a.p.match * KONE;
+    const int xK = -a.p.mismatch * KONE;
+    const int geK = a.p.gap_extend * KONE;
+    const int c0 = (a.p.gap_open - a.p.gap_extend) * KONE;
+    const int flank = a.p.flank;
+    const bool full_dump = a.out_dump != nullptr;  // wave-uniform
+    int* const wb = wbuf + lane;
+
+    // this lane's rows as 2-bit codes / N-or-padding flags, for the 6-mer filter
+    uint32_t pk = 0, nk = 0;
+    if (2 * R + 10 <= 32) {
+        uint32_t code2, nmask;
+        load_rows<R>(a, off, L, row0, code2, nmask);
+        const int n_real = min(max(L - row0, 0), R);                       // rows of this lane inside the read
+        pk = code2 & ((1u << (2 * R)) - 1u);                               // (codes of N / padding rows are never
+        nk = (nmask | ~((1u << n_real) - 1u)) & ((1u << R) - 1u);          //  looked at: their windows count as present)
+    }
+    // REPT cut-off: per-read ceil(L/period) with --useclippedreads, else the ladder's (bam_parser.py:154-155)
+    const int mu_rept = a.p.clip ? (L + period - 1) / period : max_units;
+
+    // arg-max so far, one word: (score << 9 | 511 - units) << 3 | tag; -1 = nothing yet.  A candidate must beat
+    // it on (score, -units): max(res, key=(score, -units)), first maximal element in db order (bam_parser.py:174)
+    int best = -1;
+    int n_trunk_cols = 0, n_cont_cols = 0, n_combined = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
+
+    // Only cells that can survive the score filter are tracked: min_score >= 30 (bam_parser.py:134), so a
+    // floor of 29 is exact for tagging; the per-template dump (parity/debug) tracks every positive score.
+    // 6-mer filter premise: every run break costs >= 5 matches
+    const int kmer_thr = min(a.p.mismatch, a.p.gap_open) >= 5 * a.p.match ? (30 + a.p.match - 1) / a.p.match - 5 : 0;
+    const int floor_key = (full_dump ? 0 : 29) << KSH | PAYMASK;
+
+    for (int s = 0; s < n_strands; ++s) {
+        if (!((q_strands >> s) & 1)) continue;
+        const int trunk_w = __builtin_amdgcn_readfirstlane(ld->trunk_off[s]);
+        const int alen = __builtin_amdgcn_readfirstlane(ld->alen[s]);
+        const int blen = __builtin_amdgcn_readfirstlane(ld->blen[s]);
+        const int ncols = alen + period * max_units;
+        // ---- exact strand filter.  An alignment scoring s with m matches has <= (m - s)/P run breaks
+        // (P = min(mismatch, gap_open) >= 5*match), so at least m - 5*(breaks+1) >= s/match - 5 of its
+        // 6-mers are exact; no template of this strand can reach the score filter (>= 30,
+        // bam_parser.py:134) unless that many read 6-mers occur somewhere in the strand's templates.
+        // Read windows containing N count as present; a template N scores 0 against every base, so template
+        // windows with N stand for all their fillings (tredgpu_set_ladders).  Skipped for the dump (all positive
+        // scores wanted) and for scorings outside the bound's premise.
+        int kcap = 1 << 20;  // per read: upper bound of any score on this strand
+        // (a 6-mer window starting in this lane ends at most 5 bases into the next lane's rows: needs R >= 5;
+        //  with fewer rows per lane the per-read classes of read_class_kernel already removed hopeless strands)
+        if (R >= 5 && 2 * R + 10 <= 32 && !full_dump && kmer_thr > 0 && __builtin_amdgcn_readfirstlane(ld->kmer_ok) != 0) {
+            const uint32_t* bm = a.seqw + __builtin_amdgcn_readfirstlane(ld->kmer_off[s]);
+            const uint32_t pk_n = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x101, 0xF, 0xF, false);        // row_shl:1
+            const uint32_t nk_n = (uint32_t)__builtin_amdgcn_update_dpp(0x3FF, (int)nk, 0x101, 0xF, 0xF, false);
+            const uint32_t comb = pk | ((pk_n & 0x3FFu) << (2 * R));
+            const uint32_t ncomb = nk | ((nk_n & 0x1Fu) << R);
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t win = (comb >> (2 * r)) & 0xFFFu;
+                const bool has_n = ((ncomb >> r) & 0x3Fu) != 0;
+                const bool in_read = row0 + r + 5 < L;
+                const uint32_t word = bm[win >> 5];
+                cnt += in_read && (has_n || ((word >> (win & 31)) & 1u));
+            }
+            cnt += dpp_row_shr<0x111>(0, cnt);
+            cnt += dpp_row_shr<0x112>(0, cnt);
+            cnt += dpp_row_shr<0x114>(0, cnt);
+            cnt += dpp_row_shr<0x118>(0, cnt);
+            kcap = (cnt + 5) * a.p.match;  // lane 15 of each read holds the read's total
+            if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && cnt >= kmer_thr) == 0) continue;
+        }
+        // Strand exit.  No alignment scores more than cap; a template only matters if it passes its score filter
+        // and beats the read's arg-max so far, and at equal score the smaller unit count wins: once neither is
+        // possible any more for any read of the wave, the rest of this strand changes nothing.  Quads hold reads
+        // of one level of the 6-mer count (read_class_kernel), so the four reads get there together.
+        const int cap = min(kcap, L * a.p.match);
+        // template un can still matter for this read: its score filter max(min(L, T)/2, 30) (bam_parser.py:133-134,
+        // growing with un) and the arg-max so far are within reach of cap
+        auto still_open = [&](int un) {
+            const int min_score = max(min(L, alen + period * un + blen) >> 1, 30);
+            return max(min_score, (best >> 12) + 1) <= cap;
+        };
+        if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(max_units > 0 ? 1 : 0)) == 0) continue;
+
+        Rows<R> J;
+        int H[R], E[R];
+        const bool has_suffix = max_units > 0 && blen > 0;
+        if (has_suffix) {
+            // ---- continuation vectors of this strand (see above) ----
+            build_profile<R>(J, a, off, L, row0, true, mK, xK, geK);
+            const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
+            const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
+            int D[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+            for (int y = 0; y + 1 < blen; ++y) {
+                const int s_fresh = (y << 9) + y * geK - 2 * geK;
+                switch (letter_from(bw, blen - 1 - y)) {
+                    case 0: sweep_column_free<R, 0>(J, H, E, s_fresh, geK, c0); break;
+                    case 1: sweep_column_free<R, 1>(J, H, E, s_fresh, geK, c0); break;
+                    case 2: sweep_column_free<R, 2>(J, H, E, s_fresh, geK, c0); break;
+                    case 3: sweep_column_free<R, 3>(J, H, E, s_fresh, geK, c0); break;
+                    default: sweep_column_free<R, 4>(J, H, E, s_fresh, geK, c0); break;
+                }
+            }
+            {
+                const int y = blen - 1;
+                const int s_fresh = (y << 9) + y * geK - 2 * geK;
+                switch (letter_from(bw, 0)) {
+                    case 0: match_column<R, 0>(J, H, D, s_fresh, geK); break;
+                    case 1: match_column<R, 1>(J, H, D, s_fresh, geK); break;
+                    case 2: match_column<R, 2>(J, H, D, s_fresh, geK); break;
+                    case 3: match_column<R, 3>(J, H, D, s_fresh, geK); break;
+                    default: match_column<R, 4>(J, H, D, s_fresh, geK); break;
+                }
+            }
+            // E holds the horizontal-gap state of the last reversed column (= first suffix column); its opening
+            // cost was charged on the reversed side too: + go - ge in the scaled domain
+            mirror_up<R>(D, 0, wb, PS);
+            mirror_up<R>(E, c0, wb + R * PS, PS);
+            n_cont_cols += blen;
+        }
+        build_profile<R>(J, a, off, L, row0, false, mK, xK, geK);
+        const int row0g = row0 * geK;
+        Track T;
+        // best alignment inside the suffix alone (columns relative to the suffix); it cannot reach the score
+        // floor unless the suffix is long enough, so normally only the dump needs it
+        const bool with_sfx = has_suffix && (full_dump || blen * a.p.match >= 30);
+        if (with_sfx) {
+            const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
+            const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+            T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
+            for (int j = 0; j < blen; ++j) sweep_letter<R>(letter_from(bw, j), J, H, E, T, j, row0, geK, c0, row0g);
+            int sk = T.bestkey, ss = T.beststart;
+            pair_step<0x111>(sk, ss);
+            pair_step<0x112>(sk, ss);
+            pair_step<0x114>(sk, ss);
+            pair_step<0x118>(sk, ss);
+            wb[(2 * R) * PS] = sk;
+            wb[(2 * R + 1) * PS] = ss;
+        }
+        const int tw = lane < ((ncols + 7) >> 3) ? (int)a.seqw[trunk_w + lane] : 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+        T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
+        int next_end = max_units > 0 ? alen + period - 1 : alen - 1;
+        int u = max_units > 0 ? 1 : 0;
+        for (int col = 0; col < ncols; ++col) {
+            sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g);
+            ++n_trunk_cols;
+            if (col != next_end) continue;
+            // ---- template u ends here on the trunk ----
+            // Exact pruning: no cell of its suffix can score more than max(trunk best, column max + |suffix| *
+            // match).  If that cannot reach the score filter (bam_parser.py:134) or beat the read's current
+            // arg-max key (score, -units) for ANY of the four reads, the template is dropped.
+            bool need = true;
+            const bool comb = blen > 0;
+            const int Tlen = alen + period * u + blen;
+            if (!full_dump && blen > 0) {
+                const int bestS = best >> 12, bestU = 511 - ((best >> 3) & 511);
+                const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
+                const int reach = reach_bound<R>(H, T, row0g + col * geK, geK, blen * mK);
+                need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && min(kcap, reach) >= need_score) != 0;
+            }
+            next_end += period;
+            if (!need) {
+                ++n_dropped;
+                ++u;
+                if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
+                continue;
+            }
+            int bk = T.bestkey, bs = T.beststart;
+            if (comb) {
+                // candidates entering the suffix: key = (H or E score field) + continuation (score | end cell)
+                int m = NEG;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int ef = max(E[r], H[r] - c0);   // the gap may also open from a cell reached by a vertical gap
+                    m = max3(m, (H[r] & ~PAYMASK) + wb[r * PS], (ef & ~PAYMASK) + wb[(R + r) * PS]);
+                }
+                // scaled sum -> true score; reversed start cell -> 511 - end column | 511 - end row
+                const int cu = ((511 - col - blen) << 9) + (512 - 16 * R) - (col + 16 * R + blen - 3) * geK;
+                m += cu;
+                const bool c = m > bk;     // an equal key is impossible: trunk cells end at columns <= col
+                if (!full_dump) {
+                    // the template's exact score is known now: drop it unless it can pass the score filter and
+                    // beat the arg-max of some read (the bound above only had column max + |suffix| * match)
+                    int ks = max(m, bk);
+                    ks = max(ks, dpp_row_shr<0x111>(ks, ks));
+                    ks = max(ks, dpp_row_shr<0x112>(ks, ks));
+                    ks = max(ks, dpp_row_shr<0x114>(ks, ks));
+                    ks = max(ks, dpp_row_shr<0x118>(ks, ks));
+                    if (with_sfx) ks = max(ks, wb[(2 * R) * PS]);   // (its column shift does not touch the score)
+                    const int bestS = best >> 12, bestU = 511 - ((best >> 3) & 511);
+                    const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
+                    if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && (ks >> KSH) >= need_score) == 0) {
+                        ++n_dropped;
+                        ++u;
+                        if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
+                        continue;
+                    }
+                }
+                ++n_combined;
+                int st = 0;
+                if (__builtin_amdgcn_ballot_w64(c) != 0) {
+                    // start payload of the winner (largest among equal keys); the sums are recomputed, not kept
+                    const int mm = m - cu;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int ef = max(E[r], H[r] - c0);
+                        st = max(st, (H[r] & ~PAYMASK) + wb[r * PS] == mm ? (H[r] & PAYMASK) : 0);
+                        st = max(st, (ef & ~PAYMASK) + wb[(R + r) * PS] == mm ? (ef & PAYMASK) : 0);
+                    }
+                }
+                bk = c ? m : bk;
+                bs = c ? st : bs;
+                pair_step_lex<0x111>(bk, bs);
+                pair_step_lex<0x112>(bk, bs);
+                pair_step_lex<0x114>(bk, bs);
+                pair_step_lex<0x118>(bk, bs);
+                if (with_sfx) {
+                    const int sk = wb[(2 * R) * PS], ss = wb[(2 * R + 1) * PS];
+                    const int k3 = sk - ((col + 1) << 9), s3 = ss + ((col + 1) << 9);
+                    const bool c3 = sk != floor_key && (k3 > bk || (k3 == bk && s3 > bs));
+                    bk = c3 ? k3 : bk;
+                    bs = c3 ? s3 : bs;
+                }
+            } else {
+                ++n_emit_trunk;
+                pair_step<0x111>(bk, bs);
+                pair_step<0x112>(bk, bs);
+                pair_step<0x114>(bk, bs);
+                pair_step<0x118>(bk, bs);
+            }
+            const int score = bk >> KSH;
+            const int ref_end = 511 - ((bk >> 9) & 511), read_end = 511 - (bk & 511);
+            const int ref_begin = (bs >> 9) & 511, read_begin = bs & 511;
+            const int min_len = min(L, Tlen) >> 1;              // bam_parser.py:133
+            const int min_score = max(min_len, 30);             // :134
+            const bool pass = score >= min_score && (read_end - read_begin + 1) >= min_len;  // ssw_wrap.py:217
+            const int aL = ref_begin, aR = Tlen - ref_end - 1, bL = read_begin, bR = L - read_end - 1;
+            const int hang = min(min(aR + bL, aL + bR), min(aL + aR, bL + bR));  // bam_parser.py:113-121
+            const bool prefix_read = ref_begin < flank;                           // :139
+            const bool suffix_read = ref_end > Tlen - flank - 1;                  // :140
+            int tag;
+            if (hang >= flank) tag = TREDGPU_TAG_HANG;
+            else if (prefix_read) tag = suffix_read ? TREDGPU_TAG_FULL : TREDGPU_TAG_PREF;
+            else if (suffix_read) tag = TREDGPU_TAG_POST;
+            else if (u >= mu_rept - 1 && u * period <= L) tag = TREDGPU_TAG_REPT;
+            else tag = TREDGPU_TAG_NONE;
+            if (!pass) tag = TREDGPU_TAG_NONE;
+            const int cand = (score << 9 | (511 - u)) << 3;
+            best = tag != TREDGPU_TAG_NONE && cand > (best | 7) ? cand | tag : best;
+            if (full_dump && valid && jl == 15) {
+                const int k = max_units > 0 ? 2 * (u - 1) + s : 0;
+                if (k < a.dump_templates) {
+                    int16_t* d = a.out_dump + ((int64_t)a.perm[q_first + job] * a.dump_templates + k) * 6;
+                    const bool hit = score > 0 && bk != floor_key;
+                    d[0] = (int16_t)(hit ? score : 0);
+                    d[1] = (int16_t)(hit ? ref_begin : -1);
+                    d[2] = (int16_t)(hit ? ref_end : -1);
+                    d[3] = (int16_t)(hit ? read_begin : 0);
+                    d[4] = (int16_t)(hit ? read_end : 0);
+                    d[5] = (int16_t)tag;
+                }
+            }
+            ++u;
+            if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
+        }
+    }
+    if (a.stats != nullptr && lane < 6) {
+        // one atomic per counter and wave (lanes 0..5 of one instruction), spread over SW_STAT_SLOTS lines
+        const int vals[6] = {n_trunk_cols, n_cont_cols, n_combined, n_dropped, n_emit_trunk, 1};
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v = lane == k ? vals[k] : v;
+        atomicAdd(a.stats + (size_t)(blockIdx.x & (SW_STAT_SLOTS - 1)) * 8 + lane, (unsigned long long)v);
+    }
+    if (valid && jl == 15) {
+        const int64_t rd = (int64_t)a.perm[q_first + job];
+        int bestTag = best < 0 ? TREDGPU_TAG_NONE : best & 7;
+        int bestU = 511 - ((best >> 3) & 511), bestS = best >> 12;
+        if (too_long) bestTag = TREDGPU_TAG_INVALID, bestU = 0, bestS = 0;
+        a.out_tag[rd] = (uint8_t)bestTag;
+        a.out_h[rd] = (int16_t)(bestTag == TREDGPU_TAG_NONE ? 0 : bestU);
+        a.out_score[rd] = (int16_t)(bestTag == TREDGPU_TAG_NONE ? 0 : bestS);
+    }
+}
+
+// Strand classes and quad formation.  The exact 6-mer strand filter (see sw_cont_kernel) is evaluated per read
+// here, once: bit s of the class = "strand s can reach the score filter for this read".  Reads that need no strand
+// at all are finished on the spot (no candidate: tag NONE).  The others are packed four to a wavefront by
+// (ladder, class, level) across the units of a batch -- a read's alignment does not depend on its wave-mates, so
+// only the last quad of each bin can be partial (per-unit packing left 7 % of the read slots of the bench batch
+// empty).  The level is the read's count of 6-mers present in the templates, in steps of 6: that count caps the
+// read's score, a template of length T needs a score of min(L, T)/2, so reads of one level stop needing the
+// trunk at about the same template and the wave can leave the strand together (strand exit in sw_cont_kernel).
+// Bin b = (3 * ladder + k) * SW_LEVELS + level holds class {1, 3, 2}[k].
+//   read_class_kernel   classes and levels, per-unit counts per bin, bin totals (one atomic per unit and bin)
+//   bin_scan_kernel     bin -> first slot in the permutation / first quad; the quad count of the launch
+//   scatter_kernel      each unit reserves its run inside its bins and writes its reads' indices there
+//   fill_quads_kernel   one thread per quad: its bin by binary search over the quad offsets
+constexpr int BIN_STRIDE = 16;   // ints: every bin counter on its own 64-byte line
+constexpr int SW_LEVELS = 16;
+constexpr int UNIT_BINS = 3 * SW_LEVELS;   // bins one unit can feed
+__device__ __forceinline__ int class_slot(int cls) { return cls == 1 ? 0 : (cls == 3 ? 1 : 2); }
+
+__global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_class, int32_t* unit_cnt, int32_t* bin_total) {
+    const int g = blockIdx.x;
+    if (g >= a.n_units) return;
+    // (device-resident unit tables are not validated by the host: keep a bad index from leaving the tables)
+    const int lad = min(max(a.unit_ladder[g], 0), a.n_ladders - 1);
+    const LadderDesc* ld = a.ladders + lad;
+    const bool full_dump = a.out_dump != nullptr;
+    const int thr = min(a.p.mismatch, a.p.gap_open) >= 5 * a.p.match ? (30 + a.p.match - 1) / a.p.match - 5 : 0;
+    const bool filt = !full_dump && thr > 0 && ld->kmer_ok != 0 && ld->max_units > 0;
+    const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
+    // the two 4096-bit presence maps of the ladder, in LDS: every base of every read looks both up, and a
+    // lookup in global memory (even an L1 hit) stalled the loop for its whole latency
+    __shared__ uint32_t bm[2][128];
+    __shared__ int hist[UNIT_BINS];
+    if (filt) {
+        for (int k = threadIdx.x; k < 256; k += (int)blockDim.x) bm[k >> 7][k & 127] = a.seqw[ld->kmer_off[k >> 7] + (k & 127)];
+    }
+    if (threadIdx.x < UNIT_BINS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int rd = r0 + (int)threadIdx.x; rd < r1; rd += (int)blockDim.x) {
+        int cls = ld->n_strands >= 2 ? 3 : 1;
+        int level = SW_LEVELS - 1;
+        const int L = a.read_len[rd];
+        if (filt && L <= a.max_rows) {   // over-long reads go to the SW kernel, which flags them
+            const int64_t off = a.read_off[rd];
+            const int nb = (L + 15) >> 4;
+            const uint32_t* bm0 = bm[0];
+            const uint32_t* bm1 = bm[1];
+            int cnt0 = 0, cnt1 = 0, since_n = 0;
+            uint32_t win = 0, w = 0, m = 0;
+            for (int i = 0; i < L; ++i) {
+                if ((i & 15) == 0) w = a.packed[off + (i >> 4)];
+                if ((i & 31) == 0) m = a.packed[off + nb + (i >> 5)];
+                const bool isn = (m >> (i & 31)) & 1u;
+                win = (win >> 2) | (((w >> ((i & 15) * 2)) & 3u) << 10);   // base i-5 ends up in the low bits
+                since_n = isn ? 0 : since_n + 1;
+                if (i >= 5) {
+                    const bool has_n = since_n < 6;
+                    cnt0 += has_n || ((bm0[win >> 5] >> (win & 31)) & 1u);
+                    cnt1 += has_n || ((bm1[win >> 5] >> (win & 31)) & 1u);
+                }
+            }
+            cls = (cnt0 >= thr ? 1 : 0) | (cnt1 >= thr ? 2 : 0);
+            level = min(SW_LEVELS - 1, max(cls & 1 ? cnt0 : 0, cls & 2 ? cnt1 : 0) / 5);
+        }
+        read_class[rd] = (uint8_t)(cls | level << 2);
+        if (cls == 0) {   // no strand can produce a candidate: bam_parser.py:171-172 "if not res: return"
+            a.out_tag[rd] = TREDGPU_TAG_NONE;
+            a.out_h[rd] = 0;
+            a.out_score[rd] = 0;
+        } else {
+            atomicAdd(&hist[class_slot(cls) * SW_LEVELS + level], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < UNIT_BINS) {
+        const int n = hist[threadIdx.x];
+        unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x] = n;
+        if (n) atomicAdd(bin_total + ((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE, n);
+    }
+}
+
+// bins[b * BIN_STRIDE + 0] total reads, +1 first permutation slot, +2 first quad, +3 fill cursor.
+// One block: every thread sums a contiguous chunk of bins, the chunk totals are scanned in LDS.
+__global__ __launch_bounds__(1024) void bin_scan_kernel(int32_t* bins, int n_bins, int32_t* n_quads) {
+    __shared__ int cs[1024], cq[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n_bins + 1023) / 1024;
+    const int b0 = min(t * chunk, n_bins), b1 = min(b0 + chunk, n_bins);
+    int slots = 0, quads = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int n = bins[(size_t)b * BIN_STRIDE];
+        slots += n;
+        quads += (n + 3) >> 2;
+    }
+    cs[t] = slots; cq[t] = quads;
+    __syncthreads();
+    if (t == 0) {
+        int s = 0, q = 0;
+        for (int k = 0; k < 1024; ++k) { const int a_ = cs[k], b_ = cq[k]; cs[k] = s; cq[k] = q; s += a_; q += b_; }
+        bins[(size_t)n_bins * BIN_STRIDE + 2] = q;   // sentinel for the binary search
+        *n_quads = q;
+    }
+    __syncthreads();
+    int slot = cs[t], quad = cq[t];
+    for (int b = b0; b < b1; ++b) {
+        int32_t* e = bins + (size_t)b * BIN_STRIDE;
+        e[1] = slot;
+        e[2] = quad;
+        e[3] = 0;
+        slot += e[0];
+        quad += (e[0] + 3) >> 2;
+    }
+}
+
+__global__ __launch_bounds__(64) void scatter_kernel(SwArgs a, const uint8_t* read_class, const int32_t* unit_cnt, int32_t* bins,
+                                                       int32_t* perm) {
+    const int g = blockIdx.x;
+    if (g >= a.n_units) return;
+    const int lad = min(max(a.unit_ladder[g], 0), a.n_ladders - 1);
+    __shared__ int pos[UNIT_BINS];
+    if (threadIdx.x < UNIT_BINS) {
+        const int n = unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x];
+        int p = 0;
+        if (n) {
+            int32_t* e = bins + ((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE;
+            p = e[1] + atomicAdd(e + 3, n);
+        }
+        pos[threadIdx.x] = p;
+    }
+    __syncthreads();
+    const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += (int)blockDim.x) {
+        const int c = read_class[r] & 3, level = read_class[r] >> 2;
+        if (c != 0) perm[atomicAdd(&pos[class_slot(c) * SW_LEVELS + level], 1)] = r;
+    }
+}
+
+__global__ void fill_quads_kernel(const int32_t* bins, int n_bins, const int32_t* n_quads, Quad* quads) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= *n_quads) return;
+    int lo = 0, hi = n_bins;   // largest b with first_quad[b] <= q (empty bins share their successor's offset)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bins[(size_t)mid * BIN_STRIDE + 2] <= q) lo = mid; else hi = mid;
+    }
+    const int32_t* e = bins + (size_t)lo * BIN_STRIDE;
+    const int j = q - e[2];
+    const int cls[3] = {1, 3, 2};
+    Quad qd;
+    qd.ladder = lo / UNIT_BINS;
+    qd.first = e[1] + 4 * j;
+    qd.count = min(4, e[0] - 4 * j);
+    qd.strands = cls[(lo / SW_LEVELS) % 3];
+    quads[q] = qd;
+}
+
+// bam_parser.py:256-287: histograms per unit; optional removal of REPT/REPT mate pairs.
+__global__ void mark_rept_pairs_kernel(const uint8_t* tag, const int32_t* read_pair_id,
+                                       const int32_t* unit_read_off, int32_t n_units,
+                                       uint8_t* drop) {
+    const int g = blockIdx.x;
+    if (g >= n_units) return;
+    const int r0 = unit_read_off[g], r1 = unit_read_off[g + 1];
+    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+        uint8_t d = 0;
+        const int pid = read_pair_id[i];
+        if (tag[i] == TREDGPU_TAG_REPT && pid >= 0) {
+            for (int j = r0; j < r1; ++j)
+                if (j != i && read_pair_id[j] == pid && tag[j] == TREDGPU_TAG_REPT) { d = 1; break; }
+        }
+        drop[i] = d;
+    }
+}
+
+__global__ void tally_kernel(const uint8_t* tag, const int16_t* h, const int32_t* unit_read_off,
+                             int32_t n_units, const uint8_t* drop, int32_t hist_stride,
+                             int32_t* full_cnt, int32_t* pref_cnt, int32_t* rept_cnt) {
+    const int g = blockIdx.x;
+    if (g >= n_units) return;
+    const int r0 = unit_read_off[g], r1 = unit_read_off[g + 1];
+    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+        const int t = tag[i];
+        const int hh = h[i];
+        if (t == TREDGPU_TAG_NONE || t == TREDGPU_TAG_HANG) continue;
+        if (drop != nullptr && drop[i]) continue;
+        if (hh < 0 || hh >= hist_stride) continue;
+        int32_t* dst = t == TREDGPU_TAG_FULL ? full_cnt : (t == TREDGPU_TAG_REPT ? rept_cnt : pref_cnt);
+        atomicAdd(dst + (int64_t)g * hist_stride + hh, 1);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* perm, Quad* quads, int32_t* n_quads,
+                              int32_t* unit_cnt, int32_t* bins, int n_ladders, int64_t max_quads, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(n_quads, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    if (a.n_units <= 0) return hipSuccess;
+    const int n_bins = UNIT_BINS * n_ladders;
+    if ((e = hipMemsetAsync(bins, 0, sw_bin_bytes(n_ladders), s)) != hipSuccess) return e;
+    read_class_kernel<<<a.n_units, 64, 0, s>>>(a, read_class, unit_cnt, bins);
+    bin_scan_kernel<<<1, 1024, 0, s>>>(bins, n_bins, n_quads);
+    scatter_kernel<<<a.n_units, 64, 0, s>>>(a, read_class, unit_cnt, bins, perm);
+    fill_quads_kernel<<<(unsigned)((max_quads + 255) / 256), 256, 0, s>>>(bins, n_bins, n_quads, quads);
+    return hipGetLastError();
+}
+
+size_t sw_unit_cnt_bytes(int n_units) { return (size_t)n_units * UNIT_BINS * sizeof(int32_t); }
+int64_t sw_max_quads(int64_t n_reads, int n_ladders) { return n_reads / 4 + (int64_t)UNIT_BINS * n_ladders + 1; }
+size_t sw_bin_bytes(int n_ladders) { return ((size_t)UNIT_BINS * n_ladders + 1) * BIN_STRIDE * sizeof(int32_t); }
+
+hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s) {
+    if (max_quads <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)max_quads;   // one quad = one wavefront = one workgroup
+    switch (rows_per_lane) {
+        // second parameter = waves per SIMD the register allocation is held to
+        case 4: sw_cont_kernel<4, 6><<<blocks, 64, 0, s>>>(a); break;
+        case 7: sw_cont_kernel<7, 4><<<blocks, 64, 0, s>>>(a); break;
+        case 10: sw_cont_kernel<10, 4><<<blocks, 64, 0, s>>>(a); break;
+        case 16: sw_cont_kernel<16, 2><<<blocks, 64, 0, s>>>(a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tally(const uint8_t* tag, const int16_t* h, int64_t n_reads,
+                        const int32_t* unit_read_off, int32_t n_units, const int32_t* read_pair_id,
+                        int32_t hist_stride, int32_t* full_cnt, int32_t* pref_cnt,
+                        int32_t* rept_cnt, uint8_t* scratch_drop, hipStream_t s) {
+    (void)n_reads;
+    const size_t bytes = (size_t)n_units * hist_stride * sizeof(int32_t);
+    hipError_t e;
+    if ((e = hipMemsetAsync(full_cnt, 0, bytes, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(pref_cnt, 0, bytes, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(rept_cnt, 0, bytes, s)) != hipSuccess) return e;
+    if (n_units <= 0) return hipSuccess;
+    const uint8_t* drop = nullptr;
+    if (read_pair_id != nullptr) {
+        mark_rept_pairs_kernel<<<n_units, 64, 0, s>>>(tag, read_pair_id, unit_read_off, n_units, scratch_drop);
+        drop = scratch_drop;
+    }
+    tally_kernel<<<n_units, 64, 0, s>>>(tag, h, unit_read_off, n_units, drop, hist_stride, full_cnt,
+                                        pref_cnt, rept_cnt);
+    return hipGetLastError();
+}
+
+}  // namespace tredgpu
