@@ -654,9 +654,9 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
 // read's score, a template of length T needs a score of min(L, T)/2, so reads of one level stop needing the
 // trunk at about the same template and the wave can leave the strand together (strand exit in sw_cont_kernel).
 // Bin b = (3 * ladder + k) * SW_LEVELS + level holds class {1, 3, 2}[k].
-//   read_class_kernel   classes and levels, per-unit counts per bin, bin totals (one atomic per unit and bin)
+//   read_class_kernel   classes and levels, bin totals, each unit's offset inside its bins (one atomic per unit and bin)
 //   bin_scan_kernel     bin -> first slot in the permutation / first quad; the quad count of the launch
-//   scatter_kernel      each unit reserves its run inside its bins and writes its reads' indices there
+//   scatter_kernel      each unit writes its reads' indices into its runs of the bins
 //   fill_quads_kernel   one thread per quad: its bin by binary search over the quad offsets
 constexpr int BIN_STRIDE = 16;   // ints: every bin counter on its own 64-byte line
 constexpr int SW_LEVELS = 16;
@@ -719,13 +719,15 @@ __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_
     }
     __syncthreads();
     if (threadIdx.x < UNIT_BINS) {
+        // the unit's run inside each of its bins starts where the bin's total stood when the unit arrived
         const int n = hist[threadIdx.x];
-        unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x] = n;
-        if (n) atomicAdd(bin_total + ((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE, n);
+        int at = 0;
+        if (n) at = atomicAdd(bin_total + ((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE, n);
+        unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x] = at;
     }
 }
 
-// bins[b * BIN_STRIDE + 0] total reads, +1 first permutation slot, +2 first quad, +3 fill cursor.
+// bins[b * BIN_STRIDE + 0] total reads, +1 first permutation slot, +2 first quad.
 // One block: every thread sums a contiguous chunk of bins, the chunk totals are scanned in LDS.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(int32_t* bins, int n_bins, int32_t* n_quads) {
     __shared__ int cs[1024], cq[1024];
@@ -752,7 +754,6 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(int32_t* bins, int n_bin
         int32_t* e = bins + (size_t)b * BIN_STRIDE;
         e[1] = slot;
         e[2] = quad;
-        e[3] = 0;
         slot += e[0];
         quad += (e[0] + 3) >> 2;
     }
@@ -764,15 +765,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(SwArgs a, const uint8_t* re
     if (g >= a.n_units) return;
     const int lad = min(max(a.unit_ladder[g], 0), a.n_ladders - 1);
     __shared__ int pos[UNIT_BINS];
-    if (threadIdx.x < UNIT_BINS) {
-        const int n = unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x];
-        int p = 0;
-        if (n) {
-            int32_t* e = bins + ((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE;
-            p = e[1] + atomicAdd(e + 3, n);
-        }
-        pos[threadIdx.x] = p;
-    }
+    if (threadIdx.x < UNIT_BINS)
+        pos[threadIdx.x] = bins[((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE + 1] + unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x];
     __syncthreads();
     const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
     for (int r = r0 + (int)threadIdx.x; r < r1; r += (int)blockDim.x) {
