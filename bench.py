@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X STR-genotyping hot path.
 
-Metric (BASELINE.json): sample x TRED genotypes / second at 30x 150 bp.
-One "step" = one pass of the whole hot path (template SW + tagging -> histograms -> (h1,h2)
-likelihood grid) over one resident batch of `--samples` synthetic samples x 30 loci
-(BASELINE.json configs[2]: "1k synthetic 30x 150 bp BAMs x 30 TREDs on 1 GPU").  Inputs are packed
-and already in HBM when the timed region starts; results stay on the device.
+Metric (BASELINE.json): sample x TRED genotypes / second at 30x 150 bp; 1/2/4/8 MI355X + host-CPU baseline.
+One "step" = one pass of the whole hot path (template SW + tagging -> histograms -> (h1,h2) likelihood grid) over
+one resident batch of `--samples` synthetic samples x 30 loci per GPU (BASELINE.json configs[2]: "1k synthetic
+30x 150 bp BAMs x 30 TREDs on 1 GPU").  Inputs are packed and already in HBM when the timed region starts;
+results stay on the device.
 
-Multi-GPU: one process per GPU (torchrun), every rank owns its own `--samples` samples (weak scaling,
-samples are independent -- no data-path collective); torch.distributed is used only for the
-barrier and the max-over-ranks reduction of the wall time.
+How it runs
+  * under torch.distributed.run (RANK in the environment): this process is one rank = one GPU; RCCL carries the
+    barrier and the max-over-ranks wall time only -- samples are independent, there is no data-path collective;
+  * started directly: this process is a launcher that NEVER touches a GPU.  For every rank count n of the sweep
+    (1, 2, 4, 8 up to the GPUs visible, and --gpus itself) it starts n child ranks (tredparse_amd.shard.spawn_ranks:
+    HIP_VISIBLE_DEVICES = one device per child, rank r on device r mod visible), collects their per-rank records,
+    then times the CPU baseline on 1 core and on all host cores, and prints ONE JSON line: the record of
+    n = --gpus with `scaling` (one entry per n), `cpu_baseline` (all cores) and `cpu_baseline_1core`.
+    On a 1-GPU box the sweep adds n = 2 with both ranks on the one GPU (marked oversubscribed: a check of the
+    launcher, not a scaling point).
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel = sw_ladder, VALU-bound; HIP-event
-timed inside this script) and, at N=1, `cpu_baseline` (the reference's own ssw.c compiled in
-oracle/_ref driven natively + the numpy likelihood oracle, on a bounded sample of the same batch).
+Roofline of the dominant kernel (sw_cont_kernel, integer VALU bound; HIP-event timed on the context's own stream):
+`achieved` = DP cells the kernel really swept (read rows x columns, padding rows and empty quad slots excluded) per
+second, `peak` = int32 VALU lane-ops/s / 10 ops per cell.  The brute-force cell count of SURVEY 8(d) over the same
+time is `effective_TCUPS` (it exceeds the hardware peak because of the exact shortcuts; it is not a hardware rate).
+`traffic` = HBM bytes per launch from the rocprofv3 PMC passes summarised in profiles/ (FETCH_SIZE + WRITE_SIZE).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,6 +41,7 @@ PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9      # int32 VALU lane-ops/s: 256 CU x 4 SI
 OPS_PER_CELL = 10.0                        # minimum VALU ops of one affine-gap local-alignment cell
 PEAK_TCUPS = PEAK_LANE_OPS / OPS_PER_CELL / 1e12
 HBM_PEAK_GBS = 8000.0
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
 def bench_loci(loci):
@@ -59,91 +71,120 @@ def ladder_cells(batch):
     return total
 
 
-def cpu_baseline(batch, loci, budget_s=20.0):
-    """Reference CPU path on a bounded sample: every alignment by the reference's ssw.c (oracle/_ref,
-    one ssw_init + ssw_align per pair exactly as ssw_wrap.py does) + numpy likelihood oracle."""
-    from oracle import lik_oracle as lo
-    from oracle import pyoracle as po
-    from tredparse_amd import synth
-    kind = "reference" if po.have_ref() else "port"
-    classify = po.ref_classify if kind == "reference" else po.classify
-    ls = po.LocusSet(batch.ladders)
-    n_samples = batch.n_units // len(batch.ladders)
-    # sample units round-robin over loci so the period mix matches the batch
-    order = [li * n_samples + s for s in range(n_samples) for li in range(len(batch.ladders))]
-    done, t0 = 0, time.perf_counter()
-    for u in order:
-        r0, r1 = int(batch.unit_read_off[u]), int(batch.unit_read_off[u + 1])
-        reads = [synth.decode(r) for r in batch.codes[r0:r1]]
-        lad = int(batch.unit_ladder[u])
-        cls = classify(reads, np.full(len(reads), lad, np.int32), ls, threads=1)
-        f, pp, rr = {}, {}, 0
-        for t, hh, _ in cls:
-            if t == 1: f[int(hh)] = f.get(int(hh), 0) + 1
-            elif t in (2, 3): pp[int(hh)] = pp.get(int(hh), 0) + 1
-            elif t == 4: rr += 1
-        up = batch.units[u]
-        try:
-            res = lo.Caller(int(up["period"]), int(up["readlen"]), int(up["ploidy"]), 2 * float(up["half_depth"]), f,
-                            pp, rr, batch.global_lens[up["pe_off"]:up["pe_off"] + up["n_global"]],
-                            batch.target_lens[up["tl_off"]:up["tl_off"] + up["n_target"]], int(up["ref_len"]),
-                            int(up["minpe"]), maxinsert=int(up["maxinsert"])).evaluate()
-            if res["status"] == 0:
-                locus = loci[lad]
-                lo.calc_PP(res["tot"], res["lik"], int(up["period"]), locus["cutoff_risk"],
-                           locus["mutation_nature"] == "increase", locus["inheritance"][-1] == "R")
-        except Exception:
-            pass
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "genotypes/s", "cores": 1, "kind": kind,
-            "sample": "{} units (round-robin over the 30 loci) of the same batch, {:.1f} s; SW by the reference's "
-                      "ssw.c via oracle/_ref (C driver, no Python per alignment), likelihood by the numpy oracle"
-                      .format(done, dt)}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=1000, help="synthetic samples per GPU (x 30 loci)")
-    ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--seed", type=int, default=20260101)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-
+def make_batch(args, rank, world):
     from tredparse_amd import synth
     loci = bench_loci(synth.load_loci())
     p = synth.SynthParams(coverage=args.coverage, readlen=150)
-    # synthetic data first (process pool), before this process touches the GPU
     workers = max(1, min(len(loci), (os.cpu_count() or 8) // max(1, world)))
-    batch = synth.build_batch(args.seed + rank, loci, args.samples, p, workers=workers)
+    return loci, synth.build_batch(args.seed + rank, loci, args.samples, p, workers=workers)
+
+
+# ---- CPU baseline (launcher process only: it never initialises a GPU, so it may fork workers) ---------------
+_CPU = {}
+
+
+def _cpu_unit(u):
+    """One sample x locus unit on the CPU the way the reference computes it: every (read, template) alignment by the
+    reference's own ssw.c (oracle/_ref: one ssw_init + ssw_align per pair as ssw_wrap.py does) or, without it, the
+    C restatement; then the numpy/scipy likelihood oracle.  Returns (seconds in SW, seconds in the likelihood)."""
+    from oracle import lik_oracle as lo
+    from tredparse_amd import synth
+    batch, loci, classify, ls = _CPU["batch"], _CPU["loci"], _CPU["classify"], _CPU["ls"]
+    t0 = time.perf_counter()
+    r0, r1 = int(batch.unit_read_off[u]), int(batch.unit_read_off[u + 1])
+    reads = [synth.decode(r) for r in batch.codes[r0:r1]]
+    lad = int(batch.unit_ladder[u])
+    cls = classify(reads, np.full(len(reads), lad, np.int32), ls, threads=1)
+    t1 = time.perf_counter()
+    f, pp, rr = {}, {}, 0
+    for t, hh, _ in cls:
+        if t == 1: f[int(hh)] = f.get(int(hh), 0) + 1
+        elif t in (2, 3): pp[int(hh)] = pp.get(int(hh), 0) + 1
+        elif t == 4: rr += 1
+    up = batch.units[u]
+    try:
+        res = lo.Caller(int(up["period"]), int(up["readlen"]), int(up["ploidy"]), 2 * float(up["half_depth"]), f,
+                        pp, rr, batch.global_lens[up["pe_off"]:up["pe_off"] + up["n_global"]],
+                        batch.target_lens[up["tl_off"]:up["tl_off"] + up["n_target"]], int(up["ref_len"]),
+                        int(up["minpe"]), maxinsert=int(up["maxinsert"])).evaluate()
+        if res["status"] == 0:
+            locus = loci[lad]
+            lo.calc_PP(res["tot"], res["lik"], int(up["period"]), locus["cutoff_risk"],
+                       locus["mutation_nature"] == "increase", locus["inheritance"][-1] == "R")
+    except Exception:
+        pass
+    return t1 - t0, time.perf_counter() - t1
+
+
+def cpu_baselines(batch, loci, budget_s, cores):
+    """(all-core record, 1-core record) on a bounded sample of the batch: units taken round-robin over the 30 loci
+    so that the period mix matches the whole workload."""
+    from oracle import pyoracle as po
+    kind = "reference" if po.have_ref() else "port"
+    _CPU.update(batch=batch, loci=loci, classify=po.ref_classify if kind == "reference" else po.classify,
+                ls=po.LocusSet(batch.ladders))
+    try:                                    # numpy/scipy BLAS and OpenMP pools: one thread per process, so that
+        import threadpoolctl                # "cores" is what is really used
+        threadpoolctl.threadpool_limits(1)
+    except ImportError:
+        pass
+    n_samples = batch.n_units // len(batch.ladders)
+    order = [li * n_samples + s for s in range(n_samples) for li in range(len(batch.ladders))]
+    how = ("SW by the reference's ssw.c via oracle/_ref (C driver, no Python per alignment)" if kind == "reference"
+           else "SW by the C restatement oracle/sw_oracle.c") + ", likelihood by the numpy/scipy oracle"
+    # one core
+    done, sw_s, lik_s, t0 = 0, 0.0, 0.0, time.perf_counter()
+    for u in order:
+        a, b = _cpu_unit(u)
+        sw_s, lik_s, done = sw_s + a, lik_s + b, done + 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    one = {"value": done / dt, "unit": "genotypes/s", "cores": 1, "kind": kind,
+           "sample": "{} units (round-robin over the 30 loci) of the same batch, {:.1f} s; {}; {:.0f} % of the time "
+                     "in SW".format(done, dt, how, 100 * sw_s / max(sw_s + lik_s, 1e-9))}
+    # all cores: a pool of worker processes over units, as the reference's Pool over samples (tred.py:521-532)
+    cores = max(1, cores)
+    n = int(min(len(order), max(cores, one["value"] * cores * budget_s * 0.7)))
+    import multiprocessing
+    with multiprocessing.get_context("fork").Pool(cores) as pool:
+        pool.map(_cpu_unit, order[:cores], chunksize=1)          # warm the workers (imports, page-in)
+        t0 = time.perf_counter()
+        pool.map(_cpu_unit, order[:n], chunksize=max(1, n // (cores * 8)))
+        dt = time.perf_counter() - t0
+    many = {"value": n / dt, "unit": "genotypes/s", "cores": cores, "kind": kind,
+            "sample": "{} units (round-robin over the 30 loci) of the same batch over {} worker processes, {:.1f} s; {}"
+                      .format(n, cores, dt, how)}
+    return many, one
+
+
+# ---- one rank = one GPU --------------------------------------------------------------------------------------
+def rank_main(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    spawned = os.environ.get("TRED_SPAWNED_RANK") == "1"       # started by this script's launcher, not by torchrun
+    loci, batch = make_batch(args, rank, world)                 # process pool first, before this process touches the GPU
 
     import torch
-    from oracle import lik_oracle as lo   # model constants only (data file parser)
     from tredparse_amd import _lib
+    from tredparse_amd.engine import load_model
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
-    if use_dist:
+    dist = None
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if spawned or torch.cuda.device_count() < world:
+            dist.init_process_group("gloo", rank=rank, world_size=world)       # ranks may share a device
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    red_dev = dev if dist is not None and dist.get_backend() == "nccl" else torch.device("cpu")
 
     ctx = _lib.Context(local_rank)
     ctx.set_ladders(batch.ladders)
-    step, w = lo.load_model()
-    ctx.set_model(np.array([step[k] for k in range(1, 7)]), np.array(w))
+    step, w = load_model()
+    ctx.set_model(step, w)
 
     def dv(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -172,7 +213,7 @@ def main():
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
-        if use_dist:
+        if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -184,11 +225,14 @@ def main():
         one_step()
     ctx.sync()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    elapsed_local = time.perf_counter() - t0
+    elapsed, units_all = elapsed_local, g * args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=red_dev)
+        u = torch.tensor([g * args.steps], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        elapsed, units_all = float(t.item()), int(u.item())
         dist.barrier()
 
     sw_n, sw_ms = ctx.get_timing(_lib.KERNEL_SW)
@@ -198,16 +242,32 @@ def main():
     ok = int((calls["status"] == 0).sum())
     # sanity: the genotypes are real (most simulated alleles recovered exactly on the short allele)
     short_ok = float(np.mean((calls["h1"] // batch.units["period"]) == batch.h_true[:, 0]))
+    per_rank = {"rank": rank, "device": os.environ.get("TRED_RANK_DEVICE", str(local_rank)),
+                "units": g * args.steps, "elapsed_s": elapsed_local, "units_ok_last_step": ok}
+    out_dir = os.environ.get("TREDBENCH_OUT")
+    if out_dir:
+        with open(os.path.join(out_dir, "rank{}.json".format(rank)), "w") as fp:
+            json.dump(per_rank, fp)
 
     if rank == 0:
-        units_total = g * world * args.steps
-        value = units_total / elapsed
+        value = units_all / elapsed
         alg = algorithmic_cells(batch)
         sw_s = sw_ms / 1e3 / max(sw_n, 1)
         cnt = ctx.get_sw_counters()
-        cols_per_launch = (cnt["trunk_cols"] + cnt["continuation_cols"]) / max(sw_n, 1)
-        swept = cols_per_launch * 4 * 160          # a column sweep = 4 reads x 16 lanes x 10 rows
+        launches = max(sw_n, 1)
+        cols = (cnt["trunk_cols"] + cnt["continuation_cols"]) / launches
+        # a swept column = one DP column of every read of the quad: read rows only (no padding rows, no empty slots)
+        swept = cnt["read_cols"] / launches * batch.readlen
+        lanes = cols * 4 * 160                     # cells the wavefronts occupy: 4 read slots x 16 lanes x 10 rows
         alg_bytes = int(batch.packed.nbytes + n * 12 + n * 5)  # packed reads + offsets/lengths in, tag/h/score out
+        traffic, traffic_src = None, None
+        if os.path.exists(PMC_SUMMARY):
+            with open(PMC_SUMMARY) as fp:
+                pm = json.load(fp)
+            k = pm.get("kernels", {}).get("sw_cont_kernel", {})
+            if "hbm_bytes_per_launch" in k:
+                traffic = k["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r02_pmc_summary.json ({})".format(pm.get("how", "rocprofv3 --pmc passes"))
         out = {
             "metric": "sample x TRED genotypes/sec at 30x 150bp",
             "value": value, "unit": "genotypes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -219,21 +279,22 @@ def main():
                        "units_per_step_per_gpu": g, "reads_per_step_per_gpu": n, "coverage": args.coverage,
                        "readlen": 150, "maxinsert": 300, "alleles": "uniform 5..60 units (SURVEY 8d)",
                        "parallelism": "sample-sharded x{} (no collective)".format(world)},
-            "roofline": {"kernel": "sw_cont_kernel<10,4>", "bound": "valu", "achieved": alg / sw_s / 1e12,
-                         "peak": PEAK_TCUPS, "unit": "TCUPS", "frac": alg / sw_s / 1e12 / PEAK_TCUPS,
-                         "traffic": None,
-                         "note": "achieved = brute-force forward cells of SURVEY 8(d) per launch / HIP-event launch "
-                                 "time; peak = int32 VALU lane-ops/s / 10 ops per cell. frac > 1 is the effect of the "
-                                 "exact shortcuts (shared-prefix ladder, suffix continuation vectors, strand filter, "
-                                 "score-bound pruning): the kernel sweeps {:.1f}x fewer cells than the brute-force "
-                                 "count (trunk + continuation-pass columns; a combined template costs about one "
-                                 "more column); see swept_*"
-                                 .format(alg / max(swept, 1)),
-                         "avg_launch_ms": sw_s * 1e3, "algorithmic_cells_per_launch": alg,
-                         "ladder_cells_per_launch": ladder_cells(batch),
-                         "swept_cells_per_launch": swept, "swept_TCUPS": swept / sw_s / 1e12,
-                         "swept_frac_of_peak": swept / sw_s / 1e12 / PEAK_TCUPS,
-                         "sw_counters": cnt,
+            "roofline": {"kernel": "sw_cont_kernel<10,4>", "bound": "valu",
+                         "achieved": swept / sw_s / 1e12, "peak": PEAK_TCUPS, "unit": "TCUPS",
+                         "frac": swept / sw_s / 1e12 / PEAK_TCUPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                         "note": "achieved = DP cells really swept per launch (read rows x columns of every read; "
+                                 "padding rows and empty quad slots excluded) / HIP-event launch time; peak = int32 "
+                                 "VALU lane-ops/s / 10 ops per cell (2-cycle issue; integer max/max3/add3 issue at 4 "
+                                 "cycles on gfx950, profiles/r02_ubench_valu.txt).  effective_TCUPS = SURVEY 8(d) "
+                                 "brute-force cells / the same time: {:.1f}x more cells than are swept, the effect "
+                                 "of the exact shortcuts (shared-prefix ladder, suffix continuation vectors, 6-mer "
+                                 "strand filter, score-bound pruning), not a hardware rate".format(alg / max(swept, 1)),
+                         "avg_launch_ms": sw_s * 1e3, "swept_cells_per_launch": swept,
+                         "lane_cells_per_launch": lanes, "lane_occupancy": swept / max(lanes, 1),
+                         "algorithmic_cells_per_launch": alg, "effective_TCUPS": alg / sw_s / 1e12,
+                         "ladder_cells_per_launch": ladder_cells(batch), "sw_counters": cnt,
                          "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                                  "achieved_GBps": alg_bytes / sw_s / 1e9, "peak_GBps": HBM_PEAK_GBS,
                                  "frac": alg_bytes / sw_s / 1e9 / HBM_PEAK_GBS}},
@@ -243,12 +304,128 @@ def main():
                       "mean_grid_pairs": float(calls["n_pairs"].mean()), "max_grid_pairs": int(calls["n_pairs"].max()),
                       "run_pe_frac": float(calls["run_pe"].mean())},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch, loci, args.cpu_budget)
-            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
-        print(json.dumps(out))
-    if use_dist:
+        if out_dir:
+            with open(os.path.join(out_dir, "line.json"), "w") as fp:
+                json.dump(out, fp)
+        else:
+            print(json.dumps(out), flush=True)
+    if dist is not None:
         dist.destroy_process_group()
+
+
+def stub_rank_main(args):
+    """The rank protocol without a GPU (tests of the launcher): same files, same reduction over gloo."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    units, elapsed_local = args.samples * 30 * args.steps, 0.05 * (rank + 1)
+    elapsed, units_all = elapsed_local, units
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        t = torch.tensor([elapsed_local], dtype=torch.float64)
+        u = torch.tensor([units], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        elapsed, units_all = float(t.item()), int(u.item())
+        dist.destroy_process_group()
+    out_dir = os.environ["TREDBENCH_OUT"]
+    with open(os.path.join(out_dir, "rank{}.json".format(rank)), "w") as fp:
+        json.dump({"rank": rank, "device": os.environ.get("TRED_RANK_DEVICE", "-"), "units": units,
+                   "elapsed_s": elapsed_local}, fp)
+    if rank == 0:
+        with open(os.path.join(out_dir, "line.json"), "w") as fp:
+            json.dump({"metric": "sample x TRED genotypes/sec at 30x 150bp", "value": units_all / elapsed,
+                       "unit": "genotypes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                       "ms_per_step": elapsed / args.steps * 1e3, "stub": True}, fp)
+
+
+# ---- launcher ------------------------------------------------------------------------------------------------
+def run_ranks(args, n, n_devices):
+    """Start n ranks of this script (rank r on device r mod n_devices) and return (rank 0's line, per-rank records)."""
+    from tredparse_amd import shard
+    argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
+            str(args.warmup), "--samples", str(args.samples), "--coverage", str(args.coverage), "--seed", str(args.seed)]
+    if args.stub:
+        argv.append("--stub")
+    with tempfile.TemporaryDirectory(prefix="tredbench_") as out_dir:
+        env = dict(os.environ, TREDBENCH_OUT=out_dir)
+        codes = shard.spawn_ranks(argv, n, 0 if args.stub else n_devices, timeout=args.rank_timeout, env=env)
+        if any(codes):
+            raise RuntimeError("rank exit codes {}".format(codes))
+        with open(os.path.join(out_dir, "line.json")) as fp:
+            line = json.load(fp)
+        ranks = []
+        for r in range(n):
+            with open(os.path.join(out_dir, "rank{}.json".format(r))) as fp:
+                ranks.append(json.load(fp))
+    return line, ranks
+
+
+def sweep_counts(n_target, n_devices, sweep):
+    if not sweep:
+        return [n_target]
+    top = max(n_target, n_devices)
+    ns = sorted(set([n for n in (1, 2, 4, 8) if n <= top] + [n_target]))
+    if n_devices <= 1 and ns == [1]:
+        ns.append(2)           # 1-GPU box: two ranks on the one GPU, to exercise the multi-rank path
+    return ns
+
+
+def launcher_main(args):
+    from tredparse_amd import shard
+    n_devices = 1 if args.stub else shard.visible_gpus()
+    if n_devices < 1:
+        raise SystemExit("bench.py: no HIP device visible (the hot path has no CPU fallback)")
+    lines = {}
+    scaling = []
+    for n in sweep_counts(args.gpus, n_devices, not args.no_sweep):
+        line, ranks = run_ranks(args, n, n_devices)
+        lines[n] = line
+        rec = {"n": n, "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+               "devices": min(n, n_devices), "ranks": [{k: r[k] for k in ("rank", "device", "units", "elapsed_s")}
+                                                        for r in ranks]}
+        if n > n_devices:
+            rec["oversubscribed"] = True     # several ranks per GPU: exercises the launcher, not a scaling point
+        scaling.append(rec)
+    out = lines[args.gpus]
+    out["scaling_sweep"] = scaling
+    out["gpus_visible"] = n_devices
+    if not args.no_cpu_baseline and not args.stub:
+        loci, batch = make_batch(args, 0, 1)
+        cores = args.cpu_cores or (os.cpu_count() or 1)
+        many, one = cpu_baselines(batch, loci, args.cpu_budget, cores)
+        out["cpu_baseline"] = many
+        out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        out["cpu_baseline_1core"] = one
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=1000, help="synthetic samples per GPU (x 30 loci)")
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--seed", type=int, default=20260101)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds per CPU baseline leg")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the all-core leg (0: all)")
+    ap.add_argument("--no-sweep", action="store_true", help="only --gpus ranks, no 1/2/4/8 sweep")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0)
+    ap.add_argument("--stub", action="store_true", help="launcher self-test: ranks do no GPU work")
+    args = ap.parse_args()
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:     # a rank (torch.distributed.run or our launcher)
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            args.gpus = world
+        if args.stub:
+            stub_rank_main(args)
+        else:
+            rank_main(args)
+    else:
+        launcher_main(args)
 
 
 if __name__ == "__main__":

@@ -259,9 +259,10 @@ int tredgpu_reset_timing(tredgpu_ctx* ctx);
 int tredgpu_get_timing(tredgpu_ctx* ctx, int which, int64_t* launches, double* total_ms);
 /*
  * Work counters of the SW kernel since the last tredgpu_reset_timing (one atomic set per wavefront):
- * out[0] trunk columns swept, out[1] branch columns swept, out[2] branches swept, out[3] templates
- * dropped by the exact score bound, out[4] templates emitted from the trunk state without a branch
- * sweep, out[5] wavefronts (quads of reads); out[6..7] reserved.  A column sweep covers 4 reads x
+ * out[0] trunk columns swept, out[1] continuation-pass columns swept, out[2] templates combined with the
+ * continuation vectors, out[3] templates dropped by the exact score bounds, out[4] templates emitted from the
+ * trunk state alone, out[5] wavefronts (quads of reads), out[6] read-columns = columns swept x reads in the
+ * quad (empty slots of a partial quad not counted); out[7] reserved.  A column sweep occupies 4 read slots x
  * 16 lanes x R rows.  Lets bench.py report the cells really swept next to the brute-force count.
  */
 int tredgpu_get_sw_counters(tredgpu_ctx* ctx, uint64_t out[8]);

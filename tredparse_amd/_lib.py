@@ -272,7 +272,7 @@ class Context:
         """dict of the SW kernel's work counters since reset_timing (tredgpu_get_sw_counters)."""
         out = np.zeros(8, np.uint64)
         self._chk(self.lib.tredgpu_get_sw_counters(self.h, out.ctypes.data), "tredgpu_get_sw_counters")
-        keys = ("trunk_cols", "continuation_cols", "templates_combined", "templates_dropped", "emitted_from_trunk", "waves")
+        keys = ("trunk_cols", "continuation_cols", "templates_combined", "templates_dropped", "emitted_from_trunk", "waves", "read_cols")
         return {k: int(v) for k, v in zip(keys, out)}
 
     def pe_kde(self, mem, units, n_units, global_lens, n_global_total, pdf_out, status_out):

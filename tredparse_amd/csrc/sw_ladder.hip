@@ -626,12 +626,14 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
         }
     }
-    if (a.stats != nullptr && lane < 6) {
-        // one atomic per counter and wave (lanes 0..5 of one instruction), spread over SW_STAT_SLOTS lines
-        const int vals[6] = {n_trunk_cols, n_cont_cols, n_combined, n_dropped, n_emit_trunk, 1};
+    if (a.stats != nullptr && lane < 7) {
+        // one atomic per counter and wave (lanes 0..6 of one instruction), spread over SW_STAT_SLOTS lines;
+        // the last one counts read-columns: columns swept x reads in the quad (empty slots of a partial quad excluded)
+        const int vals[7] = {n_trunk_cols, n_cont_cols, n_combined, n_dropped, n_emit_trunk, 1,
+                             (n_trunk_cols + n_cont_cols) * q_count};
         int v = 0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v = lane == k ? vals[k] : v;
+        for (int k = 0; k < 7; ++k) v = lane == k ? vals[k] : v;
         atomicAdd(a.stats + (size_t)(blockIdx.x & (SW_STAT_SLOTS - 1)) * 8 + lane, (unsigned long long)v);
     }
     if (valid && jl == 15) {

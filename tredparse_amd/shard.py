@@ -35,3 +35,67 @@ def aggregate(units_local, elapsed_local, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return int(u.item()), float(t.item())
+
+
+# ---- one process per GPU, started by a parent that never touches a GPU -------------------------------------
+def visible_gpus():
+    """Number of HIP devices, counted in a short-lived child so that the calling process stays free of any GPU
+    runtime state (it is going to start the per-GPU ranks; a process that has initialised the GPU must neither
+    fork workers nor be replaced)."""
+    import subprocess
+    import sys
+    code = "import torch; print(torch.cuda.device_count())"
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        return max(0, int(out.stdout.strip().splitlines()[-1]))
+    except Exception:
+        return 0
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(rank, world, port, device, base=None):
+    """Environment of rank `rank`: the torchrun variables (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) plus
+    HIP_VISIBLE_DEVICES = its one device (None: leave the visibility alone, e.g. CPU-only tests), so that inside the
+    child the device is always index 0.  TRED_RANK_DEVICE records which physical device that is."""
+    import os
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK="0" if device is not None else str(rank), WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRED_SPAWNED_RANK="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if device is not None:
+        env["HIP_VISIBLE_DEVICES"] = str(device)
+        env["TRED_RANK_DEVICE"] = str(device)
+    return env
+
+
+def spawn_ranks(argv, world, n_devices, timeout=None, env=None, stdout=None):
+    """Start `world` child processes running `argv` (a full command line), rank r on device r mod n_devices
+    (n_devices = 0: no device pinning), wait for all of them and return their exit codes.  The children find each
+    other through RANK / WORLD_SIZE / MASTER_PORT exactly as under torch.distributed.run; nothing is exchanged
+    on the data path (sample x locus units are independent), so no RCCL is involved -- the ranks only meet in a
+    barrier and a (sum units, max time) reduction when they want one.
+    The reference fans out the same way, one worker per sample (tredparse/tred.py:521-532)."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(world):
+        dev = (r % n_devices) if n_devices > 0 else None
+        procs.append(subprocess.Popen(argv, env=rank_env(r, world, port, dev, env), stdout=stdout))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait(timeout=timeout))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()          # exactly the processes started here
+        raise
+    return codes
