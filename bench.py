@@ -32,6 +32,12 @@ import sys
 import tempfile
 import time
 
+if "RANK" not in os.environ:
+    # launcher process (it also runs the CPU baseline): one BLAS / OpenMP thread per process, set before numpy
+    # loads, so that the worker processes of the all-core leg do not each start a thread pool of their own
+    for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(_v, "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -143,18 +149,25 @@ def cpu_baselines(batch, loci, budget_s, cores):
     one = {"value": done / dt, "unit": "genotypes/s", "cores": 1, "kind": kind,
            "sample": "{} units (round-robin over the 30 loci) of the same batch, {:.1f} s; {}; {:.0f} % of the time "
                      "in SW".format(done, dt, how, 100 * sw_s / max(sw_s + lik_s, 1e-9))}
-    # all cores: a pool of worker processes over units, as the reference's Pool over samples (tred.py:521-532)
+    # all cores: a pool of worker processes over units, as the reference's Pool over samples (tred.py:521-532);
+    # bounded by time, not by count: whatever finished when the budget is over is the sample
     cores = max(1, cores)
-    n = int(min(len(order), max(cores, one["value"] * cores * budget_s * 0.7)))
     import multiprocessing
-    with multiprocessing.get_context("fork").Pool(cores) as pool:
+    pool = multiprocessing.get_context("fork").Pool(cores)
+    try:
         pool.map(_cpu_unit, order[:cores], chunksize=1)          # warm the workers (imports, page-in)
-        t0 = time.perf_counter()
-        pool.map(_cpu_unit, order[:n], chunksize=max(1, n // (cores * 8)))
+        n, t0 = 0, time.perf_counter()
+        for _ in pool.imap_unordered(_cpu_unit, order, chunksize=1):
+            n += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
         dt = time.perf_counter() - t0
+    finally:
+        pool.terminate()
+        pool.join()
     many = {"value": n / dt, "unit": "genotypes/s", "cores": cores, "kind": kind,
-            "sample": "{} units (round-robin over the 30 loci) of the same batch over {} worker processes, {:.1f} s; {}"
-                      .format(n, cores, dt, how)}
+            "sample": "{} units (round-robin over the 30 loci) of the same batch finished by {} worker processes in "
+                      "{:.1f} s; {}".format(n, cores, dt, how)}
     return many, one
 
 
@@ -350,7 +363,8 @@ def run_ranks(args, n, n_devices):
         argv.append("--stub")
     with tempfile.TemporaryDirectory(prefix="tredbench_") as out_dir:
         env = dict(os.environ, TREDBENCH_OUT=out_dir)
-        codes = shard.spawn_ranks(argv, n, 0 if args.stub else n_devices, timeout=args.rank_timeout, env=env)
+        codes = shard.spawn_ranks(argv, n, 0 if args.stub else n_devices, timeout=args.rank_timeout, env=env,
+                                  stdout=sys.stderr)
         if any(codes):
             raise RuntimeError("rank exit codes {}".format(codes))
         with open(os.path.join(out_dir, "line.json")) as fp:

@@ -74,6 +74,66 @@ int tredbam_pe_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int6
                        int32_t span, int32_t* global_lens, int64_t cap_global, int64_t* n_global,
                        int32_t* target_lens, int64_t cap_target, int64_t* n_target);
 
+/* Largest l_seq among the first `first_n` records in file order (first_n <= 0: all): READLEN of a sample
+ * (BamReadLen, bam_parser.py:372-391, which looks at 101 records). */
+int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out);
+
+/* ---- whole-sample scan: everything the GPU batch and the JSON need for a list of loci, in one call ------------
+ * Replaces, per locus, BamDepth.region_depth (bam_parser.py:404-411), the read selection of BamParser.parse
+ * (:196-243: window fetch, position filter, unmapped mates, ALT-locus mate rescue) and PEextractor (:316-369);
+ * no per-record object ever reaches the host language.  Selected reads arrive already packed in libtredgpu's read
+ * layout (include/tredgpu.h), in the order the reference would align them. */
+typedef struct tredbam_site {
+    int32_t tid;                  /* contig of the repeat in THIS file (tredbam_tid), < 0: not present           */
+    int32_t repeat_start;         /* the locus table's repeat_start / repeat_end, used as the reference uses them */
+    int32_t repeat_end;
+    int32_t alt_first, n_alt;     /* this locus' entries in the alts[] array                                      */
+} tredbam_site;
+
+typedef struct tredbam_region { int32_t tid, start, end; } tredbam_region;   /* tid < 0: contig not in this file   */
+
+typedef struct tredbam_scan_opts {
+    int32_t readlen;     /* READLEN: reads must start within [repeat_start - readlen, repeat_end + readlen]        */
+    int32_t pad;         /* SPAN = 1000: the fetch window is [repeat_start - pad, repeat_end + pad)                */
+    int32_t flank;       /* FLANKMATCH = 9: a spanning pair starts before repeat_start - flank, ends after end + flank */
+    int32_t pe_reach;    /* 10 x SPAN: pairs are collected within +- pe_reach of the tract                         */
+    int32_t span;        /* pairs with tlen >= span are ignored                                                    */
+    int32_t use_alts;    /* scan the alternative loci (off with --noalts or --useclippedreads)                     */
+    int32_t want_depth, want_pe;
+} tredbam_scan_opts;
+
+#define TREDBAM_UNIT_NO_FETCH 1   /* unknown contig or no index: no reads (the reference logs and goes on)        */
+#define TREDBAM_UNIT_FAILED 2     /* the file could not be read: the reference's exception drops the locus        */
+
+typedef struct tredbam_unit {
+    int32_t status;               /* TREDBAM_UNIT_* flags                                                           */
+    int32_t n_reads;
+    int64_t read_first;           /* first read of the unit in the pools                                            */
+    int64_t depth_sum;            /* pileup depth sum over the window (divide by window length + 1)                 */
+    int32_t depth_status;         /* != 0: the depth query failed (the reference falls back to depth 30)            */
+    int32_t pe_status;            /* -9: a paired read without alignment end (TypeError in the reference)           */
+    int32_t n_global, n_target;
+    int64_t global_first, target_first;
+} tredbam_unit;
+
+typedef struct tredbam_pools {   /* memory owned by the handle, valid until its next scan                           */
+    int64_t n_reads, n_words, n_global, n_target;
+    const uint32_t* packed;       /* libtredgpu read records                                                        */
+    const int64_t* word_off;      /* n_reads + 1                                                                    */
+    const int32_t* read_len;
+    const uint8_t* seq4;          /* the records' 4-bit sequences ("=ACMGRSVTWYHKDBN"), (L+1)/2 bytes each          */
+    const int64_t* seq4_off;      /* n_reads + 1                                                                    */
+    const char* names;            /* query names, not terminated                                                    */
+    const int64_t* name_off;      /* n_reads + 1                                                                    */
+    const int32_t* name_id;       /* index of the read's name among the distinct names of its unit                  */
+    const int32_t* global_lens;
+    const int32_t* target_lens;
+} tredbam_pools;
+
+int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
+                 const tredbam_scan_opts* opts, tredbam_unit* units);
+int tredbam_scan_pools(tredbam* b, tredbam_pools* pools);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,13 +4,13 @@ import json
 import os
 import types
 
+import numpy as np
 import pytest
 
 from tredparse_amd import bamio, tred as tredmod
-from tredparse_amd.bam_parser import BamDepth, BamParser, BamReadLen, PEextractor, rc
+from tredparse_amd.bam_parser import BamDepth, BamParser, BamReadLen, InputParams, PEextractor, rc, scan_sample
 from tredparse_amd.meta import TREDsRepo
 from tredparse_amd.models import calc_label, histogram, mean_std
-from tredparse_amd.utils import InputParams
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BAM1 = os.path.join(GOLD, "bam", "t001.bam")
@@ -55,7 +55,7 @@ def test_locus_table_and_labels():
     assert calc_label(repo["HD"], [15, 41]) == "risk" and calc_label(repo["HD"], [15, 37]) == "prerisk"
     assert calc_label(repo["HD"], [-1, -1]) == "missing" and calc_label(repo["AR"], [6, 21]) == "ok" and calc_label(repo["AR"], [6, 7]) == "risk"
     assert calc_label(repo["FRDA"], [20, 80]) == "ok" and calc_label(repo["FRDA"], [70, 80]) == "risk"
-    assert rc("ACGTNacgtn") == "nacgtNACGT"
+    assert rc("ACGTNacgtn") == "nacgtNACGT" and rc("AXC") == "GXT"
     repo.set_ploidy(["chrX"])
     assert repo["FXS"].ploidy == 1 and repo["HD"].ploidy == 2
 
@@ -135,54 +135,146 @@ def test_native_bam_layer_matches_python_layer():
         bamio.NativeAlignmentFile(os.path.join(GOLD, "bam", "missing.bam"))
 
 
-def test_native_pe_lengths_match_python_pe_extractor(monkeypatch):
-    """tredbam_pe_lengths (the whole PEextractor selection in one native call) against the Python loop over
-    fetched records (bam_parser.py:316-369), for every locus on both test BAMs: same lists, same order."""
-    from tredparse_amd import bam_parser as bpm
+def _python_layer_selection(path, t, readlen, alts=True, strip=False):
+    """The read selection, depth and pair lengths of one locus computed record by record over the pure-Python
+    reader (bamio.PyAlignmentFile) -- the independent check of the native one-call scan."""
+    f = bamio.PyAlignmentFile(path)
+    lo, hi = max(0, t.repeat_start - 1000), t.repeat_end + 1000
+    reads = []
+    try:
+        for r in f.fetch(t.chr, lo, hi):
+            if r.is_unmapped or max(0, t.repeat_start - readlen) <= r.pos <= t.repeat_end + readlen:
+                reads.append((r.query_name, r.query_sequence))
+        if alts:
+            for c, a, b in t.alt:
+                try:
+                    for r in f.fetch(c[3:] if strip else c, a, b):
+                        if r.next_tid >= 0 and f.references[r.next_tid] == t.chr and lo <= r.next_pos <= hi:
+                            reads.append((r.query_name, r.query_sequence))
+                except ValueError:
+                    pass
+        depth = f.pileup_depth_sum(t.chr, lo, hi) / float(hi - lo + 1)
+    except ValueError:
+        return None
+    first = {}
+    for r in f.fetch(t.chr, max(t.repeat_start - 10000, 0), t.repeat_end + 10000):
+        if r.is_paired and not r.is_unmapped and not r.is_duplicate:
+            first.setdefault(r.query_name, []).append(r)
+    gl, tl = [], []
+    for pair in first.values():
+        if len(pair) < 2 or pair[0].is_reverse or not pair[1].is_reverse:
+            continue
+        a, b = pair[:2]
+        tlen = (b.reference_end + b.l_seq - b.query_alignment_end) - (a.pos - a.query_alignment_start)
+        if tlen < 1000:
+            (tl if a.pos < t.repeat_start - 9 and b.reference_end > t.repeat_end + 9 else gl).append(tlen)
+    f.close()
+    return reads, depth, gl, tl
+
+
+def test_native_scan_matches_record_by_record_selection():
+    """tredbam_scan (one native call per sample: depth, read selection incl. unmapped mates and ALT rescue, pair
+    lengths, reads 2-bit packed) against the same selection done record by record over the pure-Python reader,
+    for every locus on both test BAMs: same reads in the same order, same depth, same pair-length lists; the
+    packed words equal libtredgpu's own packer on the decoded sequences."""
+    from tredparse_amd import _lib
     repo = TREDsRepo("hg38")
-    n_pairs = 0
+    n_reads = n_pairs = 0
     for name in ("t001.bam", "t002.bam"):
         path = os.path.join(GOLD, "bam", name)
-        for tred in repo.names:
-            ip = InputParams(bam=path, READLEN=150, tredName=tred, repo=repo, maxinsert=300, fullsearch=False,
-                             gender="Unknown", depth=30, clip=False, alts=False, repeatpairs=True, log="ERROR")
-            bp = BamParser(ip)
-            monkeypatch.delenv("TREDBAM_PURE_PYTHON", raising=False)
-            bamio._lib = None
-            bpm._open_files.clear()
-            nat = PEextractor(bp)
-            monkeypatch.setenv("TREDBAM_PURE_PYTHON", "1")
-            bamio._lib = None
-            bpm._open_files.clear()
-            py = PEextractor(bp)
-            assert nat.global_lens == py.global_lens and nat.target_lens == py.target_lens, (name, tred)
-            assert nat.MINPE == py.MINPE
-            n_pairs += len(nat.global_lens) + len(nat.target_lens)
-    monkeypatch.delenv("TREDBAM_PURE_PYTHON", raising=False)
-    bamio._lib = None
-    bpm._open_files.clear()
-    assert n_pairs > 4000
+        s = scan_sample(path, repo, repo.names)
+        assert s.opened and s.readlen == 150 and not s.dropped
+        for k, tname in enumerate(repo.names):
+            want = _python_layer_selection(path, repo[tname], 150)
+            a, b = s.reads_of(k)
+            got = [(s.name(i), s.sequence(i)) for i in range(a, b)]
+            if want is None:                      # contig not in the file: no reads, depth falls back to 30
+                assert got == [] and s.depth[k] == 30.0
+                continue
+            reads, depth, gl, tl = want
+            assert got == reads, (name, tname)
+            assert s.depth[k] == depth
+            g, t = s.pair_lengths(k)
+            assert g.tolist() == gl and t.tolist() == tl, (name, tname)
+            n_reads += len(reads)
+            n_pairs += len(gl) + len(tl)
+            # name ids: equal names <-> equal ids inside the unit
+            ids = s.name_id[a:b].tolist()
+            assert [ids.index(x) for x in ids] == [[n for n, _ in reads].index(n) for n, _ in reads]
+        if len(s.read_len):
+            packed, woff, rlen = _lib.pack_reads([s.sequence(i) for i in range(len(s.read_len))])
+            assert np.array_equal(packed[:woff[-1]], s.packed) and np.array_equal(woff, s.word_off)
+            assert np.array_equal(rlen, s.read_len)
+    assert n_reads > 200 and n_pairs > 4000
 
 
-def test_host_pool_collects_samples_in_worker_processes():
-    """The host half of run() in forked workers (tred.host_pool, the reference's Pool over samples): what comes
-    back through pickling equals an in-process collect_sample -- reads, pair lengths, depth, the shared PREF/POST
-    dict -- and the workers never need a GPU."""
+def test_scan_options_and_failures(tmp_path):
+    repo = TREDsRepo("hg38")
+    s = scan_sample(BAM1, repo, ["HD", "SCA6"], alts=False)
+    assert s.unit["n_reads"].tolist() == [68, 0] and s.unit["n_global"][0] == 2805     # (ALT rescue: test_synth_bam)
+    missing = scan_sample(str(tmp_path / "nope.bam"), repo, ["HD"])
+    assert not missing.opened and missing.gender == "Unknown" and missing.ydepth == -1
+    nochr = scan_sample(BAM1, TREDsRepo("hg38_nochr"), ["HD"])       # contig "4" is not in this file
+    assert nochr.opened and nochr.unit["n_reads"][0] == 0 and nochr.depth[0] == 30.0
+    # sex: no reads on chrY in the test BAM -> Female, depthY 0.0 (the reference run says the same)
+    x = scan_sample(BAM1, repo, ["FXS"])
+    assert x.gender == WANT["t001"]["inferredGender"] and x.ydepth == WANT["t001"]["depthY"]
+
+
+def test_tally_follows_the_reference_bookkeeping():
+    """counts / details / rept from per-read (tag, h): PREF and POST pooled, HANG counts every aligned read, details
+    in BAM order without HANG reads; --norepeatpairs removes every read of a name that carries two REPT records."""
+    from tredparse_amd import _lib
+    from tredparse_amd.bam_parser import tally
+    repo = TREDsRepo("hg38")
+    s = scan_sample(BAM1, repo, ["HD"])
+    n = int(s.unit["n_reads"][0])
+    names = [s.name(i) for i in range(n)]
+    mate = next(i for i in range(1, n) if names[i] in names[:i])           # second record of some pair
+    first = names.index(names[mate])
+    tags = np.zeros(n, np.uint8)
+    hs = np.zeros(n, np.int16)
+    tags[first], hs[first] = _lib.TAG_REPT, 50
+    tags[mate], hs[mate] = _lib.TAG_REPT, 50
+    other = [i for i in range(n) if names[i] != names[mate]][:4]
+    for i, (t, h) in zip(other, ((_lib.TAG_FULL, 15), (_lib.TAG_PREF, 9), (_lib.TAG_POST, 9), (_lib.TAG_HANG, 3))):
+        tags[i], hs[i] = t, h
+    counts, details, rept = tally(s, 0, tags, hs, repeatpairs=True)
+    assert counts["PREF"] is counts["POST"] and counts["PREF"] == {9: 2} and counts["FULL"] == {15: 1}
+    assert counts["REPT"] == {50: 2} and rept == 2 and counts["HANG"] == {50: 2, 15: 1, 9: 2, 3: 1}
+    order = sorted([first, mate] + other[:3])
+    assert [(d["tag"], d["h"], d["id"], d["seq"]) for d in details] == \
+        [(_lib.TAG_NAMES[int(tags[i])], int(hs[i]), names[i], s.sequence(i)) for i in order]
+    counts2, details2, rept2 = tally(s, 0, tags, hs, repeatpairs=False)
+    assert rept2 == 0 and counts2["REPT"] == {} and counts2["FULL"] == {15: 1} and len(details2) == len(details) - 2
+
+
+def test_scans_run_in_host_threads():
+    """run_many's host half: scans in worker threads give what a serial scan gives (the native call releases the
+    GIL and every thread has its own file handle)."""
+    from concurrent.futures import ThreadPoolExecutor
     repo = TREDsRepo("hg38")
     args = [(s, os.path.join(GOLD, "bam", s + ".bam"), repo, ["HD", "DM1", "SCA1"], 300, False, False, True, True, "ERROR")
-            for s in ("t001", "t002")]
-    pool = tredmod.host_pool(2, len(args))
-    try:
-        remote = pool.map(tredmod.collect_sample, args)
-    finally:
-        pool.close()
-        pool.join()
-    local = [tredmod.collect_sample(a) for a in args]
-    for (r1, p1), (r2, p2) in zip(remote, local):
-        assert r1 == r2 and len(p1) == len(p2) == 3
-        for u1, u2 in zip(p1, p2):
-            assert u1.tred == u2.tred and u1.depth == u2.depth and u1.bp.reads == u2.bp.reads
-            assert u1.caller.pe.global_lens == u2.caller.pe.global_lens
-            assert u1.caller.pe.target_lens == u2.caller.pe.target_lens
-            assert u1.bp.counts["PREF"] is u1.bp.counts["POST"]
-    assert tredmod.host_pool(1, 5) is None and tredmod.host_pool(4, 1) is None
+            for s in ("t001", "t002", "t001", "t002")]
+    with ThreadPoolExecutor(4) as ex:
+        threaded = list(ex.map(tredmod.collect_sample, args))
+    serial = [tredmod.collect_sample(a) for a in args]
+    for a, b in zip(threaded, serial):
+        assert np.array_equal(a.unit, b.unit) and np.array_equal(a.packed, b.packed)
+        assert np.array_equal(a.global_lens, b.global_lens) and a.name_blob == b.name_blob
+        assert np.array_equal(a.depth, b.depth) and a.readlen == b.readlen == 150
+
+
+def test_long_read_drops_only_its_unit():
+    """A read beyond the kernel's 256 bp (or a ladder beyond 511 columns) costs its own sample x locus unit, with an
+    error log, like any failing locus of the reference -- not the sample, not the batch."""
+    from tredparse_amd import bam_parser
+    repo = TREDsRepo("hg38")
+    s = scan_sample(BAM1, repo, ["SCA1", "HD", "DM1"])
+    assert not s.dropped
+    a, _ = s.reads_of(1)
+    s.read_len[a] = 300                                # as if a MiSeq 2x300 read sat in HD's window
+    assert list(bam_parser.admit(s)) == [1] and "300 bp" in s.dropped[1]
+    s.read_len[a] = 150
+    s.readlen = 500                                    # ladder of 18 + 3 * 167 + 18 columns
+    assert sorted(bam_parser.admit(s)) == [0, 1, 2] and "ladder" in s.dropped[0]

@@ -20,7 +20,7 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=64, help="samples per repetition (the two BAMs, repeated)")
-    ap.add_argument("--cpus", type=int, default=1, help="host worker processes for the BAM half")
+    ap.add_argument("--cpus", type=int, default=1, help="host threads scanning BAMs")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--drivers", type=int, default=1,
                     help="independent driver processes sharing the GPU (each with its own --cpus workers); the "
@@ -46,7 +46,6 @@ def main():
     bams = [os.path.join(ROOT, "tests", "golden", "bam", b) for b in ("t001.bam", "t002.bam")]
     tasks = [("s{:04d}".format(i), bams[i % 2], repo, names, 300, False, False, False, True, "ERROR")
              for i in range(a.samples)]
-    pool = tred.host_pool(a.cpus, len(tasks))      # forked before the GPU runtime is initialised
     import torch  # noqa: F401  (load PyTorch's HIP runtime before libtredgpu)
     if torch.cuda.is_available():
         torch.cuda.init()
@@ -56,12 +55,9 @@ def main():
     tred.run_many(tasks[:4], engine, pool=None, sink=done.append)      # warm-up: caches, HIP context
     t0 = time.perf_counter()
     for _ in range(a.reps):
-        tred.run_many(tasks, engine, pool=pool, batch=64, sink=done.append)
+        tred.run_many(tasks, engine, batch=64, sink=done.append, threads=a.cpus)
     dt = time.perf_counter() - t0
     units = a.reps * len(tasks) * len(names)
-    if pool is not None:
-        pool.close()
-        pool.join()
     print(json.dumps({"metric": "sample x TRED genotypes/sec end to end from BAM",
                       "value": units / dt, "unit": "genotypes/s", "units": units, "seconds": dt,
                       "host_workers": a.cpus, "samples_per_rep": len(tasks), "reps": a.reps,

@@ -148,6 +148,8 @@ class _Bgzf(object):
         self.upos = uoffset
 
     def tell(self):
+        if self.block_clen > 0 and self.upos >= len(self.block):      # at a block's end = at the next block's start
+            return (self.block_coffset + self.block_clen) << 16      # (htslib's bgzf_tell; also 64 KiB blocks)
         return (self.block_coffset << 16) | self.upos
 
     def read(self, n):
@@ -352,11 +354,51 @@ def _native():
                                                C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
                                                C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
             lib.tredbam_pe_lengths.restype = C.c_int
+            lib.tredbam_max_read_len.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
+            lib.tredbam_max_read_len.restype = C.c_int
+            lib.tredbam_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p]
+            lib.tredbam_scan.restype = C.c_int
+            lib.tredbam_scan_pools.argtypes = [C.c_void_p, C.POINTER(Pools)]
+            lib.tredbam_scan_pools.restype = C.c_int
             _lib = lib
     return _lib or None
 
 
 _REC = struct.Struct("<10iHBB")   # tredbam_rec (include/tredbam.h)
+
+# ---- whole-sample scan (tredbam_scan, include/tredbam.h) ----------------------------------------------------
+import numpy as np   # noqa: E402  (only the scan path needs it)
+
+SITE_DTYPE = np.dtype([("tid", "<i4"), ("repeat_start", "<i4"), ("repeat_end", "<i4"), ("alt_first", "<i4"),
+                       ("n_alt", "<i4")])
+REGION_DTYPE = np.dtype([("tid", "<i4"), ("start", "<i4"), ("end", "<i4")])
+SCAN_UNIT_DTYPE = np.dtype([("status", "<i4"), ("n_reads", "<i4"), ("read_first", "<i8"), ("depth_sum", "<i8"),
+                            ("depth_status", "<i4"), ("pe_status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"),
+                            ("global_first", "<i8"), ("target_first", "<i8")])
+UNIT_NO_FETCH, UNIT_FAILED = 1, 2
+
+
+class ScanOpts(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("readlen", "pad", "flank", "pe_reach", "span", "use_alts", "want_depth",
+                                         "want_pe")]
+
+
+class Pools(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_words", C.c_int64), ("n_global", C.c_int64), ("n_target", C.c_int64),
+                ("packed", C.c_void_p), ("word_off", C.c_void_p), ("read_len", C.c_void_p), ("seq4", C.c_void_p),
+                ("seq4_off", C.c_void_p), ("names", C.c_void_p), ("name_off", C.c_void_p), ("name_id", C.c_void_p),
+                ("global_lens", C.c_void_p), ("target_lens", C.c_void_p)]
+
+
+assert SITE_DTYPE.itemsize == 20 and REGION_DTYPE.itemsize == 12 and SCAN_UNIT_DTYPE.itemsize == 56
+
+
+def _copy(ptr, count, dtype):
+    """numpy copy of `count` items at C address ptr (the pools are only valid until the handle's next scan)."""
+    dtype = np.dtype(dtype)
+    if not count:
+        return np.zeros(0, dtype)
+    return np.frombuffer(C.string_at(ptr, int(count) * dtype.itemsize), dtype).copy()
 
 
 class NativeRead(Read):
@@ -494,6 +536,40 @@ class NativeAlignmentFile(object):
     def _has_index(self):
         return any(os.path.exists(c) for c in (self.path + ".bai", os.path.splitext(self.path)[0] + ".bai"))
 
+    def max_read_len(self, first_n=101):
+        """Largest query length among the first records of the file (the sample's READLEN)."""
+        out = C.c_int32()
+        if self._lib.tredbam_max_read_len(self._h, int(first_n), C.byref(out)) != 0:
+            raise ValueError(self._err())
+        return int(out.value)
+
+    def tid(self, chrom):
+        return self._tid.get(chrom, -1)
+
+    def scan(self, sites, alts, readlen, pad=1000, flank=9, pe_reach=10000, span=1000, use_alts=True,
+             want_depth=True, want_pe=True):
+        """tredbam_scan: `sites` (SITE_DTYPE) and `alts` (REGION_DTYPE) -> (units SCAN_UNIT_DTYPE, dict of pool
+        arrays).  One native call; the GIL is released while it runs."""
+        sites = np.ascontiguousarray(sites, SITE_DTYPE)
+        alts = np.ascontiguousarray(alts if len(alts) else np.zeros(1, REGION_DTYPE), REGION_DTYPE)
+        units = np.zeros(len(sites), SCAN_UNIT_DTYPE)
+        o = ScanOpts(int(readlen), int(pad), int(flank), int(pe_reach), int(span), int(bool(use_alts)),
+                     int(bool(want_depth)), int(bool(want_pe)))
+        rc = self._lib.tredbam_scan(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o),
+                                    units.ctypes.data)
+        if rc != 0:
+            raise ValueError(self._err())
+        p = Pools()
+        self._lib.tredbam_scan_pools(self._h, C.byref(p))
+        n = p.n_reads
+        pools = {"packed": _copy(p.packed, p.n_words, "<u4"), "word_off": _copy(p.word_off, n + 1, "<i8"),
+                 "read_len": _copy(p.read_len, n, "<i4"), "seq4": _copy(p.seq4, _last(p.seq4_off, n), "u1"),
+                 "seq4_off": _copy(p.seq4_off, n + 1, "<i8"), "names": C.string_at(p.names, _last(p.name_off, n)),
+                 "name_off": _copy(p.name_off, n + 1, "<i8"), "name_id": _copy(p.name_id, n, "<i4"),
+                 "global_lens": _copy(p.global_lens, p.n_global, "<i4"),
+                 "target_lens": _copy(p.target_lens, p.n_target, "<i4")}
+        return units, pools
+
     def pe_lengths(self, chrom, start, end, tstart, tend, span):
         """(global_lens, target_lens) of PEextractor (bam_parser.py:316-369) for the window [start, end)."""
         if chrom not in self._tid:
@@ -512,6 +588,11 @@ class NativeAlignmentFile(object):
             if ng.value <= cap_g and nt.value <= cap_t:
                 return list(g[:ng.value]), list(t[:nt.value])
             cap_g, cap_t = max(cap_g, ng.value), max(cap_t, nt.value)
+
+
+def _last(off_ptr, n):
+    """off[n] of an int64 offset array at C address off_ptr."""
+    return int(C.cast(off_ptr, C.POINTER(C.c_int64))[n]) if off_ptr else 0
 
 
 def AlignmentFile(path, mode="rb"):

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -40,6 +41,12 @@ struct tredbam {
     int64_t block_coffset = -1, block_clen = 0;
     std::vector<uint8_t> block, cbuf;
     size_t upos = 0;
+    // inflated blocks seen recently (compressed offset -> data, compressed length): the three queries of a locus
+    // (depth, reads, pairs) and the alternative-locus queries of neighbouring loci walk the same blocks again
+    struct Cached { std::vector<uint8_t> data; int64_t clen; };
+    std::unordered_map<int64_t, Cached> cache;
+    std::deque<int64_t> cache_order;
+    static constexpr size_t CACHE_BLOCKS = 512;   // <= 32 MiB per open file
     // header
     std::vector<std::string> ref_names;
     std::vector<int64_t> ref_lens;
@@ -51,6 +58,12 @@ struct tredbam {
     // output of the last fetch
     std::vector<uint8_t> out;
     std::vector<uint8_t> rec;
+    // pools of the last tredbam_scan (include/tredbam.h)
+    std::vector<uint32_t> sc_packed;
+    std::vector<int64_t> sc_word_off, sc_seq4_off, sc_name_off;
+    std::vector<int32_t> sc_read_len, sc_name_id, sc_global, sc_target;
+    std::vector<uint8_t> sc_seq4;
+    std::vector<char> sc_names;
 };
 
 namespace {
@@ -67,8 +80,16 @@ int fail(tredbam* b, int code, const char* fmt, ...) {
 
 // Load the BGZF block that starts at compressed offset coffset.  Returns 1, 0 at end of file, <0 on error.
 int load_block(tredbam* b, int64_t coffset) {
-    b->block.clear();
     b->block_coffset = coffset;
+    {
+        const auto hit = b->cache.find(coffset);
+        if (hit != b->cache.end()) {
+            b->block = hit->second.data;
+            b->block_clen = hit->second.clen;
+            return 1;
+        }
+    }
+    b->block.clear();
     b->block_clen = 0;
     if (fseeko(b->fp, (off_t)coffset, SEEK_SET) != 0) return fail(b, -5, "seek to %lld failed", (long long)coffset);
     uint8_t hdr[18];
@@ -106,6 +127,12 @@ int load_block(tredbam* b, int64_t coffset) {
         if (rc != Z_STREAM_END || zs.total_out != isize) return fail(b, -7, "inflate failed at %lld", (long long)coffset);
     }
     b->block_clen = clen;
+    if (b->cache.size() >= tredbam::CACHE_BLOCKS) {
+        b->cache.erase(b->cache_order.front());
+        b->cache_order.pop_front();
+    }
+    b->cache.emplace(coffset, tredbam::Cached{b->block, clen});
+    b->cache_order.push_back(coffset);
     return 1;
 }
 
@@ -119,7 +146,12 @@ int bg_seek(tredbam* b, uint64_t voffset) {
     return 0;
 }
 
-uint64_t bg_tell(const tredbam* b) { return ((uint64_t)b->block_coffset << 16) | (uint64_t)b->upos; }
+// A position at (or, for a 64 KiB block, past the 16 bits of) the end of the current block is the start of the next
+// block -- what htslib's bgzf_tell reports -- so that it compares correctly with chunk ends of the index.
+uint64_t bg_tell(const tredbam* b) {
+    if (b->block_clen > 0 && b->upos >= b->block.size()) return (uint64_t)(b->block_coffset + b->block_clen) << 16;
+    return ((uint64_t)b->block_coffset << 16) | (uint64_t)b->upos;
+}
 
 // read n bytes; returns the number actually read (short at end of file), <0 on error
 int64_t bg_read(tredbam* b, uint8_t* dst, int64_t n) {
@@ -311,6 +343,96 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
     return n;
 }
 
+
+// The paired-end selection behind tredbam_pe_lengths / tredbam_scan (see include/tredbam.h for the rules).
+int pair_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t tstart, int64_t tend, int32_t span,
+                 std::vector<int32_t>& global_lens, std::vector<int32_t>& target_lens) {
+    struct Mate { int32_t pos, end, lead_clip, trail_clip; bool reverse; };
+    struct Pair { int n; Mate m[2]; };
+    std::unordered_map<std::string, size_t> slot;
+    std::vector<Pair> pairs;   // in order of first appearance (the reference walks a dict in that order)
+    const int64_t n = walk_region(b, tid, start, end, false, [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
+        if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) return true;   // paired, mapped, not a duplicate
+        const int l_name = r[8];
+        const int n_cigar = le16(r + 12);
+        std::string name((const char*)r + 32, (size_t)std::max(l_name - 1, 0));
+        auto it = slot.find(name);
+        if (it == slot.end()) {
+            it = slot.emplace(std::move(name), pairs.size()).first;
+            pairs.push_back(Pair{0, {}});
+        }
+        Pair& p = pairs[it->second];
+        if (p.n < 2) {
+            Mate& m = p.m[p.n];
+            m.pos = rpos;
+            m.end = rend;
+            m.reverse = (flag & 0x10) != 0;
+            const uint8_t* cig = r + 32 + l_name;
+            int32_t lead = 0, trail = 0;
+            for (int k = 0; k < n_cigar; ++k) {            // query_alignment_start: leading soft clips
+                const uint32_t c = le32(cig + 4 * k);
+                if ((c & 15) == 4) lead += (int32_t)(c >> 4);
+                else if ((c & 15) == 5) continue;
+                else break;
+            }
+            for (int k = n_cigar - 1; k >= 0; --k) {       // query_length - query_alignment_end
+                const uint32_t c = le32(cig + 4 * k);
+                if ((c & 15) == 4) trail += (int32_t)(c >> 4);
+                else if ((c & 15) == 5) continue;
+                else break;
+            }
+            m.lead_clip = lead;
+            m.trail_clip = trail;
+        }
+        ++p.n;
+        return true;
+    });
+    if (n < 0) return (int)n;
+    for (const Pair& p : pairs) {
+        if (p.n < 2) continue;
+        const Mate &a = p.m[0], &bb = p.m[1];
+        if (a.reverse || !bb.reverse) continue;            // mapped in +, - orientation
+        if (bb.end < 0) return fail(b, -9, "paired read without an alignment end in the window");
+        const int64_t tlen = ((int64_t)bb.end + bb.trail_clip) - ((int64_t)a.pos - a.lead_clip);
+        if (tlen >= span) continue;
+        if (a.pos < tstart && bb.end > tend) target_lens.push_back((int32_t)tlen);
+        else global_lens.push_back((int32_t)tlen);
+    }
+    return 0;
+}
+
+// One selected read into the scan pools: 2-bit codes + N mask in libtredgpu's read layout (tredgpu.h: ceil(L/16)
+// words of codes, base k in bits 2k..2k+1, then ceil(L/32) words of N flags), the raw 4-bit sequence for the
+// JSON `details`, the query name, and the index of that name among the unit's names (the pair id of
+// --norepeatpairs).
+void pool_read(tredbam* b, const uint8_t* r, std::unordered_map<std::string, int32_t>& names) {
+    const int l_name = r[8];
+    const int n_cigar = le16(r + 12);
+    const int32_t L = (int32_t)le32(r + 16);
+    const uint8_t* seq = r + 32 + l_name + 4 * (size_t)n_cigar;
+    const size_t nb = ((size_t)L + 15) >> 4, nm = ((size_t)L + 31) >> 5;
+    const size_t w0 = b->sc_packed.size();
+    b->sc_packed.resize(w0 + nb + nm, 0u);
+    uint32_t* rec = b->sc_packed.data() + w0;
+    static const int8_t CODE[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};   // "=ACMGRSVTWYHKDBN"
+    for (int32_t i = 0; i < L; ++i) {
+        const uint8_t v = seq[i >> 1];
+        const int code = CODE[(i & 1) ? (v & 15) : (v >> 4)];
+        if (code == 4) rec[nb + ((size_t)i >> 5)] |= 1u << (i & 31);
+        else rec[(size_t)i >> 4] |= (uint32_t)code << ((i & 15) * 2);
+    }
+    b->sc_word_off.push_back((int64_t)b->sc_packed.size());
+    b->sc_read_len.push_back(L);
+    b->sc_seq4.insert(b->sc_seq4.end(), seq, seq + ((size_t)L + 1) / 2);
+    b->sc_seq4_off.push_back((int64_t)b->sc_seq4.size());
+    const char* nm_p = (const char*)r + 32;
+    const size_t nlen = (size_t)std::max(l_name - 1, 0);
+    b->sc_names.insert(b->sc_names.end(), nm_p, nm_p + nlen);
+    b->sc_name_off.push_back((int64_t)b->sc_names.size());
+    const auto it = names.emplace(std::string(nm_p, nlen), (int32_t)names.size()).first;
+    b->sc_name_id.push_back(it->second);
+}
+
 }  // namespace
 
 extern "C" {
@@ -438,66 +560,110 @@ int tredbam_pe_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int6
                        int32_t* target_lens, int64_t cap_target, int64_t* n_target) {
     if (!b || !n_global || !n_target) return -2;
     b->out.clear();
-    struct Mate { int32_t pos, end, l_seq, lead_clip, trail_clip; bool reverse; };
-    struct Pair { int n; Mate m[2]; };
-    std::unordered_map<std::string, size_t> slot;
-    std::vector<Pair> pairs;   // in order of first appearance (the reference walks a dict in that order)
-    const int64_t n = walk_region(b, tid, start, end, false, [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
-        if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) return true;   // paired, mapped, not a duplicate
-        const int l_name = r[8];
-        const int n_cigar = le16(r + 12);
-        std::string name((const char*)r + 32, (size_t)std::max(l_name - 1, 0));
-        auto it = slot.find(name);
-        if (it == slot.end()) {
-            it = slot.emplace(std::move(name), pairs.size()).first;
-            pairs.push_back(Pair{0, {}});
+    std::vector<int32_t> g, t;
+    const int rc = pair_lengths(b, tid, start, end, tstart, tend, span, g, t);
+    if (rc < 0) return rc;
+    for (size_t i = 0; i < g.size() && global_lens && (int64_t)i < cap_global; ++i) global_lens[i] = g[i];
+    for (size_t i = 0; i < t.size() && target_lens && (int64_t)i < cap_target; ++i) target_lens[i] = t[i];
+    *n_global = (int64_t)g.size();
+    *n_target = (int64_t)t.size();
+    return 0;
+}
+
+int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out) {
+    if (!b || !out) return -2;
+    int rc = bg_seek(b, b->first_record);
+    if (rc < 0) return rc;
+    int32_t best = -1;
+    for (int64_t k = 0; first_n <= 0 || k < first_n; ++k) {
+        rc = next_record(b);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        best = std::max(best, (int32_t)le32(b->rec.data() + 16));
+    }
+    if (best < 0) return fail(b, -8, "no alignment records in %s", b->path.c_str());
+    *out = best;
+    return 0;
+}
+
+int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
+                 const tredbam_scan_opts* o, tredbam_unit* units) {
+    if (!b || !o || n_sites < 0 || (n_sites > 0 && (!sites || !units))) return -2;
+    b->out.clear();
+    b->sc_packed.clear(); b->sc_read_len.clear(); b->sc_seq4.clear(); b->sc_names.clear(); b->sc_name_id.clear();
+    b->sc_global.clear(); b->sc_target.clear();
+    b->sc_word_off.assign(1, 0); b->sc_seq4_off.assign(1, 0); b->sc_name_off.assign(1, 0);
+    for (int32_t i = 0; i < n_sites; ++i) {
+        const tredbam_site& st = sites[i];
+        tredbam_unit& u = units[i];
+        memset(&u, 0, sizeof u);
+        u.read_first = (int64_t)b->sc_read_len.size();
+        u.global_first = (int64_t)b->sc_global.size();
+        u.target_first = (int64_t)b->sc_target.size();
+        const int64_t win_lo = std::max<int64_t>(0, (int64_t)st.repeat_start - o->pad);
+        const int64_t win_hi = (int64_t)st.repeat_end + o->pad;
+        const int64_t pos_lo = std::max<int64_t>(0, (int64_t)st.repeat_start - o->readlen);
+        const int64_t pos_hi = (int64_t)st.repeat_end + o->readlen;
+        // depth of the window (pileup without truncation; see tredbam_pileup_depth_sum)
+        if (o->want_depth) {
+            int64_t total = 0;
+            const int rc = tredbam_pileup_depth_sum(b, st.tid, win_lo, win_hi, &total);
+            u.depth_status = rc;
+            u.depth_sum = rc == 0 ? total : 0;
         }
-        Pair& p = pairs[it->second];
-        if (p.n < 2) {
-            Mate& m = p.m[p.n];
-            m.pos = rpos;
-            m.end = rend;
-            m.l_seq = (int32_t)le32(r + 16);
-            m.reverse = (flag & 0x10) != 0;
-            const uint8_t* cig = r + 32 + l_name;
-            int32_t lead = 0, trail = 0;
-            for (int k = 0; k < n_cigar; ++k) {            // query_alignment_start: leading soft clips
-                const uint32_t c = le32(cig + 4 * k);
-                if ((c & 15) == 4) lead += (int32_t)(c >> 4);
-                else if ((c & 15) == 5) continue;
-                else break;
+        // read selection: unmapped reads placed in the window (their mate is the anchor) and reads starting within
+        // one read length of the tract; then, from the alternative loci, reads whose MATE lies in the window
+        std::unordered_map<std::string, int32_t> names;
+        const int64_t n = walk_region(b, st.tid, win_lo, win_hi, false, [&](int32_t, int32_t rpos, uint16_t flag, const uint8_t* r) {
+            if ((flag & 0x4) != 0 || (rpos >= pos_lo && rpos <= pos_hi)) pool_read(b, r, names);
+            return true;
+        });
+        if (n == -2 || n == -4) u.status |= TREDBAM_UNIT_NO_FETCH;        // unknown contig / no index: no reads, go on
+        else if (n < 0) u.status |= TREDBAM_UNIT_FAILED;
+        if (n >= 0 && o->use_alts) {
+            for (int32_t k = 0; k < st.n_alt; ++k) {
+                const tredbam_region& a = alts[st.alt_first + k];
+                if (a.tid < 0) continue;                                 // contig not in this file: skipped
+                walk_region(b, a.tid, a.start, a.end, false, [&](int32_t, int32_t, uint16_t, const uint8_t* r) {
+                    const int32_t mate_tid = (int32_t)le32(r + 20), mate_pos = (int32_t)le32(r + 24);
+                    if (mate_tid == st.tid && mate_pos >= win_lo && mate_pos <= win_hi) pool_read(b, r, names);
+                    return true;
+                });
             }
-            for (int k = n_cigar - 1; k >= 0; --k) {       // query_length - query_alignment_end
-                const uint32_t c = le32(cig + 4 * k);
-                if ((c & 15) == 4) trail += (int32_t)(c >> 4);
-                else if ((c & 15) == 5) continue;
-                else break;
-            }
-            m.lead_clip = lead;
-            m.trail_clip = trail;
         }
-        ++p.n;
-        return true;
-    });
-    if (n < 0) return (int)n;
-    int64_t ng = 0, nt = 0;
-    for (const Pair& p : pairs) {
-        if (p.n < 2) continue;
-        const Mate &a = p.m[0], &bb = p.m[1];
-        if (a.reverse || !bb.reverse) continue;            // mapped in +, - orientation
-        if (bb.end < 0) return fail(b, -9, "paired read without an alignment end in the window");
-        const int64_t tlen = ((int64_t)bb.end + bb.trail_clip) - ((int64_t)a.pos - a.lead_clip);
-        if (tlen >= span) continue;
-        if (a.pos < tstart && bb.end > tend) {
-            if (target_lens && nt < cap_target) target_lens[nt] = (int32_t)tlen;
-            ++nt;
-        } else {
-            if (global_lens && ng < cap_global) global_lens[ng] = (int32_t)tlen;
-            ++ng;
+        u.n_reads = (int32_t)((int64_t)b->sc_read_len.size() - u.read_first);
+        // paired-end lengths around the tract
+        if (o->want_pe && !(u.status & TREDBAM_UNIT_FAILED)) {
+            const int64_t p_lo = std::max<int64_t>((int64_t)st.repeat_start - o->pe_reach, 0);
+            const int64_t p_hi = (int64_t)st.repeat_end + o->pe_reach;
+            const size_t g0 = b->sc_global.size(), t0 = b->sc_target.size();
+            const int rc = pair_lengths(b, st.tid, p_lo, p_hi, (int64_t)st.repeat_start - o->flank,
+                                        (int64_t)st.repeat_end + o->flank, o->span, b->sc_global, b->sc_target);
+            if (rc < 0) { b->sc_global.resize(g0); b->sc_target.resize(t0); }
+            u.pe_status = (rc == -2 || rc == -4) ? 0 : rc;     // unknown contig / no index: empty lists, as for the reads
+            u.n_global = (int32_t)(b->sc_global.size() - g0);
+            u.n_target = (int32_t)(b->sc_target.size() - t0);
         }
     }
-    *n_global = ng;
-    *n_target = nt;
+    return 0;
+}
+
+int tredbam_scan_pools(tredbam* b, tredbam_pools* p) {
+    if (!b || !p) return -2;
+    p->n_reads = (int64_t)b->sc_read_len.size();
+    p->packed = b->sc_packed.data();
+    p->n_words = (int64_t)b->sc_packed.size();
+    p->word_off = b->sc_word_off.data();
+    p->read_len = b->sc_read_len.data();
+    p->seq4 = b->sc_seq4.data();
+    p->seq4_off = b->sc_seq4_off.data();
+    p->names = b->sc_names.data();
+    p->name_off = b->sc_name_off.data();
+    p->name_id = b->sc_name_id.data();
+    p->global_lens = b->sc_global.data();
+    p->n_global = (int64_t)b->sc_global.size();
+    p->target_lens = b->sc_target.data();
+    p->n_target = (int64_t)b->sc_target.size();
     return 0;
 }
 

@@ -50,6 +50,81 @@ class Unit(object):
 JOINT_CAP = 512   # sparse joint entries per unit asked for first (pairs with exp(ml - max) >= e^-10)
 
 
+class PackedUnits(object):
+    """A batch of sample x locus units already in the C ABI's layout (include/tredgpu.h): what
+    bam_parser.scan_sample produces, concatenated over samples.  No read strings, no per-read Python objects.
+
+      packed / read_off / read_len          the reads, unit after unit
+      unit_read_off, ladder_keys[unit]      reads of each unit; its template ladder (prefix, repeat, suffix, max_units)
+      params (UNIT_DTYPE)                   grid inputs; pe_off / tl_off index global_lens / target_lens
+      pair_id                               per read, for --norepeatpairs (None otherwise)
+      origin                                (scan, k) of every unit, for the way back
+    """
+
+    @classmethod
+    def from_scans(cls, picks, maxinsert=300, fullsearch=False, clip=False, repeatpairs=True):
+        """picks: [(SampleScan, [locus indices])] -- the listed loci of each scan, in that order."""
+        b = cls()
+        b.clip, b.origin, b.ladder_keys = bool(clip), [], []
+        words, lens, ids, gls, tls, n_reads = [], [], [], [], [], [0]
+        rows = []
+        n_gl = n_tl = 0
+        for scan, ks in picks:
+            for k in ks:
+                t, u = scan.loci[k], scan.unit[k]
+                a, e = scan.reads_of(k)
+                words.append((scan.packed[scan.word_off[a]:scan.word_off[e]], scan.word_off[a:e + 1] - scan.word_off[a]))
+                lens.append(scan.read_len[a:e])
+                ids.append(scan.name_id[a:e])
+                g, tl = scan.pair_lengths(k)
+                gls.append(g)
+                tls.append(tl)
+                n_reads.append(n_reads[-1] + (e - a))
+                period = len(t.repeat)
+                span = t.repeat_end - t.repeat_start
+                rows.append((period, scan.readlen, int(scan.ploidy[k]), maxinsert, int(fullsearch), span + 1,
+                             span + 20, int(t.cutoff_risk), int(t.is_expansion), int(t.is_recessive), n_gl, len(g),
+                             n_tl, len(tl), float(scan.depth[k]) / 2))
+                n_gl += len(g)
+                n_tl += len(tl)
+                b.ladder_keys.append((t.prefix, t.repeat, t.suffix, -(-scan.readlen // period)))
+                b.origin.append((scan, k))
+        b.n_units = len(rows)
+        b.params = np.array(rows, _lib.UNIT_DTYPE) if rows else np.zeros(0, _lib.UNIT_DTYPE)
+        b.unit_read_off = np.asarray(n_reads, np.int32)
+        b.n_reads = int(n_reads[-1])
+        wbase, offs = 0, [np.zeros(1, np.int64)]
+        for w, o in words:
+            offs.append(o[1:] + wbase)
+            wbase += len(w)
+        cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts), dt) if parts else np.zeros(0, dt)
+        b.packed = cat([w for w, _ in words], np.uint32)
+        b.read_off = cat(offs, np.int64)
+        b.read_len = cat(lens, np.int32)
+        b.pair_id = None if (repeatpairs or clip) else cat(ids, np.int32)
+        b.global_lens, b.target_lens = cat(gls, np.int32), cat(tls, np.int32)
+        b.max_units = max([k[3] for k in b.ladder_keys] + [1])
+        return b
+
+
+class BatchResult(object):
+    """Arrays of one genotyped PackedUnits batch; unit(i) gives the per-unit view the callers format."""
+    __slots__ = ("batch", "tag", "h", "score", "full", "pref", "rept", "calls", "marg", "joint")
+
+    def unit(self, i):
+        b = self.batch
+        a, e = int(b.unit_read_off[i]), int(b.unit_read_off[i + 1])
+        r = UnitResult()
+        r.tags, r.hs, r.scores = self.tag[a:e], self.h[a:e], self.score[a:e]
+        r.full = r.pref = r.rept_hist = None
+        r.rept = int(self.rept[i].sum())
+        r.call = self.calls[i]
+        r.grid = None
+        r.joint = self.joint[i] if self.calls[i]["status"] == 0 else None
+        r.P_h1, r.P_h2 = self.marg[i, 0], self.marg[i, 1]
+        return r
+
+
 class UnitResult(object):
     """grid: the dense dump {h1, h2, ml1..ml4} per pair (only when asked for); joint: (triples {h1, h2, exp(ml - max)}
     of the pairs >= e^-10, total over all distinct pairs) -- what P_h1h2 is printed from."""
@@ -65,6 +140,68 @@ class Engine(object):
 
     def close(self):
         self.ctx.close()
+
+    # ---- packed batches (the product path) ------------------------------------------------------------
+    def _register(self, keys):
+        """Ladder index of every key; the context's ladder table only ever grows, so indices stay valid."""
+        known = self._ladders or []
+        index = {k: i for i, k in enumerate(known)}
+        grew = False
+        for k in keys:
+            if k not in index:
+                index[k] = len(known)
+                known = known + [k]
+                grew = True
+        if grew or self._ladders is None:
+            self.ctx.set_ladders(known)
+            self._ladders = known
+        return np.asarray([index[k] for k in keys], np.int32)
+
+    def classify_packed(self, b):
+        """SW + tagging of a PackedUnits batch: (tag u8[], h i16[], score i16[]) per read."""
+        n = b.n_reads
+        tag, h, sc = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.int16), np.zeros(max(n, 1), np.int16)
+        if n:
+            lad = self._register(b.ladder_keys)
+            self.ctx.sw_classify(_lib.MEM_HOST, b.packed, b.read_off, b.read_len, n, b.unit_read_off, lad, b.n_units,
+                                 _lib.default_sw_params(clip=b.clip), tag, h, sc, None, 0)
+        return tag[:n], h[:n], sc[:n]
+
+    def genotype_packed(self, b):
+        """The whole path for a PackedUnits batch -> BatchResult (sparse joint distribution included)."""
+        r = BatchResult()
+        r.batch = b
+        r.tag, r.h, r.score = self.classify_packed(b)
+        g, n = b.n_units, b.n_reads
+        hs = b.max_units + 2
+        r.full, r.pref, r.rept = (np.zeros((g, hs), np.int32) for _ in range(3))
+        self.ctx.tally(_lib.MEM_HOST, r.tag if n else np.zeros(1, np.uint8), r.h if n else np.zeros(1, np.int16), n,
+                       b.unit_read_off, g, b.pair_id if n else None, hs, r.full, r.pref, r.rept)
+        ms = max(int(b.params["maxinsert"].max()) if g else 0, hs) + 2
+        r.calls, r.marg, r.joint = self._grid_arrays(b.params, hs, r.full, r.pref, r.rept, b.global_lens,
+                                                     b.target_lens, ms)
+        return r
+
+    def _grid_arrays(self, up, hs, full, pref, rept, gl, tl, ms):
+        """likelihood_grid_joint over array inputs; grows the joint capacity when a flat surface needs it."""
+        g = len(up)
+        ngl, ntl = len(gl), len(tl)
+        gl = gl if ngl else np.zeros(1, np.int32)
+        tl = tl if ntl else np.zeros(1, np.int32)
+        calls = np.zeros(g, _lib.CALL_DTYPE)
+        marg = np.zeros((g, 2, ms), np.float64)
+        cap = np.full(g, JOINT_CAP, np.int64)
+        while True:
+            joff = np.zeros(g + 1, np.int64)
+            joff[1:] = np.cumsum(cap)
+            trip = np.zeros((int(joff[-1]), 3), np.float64)
+            jn, jt = np.zeros(g, np.int32), np.zeros(g, np.float64)
+            self.ctx.likelihood_grid_joint(_lib.MEM_HOST, up, g, hs, full, pref, rept, gl, ngl, tl, ntl, calls, marg, ms,
+                                           joff, trip, jn, jt)
+            if (jn <= cap).all():
+                break
+            cap = np.maximum(cap, jn)
+        return calls, marg, [(trip[joff[i]:joff[i] + jn[i]], float(jt[i])) for i in range(g)]
 
     # ---- (1) SW + tagging only -----------------------------------------------------------------------
     def classify(self, units, want_dump=False):

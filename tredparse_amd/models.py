@@ -1,10 +1,9 @@
 """Host mirror of tredparse/models.py's caller interface on top of the GPU likelihood grid.
 
-IntegratedCaller keeps the reference's constructor and attributes (models.py:101-147, 394-415):
-``alleles, label, CI, PP, P_h1, P_h2, P_h1h2, PEDP, PEG, PET, P_PEG, P_PET``.  The grid itself
-(pdf_spanning .. evaluate, calc_CI, calc_PP, PEMaxLikModel; models.py:149-368, 426-473) runs in
-libtredgpu.so; what stays on the host is formatting: sparsify (:304-317), calc_label (:370-392),
-mean_std / histogram (:87-98).
+The grid itself (pdf_spanning .. evaluate, calc_CI, calc_PP, PEMaxLikModel; models.py:149-368, 426-473) runs in
+libtredgpu.so; what stays on the host is formatting: `format_call` turns a unit's kernel results into the
+caller's outputs (alleles, CI, PP, label, sparse marginals and joint), `pair_summary` the pair-length
+statistics.  IntegratedCaller keeps the reference's constructor and attributes for single-locus use.
 """
 import logging
 from math import exp
@@ -27,37 +26,39 @@ class GridError(RuntimeError):
     pass
 
 
-def mean_std(a):  # models.py:87-91
-    if not a:
+def mean_std(lengths):
+    """'346+/-78bp' (population standard deviation); '' for no pairs."""
+    if len(lengths) == 0:
         return ""
-    a = np.array(a)
-    return "{:.0f}+/-{:.0f}bp".format(a.mean(), a.std())
+    v = np.asarray(lengths, np.float64)
+    return "%.0f+/-%.0fbp" % (v.mean(), v.std())
 
 
-def histogram(a, bins=40):  # models.py:94-98
-    if not a:
+def histogram(lengths, bins=40):
+    """'0:0,25:3,...': counts of pair lengths in `bins` equal bins over [0, SPAN], keyed by the bin's left edge."""
+    if len(lengths) == 0:
         return ""
-    ar, br = np.histogram(a, bins=bins, range=(0, SPAN))
-    return ",".join(["{}:{}".format(int(b), a) for (a, b) in zip(ar, br)])
+    counts, edges = np.histogram(np.asarray(lengths), bins=bins, range=(0, SPAN))
+    return ",".join("%d:%d" % (left, c) for left, c in zip(edges[:-1], counts))
 
 
-def calc_label(tred, alleles):  # models.py:370-392
-    a, b = sorted(alleles)
-    label = "ok" if a != -1 else "missing"
-    cutoff_prerisk, cutoff_risk = tred.cutoff_prerisk, tred.cutoff_risk
+def calc_label(tred, alleles):
+    """ok / prerisk / risk / missing for a pair of allele sizes (repeat units; -1 = no call).
+    The decisive allele is the longer one for a dominant expansion disorder and the shorter one for a recessive
+    one (both copies must be expanded); for loci whose pathogenic change is a contraction the roles swap and
+    "risk" means 0 < allele <= cutoff.  The pre-risk band [cutoff_prerisk, cutoff_risk) is tested first."""
+    lo, hi = min(alleles), max(alleles)
     if tred.is_expansion:
-        crit_allele = a if tred.is_recessive else b
-        if cutoff_prerisk <= crit_allele < cutoff_risk:
-            label = "prerisk"
-        elif crit_allele >= cutoff_risk:
-            label = "risk"
+        decisive = lo if tred.is_recessive else hi
+        at_risk = decisive >= tred.cutoff_risk
     else:
-        crit_allele = b if tred.is_recessive else a
-        if cutoff_prerisk <= crit_allele < cutoff_risk:
-            label = "prerisk"
-        elif 0 < crit_allele <= cutoff_risk:
-            label = "risk"
-    return label
+        decisive = hi if tred.is_recessive else lo
+        at_risk = 0 < decisive <= tred.cutoff_risk
+    if tred.cutoff_prerisk <= decisive < tred.cutoff_risk:
+        return "prerisk"
+    if at_risk:
+        return "risk"
+    return "missing" if lo == -1 else "ok"
 
 
 def sparsify_marginal(P, epsilon=SMALL_VALUE):
@@ -83,65 +84,65 @@ def sparsify_joint_triples(triples, total, period):
     return {"{},{}".format(int(h1) // period, int(h2) // period): float(v) / total for h1, h2, v in triples}
 
 
+def format_call(tred, res):
+    """The caller's outputs for one unit from an engine.UnitResult, as a dict:
+    alleles (units, sorted), lik, PP, CI "lo-hi|lo-hi", label, P_h1, P_h2, P_h1h2 (sparse, keyed by units).
+    Raises GridError where the reference's grid raises (the locus is then dropped)."""
+    call = res.call
+    status = int(call["status"])
+    if status < 0:
+        raise GridError(STATUS_ERRORS.get(status, "status {}".format(status)))
+    period = len(tred.repeat)
+    out = {"P_h1": "", "P_h2": "", "P_h1h2": ""}
+    if status == 1:                      # no read evidence at all
+        out.update(alleles=[-1, -1], lik=-1, PP=-1, CI="")
+    else:
+        out["alleles"] = sorted((int(call["h1"]) // period, int(call["h2"]) // period))
+        out["lik"], out["PP"] = float(call["lik"]), float(call["pp"])
+        out["CI"] = "{}-{}|{}-{}".format(*(int(x) for x in call["ci"]))
+        out["P_h1"], out["P_h2"] = sparsify_marginal(res.P_h1), sparsify_marginal(res.P_h2)
+        if getattr(res, "joint", None) is not None:
+            out["P_h1h2"] = sparsify_joint_triples(res.joint[0], res.joint[1], period)
+        elif res.grid is not None:
+            out["P_h1h2"] = sparsify_joint(res.grid, period)
+    out["label"] = calc_label(tred, out["alleles"])
+    return out
+
+
+def pair_summary(global_lens, target_lens):
+    """PEDP, PEG, PET, P_PEG, P_PET of the JSON from the two pair-length lists."""
+    g, t = list(global_lens), list(target_lens)
+    return {"PEDP": len(t), "PEG": mean_std(g), "PET": mean_std(t), "P_PEG": histogram(g), "P_PET": histogram(t)}
+
+
 class IntegratedCaller:
-    """Same constructor and result attributes as the reference's IntegratedCaller."""
+    """Single-locus view with the reference's constructor and result attributes (models.py:101-147, 394-415):
+    IntegratedCaller(bamParser, maxinsert=, fullsearch=).call() fills alleles, label, CI, PP, P_h1, P_h2, P_h1h2;
+    PEDP / PEG / PET / P_PEG / P_PET are there from construction.  The grid runs in libtredgpu.so."""
 
     def __init__(self, bamParser, score=1.0, gc=.68, maxinsert=300, fullsearch=False, pe=None):
-        self.bamParser = bamParser
-        self.tred = bamParser.tred
-        self.readlen = bamParser.READLEN
-        self.period = bamParser.repeatSize
-        self.counts = bamParser.counts
-        self.rept = bamParser.rept
-        self.ploidy = bamParser.ploidy
-        self.half_depth = bamParser.depth / 2
-        self.maxinsert = maxinsert
-        self.fullsearch = fullsearch
-        self.logger = logging.getLogger('IntegratedCaller')
+        self.bamParser, self.tred = bamParser, bamParser.tred
+        self.maxinsert, self.fullsearch = maxinsert, fullsearch
         self.pe = pe if pe is not None else PEextractor(bamParser)
-        self.PEDP = len(self.pe.target_lens)
-        self.PEG = mean_std(self.pe.global_lens)
-        self.PET = mean_std(self.pe.target_lens)
-        self.P_PEG = histogram(self.pe.global_lens)
-        self.P_PET = histogram(self.pe.target_lens)
-        self.P_h1 = ""
-        self.P_h2 = ""
-        self.P_h1h2 = ""
+        for k, v in pair_summary(self.pe.global_lens, self.pe.target_lens).items():
+            setattr(self, k, v)
+        self.P_h1 = self.P_h2 = self.P_h1h2 = ""
 
     def unit(self, reads=()):
         from .engine import Unit
         bp = self.bamParser
-        return Unit(self.tred, self.readlen, reads, bp.depth, self.ploidy, self.pe.global_lens, self.pe.target_lens,
+        return Unit(self.tred, bp.READLEN, reads, bp.depth, bp.ploidy, self.pe.global_lens, self.pe.target_lens,
                     maxinsert=self.maxinsert, fullsearch=self.fullsearch, clip=bp.clip)
 
     def from_result(self, res):
-        """Fill the reference's attributes from an engine.UnitResult (models.py:394-415)."""
-        call = res.call
-        status = int(call["status"])
-        if status < 0:
-            raise GridError(STATUS_ERRORS.get(status, "status {}".format(status)))
-        if status == 1:      # no evidence: alleles (-1,-1), lik = PP = -1 (models.py:406-408)
-            self.alleles = [-1, -1]
-            self.lik = self.PP = -1
-            self.CI = ""
-        else:
-            self.alleles = sorted([int(call["h1"]) // self.period, int(call["h2"]) // self.period])
-            self.lik = float(call["lik"])
-            self.PP = float(call["pp"])
-            self.CI = "{}-{}|{}-{}".format(*[int(x) for x in call["ci"]])
-            self.P_h1 = sparsify_marginal(res.P_h1)
-            self.P_h2 = sparsify_marginal(res.P_h2)
-            if getattr(res, "joint", None) is not None:
-                self.P_h1h2 = sparsify_joint_triples(res.joint[0], res.joint[1], self.period)
-            elif res.grid is not None:
-                self.P_h1h2 = sparsify_joint(res.grid, self.period)
-        self.label = calc_label(self.tred, self.alleles)
+        for k, v in format_call(self.tred, res).items():
+            setattr(self, k, v)
 
     def call(self, engine=None, **kwargs):
-        """Single-unit convenience with the reference's signature: histograms come from bamParser.counts."""
+        """Grid from bamParser.counts / .rept (filled by bamParser.parse())."""
         from .engine import Engine
         engine = engine or Engine()
-        full = {int(k): int(v) for k, v in self.counts["FULL"].items()}
-        pref = {int(k): int(v) for k, v in self.counts["PREF"].items()}
-        res = engine.grid_from_counts(self.unit(), full, pref, int(self.rept))
-        self.from_result(res)
+        bp = self.bamParser
+        hist = lambda c: {int(k): int(v) for k, v in c.items()}
+        self.from_result(engine.grid_from_counts(self.unit(), hist(bp.counts["FULL"]), hist(bp.counts["PREF"]),
+                                                 int(bp.rept)))

@@ -76,7 +76,7 @@ def rank_env(rank, world, port, device, base=None):
     return env
 
 
-def spawn_ranks(argv, world, n_devices, timeout=None, env=None, stdout=None):
+def spawn_ranks(argv, world, n_devices, timeout=None, env=None, stdout=None, cwd=None):
     """Start `world` child processes running `argv` (a full command line), rank r on device r mod n_devices
     (n_devices = 0: no device pinning), wait for all of them and return their exit codes.  The children find each
     other through RANK / WORLD_SIZE / MASTER_PORT exactly as under torch.distributed.run; nothing is exchanged
@@ -88,7 +88,7 @@ def spawn_ranks(argv, world, n_devices, timeout=None, env=None, stdout=None):
     procs = []
     for r in range(world):
         dev = (r % n_devices) if n_devices > 0 else None
-        procs.append(subprocess.Popen(argv, env=rank_env(r, world, port, dev, env), stdout=stdout))
+        procs.append(subprocess.Popen(argv, env=rank_env(r, world, port, dev, env), stdout=stdout, cwd=cwd))
     codes = []
     try:
         for p in procs:

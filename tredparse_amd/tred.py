@@ -1,429 +1,428 @@
 #!/usr/bin/env python3
-"""TRED caller CLI -- drop-in for tredparse/tred.py (same flags, same JSON keys / formatting, same VCF
-lines), with the per-read Smith-Waterman and the (h1,h2) likelihood grid running on an MI355X through
-libtredgpu.so.  All loci of a sample (and, with --batch-samples, of several samples) are genotyped
-in one GPU batch instead of one locus at a time.
+"""Genotype tandem-repeat disease loci from Illumina BAMs on AMD MI355X GPUs.
 
-Mirrors: set_argparse tred.py:64-113, run :180-278, vcfstanza :281-293, to_json :296-313,
-to_vcf :316-374, read_csv :401-440, main :451-539.  Not carried over: S3 push (--output_path) and the
-HLI-internal "@sample" lookup (:377-398) -- both outside the hot path.
+Command-line compatible with tredparse's tred.py (same flags, same per-sample `<key>.json` and `<key>.tred.vcf.gz`
+outputs, same JSON keys and formatting) -- but a run is organised around GPU batches, not around one
+sample x locus at a time:
+
+    host threads      one native scan per BAM (bam_parser.scan_sample: sex, read length, and for every locus
+                      depth + selected reads, already 2-bit packed, + pair lengths)
+    GPU batch         the units of up to --batch-samples samples -> SW + tagging -> histograms -> (h1,h2) grid
+                      (engine.Engine.genotype_packed, three libtredgpu.so calls)
+    formatting        per sample: tredCalls dict -> JSON / VCF files
+    --gpus N          N processes, one per GPU, each with its own share of the samples (no communication)
+
+Reference counterparts: flags tred.py:64-113; per-sample driver run() :180-278; JSON :296-313; VCF :281-293,
+:316-374; input modes read_csv :401-440; main :451-539.  Not offered: S3 upload (--output_path is accepted and
+ignored) and the HLI-internal "@sample" lookup.
 """
 import argparse
 import gzip
 import json
 import logging
 import os
-import os.path as op
 import shutil
 import sys
 import time
-from datetime import datetime as dt, timedelta
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+from datetime import date, timedelta
 
 from . import __version__
-from .bam_parser import BamDepth, BamParser, BamParserResults, BamReadLen, SPAN, read_alignment
-from .meta import TREDsRepo
-from .models import IntegratedCaller
-from .utils import InputParams, mkdir
+from .bam_parser import scan_sample, tally
+from .meta import BUILDS, TREDsRepo
+from .models import GridError, format_call, pair_summary
 
 logging.basicConfig()
 logger = logging.getLogger(__name__)
 
-INFO = """##INFO=<ID=RPA,Number=1,Type=String,Description="Repeats per allele">
-##INFO=<ID=END,Number=1,Type=Integer,Description="End position of variant">
-##INFO=<ID=MOTIF,Number=1,Type=String,Description="Canonical repeat motif">
-##INFO=<ID=NS,Number=1,Type=Integer,Description="Number of samples with data">
-##INFO=<ID=REF,Number=1,Type=Integer,Description="Reference copy number">
-##INFO=<ID=CR,Number=1,Type=Integer,Description="Disease copy number cutoff">
-##INFO=<ID=IH,Number=1,Type=String,Description="Inheritance">
-##INFO=<ID=RL,Number=1,Type=Integer,Description="Reference STR track length in bp">
-##INFO=<ID=VT,Number=1,Type=String,Description="Variant type">
-##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">
-##FORMAT=<ID=GA,Number=1,Type=String,Description="Genotype with absolute copy numbers">
-##FORMAT=<ID=FR,Number=1,Type=String,Description="Full spanning reads aligned to locus">
-##FORMAT=<ID=PR,Number=1,Type=String,Description="Partial reads aligned to locus">
-##FORMAT=<ID=RR,Number=1,Type=String,Description="Repeat-only reads aligned to locus">
-##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Mean read depth around locus">
-##FORMAT=<ID=FDP,Number=1,Type=Integer,Description="Full spanning read depth">
-##FORMAT=<ID=PDP,Number=1,Type=Integer,Description="Partial read depth">
-##FORMAT=<ID=RDP,Number=1,Type=Integer,Description="Repeat read depth">
-##FORMAT=<ID=PEDP,Number=1,Type=Integer,Description="Paired-end read depth">
-##FORMAT=<ID=CI,Number=1,Type=String,Description="95% conf interval of estimates">
-##FORMAT=<ID=PP,Number=1,Type=Float,Description="Posterior probability of disease">
-##FORMAT=<ID=LABEL,Number=1,Type=String,Description="Risk assessment">
-"""
+# (ID, Number, Type, Description) of the VCF meta lines, in file order
+_VCF_INFO = (("RPA", "1", "String", "Repeats per allele"), ("END", "1", "Integer", "End position of variant"),
+             ("MOTIF", "1", "String", "Canonical repeat motif"), ("NS", "1", "Integer", "Number of samples with data"),
+             ("REF", "1", "Integer", "Reference copy number"), ("CR", "1", "Integer", "Disease copy number cutoff"),
+             ("IH", "1", "String", "Inheritance"), ("RL", "1", "Integer", "Reference STR track length in bp"),
+             ("VT", "1", "String", "Variant type"))
+_VCF_FORMAT = (("GT", "1", "String", "Genotype"), ("GA", "1", "String", "Genotype with absolute copy numbers"),
+               ("FR", "1", "String", "Full spanning reads aligned to locus"),
+               ("PR", "1", "String", "Partial reads aligned to locus"),
+               ("RR", "1", "String", "Repeat-only reads aligned to locus"),
+               ("DP", "1", "Integer", "Mean read depth around locus"), ("FDP", "1", "Integer", "Full spanning read depth"),
+               ("PDP", "1", "Integer", "Partial read depth"), ("RDP", "1", "Integer", "Repeat read depth"),
+               ("PEDP", "1", "Integer", "Paired-end read depth"), ("CI", "1", "String", "95% conf interval of estimates"),
+               ("PP", "1", "Float", "Posterior probability of disease"), ("LABEL", "1", "String", "Risk assessment"))
+_SAMPLE_KEYS = "GT:GB:FR:PR:RR:DP:FDP:PDP:RDP:PEDP:CI:PP:LABEL"
+INFO = "".join('##{}=<ID={},Number={},Type={},Description="{}">\n'.format(kind, *row)
+               for kind, rows in (("INFO", _VCF_INFO), ("FORMAT", _VCF_FORMAT)) for row in rows)
 
 
-class DefaultHelpParser(argparse.ArgumentParser):
-    def error(self, message):
-        sys.stderr.write('error: {}\n\n'.format(message))
-        sys.exit(not self.print_help())
+class _Parser(argparse.ArgumentParser):
+    def error(self, message):          # a usage error shows the full help, like the reference's parser
+        sys.stderr.write("error: {}\n\n".format(message))
+        self.print_help()
+        sys.exit(1)
 
 
 def set_argparse():
-    TRED_NAMES = TREDsRepo().names
-    p = DefaultHelpParser(description=__doc__, prog="tred.py",
-                          formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    p.add_argument('infile', nargs='?', help="Input path (BAM, list of BAMs, or csv format)")
-    p.add_argument('--ref', help='Reference genome version',
-                   choices=("hg38", "hg38_nochr", "hg19", "hg19_nochr"), default='hg38')
-    p.add_argument('--tred', help='STR disorder, default is to run all', action='append',
-                   choices=sorted(TRED_NAMES), default=None)
-    p.add_argument('--haploid', help='Treat these chromosomes as haploid', action='append')
-    p.add_argument('--useclippedreads', default=False, action="store_true", help='Include clipped reads in inference')
-    p.add_argument('--noalts', default=False, action="store_true",
-                   help='Do not scan extra sites for mismapped reads, faster but less accurate')
-    p.add_argument('--norepeatpairs', default=False, action="store_true",
-                   help='Exclude pairs of repeat-only reads from evidence')
-    p.add_argument('--log', choices=("INFO", "DEBUG"), default="INFO", help='Print debug logs, DEBUG=verbose')
-    p.add_argument('--version', action='version', version="%(prog)s " + __version__)
-    p.add_argument('--toy', help=argparse.SUPPRESS, action="store_true")
+    names = sorted(TREDsRepo().names)
+    p = _Parser(prog="tred.py", description=__doc__.split("\n\n")[0],
+                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("infile", nargs="?", help="a BAM, a text file listing BAMs, or a CSV of samplekey,bam[,locus]")
+    p.add_argument("--ref", choices=BUILDS, default="hg38", help="genome build the BAMs are aligned to")
+    p.add_argument("--tred", action="append", choices=names, default=None, help="locus to call (repeatable); all if omitted")
+    p.add_argument("--haploid", action="append", help="contig to treat as haploid (repeatable)")
+    p.add_argument("--useclippedreads", action="store_true", help="count clipped reads as evidence")
+    p.add_argument("--noalts", action="store_true", help="skip the alternative loci where repeat reads get mismapped")
+    p.add_argument("--norepeatpairs", action="store_true", help="discard pairs whose reads are both repeat-only")
+    p.add_argument("--log", choices=("INFO", "DEBUG"), default="INFO", help="log level")
+    p.add_argument("--version", action="version", version="%(prog)s " + __version__)
+    p.add_argument("--toy", action="store_true", help=argparse.SUPPRESS)
     g = p.add_argument_group("Performance options")
-    g.add_argument('--cpus', help='Host workers for BAM reading (the GPU batch is shared)', type=int, default=1)
-    g.add_argument('--gpu', help='GPU index', type=int, default=0)
-    g.add_argument('--maxinsert', default=300, type=int, help="Maximum number of repeats")
-    g.add_argument('--fullsearch', default=False, action="store_true", help="Full grid search, could be slow")
+    g.add_argument("--cpus", type=int, default=1, help="host threads scanning BAMs (per GPU)")
+    g.add_argument("--gpus", type=int, default=1, help="GPUs to spread the samples over (one process each)")
+    g.add_argument("--gpu", type=int, default=0, help="device index when --gpus is 1")
+    g.add_argument("--batch-samples", type=int, default=64, help="samples per GPU batch")
+    g.add_argument("--maxinsert", type=int, default=300, help="largest allele considered, in repeat units")
+    g.add_argument("--fullsearch", action="store_true", help="evaluate every allele pair up to --maxinsert")
     g = p.add_argument_group("I/O options")
-    g.add_argument("--workdir", default=os.getcwd(), help="Specify work dir")
-    g.add_argument('--cleanup', default=False, action="store_true", help="Cleanup the workdir after done")
-    g.add_argument('--checkexists', default=False, action="store_true", help="Do not run if JSON output exists")
-    g.add_argument('--no-output', default=False, action="store_true", help="Do not write JSON and VCF output")
+    g.add_argument("--workdir", default=os.getcwd(), help="directory for the outputs")
+    g.add_argument("--cleanup", action="store_true", help="remove --workdir when finished")
+    g.add_argument("--checkexists", action="store_true", help="skip samples whose JSON is already there")
+    g.add_argument("--no-output", action="store_true", help="compute but write nothing")
     g = p.add_argument_group("AWS and Docker options")
-    g.add_argument("--sample_id", help="Sample ID")
-    g.add_argument("--workflow_execution_id", help="Workflow execution ID")
-    g.add_argument("--input_bam_path", help="Input path, override infile")
-    g.add_argument("--output_path", help="(S3 push of the reference is not carried over; ignored)")
+    g.add_argument("--sample_id", help="sample id (names the outputs together with the execution id)")
+    g.add_argument("--workflow_execution_id", help="workflow execution id")
+    g.add_argument("--input_bam_path", help="input path; takes precedence over infile")
+    g.add_argument("--output_path", help="accepted for compatibility, ignored (no S3 upload)")
+    p.add_argument("--task-file", help=argparse.SUPPRESS)     # set by the --gpus parent for its children
     return p
 
 
+# ---- inputs -----------------------------------------------------------------------------------------------------
+_REMOTE = ("s3://", "http://", "https://", "ftp://")
+
+
 def bam_path(bam):
-    if bam.startswith(("s3://", "http://", "ftp://", "https://")):
-        return bam
-    return op.abspath(bam)
+    return bam if bam.startswith(_REMOTE) else os.path.abspath(bam)
 
 
-def check_bam(bam):
-    try:
-        read_alignment(bam).close()
-    except (IOError, ValueError) as e:
-        logger.error("Cannot retrieve file `{}` ({})".format(bam, e))
-        return None
-    return bam
+def _stem(path):
+    return os.path.basename(path).rsplit(".", 1)[0]
 
 
-def counter_s(c):
-    return ";".join(["{}|{}".format(k, int(v)) for k, v in sorted(c.items())])
-
-
-class _Pending(object):
-    """One sample x locus unit between host collection and the GPU batch."""
-    __slots__ = ("tred", "bp", "caller", "depth", "ip")
-
-
-def collect_sample(arg):
-    """Host half of run() (tred.py:180-249): open the BAM, infer sex / read length / depth, select reads
-    and pair lengths for every locus.  Returns (result skeleton, [pending units])."""
-    samplekey, bam, repo, tredNames, maxinsert, fullsearch, clip, alts, repeatpairs, log = arg
-    gender, ydepth = 'Unknown', -1
-    tredCalls = {"inferredGender": gender, "depthY": ydepth}
-    result = {'samplekey': samplekey, 'bam': bam, 'tredCalls': tredCalls}
-    if check_bam(bam) is None:
-        return result, []
-    if any(repo[tred].is_xlinked for tred in tredNames):   # infer gender from depth on chrY (:201-213)
-        try:
-            ydepth = BamDepth(bam, repo.ref, logger).get_Y_depth()
-            gender = 'Male' if ydepth > 1 else 'Female'
-        except Exception:
-            pass
-        tredCalls["inferredGender"] = gender
-        tredCalls["depthY"] = float(ydepth) if ydepth != -1 else ydepth
-    READLEN = 150
-    try:
-        READLEN = BamReadLen(bam, logger).readlen
-    except Exception:
-        pass
-    tredCalls["readLen"] = READLEN
-    pending = []
-    for tred in tredNames:
-        bd = BamDepth(bam, repo.ref, logger)
-        xtred = repo[tred]
-        WINDOW_START = max(0, xtred.repeat_start - SPAN)
-        WINDOW_END = xtred.repeat_end + SPAN
-        try:
-            depth = bd.region_depth(xtred.chr, WINDOW_START, WINDOW_END)
-        except Exception as e:
-            depth = 30
-            logger.error("Exception on `{}` {} ({}). Set depth={}".format(bam, tred, e, depth))
-        ip = InputParams(bam=bam, READLEN=READLEN, tredName=tred, repo=repo, maxinsert=maxinsert,
-                         fullsearch=fullsearch, gender=gender, depth=depth, clip=clip, alts=alts,
-                         repeatpairs=repeatpairs, log=log)
-        try:
-            bp = BamParser(ip)
-            bp.collect()
-            caller = IntegratedCaller(bp, maxinsert=maxinsert, fullsearch=fullsearch)   # runs PEextractor
-        except Exception as e:   # the reference drops the locus on any error (:245-249)
-            logger.error("Exception on `{}` {} ({})".format(bam, tred, e))
-            continue
-        u = _Pending()
-        u.tred, u.bp, u.caller, u.depth, u.ip = tred, bp, caller, depth, ip
-        pending.append(u)
-    return result, pending
-
-
-def finish_sample(result, pending, unit_results):
-    """Second half of run() (tred.py:251-275): fill tredCalls from the GPU results."""
-    tredCalls = result['tredCalls']
-    for u, res in zip(pending, unit_results):
-        tred, bp, caller = u.tred, u.bp, u.caller
-        try:
-            bp.finish(res.tags, res.hs)
-            caller.counts, caller.rept = bp.counts, bp.rept
-            caller.from_result(res)
-        except Exception as e:
-            logger.error("Exception on `{}` {} ({})".format(result['bam'], tred, e))
-            continue
-        tpResult = BamParserResults(u.ip, bp, caller)
-        alleles = tpResult.alleles
-        tredCalls[tred + ".1"] = alleles[0]  # .1 is the shorter allele
-        tredCalls[tred + ".2"] = alleles[1]  # .2 is the longer allele
-        tredCalls[tred + ".FR"] = counter_s(tpResult.counts["FULL"])
-        tredCalls[tred + ".PR"] = counter_s(tpResult.counts["PREF"])
-        tredCalls[tred + ".RR"] = counter_s(tpResult.counts["REPT"])
-        tredCalls[tred + ".DP"] = u.depth
-        tredCalls[tred + ".FDP"] = tpResult.FDP
-        tredCalls[tred + ".PDP"] = tpResult.PDP
-        tredCalls[tred + ".RDP"] = tpResult.RDP
-        tredCalls[tred + ".PEDP"] = tpResult.PEDP
-        tredCalls[tred + ".PEG"] = tpResult.PEG
-        tredCalls[tred + ".PET"] = tpResult.PET
-        tredCalls[tred + ".CI"] = tpResult.CI
-        tredCalls[tred + ".PP"] = tpResult.PP
-        tredCalls[tred + ".label"] = tpResult.label
-        tredCalls[tred + ".details"] = tpResult.details
-        tredCalls[tred + ".P_h1"] = tpResult.P_h1
-        tredCalls[tred + ".P_h2"] = tpResult.P_h2
-        tredCalls[tred + ".P_h1h2"] = tpResult.P_h1h2
-        tredCalls[tred + ".P_PEG"] = tpResult.P_PEG
-        tredCalls[tred + ".P_PET"] = tpResult.P_PET
-    return result
-
-
-def units_of(arg, pending):
-    """The engine.Unit of every pending sample x locus of one sample (arg = the run() argument tuple)."""
-    clip, repeatpairs = arg[6], arg[8]
-    units = []
-    for u in pending:
-        unit = u.caller.unit([s for _, s in u.bp.reads])
-        if not (repeatpairs or clip):   # --norepeatpairs: mates share a query name (bam_parser.py:270-287)
-            ids = {}                    # (the device removes REPT/REPT pairs from the histograms; finish() on details)
-            unit.read_pair_ids = [ids.setdefault(name, len(ids)) for name, _ in u.bp.reads]
-        units.append(unit)
-    return units
-
-
-def run(arg, engine=None):
-    """Run the TRED caller on one sample (same argument tuple and return value as tred.py:180-278)."""
-    from .engine import Engine
-    engine = engine or Engine()
-    result, pending = collect_sample(arg)
-    units = units_of(arg, pending)
-    res = engine.genotype(units) if units else []
-    return finish_sample(result, pending, res)
-
-
-def host_pool(cpus, n_tasks):
-    """Worker processes for the host half (the reference's Pool over samples, tred.py:521-532).  Create it BEFORE
-    the Engine: the workers are forked and must not inherit an initialised GPU runtime."""
-    if cpus > 1 and n_tasks > 1:
-        import multiprocessing
-        return multiprocessing.get_context("fork").Pool(min(cpus, n_tasks))
-    return None
-
-
-def run_many(task_args, engine, pool=None, batch=64, sink=None):
-    """run() over many samples: the host half of up to `batch` samples is collected (by the pool's workers, which
-    never touch the GPU), their units go to the GPU as ONE batch, and each finished result is handed to
-    sink(result) (or returned as a list).  The pool stays the caller's (close and join it when done)."""
+def read_csv(infile, args):
+    """[(samplekey, bam, locus or None)] from any of the input forms:
+    a .bam/.cram path (key = file stem, or executionid_sampleid when both ids are given); a text file with one BAM
+    per line; a CSV with samplekey,bam and an optional third column naming the one locus to call for that row
+    (rows whose second field is not a .bam path -- headers -- are skipped)."""
+    if infile.startswith("@"):
+        raise SystemExit("`@sample` inputs need HLI's internal sample database, which this build does not have")
+    if infile.endswith((".bam", ".cram")):
+        bam = bam_path(infile)
+        ids = (args.workflow_execution_id, args.sample_id)
+        return [("_".join(ids) if all(ids) else _stem(bam), bam, None)]
+    with open(infile) as fp:
+        rows = [line.strip() for line in fp.read().splitlines()]
+    if rows and rows[0].endswith(".bam") and "," not in rows[0]:
+        return [(_stem(r), bam_path(r), None) for r in rows]
     out = []
-    chunks = [task_args[i:i + batch] for i in range(0, len(task_args), batch)]
-    ahead = pool.map_async(collect_sample, chunks[0]) if pool and chunks else None
-    for k, chunk in enumerate(chunks):
-        if pool:
-            collected = ahead.get()
-            # the workers read the next batch's BAMs while this one is on the GPU and being formatted
-            ahead = pool.map_async(collect_sample, chunks[k + 1]) if k + 1 < len(chunks) else None
-        else:
-            collected = [collect_sample(a) for a in chunk]
-        units, spans = [], []
-        for a, (_, pending) in zip(chunk, collected):
-            us = units_of(a, pending)
-            spans.append((len(units), len(units) + len(us)))
-            units += us
-        res = engine.genotype(units) if units else []
-        for (result, pending), (lo, hi) in zip(collected, spans):
-            r = finish_sample(result, pending, res[lo:hi])
-            if sink is not None:
-                sink(r)
-            else:
-                out.append(r)
+    for r in rows:
+        cells = r.split(",")
+        if len(cells) >= 2 and cells[1].endswith(".bam"):
+            out.append((cells[0], bam_path(cells[1]), cells[2] if len(cells) == 3 else None))
     return out
 
 
-def vcfstanza(sampleid, bam, tredCalls, ref):
-    m = "##fileformat=VCFv4.1\n"
-    m += "##fileDate={}{:02d}{:02d}\n".format(dt.now().year, dt.now().month, dt.now().day)
-    m += "##source={} {}\n".format(__file__, bam)
-    m += "##reference={}\n".format(ref)
-    m += "##inferredGender={} depthY={}\n".format(tredCalls["inferredGender"], tredCalls["depthY"])
-    m += "##readLen={}bp\n".format(tredCalls["readLen"])
-    m += INFO
-    header = "CHROM POS ID REF ALT QUAL FILTER INFO FORMAT\n".split() + [sampleid]
-    m += "#" + "\t".join(header)
-    return m
+def counter_s(counts):
+    """{15: 4, 6: 1} -> '6|1;15|4'."""
+    return ";".join("{}|{}".format(k, int(counts[k])) for k in sorted(counts))
 
 
-def to_json(results, ref, repo, treds=("HD",), store=None, quiet=False):
-    sampleid = results['samplekey']
-    calls = results['tredCalls']
-    if not calls:
+# ---- one sample: scan -> units -> calls ---------------------------------------------------------------------------
+def _options(arg):
+    """The reference's run() argument tuple, named."""
+    samplekey, bam, repo, names, maxinsert, fullsearch, clip, alts, repeatpairs, log = arg
+    return dict(samplekey=samplekey, bam=bam, repo=repo, names=list(names), maxinsert=maxinsert,
+                fullsearch=fullsearch, clip=clip, alts=alts, repeatpairs=repeatpairs, log=log)
+
+
+def collect_sample(arg):
+    """Host half of a sample (thread-safe, no GPU): the native scan of its BAM."""
+    o = _options(arg)
+    return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"])
+
+
+def _skeleton(o, scan):
+    calls = {"inferredGender": scan.gender, "depthY": scan.ydepth}
+    if scan.opened:
+        calls["readLen"] = scan.readlen
+    return {"samplekey": o["samplekey"], "bam": o["bam"], "tredCalls": calls}
+
+
+def _fill_unit(calls, scan, k, res, repeatpairs):
+    """The 21 keys of one locus from its kernel results."""
+    t = scan.loci[k]
+    call = format_call(t, res)                       # may raise GridError: the locus is then left out
+    counts, details, rept = tally(scan, k, res.tags, res.hs, repeatpairs=repeatpairs)
+    n = t.name
+    calls[n + ".1"], calls[n + ".2"] = call["alleles"]
+    calls[n + ".FR"], calls[n + ".PR"] = counter_s(counts["FULL"]), counter_s(counts["PREF"])
+    calls[n + ".RR"] = counter_s(counts["REPT"])
+    calls[n + ".DP"] = float(scan.depth[k])
+    calls[n + ".FDP"], calls[n + ".PDP"] = sum(counts["FULL"].values()), sum(counts["PREF"].values())
+    calls[n + ".RDP"] = rept
+    for key, v in pair_summary(*(x.tolist() for x in scan.pair_lengths(k))).items():
+        calls[n + "." + key] = v
+    for key in ("CI", "PP", "label", "P_h1", "P_h2", "P_h1h2"):
+        calls[n + "." + key] = call[key]
+    calls[n + ".details"] = details
+
+
+def _genotype(engine, picks, o):
+    """PackedUnits of `picks` through the GPU.  A batch that fails as a whole is retried sample by sample and then
+    unit by unit, so that one unit the kernels reject costs only itself (the reference loses only the failing
+    locus too).  Returns {(scan index, k): UnitResult}."""
+    from ._lib import TredGpuError
+    from .engine import PackedUnits
+    kw = dict(maxinsert=o["maxinsert"], fullsearch=o["fullsearch"], clip=o["clip"],
+              repeatpairs=o["repeatpairs"] or o["clip"])
+    out = {}
+
+    def attempt(sub):
+        batch = PackedUnits.from_scans([(s, ks) for _, s, ks in sub], **kw)
+        if batch.n_units == 0:
+            return
+        br = engine.genotype_packed(batch)
+        i = 0
+        for si, _, ks in sub:
+            for k in ks:
+                out[(si, k)] = br.unit(i)
+                i += 1
+
+    try:
+        attempt(picks)
+    except TredGpuError as e:
+        logger.error("GPU batch failed (%s); retrying in smaller pieces", e)
+        for si, s, ks in picks:
+            try:
+                attempt([(si, s, ks)])
+            except TredGpuError:
+                for k in ks:
+                    try:
+                        attempt([(si, s, [k])])
+                    except TredGpuError as e1:
+                        logger.error("Exception on `%s` %s (%s)", s.path, s.names[k], e1)
+    return out
+
+
+def finish_batch(engine, task_args, scans):
+    """GPU half + formatting for the scans of one batch; returns the result dicts in task order."""
+    if not task_args:
+        return []
+    o0 = _options(task_args[0])
+    picks = [(si, s, [k for k in range(len(s.names)) if k not in s.dropped] if s.opened else [])
+             for si, s in enumerate(scans)]
+    res = _genotype(engine, picks, o0)
+    results = []
+    for si, (arg, scan) in enumerate(zip(task_args, scans)):
+        o = _options(arg)
+        result = _skeleton(o, scan)
+        for k in picks[si][2]:
+            if (si, k) not in res:
+                continue
+            try:
+                _fill_unit(result["tredCalls"], scan, k, res[(si, k)], o["repeatpairs"] or o["clip"])
+            except GridError as e:
+                logger.error("Exception on `%s` %s (%s)", o["bam"], scan.names[k], e)
+        results.append(result)
+    return results
+
+
+def run(arg, engine=None):
+    """One sample, same argument tuple and return value as the reference's run():
+    (samplekey, bam, repo, locus names, maxinsert, fullsearch, clip, alts, repeatpairs, log) ->
+    {'samplekey', 'bam', 'tredCalls'}."""
+    from .engine import Engine
+    return finish_batch(engine or Engine(), [arg], [collect_sample(arg)])[0]
+
+
+def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1):
+    """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
+    executor given as `pool`), always one batch ahead of the GPU.  Each finished result goes to sink(result), or
+    into the returned list."""
+    chunks = [task_args[i:i + batch] for i in range(0, len(task_args), batch)]
+    own = pool is None and threads > 1 and len(task_args) > 1
+    ex = ThreadPoolExecutor(max_workers=threads) if own else pool
+    out = []
+    try:
+        submit = (lambda c: [ex.submit(collect_sample, a) for a in c]) if ex is not None else None
+        ahead = deque()
+        if ex is not None and chunks:
+            ahead.append(submit(chunks[0]))
+        for i, chunk in enumerate(chunks):
+            if ex is not None:
+                if i + 1 < len(chunks):
+                    ahead.append(submit(chunks[i + 1]))
+                scans = [f.result() for f in ahead.popleft()]
+            else:
+                scans = [collect_sample(a) for a in chunk]
+            for r in finish_batch(engine, chunk, scans):
+                if sink is not None:
+                    sink(r)
+                else:
+                    out.append(r)
+    finally:
+        if own:
+            ex.shutdown()
+    return out
+
+
+# ---- outputs ------------------------------------------------------------------------------------------------------
+def to_json(results, ref=None, repo=None, treds=None, store=None, quiet=False):
+    """<samplekey>.json in the working directory (and on stdout): sorted keys, 4-space indent."""
+    if not results["tredCalls"]:
         return
-    jsonfile = ".".join((sampleid, "json"))
-    js = json.dumps(results, sort_keys=True, indent=4, separators=(',', ': '))
+    text = json.dumps(results, sort_keys=True, indent=4, separators=(",", ": "))
     if not quiet:
-        print(js)
-    with open(jsonfile, "w") as fw:
-        print(js, file=fw)
+        print(text)
+    with open(results["samplekey"] + ".json", "w") as fw:
+        fw.write(text + "\n")
+
+
+def vcfstanza(sampleid, bam, calls, ref):
+    today = date.today()
+    head = ["##fileformat=VCFv4.1", "##fileDate={}{:02d}{:02d}".format(today.year, today.month, today.day),
+            "##source={} {}".format(__file__, bam), "##reference={}".format(ref),
+            "##inferredGender={} depthY={}".format(calls["inferredGender"], calls["depthY"]),
+            "##readLen={}bp".format(calls["readLen"])]
+    columns = "#" + "\t".join("CHROM POS ID REF ALT QUAL FILTER INFO FORMAT".split() + [sampleid])
+    return "\n".join(head) + "\n" + INFO + columns
+
+
+def _vcf_line(name, calls, site):
+    """One locus as a VCF record.  GT is relative to the reference copy number: 0/0 both alleles reference, 0/1 one
+    of them, 1/1 both the same non-reference size, 1/2 two different ones; GB carries the absolute sizes."""
+    chrom, pos, ref_copy, motif, info = site
+    a, b = calls[name + ".1"], calls[name + ".2"]
+    novel = sorted({a, b} - {ref_copy})
+    if not novel:
+        gt = "0/0"
+    else:
+        info += ";RPA=" + ",".join(str(x) for x in novel)
+        gt = "0/1" if ref_copy in (a, b) else ("1/1" if len(novel) == 1 else "1/2")
+    alt = ",".join(motif * x for x in novel) if novel and novel[0] != -1 else "."
+    sample = [gt, "{}/{}".format(a, b)] + [str(calls[name + "." + k]) for k in
+                                           ("FR", "PR", "RR", "DP", "FDP", "PDP", "RDP", "PEDP", "CI")]
+    sample += ["{:.4g}".format(calls[name + ".PP"]), str(calls[name + ".label"])]
+    fields = (chrom, pos, name, motif * ref_copy, alt, ".", ".", info, _SAMPLE_KEYS, ":".join(sample))
+    return chrom, pos, "\t".join(str(x) for x in fields)
 
 
 def to_vcf(results, ref, repo, treds=("HD",), store=None):
-    registry = {tred: repo.get_info(tred) for tred in treds}
-    sampleid, bam, calls = results['samplekey'], results['bam'], results['tredCalls']
+    """<samplekey>.tred.vcf.gz: one record per called locus, ordered by contig name and position."""
+    calls = results["tredCalls"]
     if not calls:
         return
-    vcffile = ".".join((sampleid, "tred.vcf.gz"))
-    contents = []
-    for tred in treds:
-        if tred + ".1" not in calls:
-            continue
-        a, b = calls[tred + ".1"], calls[tred + ".2"]
-        chr, start, ref_copy, repeat, info = registry[tred]
-        alleles = set([a, b])
-        refv = set([ref_copy])
-        rpa = sorted(alleles - refv)
-        alt = ",".join(x * repeat for x in rpa) if (rpa and rpa[0] != -1) else "."
-        if rpa:
-            info += ";RPA={}".format(",".join((str(x) for x in rpa)))
-            if ref_copy in alleles:
-                gt = "0/1"
-            elif len(rpa) == 1:
-                gt = "1/1"
-            else:
-                gt = "1/2"
-        else:
-            gt = "0/0"
-        gb = "{}/{}".format(a, b)
-        fields = "{}:{}:{}:{}:{}:{}:{}:{}:{}:{}:{}:{:.4g}:{}".format(
-            gt, gb, calls[tred + ".FR"], calls[tred + ".PR"], calls[tred + ".RR"], calls[tred + ".DP"],
-            calls[tred + ".FDP"], calls[tred + ".PDP"], calls[tred + ".RDP"], calls[tred + ".PEDP"],
-            calls[tred + ".CI"], calls[tred + ".PP"], calls[tred + ".label"])
-        m = "\t".join(str(x) for x in (chr, start, tred, ref_copy * repeat, alt, ".", ".", info,
-                                       "GT:GB:FR:PR:RR:DP:FDP:PDP:RDP:PEDP:CI:PP:LABEL", fields))
-        contents.append((chr, start, m))
-    with gzip.open(vcffile, "wt") as fw:
-        print(vcfstanza(sampleid, bam, calls, ref), file=fw)
-        contents.sort()
-        for chr, start, m in contents:
-            print(m, file=fw)
+    records = sorted(_vcf_line(t, calls, repo.get_info(t)) for t in treds if t + ".1" in calls)
+    with gzip.open(results["samplekey"] + ".tred.vcf.gz", "wt") as fw:
+        fw.write(vcfstanza(results["samplekey"], results["bam"], calls, ref) + "\n")
+        for _, _, line in records:
+            fw.write(line + "\n")
 
 
-def read_csv(csvfile, args):
-    if csvfile[0] == '@':
-        raise SystemExit("the HLI-internal @sample lookup of the reference (tred.py:377-398) is not available")
-    if csvfile.endswith(".bam") or csvfile.endswith(".cram"):   # Mode 1: a single BAM
-        bam = bam_path(csvfile)
-        if args.workflow_execution_id and args.sample_id:
-            samplekey = "_".join((args.workflow_execution_id, args.sample_id))
-        else:
-            samplekey = op.basename(bam).rsplit(".", 1)[0]
-        return [(samplekey, bam, None)]
-    with open(csvfile) as fp:
-        lines = fp.read().splitlines()
-    contents = []
-    header = lines[0].strip() if lines else ""
-    if header.endswith(".bam") and header.count(",") == 0:      # Mode 2: list of BAM files
-        for row in lines:
-            bam = bam_path(row.strip())
-            contents.append((op.basename(bam).rsplit(".", 1)[0], bam, None))
-        return contents
-    for row in lines:                                           # Mode 3: CSV
-        atoms = row.strip().split(",")
-        if len(atoms) < 2:
-            continue
-        samplekey, bam = atoms[:2]
-        tred = atoms[2] if len(atoms) == 3 else None
-        bam = bam_path(bam)
-        if bam.endswith(".bam"):
-            contents.append((samplekey, bam, tred))
-    return contents
-
-
-def write_vcf_json(results, ref, repo, treds, store, quiet=False):
+def write_vcf_json(results, ref, repo, treds, store=None, quiet=False):
     try:
         to_vcf(results, ref, repo, treds=treds, store=store)
         to_json(results, ref, repo, treds=treds, store=store, quiet=quiet)
     except Exception as e:
-        print("Error writing: {} ({})".format(results, e), file=sys.stderr)
+        print("Error writing: {} ({})".format(results.get("samplekey"), e), file=sys.stderr)
+
+
+# ---- driver -------------------------------------------------------------------------------------------------------
+def _fan_out(argv, n_gpus, samples, launch_dir, no_output, quiet, devices=None):
+    """--gpus N: this process stays off the GPU and starts one child per GPU (shard.spawn_ranks) from the directory
+    the command was given in; child r genotypes its shard_range of `samples` -- the list is fixed here and handed
+    over in a file, so that every child partitions the same list -- and writes those samples' files.  Afterwards
+    the JSONs are echoed in sample order."""
+    import tempfile
+    from . import shard
+    if devices is None:
+        devices = shard.visible_gpus()
+    if devices < 1:
+        raise SystemExit("tred.py: no GPU visible")
+    samplekeys = [s[0] for s in samples]
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
+                                        [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p])
+    with tempfile.NamedTemporaryFile("w", suffix=".json", prefix="tred_tasks_", delete=False) as fp:
+        json.dump([list(s) for s in samples], fp)
+    try:
+        cmd = [sys.executable, "-m", "tredparse_amd.tred"] + list(argv) + ["--task-file", fp.name]
+        codes = shard.spawn_ranks(cmd, n_gpus, devices, env=env, cwd=launch_dir)
+    finally:
+        os.unlink(fp.name)
+    if not (no_output or quiet):
+        for key in samplekeys:
+            if os.path.exists(key + ".json"):
+                with open(key + ".json") as fp:
+                    sys.stdout.write(fp.read())
+    return max(codes) if codes else 0
 
 
 def main(args, quiet=False):
+    argv = list(args)
     p = set_argparse()
-    args = p.parse_args(args)
-    logger.setLevel(getattr(logging, args.log.upper(), "INFO"))
-    start = time.time()
-    workdir = args.workdir
-    cwd = os.getcwd()
+    args = p.parse_args(argv)
+    logger.setLevel(getattr(logging, args.log))
+    logging.getLogger("tredparse_amd.bam").setLevel(getattr(logging, args.log))
+    t0 = time.time()
     infile = args.input_bam_path or args.infile
     if not infile:
-        sys.exit(not p.print_help())
-    samples = read_csv(infile, args)          # paths are made absolute before the chdir, as in the reference
-    if workdir != cwd:
-        mkdir(workdir, logger=logger)
-    sites = op.join(os.getcwd(), "sites")
-    os.chdir(workdir)
-    ref = args.ref
-    repo = TREDsRepo(ref=ref, toy=args.toy, sites=sites)
-    repo.set_ploidy(args.haploid)
-    treds = args.tred or repo.names
-    if args.toy:
-        treds = ["HD"]
-    task_args = []
-    for samplekey, bam, tred in samples:
-        jsonfile = ".".join((samplekey, "json"))
-        if args.checkexists and op.exists(jsonfile):
-            continue
-        _treds = [tred] if tred else treds
-        task_args.append((samplekey, bam, repo, _treds, args.maxinsert, args.fullsearch, args.useclippedreads,
-                          (not args.noalts), (not args.norepeatpairs), args.log))
-    if not task_args:
-        os.chdir(cwd)
-        return
-    from .engine import Engine
-    pool = host_pool(args.cpus, len(task_args))
-    engine = Engine(args.gpu)
-
-    def sink(results):
-        if not args.no_output:
-            write_vcf_json(results, ref, repo, treds, None, quiet=quiet)
+        p.print_help()
+        sys.exit(1)
+    if args.task_file:                         # a --gpus child: the parent's sample list
+        with open(args.task_file) as fp:
+            samples = [tuple(x) for x in json.load(fp)]
+    else:
+        samples = read_csv(infile, args)       # paths become absolute here, before the working directory changes
+    cwd = os.getcwd()
+    sites = os.path.join(cwd, "sites")
+    os.makedirs(args.workdir, exist_ok=True)
+    os.chdir(args.workdir)
     try:
-        run_many(task_args, engine, pool=pool, sink=sink)
+        repo = TREDsRepo(ref=args.ref, toy=args.toy, sites=sites)
+        repo.set_ploidy(args.haploid)
+        loci = ["HD"] if args.toy else (args.tred or repo.names)
+        spawned = bool(args.task_file)
+        if args.checkexists and not spawned:
+            samples = [s for s in samples if not os.path.exists(s[0] + ".json")]
+        tasks = [(key, bam, repo, [only] if only else loci, args.maxinsert, args.fullsearch, args.useclippedreads,
+                  not args.noalts, not args.norepeatpairs, args.log) for key, bam, only in samples]
+        if not tasks:
+            return
+        if args.gpus > 1 and not spawned:
+            rc = _fan_out(argv, args.gpus, samples, cwd, args.no_output, quiet)
+            if rc:
+                sys.exit(rc)
+        else:
+            device = args.gpu
+            if spawned:                            # one of the --gpus children: its share of the samples, device 0
+                from .shard import shard_range
+                lo, hi = shard_range(len(tasks), int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
+                tasks, device, quiet = tasks[lo:hi], 0, True
+            if tasks:
+                from .engine import Engine
+                engine = Engine(device)
+
+                def sink(result):
+                    if not args.no_output:
+                        write_vcf_json(result, args.ref, repo, loci, quiet=quiet)
+                run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus))
+        print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
-        if pool is not None:
-            pool.close()
-            pool.join()
-    print("Elapsed time={}".format(timedelta(seconds=time.time() - start)), file=sys.stderr)
-    os.chdir(cwd)
+        os.chdir(cwd)
     if args.cleanup:
-        shutil.rmtree(workdir)
+        shutil.rmtree(args.workdir)
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     main(sys.argv[1:])

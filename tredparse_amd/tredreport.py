@@ -1,144 +1,250 @@
 #!/usr/bin/env python3
-"""Report significant calls -- counterpart of tredparse/tredreport.py for the JSON files tred.py writes.
+"""Population report over many tred.py outputs: who is at risk at which locus, and the allele spectrum.
 
-JSON files -> one TSV row per sample (df_to_tsv, tredreport.py:110-142), then per locus the
-pre-risk / risk / carrier counts, the at-risk cases with their read evidence and the allele
-frequencies (get_tred_summary :37-101, main :198-302).  VCF input of the reference (needs PyVCF) is
-not carried over; everything is host-side pandas, nothing here touches the GPU.
+Inputs: the per-sample `<key>.json` files (or `<key>.tred.vcf.gz` files) tred.py writes, or a TSV written by an
+earlier run.  Outputs, all next to --tsv:
+
+    <tsv>               one row per sample: SampleKey, inferredGender, and per locus `calls` ("a|b") and `label`
+                        (+ any --columns), columns sorted by name
+    <tsv>.cases.txt     per locus with at-risk samples: a header line, the locus' parameters, and a table of the
+                        cases with their read evidence
+    <tsv>.details.txt   tab-separated read-depth evidence (FDP, PDP, RDP, PEDP) of every case
+    <tsv>.report.txt    one row per locus: cut-offs, number of pre-risk / risk / carrier samples, allele counts
+
+Same flags and file formats as tredparse's tredreport.py (tredparse/tredreport.py:198-302); implemented on plain
+rows (dicts) rather than data frames, VCF input parsed directly (no PyVCF).  Host-side only.
 """
 import argparse
+import csv
+import gzip
 import json
-import math
-import os.path as op
+import os
 import sys
 from collections import Counter
 
-import pandas as pd
-
 from . import __version__
-from .meta import TREDsRepo
+from .meta import BUILDS, TREDsRepo
+
+DETAIL_COLUMNS = ("Locus", "Inheritance", "SampleKey", "Sex", "Calls", "FullReads", "PartialReads", "RepeatReads",
+                  "PairedReads")
+REPORT_COLUMNS = ("abbreviation", "allele_freq", "cutoff_prerisk", "cutoff_risk", "inheritance", "motif", "n_carrier",
+                  "n_prerisk", "n_risk", "title")
 
 
-def left_truncate_text(a, maxcol=30):  # tredreport.py:31-34
-    trim = lambda t: (t if not isinstance(t, str) or len(t) <= maxcol else "..." + t[-(maxcol - 3):])
-    return [trim(x) for x in list(a)]
+def left_truncate_text(values, maxcol=30):
+    """Long strings keep their tail: '...' + the last maxcol-3 characters."""
+    return [v if not isinstance(v, str) or len(v) <= maxcol else "..." + v[3 - maxcol:] for v in values]
 
 
-def counts_to_af(counts):  # tredreport.py:104-107
-    return "{" + ",".join("{}:{}".format(k, v) for k, v in sorted(counts.items())
-                          if not (k == '.' or (isinstance(k, float) and math.isnan(k)))) + "}"
+def counts_to_af(counts):
+    """Counter of allele sizes -> '{5:12,6:3}' (sorted by size; missing calls are not alleles)."""
+    return "{" + ",".join("{}:{}".format(k, counts[k]) for k in sorted(k for k in counts if isinstance(k, int))) + "}"
 
 
-def json_to_df(jsonfiles):  # tredreport.py:172-195 (sample key from the file name)
-    rows = []
-    for jsonfile in jsonfiles:
-        with open(jsonfile) as fp:
-            js = json.load(fp)
-        d = {'SampleKey': op.basename(jsonfile).split(".")[0]}
-        d.update(js['tredCalls'])
-        rows.append(d)
-    return pd.DataFrame(rows)
+# ---- loading ------------------------------------------------------------------------------------------------------
+def _key_of(path):
+    return os.path.basename(path).split(".")[0]
 
 
-def df_to_tsv(df, tsvfile, extra_columns=(), ref="hg38"):  # tredreport.py:110-142
-    df = df.fillna(-1)
-    dd = ["SampleKey", "inferredGender"]
-    repo = TREDsRepo(ref)
-    for tred in repo.names:
-        tr = repo[tred]
-        if tred + ".1" not in df.columns:
+def read_json(path):
+    with open(path) as fp:
+        row = dict(json.load(fp)["tredCalls"])
+    row["SampleKey"] = _key_of(path)        # the file name is the key (early versions left the field empty)
+    return row
+
+
+def read_vcf(path):
+    """One sample's tred.vcf(.gz): per record the GB sizes, PP, FR, PR and LABEL of the sample column."""
+    row = {"SampleKey": _key_of(path)}
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt") as fp:
+        for line in fp:
+            if line.startswith("#") or not line.strip():
+                continue
+            cells = line.rstrip("\n").split("\t")
+            sample = dict(zip(cells[8].split(":"), cells[9].split(":")))
+            locus = cells[2]
+            a, b = sample["GB"].split("/")
+            row[locus + ".1"], row[locus + ".2"] = int(a), int(b)
+            row[locus + ".PP"] = float(sample["PP"])
+            row[locus + ".FR"], row[locus + ".PR"], row[locus + ".label"] = sample["FR"], sample["PR"], sample["LABEL"]
+    return row
+
+
+def read_tsv(path):
+    with open(path) as fp:
+        return [dict(r) for r in csv.DictReader(fp, delimiter="\t")]
+
+
+def load(files, cpus=1):
+    reader = read_json if files[0].endswith(".json") else read_vcf
+    if cpus > 1 and len(files) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(cpus, len(files))) as ex:
+            return list(ex.map(reader, files))
+    return [reader(f) for f in files]
+
+
+# ---- the sample table -----------------------------------------------------------------------------------------------
+def add_calls(rows, repo, has_sex):
+    """Per locus and sample: integer allele sizes (`.1_`, `.2_`; -1 = missing; '.' for the second allele of a male
+    at an X-linked locus) and the `calls` string."""
+    def size(v):
+        return -1 if v in (None, "") else int(float(v))
+
+    for name in repo.names:
+        if not any((name + ".1") in r for r in rows):
             continue
-        df[tred + ".1_"] = df[tred + ".1"].astype("int")
-        df[tred + ".2_"] = df[tred + ".2"].astype("int").astype(object)
-        if tr.is_xlinked:
-            df.loc[(df["inferredGender"] == "Male"), tred + ".2_"] = "."
-        df[tred + ".calls"] = ["{}|{}".format(a, b) for (a, b) in zip(df[tred + ".1_"], df[tred + ".2_"])]
-    all_columns = ["calls", "label"] + list(extra_columns)
-    columns = dd + sorted([x for x in df.columns if (x not in dd) and any(x.endswith("." + z) for z in all_columns)])
-    tf = df.reindex(columns=columns)
-    tf.to_csv(tsvfile, sep='\t', index=False)
-    print("TSV output written to `{}` (# samples={})".format(tsvfile, tf.shape[0]), file=sys.stderr)
-    return df
+        hemizygous = has_sex and repo[name].is_xlinked
+        for r in rows:
+            a, b = size(r.get(name + ".1")), size(r.get(name + ".2"))
+            if hemizygous and r.get("inferredGender") == "Male":
+                b = "."
+            r[name + ".1_"], r[name + ".2_"] = a, b
+            r[name + ".calls"] = "{}|{}".format(a, b)
 
 
-def get_tred_summary(df, tred, repo, minPP=.5, casesfw=None, detailsfw=None):  # tredreport.py:37-101
-    pf2, label, pp = tred + ".2", tred + ".label", tred + ".PP"
-    tr = repo[tred]
-    row = repo.rows[tred]
-    prerisk = df[df[label] == "prerisk"]
-    risk = df[(df[label] == "risk") & (df[pp] > minPP)].copy()
-    if tr.is_expansion:
-        carrier = df[(df[label] != "risk") & (df[pf2] >= tr.cutoff_risk)]
+def write_tsv(rows, path, extra_columns, has_sex):
+    lead = ["SampleKey"] + (["inferredGender"] if has_sex else [])
+    wanted = ("calls", "label") + tuple(extra_columns)
+    seen = set()
+    for r in rows:
+        seen.update(r)
+    columns = lead + sorted(c for c in seen if c not in lead and c.rsplit(".", 1)[-1] in wanted and "." in c)
+    with open(path, "w", newline="") as fp:
+        w = csv.writer(fp, delimiter="\t", lineterminator="\n")
+        w.writerow(columns)
+        for r in rows:
+            w.writerow([r.get(c, -1) if r.get(c) is not None else -1 for c in columns])
+    print("TSV output written to `{}` (# samples={})".format(path, len(rows)), file=sys.stderr)
+
+
+def df_to_tsv(rows, tsvfile, extra_columns=(), jsonformat=True, ref="hg38"):
+    """Table of samples -> TSV; returns the rows with the per-locus call columns added."""
+    add_calls(rows, TREDsRepo(ref), jsonformat)
+    write_tsv(rows, tsvfile, extra_columns, jsonformat)
+    return rows
+
+
+# ---- per-locus summary --------------------------------------------------------------------------------------------
+def _num(v, default=-1.0):
+    try:
+        return float(v)
+    except (TypeError, ValueError):
+        return default
+
+
+def _table(rows, columns):
+    """Fixed-width text table, right-aligned, one header line."""
+    cells = [[str(r.get(c, "")) for c in columns] for r in rows]
+    widths = [max([len(c)] + [len(x[i]) for x in cells]) for i, c in enumerate(columns)]
+    lines = [" ".join(c.rjust(w) for c, w in zip(columns, widths))]
+    lines += [" ".join(v.rjust(w) for v, w in zip(x, widths)) for x in cells]
+    return "\n".join(lines)
+
+
+def get_tred_summary(rows, name, repo, minPP=.5, casesfw=None, detailsfw=None):
+    """(locus, n_prerisk, n_risk, n_carrier, allele spectrum) of one locus; cases and their evidence are appended to
+    the two open files.  A case is a sample labelled `risk` with PP above minPP; a carrier is a sample not labelled
+    risk whose longer allele is past the disease cut-off (for contraction loci: at or below it, and called)."""
+    t = repo[name]
+    meta = repo.rows[name]
+    label, pp, second = name + ".label", name + ".PP", name + ".2"
+    have = [r for r in rows if label in r]
+    prerisk = [r for r in have if r[label] == "prerisk"]
+    cases = [r for r in have if r[label] == "risk" and _num(r.get(pp)) > minPP]
+    if t.is_expansion:
+        carriers = [r for r in have if r[label] != "risk" and _num(r.get(second)) >= t.cutoff_risk]
     else:
-        carrier = df[(df[label] != "risk") & (df[pf2] <= tr.cutoff_risk) & (df[pf2] > 0)]
-    n_prerisk, n_risk, n_carrier = prerisk.shape[0], risk.shape[0], carrier.shape[0]
-    calls = tred + ".calls"
-    core = ["SampleKey", "inferredGender", calls]
-    columns = core + [tred + ".FR", tred + ".PR", tred + ".RR", pp]
-    for k in (".FR", ".PR", ".RR"):
-        if tred + k in risk.columns:
-            risk[tred + k] = left_truncate_text(risk[tred + k])
-    if detailsfw is not None and tred != "AR":
-        have = [c for c in (tred + ".FDP", tred + ".PDP", tred + ".RDP", tred + ".PEDP") if c in risk.columns]
-        if len(have) == 4:
-            for _, r in risk[core + have].iterrows():
-                samplekey, sex, call, fdp, pdp, rdp, pedp = r
-                print("\t".join(str(x) for x in (tred, tr.inheritance, samplekey, sex, call, int(fdp), int(pdp),
-                                                 int(rdp), int(pedp))), file=detailsfw)
-    if n_risk and casesfw is not None:
-        print("[{}] - {}".format(tred, row.get("title", "")), file=casesfw)
-        print("rep={}".format(tr.repeat), "inherit={}".format(tr.inheritance), "cutoff={}".format(tr.cutoff_risk),
-              "n_risk={}".format(n_risk), "n_carrier={}".format(n_carrier),
-              "loc={}".format(row["repeat_location"]), file=casesfw)
-        print(risk[[c for c in columns if c in risk.columns]].to_string(index=False), file=casesfw)
+        carriers = [r for r in have if r[label] != "risk" and 0 < _num(r.get(second)) <= t.cutoff_risk]
+    if detailsfw is not None and name != "AR":
+        depth_keys = [name + k for k in (".FDP", ".PDP", ".RDP", ".PEDP")]
+        for r in cases:
+            if all(k in r for k in depth_keys):
+                fields = [name, t.inheritance, r["SampleKey"], r.get("inferredGender", ""), r[name + ".calls"]]
+                fields += [int(_num(r[k])) for k in depth_keys]
+                print("\t".join(str(x) for x in fields), file=detailsfw)
+    if cases and casesfw is not None:
+        print("[{}] - {}".format(name, meta.get("title", "")), file=casesfw)
+        print("rep={} inherit={} cutoff={} n_risk={} n_carrier={} loc={}".format(
+            t.repeat, t.inheritance, t.cutoff_risk, len(cases), len(carriers), meta["repeat_location"]), file=casesfw)
+        columns = ["SampleKey", "inferredGender", name + ".calls", name + ".FR", name + ".PR", name + ".RR", pp]
+        columns = [c for c in columns if any(c in r for r in cases)]
+        shown = []
+        for r in cases:
+            view = {c: r.get(c, "") for c in columns}
+            for k in (".FR", ".PR", ".RR"):
+                if name + k in view:
+                    view[name + k] = left_truncate_text([view[name + k]])[0]
+            shown.append(view)
+        print(_table(shown, columns), file=casesfw)
         print(file=casesfw)
-    cnt = Counter()
-    cnt.update(df[tred + ".1_"])
-    cnt.update(x for x in df[tred + ".2_"] if x != ".")
-    cnt.pop(-1, None)
-    return tr, n_prerisk, n_risk, n_carrier, counts_to_af(cnt)
+    spectrum = Counter()
+    for r in have:
+        for allele in (r[name + ".1_"], r[name + ".2_"]):
+            if isinstance(allele, int) and allele != -1:
+                spectrum[allele] += 1
+    return t, len(prerisk), len(cases), len(carriers), counts_to_af(spectrum)
 
 
 def main(args):
-    p = argparse.ArgumentParser(description=__doc__, prog="tredreport.py",
+    p = argparse.ArgumentParser(prog="tredreport.py", description=__doc__.split("\n\n")[0],
                                 formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    p.add_argument("files", nargs="*")
-    p.add_argument('--ref', choices=("hg38", "hg38_nochr", "hg19", "hg19_nochr"), default='hg38')
-    p.add_argument('--tsv', default="out.tsv", help="Path to the tsv file")
-    p.add_argument('--columns', help="Columns to extract, use comma to separate")
-    p.add_argument('--minPP', default=.5, type=float, help="Minimum Prob(pathological) to report cases")
-    p.add_argument('--version', action='version', version="%(prog)s " + __version__)
-    args = p.parse_args(args)
-    columns = args.columns.split(",") if args.columns else []
-    repo = TREDsRepo(args.ref)
-    if not args.files:
-        sys.exit(not p.print_help())
-    if not args.files[0].endswith(".json"):
-        sys.exit("only the JSON output of tred.py is supported (the reference's VCF path needs PyVCF)")
-    df = df_to_tsv(json_to_df(args.files), args.tsv, extra_columns=columns, ref=args.ref)
-    if df.empty:
+    p.add_argument("files", nargs="*", help="tred.py JSON or VCF outputs; none: re-read --tsv")
+    p.add_argument("--ref", choices=BUILDS, default="hg38", help="genome build of the calls")
+    p.add_argument("--tsv", default="out.tsv", help="sample table to write (or to read when no files are given)")
+    p.add_argument("--columns", help="further per-locus fields for the table, comma separated (e.g. PP,FR)")
+    p.add_argument("--minPP", type=float, default=.5, help="smallest P(pathological) for a sample to count as a case")
+    p.add_argument("--cpus", type=int, default=os.cpu_count() or 1, help="threads reading the input files")
+    p.add_argument("--version", action="version", version="%(prog)s " + __version__)
+    a = p.parse_args(args)
+    repo = TREDsRepo(a.ref)
+    if a.files:
+        jsonformat = a.files[0].endswith(".json")
+        print("Using {} cpus to parse {} {} files".format(min(len(a.files), a.cpus), len(a.files),
+                                                          "JSON" if jsonformat else "VCF"), file=sys.stderr)
+        rows = load(a.files, a.cpus)
+        rows = df_to_tsv(rows, a.tsv, extra_columns=a.columns.split(",") if a.columns else (), jsonformat=jsonformat,
+                         ref=a.ref)
+    elif os.path.exists(a.tsv):
+        rows = read_tsv(a.tsv)
+        for r in rows:                           # a table written earlier: split the calls back into sizes
+            for name in repo.names:
+                if name + ".calls" in r:
+                    x, y = r[name + ".calls"].split("|")
+                    r[name + ".1_"], r[name + ".2_"] = int(x), (int(y) if y != "." else ".")
+                    r.setdefault(name + ".2", y if y != "." else -1)
+    else:
+        p.print_help()
+        sys.exit(1)
+    if not rows:
         sys.exit("Dataframe empty - check input files")
-    rows = []
     total = Counter()
-    with open(args.tsv + ".cases.txt", "w") as casesfw, open(args.tsv + ".details.txt", "w") as detailsfw:
-        print("\t".join("Locus,Inheritance,SampleKey,Sex,Calls,FullReads,PartialReads,RepeatReads,PairedReads".split(',')),
-              file=detailsfw)
-        for tred in repo.names:
-            if tred + ".label" not in df.columns:
+    report = []
+    with open(a.tsv + ".cases.txt", "w") as casesfw, open(a.tsv + ".details.txt", "w") as detailsfw:
+        print("\t".join(DETAIL_COLUMNS), file=detailsfw)
+        for name in repo.names:
+            if not any(name + ".label" in r for r in rows):
                 continue
-            tr, n_prerisk, n_risk, n_carrier, af = get_tred_summary(df, tred, repo, minPP=args.minPP, casesfw=casesfw,
+            t, n_prerisk, n_risk, n_carrier, af = get_tred_summary(rows, name, repo, minPP=a.minPP, casesfw=casesfw,
                                                                     detailsfw=detailsfw)
-            total.update(prerisk=n_prerisk, risk=n_risk, carrier=n_carrier, loci=1 if n_risk else 0)
-            r = repo.rows[tred]
-            rows.append({"abbreviation": tred, "title": r.get("title", ""), "motif": r.get("repeat", ""),
-                         "inheritance": tr.inheritance, "cutoff_prerisk": tr.cutoff_prerisk,
-                         "cutoff_risk": tr.cutoff_risk, "n_prerisk": n_prerisk, "n_risk": n_risk,
-                         "n_carrier": n_carrier, "allele_freq": af})
-    pd.DataFrame(rows).to_csv(args.tsv + ".report.txt", sep="\t", index=False)
-    print("Summary: n_prerisk={prerisk}, n_risk={risk}, n_carrier={carrier}, n_affected_loci={loci}".format(**total),
-          file=sys.stderr)
+            total.update(prerisk=n_prerisk, risk=n_risk, carrier=n_carrier, loci=int(n_risk > 0))
+            meta = repo.rows[name]
+            report.append({"abbreviation": name, "title": meta.get("title", ""), "motif": meta.get("repeat", ""),
+                           "inheritance": t.inheritance, "cutoff_prerisk": t.cutoff_prerisk,
+                           "cutoff_risk": t.cutoff_risk, "n_prerisk": n_prerisk, "n_risk": n_risk,
+                           "n_carrier": n_carrier, "allele_freq": af})
+    print("Outlier cases saved to `{}`".format(a.tsv + ".cases.txt"), file=sys.stderr)
+    print("Read count details saved to `{}`".format(a.tsv + ".details.txt"), file=sys.stderr)
+    with open(a.tsv + ".report.txt", "w", newline="") as fp:
+        w = csv.DictWriter(fp, REPORT_COLUMNS, delimiter="\t", lineterminator="\n")
+        w.writeheader()
+        w.writerows(report)
+    print("Summary report written to `{}` (# samples={})".format(a.tsv + ".report.txt", len(report)), file=sys.stderr)
+    print("Summary: n_prerisk={prerisk}, n_risk={risk}, n_carrier={carrier}, n_affected_loci={loci}".format(
+        **{k: total[k] for k in ("prerisk", "risk", "carrier", "loci")}), file=sys.stderr)
     return total
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     main(sys.argv[1:])
