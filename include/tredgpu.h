@@ -55,7 +55,11 @@ extern "C" {
 
 typedef struct tredgpu_ctx tredgpu_ctx;
 
-/* scoring + tagging constants: bam_parser.py:95-98 (1/5/7/2), :30 (FLANKMATCH 9), :154-155 (clip) */
+/* scoring + tagging constants: bam_parser.py:95-98 (1/5/7/2), :30 (FLANKMATCH 9), :154-155 (clip).
+ * Accepted range: match 1..8, mismatch 0..16, 1 <= gap_extend <= gap_open <= 16, and -- because a DP value is
+ * (score + (row + col) * gap_extend) << 18 | start cell in one int32 --
+ *     (rows + 511) * gap_extend + max_read_len * match < 8192,   rows = 64 / 112 / 160 / 256 for max_read_len
+ * (max_read_len 0 counts as 256).  Anything else is refused with status -2; 1/5/7/2 needs 1 790. */
 typedef struct tredgpu_sw_params {
     int32_t match;      /* +match on the diagonal                (ssw_wrap.py:154-167) */
     int32_t mismatch;   /* -mismatch off the diagonal, N scores 0                       */

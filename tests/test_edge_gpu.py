@@ -112,6 +112,73 @@ def test_norepeatpairs_removes_rept_mates(ctx):
     assert rept[0].sum() == 4
 
 
+class _FakeScan(object):
+    """The handful of SampleScan members bam_parser.tally reads, over plain arrays."""
+
+    def __init__(self, name_id):
+        self.name_id = np.asarray(name_id, np.int32)
+
+    def reads_of(self, k):
+        return 0, len(self.name_id)
+
+    def name(self, i):
+        return "q{}".format(self.name_id[i])
+
+    def sequence(self, i):
+        return "ACGT"
+
+
+@pytest.mark.parametrize("n_reads", [3, 700, 2500])     # 2500: beyond the LDS table, the pairwise fallback
+def test_norepeatpairs_device_histograms_equal_host_counts(ctx, n_reads):
+    """--norepeatpairs: the device histograms (what the grid genotypes from) and the host's counts (what the JSON
+    prints as FR / PR / RR / FDP ...) agree, also when a name carries three records -- two REPT and a FULL one
+    (supplementary alignment, ALT refetch): the reference removes every record of that name."""
+    from tredparse_amd.bam_parser import tally
+    rng = np.random.default_rng(n_reads)
+    if n_reads == 3:
+        tag = np.array([4, 1, 4], np.uint8)
+        h = np.array([50, 20, 50], np.int16)
+        pair = np.array([5, 5, 5], np.int32)
+    else:
+        tag = rng.choice(np.array([0, 1, 2, 3, 4, 4, 4, 5], np.uint8), n_reads)
+        h = rng.integers(1, 51, n_reads).astype(np.int16)
+        pair = rng.integers(0, n_reads // 2, n_reads).astype(np.int32)     # names with 1, 2, 3, ... records
+    hs = 52
+    full = np.zeros((1, hs), np.int32); pref = np.zeros((1, hs), np.int32); rept = np.zeros((1, hs), np.int32)
+    ctx.tally(_lib.MEM_HOST, tag, h, n_reads, np.array([0, n_reads], np.int32), 1, pair, hs, full, pref, rept)
+    counts, details, n_rept = tally(_FakeScan(pair), 0, tag, h, repeatpairs=False)
+    for dev, key in ((full, "FULL"), (pref, "PREF"), (rept, "REPT")):
+        assert {int(k): int(v) for k, v in enumerate(dev[0]) if v} == dict(counts[key]), key
+    assert int(rept.sum()) == n_rept
+    if n_reads == 3:
+        assert full.sum() == 0 and rept.sum() == 0 and details == []
+    else:
+        assert 0 < n_rept < int((tag == 4).sum())          # some pairs removed, some REPT reads kept
+
+
+def test_scoring_bound_of_the_packed_values(ctx):
+    """(rows + 511) * gap_extend + max_read_len * match must stay below 2^13: accepted under the bound
+    (and the alignment is right: checked against the oracle), refused just over it."""
+    lad = HD
+    tmpl = HD[0] + "CAG" * 20 + HD[2]
+    reads = [tmpl[3:93], tmpl[10:60] + "T" + tmpl[60:99], "CAG" * 30]
+    ok = _lib.SwParams(4, 9, 10, 10, 9, 0, 100, 0)           # (100 + 511) * 10 + 100 * 4 = 6510
+    cls = po.classify(reads, np.zeros(len(reads), np.int32), po.LocusSet([lad]), scoring=(4, 9, 10, 10))
+    t, hh, sc, _ = _classify(ctx, [lad], reads, [0, len(reads)], [0], params=ok)
+    assert np.array_equal(t, cls[:, 0]) and np.array_equal(hh, cls[:, 1]) and np.array_equal(sc, cls[:, 2])
+    edge = _lib.SwParams(1, 5, 12, 12, 9, 0, 100, 0)         # 7 rows x 16 lanes: (112 + 511) * 12 + 100 = 7576
+    _classify(ctx, [lad], reads, [0, len(reads)], [0], params=edge)
+    over1 = _lib.SwParams(1, 5, 13, 13, 9, 0, 100, 0)        # (112 + 511) * 13 + 100 = 8199
+    with pytest.raises(_lib.TredGpuError, match="packed DP values"):
+        _classify(ctx, [lad], reads, [0, len(reads)], [0], params=over1)
+    over = _lib.SwParams(1, 5, 11, 11, 9, 0, 0, 0)           # no max_read_len: 256 assumed -> 767 * 11 + 256 = 8693
+    with pytest.raises(_lib.TredGpuError, match="packed DP values"):
+        _classify(ctx, [lad], reads, [0, len(reads)], [0], params=over)
+    over2 = _lib.SwParams(8, 9, 9, 9, 9, 0, 0, 0)            # 767 * 9 + 2048 = 8951
+    with pytest.raises(_lib.TredGpuError, match="packed DP values"):
+        _classify(ctx, [lad], reads, [0, len(reads)], [0], params=over2)
+
+
 def test_error_reporting(ctx):
     lib = ctx.lib
     p = _lib.default_sw_params()

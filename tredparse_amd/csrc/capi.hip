@@ -153,6 +153,8 @@ std::vector<int8_t> revcomp(const std::vector<int8_t>& v) {
     return o;
 }
 
+int check_sw_range(tredgpu_ctx* c, const tredgpu_sw_params* p);
+
 int check_sw_params(tredgpu_ctx* c, const tredgpu_sw_params* p) {
     if (!p) return fail(c, -2, "params is NULL");
     if (p->match < 1 || p->match > 8 || p->mismatch < 0 || p->mismatch > 16 || p->gap_open < 1 ||
@@ -160,7 +162,7 @@ int check_sw_params(tredgpu_ctx* c, const tredgpu_sw_params* p) {
         return fail(c, -2, "scoring out of the supported range (match 1..8, mismatch 0..16, "
                            "1 <= gap_extend <= gap_open <= 16)");
     if (p->flank < 0 || p->flank > 255) return fail(c, -2, "flank out of range");
-    return 0;
+    return check_sw_range(c, p);
 }
 
 int rows_for(int max_len) {
@@ -168,6 +170,19 @@ int rows_for(int max_len) {
     if (max_len <= 112) return 7;
     if (max_len <= 160) return 10;
     return 16;
+}
+
+// Every DP value is (score + (row + col) * gap_extend) << 18 | payload in an int32: the scaled score must stay
+// below 2^13 on the longest template (511 columns) for every row the kernel instantiation holds (16 lanes x R rows
+// for reads up to params.max_read_len, TREDGPU_MAX_READ_LEN when that is 0).  The default 1/5/7/2 scoring needs
+// 1 790 of the 8 192.
+int check_sw_range(tredgpu_ctx* c, const tredgpu_sw_params* p) {
+    const int L = p->max_read_len > 0 && p->max_read_len < TREDGPU_MAX_READ_LEN ? p->max_read_len : TREDGPU_MAX_READ_LEN;
+    const int need = (16 * rows_for(L) + 511) * p->gap_extend + L * p->match;
+    if (need >= 8192)
+        return fail(c, -2, "scoring too large for the packed DP values: (rows + 511) * gap_extend + max_read_len * "
+                           "match must stay below 8192 (is %d)", need);
+    return 0;
 }
 
 // copy a host array to a staging buffer; returns device pointer through out

@@ -796,21 +796,56 @@ __global__ void fill_quads_kernel(const int32_t* bins, int n_bins, const int32_t
     quads[q] = qd;
 }
 
-// bam_parser.py:256-287: histograms per unit; optional removal of REPT/REPT mate pairs.
-__global__ void mark_rept_pairs_kernel(const uint8_t* tag, const int32_t* read_pair_id,
-                                       const int32_t* unit_read_off, int32_t n_units,
-                                       uint8_t* drop) {
+// bam_parser.py:256-287: histograms per unit; optional removal of REPT/REPT mate pairs (--norepeatpairs).
+// remove_pairs_of_rept (:270-287) drops EVERY tagged read whose pair id carries two or more REPT reads, whatever
+// its own tag (a supplementary FULL record of the same name goes too).  One workgroup per unit: REPT reads count
+// their pair id in an open-addressing table in LDS, then every read looks its id up.  Units with more reads than
+// the table holds comfortably fall back to comparing pairs of reads directly.
+constexpr int PAIR_SLOTS = 4096;   // LDS table: 32 KiB (key + count)
+
+__global__ __launch_bounds__(256) void mark_rept_pairs_kernel(const uint8_t* tag, const int32_t* read_pair_id,
+                                                              const int32_t* unit_read_off, int32_t n_units,
+                                                              uint8_t* drop) {
+    __shared__ int keys[PAIR_SLOTS];
+    __shared__ int cnts[PAIR_SLOTS];
     const int g = blockIdx.x;
     if (g >= n_units) return;
     const int r0 = unit_read_off[g], r1 = unit_read_off[g + 1];
-    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
-        uint8_t d = 0;
-        const int pid = read_pair_id[i];
-        if (tag[i] == TREDGPU_TAG_REPT && pid >= 0) {
-            for (int j = r0; j < r1; ++j)
-                if (j != i && read_pair_id[j] == pid && tag[j] == TREDGPU_TAG_REPT) { d = 1; break; }
+    if (r1 - r0 > PAIR_SLOTS / 2) {
+        for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+            const int pid = read_pair_id[i];
+            int n = 0;
+            if (pid >= 0)
+                for (int j = r0; j < r1 && n < 2; ++j) n += read_pair_id[j] == pid && tag[j] == TREDGPU_TAG_REPT;
+            drop[i] = n >= 2;
         }
-        drop[i] = d;
+        return;
+    }
+    for (int k = threadIdx.x; k < PAIR_SLOTS; k += blockDim.x) { keys[k] = -1; cnts[k] = 0; }
+    __syncthreads();
+    auto slot_of = [&](int pid, bool insert) {
+        unsigned h = ((unsigned)pid * 2654435761u) >> 20;          // 12 bits
+        for (;;) {
+            const int k = (int)(h & (PAIR_SLOTS - 1));
+            int cur = keys[k];
+            if (cur == pid) return k;
+            if (cur == -1) {
+                if (!insert) return -1;
+                cur = atomicCAS(&keys[k], -1, pid);
+                if (cur == -1 || cur == pid) return k;
+            }
+            ++h;
+        }
+    };
+    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+        const int pid = read_pair_id[i];
+        if (pid >= 0 && tag[i] == TREDGPU_TAG_REPT) atomicAdd(&cnts[slot_of(pid, true)], 1);
+    }
+    __syncthreads();
+    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+        const int pid = read_pair_id[i];
+        const int k = pid >= 0 ? slot_of(pid, false) : -1;
+        drop[i] = k >= 0 && cnts[k] >= 2;
     }
 }
 
@@ -878,7 +913,7 @@ hipError_t launch_tally(const uint8_t* tag, const int16_t* h, int64_t n_reads,
     if (n_units <= 0) return hipSuccess;
     const uint8_t* drop = nullptr;
     if (read_pair_id != nullptr) {
-        mark_rept_pairs_kernel<<<n_units, 64, 0, s>>>(tag, read_pair_id, unit_read_off, n_units, scratch_drop);
+        mark_rept_pairs_kernel<<<n_units, 256, 0, s>>>(tag, read_pair_id, unit_read_off, n_units, scratch_drop);
         drop = scratch_drop;
     }
     tally_kernel<<<n_units, 64, 0, s>>>(tag, h, unit_read_off, n_units, drop, hist_stride, full_cnt,
