@@ -353,6 +353,84 @@ def stub_rank_main(args):
                        "ms_per_step": elapsed / args.steps * 1e3, "stub": True}, fp)
 
 
+# ---- end to end from BAM files (one child process with the GPU; the launcher made the files) -----------------------
+def e2e_main(args):
+    """The product path over synthetic BAMs: tred.run_many = native scans in host threads -> GPU batches -> tredCalls
+    -> <key>.json + <key>.tred.vcf.gz written to a scratch directory.  Reports whole-path genotypes/s."""
+    import glob
+    import shutil
+    out_dir = os.environ["TREDBENCH_OUT"]
+    with open(os.path.join(args.e2e_child, "truth.json")) as fp:
+        truth = json.load(fp)
+    bams = sorted(glob.glob(os.path.join(args.e2e_child, "*.bam")))
+    import torch
+    torch.cuda.init()
+    from tredparse_amd import synth_bam, tred
+    from tredparse_amd.engine import Engine
+    from tredparse_amd.meta import TREDsRepo
+    repo = TREDsRepo("hg38", sites=os.path.join(args.e2e_child, "no_sites"))
+    names = [l["name"] for l in synth_bam.bench_loci()]
+    tasks = [(os.path.basename(b)[:-4], b, repo, names, 300, False, False, True, True, "ERROR") for b in bams]
+    threads = max(1, min(args.e2e_threads or (os.cpu_count() or 1), len(tasks)))
+    engine = Engine(0)
+    work = os.path.join(args.e2e_child, "work")
+    os.makedirs(work, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(work)
+    done = []
+
+    def sink(result):
+        tred.write_vcf_json(result, "hg38", repo, names, quiet=True)
+        done.append(result)
+    try:
+        tred.run_many(tasks[:2], engine, batch=2, sink=sink, threads=2)          # warm-up: HIP context, ladders, caches
+        del done[:]
+        t0 = time.perf_counter()
+        tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads)
+        dt = time.perf_counter() - t0
+    finally:
+        os.chdir(cwd)
+    units = sum(sum(1 for n in names if n + ".1" in r["tredCalls"]) for r in done)
+    short_ok = np.mean([r["tredCalls"].get(n + ".1") == truth[r["samplekey"]][k][0] for r in done for k, n in enumerate(names)])
+    nbytes = sum(os.path.getsize(b) for b in bams)
+    rec = {"value": units / dt, "unit": "genotypes/s", "samples": len(tasks), "loci": len(names), "units": units,
+           "seconds": dt, "host_workers": threads, "samples_per_gpu_batch": args.e2e_batch,
+           "bam_MB": nbytes / 1e6, "bam_MBps": nbytes / 1e6 / dt, "short_allele_exact_frac": float(short_ok),
+           "what": "synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
+                   "native scan (BGZF inflate, BAI queries, read selection, pair lengths, depth) in host threads -> GPU "
+                   "batches -> tredCalls -> JSON + VCF files; one driver process, one GPU"}
+    with open(os.path.join(out_dir, "e2e.json"), "w") as fp:
+        json.dump(rec, fp)
+    shutil.rmtree(work, ignore_errors=True)
+
+
+def run_e2e(args):
+    """Launcher side of the end-to-end leg: make the BAMs (process pool, no GPU), run one child over them."""
+    from tredparse_amd import shard, synth_bam
+    import shutil
+    root = tempfile.mkdtemp(prefix="tredbench_e2e_")
+    try:
+        t0 = time.perf_counter()
+        made = synth_bam.make_bams(root, args.e2e_samples, seed=args.seed, workers=min(os.cpu_count() or 1, 64))
+        gen_s = time.perf_counter() - t0
+        with open(os.path.join(root, "truth.json"), "w") as fp:
+            json.dump({key: h.tolist() for key, _, h in made}, fp)
+        argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(args.e2e_batch),
+                "--e2e-threads", str(args.e2e_threads)]
+        out_dir = os.path.join(root, "out")
+        os.makedirs(out_dir)
+        env = dict(os.environ, TREDBENCH_OUT=out_dir)
+        codes = shard.spawn_ranks(argv, 1, 1, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
+        if any(codes):
+            return {"error": "end-to-end child exited with {}".format(codes)}
+        with open(os.path.join(out_dir, "e2e.json")) as fp:
+            rec = json.load(fp)
+        rec["bam_generation_seconds"] = gen_s
+        return rec
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 # ---- launcher ------------------------------------------------------------------------------------------------
 def run_ranks(args, n, n_devices):
     """Start n ranks of this script (rank r on device r mod n_devices) and return (rank 0's line, per-rank records)."""
@@ -405,6 +483,8 @@ def launcher_main(args):
     out = lines[args.gpus]
     out["scaling_sweep"] = scaling
     out["gpus_visible"] = n_devices
+    if args.e2e_samples > 0 and not args.stub:
+        out["end_to_end"] = run_e2e(args)
     if not args.no_cpu_baseline and not args.stub:
         loci, batch = make_batch(args, 0, 1)
         cores = args.cpu_cores or (os.cpu_count() or 1)
@@ -429,7 +509,13 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="only --gpus ranks, no 1/2/4/8 sweep")
     ap.add_argument("--rank-timeout", type=float, default=1500.0)
     ap.add_argument("--stub", action="store_true", help="launcher self-test: ranks do no GPU work")
+    ap.add_argument("--e2e-samples", type=int, default=64, help="synthetic BAMs of the end-to-end leg (0: skip it)")
+    ap.add_argument("--e2e-batch", type=int, default=32, help="samples per GPU batch in the end-to-end leg")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the end-to-end leg (0: all cores)")
+    ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.e2e_child:
+        return e2e_main(args)
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:     # a rank (torch.distributed.run or our launcher)
         world = int(os.environ["WORLD_SIZE"])
         if world != args.gpus:

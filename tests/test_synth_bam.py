@@ -1,0 +1,133 @@
+"""Synthetic BAMs (tredparse_amd/synth_bam.py; BASELINE configs 3-5 are "synthetic 30x 150 bp BAMs").
+
+CPU: the writer produces files both readers accept, the .bai finds exactly the overlapping records, and the native
+one-call scan selects what `expected_scan` -- numpy over the record table, written from the reference's rules
+(bam_parser.py:196-243, 316-369, 404-411) -- says it must: unmapped mates, ALT-rescued reads, soft clips,
+duplicates / QC-fail / secondary records included.
+GPU: BAM -> tred.run_many gives the calls of the packed-batch path fed from the same simulation."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tredparse_amd import bamio, synth, synth_bam as sb
+from tredparse_amd.bam_parser import scan_sample
+from tredparse_amd.meta import TREDsRepo
+
+NAMES = ("HD", "DM1", "SCA10", "FXS", "FRDA")
+
+
+@pytest.fixture(scope="module")
+def sample(tmp_path_factory):
+    loci = [l for l in synth.load_loci() if l["name"] in NAMES]
+    p = synth.SynthParams(coverage=30, expanded_max=120, expanded_frac=0.5)       # some tracts longer than a read
+    recs, h_true = sb.simulate_sample(11, loci, p)
+    path = str(tmp_path_factory.mktemp("synbam") / "s11.bam")
+    sb.write_bam(path, recs, sample="s11")
+    return loci, recs, h_true, path
+
+
+def test_both_readers_parse_the_written_file(sample):
+    loci, recs, _, path = sample
+    names = recs.names("s11")
+    for reader in (bamio.NativeAlignmentFile, bamio.PyAlignmentFile):
+        f = reader(path)
+        assert f.references == sb.CONTIGS
+        got = list(f.fetch())
+        assert len(got) == len(recs)
+        for i in list(range(0, len(recs), 997)) + [len(recs) - 1]:
+            r = got[i]
+            assert (r.tid, r.pos, r.flag, r.next_tid, r.next_pos) == (recs.tid[i], recs.pos[i], recs.flag[i], recs.mtid[i], recs.mpos[i])
+            assert r.query_name == names[i] and r.query_sequence == synth.decode(recs.codes[i])
+            assert [(op, n) for op, n in r.cigartuples] == [(int(c & 15), int(c >> 4)) for c in recs.cig[i, :recs.n_cig[i]]]
+            end = r.reference_end
+            assert (end if end is not None else -1) == recs.ref_end[i]
+        f.close()
+    flags = recs.flag
+    assert (flags & sb.FUNMAP).any() and (flags & sb.FDUP).any() and (flags & sb.FSEC).any() and (flags & sb.FQC).any()
+    assert (recs.n_cig == 3).any() and ((recs.cig[:, 0] & 15) == sb.OP_S).any()
+
+
+def test_index_finds_exactly_the_overlapping_records(sample):
+    loci, recs, _, path = sample
+    rng = np.random.default_rng(3)
+    f = bamio.NativeAlignmentFile(path)
+    rend = recs.ref_end
+    epos = np.where(rend > recs.pos, rend, recs.pos + 1)
+    for _ in range(200):
+        i = int(rng.integers(0, len(recs)))
+        lo = max(0, int(recs.pos[i]) + int(rng.integers(-3000, 3000)))
+        hi = lo + int(rng.choice([1, 40, 300, 2000, 21000]))
+        want = np.nonzero((recs.tid == recs.tid[i]) & (recs.pos < hi) & (epos > lo))[0]
+        got = [(r.pos, r.flag, r.query_name) for r in f.fetch(sb.CONTIGS[recs.tid[i]], lo, hi)]
+        names = recs.names("s11")
+        assert got == [(recs.pos[k], recs.flag[k], names[k]) for k in want]
+    f.close()
+
+
+@pytest.mark.parametrize("alts", [True, False])
+def test_native_scan_finds_what_the_rules_say(sample, alts):
+    loci, recs, _, path = sample
+    repo = TREDsRepo()
+    names = recs.names("s11")
+    scan = scan_sample(path, repo, [l["name"] for l in loci], alts=alts)
+    assert scan.opened and scan.readlen == 150 and not scan.dropped
+    n_unmapped = n_alt = 0
+    for k, l in enumerate(loci):
+        reads, depth, gl, tl = sb.expected_scan(recs, l, 150, alts=alts)
+        a, b = scan.reads_of(k)
+        assert [scan.name(i) for i in range(a, b)] == [names[i] for i in reads], l["name"]
+        assert [scan.sequence(i) for i in range(a, b)] == [synth.decode(recs.codes[i]) for i in reads]
+        assert scan.depth[k] == depth
+        g, t = scan.pair_lengths(k)
+        assert g.tolist() == gl and t.tolist() == tl and len(gl) > 1000 and len(tl) >= 5
+        n_unmapped += int(((recs.flag[reads] & sb.FUNMAP) != 0).sum())
+        n_alt += int((recs.tid[reads] != sb.CONTIGS.index(l["repeat_location"].split(":")[0])).sum())
+    assert n_unmapped > 0 and (n_alt > 0) == alts
+
+
+@pytest.mark.gpu
+def test_bam_path_equals_packed_path(tmp_path):
+    """BAM -> CLI driver (native scan, PackedUnits) against the packed-batch path fed straight from the simulation's
+    record table (read strings, depth and pair lengths from expected_scan): identical tredCalls."""
+    from tredparse_amd import tred as tredmod
+    from tredparse_amd.engine import Engine, Unit
+    from tredparse_amd.models import format_call, pair_summary
+    repo = TREDsRepo()
+    loci = [l for l in synth.load_loci() if l["name"] in NAMES]
+    p = synth.SynthParams(coverage=30, expanded_max=150, expanded_frac=0.4)
+    made = sb.make_bams(str(tmp_path), 3, seed=500, loci=loci, p=p)
+    engine = Engine(0)
+    names = [l["name"] for l in loci]
+    tasks = [(key, path, repo, names, 300, False, False, True, True, "ERROR") for key, path, _ in made]
+    results = tredmod.run_many(tasks, engine, batch=2, threads=2)
+    n_called = short_ok = 0
+    for i, ((key, path, h_true), res) in enumerate(zip(made, results)):
+        recs, h2 = sb.simulate_sample(500 + i, loci, p)
+        assert np.array_equal(h_true, h2)
+        units = []
+        for l in loci:
+            reads, depth, gl, tl = sb.expected_scan(recs, l, 150)
+            units.append(Unit(repo[l["name"]], 150, [synth.decode(recs.codes[r]) for r in reads], depth, 2, gl, tl))
+        direct = engine.genotype(units)
+        calls = res["tredCalls"]
+        assert calls["readLen"] == 150
+        for l, u, r in zip(loci, units, direct):
+            n = l["name"]
+            want = format_call(repo[n], r)
+            assert [calls[n + ".1"], calls[n + ".2"]] == want["alleles"], (key, n)
+            for k in ("CI", "PP", "label", "P_h1", "P_h2", "P_h1h2"):
+                assert calls[n + "." + k] == want[k], (key, n, k)
+            assert calls[n + ".DP"] == u.depth
+            for k, v in pair_summary(u.global_lens, u.target_lens).items():
+                assert calls[n + "." + k] == v
+            assert calls[n + ".RDP"] == r.rept and calls[n + ".FDP"] == sum(r.full.values())
+            assert len(calls[n + ".details"]) == calls[n + ".FDP"] + calls[n + ".PDP"] + calls[n + ".RDP"]
+            n_called += want["alleles"][0] > 0
+            # the simulated short allele is recovered (the long one may exceed what 150 bp reads can size)
+        short_ok += sum(calls[l["name"] + ".1"] == int(h) for l, h in zip(loci, h_true[:, 0]))
+    assert n_called == 3 * len(loci)
+    assert short_ok >= 0.6 * 3 * len(loci)         # the caller is right on ~80 % of such units (bench.py's check says the same)
+    json.dumps(results)          # everything in the results is JSON-serialisable
+    engine.close()

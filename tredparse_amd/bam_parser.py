@@ -62,19 +62,22 @@ class SampleScan(object):
     """
     __slots__ = ("path", "names", "loci", "readlen", "gender", "ydepth", "unit", "depth", "ploidy", "dropped",
                  "packed", "word_off", "read_len", "seq4", "seq4_off", "name_blob", "name_off", "name_id",
-                 "global_lens", "target_lens", "opened")
+                 "global_lens", "target_lens", "opened", "_text")
 
     def reads_of(self, k):
         u = self.unit[k]
         return int(u["read_first"]), int(u["read_first"]) + int(u["n_reads"])
 
     def sequence(self, i):
-        """Read i as the string the BAM record decodes to."""
-        a, n = int(self.seq4_off[i]), int(self.read_len[i])
-        raw = self.seq4[a:a + (n + 1) // 2]
-        nib = np.empty(2 * len(raw), np.uint8)
-        nib[0::2], nib[1::2] = raw >> 4, raw & 15
-        return _SEQ4[nib[:n]].tobytes().decode()
+        """Read i as the string the BAM record decodes to.  The whole 4-bit pool is decoded once, on first use
+        (every record starts on a byte, so read i is text[2 * seq4_off[i] :][:read_len[i]])."""
+        text = getattr(self, "_text", None)
+        if text is None:
+            nib = np.empty(2 * len(self.seq4), np.uint8)
+            nib[0::2], nib[1::2] = self.seq4 >> 4, self.seq4 & 15
+            text = self._text = _SEQ4[nib].tobytes().decode("ascii")
+        a = 2 * int(self.seq4_off[i])
+        return text[a:a + int(self.read_len[i])]
 
     def name(self, i):
         return self.name_blob[int(self.name_off[i]):int(self.name_off[i + 1])].decode()
@@ -99,6 +102,29 @@ def _y_depth(f, build):
             lo, hi = int(lo), int(hi)
             depths.append(f.pileup_depth_sum(contig, lo, hi) / float(hi - lo + 1))
     return float(np.median(depths))
+
+
+_site_cache = {}
+
+
+def _site_arrays(repo, names, loci, f):
+    """The tredbam_site / tredbam_region arrays of a locus list for a file's contig table -- the same for every BAM
+    of a cohort, so built once per (locus table, locus list, contig names)."""
+    key = (id(repo), repo.ref, tuple(names), tuple(f.references))
+    hit = _site_cache.get(key)
+    if hit is None:
+        sites = np.zeros(len(loci), bamio.SITE_DTYPE)
+        regions = []
+        strip = "nochr" in repo.ref       # the ALT table names contigs chrN in every build
+        for k, t in enumerate(loci):
+            mine = [(f.tid(c[3:] if strip else c), a, b) for c, a, b in t.alt]
+            sites[k] = (f.tid(t.chr), t.repeat_start, t.repeat_end, len(regions), len(mine))
+            regions += mine
+        hit = (sites, np.array(regions, bamio.REGION_DTYPE) if regions else np.zeros(0, bamio.REGION_DTYPE))
+        if len(_site_cache) > 64:
+            _site_cache.clear()
+        _site_cache[key] = hit
+    return hit
 
 
 def scan_sample(path, repo, names, clip=False, alts=True, readlen=None, want_sex=None, handle=None):
@@ -129,15 +155,8 @@ def scan_sample(path, repo, names, clip=False, alts=True, readlen=None, want_sex
             s.readlen = f.max_read_len(101)
         except Exception:
             pass
-    sites = np.zeros(len(s.loci), bamio.SITE_DTYPE)
-    regions = []
-    strip = "nochr" in repo.ref       # the ALT table names contigs chrN in every build
-    for k, t in enumerate(s.loci):
-        mine = [(f.tid(c[3:] if strip else c), a, b) for c, a, b in t.alt]
-        sites[k] = (f.tid(t.chr), t.repeat_start, t.repeat_end, len(regions), len(mine))
-        regions += mine
-    s.unit, pools = f.scan(sites, np.array(regions, bamio.REGION_DTYPE) if regions else np.zeros(0, bamio.REGION_DTYPE),
-                           s.readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN,
+    sites, regions = _site_arrays(repo, s.names, s.loci, f)
+    s.unit, pools = f.scan(sites, regions, s.readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN,
                            use_alts=alts and not clip)
     s.packed, s.word_off, s.read_len = pools["packed"], pools["word_off"], pools["read_len"]
     s.seq4, s.seq4_off = pools["seq4"], pools["seq4_off"]

@@ -494,7 +494,12 @@ static int run_sw_device(tredgpu_ctx* c, const uint32_t* packed, const int64_t* 
     a.stats = (unsigned long long*)c->ws_stats.p;
     {
         ScopedTimer tm(c, TREDGPU_KERNEL_SW);
-        HIPCHK(c, launch_sw_ladder(a, rows_for(max_len), max_quads, c->stream));
+        // a branch (suffix, or prefix on the reverse strand) long enough to pass the score filter of 30 by itself
+        // needs the kernel variant that also sweeps the branch alone
+        bool generic = false;
+        for (const LadderDesc& d : c->h_ladders)
+            for (int s2 = 0; s2 < d.n_strands; ++s2) generic = generic || (d.max_units > 0 && d.blen[s2] * p->match >= 30);
+        HIPCHK(c, launch_sw_ladder(a, rows_for(max_len), generic, max_quads, c->stream));
     }
     return 0;
 }

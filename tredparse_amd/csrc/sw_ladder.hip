@@ -102,8 +102,8 @@ __device__ __forceinline__ int row_excl_scan_max(int x) {
 
 // One DP column for all rows of the four alignments in this wave; LET = template letter (4 = N).
 //   s_fresh = (col<<9) + col*geK - 2*geK   (wave-uniform)      s_scale = col*geK
-template <int R, int LET>
-__device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int (&E)[R], Track& T,
+template <int R>
+__device__ __forceinline__ void sweep_column(const Rows<R>& J, const int (&SL)[R], int (&H)[R], int (&E)[R], Track& T,
                                              int col, int row0, int s_fresh, int s_scale, int geK,
                                              int c0, int row0g) {
     const int hup = dpp_row_shr<0x111>(NEG, H[R - 1]);  // last row of the lane above, previous column
@@ -112,9 +112,7 @@ __device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int 
     int run = NEG;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int S;
-        if (LET < 4) S = J.S[LET][r];
-        else S = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;  // N column: 0 against every real row
+        const int S = SL[r];
         const int t1 = diag + S;                          // extend the alignment ending at (row-1, col-1)
         const int t2 = add3_vsv(J.rowc0, s_fresh + r * (1 + geK), S);   // or start a new one here
         const int v = max3(t1, t2, E[r]);
@@ -166,18 +164,45 @@ __device__ __forceinline__ void sweep_column(const Rows<R>& J, int (&H)[R], int 
     }
 }
 
+// The profile row values of one template letter (wave-uniform): R register moves behind a scalar switch.
+template <int R>
+__device__ __forceinline__ void pick_profile(const Rows<R>& J, int letter, int geK, int (&S)[R]) {
+    switch (letter) {
+#define TREDGPU_PICK(K)                              \
+    case K:                                          \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) S[r] = J.S[K][r]; \
+        break;
+        TREDGPU_PICK(0)
+        TREDGPU_PICK(1)
+        TREDGPU_PICK(2)
+        TREDGPU_PICK(3)
+#undef TREDGPU_PICK
+        default:   // N column: 0 against every real row
+#pragma unroll
+            for (int r = 0; r < R; ++r) S[r] = J.S[0][r] < (PADNEG >> 1) ? PADNEG : 2 * geK;
+            break;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(S[r]));   // (keeps the column body from being cloned into the cases)
+}
+
+template <int R>
+__device__ __forceinline__ void sweep_at(const Rows<R>& J, const int (&S)[R], int (&H)[R], int (&E)[R], Track& T,
+                                         int col, int row0, int geK, int c0, int row0g) {
+    const int s_scale = col * geK;
+    const int s_fresh = (col << 9) + s_scale - 2 * geK;
+    sweep_column<R>(J, S, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g);
+}
+
+// One column whose letter is only known at run time.  Only the choice of the profile row values sits in a switch; the
+// column itself is ONE body (with the whole column inlined five times behind the switch the compiler reconciled the
+// five copies' register allocations with 23 moves at the head of every column).
 template <int R>
 __device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (&H)[R], int (&E)[R], Track& T,
                                              int col, int row0, int geK, int c0, int row0g) {
-    const int s_scale = col * geK;
-    const int s_fresh = (col << 9) + s_scale - 2 * geK;
-    switch (letter) {
-        case 0: sweep_column<R, 0>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
-        case 1: sweep_column<R, 1>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
-        case 2: sweep_column<R, 2>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
-        case 3: sweep_column<R, 3>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
-        default: sweep_column<R, 4>(J, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g); break;
-    }
+    int S[R];
+    pick_profile<R>(J, letter, geK, S);
+    sweep_at<R>(J, S, H, E, T, col, row0, geK, c0, row0g);
 }
 
 // Per read (valid in lane 15 of its DPP row): upper bound of the score template u can reach at its end column,
@@ -307,7 +332,7 @@ __device__ __forceinline__ void build_profile(Rows<R>& J, const SwArgs& a, int64
                                               int mK, int xK, int geK) {
     // (the profile is the same for both strands; the empty asm keeps the compiler from hoisting it out of the
     //  strand loop, where the forward and the reversed one would be live together: 2 x 4R registers)
-    asm volatile("" : "+v"(L));
+    asm volatile("" : "+v"(L), "+v"(off), "+v"(row0));   // (likewise the addresses and shifts of the four loads)
     J.rowc0 = row0 + row0 * geK;
     const int i_lo = reversed ? 16 * R - R - row0 : row0;
     uint32_t code2, nmask;
@@ -323,7 +348,19 @@ __device__ __forceinline__ void build_profile(Rows<R>& J, const SwArgs& a, int64
     }
 }
 
-template <int R, int W>
+// The lane index, recomputed on the spot (two instructions) instead of held in a register from the kernel's entry
+// to its last line: with 64-thread workgroups threadIdx.x is the lane.  Used by the cold parts of the kernel so
+// that nothing derived from the thread id has to survive the column loop in scratch.
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// GENERIC = false is the production kernel: no per-template dump, and no sweep of the suffix alone (an alignment
+// inside an 18-base suffix cannot reach the score filter of 30).  The host picks GENERIC = true when a dump is asked
+// for or some registered ladder has a branch long enough to reach the filter on its own (|branch| * match >= 30).
+template <int R, int W, bool GENERIC>
 __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     // One wavefront per workgroup: quads differ a lot in length (pruning), and a wave slot freed by a short
     // quad is only refilled when a whole new workgroup fits.
@@ -346,40 +383,37 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     const int job = lane >> 4, jl = lane & 15;
     const bool valid = job < q_count;
     int L, row0;
-    int64_t off;
     bool too_long;
     {
         const int64_t rd = valid ? (int64_t)a.perm[q_first + job] : 0;
         L = valid ? a.read_len[rd] : 0;
         too_long = L > 16 * R;  // not representable in this instantiation: flagged, not aligned
         if (too_long) L = 0;
-        off = valid ? a.read_off[rd] : 0;
         row0 = jl * R;
     }
+    // first packed word of this lane's read, looked up again wherever the read's codes are loaded (cold code)
+    auto read_base = [&]() -> int64_t {
+        const int jb = lane_now() >> 4;
+        return jb < q_count ? a.read_off[a.perm[q_first + jb]] : 0;
+    };
     const int mK = a.p.match * KONE;
     const int xK = -a.p.mismatch * KONE;
     const int geK = a.p.gap_extend * KONE;
     const int c0 = (a.p.gap_open - a.p.gap_extend) * KONE;
     const int flank = a.p.flank;
-    const bool full_dump = a.out_dump != nullptr;  // wave-uniform
+    const bool full_dump = GENERIC && a.out_dump != nullptr;  // wave-uniform
     int* const wb = wbuf + lane;
 
-    // this lane's rows as 2-bit codes / N-or-padding flags, for the 6-mer filter
-    uint32_t pk = 0, nk = 0;
-    if (2 * R + 10 <= 32) {
-        uint32_t code2, nmask;
-        load_rows<R>(a, off, L, row0, code2, nmask);
-        const int n_real = min(max(L - row0, 0), R);                       // rows of this lane inside the read
-        pk = code2 & ((1u << (2 * R)) - 1u);                               // (codes of N / padding rows are never
-        nk = (nmask | ~((1u << n_real) - 1u)) & ((1u << R) - 1u);          //  looked at: their windows count as present)
-    }
     // REPT cut-off: per-read ceil(L/period) with --useclippedreads, else the ladder's (bam_parser.py:154-155)
     const int mu_rept = a.p.clip ? (L + period - 1) / period : max_units;
 
     // arg-max so far, one word: (score << 9 | 511 - units) << 3 | tag; -1 = nothing yet.  A candidate must beat
     // it on (score, -units): max(res, key=(score, -units)), first maximal element in db order (bam_parser.py:174)
     int best = -1;
-    int n_trunk_cols = 0, n_cont_cols = 0, n_combined = 0, n_emit_trunk = 0, n_dropped = 0;  // wave-uniform work counters
+    // wave-uniform work counters, packed so that they cost two scalar registers and never a scratch slot:
+    // cnt_cols = trunk columns | continuation columns << 16;  cnt_ends = combined | dropped << 8 | from trunk << 16
+    // (a strand has at most 511 columns and 127 templates)
+    uint32_t cnt_cols = 0, cnt_ends = 0;
 
     // Only cells that can survive the score filter are tracked: min_score >= 30 (bam_parser.py:134), so a
     // floor of 29 is exact for tagging; the per-template dump (parity/debug) tracks every positive score.
@@ -405,10 +439,23 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
         //  with fewer rows per lane the per-read classes of read_class_kernel already removed hopeless strands)
         if (R >= 5 && 2 * R + 10 <= 32 && !full_dump && kmer_thr > 0 && __builtin_amdgcn_readfirstlane(ld->kmer_ok) != 0) {
             const uint32_t* bm = a.seqw + __builtin_amdgcn_readfirstlane(ld->kmer_off[s]);
-            const uint32_t pk_n = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x101, 0xF, 0xF, false);        // row_shl:1
-            const uint32_t nk_n = (uint32_t)__builtin_amdgcn_update_dpp(0x3FF, (int)nk, 0x101, 0xF, 0xF, false);
-            const uint32_t comb = pk | ((pk_n & 0x3FFu) << (2 * R));
-            const uint32_t ncomb = nk | ((nk_n & 0x1Fu) << R);
+            // this lane's rows as 2-bit codes / N-or-padding flags, loaded here, per strand: they and the window
+            // indices below depend on the read only, and hoisted out of the strand loop they would sit in 2R + 2
+            // registers across the column loop -- i.e. in scratch
+            uint32_t pk_s, nk_s;
+            {
+                int L_s = L, row0_s = row0;
+                asm volatile("" : "+v"(L_s), "+v"(row0_s));
+                uint32_t code2, nmask;
+                load_rows<R>(a, read_base(), L_s, row0_s, code2, nmask);
+                const int n_real = min(max(L_s - row0_s, 0), R);                 // rows of this lane inside the read
+                pk_s = code2 & ((1u << (2 * R)) - 1u);                             // (codes of N / padding rows are never
+                nk_s = (nmask | ~((1u << n_real) - 1u)) & ((1u << R) - 1u);        //  looked at: their windows count as present)
+            }
+            const uint32_t pk_n = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk_s, 0x101, 0xF, 0xF, false);        // row_shl:1
+            const uint32_t nk_n = (uint32_t)__builtin_amdgcn_update_dpp(0x3FF, (int)nk_s, 0x101, 0xF, 0xF, false);
+            const uint32_t comb = pk_s | ((pk_n & 0x3FFu) << (2 * R));
+            const uint32_t ncomb = nk_s | ((nk_n & 0x1Fu) << R);
             int cnt = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -443,9 +490,10 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
         const bool has_suffix = max_units > 0 && blen > 0;
         if (has_suffix) {
             // ---- continuation vectors of this strand (see above) ----
-            build_profile<R>(J, a, off, L, row0, true, mK, xK, geK);
+            build_profile<R>(J, a, read_base(), L, row0, true, mK, xK, geK);
             const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
-            const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
+            const int ln = lane_now();
+            const int bw = ln < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + ln] : 0;
             int D[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
@@ -474,17 +522,18 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             // cost was charged on the reversed side too: + go - ge in the scaled domain
             mirror_up<R>(D, 0, wb, PS);
             mirror_up<R>(E, c0, wb + R * PS, PS);
-            n_cont_cols += blen;
+            cnt_cols += (uint32_t)blen << 16;
         }
-        build_profile<R>(J, a, off, L, row0, false, mK, xK, geK);
+        build_profile<R>(J, a, read_base(), L, row0, false, mK, xK, geK);
         const int row0g = row0 * geK;
         Track T;
         // best alignment inside the suffix alone (columns relative to the suffix); it cannot reach the score
         // floor unless the suffix is long enough, so normally only the dump needs it
-        const bool with_sfx = has_suffix && (full_dump || blen * a.p.match >= 30);
+        const bool with_sfx = GENERIC && has_suffix && (full_dump || blen * a.p.match >= 30);
         if (with_sfx) {
             const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
-            const int bw = lane < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + lane] : 0;
+            const int ln = lane_now();
+            const int bw = ln < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + ln] : 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
             T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
@@ -497,16 +546,15 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             wb[(2 * R) * PS] = sk;
             wb[(2 * R + 1) * PS] = ss;
         }
-        const int tw = lane < ((ncols + 7) >> 3) ? (int)a.seqw[trunk_w + lane] : 0;
+        const int ln_t = lane_now();
+        const int tw = ln_t < ((ncols + 7) >> 3) ? (int)a.seqw[trunk_w + ln_t] : 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
         T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
         int next_end = max_units > 0 ? alen + period - 1 : alen - 1;
         int u = max_units > 0 ? 1 : 0;
-        for (int col = 0; col < ncols; ++col) {
-            sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g);
-            ++n_trunk_cols;
-            if (col != next_end) continue;
+        // ---- what happens when template u ends at column `col` of the trunk; true = leave this strand ----
+        auto template_end = [&](int col) -> bool {
             // ---- template u ends here on the trunk ----
             // Exact pruning: no cell of its suffix can score more than max(trunk best, column max + |suffix| *
             // match).  If that cannot reach the score filter (bam_parser.py:134) or beat the read's current
@@ -522,10 +570,10 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             }
             next_end += period;
             if (!need) {
-                ++n_dropped;
+                cnt_ends += 1u << 8;
                 ++u;
-                if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
-                continue;
+                if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) return true;
+                return false;
             }
             int bk = T.bestkey, bs = T.beststart;
             if (comb) {
@@ -552,13 +600,13 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                     const int bestS = best >> 12, bestU = 511 - ((best >> 3) & 511);
                     const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
                     if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && (ks >> KSH) >= need_score) == 0) {
-                        ++n_dropped;
+                        cnt_ends += 1u << 8;
                         ++u;
-                        if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
-                        continue;
+                        if (__builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) return true;
+                        return false;
                     }
                 }
-                ++n_combined;
+                ++cnt_ends;
                 int st = 0;
                 if (__builtin_amdgcn_ballot_w64(c) != 0) {
                     // start payload of the winner (largest among equal keys); the sums are recomputed, not kept
@@ -584,7 +632,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                     bs = c3 ? s3 : bs;
                 }
             } else {
-                ++n_emit_trunk;
+                cnt_ends += 1u << 16;
                 pair_step<0x111>(bk, bs);
                 pair_step<0x112>(bk, bs);
                 pair_step<0x114>(bk, bs);
@@ -623,21 +671,54 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 }
             }
             ++u;
-            if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) break;
+            if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) return true;
+            return false;
+        };
+        if (period == 3 && max_units > 0) {
+            // Period-3 ladders (27 of the 30 loci): inside the repeat the column letters cycle through the motif, so
+            // the three profile rows are picked once per strand and the column loop is unrolled by the period --
+            // no letter fetch, no profile selection and no register shuffling between columns, and the template
+            // ends fall on the loop's own boundary.
+            int col = 0;
+            for (; col < alen; ++col) {
+                sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g);
+                ++cnt_cols;
+            }
+            int P0[R], P1[R], P2[R];
+            pick_profile<R>(J, letter_from(tw, alen), geK, P0);
+            pick_profile<R>(J, letter_from(tw, alen + 1), geK, P1);
+            pick_profile<R>(J, letter_from(tw, alen + 2), geK, P2);
+            for (;;) {
+                sweep_at<R>(J, P0, H, E, T, col, row0, geK, c0, row0g);
+                sweep_at<R>(J, P1, H, E, T, col + 1, row0, geK, c0, row0g);
+                sweep_at<R>(J, P2, H, E, T, col + 2, row0, geK, c0, row0g);
+                col += 3;
+                cnt_cols += 3;
+                if (template_end(col - 1) || col >= ncols) break;
+            }
+        } else {
+            for (int col = 0; col < ncols; ++col) {
+                sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g);
+                ++cnt_cols;
+                if (col != next_end) continue;
+                if (template_end(col)) break;
+            }
         }
     }
-    if (a.stats != nullptr && lane < 7) {
+    const int lane_e = lane_now();
+    if (a.stats != nullptr && lane_e < 7) {
         // one atomic per counter and wave (lanes 0..6 of one instruction), spread over SW_STAT_SLOTS lines;
         // the last one counts read-columns: columns swept x reads in the quad (empty slots of a partial quad excluded)
-        const int vals[7] = {n_trunk_cols, n_cont_cols, n_combined, n_dropped, n_emit_trunk, 1,
-                             (n_trunk_cols + n_cont_cols) * q_count};
+        const int n_trunk_cols = (int)(cnt_cols & 0xFFFFu), n_cont_cols = (int)(cnt_cols >> 16);
+        const int vals[7] = {n_trunk_cols, n_cont_cols, (int)(cnt_ends & 0xFFu), (int)((cnt_ends >> 8) & 0xFFu),
+                             (int)(cnt_ends >> 16), 1, (n_trunk_cols + n_cont_cols) * q_count};
         int v = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) v = lane == k ? vals[k] : v;
-        atomicAdd(a.stats + (size_t)(blockIdx.x & (SW_STAT_SLOTS - 1)) * 8 + lane, (unsigned long long)v);
+        for (int k = 0; k < 7; ++k) v = lane_e == k ? vals[k] : v;
+        atomicAdd(a.stats + (size_t)(blockIdx.x & (SW_STAT_SLOTS - 1)) * 8 + lane_e, (unsigned long long)v);
     }
-    if (valid && jl == 15) {
-        const int64_t rd = (int64_t)a.perm[q_first + job];
+    if ((lane_e >> 4) < q_count && (lane_e & 15) == 15) {
+        const int64_t rd = (int64_t)a.perm[q_first + (lane_e >> 4)];
         int bestTag = best < 0 ? TREDGPU_TAG_NONE : best & 7;
         int bestU = 511 - ((best >> 3) & 511), bestS = best >> 12;
         if (too_long) bestTag = TREDGPU_TAG_INVALID, bestU = 0, bestS = 0;
@@ -815,8 +896,9 @@ __global__ __launch_bounds__(256) void mark_rept_pairs_kernel(const uint8_t* tag
         for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
             const int pid = read_pair_id[i];
             int n = 0;
-            if (pid >= 0)
-                for (int j = r0; j < r1 && n < 2; ++j) n += read_pair_id[j] == pid && tag[j] == TREDGPU_TAG_REPT;
+            // (no per-lane early exit at n == 2: hipcc 7.2 takes the exit test of the LAST loop trip for every lane
+            //  of a loop whose lanes leave at different trips; the wave-uniform bound is also the simpler code)
+            for (int j = r0; j < r1; ++j) n += (pid >= 0) & (read_pair_id[j] == pid) & (tag[j] == TREDGPU_TAG_REPT);
             drop[i] = n >= 2;
         }
         return;
@@ -886,15 +968,20 @@ size_t sw_unit_cnt_bytes(int n_units) { return (size_t)n_units * UNIT_BINS * siz
 int64_t sw_max_quads(int64_t n_reads, int n_ladders) { return n_reads / 4 + (int64_t)UNIT_BINS * n_ladders + 1; }
 size_t sw_bin_bytes(int n_ladders) { return ((size_t)UNIT_BINS * n_ladders + 1) * BIN_STRIDE * sizeof(int32_t); }
 
-hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s) {
+hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, bool generic, int64_t max_quads, hipStream_t s) {
     if (max_quads <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)max_quads;   // one quad = one wavefront = one workgroup
-    switch (rows_per_lane) {
+    generic = generic || a.out_dump != nullptr;
+    switch (rows_per_lane * 2 + (generic ? 1 : 0)) {
         // second parameter = waves per SIMD the register allocation is held to
-        case 4: sw_cont_kernel<4, 6><<<blocks, 64, 0, s>>>(a); break;
-        case 7: sw_cont_kernel<7, 4><<<blocks, 64, 0, s>>>(a); break;
-        case 10: sw_cont_kernel<10, 4><<<blocks, 64, 0, s>>>(a); break;
-        case 16: sw_cont_kernel<16, 2><<<blocks, 64, 0, s>>>(a); break;
+        case 8: sw_cont_kernel<4, 6, false><<<blocks, 64, 0, s>>>(a); break;
+        case 9: sw_cont_kernel<4, 6, true><<<blocks, 64, 0, s>>>(a); break;
+        case 14: sw_cont_kernel<7, 4, false><<<blocks, 64, 0, s>>>(a); break;
+        case 15: sw_cont_kernel<7, 4, true><<<blocks, 64, 0, s>>>(a); break;
+        case 20: sw_cont_kernel<10, 4, false><<<blocks, 64, 0, s>>>(a); break;
+        case 21: sw_cont_kernel<10, 4, true><<<blocks, 64, 0, s>>>(a); break;
+        case 32: sw_cont_kernel<16, 2, false><<<blocks, 64, 0, s>>>(a); break;
+        case 33: sw_cont_kernel<16, 2, true><<<blocks, 64, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -63,7 +63,8 @@ hipError_t launch_build_quads(const SwArgs& a, uint8_t* read_class, int32_t* per
 size_t sw_bin_bytes(int n_ladders);
 size_t sw_unit_cnt_bytes(int n_units);
 int64_t sw_max_quads(int64_t n_reads, int n_ladders);   // one partial quad per (ladder, class, level) bin
-hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, int64_t max_quads, hipStream_t s);
+// generic: some ladder's branch could reach the score filter on its own (the production kernel skips that sweep)
+hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, bool generic, int64_t max_quads, hipStream_t s);
 hipError_t launch_tally(const uint8_t* tag, const int16_t* h, int64_t n_reads,
                         const int32_t* unit_read_off, int32_t n_units, const int32_t* read_pair_id,
                         int32_t hist_stride, int32_t* full_cnt, int32_t* pref_cnt,

@@ -64,7 +64,8 @@ def calc_label(tred, alleles):
 def sparsify_marginal(P, epsilon=SMALL_VALUE):
     """models.py:304-317 for a marginal given as a dense array indexed by repeat units."""
     total = float(P.sum())
-    return {str(int(k)): float(P[k] / total) for k in np.nonzero(P >= epsilon)[0]}
+    keep = np.nonzero(P >= epsilon)[0]
+    return dict(zip(map(str, keep.tolist()), (P[keep] / total).tolist()))
 
 
 def sparsify_joint(grid, period, epsilon=SMALL_VALUE):
@@ -81,7 +82,9 @@ def sparsify_joint(grid, period, epsilon=SMALL_VALUE):
 def sparsify_joint_triples(triples, total, period):
     """models.py:279-285 + 304-317 from the kernel's sparse joint output: triples {h1, h2, exp(ml - max)} of the
     distinct pairs >= e^-10 and the sum over all distinct pairs."""
-    return {"{},{}".format(int(h1) // period, int(h2) // period): float(v) / total for h1, h2, v in triples}
+    t = np.asarray(triples)
+    a, b = (t[:, 0].astype(np.int64) // period).tolist(), (t[:, 1].astype(np.int64) // period).tolist()
+    return {"%d,%d" % k: v for k, v in zip(zip(a, b), (t[:, 2] / total).tolist())}
 
 
 def format_call(tred, res):
@@ -113,6 +116,42 @@ def pair_summary(global_lens, target_lens):
     """PEDP, PEG, PET, P_PEG, P_PET of the JSON from the two pair-length lists."""
     g, t = list(global_lens), list(target_lens)
     return {"PEDP": len(t), "PEG": mean_std(g), "PET": mean_std(t), "P_PEG": histogram(g), "P_PET": histogram(t)}
+
+
+_HIST_BINS = 40
+_HIST_LEFT = ["%d:" % (SPAN // _HIST_BINS * j) for j in range(_HIST_BINS)]
+
+
+def _pool_strings(pool, first, count):
+    """mean_std and histogram strings of many slices pool[first[k] : first[k] + count[k]] at once (the slices are
+    consecutive and in order, as the scan's pools are).  Same values as mean_std / histogram per slice: the sums of
+    these small integers are exact in float64, the bins of np.histogram over (0, SPAN) are x // 25 for integers."""
+    g = len(first)
+    count = np.asarray(count, np.int64)
+    lo, hi = (int(first[0]), int(first[-1] + count[-1])) if g else (0, 0)
+    x = np.asarray(pool[lo:hi], np.int64)
+    unit = np.repeat(np.arange(g), count)
+    n = np.maximum(count, 1).astype(np.float64)
+    xf = x.astype(np.float64)
+    mean = np.bincount(unit, xf, g) / n
+    dev = xf - mean[unit]
+    std = np.sqrt(np.bincount(unit, dev * dev, g) / n)
+    ok = (x >= 0) & (x <= SPAN)
+    width = SPAN // _HIST_BINS
+    hist = np.bincount(unit[ok] * _HIST_BINS + np.minimum(x[ok] // width, _HIST_BINS - 1),
+                       minlength=g * _HIST_BINS).reshape(g, _HIST_BINS).tolist()
+    ms = ["%.0f+/-%.0fbp" % (m, sd) if c else "" for m, sd, c in zip(mean.tolist(), std.tolist(), count.tolist())]
+    hs = [",".join([a + str(b) for a, b in zip(_HIST_LEFT, row)]) if c else "" for row, c in zip(hist, count.tolist())]
+    return ms, hs
+
+
+def pair_summaries(scan):
+    """pair_summary for every locus of a bam_parser.SampleScan, computed over the scan's pools in one go."""
+    u = scan.unit
+    peg, p_peg = _pool_strings(scan.global_lens, u["global_first"], u["n_global"])
+    pet, p_pet = _pool_strings(scan.target_lens, u["target_first"], u["n_target"])
+    return [{"PEDP": int(n), "PEG": a, "PET": b, "P_PEG": c, "P_PET": d}
+            for n, a, b, c, d in zip(u["n_target"].tolist(), peg, pet, p_peg, p_pet)]
 
 
 class IntegratedCaller:

@@ -31,7 +31,7 @@ from datetime import date, timedelta
 from . import __version__
 from .bam_parser import scan_sample, tally
 from .meta import BUILDS, TREDsRepo
-from .models import GridError, format_call, pair_summary
+from .models import GridError, format_call, pair_summaries
 
 logging.basicConfig()
 logger = logging.getLogger(__name__)
@@ -158,8 +158,8 @@ def _skeleton(o, scan):
     return {"samplekey": o["samplekey"], "bam": o["bam"], "tredCalls": calls}
 
 
-def _fill_unit(calls, scan, k, res, repeatpairs):
-    """The 21 keys of one locus from its kernel results."""
+def _fill_unit(calls, scan, k, res, repeatpairs, pairs):
+    """The 21 keys of one locus from its kernel results (pairs = models.pair_summaries(scan))."""
     t = scan.loci[k]
     call = format_call(t, res)                       # may raise GridError: the locus is then left out
     counts, details, rept = tally(scan, k, res.tags, res.hs, repeatpairs=repeatpairs)
@@ -170,7 +170,7 @@ def _fill_unit(calls, scan, k, res, repeatpairs):
     calls[n + ".DP"] = float(scan.depth[k])
     calls[n + ".FDP"], calls[n + ".PDP"] = sum(counts["FULL"].values()), sum(counts["PREF"].values())
     calls[n + ".RDP"] = rept
-    for key, v in pair_summary(*(x.tolist() for x in scan.pair_lengths(k))).items():
+    for key, v in pairs[k].items():
         calls[n + "." + key] = v
     for key in ("CI", "PP", "label", "P_h1", "P_h2", "P_h1h2"):
         calls[n + "." + key] = call[key]
@@ -226,11 +226,12 @@ def finish_batch(engine, task_args, scans):
     for si, (arg, scan) in enumerate(zip(task_args, scans)):
         o = _options(arg)
         result = _skeleton(o, scan)
+        pairs = pair_summaries(scan) if picks[si][2] else None
         for k in picks[si][2]:
             if (si, k) not in res:
                 continue
             try:
-                _fill_unit(result["tredCalls"], scan, k, res[(si, k)], o["repeatpairs"] or o["clip"])
+                _fill_unit(result["tredCalls"], scan, k, res[(si, k)], o["repeatpairs"] or o["clip"], pairs)
             except GridError as e:
                 logger.error("Exception on `%s` %s (%s)", o["bam"], scan.names[k], e)
         results.append(result)
