@@ -43,14 +43,18 @@ def _run(ctx, b, order=None):
 def test_full_size_properties(ctx, loci):
     _model(ctx)
     sel = [l for l in loci if l["name"] not in ("FXTAS", "AR")]
-    b = synth.build_batch(20260101, sel, 200, synth.SynthParams(coverage=30), workers=16)   # 6 000 units, ~580 k reads
+    # BASELINE configs[2] at full size: 1 000 samples x 30 loci = 30 000 units, ~2.9 M reads (bench.py's batch)
+    b = synth.build_batch(20260101, sel, 1000, synth.SynthParams(coverage=30), workers=32)
+    assert b.n_units == 30000 and b.n_reads > 2500000
     ctx.set_ladders(b.ladders)
     r1 = _run(ctx, b)
     r2 = _run(ctx, b)
     for k in ("tag", "h", "sc", "full", "pref", "rept"):
         assert np.array_equal(r1[k], r2[k]), k                           # idempotent, bit for bit
     assert r1["calls"].tobytes() == r2["calls"].tobytes()
-    # unit order must not matter (units are independent; quads never mix units)
+    # unit order must not matter: units are independent, and although a quad of the SW kernel holds reads of
+    # several units (quads are packed by ladder / class / 6-mer level across the batch), a read's result does not
+    # depend on its wave-mates
     rng = np.random.default_rng(1)
     perm = rng.permutation(b.n_units)
     r3 = _run(ctx, b, perm)
@@ -69,9 +73,9 @@ def test_full_size_properties(ctx, loci):
     assert (r1["calls"]["status"] == 0).all()
     ok = (r1["calls"]["h1"] // b.units["period"]) == b.h_true[:, 0]
     assert ok.mean() > 0.75
-    # oracle spot check (classification + likelihood) on 24 random units
+    # oracle spot check (classification + likelihood) on 48 random units
     ls = po.LocusSet(b.ladders)
-    for u in rng.choice(b.n_units, 24, replace=False):
+    for u in rng.choice(b.n_units, 48, replace=False):
         r0, r1_ = b.unit_read_off[u], b.unit_read_off[u + 1]
         reads = [synth.decode(x) for x in b.codes[r0:r1_]]
         cls = po.classify(reads, np.full(len(reads), b.unit_ladder[u], np.int32), ls, threads=0)

@@ -47,6 +47,13 @@ __device__ __forceinline__ int add3_vsv(int v0, int s1, int v2) {
     asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(v0), "s"(s1), "v"(v2));
     return d;
 }
+// v_add_u32 of a wave-uniform term (SGPR) and a lane value, opaque to the optimiser: written out in C the compiler
+// hoists "row part + r * stride" for every row out of the column loop -- R more live registers, i.e. scratch.
+__device__ __forceinline__ int add_sv(int s0, int v1) {
+    int d;
+    asm("v_add_u32 %0, %1, %2" : "=v"(d) : "s"(s0), "v"(v1));
+    return d;
+}
 __device__ __forceinline__ int max3(int a, int b, int c) { return max(max(a, b), c); }
 
 // inclusive max scan over the 16 lanes of a DPP row (old = x: lanes without a source keep x)
@@ -102,20 +109,39 @@ __device__ __forceinline__ int row_excl_scan_max(int x) {
 
 // One DP column for all rows of the four alignments in this wave; LET = template letter (4 = N).
 //   s_fresh = (col<<9) + col*geK - 2*geK   (wave-uniform)      s_scale = col*geK
+// The local-alignment floor.  Z(i, c) = "the empty alignment whose first cell will be (i+1, c+1)": score 0, start
+// payload (c+1) << 9 | (i+1), in the scale of cell (i, c).  Every stored H is max(H, Z), so that the diagonal step
+// H[i][c] + S into (i+1, c+1) is at once "extend" and "start a new alignment here" -- the fresh-start term costs
+// one two-operand add (the row part is a register, the column part a scalar) inside the max3 that is there anyway,
+// instead of a three-operand add of its own.  A path through a cell of score 0 or less never beats the alignment
+// that starts after it (same score or more, later start), so the maxima -- scores, end cells and the start-cell
+// tie rule -- are those of the recurrences without the floor (checked by tools/fuzz_parity.py against ssw.c).
+//   s_z(col) = ((col + 1) << 9) + 1 + col*geK   (wave-uniform column part of Z)
+__device__ __forceinline__ int z_col(int col, int geK) { return ((col + 1) << 9) + 1 + col * geK; }
+
+// state in front of column 0: H = Z(i, -1), no horizontal gap open
+template <int R>
+__device__ __forceinline__ void column_start(const Rows<R>& J, int (&H)[R], int (&E)[R], int geK) {
+    const int zc = z_col(-1, geK);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { H[r] = J.rowc0 + r * (1 + geK) + zc; E[r] = NEG; }
+}
+
 template <int R>
 __device__ __forceinline__ void sweep_column(const Rows<R>& J, const int (&SL)[R], int (&H)[R], int (&E)[R], Track& T,
-                                             int col, int row0, int s_fresh, int s_scale, int geK,
+                                             int col, int row0, int s_z, int s_scale, int geK,
                                              int c0, int row0g) {
-    const int hup = dpp_row_shr<0x111>(NEG, H[R - 1]);  // last row of the lane above, previous column
+    // last row of the lane above, previous column; above the first row lies Z(-1, col-1) = (col << 9) + (col-2)*geK
+    const int hup = __builtin_amdgcn_update_dpp((col << 9) + s_scale - 2 * geK, H[R - 1], 0x111, 0xF, 0xF, false);
     int ht[R], pl[R];
     int diag = hup;
     int run = NEG;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int S = SL[r];
-        const int t1 = diag + S;                          // extend the alignment ending at (row-1, col-1)
-        const int t2 = add3_vsv(J.rowc0, s_fresh + r * (1 + geK), S);   // or start a new one here
-        const int v = max3(t1, t2, E[r]);
+        const int t1 = diag + S;                          // extend the alignment ending at (row-1, col-1), or start here
+        const int z = add_sv(s_z + r * (1 + geK), J.rowc0);   // Z(row, col): nothing aligned yet
+        const int v = max3(t1, z, E[r]);
         diag = H[r];
         ht[r] = v;
         pl[r] = run;                                      // F~ from this lane's rows above
@@ -190,13 +216,13 @@ template <int R>
 __device__ __forceinline__ void sweep_at(const Rows<R>& J, const int (&S)[R], int (&H)[R], int (&E)[R], Track& T,
                                          int col, int row0, int geK, int c0, int row0g) {
     const int s_scale = col * geK;
-    const int s_fresh = (col << 9) + s_scale - 2 * geK;
-    sweep_column<R>(J, S, H, E, T, col, row0, s_fresh, s_scale, geK, c0, row0g);
+    sweep_column<R>(J, S, H, E, T, col, row0, z_col(col, geK), s_scale, geK, c0, row0g);
 }
 
-// One column whose letter is only known at run time.  Only the choice of the profile row values sits in a switch; the
-// column itself is ONE body (with the whole column inlined five times behind the switch the compiler reconciled the
-// five copies' register allocations with 23 moves at the head of every column).
+// One column whose letter is only known at run time (prefix columns, ladders of other periods, the dump variant's
+// suffix sweep).  Only the choice of the profile row values sits in a switch; the column itself is ONE body (with
+// the whole column inlined five times behind the switch the compiler reconciled the five copies' register
+// allocations with 23 moves at the head of every column).
 template <int R>
 __device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (&H)[R], int (&E)[R], Track& T,
                                              int col, int row0, int geK, int c0, int row0g) {
@@ -210,9 +236,12 @@ __device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (
 // column held in H; gain = |suffix| * match * K.
 template <int R>
 __device__ __forceinline__ int reach_bound(const int (&H)[R], const Track& T, int lane_scale, int geK, int gain) {
-    int cmx = NEG, scale = lane_scale;
+    // (row offsets as scalars, the lane's own scale taken off once: with a per-lane running scale the compiler keeps
+    //  "lane scale + r * ge*K" for all R rows in registers across the whole strand)
+    int cmx = NEG, rs = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) { cmx = max(cmx, H[r] - scale); scale += geK; }
+    for (int r = 0; r < R; ++r) { cmx = max(cmx, H[r] - rs); rs += geK; }
+    cmx -= lane_scale;
     constexpr int IMIN = -2147483647 - 1;
     int v = max(max(cmx, 0) + gain, T.bestkey);
     v = max(v, dpp_row_shr<0x111>(IMIN, v));
@@ -534,8 +563,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             const int branch_w = __builtin_amdgcn_readfirstlane(ld->branch_off[s]);
             const int ln = lane_now();
             const int bw = ln < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + ln] : 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+            column_start<R>(J, H, E, geK);
             T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
             for (int j = 0; j < blen; ++j) sweep_letter<R>(letter_from(bw, j), J, H, E, T, j, row0, geK, c0, row0g);
             int sk = T.bestkey, ss = T.beststart;
@@ -548,8 +576,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
         }
         const int ln_t = lane_now();
         const int tw = ln_t < ((ncols + 7) >> 3) ? (int)a.seqw[trunk_w + ln_t] : 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) { H[r] = NEG; E[r] = NEG; }
+        column_start<R>(J, H, E, geK);
         T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
         int next_end = max_units > 0 ? alen + period - 1 : alen - 1;
         int u = max_units > 0 ? 1 : 0;
