@@ -81,7 +81,8 @@ def make_batch(args, rank, world):
     from tredparse_amd import synth
     loci = bench_loci(synth.load_loci())
     p = synth.SynthParams(coverage=args.coverage, readlen=150)
-    workers = max(1, min(len(loci), (os.cpu_count() or 8) // max(1, world)))
+    from tredparse_amd import shard
+    workers = max(1, min(len(loci), shard.usable_cpus() // max(1, world)))
     return loci, synth.build_batch(args.seed + rank, loci, args.samples, p, workers=workers)
 
 
@@ -356,28 +357,36 @@ def stub_rank_main(args):
 # ---- end to end from BAM files (one child process with the GPU; the launcher made the files) -----------------------
 def e2e_main(args):
     """The product path over synthetic BAMs: tred.run_many = native scans in host threads -> GPU batches -> tredCalls
-    -> <key>.json + <key>.tred.vcf.gz written to a scratch directory.  Reports whole-path genotypes/s."""
+    -> <key>.json + <key>.tred.vcf.gz written to a scratch directory.  One or several driver processes (ranks) share
+    the GPU; each takes its block of the BAMs (shard_range), they start together (barrier) and the slowest one's
+    time counts."""
     import glob
     import shutil
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     out_dir = os.environ["TREDBENCH_OUT"]
     with open(os.path.join(args.e2e_child, "truth.json")) as fp:
         truth = json.load(fp)
     bams = sorted(glob.glob(os.path.join(args.e2e_child, "*.bam")))
     import torch
     torch.cuda.init()
-    from tredparse_amd import synth_bam, tred
+    from tredparse_amd import shard, synth_bam, tred
     from tredparse_amd.engine import Engine
     from tredparse_amd.meta import TREDsRepo
+    lo, hi = shard.shard_range(len(bams), rank, world)
     repo = TREDsRepo("hg38", sites=os.path.join(args.e2e_child, "no_sites"))
     names = [l["name"] for l in synth_bam.bench_loci()]
-    tasks = [(os.path.basename(b)[:-4], b, repo, names, 300, False, False, True, True, "ERROR") for b in bams]
-    threads = max(1, min(args.e2e_threads or (os.cpu_count() or 1), len(tasks)))
+    tasks = [(os.path.basename(b)[:-4], b, repo, names, 300, False, False, True, True, "ERROR") for b in bams[lo:hi]]
+    threads = max(1, min(args.e2e_threads or max(1, (shard.usable_cpus() - world) // world), max(len(tasks), 1)))
     engine = Engine(0)
-    work = os.path.join(args.e2e_child, "work")
+    work = os.path.join(args.e2e_child, "work{}".format(rank))
     os.makedirs(work, exist_ok=True)
     cwd = os.getcwd()
     os.chdir(work)
     done = []
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def sink(result):
         tred.write_vcf_json(result, "hg38", repo, names, quiet=True)
@@ -385,22 +394,25 @@ def e2e_main(args):
     try:
         tred.run_many(tasks[:2], engine, batch=2, sink=sink, threads=2)          # warm-up: HIP context, ladders, caches
         del done[:]
+        for k in tred.TIMING:
+            tred.TIMING[k] = 0.0
+        if dist is not None:
+            dist.barrier()
         t0 = time.perf_counter()
         tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads)
         dt = time.perf_counter() - t0
     finally:
         os.chdir(cwd)
     units = sum(sum(1 for n in names if n + ".1" in r["tredCalls"]) for r in done)
-    short_ok = np.mean([r["tredCalls"].get(n + ".1") == truth[r["samplekey"]][k][0] for r in done for k, n in enumerate(names)])
-    nbytes = sum(os.path.getsize(b) for b in bams)
-    rec = {"value": units / dt, "unit": "genotypes/s", "samples": len(tasks), "loci": len(names), "units": units,
-           "seconds": dt, "host_workers": threads, "samples_per_gpu_batch": args.e2e_batch,
-           "bam_MB": nbytes / 1e6, "bam_MBps": nbytes / 1e6 / dt, "short_allele_exact_frac": float(short_ok),
-           "what": "synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
-                   "native scan (BGZF inflate, BAI queries, read selection, pair lengths, depth) in host threads -> GPU "
-                   "batches -> tredCalls -> JSON + VCF files; one driver process, one GPU"}
-    with open(os.path.join(out_dir, "e2e.json"), "w") as fp:
+    hits = [r["tredCalls"].get(n + ".1") == truth[r["samplekey"]][k][0] for r in done for k, n in enumerate(names)]
+    rec = {"rank": rank, "units": units, "seconds": dt, "samples": len(tasks), "host_threads": threads,
+           "driver_seconds": {k: round(v, 4) for k, v in tred.TIMING.items()},
+           "short_ok": int(sum(hits)), "short_n": len(hits), "bam_bytes": sum(os.path.getsize(b) for b in bams[lo:hi])}
+    with open(os.path.join(out_dir, "e2e_rank{}.json".format(rank)), "w") as fp:
         json.dump(rec, fp)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     shutil.rmtree(work, ignore_errors=True)
 
 
@@ -411,21 +423,43 @@ def run_e2e(args):
     root = tempfile.mkdtemp(prefix="tredbench_e2e_")
     try:
         t0 = time.perf_counter()
-        made = synth_bam.make_bams(root, args.e2e_samples, seed=args.seed, workers=min(os.cpu_count() or 1, 64))
+        made = synth_bam.make_bams(root, args.e2e_samples, seed=args.seed, workers=shard.usable_cpus())
         gen_s = time.perf_counter() - t0
         with open(os.path.join(root, "truth.json"), "w") as fp:
             json.dump({key: h.tolist() for key, _, h in made}, fp)
         argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(args.e2e_batch),
                 "--e2e-threads", str(args.e2e_threads)]
-        out_dir = os.path.join(root, "out")
-        os.makedirs(out_dir)
-        env = dict(os.environ, TREDBENCH_OUT=out_dir)
-        codes = shard.spawn_ranks(argv, 1, 1, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
-        if any(codes):
-            return {"error": "end-to-end child exited with {}".format(codes)}
-        with open(os.path.join(out_dir, "e2e.json")) as fp:
-            rec = json.load(fp)
+        legs = []
+        many = args.e2e_drivers or max(1, shard.usable_cpus() // 6)   # ~5 scan threads keep one formatting driver busy
+        for drivers in sorted(set([1, many])):
+            out_dir = os.path.join(root, "out{}".format(drivers))
+            os.makedirs(out_dir)
+            env = dict(os.environ, TREDBENCH_OUT=out_dir)
+            codes = shard.spawn_ranks(argv, drivers, 1, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
+            if any(codes):
+                legs.append({"drivers": drivers, "error": "exit codes {}".format(codes)})
+                continue
+            ranks = []
+            for r in range(drivers):
+                with open(os.path.join(out_dir, "e2e_rank{}.json".format(r))) as fp:
+                    ranks.append(json.load(fp))
+            units, secs = sum(r["units"] for r in ranks), max(r["seconds"] for r in ranks)
+            nbytes = sum(r["bam_bytes"] for r in ranks)
+            legs.append({"drivers": drivers, "value": units / secs, "unit": "genotypes/s", "units": units,
+                         "seconds": secs, "samples": sum(r["samples"] for r in ranks),
+                         "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,
+                         "per_driver": [{"seconds": round(r["seconds"], 3), **r["driver_seconds"]} for r in ranks],
+                         "bam_MBps": nbytes / 1e6 / secs,
+                         "short_allele_exact_frac": sum(r["short_ok"] for r in ranks) / max(1, sum(r["short_n"] for r in ranks))})
+        best = max((l for l in legs if "value" in l), key=lambda l: l["value"], default=None)
+        rec = dict(best) if best else {"error": "no end-to-end leg finished"}
+        rec["legs"] = legs
+        rec["samples_per_gpu_batch"] = args.e2e_batch
         rec["bam_generation_seconds"] = gen_s
+        rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
+                       "native scan (BGZF inflate, BAI queries, read selection, pair lengths, depth) in host threads -> GPU "
+                       "batches -> tredCalls -> JSON + VCF files; `drivers` processes share ONE GPU, each with its block of "
+                       "the samples (tred.py --gpus N uses the same fan-out, rank r on device r mod devices)")
         return rec
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -487,10 +521,12 @@ def launcher_main(args):
         out["end_to_end"] = run_e2e(args)
     if not args.no_cpu_baseline and not args.stub:
         loci, batch = make_batch(args, 0, 1)
-        cores = args.cpu_cores or (os.cpu_count() or 1)
+        from tredparse_amd import shard as _shard
+        cores = args.cpu_cores or _shard.usable_cpus()      # the cgroup quota, not the CPUs merely visible
         many, one = cpu_baselines(batch, loci, args.cpu_budget, cores)
         out["cpu_baseline"] = many
         out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        out["cpu_baseline"]["usable_cpus"] = cores
         out["cpu_baseline_1core"] = one
     print(json.dumps(out), flush=True)
 
@@ -509,9 +545,10 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="only --gpus ranks, no 1/2/4/8 sweep")
     ap.add_argument("--rank-timeout", type=float, default=1500.0)
     ap.add_argument("--stub", action="store_true", help="launcher self-test: ranks do no GPU work")
-    ap.add_argument("--e2e-samples", type=int, default=64, help="synthetic BAMs of the end-to-end leg (0: skip it)")
-    ap.add_argument("--e2e-batch", type=int, default=32, help="samples per GPU batch in the end-to-end leg")
-    ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the end-to-end leg (0: all cores)")
+    ap.add_argument("--e2e-samples", type=int, default=128, help="synthetic BAMs of the end-to-end leg (0: skip it)")
+    ap.add_argument("--e2e-batch", type=int, default=16, help="samples per GPU batch in the end-to-end leg")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="host threads per driver in the end-to-end leg (0: cores / drivers)")
+    ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 6; also run with 1)")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.e2e_child:

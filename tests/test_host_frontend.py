@@ -75,6 +75,20 @@ def test_read_csv_modes(tmp_path):
     assert a.tred == ["HD"] and a.maxinsert == 100 and a.norepeatpairs and not a.fullsearch
 
 
+def test_fast_json_writer_is_byte_identical():
+    """tred.dumps_result against the reference's json.dumps(sort_keys=True, indent=4, separators=(',', ': '))
+    (tred.py:305-306): same bytes, for the golden runs and for awkward values."""
+    for s in WANT:
+        r = {"samplekey": s, "bam": "/data/" + s + ".bam", "tredCalls": WANT[s]}
+        assert tredmod.dumps_result(r) == json.dumps(r, sort_keys=True, indent=4, separators=(",", ": "))
+    odd = {"samplekey": 'a"q', "bam": "b", "tredCalls": {
+        "X.details": [], "X.P_h1": "", "X.P_h2": {}, "X.PP": 0.1 + 0.2, "X.1": -1, "X.lik": float("-inf"),
+        "X.d": [{"id": 'r,"1},\n                {', "h": 3, "seq": "AC", "tag": "FULL"}, {"id": "\u00e9", "h": 4, "seq": "", "tag": "PREF"}]}}
+    assert tredmod.dumps_result(odd) == json.dumps(odd, sort_keys=True, indent=4, separators=(",", ": "))
+    bare = {"samplekey": "k", "bam": "b", "tredCalls": {"inferredGender": "Unknown", "depthY": -1}}
+    assert tredmod.dumps_result(bare) == json.dumps(bare, sort_keys=True, indent=4, separators=(",", ": "))
+
+
 def test_tredreport_on_reference_results(tmp_path):
     """tests.py:15-19 of the reference: tredreport on work/t001.json work/t002.json."""
     from tredparse_amd import tredreport
@@ -97,6 +111,29 @@ def test_tredreport_on_reference_results(tmp_path):
     assert det[1].split("\t")[:5] == ["DM1", "AD", "t002", "Female", "5|66"]
     rep = open(tsv + ".report.txt").read()
     assert "{15:1,41:1}" in rep
+
+
+def test_tredreport_reads_vcf_and_accepts_cpus(tmp_path, monkeypatch):
+    """The reference's reporter also takes the per-sample VCFs (tredreport.py:144-169, through PyVCF) and a --cpus
+    flag: here the VCFs tred.to_vcf writes are parsed directly; the summary equals the JSON route's."""
+    from tredparse_amd import tredreport
+    repo = TREDsRepo()
+    monkeypatch.chdir(tmp_path)
+    files = []
+    for s in ("t001", "t002"):
+        tredmod.to_vcf({"samplekey": s, "bam": s + ".bam", "tredCalls": WANT[s]}, "hg38", repo, treds=repo.names)
+        files.append(str(tmp_path / (s + ".tred.vcf.gz")))
+    row = tredreport.read_vcf(files[0])
+    assert row["SampleKey"] == "t001" and (row["HD.1"], row["HD.2"]) == (15, 41) and row["HD.label"] == "risk"
+    assert row["HD.FR"] == WANT["t001"]["HD.FR"] and abs(row["HD.PP"] - WANT["t001"]["HD.PP"]) < 1e-3
+    total = tredreport.main(files + ["--tsv", str(tmp_path / "v.tsv"), "--cpus", "2", "--columns", "PP"])
+    assert total["risk"] == 2 and total["loci"] == 2
+    hdr, first = [l.split("\t") for l in open(tmp_path / "v.tsv").read().splitlines()[:2]]
+    assert hdr[0] == "SampleKey" and "inferredGender" not in hdr            # VCFs carry no sex
+    assert dict(zip(hdr, first))["HD.calls"] == "15|41"
+    # no files: the table written before is read back (it has calls, label and the PP asked for)
+    again = tredreport.main(["--tsv", str(tmp_path / "v.tsv")])
+    assert again["risk"] == 2
 
 
 def test_native_bam_layer_matches_python_layer():

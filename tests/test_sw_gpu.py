@@ -151,6 +151,20 @@ def test_aligner_mirror_matches_reference_goldens(ctx):
         assert got == tuple(int(x) for x in want[k]), k
         # the min_score / min_len filter of Aligner.align (ssw_wrap.py:214-220)
         assert al.align(reads[pr[k]], min_score=int(want[k][0]) + 1, min_len=0) is None
+    # without ctx=: all Aligners share one private context (not one GPU context each), the reference is registered
+    # once per change, and align_many batches the reads of one reference into one launch
+    by_ref = {}
+    for k in rng.choice(len(pr), 400, replace=False):
+        if len(refs[pt[k]]) <= 511:
+            by_ref.setdefault(int(pt[k]), []).append(int(k))
+    from tredparse_amd import ssw
+    for t, ks in list(by_ref.items())[:12]:
+        al = Aligner(ref_seq=refs[t], match=1, mismatch=5, gap_open=7, gap_extend=2)
+        got = al.align_many([reads[pr[k]] for k in ks])
+        for k, res in zip(ks, got):
+            assert (res.score, res.ref_begin, res.ref_end, res.query_begin, res.query_end) == tuple(int(x) for x in want[k])
+        assert al.align(reads[pr[ks[0]]]).score == int(want[ks[0]][0])
+    assert ssw._shared["ctx"] is not None and ssw._shared["ctx"] is not ctx
 
 
 def _checker():

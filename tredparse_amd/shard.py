@@ -52,6 +52,29 @@ def visible_gpus():
         return 0
 
 
+def usable_cpus():
+    """CPUs this process may really keep busy: the affinity mask, capped by the cgroup CPU quota when there is one
+    (a container may see 256 CPUs and be throttled to 16: running 256 busy threads there is slower than 16)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fp:
+                fields = fp.read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    n = min(n, max(1, int(float(fields[0]) / float(fields[1]) + 0.5)))
+            else:
+                quota = int(fields[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                        n = min(n, max(1, int(quota / float(fp.read().split()[0]) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def free_port():
     import socket
     s = socket.socket()
