@@ -231,26 +231,6 @@ __device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (
     sweep_at<R>(J, S, H, E, T, col, row0, geK, c0, row0g);
 }
 
-// Per read (valid in lane 15 of its DPP row): upper bound of the score template u can reach at its end column,
-// max(trunk best, column max + |suffix| * match), in one reduction.  lane_scale = (row0 + col) * geK of the
-// column held in H; gain = |suffix| * match * K.
-template <int R>
-__device__ __forceinline__ int reach_bound(const int (&H)[R], const Track& T, int lane_scale, int geK, int gain) {
-    // (row offsets as scalars, the lane's own scale taken off once: with a per-lane running scale the compiler keeps
-    //  "lane scale + r * ge*K" for all R rows in registers across the whole strand)
-    int cmx = NEG, rs = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) { cmx = max(cmx, H[r] - rs); rs += geK; }
-    cmx -= lane_scale;
-    constexpr int IMIN = -2147483647 - 1;
-    int v = max(max(cmx, 0) + gain, T.bestkey);
-    v = max(v, dpp_row_shr<0x111>(IMIN, v));
-    v = max(v, dpp_row_shr<0x112>(IMIN, v));
-    v = max(v, dpp_row_shr<0x114>(IMIN, v));
-    v = max(v, dpp_row_shr<0x118>(IMIN, v));
-    return v >> KSH;
-}
-
 // Letters are packed 8 per 32-bit word (4 bits each).  A strand's trunk (<= 64 words) and suffix words
 // are loaded once into one VGPR each, word k in lane k, and fetched per column with v_readlane (no
 // memory access in the column loop).
@@ -329,6 +309,15 @@ __device__ __forceinline__ void mirror_up(const int (&X)[R], int add, int* out, 
     const int m0 = row_mirror(X[R - 1]);
     const int nx = __builtin_amdgcn_update_dpp(NEGH, m0, 0x101, 0xF, 0xF, false);  // row_shl:1
     out[(R - 1) * stride] = max(nx + add, NEGH);
+}
+
+// max over the 16 lanes of a DPP row, delivered to every lane of the row: four rotate-and-max steps
+__device__ __forceinline__ int row_max_all(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false));   // row_ror:1
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false));   // row_ror:2
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xF, 0xF, false));   // row_ror:4
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));   // row_ror:8
+    return x;
 }
 
 template <int CTRL>
@@ -583,25 +572,13 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
         // ---- what happens when template u ends at column `col` of the trunk; true = leave this strand ----
         auto template_end = [&](int col) -> bool {
             // ---- template u ends here on the trunk ----
-            // Exact pruning: no cell of its suffix can score more than max(trunk best, column max + |suffix| *
-            // match).  If that cannot reach the score filter (bam_parser.py:134) or beat the read's current
-            // arg-max key (score, -units) for ANY of the four reads, the template is dropped.
-            bool need = true;
+            // (Round 1 first tested an upper bound -- trunk best, or column max + |suffix| * match -- and dropped the
+            //  template without looking at the continuation vectors when the bound could not matter.  The exact score
+            //  from the first combine pass below drops the same templates; testing the bound first cost more on the
+            //  templates that survive it than it saved on the others: 20.4 -> 20.0 ms without it.)
             const bool comb = blen > 0;
             const int Tlen = alen + period * u + blen;
-            if (!full_dump && blen > 0) {
-                const int bestS = best >> 12, bestU = 511 - ((best >> 3) & 511);
-                const int need_score = max(max(min(L, Tlen) >> 1, 30), u >= bestU ? bestS + 1 : bestS);
-                const int reach = reach_bound<R>(H, T, row0g + col * geK, geK, blen * mK);
-                need = __builtin_amdgcn_ballot_w64(valid && jl == 15 && min(kcap, reach) >= need_score) != 0;
-            }
             next_end += period;
-            if (!need) {
-                cnt_ends += 1u << 8;
-                ++u;
-                if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) return true;
-                return false;
-            }
             int bk = T.bestkey, bs = T.beststart;
             if (comb) {
                 // candidates entering the suffix: key = (H or E score field) + continuation (score | end cell)
@@ -647,10 +624,13 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 }
                 bk = c ? m : bk;
                 bs = c ? st : bs;
-                pair_step_lex<0x111>(bk, bs);
-                pair_step_lex<0x112>(bk, bs);
-                pair_step_lex<0x114>(bk, bs);
-                pair_step_lex<0x118>(bk, bs);
+                // largest (key, start) of the read's 16 lanes, in every lane: the key's row maximum first, then the
+                // largest start payload among the lanes that hold it (payloads are >= 0)
+                {
+                    const int bkm = row_max_all(bk);
+                    bs = row_max_all(bk == bkm ? bs : -1);
+                    bk = bkm;
+                }
                 if (with_sfx) {
                     const int sk = wb[(2 * R) * PS], ss = wb[(2 * R + 1) * PS];
                     const int k3 = sk - ((col + 1) << 9), s3 = ss + ((col + 1) << 9);
