@@ -74,6 +74,11 @@ int tredbam_pe_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int6
                        int32_t span, int32_t* global_lens, int64_t cap_global, int64_t* n_global,
                        int32_t* target_lens, int64_t cap_target, int64_t* n_target);
 
+/* The block decoder behind the reader (csrc/inflate_block.h), exposed for tests: inflate the raw-deflate stream
+ * in[0..n_in) whose output is exactly out_len bytes.  1 = decoded, 0 = declined (the reader would fall back to zlib),
+ * < 0 bad arguments. */
+int tredbam_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t out_len);
+
 /* Largest l_seq among the first `first_n` records in file order (first_n <= 0: all): READLEN of a sample
  * (BamReadLen, bam_parser.py:372-391, which looks at 101 records). */
 int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out);

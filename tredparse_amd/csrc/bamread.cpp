@@ -17,6 +17,7 @@
 #include <utility>
 #include <vector>
 
+#include "inflate_block.h"
 #include "tredbam.h"
 
 namespace {
@@ -47,6 +48,7 @@ struct tredbam {
     std::unordered_map<int64_t, Cached> cache;
     std::deque<int64_t> cache_order;
     static constexpr size_t CACHE_BLOCKS = 512;   // <= 32 MiB per open file
+    tredbam_inflate::Tables inflate_tables;        // decoding tables of the block decoder (inflate_block.h)
     // header
     std::vector<std::string> ref_names;
     std::vector<int64_t> ref_lens;
@@ -57,7 +59,9 @@ struct tredbam {
     std::vector<RefIndex> index;
     // output of the last fetch
     std::vector<uint8_t> out;
-    std::vector<uint8_t> rec;
+    std::vector<uint8_t> rec;            // a record that straddles blocks is assembled here
+    const uint8_t* recp = nullptr;       // the current record (into `block` or `rec`), rec_size bytes
+    size_t rec_size = 0;
     // pools of the last tredbam_scan (include/tredbam.h)
     std::vector<uint32_t> sc_packed;
     std::vector<int64_t> sc_word_off, sc_seq4_off, sc_name_off;
@@ -114,7 +118,14 @@ int load_block(tredbam* b, int64_t coffset) {
     if (fread(b->cbuf.data(), 1, (size_t)dlen, b->fp) != (size_t)dlen) return fail(b, -6, "truncated BGZF block");
     const uint32_t isize = le32(b->cbuf.data() + dlen - 4);
     b->block.resize(isize);
+    bool done = false;
     if (isize > 0) {
+        // own whole-block decoder first (about twice zlib's speed on BAM data); zlib decides whenever it declines
+        b->block.resize((size_t)isize + tredbam_inflate::SLACK);
+        done = tredbam_inflate::inflate_block(b->cbuf.data(), (size_t)(dlen - 8), b->block.data(), isize, b->inflate_tables);
+        b->block.resize(isize);
+    }
+    if (isize > 0 && !done) {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) return fail(b, -7, "inflateInit2 failed");
@@ -173,8 +184,19 @@ int64_t bg_read(tredbam* b, uint8_t* dst, int64_t n) {
     return done;
 }
 
-// next alignment record into b->rec (without its 4-byte block_size); 1 ok, 0 end of file, <0 error
+// next alignment record (without its 4-byte block_size) at b->recp, b->rec_size bytes: in place when it lies inside
+// the current block, assembled in b->rec when it straddles blocks; 1 ok, 0 end of file, <0 error
 int next_record(tredbam* b) {
+    if (b->upos + 4 <= b->block.size()) {
+        const int32_t size = (int32_t)le32(b->block.data() + b->upos);
+        if (size < 32) return fail(b, -8, "bad alignment record size %d", size);
+        if (b->upos + 4 + (size_t)size <= b->block.size()) {
+            b->recp = b->block.data() + b->upos + 4;
+            b->rec_size = (size_t)size;
+            b->upos += 4 + (size_t)size;
+            return 1;
+        }
+    }
     uint8_t head[4];
     const int64_t g = bg_read(b, head, 4);
     if (g < 0) return (int)g;
@@ -185,6 +207,8 @@ int next_record(tredbam* b) {
     const int64_t g2 = bg_read(b, b->rec.data(), size);
     if (g2 < 0) return (int)g2;
     if (g2 < size) return 0;
+    b->recp = b->rec.data();
+    b->rec_size = (size_t)size;
     return 1;
 }
 
@@ -192,8 +216,8 @@ const bool CIGAR_REF[16] = {true, false, true, true, false, false, false, true, 
 
 // append b->rec to b->out in the tredbam_rec layout; returns reference_end (-1: none) through *endp
 int emit_record(tredbam* b, int32_t* endp, bool store) {
-    const uint8_t* r = b->rec.data();
-    const size_t size = b->rec.size();
+    const uint8_t* r = b->recp;
+    const size_t size = b->rec_size;
     tredbam_rec h;
     h.tid = (int32_t)le32(r);
     h.pos = (int32_t)le32(r + 4);
@@ -324,8 +348,8 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
             rc = next_record(b);
             if (rc < 0) return rc;
             if (rc == 0) break;
-            const int32_t rtid = (int32_t)le32(b->rec.data());
-            const int32_t rpos = (int32_t)le32(b->rec.data() + 4);
+            const int32_t rtid = (int32_t)le32(b->recp);
+            const int32_t rpos = (int32_t)le32(b->recp + 4);
             if (rtid != tid || rpos >= end) {
                 if (rtid > tid || (rtid == tid && rpos >= end)) break;
                 continue;
@@ -336,7 +360,7 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
             if ((rc = emit_record(b, &rend, store)) < 0) return rc;
             int64_t e = rend;
             if (rend < 0 || rend <= rpos) e = (int64_t)rpos + 1;   // placed-unmapped / zero length: one base (bam_endpos)
-            if (e > start && visit(rend, rpos, le16(b->rec.data() + 14), b->rec.data())) ++n;
+            if (e > start && visit(rend, rpos, le16(b->recp + 14), b->recp)) ++n;
             else b->out.resize(mark);
         }
     }
@@ -348,20 +372,48 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
 int pair_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t tstart, int64_t tend, int32_t span,
                  std::vector<int32_t>& global_lens, std::vector<int32_t>& target_lens) {
     struct Mate { int32_t pos, end, lead_clip, trail_clip; bool reverse; };
-    struct Pair { int n; Mate m[2]; };
-    std::unordered_map<std::string, size_t> slot;
-    std::vector<Pair> pairs;   // in order of first appearance (the reference walks a dict in that order)
+    struct Pair { int n; uint32_t name_at, name_len; Mate m[2]; };
+    // query name -> pair, in order of first appearance (the reference walks a dict in that order): an open-addressing
+    // table over a 64-bit FNV-1a hash of the name, names kept in one pool for the equality check (a +-10 kb window
+    // holds ~4 000 records; a std::string and a node allocation per record were a third of the scan's parse time)
+    std::vector<Pair> pairs;
+    std::vector<char> pool;
+    std::vector<int32_t> table(1 << 13, -1);
+    size_t mask = table.size() - 1;
+    auto find_or_add = [&](const char* name, uint32_t len) -> Pair& {
+        uint64_t h = 1469598103934665603ull;
+        for (uint32_t i = 0; i < len; ++i) h = (h ^ (uint8_t)name[i]) * 1099511628211ull;
+        if ((pairs.size() + 1) * 2 > table.size()) {          // keep the load below one half
+            table.assign(table.size() * 2, -1);
+            mask = table.size() - 1;
+            for (size_t k = 0; k < pairs.size(); ++k) {
+                uint64_t g = 1469598103934665603ull;
+                for (uint32_t i = 0; i < pairs[k].name_len; ++i) g = (g ^ (uint8_t)pool[pairs[k].name_at + i]) * 1099511628211ull;
+                size_t at = (size_t)(g ^ (g >> 29)) & mask;
+                while (table[at] >= 0) at = (at + 1) & mask;
+                table[at] = (int32_t)k;
+            }
+        }
+        size_t at = (size_t)(h ^ (h >> 29)) & mask;
+        for (;; at = (at + 1) & mask) {
+            const int32_t k = table[at];
+            if (k < 0) break;
+            const Pair& q = pairs[(size_t)k];
+            if (q.name_len == len && memcmp(pool.data() + q.name_at, name, len) == 0) return pairs[(size_t)k];
+        }
+        table[at] = (int32_t)pairs.size();
+        Pair p{};
+        p.name_at = (uint32_t)pool.size();
+        p.name_len = len;
+        pool.insert(pool.end(), name, name + len);
+        pairs.push_back(p);
+        return pairs.back();
+    };
     const int64_t n = walk_region(b, tid, start, end, false, [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
         if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) return true;   // paired, mapped, not a duplicate
         const int l_name = r[8];
         const int n_cigar = le16(r + 12);
-        std::string name((const char*)r + 32, (size_t)std::max(l_name - 1, 0));
-        auto it = slot.find(name);
-        if (it == slot.end()) {
-            it = slot.emplace(std::move(name), pairs.size()).first;
-            pairs.push_back(Pair{0, {}});
-        }
-        Pair& p = pairs[it->second];
+        Pair& p = find_or_add((const char*)r + 32, (uint32_t)std::max(l_name - 1, 0));
         if (p.n < 2) {
             Mate& m = p.m[p.n];
             m.pos = rpos;
@@ -570,6 +622,15 @@ int tredbam_pe_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int6
     return 0;
 }
 
+int tredbam_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t out_len) {
+    if (!in || !out || n_in < 0 || out_len < 0) return -2;
+    static thread_local tredbam_inflate::Tables tables;
+    std::vector<uint8_t> buf((size_t)out_len + tredbam_inflate::SLACK);
+    if (!tredbam_inflate::inflate_block(in, (size_t)n_in, buf.data(), (size_t)out_len, tables)) return 0;
+    memcpy(out, buf.data(), (size_t)out_len);
+    return 1;
+}
+
 int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out) {
     if (!b || !out) return -2;
     int rc = bg_seek(b, b->first_record);
@@ -579,7 +640,7 @@ int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out) {
         rc = next_record(b);
         if (rc < 0) return rc;
         if (rc == 0) break;
-        best = std::max(best, (int32_t)le32(b->rec.data() + 16));
+        best = std::max(best, (int32_t)le32(b->recp + 16));
     }
     if (best < 0) return fail(b, -8, "no alignment records in %s", b->path.c_str());
     *out = best;
