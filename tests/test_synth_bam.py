@@ -131,3 +131,30 @@ def test_bam_path_equals_packed_path(tmp_path):
     assert short_ok >= 0.6 * 3 * len(loci)         # the caller is right on ~80 % of such units (bench.py's check says the same)
     json.dumps(results)          # everything in the results is JSON-serialisable
     engine.close()
+
+
+@pytest.mark.gpu
+def test_cli_two_rank_processes_equal_one(tmp_path):
+    """`tred.py --gpus 2` as real processes (both ranks on whatever devices are visible; one GPU is enough): every
+    sample's JSON equals the one a single-process run writes, each file exactly once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    loci = [l for l in synth.load_loci() if l["name"] in NAMES]
+    made = sb.make_bams(str(tmp_path / "bams"), 5, seed=900, loci=loci)
+    (tmp_path / "list.txt").write_text("\n".join(p for _, p, _ in made) + "\n")
+    base = [sys.executable, "-m", "tredparse_amd.tred", str(tmp_path / "list.txt"), "--cpus", "2", "--log", "INFO"]
+    base += [x for n in NAMES for x in ("--tred", n)]
+    env = dict(os.environ, PYTHONPATH=root)
+    for name, extra in (("one", []), ("two", ["--gpus", "2"])):
+        out = subprocess.run(base + ["--workdir", str(tmp_path / name)] + extra, cwd=str(tmp_path), env=env,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.count('"samplekey"') == 5          # every sample's JSON echoed once
+    files = sorted(os.listdir(tmp_path / "one"))
+    assert files == sorted(os.listdir(tmp_path / "two")) and len(files) == 10
+    for f in files:
+        if f.endswith(".json"):
+            a, b = (json.load(open(tmp_path / d / f)) for d in ("one", "two"))
+            assert a == b, f
+            assert set(n + ".1" for n in NAMES) <= set(a["tredCalls"])
