@@ -208,23 +208,20 @@ def tally(scan, k, tags, hs, repeatpairs=True):
     removed before counting."""
     a, b = scan.reads_of(k)
     tags, hs = np.asarray(tags), np.asarray(hs)
-    flank = Counter()
-    counts = {"FULL": Counter(), "PREF": flank, "POST": flank, "REPT": Counter(), "HANG": Counter()}
     hit = np.nonzero(tags != _lib.TAG_NONE)[0]
-    for h in hs[hit].tolist():
-        counts["HANG"][h] += 1
     keep = hit[tags[hit] != _lib.TAG_HANG]
     if not repeatpairs and len(keep):
         ids = scan.name_id[a:b][keep]
         rept_ids = ids[tags[keep] == _lib.TAG_REPT]
         twice = np.nonzero(np.bincount(rept_ids, minlength=int(ids.max()) + 1) > 1)[0]
         keep = keep[~np.isin(ids, twice)]
-    details = []
-    for i in keep.tolist():
-        label = _lib.TAG_NAMES[int(tags[i])]
-        h = int(hs[i])
-        counts[label][h] += 1
-        details.append({"tag": label, "h": h, "id": scan.name(a + i), "seq": scan.sequence(a + i)})
+    kt, kh = tags[keep], hs[keep]
+    flank = Counter(kh[(kt == _lib.TAG_PREF) | (kt == _lib.TAG_POST)].tolist())
+    counts = {"FULL": Counter(kh[kt == _lib.TAG_FULL].tolist()), "PREF": flank, "POST": flank,
+              "REPT": Counter(kh[kt == _lib.TAG_REPT].tolist()), "HANG": Counter(hs[hit].tolist())}
+    names, labels = _lib.TAG_NAMES, kt.tolist()
+    details = [{"tag": names[t], "h": h, "id": scan.name(a + i), "seq": scan.sequence(a + i)}
+               for t, h, i in zip(labels, kh.tolist(), keep.tolist())]
     return counts, details, sum(counts["REPT"].values())
 
 
