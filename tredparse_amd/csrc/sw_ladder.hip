@@ -89,9 +89,9 @@ struct Rows {
 };
 
 struct Track {
-    int bestkey;    // score<<18 | (511-col)<<9 | (511-row), true (unscaled) score
+    int bestkey;    // score<<18 | (511-col)<<9 | (511-row), true (unscaled) score; < 0: see resolve_best
     int beststart;  // packed value of that cell (start col/row in the low 18 bits)
-    int ceil;       // bestkey | PAYMASK: what a cell must exceed to be a new best
+    int ceil;       // best score << 18 | PAYMASK: what a cell must exceed to be a new best
 };
 
 // inclusive max scan over the 16 lanes of a DPP row fused with the exclusive shift, as one asm block:
@@ -105,6 +105,15 @@ __device__ __forceinline__ int row_excl_scan_max(int x) {
     x = max(x, dpp_row_shr<0x114>(IMIN, x));
     x = max(x, dpp_row_shr<0x118>(IMIN, x));
     return dpp_row_shr<0x111>(NEG, x);
+}
+
+// max over the 16 lanes of a DPP row, delivered to every lane of the row: four rotate-and-max steps
+__device__ __forceinline__ int row_max_all(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false));   // row_ror:1
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false));   // row_ror:2
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xF, 0xF, false));   // row_ror:4
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));   // row_ror:8
+    return x;
 }
 
 // One DP column for all rows of the four alignments in this wave; LET = template letter (4 = N).
@@ -130,7 +139,7 @@ __device__ __forceinline__ void column_start(const Rows<R>& J, int (&H)[R], int 
 template <int R>
 __device__ __forceinline__ void sweep_column(const Rows<R>& J, const int (&SL)[R], int (&H)[R], int (&E)[R], Track& T,
                                              int col, int row0, int s_z, int s_scale, int geK,
-                                             int c0, int row0g) {
+                                             int c0, int row0g, int* rowbuf) {
     // last row of the lane above, previous column; above the first row lies Z(-1, col-1) = (col << 9) + (col-2)*geK
     const int hup = __builtin_amdgcn_update_dpp((col << 9) + s_scale - 2 * geK, H[R - 1], 0x111, 0xF, 0xF, false);
     int ht[R], pl[R];
@@ -159,8 +168,12 @@ __device__ __forceinline__ void sweep_column(const Rows<R>& J, const int (&SL)[R
     // running best: only columns in which some lane could beat its best take the exact path.
     // run + c0 = max over this lane's rows of H~ without the vertical-gap term (a best cell never ends
     // in a gap); minus (row0 + col)*geK it over-estimates every row's true value by <= (R-1)*geK.
+    // Two segments: rows below MID over-estimate by < MID*ge, the others by <= (R-1-MID)*ge (pl[MID] is the maximum of
+    // the rows above MID).  With one segment the slack was (R-1)*ge = 18 at the default scoring -- more than the 11 a
+    // one-period gap costs, so on a periodic trunk nearly every lane was "within reach" in nearly every column.
+    constexpr int MID = R / 2;
     const int lane_scale = row0g + s_scale;
-    const bool trig = run + c0 - lane_scale > T.ceil;
+    const bool trig = max(pl[MID], run - MID * geK) + c0 - lane_scale > T.ceil;
     if (__builtin_amdgcn_ballot_w64(trig) != 0) {
         // exact: does some row of this lane score more than the lane's best?  (a later column never wins a tie)
         int tr[R];
@@ -172,22 +185,37 @@ __device__ __forceinline__ void sweep_column(const Rows<R>& J, const int (&SL)[R
             rs += geK;
             m0 = max(m0, tr[r]);
         }
-        const bool imp = m0 - lane_scale > T.ceil;
-        if (__builtin_amdgcn_ballot_w64(imp) != 0) {
-            // the row: maximum of score<<18 | (R-1-r) (smallest row among equal scores), then its packed value
-            int m = NEG;
+        const int top = m0 - lane_scale;
+        if (top > T.ceil) {
+            // A new best cell somewhere in this lane's rows.  Which row, and that row's start payload, are only needed
+            // when a template end is really combined (one column in nine), and by then a later column has usually
+            // replaced this one: park the rows in LDS (stores cost no VALU issue slot, the kernel's bound) and leave a
+            // note -- bestkey = -1 - column, beststart = the lane's best packed value (its score is what counts).
 #pragma unroll
-            for (int r = 0; r < R; ++r) m = max(m, (tr[r] & ~PAYMASK) | (R - 1 - r));
-            int st = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) st = ((tr[r] & ~PAYMASK) | (R - 1 - r)) == m ? tr[r] : st;
-            // -> score<<18 | (511-col)<<9 | (511-row)
-            const int cand = m - lane_scale + (((511 - col) << 9) + (511 - (R - 1)) - row0);
-            T.bestkey = imp ? cand : T.bestkey;
-            T.beststart = imp ? st - lane_scale : T.beststart;
-            T.ceil = T.bestkey | PAYMASK;
+            for (int r = 0; r < R; ++r) rowbuf[r * 64] = tr[r];
+            T.bestkey = -1 - col;
+            T.beststart = top;
+            T.ceil = top | PAYMASK;
         }
     }
+}
+
+// Turns the note left by sweep_column into the lane's best cell: the row is the maximum of score<<18 | (R-1-r) over
+// the parked rows (smallest row among equal scores), the start payload that row's packed value.  Wave-uniform call.
+template <int R>
+__device__ __forceinline__ void resolve_best(Track& T, int row0, int row0g, int geK, const int* rowbuf) {
+    const bool pend = T.bestkey < 0;
+    if (__builtin_amdgcn_ballot_w64(pend) == 0) return;
+    const int pcol = -1 - T.bestkey;     // (lanes without a note compute on stale rows and keep what they have)
+    int m = NEG;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m = max(m, (rowbuf[r * 64] & ~PAYMASK) | (R - 1 - r));
+    const int st = rowbuf[(R - 1 - (m & 15)) * 64];
+    const int lane_scale = row0g + pcol * geK;
+    // -> score<<18 | (511-col)<<9 | (511-row)
+    const int cand = m - lane_scale + (((511 - pcol) << 9) + (511 - (R - 1)) - row0);
+    T.bestkey = pend ? cand : T.bestkey;
+    T.beststart = pend ? st - lane_scale : T.beststart;
 }
 
 // The profile row values of one template letter (wave-uniform): R register moves behind a scalar switch.
@@ -214,9 +242,9 @@ __device__ __forceinline__ void pick_profile(const Rows<R>& J, int letter, int g
 
 template <int R>
 __device__ __forceinline__ void sweep_at(const Rows<R>& J, const int (&S)[R], int (&H)[R], int (&E)[R], Track& T,
-                                         int col, int row0, int geK, int c0, int row0g) {
+                                         int col, int row0, int geK, int c0, int row0g, int* rowbuf) {
     const int s_scale = col * geK;
-    sweep_column<R>(J, S, H, E, T, col, row0, z_col(col, geK), s_scale, geK, c0, row0g);
+    sweep_column<R>(J, S, H, E, T, col, row0, z_col(col, geK), s_scale, geK, c0, row0g, rowbuf);
 }
 
 // One column whose letter is only known at run time (prefix columns, ladders of other periods, the dump variant's
@@ -225,10 +253,10 @@ __device__ __forceinline__ void sweep_at(const Rows<R>& J, const int (&S)[R], in
 // allocations with 23 moves at the head of every column).
 template <int R>
 __device__ __forceinline__ void sweep_letter(int letter, const Rows<R>& J, int (&H)[R], int (&E)[R], Track& T,
-                                             int col, int row0, int geK, int c0, int row0g) {
+                                             int col, int row0, int geK, int c0, int row0g, int* rowbuf) {
     int S[R];
     pick_profile<R>(J, letter, geK, S);
-    sweep_at<R>(J, S, H, E, T, col, row0, geK, c0, row0g);
+    sweep_at<R>(J, S, H, E, T, col, row0, geK, c0, row0g, rowbuf);
 }
 
 // Letters are packed 8 per 32-bit word (4 bits each).  A strand's trunk (<= 64 words) and suffix words
@@ -311,15 +339,6 @@ __device__ __forceinline__ void mirror_up(const int (&X)[R], int add, int* out, 
     out[(R - 1) * stride] = max(nx + add, NEGH);
 }
 
-// max over the 16 lanes of a DPP row, delivered to every lane of the row: four rotate-and-max steps
-__device__ __forceinline__ int row_max_all(int x) {
-    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false));   // row_ror:1
-    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false));   // row_ror:2
-    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xF, 0xF, false));   // row_ror:4
-    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));   // row_ror:8
-    return x;
-}
-
 template <int CTRL>
 __device__ __forceinline__ void pair_step_lex(int& k, int& s) {
     const int tk = dpp_row_shr<CTRL>(k, k);
@@ -384,7 +403,8 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     // quad is only refilled when a whole new workgroup fits.
     // continuation vectors of the strand being swept: [WH rows | WE rows | suffix-only best: key, start][64 lanes]
     constexpr int PS = 64;
-    __shared__ int wbuf[(2 * R + 2) * PS];
+    // + R rows per lane: where the exact path of sweep_column picks the start payload of a new best cell
+    __shared__ int wbuf[(3 * R + 2) * PS];
     const int lane = threadIdx.x;
     const int64_t q = (int64_t)blockIdx.x;
     const int nq = *a.n_quads;
@@ -421,6 +441,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     const int flank = a.p.flank;
     const bool full_dump = GENERIC && a.out_dump != nullptr;  // wave-uniform
     int* const wb = wbuf + lane;
+    int* const rowbuf = wb + (2 * R + 2) * PS;
 
     // REPT cut-off: per-read ceil(L/period) with --useclippedreads, else the ladder's (bam_parser.py:154-155)
     const int mu_rept = a.p.clip ? (L + period - 1) / period : max_units;
@@ -554,7 +575,8 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             const int bw = ln < ((blen + 7) >> 3) ? (int)a.seqw[branch_w + ln] : 0;
             column_start<R>(J, H, E, geK);
             T.bestkey = floor_key; T.beststart = 0; T.ceil = floor_key;
-            for (int j = 0; j < blen; ++j) sweep_letter<R>(letter_from(bw, j), J, H, E, T, j, row0, geK, c0, row0g);
+            for (int j = 0; j < blen; ++j) sweep_letter<R>(letter_from(bw, j), J, H, E, T, j, row0, geK, c0, row0g, rowbuf);
+            resolve_best<R>(T, row0, row0g, geK, rowbuf);
             int sk = T.bestkey, ss = T.beststart;
             pair_step<0x111>(sk, ss);
             pair_step<0x112>(sk, ss);
@@ -579,7 +601,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             const bool comb = blen > 0;
             const int Tlen = alen + period * u + blen;
             next_end += period;
-            int bk = T.bestkey, bs = T.beststart;
+            int bk, bs;
             if (comb) {
                 // candidates entering the suffix: key = (H or E score field) + continuation (score | end cell)
                 int m = NEG;
@@ -591,11 +613,10 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 // scaled sum -> true score; reversed start cell -> 511 - end column | 511 - end row
                 const int cu = ((511 - col - blen) << 9) + (512 - 16 * R) - (col + 16 * R + blen - 3) * geK;
                 m += cu;
-                const bool c = m > bk;     // an equal key is impossible: trunk cells end at columns <= col
                 if (!full_dump) {
-                    // the template's exact score is known now: drop it unless it can pass the score filter and
-                    // beat the arg-max of some read (the bound above only had column max + |suffix| * match)
-                    int ks = max(m, bk);
+                    // the template's exact score is known now (T.ceil carries the trunk's best score): drop it unless
+                    // it can pass the score filter and beat the arg-max of some read
+                    int ks = max(m, T.ceil);
                     ks = max(ks, dpp_row_shr<0x111>(ks, ks));
                     ks = max(ks, dpp_row_shr<0x112>(ks, ks));
                     ks = max(ks, dpp_row_shr<0x114>(ks, ks));
@@ -610,6 +631,9 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                         return false;
                     }
                 }
+                resolve_best<R>(T, row0, row0g, geK, rowbuf);
+                bk = T.bestkey, bs = T.beststart;
+                const bool c = m > bk;     // an equal key is impossible: trunk cells end at columns <= col
                 ++cnt_ends;
                 int st = 0;
                 if (__builtin_amdgcn_ballot_w64(c) != 0) {
@@ -640,6 +664,8 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 }
             } else {
                 cnt_ends += 1u << 16;
+                resolve_best<R>(T, row0, row0g, geK, rowbuf);
+                bk = T.bestkey, bs = T.beststart;
                 pair_step<0x111>(bk, bs);
                 pair_step<0x112>(bk, bs);
                 pair_step<0x114>(bk, bs);
@@ -688,7 +714,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             // ends fall on the loop's own boundary.
             int col = 0;
             for (; col < alen; ++col) {
-                sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g);
+                sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g, rowbuf);
                 ++cnt_cols;
             }
             int P0[R], P1[R], P2[R];
@@ -696,16 +722,16 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             pick_profile<R>(J, letter_from(tw, alen + 1), geK, P1);
             pick_profile<R>(J, letter_from(tw, alen + 2), geK, P2);
             for (;;) {
-                sweep_at<R>(J, P0, H, E, T, col, row0, geK, c0, row0g);
-                sweep_at<R>(J, P1, H, E, T, col + 1, row0, geK, c0, row0g);
-                sweep_at<R>(J, P2, H, E, T, col + 2, row0, geK, c0, row0g);
+                sweep_at<R>(J, P0, H, E, T, col, row0, geK, c0, row0g, rowbuf);
+                sweep_at<R>(J, P1, H, E, T, col + 1, row0, geK, c0, row0g, rowbuf);
+                sweep_at<R>(J, P2, H, E, T, col + 2, row0, geK, c0, row0g, rowbuf);
                 col += 3;
                 cnt_cols += 3;
                 if (template_end(col - 1) || col >= ncols) break;
             }
         } else {
             for (int col = 0; col < ncols; ++col) {
-                sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g);
+                sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g, rowbuf);
                 ++cnt_cols;
                 if (col != next_end) continue;
                 if (template_end(col)) break;
