@@ -222,9 +222,10 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
     }
     for (int i = SPAN + tid; i < KERN2_RAW; i += NT) kern2[kswz(i)] = 0;
     // the bins once more, swizzled (i + i/8: the lanes below read with a stride of XPER ints), in the memory of `pdf`
-    // (written only after the loop, behind a barrier)
+    // (written only after the loop, behind a barrier); entry 0 and entry SPAN + 1 are zero guards, bin v sits at v + 1:
+    // a lane's out-of-range bins clamp onto a guard, so the load in the loop needs no branch
     int* const khist = reinterpret_cast<int*>(pdf);
-    for (int i = tid; i < SPAN; i += NT) khist[kswz(i)] = hist[i];
+    for (int i = tid; i < SPAN + 2; i += NT) khist[kswz(i)] = (i >= 1 && i <= SPAN) ? hist[i - 1] : 0;
     __syncthreads();
     // A Gaussian term below 1e-17 of the kernel's peak cannot change a sum of at most 65 535 terms of that scale in
     // its 16th digit: only bins within W = 9 sigma of x are added up (exp(-81/2) = 2.6e-18).  Every thread owns XPER
@@ -232,6 +233,8 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
     // kernel values K(qx - d) are the same for all lanes and slide by one entry per step (rotating window of XPER
     // registers, one broadcast load per step).  With sigma ~ 17 bp (2 000 pairs, sd 80) that is 312 steps instead
     // of the ~850 of the occupied range of pair lengths (grid_prepare_kernel: 2.62 -> 2.38 ms per 30 000 units).
+    // The products are accumulated with explicit fused multiply-adds (the file is compiled with -ffp-contract=off,
+    // which had left a multiply and an add per term: twice the fp64 issue slots of the loop).
     const int W = (int)fmin((double)SPAN, ceil(9.0 * sigma));
     const int x0 = tid * XPER;
     double acc[XPER], win[XPER];
@@ -243,14 +246,20 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
     // step st of a group handles d = db + st with the window rotated by st: K(qx - d) sits in win[(qx - st) & 7];
     // afterwards the slot of qx = 7 is refilled with K(0 - (d + 1))
     for (int db = -W; db <= W + XPER - 1; db += XPER) {
+        int cnt[XPER];
+        double nxt[XPER];
 #pragma unroll
         for (int st = 0; st < XPER; ++st) {
-            const int d = db + st;
-            const int v = x0 + d;
-            const double wk = ((unsigned)v < (unsigned)SPAN ? khist[kswz(v < 0 ? 0 : (v < SPAN ? v : 0))] : 0) * w;
+            const int v = x0 + db + st;
+            cnt[st] = khist[kswz(min(max(v, -1), SPAN) + 1)];
+            nxt[st] = kern2[kswz(abs(db + st + 1))];
+        }
 #pragma unroll
-            for (int qx = 0; qx < XPER; ++qx) acc[qx] += wk * win[(qx - st) & 7];
-            win[(7 - st) & 7] = kern2[kswz(abs(d + 1))];
+        for (int st = 0; st < XPER; ++st) {
+            const double wk = cnt[st] * w;
+#pragma unroll
+            for (int qx = 0; qx < XPER; ++qx) acc[qx] = __builtin_fma(wk, win[(qx - st) & 7], acc[qx]);
+            win[(7 - st) & 7] = nxt[st];
         }
     }
     __syncthreads();     // khist lives in pdf's memory

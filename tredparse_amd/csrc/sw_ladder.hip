@@ -404,7 +404,8 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     // continuation vectors of the strand being swept: [WH rows | WE rows | suffix-only best: key, start][64 lanes]
     constexpr int PS = 64;
     // + R rows per lane: where the exact path of sweep_column picks the start payload of a new best cell
-    __shared__ int wbuf[(3 * R + 2) * PS];
+    // + one 64-bit slot per lane: the (key, start) maximum of a template end
+    __shared__ __attribute__((aligned(8))) int wbuf[(3 * R + 2) * PS + 2 * PS];
     const int lane = threadIdx.x;
     const int64_t q = (int64_t)blockIdx.x;
     const int nq = *a.n_quads;
@@ -603,13 +604,22 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             next_end += period;
             int bk, bs;
             if (comb) {
-                // candidates entering the suffix: key = (H or E score field) + continuation (score | end cell)
-                int m = NEG;
+                // candidates entering the suffix: key = (H or E score field) + continuation (score | end cell), and
+                // behind it the start payload the candidate carries.  The lane's largest (key, payload) pair is taken
+                // by 64-bit max atomics on a slot of the lane's own in LDS: the 2R compare-and-keep steps cost no VALU
+                // issue slot (a second pass over the rows to find the winner's payload cost as much as the first).
+                long long* const slot = reinterpret_cast<long long*>(wbuf + (3 * R + 2) * PS) + lane_now();
+                *slot = (long long)NEG * (1LL << 32);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int ef = max(E[r], H[r] - c0);   // the gap may also open from a cell reached by a vertical gap
-                    m = max3(m, (H[r] & ~PAYMASK) + wb[r * PS], (ef & ~PAYMASK) + wb[(R + r) * PS]);
+                    const int sh = (H[r] & ~PAYMASK) + wb[r * PS], se = (ef & ~PAYMASK) + wb[(R + r) * PS];
+                    atomicMax(slot, (long long)(((unsigned long long)(uint32_t)sh << 32) | (uint32_t)(H[r] & PAYMASK)));
+                    atomicMax(slot, (long long)(((unsigned long long)(uint32_t)se << 32) | (uint32_t)(ef & PAYMASK)));
                 }
+                const long long won = *slot;
+                int m = (int)(won >> 32);
+                const int st = (int)(won & PAYMASK);
                 // scaled sum -> true score; reversed start cell -> 511 - end column | 511 - end row
                 const int cu = ((511 - col - blen) << 9) + (512 - 16 * R) - (col + 16 * R + blen - 3) * geK;
                 m += cu;
@@ -635,17 +645,6 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 bk = T.bestkey, bs = T.beststart;
                 const bool c = m > bk;     // an equal key is impossible: trunk cells end at columns <= col
                 ++cnt_ends;
-                int st = 0;
-                if (__builtin_amdgcn_ballot_w64(c) != 0) {
-                    // start payload of the winner (largest among equal keys); the sums are recomputed, not kept
-                    const int mm = m - cu;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int ef = max(E[r], H[r] - c0);
-                        st = max(st, (H[r] & ~PAYMASK) + wb[r * PS] == mm ? (H[r] & PAYMASK) : 0);
-                        st = max(st, (ef & ~PAYMASK) + wb[(R + r) * PS] == mm ? (ef & PAYMASK) : 0);
-                    }
-                }
                 bk = c ? m : bk;
                 bs = c ? st : bs;
                 // largest (key, start) of the read's 16 lanes, in every lane: the key's row maximum first, then the
