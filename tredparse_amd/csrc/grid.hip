@@ -546,18 +546,19 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         }
 
         // ---- grid axes (models.py:239-257) ----
-        if (tid == 0) {
-            int nb = 0, i = 0;
-            bool mp_done = nP == 0;
-            while (i < nF || !mp_done) {  // sorted(set(FULL keys) | {max_partial})
-                int v;
-                if (i < nF && (mp_done || S.obs.fullK[i] <= max_partial)) {
-                    v = S.obs.fullK[i++];
-                    if (!mp_done && v == max_partial) mp_done = true;
-                } else { v = max_partial; mp_done = true; }
-                S.obs.base[nb++] = v;
+        {   // sorted(set(FULL keys) | {max_partial}): the ascending, distinct FULL sizes with max_partial slipped in
+            // (when there are PREF/POST reads and no FULL size equals it) -- every entry moves at most one place
+            int below = 0, same = 0;
+            for (int i = 0; i < nF; ++i) { const int v = S.obs.fullK[i]; below += v < max_partial; same += v == max_partial; }
+            const bool insert = nP != 0 && same == 0;
+            for (int i = tid; i < nF; i += NT) {
+                const int v = S.obs.fullK[i];
+                S.obs.base[i + (insert && v > max_partial ? 1 : 0)] = v;
             }
-            S.obs.nb = nb;
+            if (tid == 0) {
+                if (insert) S.obs.base[below] = max_partial;
+                S.obs.nb = nF + (insert ? 1 : 0);
+            }
         }
         __syncthreads();
         const int nb = __builtin_amdgcn_readfirstlane(S.obs.nb);
@@ -678,10 +679,20 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             slot[L.far2 + i] = f2;
         }
         __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int i = 0; i < nrow; ++i) { const int c = S.row_off[i]; S.row_off[i] = acc; acc += c; }
-            S.row_off[nrow] = acc;
+        if (tid < 64) {   // exclusive scan of the row counts: wavefront 0, 64 rows per step
+            int carry = 0;
+            for (int b0 = 0; b0 < nrow; b0 += 64) {
+                const int i = b0 + tid;
+                const int c = i < nrow ? S.row_off[i] : 0;
+                int incl = c;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (tid >= o) incl += up;
+                }
+                if (i < nrow) S.row_off[i] = carry + incl - c;
+                carry += __shfl(incl, 63, 64);
+            }
+            if (tid == 0) S.row_off[nrow] = carry;
         }
         __syncthreads();
         d.n_pairs = __builtin_amdgcn_readfirstlane(S.row_off[nrow]);
@@ -723,23 +734,30 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         }
         // ---- the paired-end tables: .5 * roll(h)[x_t] per row and (two alleles) per column
         if (run_pe) {
+            // (no index arithmetic by division: rows as 32 targets x 4 rows per sweep of the workgroup -- roll1 rows are
+            //  padded to a multiple of 32 targets, the padding holds .5: .5 + .5 = a factor of 1 --, columns one per
+            //  thread with the targets in the inner loop, which is also what makes the transposed roll2 rows coalesced)
             const int nt = u.n_target, ntp = (nt + 31) & ~31;
-            const int ncol_t = haploid ? 0 : ncol;
-            for (int k = tid; k < (nrow + ncol_t) * nt; k += NT) {
-                const bool isrow = k < nrow * nt;
-                const int kk = isrow ? k : k - nrow * nt;
-                const int ai = kk / nt, t = kk - ai * nt;
-                const int h = isrow ? axis_value(ax1, S.obs.base, period, ai) : axis_value(ax2, S.obs.base, period, ai);
-                int x = C.tl[t];
+            static_assert(NT % 32 == 0, "row sweep below");
+            for (int tb = 0; tb < ntp; tb += 32) {
+                const int t = tb + (tid & 31);
+                int x = t < nt ? C.tl[t] : 0;
                 if (x < 0) x += SPAN;
-                // the tables hold .5 * roll(h)[x]: the pair's factor is the plain sum of two entries (models.py:469)
-                const double rv = .5 * roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);
-                if (isrow) slot[L.roll1 + (size_t)ai * ntp + t] = rv;
-                else slot[L.roll2 + (size_t)t * ncol + ai] = rv;   // transposed: coalesced across columns
+                for (int ai = tid >> 5; ai < nrow; ai += NT / 32) {
+                    const int h = axis_value(ax1, S.obs.base, period, ai);
+                    // the tables hold .5 * roll(h)[x]: the pair's factor is the plain sum of two entries (models.py:469)
+                    slot[L.roll1 + (size_t)ai * ntp + t] = t < nt ? .5 * roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small) : .5;
+                }
             }
-            for (int k = tid; k < nrow * (ntp - nt); k += NT) {     // padding: .5 + .5 = a factor of 1
-                const int ai = k / (ntp - nt), t = nt + k - ai * (ntp - nt);
-                slot[L.roll1 + (size_t)ai * ntp + t] = .5;
+            if (!haploid) {
+                for (int ai = tid; ai < ncol; ai += NT) {
+                    const int h = axis_value(ax2, S.obs.base, period, ai);
+                    for (int t = 0; t < nt; ++t) {
+                        int x = C.tl[t];
+                        if (x < 0) x += SPAN;
+                        slot[L.roll2 + (size_t)t * ncol + ai] = .5 * roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);   // transposed
+                    }
+                }
             }
         }
         if (tid == 0) descs[g] = d;

@@ -23,6 +23,10 @@
 //    max equals the score, smallest reversed row).  End coordinates use the key
 //    score<<18 | (511-col)<<9 | (511-row): its max is "first column reaching the max, smallest row".
 //    Both rules are validated against the compiled reference in oracle/ladder_model.c's tests.
+//  * the kernel is bound by VALU issue slots, LDS is idle: what can be left to the LDS pipe is.  A lane that sees a
+//    new best cell parks its R row values in LDS and leaves a note (resolve_best works out row and start payload
+//    only at template ends that are really combined); the (key, start) maximum of a template end's 2R candidates
+//    is taken by 64-bit LDS max atomics on a slot of the lane's own.  No lane reads another lane's slots.
 #include "tredgpu_internal.h"
 
 namespace tredgpu {
