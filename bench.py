@@ -392,14 +392,14 @@ def e2e_main(args):
         tred.write_vcf_json(result, "hg38", repo, names, quiet=True)
         done.append(result)
     try:
-        tred.run_many(tasks[:2], engine, batch=2, sink=sink, threads=2)          # warm-up: HIP context, ladders, caches
+        tred.run_many(tasks[:2], engine, batch=2, sink=sink, threads=2, lazy_details=True)          # warm-up: HIP context, ladders, caches
         del done[:]
         for k in tred.TIMING:
             tred.TIMING[k] = 0.0
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads)
+        tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads, lazy_details=True)
         dt = time.perf_counter() - t0
     finally:
         os.chdir(cwd)

@@ -139,6 +139,18 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
                  const tredbam_scan_opts* opts, tredbam_unit* units);
 int tredbam_scan_pools(tredbam* b, tredbam_pools* pools);
 
+/* The JSON text of one locus' `details` list exactly as the driver prints it inside a sample's file (what
+ * json.dumps(list, sort_keys=True, indent=4, separators=(',', ': ')) yields for the list at nesting depth 2:
+ * elements {"h": int, "id": name, "seq": bases, "tag": "FULL" | "PREF" | "POST" | "REPT" | "HANG"}), written straight
+ * from the pools of tredbam_scan_pools -- no per-read Python objects (tredparse/tred.py:118-121 stores the list, its
+ * to_json :160-170 prints it).  reads[i] indexes the pools, tags[i] is the read's TREDGPU_TAG_* code (1..5), hs[i]
+ * its repeat count.  Returns the number of bytes written; -3 when `cap` is too small; -1 when a name holds a byte
+ * that json.dumps would not print as itself or as \" / \\ (control characters, non-ASCII: the caller's generic
+ * encoder handles those); -2 on bad arguments. */
+int64_t tredbam_details_json(const uint8_t* seq4, const int64_t* seq4_off, const int32_t* read_len, const char* names,
+                             const int64_t* name_off, const int64_t* reads, const uint8_t* tags, const int32_t* hs,
+                             int64_t n, char* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

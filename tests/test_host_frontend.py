@@ -286,6 +286,54 @@ def test_tally_follows_the_reference_bookkeeping():
     assert rept2 == 0 and counts2["REPT"] == {} and counts2["FULL"] == {15: 1} and len(details2) == len(details) - 2
 
 
+def test_lazy_details_print_like_the_list():
+    """bam_parser.Details (the pools' view of a locus' details) equals the list of dicts, and its natively written JSON
+    is byte for byte what the driver's encoder prints for that list -- also for names with quotes and backslashes;
+    names the native writer does not handle (control / non-ASCII bytes) go through the generic encoder."""
+    from tredparse_amd import _lib
+    from tredparse_amd.bam_parser import Details, SampleScan, tally
+    repo = TREDsRepo("hg38")
+    s = scan_sample(BAM1, repo, ["HD"])
+    n = int(s.unit["n_reads"][0])
+    rng = np.random.default_rng(5)
+    tags = rng.integers(0, 6, n).astype(np.uint8)
+    hs = rng.integers(0, 60, n).astype(np.int16)
+    _, plain, _ = tally(s, 0, tags, hs)
+    _, lazy, _ = tally(s, 0, tags, hs, lazy=True)
+    assert isinstance(plain, list) and isinstance(lazy, Details) and len(lazy) == len(plain) > 10
+    assert lazy == plain and plain == list(lazy) and lazy[3] == plain[3] and not (lazy != plain)
+    text = lazy.json_text()
+    assert text is not None and text == tredmod._flat_list(plain)
+    res = {"samplekey": "x", "bam": "x.bam", "tredCalls": {"HD.1": 17, "HD.details": lazy, "HD.PP": 1.0}}
+    ref = {"samplekey": "x", "bam": "x.bam", "tredCalls": {"HD.1": 17, "HD.details": plain, "HD.PP": 1.0}}
+    assert tredmod.dumps_result(res) == json.dumps(ref, sort_keys=True, indent=4, separators=(",", ": "))
+    _, none, _ = tally(s, 0, np.zeros(n, np.uint8), hs, lazy=True)
+    assert len(none) == 0 and none.json_text() == "[]" == tredmod._flat_list([])
+    # hand-made pools: odd and even read lengths, N and = codes, names that need escapes
+    fake = SampleScan()
+    names = [b'a"b', b"back\\slash", b"plain/1", b"x", b"tab\there", "smørre".encode("utf-8")]
+    seqs = ["ACGTN", "=ACMGRSVTWYHKDBN", "", "T", "GG", "CA"]
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    blob, offs = bytearray(), [0]
+    for q in seqs:
+        nib = [code[c] for c in q] + [0]
+        blob += bytes((nib[i] << 4) | nib[i + 1] for i in range(0, len(q), 2))
+        offs.append(len(blob))
+    fake.seq4, fake.seq4_off = np.frombuffer(bytes(blob), np.uint8), np.asarray(offs, np.int64)
+    fake.read_len = np.asarray([len(q) for q in seqs], np.int32)
+    fake.name_blob = b"".join(names)
+    fake.name_off = np.cumsum([0] + [len(x) for x in names]).astype(np.int64)
+    fake._text = None
+    ok = Details(fake, np.asarray([2, 0, 1, 3], np.int64), np.asarray([1, 2, 4, 5], np.uint8), np.asarray([7, 0, 33, 120], np.int32))
+    assert [d["seq"] for d in ok] == ["", "ACGTN", "=ACMGRSVTWYHKDBN", "T"] and ok[1]["id"] == 'a"b' and ok[2]["id"] == "back\\slash"
+    assert ok.json_text() == tredmod._flat_list(ok.items())
+    for bad in (4, 5):     # a tab, a non-ASCII letter: the generic encoder's business
+        d = Details(fake, np.asarray([0, bad], np.int64), np.asarray([1, 1], np.uint8), np.asarray([1, 2], np.int32))
+        assert d.json_text() is None
+        out = tredmod.dumps_result({"samplekey": "k", "bam": "b", "tredCalls": {"X.details": d}})
+        assert json.loads(out)["tredCalls"]["X.details"] == d.items()
+
+
 def test_scans_run_in_host_threads():
     """run_many's host half: scans in worker threads give what a serial scan gives (the native call releases the
     GIL and every thread has its own file handle)."""

@@ -14,6 +14,7 @@ thin single-locus views of the same scan for callers and tests that address one 
 import logging
 import os
 from collections import Counter
+from collections.abc import Sequence
 
 import numpy as np
 
@@ -200,12 +201,58 @@ def admit(s):
 
 
 # ---- what becomes of the per-read results ---------------------------------------------------------------------
-def tally(scan, k, tags, hs, repeatpairs=True):
+class Details(Sequence):
+    """A locus' `details` -- [{"tag", "h", "id", "seq"}] for every read with a usable tag, in BAM order -- held as
+    index arrays into the scan's pools.  Behaves like that list (len, indexing, iteration, == against a list build
+    the dicts on first use); json_text() is the list as tred.to_json prints it, written natively from the pools
+    without a Python object per read (the driver's formatting time was mostly these thousands of small strings)."""
+    __slots__ = ("scan", "reads", "tags", "hs", "_items")
+
+    def __init__(self, scan, reads, tags, hs):
+        self.scan, self.reads, self.tags, self.hs, self._items = scan, reads, tags, hs, None
+
+    def items(self):
+        if self._items is None:
+            names, s = _lib.TAG_NAMES, self.scan
+            self._items = [{"tag": names[t], "h": h, "id": s.name(i), "seq": s.sequence(i)}
+                           for t, h, i in zip(self.tags.tolist(), self.hs.tolist(), self.reads.tolist())]
+        return self._items
+
+    def __len__(self):
+        return len(self.reads)
+
+    def __getitem__(self, i):
+        return self.items()[i]
+
+    def __iter__(self):
+        return iter(self.items())
+
+    def __eq__(self, other):
+        if isinstance(other, Details):
+            other = other.items()
+        return self.items() == other if isinstance(other, list) else NotImplemented
+
+    def __ne__(self, other):
+        eq = self.__eq__(other)
+        return eq if eq is NotImplemented else not eq
+
+    __hash__ = None
+
+    def __repr__(self):
+        return repr(self.items())
+
+    def json_text(self):
+        """The list at nesting depth 2 of json.dumps(..., sort_keys=True, indent=4), or None (generic encoder)."""
+        s = self.scan
+        return bamio.details_json(s.seq4, s.seq4_off, s.read_len, s.name_blob, s.name_off, self.reads, self.tags, self.hs)
+
+
+def tally(scan, k, tags, hs, repeatpairs=True, lazy=False):
     """The reference's bookkeeping for one locus (bam_parser.py:174-182, 248-287) from the kernel's per-read
     (tag, h): returns (counts, details, rept).  counts["PREF"] and counts["POST"] are ONE Counter (reads anchored
     on either flank are pooled), counts["HANG"] counts every read that aligned somewhere; details lists the reads
     with a usable tag in BAM order; with repeatpairs off every read whose name carries two or more REPT records is
-    removed before counting."""
+    removed before counting.  lazy: details as a Details view of the pools instead of the list of dicts."""
     a, b = scan.reads_of(k)
     tags, hs = np.asarray(tags), np.asarray(hs)
     hit = np.nonzero(tags != _lib.TAG_NONE)[0]
@@ -219,9 +266,9 @@ def tally(scan, k, tags, hs, repeatpairs=True):
     flank = Counter(kh[(kt == _lib.TAG_PREF) | (kt == _lib.TAG_POST)].tolist())
     counts = {"FULL": Counter(kh[kt == _lib.TAG_FULL].tolist()), "PREF": flank, "POST": flank,
               "REPT": Counter(kh[kt == _lib.TAG_REPT].tolist()), "HANG": Counter(hs[hit].tolist())}
-    names, labels = _lib.TAG_NAMES, kt.tolist()
-    details = [{"tag": names[t], "h": h, "id": scan.name(a + i), "seq": scan.sequence(a + i)}
-               for t, h, i in zip(labels, kh.tolist(), keep.tolist())]
+    details = Details(scan, keep.astype(np.int64) + a, kt.astype(np.uint8), kh.astype(np.int32))
+    if not lazy:
+        details = details.items()
     return counts, details, sum(counts["REPT"].values())
 
 

@@ -360,6 +360,8 @@ def _native():
             lib.tredbam_scan.restype = C.c_int
             lib.tredbam_scan_pools.argtypes = [C.c_void_p, C.POINTER(Pools)]
             lib.tredbam_scan_pools.restype = C.c_int
+            lib.tredbam_details_json.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_int64]
+            lib.tredbam_details_json.restype = C.c_int64
             _lib = lib
     return _lib or None
 
@@ -376,6 +378,28 @@ SCAN_UNIT_DTYPE = np.dtype([("status", "<i4"), ("n_reads", "<i4"), ("read_first"
                             ("depth_status", "<i4"), ("pe_status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"),
                             ("global_first", "<i8"), ("target_first", "<i8")])
 UNIT_NO_FETCH, UNIT_FAILED = 1, 2
+
+
+def details_json(seq4, seq4_off, read_len, names, name_off, reads, tags, hs):
+    """tredbam_details_json over numpy pools (names: bytes); the text, or None when the generic encoder has to do it
+    (library absent, a name with bytes json.dumps escapes other than the quote and the backslash)."""
+    lib = _native()
+    if lib is None:
+        return None
+    n = len(reads)
+    reads = np.ascontiguousarray(reads, np.int64)
+    tags = np.ascontiguousarray(tags, np.uint8)
+    hs = np.ascontiguousarray(hs, np.int32)
+    name_len = int((name_off[reads + 1] - name_off[reads]).sum()) if n else 0
+    cap = 64 + 200 * n + 2 * name_len + (int(read_len[reads].sum()) if n else 0)
+    buf = C.create_string_buffer(cap)
+    got = lib.tredbam_details_json(seq4.ctypes.data, seq4_off.ctypes.data, read_len.ctypes.data, names,
+                                   name_off.ctypes.data, reads.ctypes.data, tags.ctypes.data, hs.ctypes.data, n, buf, cap)
+    if got == -1:
+        return None
+    if got < 0:
+        raise RuntimeError("tredbam_details_json failed ({})".format(got))
+    return buf.raw[:got].decode("ascii")
 
 
 class ScanOpts(C.Structure):

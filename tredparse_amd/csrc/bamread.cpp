@@ -631,6 +631,49 @@ int tredbam_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t o
     return 1;
 }
 
+int64_t tredbam_details_json(const uint8_t* seq4, const int64_t* seq4_off, const int32_t* read_len, const char* names,
+                             const int64_t* name_off, const int64_t* reads, const uint8_t* tags, const int32_t* hs,
+                             int64_t n, char* out, int64_t cap) {
+    if (n < 0 || !out || cap < 2 || (n > 0 && (!seq4 || !seq4_off || !read_len || !names || !name_off || !reads || !tags || !hs)))
+        return -2;
+    static const char* const TAGS[6] = {nullptr, "FULL", "PREF", "POST", "REPT", "HANG"};
+    static const char BASES[] = "=ACMGRSVTWYHKDBN";
+    char* p = out;
+    char* const end = out + cap;
+    auto put = [&](const char* s, size_t len) { memcpy(p, s, len); p += len; };
+#define TREDBAM_LIT(S) put(S, sizeof(S) - 1)
+    if (n == 0) { TREDBAM_LIT("[]"); return p - out; }
+    TREDBAM_LIT("[\n");
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t rd = reads[i];
+        const int64_t n0 = name_off[rd], n1 = name_off[rd + 1];
+        const int32_t L = read_len[rd];
+        if (tags[i] < 1 || tags[i] > 5 || L < 0 || n1 < n0) return -2;
+        // worst case of this element: fixed text < 160, the name doubled by escapes, the bases, 11 digits
+        if ((int64_t)(end - p) < 200 + 2 * (n1 - n0) + L) return -3;
+        TREDBAM_LIT("            {\n                \"h\": ");
+        p += snprintf(p, 16, "%d", (int)hs[i]);
+        TREDBAM_LIT(",\n                \"id\": \"");
+        for (int64_t k = n0; k < n1; ++k) {
+            const unsigned char c = (unsigned char)names[k];
+            if (c < 0x20 || c >= 0x7f) return -1;
+            if (c == '"' || c == '\\') *p++ = '\\';
+            *p++ = (char)c;
+        }
+        TREDBAM_LIT("\",\n                \"seq\": \"");
+        const uint8_t* sq = seq4 + seq4_off[rd];
+        for (int32_t k = 0; k < L; ++k) *p++ = BASES[(sq[k >> 1] >> ((k & 1) ? 0 : 4)) & 15];
+        TREDBAM_LIT("\",\n                \"tag\": \"");
+        put(TAGS[tags[i]], 4);
+        TREDBAM_LIT("\"\n            }");
+        if (i + 1 < n) TREDBAM_LIT(",\n");
+    }
+    if (end - p < 16) return -3;
+    TREDBAM_LIT("\n        ]");
+#undef TREDBAM_LIT
+    return p - out;
+}
+
 int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out) {
     if (!b || !out) return -2;
     int rc = bg_seek(b, b->first_record);

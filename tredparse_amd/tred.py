@@ -29,7 +29,7 @@ from concurrent.futures import ThreadPoolExecutor
 from datetime import date, timedelta
 
 from . import __version__
-from .bam_parser import scan_sample, tally
+from .bam_parser import Details, scan_sample, tally
 from .meta import BUILDS, TREDsRepo
 from .models import GridError, format_call, pair_summaries
 
@@ -159,11 +159,11 @@ def _skeleton(o, scan):
     return {"samplekey": o["samplekey"], "bam": o["bam"], "tredCalls": calls}
 
 
-def _fill_unit(calls, scan, k, res, repeatpairs, pairs):
+def _fill_unit(calls, scan, k, res, repeatpairs, pairs, lazy=False):
     """The 21 keys of one locus from its kernel results (pairs = models.pair_summaries(scan))."""
     t = scan.loci[k]
     call = format_call(t, res)                       # may raise GridError: the locus is then left out
-    counts, details, rept = tally(scan, k, res.tags, res.hs, repeatpairs=repeatpairs)
+    counts, details, rept = tally(scan, k, res.tags, res.hs, repeatpairs=repeatpairs, lazy=lazy)
     n = t.name
     calls[n + ".1"], calls[n + ".2"] = call["alleles"]
     calls[n + ".FR"], calls[n + ".PR"] = counter_s(counts["FULL"]), counter_s(counts["PREF"])
@@ -215,8 +215,9 @@ def _genotype(engine, picks, o):
     return out
 
 
-def finish_batch(engine, task_args, scans):
-    """GPU half + formatting for the scans of one batch; returns the result dicts in task order."""
+def finish_batch(engine, task_args, scans, lazy_details=False):
+    """GPU half + formatting for the scans of one batch; returns the result dicts in task order.  lazy_details:
+    `<locus>.details` as bam_parser.Details views (list-like; to_json prints them natively) instead of lists."""
     if not task_args:
         return []
     o0 = _options(task_args[0])
@@ -235,7 +236,8 @@ def finish_batch(engine, task_args, scans):
             if (si, k) not in res:
                 continue
             try:
-                _fill_unit(result["tredCalls"], scan, k, res[(si, k)], o["repeatpairs"] or o["clip"], pairs)
+                _fill_unit(result["tredCalls"], scan, k, res[(si, k)], o["repeatpairs"] or o["clip"], pairs,
+                           lazy=lazy_details)
             except GridError as e:
                 logger.error("Exception on `%s` %s (%s)", o["bam"], scan.names[k], e)
         results.append(result)
@@ -251,29 +253,33 @@ def run(arg, engine=None):
     return finish_batch(engine or Engine(), [arg], [collect_sample(arg)])[0]
 
 
-def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1):
+def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2):
     """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
-    executor given as `pool`), always one batch ahead of the GPU.  Each finished result goes to sink(result), or
-    into the returned list."""
-    chunks = [task_args[i:i + batch] for i in range(0, len(task_args), batch)]
+    executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in flight the
+    scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
+    finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch."""
     own = pool is None and threads > 1 and len(task_args) > 1
+    # the first GPU batch is only as large as one round of the scan threads: nothing else can start before it is in
+    first = min(batch, max(1, threads)) if (own or pool is not None) else batch
+    chunks = [task_args[:first]] + [task_args[i:i + batch] for i in range(first, len(task_args), batch)]
+    chunks = [c for c in chunks if c]
     ex = ThreadPoolExecutor(max_workers=threads) if own else pool
     out = []
     try:
         submit = (lambda c: [ex.submit(collect_sample, a) for a in c]) if ex is not None else None
         ahead = deque()
-        if ex is not None and chunks:
-            ahead.append(submit(chunks[0]))
+        nxt = 0
         for i, chunk in enumerate(chunks):
             if ex is not None:
-                if i + 1 < len(chunks):
-                    ahead.append(submit(chunks[i + 1]))
+                while nxt < len(chunks) and nxt <= i + max(1, ahead_batches):
+                    ahead.append(submit(chunks[nxt]))
+                    nxt += 1
                 t0 = time.perf_counter()
                 scans = [f.result() for f in ahead.popleft()]
                 TIMING["scan_wait"] += time.perf_counter() - t0
             else:
                 scans = [collect_sample(a) for a in chunk]
-            for r in finish_batch(engine, chunk, scans):
+            for r in finish_batch(engine, chunk, scans, lazy_details=lazy_details):
                 if sink is not None:
                     sink(r)
                 else:
@@ -311,22 +317,32 @@ def _flat_list(items):
 
 
 def dumps_result(results):
-    """json.dumps(results, sort_keys=True, indent=4, separators=(',', ': ')) for a run() result, byte for byte, about
-    five times faster: with an indent the standard encoder runs in pure Python, and a sample's `details` alone are
+    """json.dumps(results, sort_keys=True, indent=4, separators=(',', ': ')) for a run() result, byte for byte, many
+    times faster: with an indent the standard encoder runs in pure Python, and a sample's `details` alone are
     thousands of strings.  The structure is known -- {samplekey, bam, tredCalls: {key: scalar | flat dict | list of
-    flat dicts}} -- so every flat container goes through the C encoder with the indentation in its separators."""
+    flat dicts}} -- so: all scalar entries go through the C encoder in ONE call (the item separator carries the line
+    break and the indentation; a literal line break cannot occur inside a JSON string, so the text splits back into
+    one line per sorted key), every flat dict in one call, `details` natively from the scan's pools."""
     calls = results["tredCalls"]
-    lines = []
-    for key in sorted(calls):
-        v = calls[key]
+    sep = ",\n" + _P8
+    scalars = {k: v for k, v in calls.items() if not isinstance(v, (dict, list, Details))}
+    entry = {}
+    if scalars:
+        lines = json.dumps(scalars, sort_keys=True, separators=(sep, ": "))[1:-1].split(sep)
+        entry = dict(zip(sorted(scalars), lines))
+    for key, v in calls.items():
+        if key in scalars:
+            continue
         if isinstance(v, dict):
             text = _flat(v, 2)
-        elif isinstance(v, list):
-            text = _flat_list(v)
+        elif isinstance(v, Details):
+            text = v.json_text()
+            if text is None:
+                text = _flat_list(v.items())
         else:
-            text = json.dumps(v)
-        lines.append(" " * 8 + json.dumps(key) + ": " + text)
-    inner = "{\n" + ",\n".join(lines) + "\n    }" if lines else "{}"
+            text = _flat_list(v)
+        entry[key] = json.dumps(key) + ": " + text
+    inner = "{\n" + _P8 + sep.join(entry[k] for k in sorted(entry)) + "\n    }" if entry else "{}"
     top = {k: v for k, v in results.items() if k != "tredCalls"}
     parts = [(k, json.dumps(v)) for k, v in top.items()] + [("tredCalls", inner)]
     return "{\n" + ",\n".join("    " + json.dumps(k) + ": " + t for k, t in sorted(parts)) + "\n}"
@@ -471,7 +487,8 @@ def main(args, quiet=False):
                 def sink(result):
                     if not args.no_output:
                         write_vcf_json(result, args.ref, repo, loci, quiet=quiet)
-                run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus))
+                run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus),
+                         lazy_details=True)
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
         os.chdir(cwd)
