@@ -109,11 +109,47 @@ struct PairCtx {
     double half_depth, lgam_rept, small, really_small, logsmall;
 };
 
+// log(x) for positive, finite, normal x -- the two hot uses (a pair's product of <= 32 factors in [e^-10, 1]; an
+// observation's probability >= SMALL_VALUE).  x = m * 2^e with m in [0.7071, 1.4142], s = (m - 1) / (m + 1),
+// log(m) = 2 s + s z (2/3 + 2 z/5 + ... + 2 z^8/19), z = s^2 <= 0.0295 (the next term is < 3e-17 of the result);
+// e ln2 is added in two parts.  < 2 ulp against a 120-bit reference over 7 M arguments (the device library's log
+// is correctly rounded to the last bit or so and costs 89 instructions, 76 of them fp64; this is ~40, and the
+// contract is 1e-6 absolute on sums of O(100) such terms).
+__device__ __forceinline__ double pos_log(double x) {
+    int hi = __double2hiint(x);
+    const int lo = __double2loint(x);
+    int e = (hi >> 20) - 1023;
+    hi = (hi & 0x000FFFFF) | 0x3FF00000;                         // mantissa in [1, 2)
+    double m = __hiloint2double(hi, lo);
+    const bool up = m > 1.4142135623730951;
+    m = up ? m * 0.5 : m;                                        // -> [0.7071, 1.4142]
+    e += up ? 1 : 0;
+    const double f = m - 1.0, d = m + 1.0;
+    double r = __builtin_amdgcn_rcp(d);                          // ~2^-23; two Newton steps
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    double s = f * r;
+    s = __builtin_fma(__builtin_fma(-s, d, f), r, s);            // s = f / d to the last bit or so
+    const double z = s * s;
+    double p = 2.0 / 19;
+    p = __builtin_fma(p, z, 2.0 / 17);
+    p = __builtin_fma(p, z, 2.0 / 15);
+    p = __builtin_fma(p, z, 2.0 / 13);
+    p = __builtin_fma(p, z, 2.0 / 11);
+    p = __builtin_fma(p, z, 2.0 / 9);
+    p = __builtin_fma(p, z, 2.0 / 7);
+    p = __builtin_fma(p, z, 2.0 / 5);
+    p = __builtin_fma(p, z, 2.0 / 3);
+    const double ef = (double)e;
+    const double t = __builtin_fma(s * z, p, ef * 1.90821492927058770002e-10);
+    return __builtin_fma(ef, 6.93147180369123816490e-01, 2.0 * s + t);
+}
+
 // log(max(p, SMALL_VALUE)) (safe_log, models.py:418-423); log(SMALL_VALUE) itself is evaluated once
 // per unit with the same device log, so clamped terms cost no transcendental.
 __device__ __forceinline__ double safe_log(const PairCtx& C, double p) {
     if (p < C.small) return C.logsmall;
-    return log(p);
+    return pos_log(p);
 }
 
 // spanning + partial terms (models.py:192-207)
@@ -156,6 +192,32 @@ __device__ double rept_term(const PairCtx& C, int dsum) {
 
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Sum over the wavefront by DPP moves (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast:15 and row_bcast:31):
+// the total arrives in lane 63.  A fixed tree like wave_sum's, but ~100 cycles of latency instead of six LDS-crossbar
+// round trips (ds_bpermute) -- it sits in the per-row chain of grid_reduce_kernel.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __hiloint2double(hi, lo);     // lanes without a source (or outside the row mask) add +0.0
+}
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax_to_last(int v) {
+#define TRED_STEP(CTRL, ROW_MASK) { const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); v = MAX ? max(v, o) : min(v, o); }
+    TRED_STEP(0x111, 0xF) TRED_STEP(0x112, 0xF) TRED_STEP(0x114, 0xF) TRED_STEP(0x118, 0xF) TRED_STEP(0x142, 0xA) TRED_STEP(0x143, 0xC)
+#undef TRED_STEP
+    return v;
+}
+__device__ __forceinline__ double wave_sum_to_last(double v) {
+    v = dpp_add<0x111, 0xF>(v);
+    v = dpp_add<0x112, 0xF>(v);
+    v = dpp_add<0x114, 0xF>(v);
+    v = dpp_add<0x118, 0xF>(v);
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -887,7 +949,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                         else { TRED_PROD(b[q]) }
 #undef TRED_PROD
 #undef TRED_PROD8
-                        lp = log(prod);
+                        lp = pos_log(prod);
                     }
                     if (ok) {
                         const int pos = i * ncol + j;
@@ -939,6 +1001,7 @@ struct ReduceShared {
     int lo[2], brk[2], lastnz[2];
     int jn;      // sparse joint entries found so far
     int unit;
+    int base[MAXOBS + 1];   // the unit's observed sizes (base part of the axes)
 };
 
 __device__ double block_sum_r(double v, double* red) {
@@ -1001,6 +1064,7 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
         for (int m = tid; m < mlim; m += NR) { S.ph1[m] = 0; S.ph2[m] = 0; }
         if (tid < 2) { S.lo[tid] = MAXM; S.brk[tid] = MAXM; S.lastnz[tid] = 0; }
         if (tid == 0) S.jn = 0;
+        for (int k = tid; k < d.nb; k += NR) S.base[k] = obs->base[k];   // axis values in LDS: every row of the sweep asks
         __syncthreads();
         Best top = S.bred[0];
         for (int w = 1; w < NR / 64; ++w) if (better(S.bred[w], top)) top = S.bred[w];
@@ -1026,7 +1090,7 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
     #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 const int j = lane + 64 * (k0 + k);
-                h2k[k] = k0 + k < nk && j < ncol ? axis_value(d.ax2, obs->base, period, j) : -1;   // -1: no column
+                h2k[k] = k0 + k < nk && j < ncol ? axis_value(d.ax2, S.base, period, j) : -1;   // -1: no column
                 const int hi = h2k[k] / period;
                 if (by_col && h2k[k] >= 0 && (d.is_expansion ? hi >= d.cutoff_risk : hi <= d.cutoff_risk)) colpath |= 1u << k;
             }
@@ -1038,18 +1102,20 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
                 for (int k = 0; k < KC; ++k) {
                     const int j = lane + 64 * (k0 + k);
                     if (h2k[k] >= 0 && j >= d.ax2.nb)
-                        for (int q = 0; q < d.ax2.nb; ++q) if (obs->base[q] == h2k[k]) coldup |= 1u << k;
+                        for (int q = 0; q < d.ax2.nb; ++q) if (S.base[q] == h2k[k]) coldup |= 1u << k;
                 }
             }
             double colacc[KC];
     #pragma unroll
             for (int k = 0; k < KC; ++k) colacc[k] = 0;
-            for (int i = wv; i < nrow; i += NR / 64) {
-                const int h1 = axis_value(d.ax1, obs->base, period, i);
+            // two rows of the wave per step (i and i + 4): two independent chains of loads, exps and the row-sum
+            // reduction in one straight line of code -- the kernel's time per unit is this chain's latency
+            auto one_row = [&](const int i) -> double {
+                const int h1 = __builtin_amdgcn_readfirstlane(axis_value(d.ax1, S.base, period, i));
                 const int lo = h1 / period;
                 bool rowdup = false;
                 if (want_joint && i >= d.ax1.nb)
-                    for (int q = 0; q < d.ax1.nb; ++q) rowdup |= obs->base[q] == h1;
+                    for (int q = 0; q < d.ax1.nb; ++q) rowdup |= S.base[q] == h1;
                 // ploidy 1: h2 = h1, one column; both alleles equal, so lo decides whatever the inheritance
                 const bool rowpath = !by_col && (d.is_expansion ? lo >= d.cutoff_risk : lo <= d.cutoff_risk);
                 double v[KC];
@@ -1080,9 +1146,21 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
                         }
                     }
                 }
-                all += acc;
-                acc = wave_sum(acc);
-                if (lane == 0) S.cum1[i] = k0 == 0 ? acc : S.cum1[i] + acc;
+                return acc;
+            };
+            for (int i = wv; i < nrow; i += 2 * (NR / 64)) {
+                const int i2 = i + NR / 64;
+                const bool two = i2 < nrow;               // wave-uniform
+                double acc0 = one_row(i), acc1 = 0;
+                if (two) acc1 = one_row(i2);
+                all += acc0;
+                all += acc1;
+                acc0 = wave_sum_to_last(acc0);
+                acc1 = wave_sum_to_last(acc1);
+                if (lane == 63) {
+                    S.cum1[i] = k0 == 0 ? acc0 : S.cum1[i] + acc0;
+                    if (two) S.cum1[i2] = k0 == 0 ? acc1 : S.cum1[i2] + acc1;
+                }
             }
             // column sums: wave 0 stores, waves 1..3 add in turn
             for (int w = 0; w < NR / 64; ++w) {
@@ -1105,14 +1183,14 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
         // arithmetic part, models.py:251-252): the first occurrence owns the sum of both columns.
         if (d.ploidy != 1) {
             for (int j = tid; j < ncol; j += NR) {
-                const int h2 = axis_value(d.ax2, obs->base, period, j);
+                const int h2 = axis_value(d.ax2, S.base, period, j);
                 int twin = -1;
                 if (j < d.ax2.nb) {
                     const int dd = h2 - d.ax2.start;
                     if (d.ax2.n > 0 && dd >= 0 && dd % period == 0 && dd / period < d.ax2.n) twin = d.ax2.nb + dd / period;
                 } else {
                     bool dup = false;
-                    for (int k = 0; k < d.ax2.nb; ++k) dup |= obs->base[k] == h2;
+                    for (int k = 0; k < d.ax2.nb; ++k) dup |= S.base[k] == h2;
                     if (dup) continue;  // owned by the base occurrence
                 }
                 const int m = h2 / period;
@@ -1125,11 +1203,22 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
             uniq = block_sum_r(uniq, S.red);
             if (tid == 0) { a.joint_n[g] = S.jn; a.joint_total[g] = uniq; }
         }
-        if (tid == 0) {
-            for (int i = 0; i < nrow; ++i) {   // rows merged by key in row order
-                const int m = axis_value(d.ax1, obs->base, period, i) / period;
-                if (m < MAXM) S.ph1[m] += S.cum1[i];
+        // marginal P_h1 by distinct h1 value, rows merged by key in row order: like the columns, a value can be listed
+        // twice (once in the base part, once in the arithmetic part) and the base occurrence owns base + twin -- the
+        // order in which a serial walk over the rows adds them up
+        for (int i = tid; i < nrow; i += NR) {
+            const int h1 = axis_value(d.ax1, S.base, period, i);
+            int twin = -1;
+            if (i < d.ax1.nb) {
+                const int dd = h1 - d.ax1.start;
+                if (d.ax1.n > 0 && dd >= 0 && dd % period == 0 && dd / period < d.ax1.n) twin = d.ax1.nb + dd / period;
+            } else {
+                bool dup = false;
+                for (int k = 0; k < d.ax1.nb; ++k) dup |= S.base[k] == h1;
+                if (dup) continue;  // owned by the base occurrence
             }
+            const int m = h1 / period;
+            if (m < MAXM) S.ph1[m] = twin >= 0 ? S.cum1[i] + S.cum1[twin] : S.cum1[i];
         }
         __syncthreads();
         if (d.ploidy == 1) {
@@ -1139,21 +1228,42 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
         // ---- calc_CI, models.py:319-340 on each marginal: running sums by one lane each, then every
         //      thread tests its own bins against the 2.5 % / 97.5 % marks ----
         if (tid == 0 || tid == 64) {
+            // (eight bins per step: the loads of a step do not wait for one another, only the additions form a chain --
+            //  bin by bin the loop ran at one LDS round trip per bin, a third of the kernel's time per unit)
             const double* P = tid ? S.ph2 : S.ph1;
             double* cum = tid ? S.cum2 : S.cum1;
             double c = 0;
-            for (int m = 0; m < mlim; ++m) { c += P[m]; cum[m] = c; }
+            int m = 0;
+            for (; m + 8 <= mlim; m += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = P[m + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c += v[q]; v[q] = c; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cum[m + q] = v[q];
+            }
+            for (; m < mlim; ++m) { c += P[m]; cum[m] = c; }
         }
         __syncthreads();
         for (int which = 0; which < 2; ++which) {
             const double* P = which ? S.ph2 : S.ph1;
             const double* cum = which ? S.cum2 : S.cum1;
             const double total = cum[mlim - 1];
+            int last = 0, lo = MAXM, brk = MAXM;      // (one LDS atomic per wave and mark, not one per bin)
             for (int m = tid; m < mlim; m += NR) {
                 if (P[m] == 0) continue;
-                atomicMax(&S.lastnz[which], m);
-                if (cum[m] > .025 * total) atomicMin(&S.lo[which], m);
-                if (cum[m] > .975 * total) atomicMin(&S.brk[which], m);
+                last = max(last, m);
+                if (cum[m] > .025 * total) lo = min(lo, m);
+                if (cum[m] > .975 * total) brk = min(brk, m);
+            }
+            last = wave_minmax_to_last<true>(last);
+            lo = wave_minmax_to_last<false>(lo);
+            brk = wave_minmax_to_last<false>(brk);
+            if ((tid & 63) == 63) {
+                atomicMax(&S.lastnz[which], last);
+                atomicMin(&S.lo[which], lo);
+                atomicMin(&S.brk[which], brk);
             }
         }
         __syncthreads();
@@ -1163,8 +1273,8 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
                 call.ci[2 * which + 1] = S.brk[which] < MAXM ? S.brk[which] : S.lastnz[which];
             }
             const int bi = top.pos / ncol, bj = top.pos - bi * ncol;
-            call.h1 = axis_value(d.ax1, obs->base, period, bi);
-            call.h2 = d.ploidy == 1 ? call.h1 : axis_value(d.ax2, obs->base, period, bj);
+            call.h1 = axis_value(d.ax1, S.base, period, bi);
+            call.h2 = d.ploidy == 1 ? call.h1 : axis_value(d.ax2, S.base, period, bj);
             call.lik = max_ml;
             const double pp = path / all;
             call.pp = pp < 1 ? pp : 1;
