@@ -854,6 +854,12 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
     const int lane = threadIdx.x & 63;
     const double small = a.model->small;
     const int total = ctr->n_items;
+    // the row's 32 roll(h1) values, one buffer per wavefront: written by the wave, read back as LDS broadcasts (the
+    // same address in every lane) -- an LDS instruction per value instead of two v_readlane on the VALU, which is
+    // what the kernel is short of
+    __shared__ double rowvals[4][TC];
+    static_assert(TC == 32, "rowvals is written by lane & 31");
+    double* const myrow = rowvals[threadIdx.x >> 6];
     while (true) {
         int t = 0;
         if (lane == 0) t = atomicAdd(&ctr->next_item, 1);
@@ -941,8 +947,9 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                         // (entries past the unit's n_target are .5 + .5 = 1: whole groups of eight of them are skipped,
                         //  which leaves the product bit-identical -- the median unit has 16 spanning pairs, not 32)
                         double prod = 1.0;
+                        myrow[lane & (TC - 1)] = cur.r1v;     // (both halves of the wave hold the same 32 values)
 #define TRED_PROD8(Q0, OTHER) _Pragma("unroll") for (int q = (Q0); q < (Q0) + 8; ++q) { \
-                            const double av = readlane_d(cur.r1v, q); prod *= fmax(av + (OTHER), small); }
+                            const double av = myrow[q]; prod *= fmax(av + (OTHER), small); }
 #define TRED_PROD(OTHER) TRED_PROD8(0, OTHER) \
                         if (nq > 8) { TRED_PROD8(8, OTHER) if (nq > 16) { TRED_PROD8(16, OTHER) if (nq > 24) { TRED_PROD8(24, OTHER) } } }
                         if (haploid) { TRED_PROD(av) }   // both alleles are the row's h1: .5 * roll + .5 * roll
