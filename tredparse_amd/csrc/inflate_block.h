@@ -20,12 +20,13 @@ constexpr int LL_BITS = 11;       // primary table bits, literal/length alphabet
 constexpr int D_BITS = 8;         // primary table bits, distance alphabet
 constexpr int LL_ENTRIES = (1 << LL_BITS) + 2048;   // + second-level tables (15 - 11 bits deep, <= 288 symbols)
 constexpr int D_ENTRIES = (1 << D_BITS) + 512;
-constexpr int SLACK = 16;         // bytes the output buffer must have beyond the expected size
+constexpr int SLACK = 32;         // bytes the output buffer must have beyond the expected size
 
 // table entry: bits 0-4 code length to consume (second-level entries: the bits left after the primary ones);
 // bits 5-8 number of extra bits (pointer entries: bits of the second-level index); bits 9-12 flags;
 // bits 16-31 value (literal, base length, base distance, start of the second-level table)
 constexpr uint32_t F_LITERAL = 1u << 9, F_SUB = 1u << 10, F_EOB = 1u << 11, F_BAD = 1u << 12;
+constexpr uint32_t F_LIT2 = 1u << 13;   // literal entry that carries a second literal in bits 24-31 (length field: both codes)
 inline int e_len(uint32_t e) { return (int)(e & 31); }
 inline int e_extra(uint32_t e) { return (int)((e >> 5) & 15); }
 inline uint32_t e_value(uint32_t e) { return e >> 16; }
@@ -112,6 +113,21 @@ inline bool build(const uint8_t* lens, int n, bool ll, uint32_t* table, int tabl
             const uint32_t start = e_value(pe);
             const int rest = l - tbits;
             for (uint32_t i = r >> tbits; i < (1u << sb); i += 1u << rest) table[start + i] = e | (uint32_t)rest;
+        }
+    }
+    if (ll) {
+        // Two literals per look-up where both codes fit the primary index (4-bit sequence bytes and binned qualities
+        // get 4-6 bit codes): the entry keeps the first literal in bits 16-23, takes the second into bits 24-31 and
+        // counts both codes in its length.  The second code is read off the single-literal table: index = the bits left
+        // after the first code, upper bits zero -- valid iff that entry is a literal no longer than those bits.
+        // (Descending order: the entries looked up, at indices i >> l1 < i, are still single.)
+        for (int i = (1 << tbits) - 1; i >= 0; --i) {
+            const uint32_t e1 = table[i];
+            if (!(e1 & F_LITERAL)) continue;
+            const int l1 = e_len(e1);
+            const uint32_t e2 = table[(uint32_t)i >> l1];
+            if ((e2 & (F_LITERAL | F_LIT2)) != F_LITERAL || e_len(e2) > tbits - l1) continue;
+            table[i] = F_LITERAL | F_LIT2 | (e1 & 0x00FF0000u) | ((e2 & 0x00FF0000u) << 8) | (uint32_t)(l1 + e_len(e2));
         }
     }
     return true;
@@ -239,48 +255,53 @@ inline bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t
             if (!build(lens, hlit, true, T.ll, LL_ENTRIES)) return false;
             if (!build(lens + 288, hdist, false, T.d, D_ENTRIES)) return false;
             // ---- symbols, fast loop: while 16 input bytes and the longest match plus the copy slack are in reach no
-            //      bound needs testing except a match's distance; the careful loop below finishes the block ----
+            //      bound needs testing except a match's distance; the careful loop below finishes the block.
+            //      Every path ends with "refill, look the next symbol up": the table load of the next symbol is in
+            //      flight while a match is copied (BAM blocks are match-dominated: ~12 bytes per match), and the bit
+            //      buffer holds >= 56 bits whenever a symbol is taken apart (length 15 + 5, distance 15 + 13). ----
             bool eob = false;
-            while (b.end - b.p >= 16 && oend - o >= 258 + 16) {
-                {   // branch-free refill (the input margin makes the 8-byte load safe)
-                    uint64_t w;
-                    memcpy(&w, b.p, 8);
-                    b.buf |= w << b.n;
-                    const int take = (63 - b.n) >> 3;
-                    b.p += take;
-                    b.n += take << 3;
-                }
+#define TREDBAM_REFILL { uint64_t w; memcpy(&w, b.p, 8); b.buf |= w << b.n; const int take = (63 - b.n) >> 3; b.p += take; b.n += take << 3; }
+            if (b.end - b.p >= 16) {
+                TREDBAM_REFILL
                 uint32_t e = T.ll[b.peek(LL_BITS)];
-                if (e & F_LITERAL) {                          // up to three literals per refill (3 x 15 <= 56 bits)
-                    b.drop(e_len(e));
-                    *o++ = (uint8_t)e_value(e);
-                    e = T.ll[b.peek(LL_BITS)];
-                    if (!(e & F_LITERAL)) continue;           // (a fresh refill for whatever comes next: a literal, a
-                                                              //  length and a distance together can need 63 bits)
-                    b.drop(e_len(e));
-                    *o++ = (uint8_t)e_value(e);
-                    e = T.ll[b.peek(LL_BITS)];
-                    if (!(e & F_LITERAL)) continue;           // (a fresh refill for whatever comes next)
-                    b.drop(e_len(e));
-                    *o++ = (uint8_t)e_value(e);
-                    continue;
-                }
-                if (e & F_SUB) {
-                    b.drop(LL_BITS);
-                    e = T.ll[e_value(e) + b.peek(e_extra(e))];
-                    if (e & F_LITERAL) {
-                        b.drop(e_len(e));
-                        *o++ = (uint8_t)e_value(e);
+                while (b.end - b.p >= 16 && oend - o >= 258 + 32) {
+                    if (e & F_LITERAL) {                      // up to three look-ups per refill (3 x 15 <= 56 bits),
+                                                              // each one or two literals (the second byte written for a
+                                                              // single literal is scratch: the output has room here)
+#define TREDBAM_PUT_LITERALS(E) { b.drop(e_len(E)); o[0] = (uint8_t)((E) >> 16); o[1] = (uint8_t)((E) >> 24); o += 1 + (((E) >> 13) & 1u); }
+                        TREDBAM_PUT_LITERALS(e)
+                        e = T.ll[b.peek(LL_BITS)];
+                        if (e & F_LITERAL) {
+                            TREDBAM_PUT_LITERALS(e)
+                            e = T.ll[b.peek(LL_BITS)];
+                            if (e & F_LITERAL) {
+                                TREDBAM_PUT_LITERALS(e)
+                                e = T.ll[b.peek(LL_BITS)];        // (>= 56 - 45 = 11 bits are left: enough for the index)
+                                TREDBAM_REFILL
+                                continue;
+                            }
+                        }
+#undef TREDBAM_PUT_LITERALS
+                        TREDBAM_REFILL                        // e stays valid: a refill only adds bits above the ones seen
                         continue;
                     }
-                }
-                if (e & (F_EOB | F_BAD)) {
-                    if (e & F_BAD) return false;
-                    b.drop(e_len(e));
-                    eob = true;
-                    break;
-                }
-                {
+                    if (e & F_SUB) {
+                        b.drop(LL_BITS);
+                        e = T.ll[e_value(e) + b.peek(e_extra(e))];
+                        if (e & F_LITERAL) {
+                            b.drop(e_len(e));
+                            *o++ = (uint8_t)e_value(e);
+                            TREDBAM_REFILL
+                            e = T.ll[b.peek(LL_BITS)];
+                            continue;
+                        }
+                    }
+                    if (e & (F_EOB | F_BAD)) {
+                        if (e & F_BAD) return false;
+                        b.drop(e_len(e));
+                        eob = true;
+                        break;
+                    }
                     const int cl = e_len(e), xb = e_extra(e);
                     const uint32_t len = e_value(e) + ((uint32_t)(b.buf >> cl) & ((1u << xb) - 1));
                     b.drop(cl + xb);
@@ -293,11 +314,23 @@ inline bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t
                     const int dcl = e_len(de), dxb = e_extra(de);
                     const uint32_t dist = e_value(de) + ((uint32_t)(b.buf >> dcl) & ((1u << dxb) - 1));
                     b.drop(dcl + dxb);
+                    // the next symbol's entry, loaded while the match is copied -- from the bits at hand when they cover
+                    // the index (nearly always), so that the refill is off the chain load -> shift -> load -> shift
+                    if (b.n >= LL_BITS) {
+                        e = T.ll[b.peek(LL_BITS)];
+                        TREDBAM_REFILL
+                    } else {
+                        TREDBAM_REFILL
+                        e = T.ll[b.peek(LL_BITS)];
+                    }
                     if (dist > (size_t)(o - out)) return false;
                     const uint8_t* s = o - dist;
                     uint8_t* const stop = o + len;
-                    if (dist >= 8) {
-                        memcpy(o, s, 8); memcpy(o + 8, s + 8, 8);                      // most matches are short
+                    if (dist >= 16) {
+                        memcpy(o, s, 16);                                              // most matches are short
+                        if (len > 16) { memcpy(o + 16, s + 16, 16); if (len > 32) { o += 32; s += 32; do { memcpy(o, s, 16); o += 16; s += 16; } while (o < stop); } }
+                    } else if (dist >= 8) {
+                        memcpy(o, s, 8); memcpy(o + 8, s + 8, 8);
                         if (len > 16) { o += 16; s += 16; do { memcpy(o, s, 8); o += 8; s += 8; } while (o < stop); }
                     } else if (dist == 1) {
                         memset(o, *s, len);
@@ -307,6 +340,7 @@ inline bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t
                     o = stop;
                 }
             }
+#undef TREDBAM_REFILL
             // ---- symbols, careful loop ----
             while (!eob) {
                 b.refill();                                   // >= 56 bits: a length (15 + 5) and a distance (15 + 13) fit
@@ -317,19 +351,11 @@ inline bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t
                 }
                 if (e & F_LITERAL) {
                     b.drop(e_len(e));
-                    if (o >= oend) return false;
-                    *o++ = (uint8_t)e_value(e);
-                    // a second and third literal out of the same refill (literal runs dominate 4-bit sequence data)
-                    e = T.ll[b.peek(LL_BITS)];
-                    if ((e & (F_LITERAL | F_SUB)) == F_LITERAL && o < oend) {
-                        b.drop(e_len(e));
-                        *o++ = (uint8_t)e_value(e);
-                        e = T.ll[b.peek(LL_BITS)];
-                        if ((e & (F_LITERAL | F_SUB)) == F_LITERAL && o < oend) {
-                            b.drop(e_len(e));
-                            *o++ = (uint8_t)e_value(e);
-                        }
-                    }
+                    const int cnt = 1 + (int)((e >> 13) & 1u);        // (second-level entries are always single)
+                    if (oend - o < cnt) return false;
+                    o[0] = (uint8_t)(e >> 16);
+                    if (cnt == 2) o[1] = (uint8_t)(e >> 24);
+                    o += cnt;
                     continue;
                 }
                 if (e & (F_EOB | F_BAD)) {
