@@ -430,7 +430,7 @@ def run_e2e(args):
         argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(args.e2e_batch),
                 "--e2e-threads", str(args.e2e_threads)]
         legs = []
-        many = args.e2e_drivers or max(1, shard.usable_cpus() // 6)   # ~5 scan threads keep one formatting driver busy
+        many = args.e2e_drivers or max(1, shard.usable_cpus() // 5)   # ~4 scan threads keep one formatting driver busy
         for drivers in sorted(set([1, many])):
             out_dir = os.path.join(root, "out{}".format(drivers))
             os.makedirs(out_dir)
@@ -548,7 +548,7 @@ def main():
     ap.add_argument("--e2e-samples", type=int, default=128, help="synthetic BAMs of the end-to-end leg (0: skip it)")
     ap.add_argument("--e2e-batch", type=int, default=16, help="samples per GPU batch in the end-to-end leg")
     ap.add_argument("--e2e-threads", type=int, default=0, help="host threads per driver in the end-to-end leg (0: cores / drivers)")
-    ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 6; also run with 1)")
+    ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 5; also run with 1)")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.e2e_child:

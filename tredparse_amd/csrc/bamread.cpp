@@ -391,9 +391,9 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
 }
 
 
-// The paired-end selection behind tredbam_pe_lengths / tredbam_scan (see include/tredbam.h for the rules).
-int pair_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t tstart, int64_t tend, int32_t span,
-                 std::vector<int32_t>& global_lens, std::vector<int32_t>& target_lens) {
+// The paired-end selection behind tredbam_pe_lengths / tredbam_scan (see include/tredbam.h for the rules): records are
+// fed one by one (add), the lengths come out at the end (finish).
+struct PairTable {
     struct Mate { int32_t pos, end, lead_clip, trail_clip; bool reverse; };
     struct Pair { int n; uint32_t name_at, name_len; Mate m[2]; };
     // query name -> pair, in order of first appearance (the reference walks a dict in that order): an open-addressing
@@ -401,9 +401,10 @@ int pair_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t ts
     // holds ~4 000 records; a std::string and a node allocation per record were a third of the scan's parse time)
     std::vector<Pair> pairs;
     std::vector<char> pool;
-    std::vector<int32_t> table(1 << 13, -1);
-    size_t mask = table.size() - 1;
-    auto find_or_add = [&](const char* name, uint32_t len) -> Pair& {
+    std::vector<int32_t> table = std::vector<int32_t>(1 << 13, -1);
+    size_t mask = (1 << 13) - 1;
+
+    Pair& find_or_add(const char* name, uint32_t len) {
         uint64_t h = 1469598103934665603ull;
         for (uint32_t i = 0; i < len; ++i) h = (h ^ (uint8_t)name[i]) * 1099511628211ull;
         if ((pairs.size() + 1) * 2 > table.size()) {          // keep the load below one half
@@ -431,9 +432,10 @@ int pair_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t ts
         pool.insert(pool.end(), name, name + len);
         pairs.push_back(p);
         return pairs.back();
-    };
-    const int64_t n = walk_region(b, tid, start, end, false, [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
-        if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) return true;   // paired, mapped, not a duplicate
+    }
+
+    void add(int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
+        if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) return;   // paired, mapped, not a duplicate
         const int l_name = r[8];
         const int n_cigar = le16(r + 12);
         Pair& p = find_or_add((const char*)r + 32, (uint32_t)std::max(l_name - 1, 0));
@@ -460,20 +462,33 @@ int pair_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t ts
             m.trail_clip = trail;
         }
         ++p.n;
+    }
+
+    int finish(tredbam* b, int64_t tstart, int64_t tend, int32_t span, std::vector<int32_t>& global_lens,
+               std::vector<int32_t>& target_lens) const {
+        for (const Pair& p : pairs) {
+            if (p.n < 2) continue;
+            const Mate &a = p.m[0], &bb = p.m[1];
+            if (a.reverse || !bb.reverse) continue;            // mapped in +, - orientation
+            if (bb.end < 0) return fail(b, -9, "paired read without an alignment end in the window");
+            const int64_t tlen = ((int64_t)bb.end + bb.trail_clip) - ((int64_t)a.pos - a.lead_clip);
+            if (tlen >= span) continue;
+            if (a.pos < tstart && bb.end > tend) target_lens.push_back((int32_t)tlen);
+            else global_lens.push_back((int32_t)tlen);
+        }
+        return 0;
+    }
+};
+
+int pair_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int64_t tstart, int64_t tend, int32_t span,
+                 std::vector<int32_t>& global_lens, std::vector<int32_t>& target_lens) {
+    PairTable pt;
+    const int64_t n = walk_region(b, tid, start, end, false, [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
+        pt.add(rend, rpos, flag, r);
         return true;
     });
     if (n < 0) return (int)n;
-    for (const Pair& p : pairs) {
-        if (p.n < 2) continue;
-        const Mate &a = p.m[0], &bb = p.m[1];
-        if (a.reverse || !bb.reverse) continue;            // mapped in +, - orientation
-        if (bb.end < 0) return fail(b, -9, "paired read without an alignment end in the window");
-        const int64_t tlen = ((int64_t)bb.end + bb.trail_clip) - ((int64_t)a.pos - a.lead_clip);
-        if (tlen >= span) continue;
-        if (a.pos < tstart && bb.end > tend) target_lens.push_back((int32_t)tlen);
-        else global_lens.push_back((int32_t)tlen);
-    }
-    return 0;
+    return pt.finish(b, tstart, tend, span, global_lens, target_lens);
 }
 
 // One selected read into the scan pools: 2-bit codes + N mask in libtredgpu's read layout (tredgpu.h: ceil(L/16)
@@ -740,20 +755,36 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
         const int64_t win_hi = (int64_t)st.repeat_end + o->pad;
         const int64_t pos_lo = std::max<int64_t>(0, (int64_t)st.repeat_start - o->readlen);
         const int64_t pos_hi = (int64_t)st.repeat_end + o->readlen;
-        // depth of the window (pileup without truncation; see tredbam_pileup_depth_sum)
-        if (o->want_depth) {
-            int64_t total = 0;
-            const int rc = tredbam_pileup_depth_sum(b, st.tid, win_lo, win_hi, &total);
-            u.depth_status = rc;
-            u.depth_sum = rc == 0 ? total : 0;
-        }
-        // read selection: unmapped reads placed in the window (their mate is the anchor) and reads starting within
-        // one read length of the tract; then, from the alternative loci, reads whose MATE lies in the window
+        // ONE walk per locus: the +-pe_reach region of the pair lengths contains the window of the depth and of the
+        // read selection, and a region query starts parsing at the beginning of its 16 kb index bin -- three separate
+        // walks parsed ~11 000 records per locus to use ~4 500 of them.  A record of the large region is in the
+        // window's query exactly when it starts before the window's end and ends behind its start (walk_region's own
+        // test); depth, selection and pairing then see the records they saw before, in the same order.
+        //   depth: pileup without truncation (see tredbam_pileup_depth_sum)
+        //   selection: unmapped reads placed in the window (their mate is the anchor) and reads starting within one
+        //   read length of the tract; then, from the alternative loci, reads whose MATE lies in the window
         std::unordered_map<std::string, int32_t> names;
-        const int64_t n = walk_region(b, st.tid, win_lo, win_hi, false, [&](int32_t, int32_t rpos, uint16_t flag, const uint8_t* r) {
-            if ((flag & 0x4) != 0 || (rpos >= pos_lo && rpos <= pos_hi)) pool_read(b, r, names);
+        const bool with_pe = o->want_pe != 0;
+        const int64_t p_lo = std::max<int64_t>((int64_t)st.repeat_start - o->pe_reach, 0);
+        const int64_t p_hi = (int64_t)st.repeat_end + o->pe_reach;
+        const bool wide = with_pe && p_lo <= win_lo && p_hi >= win_hi;
+        PairTable pt;
+        int64_t depth_total = 0;
+        const int64_t n = walk_region(b, st.tid, wide ? p_lo : win_lo, wide ? p_hi : win_hi, false,
+                                      [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
+            int64_t e = rend;
+            if (rend < 0 || rend <= rpos) e = (int64_t)rpos + 1;
+            if (rpos < win_hi && e > win_lo) {                           // the window's query would return it
+                if (o->want_depth && !(flag & (0x4 | 0x100 | 0x200 | 0x400)) && rend >= 0) depth_total += (int64_t)rend - rpos;
+                if ((flag & 0x4) != 0 || (rpos >= pos_lo && rpos <= pos_hi)) pool_read(b, r, names);
+            }
+            if (wide) pt.add(rend, rpos, flag, r);
             return true;
         });
+        if (o->want_depth) {
+            u.depth_status = n < 0 ? (int32_t)n : 0;
+            u.depth_sum = n < 0 ? 0 : depth_total;
+        }
         if (n == -2 || n == -4) u.status |= TREDBAM_UNIT_NO_FETCH;        // unknown contig / no index: no reads, go on
         else if (n < 0) u.status |= TREDBAM_UNIT_FAILED;
         if (n >= 0 && o->use_alts) {
@@ -769,12 +800,13 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
         }
         u.n_reads = (int32_t)((int64_t)b->sc_read_len.size() - u.read_first);
         // paired-end lengths around the tract
-        if (o->want_pe && !(u.status & TREDBAM_UNIT_FAILED)) {
-            const int64_t p_lo = std::max<int64_t>((int64_t)st.repeat_start - o->pe_reach, 0);
-            const int64_t p_hi = (int64_t)st.repeat_end + o->pe_reach;
+        if (with_pe && !(u.status & TREDBAM_UNIT_FAILED)) {
             const size_t g0 = b->sc_global.size(), t0 = b->sc_target.size();
-            const int rc = pair_lengths(b, st.tid, p_lo, p_hi, (int64_t)st.repeat_start - o->flank,
-                                        (int64_t)st.repeat_end + o->flank, o->span, b->sc_global, b->sc_target);
+            int rc;
+            if (wide) rc = n < 0 ? (int)n : pt.finish(b, (int64_t)st.repeat_start - o->flank, (int64_t)st.repeat_end + o->flank,
+                                                       o->span, b->sc_global, b->sc_target);
+            else rc = pair_lengths(b, st.tid, p_lo, p_hi, (int64_t)st.repeat_start - o->flank,
+                                   (int64_t)st.repeat_end + o->flank, o->span, b->sc_global, b->sc_target);
             if (rc < 0) { b->sc_global.resize(g0); b->sc_target.resize(t0); }
             u.pe_status = (rc == -2 || rc == -4) ? 0 : rc;     // unknown contig / no index: empty lists, as for the reads
             u.n_global = (int32_t)(b->sc_global.size() - g0);
