@@ -151,6 +151,17 @@ int64_t tredbam_details_json(const uint8_t* seq4, const int64_t* seq4_off, const
                              const int64_t* name_off, const int64_t* reads, const uint8_t* tags, const int32_t* hs,
                              int64_t n, char* out, int64_t cap);
 
+/* The JSON text of one sparse distribution of the output -- `P_h1`, `P_h2` (keys "a") or `P_h1h2` (keys "a,b") of
+ * tred.py's per-locus result (models.py:304-317 builds the dicts, tred.py:160-170 prints them) -- as
+ * json.dumps(dict, sort_keys=True, indent=4, separators=(',', ': ')) prints it at nesting `depth`: keys sorted as
+ * strings, values in Python's repr(float) (shortest digits that round-trip; exponent form below 1e-4 and from 1e16).
+ * b == NULL: one-part keys.  Returns the bytes written; -3: `cap` too small; -1: not representable here (a value that
+ * is not finite, a key listed twice) -- the caller's generic encoder then decides; -2: bad arguments. */
+int64_t tredbam_sparse_json(const int32_t* a, const int32_t* b, const double* values, int64_t n, int32_t depth,
+                            char* out, int64_t cap);
+/* repr(float) of one value into out (>= 32 bytes); returns the length, -1 for a value that is not finite (test hook) */
+int tredbam_float_repr(double value, char* out);
+
 #ifdef __cplusplus
 }
 #endif

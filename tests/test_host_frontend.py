@@ -334,6 +334,49 @@ def test_lazy_details_print_like_the_list():
         assert json.loads(out)["tredCalls"]["X.details"] == d.items()
 
 
+def test_sparse_distributions_print_like_the_dicts():
+    """models.SparseDist (P_h1 / P_h2 / P_h1h2 as arrays) reads like the dict and its natively written JSON is what the
+    driver's encoder prints: keys sorted as strings ("10" < "9"), values in Python's repr(float) -- checked on its own
+    over the exponent-form boundaries, subnormals and random bit patterns."""
+    import ctypes as C
+    import random
+    import struct
+    from tredparse_amd.models import SparseDist, sparsify_joint_triples, sparsify_marginal
+    lib = bamio._native()
+    lib.tredbam_float_repr.argtypes, lib.tredbam_float_repr.restype = [C.c_double, C.c_char_p], C.c_int
+    buf = C.create_string_buffer(64)
+    rnd = random.Random(11)
+    xs = [0.0, -0.0, 1.0, 0.1, 1e-4, 9.999e-5, 1e-5, 1e15, 1e16, 9999999999999998.0, 1e22, 5e-324, 2.2250738585072014e-308,
+          1.7976931348623157e308, 1 / 3, 100.0, 123.456, 4.5399929762484854e-05, -2.5e-7]
+    xs += [rnd.random() for _ in range(20000)] + [rnd.random() * 10 ** rnd.randint(-12, 20) for _ in range(20000)]
+    xs += [struct.unpack("<d", struct.pack("<Q", rnd.getrandbits(64)))[0] for _ in range(20000)]
+    for x in xs:
+        if x != x or x in (float("inf"), float("-inf")):
+            assert lib.tredbam_float_repr(x, buf) == -1
+            continue
+        n = lib.tredbam_float_repr(x, buf)
+        assert buf.raw[:n].decode() == repr(x), x
+    rng = np.random.default_rng(4)
+    P = rng.random(300) ** 8
+    P[rng.random(300) < .5] = 0
+    d, lazy = sparsify_marginal(P), sparsify_marginal(P, lazy=True)
+    assert isinstance(d, dict) and isinstance(lazy, SparseDist) and lazy == d and d == dict(lazy) and len(lazy) == len(d) > 20
+    assert "10" in lazy or "11" in lazy or "12" in lazy
+    assert lazy.json_text(2) == tredmod._flat(d, 2)
+    tr = np.stack([rng.integers(1, 60, 300) * 3, rng.integers(1, 300, 300) * 3, rng.random(300) ** 6], 1).astype(float)
+    tr = tr[np.unique(tr[:, :2], axis=0, return_index=True)[1]]
+    dj, lj = sparsify_joint_triples(tr, 7.3, 3), sparsify_joint_triples(tr, 7.3, 3, lazy=True)
+    assert lj == dj and lj.json_text(2) == tredmod._flat(dj, 2) and lj.json_text(0) == tredmod._flat(dj, 0)
+    assert SparseDist(np.zeros(0, np.int64), None, np.zeros(0)).json_text(2) == "{}"
+    twice = SparseDist(np.array([3, 3]), None, np.array([.5, .25]))            # the generic encoder's business
+    assert twice.json_text(2) is None and twice == {"3": .25}
+    notfinite = SparseDist(np.array([1]), None, np.array([float("nan")]))
+    assert notfinite.json_text(2) is None
+    res = {"samplekey": "s", "bam": "b", "tredCalls": {"X.P_h1": lazy, "X.P_h1h2": lj, "X.P_h2": twice, "X.PP": 0.5, "X.1": 3}}
+    ref = {"samplekey": "s", "bam": "b", "tredCalls": {"X.P_h1": d, "X.P_h1h2": dj, "X.P_h2": {"3": .25}, "X.PP": 0.5, "X.1": 3}}
+    assert tredmod.dumps_result(res) == json.dumps(ref, sort_keys=True, indent=4, separators=(",", ": "))
+
+
 def test_scans_run_in_host_threads():
     """run_many's host half: scans in worker threads give what a serial scan gives (the native call releases the
     GIL and every thread has its own file handle)."""

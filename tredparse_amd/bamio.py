@@ -362,6 +362,8 @@ def _native():
             lib.tredbam_scan_pools.restype = C.c_int
             lib.tredbam_details_json.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_int64]
             lib.tredbam_details_json.restype = C.c_int64
+            lib.tredbam_sparse_json.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
+            lib.tredbam_sparse_json.restype = C.c_int64
             _lib = lib
     return _lib or None
 
@@ -378,6 +380,26 @@ SCAN_UNIT_DTYPE = np.dtype([("status", "<i4"), ("n_reads", "<i4"), ("read_first"
                             ("depth_status", "<i4"), ("pe_status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"),
                             ("global_first", "<i8"), ("target_first", "<i8")])
 UNIT_NO_FETCH, UNIT_FAILED = 1, 2
+
+
+def sparse_json(a, b, values, depth):
+    """tredbam_sparse_json: the text of {"a" | "a,b": value} as the driver's JSON prints it at nesting `depth`, or None
+    (library absent / a case for the generic encoder)."""
+    lib = _native()
+    if lib is None:
+        return None
+    n = len(values)
+    a = np.ascontiguousarray(a, np.int32)
+    b = None if b is None else np.ascontiguousarray(b, np.int32)
+    values = np.ascontiguousarray(values, np.float64)
+    cap = 64 + n * (4 * (depth + 1) + 80)
+    buf = C.create_string_buffer(cap)
+    got = lib.tredbam_sparse_json(a.ctypes.data, None if b is None else b.ctypes.data, values.ctypes.data, n, depth, buf, cap)
+    if got == -1:
+        return None
+    if got < 0:
+        raise RuntimeError("tredbam_sparse_json failed ({})".format(got))
+    return buf.raw[:got].decode("ascii")
 
 
 def details_json(seq4, seq4_off, read_len, names, name_off, reads, tags, hs):

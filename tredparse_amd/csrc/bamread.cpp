@@ -11,6 +11,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <charconv>
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -718,6 +720,86 @@ int64_t tredbam_details_json(const uint8_t* seq4, const int64_t* seq4_off, const
     if (end - p < 16) return -3;
     TREDBAM_LIT("\n        ]");
 #undef TREDBAM_LIT
+    return p - out;
+}
+
+// Python's repr(float) (float_repr_style 'short'): the shortest digit string that round-trips -- std::to_chars
+// produces the same digits -- laid out in exponent form when the decimal exponent is <= -5 or >= 16, else positionally
+// with ".0" appended to integers.
+int tredbam_float_repr(double x, char* out) {
+    if (!out || !std::isfinite(x)) return -1;
+    char* p = out;
+    if (std::signbit(x)) { *p++ = '-'; x = -x; }
+    if (x == 0) { memcpy(p, "0.0", 3); return (int)(p - out) + 3; }
+    char sci[40];
+    const auto res = std::to_chars(sci, sci + sizeof sci, x, std::chars_format::scientific);
+    // d[.ddd]e[+-]XX[X]
+    char digits[24];
+    int nd = 0;
+    const char* q = sci;
+    for (; q < res.ptr && *q != 'e'; ++q) if (*q != '.') digits[nd++] = *q;
+    int e10 = 0;
+    {
+        const char* r = q + 1;
+        const bool neg = *r == '-';
+        ++r;
+        for (; r < res.ptr; ++r) e10 = e10 * 10 + (*r - '0');
+        if (neg) e10 = -e10;
+    }
+    if (e10 <= -5 || e10 >= 16) {                      // exponent form: to_chars' own text is Python's
+        const size_t len = (size_t)(res.ptr - sci);
+        memcpy(p, sci, len);
+        return (int)(p - out) + (int)len;
+    }
+    if (e10 >= 0) {
+        for (int i = 0; i <= e10; ++i) *p++ = i < nd ? digits[i] : '0';
+        *p++ = '.';
+        if (nd > e10 + 1) for (int i = e10 + 1; i < nd; ++i) *p++ = digits[i];
+        else *p++ = '0';
+    } else {
+        *p++ = '0'; *p++ = '.';
+        for (int i = 0; i < -e10 - 1; ++i) *p++ = '0';
+        for (int i = 0; i < nd; ++i) *p++ = digits[i];
+    }
+    return (int)(p - out);
+}
+
+int64_t tredbam_sparse_json(const int32_t* a, const int32_t* b, const double* values, int64_t n, int32_t depth,
+                            char* out, int64_t cap) {
+    if (n < 0 || depth < 0 || depth > 16 || !out || cap < 2 || (n > 0 && (!a || !values))) return -2;
+    char* p = out;
+    char* const end = out + cap;
+    if (n == 0) { memcpy(p, "{}", 2); return 2; }
+    struct Item { char key[24]; int klen; int64_t at; };
+    std::vector<Item> items((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        Item& it = items[(size_t)i];
+        it.klen = b ? snprintf(it.key, sizeof it.key, "%d,%d", (int)a[i], (int)b[i]) : snprintf(it.key, sizeof it.key, "%d", (int)a[i]);
+        it.at = i;
+    }
+    std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) {
+        const int c = memcmp(x.key, y.key, (size_t)std::min(x.klen, y.klen));
+        return c != 0 ? c < 0 : x.klen < y.klen;
+    });
+    for (size_t i = 1; i < items.size(); ++i)
+        if (items[i].klen == items[i - 1].klen && memcmp(items[i].key, items[i - 1].key, (size_t)items[i].klen) == 0) return -1;
+    const int pad = 4 * (depth + 1);
+    *p++ = '{'; *p++ = '\n';
+    for (size_t i = 0; i < items.size(); ++i) {
+        if (end - p < pad + 80) return -3;
+        memset(p, ' ', (size_t)pad); p += pad;
+        *p++ = '"';
+        memcpy(p, items[i].key, (size_t)items[i].klen); p += items[i].klen;
+        *p++ = '"'; *p++ = ':'; *p++ = ' ';
+        const int len = tredbam_float_repr(values[items[i].at], p);
+        if (len < 0) return -1;
+        p += len;
+        if (i + 1 < items.size()) *p++ = ',';
+        *p++ = '\n';
+    }
+    if (end - p < 4 * depth + 2) return -3;
+    memset(p, ' ', (size_t)(4 * depth)); p += 4 * depth;
+    *p++ = '}';
     return p - out;
 }
 

@@ -6,6 +6,7 @@ caller's outputs (alleles, CI, PP, label, sparse marginals and joint), `pair_sum
 statistics.  IntegratedCaller keeps the reference's constructor and attributes for single-locus use.
 """
 import logging
+from collections.abc import Mapping
 from math import exp
 
 import numpy as np
@@ -61,11 +62,47 @@ def calc_label(tred, alleles):
     return "missing" if lo == -1 else "ok"
 
 
-def sparsify_marginal(P, epsilon=SMALL_VALUE):
+class SparseDist(Mapping):
+    """A sparse distribution of the output (`P_h1`, `P_h2`: keys "a"; `P_h1h2`: keys "a,b") held as arrays.  Reads
+    like the dict {key string: probability} (built on first use; == against a dict works); json_text() is the dict as
+    tred.to_json prints it, written natively without a Python string and float per entry."""
+    __slots__ = ("a", "b", "values", "_dict")
+
+    def __init__(self, a, b, values):
+        self.a, self.b, self.values, self._dict = a, b, values, None
+
+    def as_dict(self):
+        if self._dict is None:
+            if self.b is None:
+                keys = map(str, self.a.tolist())
+            else:
+                keys = ("%d,%d" % k for k in zip(self.a.tolist(), self.b.tolist()))
+            self._dict = dict(zip(keys, self.values.tolist()))
+        return self._dict
+
+    def __getitem__(self, key):
+        return self.as_dict()[key]
+
+    def __iter__(self):
+        return iter(self.as_dict())
+
+    def __len__(self):
+        return len(self.as_dict())
+
+    def __repr__(self):
+        return repr(self.as_dict())
+
+    def json_text(self, depth):
+        from . import bamio
+        return bamio.sparse_json(self.a, self.b, self.values, depth)
+
+
+def sparsify_marginal(P, epsilon=SMALL_VALUE, lazy=False):
     """models.py:304-317 for a marginal given as a dense array indexed by repeat units."""
     total = float(P.sum())
     keep = np.nonzero(P >= epsilon)[0]
-    return dict(zip(map(str, keep.tolist()), (P[keep] / total).tolist()))
+    d = SparseDist(keep, None, P[keep] / total)
+    return d if lazy else d.as_dict()
 
 
 def sparsify_joint(grid, period, epsilon=SMALL_VALUE):
@@ -79,15 +116,15 @@ def sparsify_joint(grid, period, epsilon=SMALL_VALUE):
     return {"{},{}".format(h1 // period, h2 // period): v / total for (h1, h2), v in P.items() if v >= epsilon}
 
 
-def sparsify_joint_triples(triples, total, period):
+def sparsify_joint_triples(triples, total, period, lazy=False):
     """models.py:279-285 + 304-317 from the kernel's sparse joint output: triples {h1, h2, exp(ml - max)} of the
     distinct pairs >= e^-10 and the sum over all distinct pairs."""
     t = np.asarray(triples)
-    a, b = (t[:, 0].astype(np.int64) // period).tolist(), (t[:, 1].astype(np.int64) // period).tolist()
-    return {"%d,%d" % k: v for k, v in zip(zip(a, b), (t[:, 2] / total).tolist())}
+    d = SparseDist(t[:, 0].astype(np.int64) // period, t[:, 1].astype(np.int64) // period, t[:, 2] / total)
+    return d if lazy else d.as_dict()
 
 
-def format_call(tred, res):
+def format_call(tred, res, lazy=False):
     """The caller's outputs for one unit from an engine.UnitResult, as a dict:
     alleles (units, sorted), lik, PP, CI "lo-hi|lo-hi", label, P_h1, P_h2, P_h1h2 (sparse, keyed by units).
     Raises GridError where the reference's grid raises (the locus is then dropped)."""
@@ -103,9 +140,9 @@ def format_call(tred, res):
         out["alleles"] = sorted((int(call["h1"]) // period, int(call["h2"]) // period))
         out["lik"], out["PP"] = float(call["lik"]), float(call["pp"])
         out["CI"] = "{}-{}|{}-{}".format(*(int(x) for x in call["ci"]))
-        out["P_h1"], out["P_h2"] = sparsify_marginal(res.P_h1), sparsify_marginal(res.P_h2)
+        out["P_h1"], out["P_h2"] = sparsify_marginal(res.P_h1, lazy=lazy), sparsify_marginal(res.P_h2, lazy=lazy)
         if getattr(res, "joint", None) is not None:
-            out["P_h1h2"] = sparsify_joint_triples(res.joint[0], res.joint[1], period)
+            out["P_h1h2"] = sparsify_joint_triples(res.joint[0], res.joint[1], period, lazy=lazy)
         elif res.grid is not None:
             out["P_h1h2"] = sparsify_joint(res.grid, period)
     out["label"] = calc_label(tred, out["alleles"])

@@ -31,7 +31,7 @@ from datetime import date, timedelta
 from . import __version__
 from .bam_parser import Details, scan_sample, tally
 from .meta import BUILDS, TREDsRepo
-from .models import GridError, format_call, pair_summaries
+from .models import GridError, SparseDist, format_call, pair_summaries
 
 logging.basicConfig()
 logger = logging.getLogger(__name__)
@@ -162,7 +162,7 @@ def _skeleton(o, scan):
 def _fill_unit(calls, scan, k, res, repeatpairs, pairs, lazy=False):
     """The 21 keys of one locus from its kernel results (pairs = models.pair_summaries(scan))."""
     t = scan.loci[k]
-    call = format_call(t, res)                       # may raise GridError: the locus is then left out
+    call = format_call(t, res, lazy=lazy)            # may raise GridError: the locus is then left out
     counts, details, rept = tally(scan, k, res.tags, res.hs, repeatpairs=repeatpairs, lazy=lazy)
     n = t.name
     calls[n + ".1"], calls[n + ".2"] = call["alleles"]
@@ -217,7 +217,8 @@ def _genotype(engine, picks, o):
 
 def finish_batch(engine, task_args, scans, lazy_details=False):
     """GPU half + formatting for the scans of one batch; returns the result dicts in task order.  lazy_details:
-    `<locus>.details` as bam_parser.Details views (list-like; to_json prints them natively) instead of lists."""
+    `<locus>.details` as bam_parser.Details views (list-like) and the sparse distributions as models.SparseDist
+    (dict-like) instead of lists and dicts; to_json prints both natively."""
     if not task_args:
         return []
     o0 = _options(task_args[0])
@@ -325,7 +326,7 @@ def dumps_result(results):
     one line per sorted key), every flat dict in one call, `details` natively from the scan's pools."""
     calls = results["tredCalls"]
     sep = ",\n" + _P8
-    scalars = {k: v for k, v in calls.items() if not isinstance(v, (dict, list, Details))}
+    scalars = {k: v for k, v in calls.items() if not isinstance(v, (dict, list, Details, SparseDist))}
     entry = {}
     if scalars:
         lines = json.dumps(scalars, sort_keys=True, separators=(sep, ": "))[1:-1].split(sep)
@@ -335,6 +336,10 @@ def dumps_result(results):
             continue
         if isinstance(v, dict):
             text = _flat(v, 2)
+        elif isinstance(v, SparseDist):
+            text = v.json_text(2)
+            if text is None:
+                text = _flat(v.as_dict(), 2)
         elif isinstance(v, Details):
             text = v.json_text()
             if text is None:
