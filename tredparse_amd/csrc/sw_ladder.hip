@@ -710,6 +710,29 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             if (!full_dump && __builtin_amdgcn_ballot_w64(valid && jl == 15 && still_open(u)) == 0) return true;
             return false;
         };
+        // Steady-state exit.  If every H and E entry of the column at a period boundary c records an alignment that
+        // started inside the repeat (start column >= alen), and one period later every entry one that started at
+        // alen + period or later, the two columns are shifts of each other: an optimal alignment of the later column
+        // moved one period to the left is an alignment of the earlier one and vice versa, so the scores are equal and
+        // the recorded (largest) starts differ by exactly the period -- and then every later column is the shift of the
+        // column one period before it (same letters, same recurrence).  Every later template end then has the score of
+        // this one (the trunk's best does not move, the continuation vectors do not depend on u); the score a template
+        // needs never decreases with u; so after a template end that was DROPPED in that state all later ones would be
+        // dropped too: the strand is done.  (Typically 5-6 periods after a read's peak: that long a horizontal gap out
+        // of the best alignment still beats an alignment that starts afresh inside the repeat.)  Tested only after
+        // dropped template ends -- reads before their peak keep improving -- and never for the dump.
+        int ok_run = 0;
+        auto steady_exit = [&](const uint32_t ends_before) -> bool {
+            if (full_dump || ((cnt_ends ^ ends_before) & 0xFF00u) == 0) { ok_run = 0; return false; }
+            const uint32_t thr = (uint32_t)(alen + (ok_run ? period : 0)) << 9;
+            uint32_t lo = 0x3FFFFu;
+#pragma unroll
+            for (int r = 0; r < R; ++r) lo = min(lo, min((uint32_t)H[r] & 0x3FE00u, (uint32_t)E[r] & 0x3FE00u));
+            if (__builtin_amdgcn_ballot_w64(lo < thr) != 0) { ok_run = 0; return false; }
+            if (ok_run) return true;
+            ok_run = 1;
+            return false;
+        };
         if (period == 3 && max_units > 0) {
             // Period-3 ladders (27 of the 30 loci): inside the repeat the column letters cycle through the motif, so
             // the three profile rows are picked once per strand and the column loop is unrolled by the period --
@@ -730,14 +753,16 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 sweep_at<R>(J, P2, H, E, T, col + 2, row0, geK, c0, row0g, rowbuf);
                 col += 3;
                 cnt_cols += 3;
-                if (template_end(col - 1) || col >= ncols) break;
+                const uint32_t ends_before = cnt_ends;
+                if (template_end(col - 1) || col >= ncols || steady_exit(ends_before)) break;
             }
         } else {
             for (int col = 0; col < ncols; ++col) {
                 sweep_letter<R>(letter_from(tw, col), J, H, E, T, col, row0, geK, c0, row0g, rowbuf);
                 ++cnt_cols;
                 if (col != next_end) continue;
-                if (template_end(col)) break;
+                const uint32_t ends_before = cnt_ends;
+                if (template_end(col) || (max_units > 0 && steady_exit(ends_before))) break;
             }
         }
     }
@@ -769,7 +794,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
 // at all are finished on the spot (no candidate: tag NONE).  The others are packed four to a wavefront by
 // (ladder, class, level) across the units of a batch -- a read's alignment does not depend on its wave-mates, so
 // only the last quad of each bin can be partial (per-unit packing left 7 % of the read slots of the bench batch
-// empty).  The level is the read's count of 6-mers present in the templates, in steps of 6: that count caps the
+// empty).  The level is the read's count of 6-mers present in the templates, in steps of 6 (32 levels): that count caps the
 // read's score, a template of length T needs a score of min(L, T)/2, so reads of one level stop needing the
 // trunk at about the same template and the wave can leave the strand together (strand exit in sw_cont_kernel).
 // Bin b = (3 * ladder + k) * SW_LEVELS + level holds class {1, 3, 2}[k].
@@ -778,7 +803,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
 //   scatter_kernel      each unit writes its reads' indices into its runs of the bins
 //   fill_quads_kernel   one thread per quad: its bin by binary search over the quad offsets
 constexpr int BIN_STRIDE = 16;   // ints: every bin counter on its own 64-byte line
-constexpr int SW_LEVELS = 16;
+constexpr int SW_LEVELS = 32;
 constexpr int UNIT_BINS = 3 * SW_LEVELS;   // bins one unit can feed
 __device__ __forceinline__ int class_slot(int cls) { return cls == 1 ? 0 : (cls == 3 ? 1 : 2); }
 
@@ -799,7 +824,7 @@ __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_
     if (filt) {
         for (int k = threadIdx.x; k < 256; k += (int)blockDim.x) bm[k >> 7][k & 127] = a.seqw[ld->kmer_off[k >> 7] + (k & 127)];
     }
-    if (threadIdx.x < UNIT_BINS) hist[threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < UNIT_BINS; k += (int)blockDim.x) hist[k] = 0;
     __syncthreads();
     for (int rd = r0 + (int)threadIdx.x; rd < r1; rd += (int)blockDim.x) {
         int cls = ld->n_strands >= 2 ? 3 : 1;
@@ -837,12 +862,12 @@ __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_
         }
     }
     __syncthreads();
-    if (threadIdx.x < UNIT_BINS) {
+    for (int k = threadIdx.x; k < UNIT_BINS; k += (int)blockDim.x) {
         // the unit's run inside each of its bins starts where the bin's total stood when the unit arrived
-        const int n = hist[threadIdx.x];
+        const int n = hist[k];
         int at = 0;
-        if (n) at = atomicAdd(bin_total + ((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE, n);
-        unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x] = at;
+        if (n) at = atomicAdd(bin_total + ((size_t)lad * UNIT_BINS + k) * BIN_STRIDE, n);
+        unit_cnt[(size_t)g * UNIT_BINS + k] = at;
     }
 }
 
@@ -884,8 +909,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(SwArgs a, const uint8_t* re
     if (g >= a.n_units) return;
     const int lad = min(max(a.unit_ladder[g], 0), a.n_ladders - 1);
     __shared__ int pos[UNIT_BINS];
-    if (threadIdx.x < UNIT_BINS)
-        pos[threadIdx.x] = bins[((size_t)lad * UNIT_BINS + threadIdx.x) * BIN_STRIDE + 1] + unit_cnt[(size_t)g * UNIT_BINS + threadIdx.x];
+    for (int k = threadIdx.x; k < UNIT_BINS; k += (int)blockDim.x)
+        pos[k] = bins[((size_t)lad * UNIT_BINS + k) * BIN_STRIDE + 1] + unit_cnt[(size_t)g * UNIT_BINS + k];
     __syncthreads();
     const int r0 = a.unit_read_off[g], r1 = a.unit_read_off[g + 1];
     for (int r = r0 + (int)threadIdx.x; r < r1; r += (int)blockDim.x) {
