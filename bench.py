@@ -304,7 +304,7 @@ def rank_main(args):
                                  "cycles on gfx950, profiles/r02_ubench_valu.txt).  effective_TCUPS = SURVEY 8(d) "
                                  "brute-force cells / the same time: {:.1f}x more cells than are swept, the effect "
                                  "of the exact shortcuts (shared-prefix ladder, suffix continuation vectors, 6-mer "
-                                 "strand filter, score-bound pruning), not a hardware rate".format(alg / max(swept, 1)),
+                                 "strand filter, score-bound pruning, steady-state strand exit), not a hardware rate".format(alg / max(swept, 1)),
                          "avg_launch_ms": sw_s * 1e3, "swept_cells_per_launch": swept,
                          "lane_cells_per_launch": lanes, "lane_occupancy": swept / max(lanes, 1),
                          "algorithmic_cells_per_launch": alg, "effective_TCUPS": alg / sw_s / 1e12,
