@@ -108,6 +108,42 @@ def test_all_loci_tags_against_oracle(ctx, loci):
     assert (tag == 4).sum() > 0 and (tag == 1).sum() > 0 and (tag == 5).sum() > 0
 
 
+@pytest.mark.parametrize("scoring", [(1, 5, 7, 2), (2, 3, 5, 2), (1, 1, 2, 1)])
+def test_pruned_path_equals_argmax_of_the_unpruned_dump(ctx, loci, scoring):
+    """Every exact shortcut of the production kernel (6-mer strand filter, exact-score drop, strand exit, steady-state
+    exit, deferred best-cell resolution) against the kernel variant that has none of them: the per-template dump
+    (each of its records is checked against ssw.c elsewhere) gives (score, tag) of every (read, template); the arg-max
+    by (score, -units), forward strand before reverse complement, must be what the production launch returns --
+    ~60 000 reads over all loci incl. tracts longer than a read, without the CPU oracle's cost."""
+    sp = synth.SynthParams(coverage=30, expanded_max=150, expanded_frac=0.3)
+    b = synth.build_batch(1234 + scoring[1], loci, 20, sp, workers=8)
+    ctx.set_ladders(b.ladders)
+    n = b.n_reads
+    params = _lib.SwParams(scoring[0], scoring[1], scoring[2], scoring[3], 9, 0, 150, 0)
+    tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
+    ctx.sw_classify(_lib.MEM_HOST, b.packed, b.read_off, b.read_len, n, b.unit_read_off, b.unit_ladder, b.n_units,
+                    params, tag, h, sc)
+    nt = 2 * max(l[3] for l in b.ladders)
+    dump = np.zeros((n, nt, 6), np.int16)
+    t2 = np.zeros(n, np.uint8); h2 = np.zeros(n, np.int16); s2 = np.zeros(n, np.int16)
+    ctx.sw_classify(_lib.MEM_HOST, b.packed, b.read_off, b.read_len, n, b.unit_read_off, b.unit_ladder, b.n_units,
+                    params, t2, h2, s2, dump, nt)
+    assert np.array_equal(tag, t2) and np.array_equal(h, h2) and np.array_equal(sc, s2)      # the two kernel variants
+    k = np.arange(nt)
+    units, strand = k // 2 + 1, k % 2
+    score, dtag = dump[:, :, 0].astype(np.int64), dump[:, :, 5].astype(np.int64)
+    key = np.where(dtag != _lib.TAG_NONE, (score << 11) | ((511 - units)[None, :] << 1) | (1 - strand)[None, :], -1)
+    at = key.argmax(1)
+    rows = np.arange(n)
+    none = key[rows, at] < 0
+    want_tag = np.where(none, _lib.TAG_NONE, dtag[rows, at])
+    want_h = np.where(none, 0, units[at])
+    want_sc = np.where(none, 0, score[rows, at])
+    bad = np.nonzero((tag != want_tag) | (h != want_h) | (sc != want_sc))[0]
+    assert len(bad) == 0, (scoring, len(bad), bad[:5], tag[bad[:5]], h[bad[:5]], want_tag[bad[:5]], want_h[bad[:5]])
+    assert n > 40000 and all((tag == t).sum() > 100 for t in (1, 2, 3, 4))
+
+
 def test_device_memory_path_matches_host_path(ctx, loci):
     torch = pytest.importorskip("torch")
     _model(ctx)
