@@ -18,6 +18,76 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def draw_round(rng, loci, synth, po, samples=(1, 4)):
+    """One random batch: (batch, reads, unit_read_off, unit_ladder, clip, scoring, readlen)."""
+    readlen = int(rng.choice([36, 75, 100, 125, 150, 150, 150, 250]))
+    p = synth.SynthParams(coverage=float(rng.choice([10, 30, 60])), readlen=readlen,
+                          sub=float(rng.choice([0.0, 0.01, 0.03])), indel=float(rng.choice([0.0, 0.001, 0.01])),
+                          nrate=float(rng.choice([0.0, 0.005, 0.05])), min_units=int(rng.integers(1, 8)),
+                          max_units=int(rng.integers(20, 70)), expanded_max=int(rng.choice([0, 120, 200])),
+                          expanded_frac=0.3)
+    sel = [l for l in loci if 36 + len(l["repeat"]) * -(-readlen // len(l["repeat"])) <= 511]
+    sel = [sel[i] for i in rng.permutation(len(sel))[:int(rng.integers(4, len(sel) + 1))]]
+    b = synth.build_batch(int(rng.integers(1 << 30)), sel, int(rng.integers(samples[0], samples[1])), p, workers=8)
+    reads = [synth.decode(r) for r in b.codes]
+    uro, ulad = list(b.unit_read_off), list(b.unit_ladder)
+    # adversarial units: pure repeats in any phase / strand, exact template windows, chimeras, N runs, junk
+    for _ in range(4):
+        lad = int(rng.integers(len(b.ladders)))
+        prefix, rep, suffix, mu = b.ladders[lad]
+        rep_c = rep.replace("N", "C")
+        extra = []
+        for _ in range(25):
+            kind = int(rng.integers(9))
+            u = int(rng.integers(1, mu + 1))
+            tmpl = prefix + rep_c * u + suffix
+            if kind == 0:
+                ph = int(rng.integers(len(rep_c)))
+                r = (rep_c * (readlen // len(rep_c) + 2))[ph:ph + readlen]
+            elif kind == 1:
+                o = int(rng.integers(0, max(1, len(tmpl) - 10)))
+                r = tmpl[o:o + readlen]
+            elif kind == 2:
+                other = b.ladders[int(rng.integers(len(b.ladders)))]
+                r = (tmpl[:readlen // 2] + other[0] + other[1].replace("N", "A") * 4 + other[2])[:readlen]
+            elif kind == 3:
+                r = "".join("ACGT"[i] for i in rng.integers(0, 4, readlen))
+            elif kind == 4:
+                cut = int(rng.integers(1, readlen))
+                r = (tmpl * 3)[:cut] + "N" * (readlen - cut)
+            elif kind == 5:
+                r = (rep_c * u)[:readlen // 2] + "ACGT"[int(rng.integers(4))] + (rep_c * (mu + 2))[:readlen // 2]
+            elif kind == 6:
+                r = "N" * int(rng.integers(1, readlen + 1))
+            else:
+                # indels at the repeat / suffix junction (where an alignment leaves the trunk for the suffix
+                # continuation vectors): deletion, insertion, or both back to back
+                j = len(prefix) + len(rep_c) * u + int(rng.integers(-4, 5))
+                a, c = tmpl[:max(j, 0)], tmpl[max(j, 0):]
+                mode = int(rng.integers(3))
+                if mode != 1:
+                    c = c[int(rng.integers(1, 7)):]
+                if mode != 0:
+                    a = a + "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 7))))
+                r = (a + c)[max(0, len(a) - readlen + int(rng.integers(4, 30))):]
+            if rng.random() < 0.5:
+                r = po.rc(r)
+            if r:
+                extra.append(r[:readlen])
+        reads += extra
+        uro.append(len(reads))
+        ulad.append(lad)
+    n = len(reads)
+    unit_read_off, unit_ladder = np.asarray(uro, np.int32), np.asarray(ulad, np.int32)
+    clip = bool(rng.random() < 0.3)
+    scoring = [(1, 5, 7, 2)] * 3 + [(2, 3, 5, 2), (1, 4, 6, 1), (1, 1, 2, 1), (3, 5, 7, 2), (1, 9, 12, 3),
+                                      (2, 6, 3, 1), (1, 3, 2, 2), (3, 2, 4, 1)]
+    scoring = scoring[int(rng.integers(len(scoring)))]
+    if clip:   # --useclippedreads: ragged lengths exercise the per-read REPT cut-off (bam_parser.py:154-155)
+        reads = [r[int(rng.integers(0, max(1, len(r) // 3))):] for r in reads]
+    return b, reads, unit_read_off, unit_ladder, clip, scoring, readlen
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -33,72 +103,9 @@ def main():
     tags = np.zeros(6, np.int64)
     t0 = time.time()
     for k in range(rounds):
-        readlen = int(rng.choice([36, 75, 100, 125, 150, 150, 150, 250]))
-        p = synth.SynthParams(coverage=float(rng.choice([10, 30, 60])), readlen=readlen,
-                              sub=float(rng.choice([0.0, 0.01, 0.03])), indel=float(rng.choice([0.0, 0.001, 0.01])),
-                              nrate=float(rng.choice([0.0, 0.005, 0.05])), min_units=int(rng.integers(1, 8)),
-                              max_units=int(rng.integers(20, 70)), expanded_max=int(rng.choice([0, 120, 200])),
-                              expanded_frac=0.3)
-        sel = [l for l in loci if 36 + len(l["repeat"]) * -(-readlen // len(l["repeat"])) <= 511]
-        sel = [sel[i] for i in rng.permutation(len(sel))[:int(rng.integers(4, len(sel) + 1))]]
-        b = synth.build_batch(int(rng.integers(1 << 30)), sel, int(rng.integers(1, 4)), p, workers=8)
+        b, reads, unit_read_off, unit_ladder, clip, scoring, readlen = draw_round(rng, loci, synth, po)
         ctx.set_ladders(b.ladders)
-        reads = [synth.decode(r) for r in b.codes]
-        uro, ulad = list(b.unit_read_off), list(b.unit_ladder)
-        # adversarial units: pure repeats in any phase / strand, exact template windows, chimeras, N runs, junk
-        for _ in range(4):
-            lad = int(rng.integers(len(b.ladders)))
-            prefix, rep, suffix, mu = b.ladders[lad]
-            rep_c = rep.replace("N", "C")
-            extra = []
-            for _ in range(25):
-                kind = int(rng.integers(9))
-                u = int(rng.integers(1, mu + 1))
-                tmpl = prefix + rep_c * u + suffix
-                if kind == 0:
-                    ph = int(rng.integers(len(rep_c)))
-                    r = (rep_c * (readlen // len(rep_c) + 2))[ph:ph + readlen]
-                elif kind == 1:
-                    o = int(rng.integers(0, max(1, len(tmpl) - 10)))
-                    r = tmpl[o:o + readlen]
-                elif kind == 2:
-                    other = b.ladders[int(rng.integers(len(b.ladders)))]
-                    r = (tmpl[:readlen // 2] + other[0] + other[1].replace("N", "A") * 4 + other[2])[:readlen]
-                elif kind == 3:
-                    r = "".join("ACGT"[i] for i in rng.integers(0, 4, readlen))
-                elif kind == 4:
-                    cut = int(rng.integers(1, readlen))
-                    r = (tmpl * 3)[:cut] + "N" * (readlen - cut)
-                elif kind == 5:
-                    r = (rep_c * u)[:readlen // 2] + "ACGT"[int(rng.integers(4))] + (rep_c * (mu + 2))[:readlen // 2]
-                elif kind == 6:
-                    r = "N" * int(rng.integers(1, readlen + 1))
-                else:
-                    # indels at the repeat / suffix junction (where an alignment leaves the trunk for the suffix
-                    # continuation vectors): deletion, insertion, or both back to back
-                    j = len(prefix) + len(rep_c) * u + int(rng.integers(-4, 5))
-                    a, c = tmpl[:max(j, 0)], tmpl[max(j, 0):]
-                    mode = int(rng.integers(3))
-                    if mode != 1:
-                        c = c[int(rng.integers(1, 7)):]
-                    if mode != 0:
-                        a = a + "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 7))))
-                    r = (a + c)[max(0, len(a) - readlen + int(rng.integers(4, 30))):]
-                if rng.random() < 0.5:
-                    r = po.rc(r)
-                if r:
-                    extra.append(r[:readlen])
-            reads += extra
-            uro.append(len(reads))
-            ulad.append(lad)
         n = len(reads)
-        unit_read_off, unit_ladder = np.asarray(uro, np.int32), np.asarray(ulad, np.int32)
-        clip = bool(rng.random() < 0.3)
-        scoring = [(1, 5, 7, 2)] * 3 + [(2, 3, 5, 2), (1, 4, 6, 1), (1, 1, 2, 1), (3, 5, 7, 2), (1, 9, 12, 3),
-                                          (2, 6, 3, 1), (1, 3, 2, 2), (3, 2, 4, 1)]
-        scoring = scoring[int(rng.integers(len(scoring)))]
-        if clip:   # --useclippedreads: ragged lengths exercise the per-read REPT cut-off (bam_parser.py:154-155)
-            reads = [r[int(rng.integers(0, max(1, len(r) // 3))):] for r in reads]
         packed, woff, rlen = _lib.pack_reads(reads)
         tag = np.zeros(n, np.uint8); h = np.zeros(n, np.int16); sc = np.zeros(n, np.int16)
         ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, n, unit_read_off, unit_ladder, len(unit_ladder),
