@@ -718,7 +718,12 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             int* dst = reinterpret_cast<int*>(gobs);
             for (int k = tid; k < (int)(sizeof(Obs) / sizeof(int)); k += NT) dst[k] = src[k];
         }
-        const PairCtx C = make_ctx(d, M, &S.obs, S.pdf, a.target_lens);
+        // the step-size row of this period in LDS (the KDE's kernel table is dead by now): every spanning / partial term
+        // of the row and near tables below looks it up, and from global memory each look-up sat in the terms' chain
+        for (int k = tid; k < 37; k += NT) S.kern[k] = M.step[d.period <= 6 ? d.period - 1 : 5][k];
+        __syncthreads();
+        PairCtx C = make_ctx(d, M, &S.obs, S.pdf, a.target_lens);
+        C.step = S.kern;
 
         // ---- rows: count of valid h2 per h1 (h1 <= h2), dump offsets; per-row "far" terms ----
         // For h2 >= h_far the spanning and partial terms no longer depend on h2 (S(k|h2) = 0 for every
