@@ -152,15 +152,18 @@ __device__ __forceinline__ double safe_log(const PairCtx& C, double p) {
     return pos_log(p);
 }
 
-// spanning + partial terms (models.py:192-207)
-__device__ void eval_reads(const PairCtx& C, int h1, int h2, double& ml1, double& ml2) {
+// spanning + partial terms (models.py:192-207), evaluated by a group of G adjacent lanes (G a power of two <= 32, the
+// same for all of them; lane g of the group takes observations g, g + G, ... and a butterfly adds the parts up, so
+// every lane of the group returns the sums).  G = 1 is the plain serial sum in the reference's order; small grids use
+// larger groups: with one thread per row a 20-row grid kept 20 of the workgroup's 128 lanes busy for 30 iterations.
+__device__ void eval_reads(const PairCtx& C, int h1, int h2, double& ml1, double& ml2, int g = 0, int G = 1) {
     const Obs& O = *C.obs;
     ml1 = 0;
     if (O.nF > 0) {
         const double pi1 = stutter_prob(*C.M, C.period, h1), pi2 = stutter_prob(*C.M, C.period, h2);
         const int s1 = max(0, C.t2 - h1), s2 = max(0, C.t2 - h2);
         const double alpha = (s1 + s2) ? s1 * 1. / (s1 + s2) : .5;
-        for (int i = 0; i < O.nF; ++i) {
+        for (int i = g; i < O.nF; i += G) {
             const int k = O.fullK[i];
             const double p = alpha * spanning_at(C.step, pi1, h1, k) + (1 - alpha) * spanning_at(C.step, pi2, h2, k);
             ml1 += safe_log(C, p) * O.fullC[i];
@@ -172,11 +175,15 @@ __device__ void eval_reads(const PairCtx& C, int h1, int h2, double& ml1, double
         const double pi1 = stutter_prob(*C.M, C.period, hp1), pi2 = stutter_prob(*C.M, C.period, hp2);
         const int s1 = min(h1, C.t1), s2 = min(h2, C.t1);
         const double alpha = (s1 + s2) ? s1 * 1. / (s1 + s2) : .5;
-        for (int i = 0; i < O.nP; ++i) {
+        for (int i = g; i < O.nP; i += G) {
             const int k = O.partK[i];
             const double p = alpha * partial_at(C.step, pi1, hp1, k) + (1 - alpha) * partial_at(C.step, pi2, hp2, k);
             ml2 += safe_log(C, p) * O.partC[i];
         }
+    }
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        ml1 += __shfl_xor(ml1, o, 64);
+        ml2 += __shfl_xor(ml2, o, 64);
     }
 }
 
@@ -730,7 +737,11 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         // observed size, alpha is pinned, pdf_partial is clipped at max_partial): bit-identical values,
         // evaluated once per row instead of once per pair.
         int* row_off = reinterpret_cast<int*>(slot + L.rowoff);
-        for (int i = tid; i < nrow; i += NT) {
+        // lanes per table entry (eval_reads): as many as keep the workgroup busy, at most 32
+        int G = 1;
+        while (G < 32 && nrow * (2 * G) <= NT) G *= 2;
+        int gl = tid & (G - 1);
+        for (int i = tid / G; i < nrow; i += NT / G) {
             const int h1 = axis_value(ax1, S.obs.base, period, i);
             int cnt = 0;   // columns with h2 >= h1: base entries one by one, the arithmetic part in closed form
             if (u.ploidy == 1) cnt = 1;
@@ -739,11 +750,13 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
                 const int m0 = h1 <= ax2.start ? 0 : (h1 - ax2.start + period - 1) / period;
                 cnt += max(0, ax2.n - m0);
             }
-            S.row_off[i] = cnt;
             double f1, f2;
-            eval_reads(C, h1, haploid ? h1 : max(d.h_far, h1), f1, f2);   // (one allele: the only column is h2 = h1)
-            slot[L.far1 + i] = f1;
-            slot[L.far2 + i] = f2;
+            eval_reads(C, h1, haploid ? h1 : max(d.h_far, h1), f1, f2, gl, G);   // (one allele: the only column is h2 = h1)
+            if (gl == 0) {
+                S.row_off[i] = cnt;
+                slot[L.far1 + i] = f1;
+                slot[L.far2 + i] = f2;
+            }
         }
         __syncthreads();
         if (tid < 64) {   // exclusive scan of the row counts: wavefront 0, 64 rows per step
@@ -767,14 +780,19 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             for (int i = tid; i <= nrow; i += NT) row_off[i] = S.row_off[i];
 
         // ---- spanning + partial terms of the near columns
-        for (int k = tid; k < nrow * d.n_near; k += NT) {
+        G = 1;
+        while (G < 32 && nrow * d.n_near * (2 * G) <= NT) G *= 2;
+        gl = tid & (G - 1);
+        for (int k = tid / G; k < nrow * d.n_near; k += NT / G) {
             const int i = k / d.n_near, c = k - i * d.n_near;
             const int h1 = axis_value(ax1, S.obs.base, period, i);
             const int h2 = c < d.nbn ? S.obs.base[c] : ax2.start + (c - d.nbn) * period;
             double f1 = 0, f2 = 0;
-            if (h1 <= h2) eval_reads(C, h1, h2, f1, f2);
-            slot[L.near1 + k] = f1;
-            slot[L.near2 + k] = f2;
+            if (h1 <= h2) eval_reads(C, h1, h2, f1, f2, gl, G);     // (h1, h2 are the group's: all its lanes or none)
+            if (gl == 0) {
+                slot[L.near1 + k] = f1;
+                slot[L.near2 + k] = f2;
+            }
         }
         // ---- the repeat-only table
         {
