@@ -257,3 +257,34 @@ def test_sparse_joint_matches_dense_dump(ctx):
                 assert key in want and abs(v / jt[i] - want[key]) <= 1e-9, (c["name"], key)
             if cap_each >= jn[i]:
                 assert len(got) == len(want)
+
+
+def test_exact_tie_between_a_near_and_a_far_column(ctx):
+    """Found by tools/fuzz_hist.py (seed 20261018, case 469): 300 repeat-only reads push the Poisson term of every
+    long-allele pair onto its floor (log e^-100), the spanning / partial terms of a near column have already stopped
+    depending on h2, so two pairs of one row have EXACTLY the same likelihood in the reference, which then keeps the
+    first in enumeration order.  The near and the far table must therefore add their terms up in the same order (one
+    lane-group size for both in grid_prepare_kernel): a last-bit difference picked (90, 111) instead of (90, 102)."""
+    _set_model(ctx)
+    locus = next(l for l in synth.load_loci() if l["name"] == "CCD")
+    chrom, span = locus["repeat_location"].split(":")
+    start, end = (int(x) for x in span.split("-"))
+    c = {"locus_rec": locus, "readlen": 100, "ploidy": 2, "depth": 12.0, "maxinsert": 300, "fullsearch": False,
+         "full": {24: 15, 30: 17},
+         "partial": {30: 3, 11: 5, 29: 7, 20: 6, 3: 7, 34: 1, 9: 1, 27: 5, 14: 7, 33: 3, 21: 4, 22: 7, 26: 3, 25: 7, 28: 3,
+                     32: 4, 1: 4, 12: 7, 6: 7, 5: 3},
+         "rept": 300, "global_lens": [], "target_lens": [], "ref_len": end - start + 1, "minpe": end - start + 20}
+    w = lo.Caller(len(locus["repeat"]), c["readlen"], c["ploidy"], c["depth"], c["full"], c["partial"], c["rept"],
+                  c["global_lens"], c["target_lens"], c["ref_len"], c["minpe"], maxinsert=c["maxinsert"],
+                  fullsearch=c["fullsearch"]).evaluate()
+    mls = np.asarray(w["mls"], np.float64)
+    tot = mls[:, 2:].sum(1)
+    assert (tot == tot.max()).sum() >= 2, "the reference no longer has a tie here"
+    units, full, pref, rept, gl, tl = _case_inputs([c], 128)
+    calls = np.zeros(1, _lib.CALL_DTYPE)
+    goff = np.array([0, len(mls)], np.int64)
+    dump = np.zeros((len(mls), 6), np.float64)
+    ctx.likelihood_grid(_lib.MEM_HOST, units, 1, 128, full, pref, rept, gl, len(gl), tl, len(tl), calls, goff, dump, None, 0)
+    assert calls[0]["status"] == 0 and (int(calls[0]["h1"]), int(calls[0]["h2"])) == tuple(w["alleles"]) == (90, 102)
+    got = dump[:, 2:].sum(1)
+    assert (got == got.max()).sum() == (tot == tot.max()).sum()          # the tie is a tie on the device too

@@ -738,9 +738,13 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         // evaluated once per row instead of once per pair.
         int* row_off = reinterpret_cast<int*>(slot + L.rowoff);
         // lanes per table entry (eval_reads): as many as keep the workgroup busy, at most 32
+        // ONE group size for the row table and the near table: where the reference's terms are the same numbers for
+        // two columns of a row (a near column whose terms have already stopped depending on h2, and the far ones) their
+        // sums must come out bit-identical here too -- same lanes, same order -- or an exact tie of two pairs'
+        // likelihoods (which the reference breaks by enumeration order) would be broken by the last bit
         int G = 1;
-        while (G < 32 && nrow * (2 * G) <= NT) G *= 2;
-        int gl = tid & (G - 1);
+        while (G < 32 && nrow * (1 + d.n_near) * (2 * G) <= NT) G *= 2;
+        const int gl = tid & (G - 1);
         for (int i = tid / G; i < nrow; i += NT / G) {
             const int h1 = axis_value(ax1, S.obs.base, period, i);
             int cnt = 0;   // columns with h2 >= h1: base entries one by one, the arithmetic part in closed form
@@ -780,9 +784,6 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             for (int i = tid; i <= nrow; i += NT) row_off[i] = S.row_off[i];
 
         // ---- spanning + partial terms of the near columns
-        G = 1;
-        while (G < 32 && nrow * d.n_near * (2 * G) <= NT) G *= 2;
-        gl = tid & (G - 1);
         for (int k = tid / G; k < nrow * d.n_near; k += NT / G) {
             const int i = k / d.n_near, c = k - i * d.n_near;
             const int h1 = axis_value(ax1, S.obs.base, period, i);
