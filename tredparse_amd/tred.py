@@ -261,7 +261,8 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch."""
     own = pool is None and threads > 1 and len(task_args) > 1
     # the first GPU batch is only as large as one round of the scan threads: nothing else can start before it is in
-    first = min(batch, max(1, threads)) if (own or pool is not None) else batch
+    # (only when there is more than one batch anyway: an extra GPU call costs more than it hides on small inputs)
+    first = min(batch, max(1, threads)) if (own or pool is not None) and len(task_args) > batch else batch
     chunks = [task_args[:first]] + [task_args[i:i + batch] for i in range(first, len(task_args), batch)]
     chunks = [c for c in chunks if c]
     ex = ThreadPoolExecutor(max_workers=threads) if own else pool
