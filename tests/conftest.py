@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built libraries (they are git-ignored): build them once, as __graft_entry__.build() does
+    pkg = os.path.join(ROOT, "tredparse_amd")
+    if not all(os.path.exists(os.path.join(pkg, n)) for n in ("libtredgpu.so", "libtredbam.so")):
+        import subprocess
+        subprocess.call(["make", "-C", os.path.join(pkg, "csrc")], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
