@@ -183,6 +183,8 @@ def rank_main(args):
     import torch
     from tredparse_amd import _lib
     from tredparse_amd.engine import load_model
+    n_dev = max(1, torch.cuda.device_count())
+    local_rank %= n_dev                                         # (more ranks than devices: ranks share them)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
