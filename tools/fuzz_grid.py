@@ -18,10 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    max_pairs = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+def campaign(rounds=6, seed=1, max_pairs=20000):
+    """Runs the campaign and returns its summary (tests/test_fuzz_gpu.py runs a fixed-seed slice of it)."""
     import torch
     if torch.cuda.is_available():
         torch.cuda.init()
@@ -79,9 +77,16 @@ def main():
                 bad += 1
                 print("MISMATCH round", k, "unit", u, locus["name"], "ploidy", int(up["ploidy"]), c, res.get("alleles"),
                       res.get("CI"), res.get("lik"), file=sys.stderr)
-    print(json.dumps({"units_checked": checked, "units_skipped_big": skipped, "mismatches": bad, "rounds": rounds,
-                      "seed": seed, "max_abs_diff_lik_or_pp": worst, "seconds": round(time.time() - t0, 1)}))
-    return 1 if bad else 0
+    ctx.close()
+    return {"units_checked": checked, "units_skipped_big": skipped, "mismatches": bad, "rounds": rounds,
+            "seed": seed, "max_abs_diff_lik_or_pp": worst, "seconds": round(time.time() - t0, 1)}
+
+
+def main():
+    a = [int(x) for x in sys.argv[1:4]]
+    res = campaign(*a)
+    print(json.dumps(res))
+    return 1 if res["mismatches"] else 0
 
 
 if __name__ == "__main__":

@@ -43,9 +43,8 @@ def draw_case(rng, loci):
     return c
 
 
-def main():
-    cases_n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def campaign(cases_n=300, seed=1):
+    """Runs the campaign and returns its summary (tests/test_fuzz_gpu.py runs a fixed-seed slice of it)."""
     import torch
     if torch.cuda.is_available():
         torch.cuda.init()
@@ -136,10 +135,16 @@ def main():
             print("MISMATCH case", i, l["name"], {k: c[k] for k in ("readlen", "ploidy", "depth", "maxinsert", "fullsearch",
                   "full", "partial", "rept")}, len(c["global_lens"]), len(c["target_lens"]), call, w.get("alleles"),
                   w.get("CI"), file=sys.stderr)
-    print(json.dumps({"cases": n, "mismatches": bad, "cases_the_reference_raises_on": singular, "no_evidence_cases": empty,
-                      "pairs_compared": int(sum(len(w.get("mls", [])) for w in want)), "max_abs_diff_ml_terms": worst,
-                      "seed": seed}))
-    return 1 if bad else 0
+    ctx.close()
+    return {"cases": n, "mismatches": bad, "cases_the_reference_raises_on": singular, "no_evidence_cases": empty,
+            "pairs_compared": int(sum(len(w.get("mls", [])) for w in want)), "max_abs_diff_ml_terms": worst,
+            "seed": seed}
+
+
+def main():
+    res = campaign(*[int(x) for x in sys.argv[1:3]])
+    print(json.dumps(res))
+    return 1 if res["mismatches"] else 0
 
 
 if __name__ == "__main__":

@@ -88,9 +88,8 @@ def draw_round(rng, loci, synth, po, samples=(1, 4)):
     return b, reads, unit_read_off, unit_ladder, clip, scoring, readlen
 
 
-def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def campaign(rounds=12, seed=1):
+    """Runs the campaign and returns its summary (tests/test_fuzz_gpu.py runs a fixed-seed slice of it)."""
     import torch
     if torch.cuda.is_available():
         torch.cuda.init()
@@ -151,9 +150,16 @@ def main():
         if len(bad):
             print("MISMATCH round", k, "readlen", readlen, "clip", clip, "scoring", scoring, bad[:5], tag[bad[:5]], h[bad[:5]], sc[bad[:5]], cls[bad[:5]],
                   file=sys.stderr)
-    print(json.dumps({"reads": int(n_reads), "mismatches": int(n_bad), "template_pairs": int(n_pairs), "pair_mismatches": int(n_bad_pairs), "rounds": rounds, "seed": seed,
-                      "tags_none_full_pref_post_rept_hang": [int(x) for x in tags], "seconds": round(time.time() - t0, 1)}))
-    return 1 if (n_bad or n_bad_pairs) else 0
+    ctx.close()
+    return {"reads": int(n_reads), "mismatches": int(n_bad), "template_pairs": int(n_pairs),
+            "pair_mismatches": int(n_bad_pairs), "rounds": rounds, "seed": seed,
+            "tags_none_full_pref_post_rept_hang": [int(x) for x in tags], "seconds": round(time.time() - t0, 1)}
+
+
+def main():
+    res = campaign(int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(json.dumps(res))
+    return 1 if (res["mismatches"] or res["pair_mismatches"]) else 0
 
 
 if __name__ == "__main__":

@@ -20,9 +20,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def campaign(rounds=20, seed=1):
+    """Runs the campaign and returns its summary (tests/test_fuzz_gpu.py runs a fixed-seed slice of it)."""
     import torch
     if torch.cuda.is_available():
         torch.cuda.init()
@@ -68,10 +67,16 @@ def main():
         if len(bad):
             print("MISMATCH round", k, "readlen", readlen, "clip", clip, "scoring", scoring, bad[:5], got[bad[:5]].tolist(),
                   want[bad[:5]].tolist(), file=sys.stderr)
-    print(json.dumps({"reads": int(n_reads), "mismatches": int(n_bad), "rounds": rounds, "seed": seed,
-                      "tags_none_full_pref_post_rept_hang": [int(x) for x in tags], "reads_by_scoring": by_scoring,
-                      "seconds": round(time.time() - t0, 1)}))
-    return 1 if n_bad else 0
+    ctx.close()
+    return {"reads": int(n_reads), "mismatches": int(n_bad), "rounds": rounds, "seed": seed,
+            "tags_none_full_pref_post_rept_hang": [int(x) for x in tags], "reads_by_scoring": by_scoring,
+            "seconds": round(time.time() - t0, 1)}
+
+
+def main():
+    res = campaign(*[int(x) for x in sys.argv[1:3]])
+    print(json.dumps(res))
+    return 1 if res["mismatches"] else 0
 
 
 if __name__ == "__main__":

@@ -296,7 +296,7 @@ class PysamStandin(types.ModuleType):
         types.ModuleType.__init__(self, "pysam")
         from tredparse_amd import bamio
 
-        class AlignmentFile(bamio.AlignmentFile):
+        class AlignmentFile(bamio.PyAlignmentFile):
             def pileup(self, chrom, start, end):
                 # htslib default pileup: every column covered by a read overlapping the region
                 cov = {}
@@ -342,6 +342,271 @@ def gen_e2e(loci):
                                 "default flags; pysam replaced by tredparse_amd.bamio", "samples": out}, fp)
 
 
+FLAG_LOCI = ("HD", "DM1", "SCA17", "AR", "FXS")        # two covered loci + an autosomal and two X-linked empty ones
+SYNF_LOCI = ("HD", "DM1", "FXS", "SCA10")             # the loci tests/golden/bam/synf.bam carries reads for
+SYNF_ALLELES = {"HD": (17, 95), "DM1": (5, 48), "SCA10": (12, 14), "FXS": (30, 120)}
+# (name, sample, haploid contigs, maxinsert, fullsearch, clip, alts, repeatpairs): the non-default corners of
+# tred.py:75-93 as they reach run() (tred.py:508-512) and repo.set_ploidy (tred.py:492).  The reference's two
+# mini-BAMs hold no ALT-region reads, no pairs of repeat-only reads and only 150 bp reads, so three of the flags
+# change nothing there; synf.bam (make_synf: expanded alleles, mates mismapped into ALT regions, unmapped mates
+# inside the tract) is where they bite.
+FLAG_CASES = [
+    ("default", "synf", None, 300, False, False, True, True),
+    ("clip", "synf", None, 300, False, True, True, True),
+    ("noalts", "synf", None, 300, False, False, False, True),
+    ("norepeatpairs", "synf", None, 300, False, False, True, False),
+    ("noalts_norepeatpairs", "synf", None, 300, False, False, False, False),
+    ("haploid", "synf", ["chrX", "chr19"], 300, False, False, True, True),
+    ("fullsearch_maxinsert60", "synf", None, 60, True, False, True, True),
+    ("maxinsert100", "synf", None, 100, False, False, True, True),
+    ("clip_noalts_norepeatpairs", "t002", None, 300, False, True, False, False),
+    ("haploid", "t001", ["chr4", "chrX"], 300, False, False, True, True),
+    ("haploid", "t002", ["chr19"], 300, False, False, True, True),
+    ("fullsearch_maxinsert60", "t001", None, 60, True, False, True, True),
+    ("fullsearch_maxinsert60", "t002", None, 60, True, False, True, True),
+    ("maxinsert100", "t002", None, 100, False, False, True, True),
+    ("haploid_fullsearch", "t001", ["chr4"], 80, True, False, True, True),
+]
+
+
+def make_synf():
+    """tests/golden/bam/synf.bam(.bai.gz): one synthetic 24x sample over SYNF_LOCI (tredparse_amd.synth_bam, fixed
+    seed) -- test DATA for the flag goldens; the index is stored gzipped (it is 0.5 MB of mostly empty bins)."""
+    import gzip
+    import shutil
+    from tredparse_amd import synth_bam
+    chosen = [l for l in synth.load_loci() if l["name"] in SYNF_LOCI]
+    recs, _ = synth_bam.simulate_sample(20260301, chosen, synth.SynthParams(coverage=24),
+                                        h_pairs=[SYNF_ALLELES[l["name"]] for l in chosen], alt_rate=0.4)
+    # every third tract-internal (unmapped, mate-anchored) read gets a secondary copy right behind it: two records
+    # of one name that both come out repeat-only -- what --norepeatpairs removes (bam_parser.py:270-287)
+    un = np.nonzero((recs.flag & synth_bam.FUNMAP) != 0)[0][::3]
+    order = np.sort(np.concatenate([np.arange(len(recs)), un]), kind="stable")
+    second = np.zeros(len(order), bool)
+    second[1:] = order[1:] == order[:-1]
+    recs = recs.take(order)
+    recs.flag = np.where(second, recs.flag | synth_bam.FSEC, recs.flag).astype(recs.flag.dtype)
+    path = os.path.join(GOLD, "bam", "synf.bam")
+    for f in (path, path + ".bai.gz"):
+        if os.path.exists(f):
+            os.chmod(f, 0o644)
+    synth_bam.write_bam(path, recs, sample="synf", level=9)
+    with open(path + ".bai", "rb") as src, gzip.GzipFile(path + ".bai.gz", "wb", mtime=0) as dst:
+        shutil.copyfileobj(src, dst)
+    os.unlink(path + ".bai")
+    print("synf:", len(recs), "records,", os.path.getsize(path), "+", os.path.getsize(path + ".bai.gz"), "bytes")
+
+
+def _bam_of(sample, tmp):
+    """Path of a flag-case BAM; synf is unpacked (with its index) into `tmp`."""
+    import gzip
+    import shutil
+    if sample != "synf":
+        return os.path.join(refshim.REF, "tests", sample + ".bam"), list(FLAG_LOCI)
+    dst = os.path.join(tmp, "synf.bam")
+    if not os.path.exists(dst):
+        shutil.copy(os.path.join(GOLD, "bam", "synf.bam"), dst)
+        with gzip.open(os.path.join(GOLD, "bam", "synf.bam.bai.gz"), "rb") as src, open(dst + ".bai", "wb") as out:
+            shutil.copyfileobj(src, out)
+    return dst, list(SYNF_LOCI)
+
+
+def _plain(calls):
+    for k, v in list(calls.items()):
+        if isinstance(v, (np.floating, np.integer)):
+            calls[k] = v.item()
+    return calls
+
+
+def _load_full_reference():
+    ref = refshim.load_reference(pysam_standin=PysamStandin(), full=True)
+    logging.disable(logging.CRITICAL)
+    return ref
+
+
+def gen_flags(loci):
+    """The reference's run() under every non-default flag combination of FLAG_CASES."""
+    import tempfile
+    ref = _load_full_reference()
+    cases = []
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        for name, sample, haploid, maxinsert, fullsearch, clip, alts, repeatpairs in FLAG_CASES:
+            repo = ref.meta.TREDsRepo(ref="hg38", toy=False, sites=os.path.join(tmp, "sites"))
+            repo.set_ploidy(haploid)
+            bampath, names = _bam_of(sample, tmp)
+            res = ref.tred.run((sample, bampath, repo, names, maxinsert, fullsearch, clip, alts,
+                                repeatpairs, "INFO"))
+            calls = _plain(res["tredCalls"])
+            cases.append({"name": name, "sample": sample, "loci": names, "haploid": haploid,
+                          "maxinsert": maxinsert, "fullsearch": fullsearch, "clip": clip, "alts": alts,
+                          "repeatpairs": repeatpairs, "tredCalls": calls})
+            print("flags:", name, sample, {k: calls[k] for k in calls if k.endswith((".1", ".2", ".CI", ".RR"))
+                                           and calls[k] not in (-1, "", "missing")})
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(GOLD, "run_flags.json"), "w") as fp:
+        json.dump({"generator": "tools/gen_golden.py flags: the reference's tredparse.tred.run() (v0.7.8 via "
+                                "tools/refshim.py) on its tests/t001.bam / t002.bam under non-default options; "
+                                "pysam replaced by tredparse_amd.bamio", "cases": cases}, fp)
+
+
+class _TextGzip(object):
+    """gzip whose open(path, "w") is text mode: the py2 writers print str into it (tred.py:367-372)."""
+
+    @staticmethod
+    def open(path, mode="r", *a, **k):
+        import gzip
+        return gzip.open(path, mode + "t" if "b" not in mode and "t" not in mode else mode, *a, **k)
+
+
+def gen_vcf(loci):
+    """The reference's to_vcf text (tred.py:316-374) for its own run() results of both test BAMs, all loci, and for
+    the flag cases that change a record (haploid)."""
+    import gzip
+    import tempfile
+    ref = _load_full_reference()
+    ref.tred.gzip = _TextGzip
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        repo = ref.meta.TREDsRepo(ref="hg38", toy=False, sites=os.path.join(tmp, "sites"))
+        gold = json.load(open(os.path.join(GOLD, "run_t001_t002.json")))["samples"]
+        for sample in ("t001", "t002"):
+            results = {"samplekey": sample, "bam": "tests/{}.bam".format(sample), "tredCalls": gold[sample]}
+            ref.tred.to_vcf(results, "hg38", repo, treds=list(repo.names))
+            text = gzip.open(sample + ".tred.vcf.gz", "rt").read()
+            out[sample] = text.splitlines()
+        # hg19 coordinates and a single-locus call list (the CSV's third column)
+        repo19 = ref.meta.TREDsRepo(ref="hg19_nochr", toy=False, sites=os.path.join(tmp, "sites"))
+        results = {"samplekey": "t001_hg19", "bam": "tests/t001.bam", "tredCalls": gold["t001"]}
+        ref.tred.to_vcf(results, "hg19_nochr", repo19, treds=["HD", "DM1", "SCA1"])
+        out["t001_hg19_nochr_3loci"] = gzip.open("t001_hg19.tred.vcf.gz", "rt").read().splitlines()
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(GOLD, "vcf_t001_t002.json"), "w") as fp:
+        json.dump({"generator": "tools/gen_golden.py vcf: the reference's tredparse.tred.to_vcf (v0.7.8 via "
+                                "tools/refshim.py, gzip opened in text mode) on tests/golden/run_t001_t002.json; "
+                                "the ##fileDate and ##source lines depend on the day and the install path",
+                   "source_module_file": ref.tred.__file__, "vcf": out}, fp, indent=0)
+    print("vcf:", {k: len(v) for k, v in out.items()})
+
+
+def report_inputs():
+    """Eight per-sample result files for the reporter: the reference's two run() results (without the bulky
+    per-read and distribution entries, which the reporter never reads) and edited copies that reach the corners of
+    tredreport.py:36-141 -- a male at an X-linked locus, a pre-risk sample, carriers of both mutation natures,
+    a case below --minPP, a long evidence string, the AR exemption of the details file."""
+    gold = json.load(open(os.path.join(GOLD, "run_t001_t002.json")))["samples"]
+    drop = (".details", ".P_h1", ".P_h2", ".P_h1h2", ".P_PEG", ".P_PET")
+
+    def base(sample):
+        return {k: v for k, v in gold[sample].items() if not k.endswith(drop)}
+
+    def called(calls, locus, a, b, label, pp, fr="", pr="", rr="", fdp=0, pdp=0, rdp=0, pedp=0):
+        calls.update({locus + ".1": a, locus + ".2": b, locus + ".label": label, locus + ".PP": pp,
+                      locus + ".FR": fr, locus + ".PR": pr, locus + ".RR": rr, locus + ".FDP": fdp,
+                      locus + ".PDP": pdp, locus + ".RDP": rdp, locus + ".PEDP": pedp,
+                      locus + ".CI": "{0}-{0}|{1}-{1}".format(a, b), locus + ".DP": 31.5})
+        return calls
+
+    out = {"t001": base("t001"), "t002": base("t002")}
+    s = base("t001"); s["inferredGender"] = "Male"; s["depthY"] = 14.2
+    called(s, "AR", 45, 45, "risk", 0.99, fr="45|9", fdp=9, pdp=4, pedp=11)
+    called(s, "FXS", 30, 30, "ok", 0.0, fr="30|12", fdp=12)
+    called(s, "HD", 17, 37, "prerisk", 0.31, fr="17|6;37|3", pr="5|1;12|2", fdp=9, pdp=3, pedp=20)
+    out["m003"] = s
+    s = base("t002"); s["inferredGender"] = "Female"
+    called(s, "FXS", 30, 210, "risk", 0.97, fr="30|7", pr=";".join("{}|1".format(k) for k in range(3, 48)),
+           rr="49|2;50|5", fdp=7, pdp=45, rdp=7, pedp=3)
+    called(s, "HD", 19, 40, "risk", 0.42, fr="19|8", pr="40|1", fdp=8, pdp=1)          # below --minPP
+    called(s, "SCA17", 36, 49, "ok", 0.2, fr="36|5;49|4", fdp=9)                       # carrier (>= cut-off, not risk)
+    out["f004"] = s
+    s = base("t001")
+    called(s, "OPMD", 10, 13, "risk", 1.0, fr="10|6;13|5", fdp=11, pedp=8)
+    called(s, "FRDA", 9, 80, "ok", 0.02, fr="9|7", pr="44|1", rr="50|1", fdp=7, pdp=1, rdp=1)   # recessive carrier
+    called(s, "ULD", 2, 3, "ok", 0.0, fr="2|5;3|6", fdp=11)
+    out["s005"] = s
+    s = base("t002")
+    called(s, "HD", 15, 15, "ok", 0.0, fr="15|11", fdp=11)
+    called(s, "SCA17", 36, 37, "ok", 0.0, fr="36|4;37|5", fdp=9)
+    called(s, "FRDA", 70, 85, "risk", 0.93, pr="44|2;46|1", rr="49|1;50|3", pdp=3, rdp=4, pedp=6)
+    out["s006"] = s
+    s = base("t001"); s["inferredGender"] = "Male"; s["depthY"] = 9.0
+    called(s, "FXS", 230, 230, "risk", 0.88, pr="40|2;45|1", rr="50|6", pdp=3, rdp=6, pedp=2)
+    called(s, "SBMA", 22, 22, "ok", 0.0, fr="22|8", fdp=8) if "SBMA.1" in s else None
+    out["m007"] = s
+    s = base("t002"); s["inferredGender"] = "Unknown"; s["depthY"] = -1
+    out["u008"] = s
+    return out
+
+
+def gen_report(loci):
+    """The reference's tredreport.main (tredreport.py:198-302) on report_inputs(): <tsv>, .cases.txt, .details.txt,
+    .report.txt, with default options, with --columns PP,FR --minPP 0.3, and re-read from the TSV."""
+    import tempfile
+    import pandas as pd
+    ref = _load_full_reference()
+
+    # pandas >= 2 dropped two calls the py2-era reporter makes; both restated with their old semantics
+    def _append(self, other, ignore_index=False, **k):
+        other = pd.DataFrame(other if isinstance(other, list) else [other])
+        return pd.concat([self, other], ignore_index=ignore_index, sort=True)      # unaligned columns came out sorted
+
+    def _reindex_axis(self, labels, axis=0, **k):
+        return self.reindex(columns=labels) if axis in (1, "columns") else self.reindex(labels)
+    pd.DataFrame.append = _append
+    pd.DataFrame.reindex_axis = _reindex_axis
+    def py2_sorted(items, **k):                     # Python 2 orders numbers before strings (tredreport.py:107-108)
+        try:
+            return sorted(items, **k)
+        except TypeError:
+            key = k.get("key") or (lambda x: x)
+
+            def rank(x):
+                v = key(x)
+                v0 = v[0] if isinstance(v, tuple) else v
+                return (isinstance(v0, str), v)
+            return sorted(items, key=rank)
+    rep = refshim._load("tredparse/tredreport.py", "tredparse.tredreport", extra={"sorted": py2_sorted})
+    inputs = report_inputs()
+    out = {"inputs": inputs, "runs": []}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        files = []
+        for key, calls in inputs.items():
+            with open(key + ".json", "w") as fp:
+                json.dump({"samplekey": key, "bam": key + ".bam", "tredCalls": calls}, fp)
+            files.append(key + ".json")
+
+        def collect(tsv):
+            got = {}
+            for suffix in ("", ".cases.txt", ".details.txt", ".report.txt"):
+                with open(tsv + suffix) as fp:
+                    got["tsv" + suffix] = fp.read()
+            return got
+        for name, argv in (("default", files + ["--tsv", "a.tsv"]),
+                           ("columns_minpp", files + ["--tsv", "b.tsv", "--columns", "PP,FR", "--minPP", "0.3"]),
+                           ("two_reference_samples", files[:2] + ["--tsv", "c.tsv"])):
+            rep.main(argv)
+            tsv = argv[argv.index("--tsv") + 1]
+            out["runs"].append({"name": name, "files": [f for f in argv if f.endswith(".json")],
+                                "options": [a for a in argv if not a.endswith(".json")], "outputs": collect(tsv)})
+            print("report:", name, {k: len(v) for k, v in out["runs"][-1]["outputs"].items()})
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(GOLD, "report.json"), "w") as fp:
+        json.dump({"generator": "tools/gen_golden.py report: the reference's tredparse.tredreport.main (v0.7.8 via "
+                                "tools/refshim.py; pandas {} with DataFrame.append / reindex_axis restated) on the "
+                                "listed per-sample JSON inputs".format(pd.__version__), **out}, fp)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     loci = synth.load_loci()
@@ -357,6 +622,14 @@ def main():
             gen_grid(ref, loci)
     if "e2e" in what:
         gen_e2e(loci)
+    if "synf" in what:
+        make_synf()
+    if "flags" in what:
+        gen_flags(loci)
+    if "vcf" in what:
+        gen_vcf(loci)
+    if "report" in what:
+        gen_report(loci)
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ Run in the build container only (reads /root/reference at run time; nothing of t
 source text is embedded here).  Outputs (committed, plain data):
 
   tredparse_amd/data/treds.json   locus table: the columns of tredparse/data/TREDs.meta.csv that the
-                                  hot path and its callers consume (meta.py:103-129) + the ALT regions
+                                  hot path and its callers consume (meta.py:103-129) and the reporter prints (motif, title) + the ALT regions
                                   of TREDs.alts.csv (meta.py:81-95) + the allele_freq column (used only
                                   by the synthetic generator).
   tredparse_amd/data/model.json   lobSTR step-size / stutter constants parsed the way
@@ -37,6 +37,7 @@ def main():
             "name": name,
             "title": str(row["title"]),
             "gene_name": str(row["gene_name"]),
+            "motif": str(row["motif"]),
             "repeat": row["repeat"],
             "repeat_location": row["repeat_location"],
             "repeat_location.hg19": row["repeat_location.hg19"],

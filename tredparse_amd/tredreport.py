@@ -19,6 +19,7 @@ import csv
 import gzip
 import json
 import os
+import re
 import sys
 from collections import Counter
 
@@ -104,6 +105,21 @@ def add_calls(rows, repo, has_sex):
             r[name + ".calls"] = "{}|{}".format(a, b)
 
 
+def _is_number(v):
+    return isinstance(v, (int, float)) and not isinstance(v, bool)
+
+
+def _column_cells(values):
+    """One TSV column as the reference's data frame prints it (tredreport.py:112-141: fillna(-1), to_csv): a column
+    of whole numbers without gaps stays integer; numbers with a gap or a fraction are floats throughout (a gap
+    reads -1.0); a column holding any text prints every entry as it is and gaps as -1."""
+    present = [v for v in values if v is not None]
+    if present and all(_is_number(v) for v in present) and \
+            (len(present) < len(values) or any(isinstance(v, float) for v in present)):
+        return [repr(float(-1 if v is None else v)) for v in values]
+    return ["-1" if v is None else str(v) for v in values]
+
+
 def write_tsv(rows, path, extra_columns, has_sex):
     lead = ["SampleKey"] + (["inferredGender"] if has_sex else [])
     wanted = ("calls", "label") + tuple(extra_columns)
@@ -111,11 +127,12 @@ def write_tsv(rows, path, extra_columns, has_sex):
     for r in rows:
         seen.update(r)
     columns = lead + sorted(c for c in seen if c not in lead and c.rsplit(".", 1)[-1] in wanted and "." in c)
+    cells = [_column_cells([r.get(c) for r in rows]) for c in columns]
     with open(path, "w", newline="") as fp:
         w = csv.writer(fp, delimiter="\t", lineterminator="\n")
         w.writerow(columns)
-        for r in rows:
-            w.writerow([r.get(c, -1) if r.get(c) is not None else -1 for c in columns])
+        for i in range(len(rows)):
+            w.writerow([col[i] for col in cells])
     print("TSV output written to `{}` (# samples={})".format(path, len(rows)), file=sys.stderr)
 
 
@@ -134,12 +151,54 @@ def _num(v, default=-1.0):
         return default
 
 
+_PLAIN_NUMBER = re.compile(r"^\s*[+-]?[0-9]+\.[0-9]*$")
+
+
+def _float_cells(values, digits=6):
+    """A column of floats as a data frame's text form shows it: fixed notation with `digits` decimals, trailing
+    zeros dropped as long as every entry ends in one (one decimal stays); scientific
+    notation for the whole column once an entry would otherwise show as 0 (|x| < 10^-digits) or the column is both
+    wide and holds |x| > 1e6."""
+    def trim(cells):
+        def plain(x):
+            return _PLAIN_NUMBER.match(x) is not None
+        while True:
+            numbers = [x for x in cells if plain(x)]
+            if not numbers or not all(x.endswith("0") for x in numbers):
+                break
+            cells = [x[:-1] if plain(x) else x for x in cells]
+        return [x + "0" if plain(x) and x.endswith(".") else x for x in cells]
+
+    def render(spec):
+        return trim(["NaN" if v != v else spec.format(v) for v in values])
+    cells = render("{:." + str(digits) + "f}")
+    mags = [abs(v) for v in values if v == v]
+    too_long = bool(cells) and max(len(x) for x in cells) > digits + 6
+    if any(0 < m < 10 ** -digits for m in mags) or (too_long and any(m > 1e6 for m in mags)):
+        cells = render("{:." + str(digits) + "e}")
+    return cells
+
+
 def _table(rows, columns):
-    """Fixed-width text table, right-aligned, one header line."""
-    cells = [[str(r.get(c, "")) for c in columns] for r in rows]
-    widths = [max([len(c)] + [len(x[i]) for x in cells]) for i, c in enumerate(columns)]
-    lines = [" ".join(c.rjust(w) for c, w in zip(columns, widths))]
-    lines += [" ".join(v.rjust(w) for v, w in zip(x, widths)) for x in cells]
+    """Fixed-width text table the way the reference prints its case tables (tredreport.py:89-97, a data frame's
+    to_string(index=False)): one header line, every cell right-aligned to its column's width, one blank between
+    columns; a numeric column's header carries one leading blank, its values the float layout of _float_cells."""
+    heads, cols = [], []
+    for c in columns:
+        values = [r.get(c, "") for r in rows]
+        if values and all(_is_number(v) for v in values):
+            heads.append(" " + c)
+            if any(isinstance(v, float) for v in values):
+                cols.append(_float_cells([float(v) for v in values]))
+            else:
+                cols.append([str(v) for v in values])
+        else:
+            heads.append(c)
+            cols.append([str(v) for v in values])
+    widths = [max([len(h)] + [len(x) for x in col]) for h, col in zip(heads, cols)]
+    lines = [" ".join(h.rjust(w) for h, w in zip(heads, widths))]
+    for i in range(len(rows)):
+        lines.append(" ".join(col[i].rjust(w) for col, w in zip(cols, widths)))
     return "\n".join(lines)
 
 
@@ -230,7 +289,7 @@ def main(args):
                                                                     detailsfw=detailsfw)
             total.update(prerisk=n_prerisk, risk=n_risk, carrier=n_carrier, loci=int(n_risk > 0))
             meta = repo.rows[name]
-            report.append({"abbreviation": name, "title": meta.get("title", ""), "motif": meta.get("repeat", ""),
+            report.append({"abbreviation": name, "title": meta.get("title", ""), "motif": meta.get("motif", meta.get("repeat", "")),
                            "inheritance": t.inheritance, "cutoff_prerisk": t.cutoff_prerisk,
                            "cutoff_risk": t.cutoff_risk, "n_prerisk": n_prerisk, "n_risk": n_risk,
                            "n_carrier": n_carrier, "allele_freq": af})
