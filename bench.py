@@ -82,7 +82,9 @@ def make_batch(args, rank, world):
     loci = bench_loci(synth.load_loci())
     p = synth.SynthParams(coverage=args.coverage, readlen=150)
     from tredparse_amd import shard
-    workers = max(1, min(len(loci), shard.usable_cpus() // max(1, world)))
+    # TRED_BENCH_WORKERS=1 (tools/profile_round.sh): under rocprofv3 the profiler's preloaded library has initialised
+    # the GPU before Python starts, and a GPU-initialised process must not fork workers -- build the batch in-process
+    workers = int(os.environ.get("TRED_BENCH_WORKERS", "0")) or max(1, min(len(loci), shard.usable_cpus() // max(1, world)))
     return loci, synth.build_batch(args.seed + rank, loci, args.samples, p, workers=workers)
 
 

@@ -79,6 +79,11 @@ int tredbam_pe_lengths(tredbam* b, int32_t tid, int64_t start, int64_t end, int6
  * < 0 bad arguments. */
 int tredbam_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t out_len);
 
+/* The checksum every block is verified with after decoding (csrc/crc32_fold.h: carry-less-multiply folding with
+ * zlib's crc32 as fallback), exposed for tests: CRC-32 of buf[0..len) continued from `crc` (0 to start).  A block
+ * whose trailer does not match fails the call that needed it with -7, as htslib's bgzf_read_block does. */
+uint32_t tredbam_crc32(uint32_t crc, const uint8_t* buf, int64_t len);
+
 /* Largest l_seq among the first `first_n` records in file order (first_n <= 0: all): READLEN of a sample
  * (BamReadLen, bam_parser.py:372-391, which looks at 101 records). */
 int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out);

@@ -104,3 +104,61 @@ def test_bad_input_is_declined(lib):
         assert lib.tredbam_inflate_raw(comp, len(comp), C.create_string_buffer(9000), wrong) == 0
     ok = C.create_string_buffer(9000)
     assert lib.tredbam_inflate_raw(comp, len(comp), ok, len(plain)) == 1 and ok.raw[:len(plain)] == plain
+
+
+def test_crc32_equals_zlibs(lib):
+    """csrc/crc32_fold.h (carry-less-multiply folding; zlib's crc32 for tails and old CPUs) against zlib.crc32 at
+    every length around the 16- and 64-byte lane boundaries, with and without a running value."""
+    lib.tredbam_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_int64]
+    lib.tredbam_crc32.restype = C.c_uint32
+    rng = random.Random(11)
+    for n in list(range(0, 260)) + [1000, 4095, 4096, 65535, 65536]:
+        data = bytes(rng.randrange(256) for _ in range(n)) if n < 5000 else os.urandom(n)
+        for init in (0, 0x9E3779B9):
+            assert lib.tredbam_crc32(init, data, n) == zlib.crc32(data, init), (n, init)
+    a, b = os.urandom(777), os.urandom(4242)
+    assert lib.tredbam_crc32(lib.tredbam_crc32(0, a, len(a)), b, len(b)) == zlib.crc32(a + b)
+
+
+def test_damaged_blocks_are_errors_not_genotypes(tmp_path):
+    """A BGZF block is checked against its trailer after decoding (htslib does; pysam would raise): flipping a literal
+    byte inside a stored block, or the CRC itself, fails the fetch; an ISIZE beyond 64 KiB is refused before anything
+    is allocated."""
+    def bgzf(payload, stored=True):
+        comp = zlib.compressobj(0 if stored else 6, zlib.DEFLATED, -15)
+        body = comp.compress(payload) + comp.flush()
+        head = struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, len(body) + 25)
+        return head + body + struct.pack("<II", zlib.crc32(payload), len(payload))
+    src = open(os.path.join(GOLD, "bam", "t001.bam"), "rb").read()
+    # re-block the file's first 60 kB of records as stored blocks so that a flipped byte stays a valid stream
+    pos, plain = 0, b""
+    while len(plain) < 60000:
+        bsize = struct.unpack_from("<H", src, pos + 16)[0] + 1
+        plain += zlib.decompress(src[pos + 18:pos + bsize - 8], -15)
+        pos += bsize
+    blocks = [bgzf(plain[i:i + 20000]) for i in range(0, len(plain), 20000)]
+    eof = bgzf(b"", stored=False)
+
+    def fetch_all(raw):
+        path = str(tmp_path / "x.bam")
+        with open(path, "wb") as fp:
+            fp.write(raw)
+        f = bamio.NativeAlignmentFile(path)
+        try:
+            return sum(1 for _ in f.fetch())
+        finally:
+            f.close()
+    good = b"".join(blocks) + eof
+    assert fetch_all(good) > 100
+    bad = bytearray(good)
+    bad[len(blocks[0]) + 18 + 5 + 9000] ^= 0x20            # a payload byte of the second (stored) block
+    with pytest.raises(Exception, match="CRC"):
+        fetch_all(bytes(bad))
+    bad = bytearray(good)
+    bad[len(blocks[0]) - 8] ^= 1                            # the first block's CRC field
+    with pytest.raises(Exception, match="CRC"):
+        fetch_all(bytes(bad))
+    bad = bytearray(good)
+    bad[len(blocks[0]) - 4:len(blocks[0])] = struct.pack("<I", 3000000000)   # ISIZE
+    with pytest.raises(Exception, match="claims"):
+        fetch_all(bytes(bad))

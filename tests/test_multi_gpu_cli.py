@@ -98,3 +98,90 @@ def test_checkexists_is_decided_by_the_parent(tmp_path, monkeypatch):
     os.remove(tmp_path / "t001.json")
     tredmod.main(["list.txt", "--gpus", "2", "--checkexists"], quiet=True)
     assert seen["tasks"] == [["t001", bam, None]]
+
+
+def test_cleanup_with_gpus_is_the_parents(tmp_path, monkeypatch, capsys):
+    """--gpus N --cleanup: the children never see --cleanup (the first one to finish would remove the directory its
+    siblings are still writing to); the parent echoes the JSONs and only then removes the working directory."""
+    monkeypatch.setattr("tredparse_amd.engine.Engine", NoEvidenceEngine)
+    monkeypatch.chdir(tmp_path)
+    bams = [os.path.join(GOLD, "bam", b) for b in ("t001.bam", "t002.bam")]
+    (tmp_path / "samples.csv").write_text("".join("c{},{}\n".format(i, bams[i % 2]) for i in range(3)))
+    work = tmp_path / "work"
+    seen = []
+
+    def fake_spawn(cmd, world, devices, env=None, cwd=None, **kw):
+        assert "--cleanup" not in cmd
+        parent_cwd = os.getcwd()                     # real children are processes: the parent's directory stays put
+        for r in range(world):
+            for k, v in (("RANK", str(r)), ("WORLD_SIZE", str(world)), ("TRED_SPAWNED_RANK", "1")):
+                monkeypatch.setenv(k, v)
+            os.chdir(cwd)
+            tredmod.main(cmd[3:], quiet=True)
+            assert work.exists()                     # a finished child leaves the directory alone
+            seen.append(sorted(os.listdir(work)))
+        for k in ("RANK", "WORLD_SIZE", "TRED_SPAWNED_RANK"):
+            monkeypatch.delenv(k)
+        os.chdir(parent_cwd)
+        return [0] * world
+
+    monkeypatch.setattr(shard, "spawn_ranks", fake_spawn)
+    monkeypatch.setattr(shard, "visible_gpus", lambda: 2)
+    tredmod.main(["samples.csv", "--workdir", str(work), "--gpus", "2", "--tred", "HD", "--cleanup"])
+    assert len(seen) == 2 and len(seen[1]) == 6      # both ranks' files were all there before the parent cleaned up
+    echoed = capsys.readouterr().out
+    assert [echoed.count('"samplekey": "c{}"'.format(i)) for i in range(3)] == [1, 1, 1]
+    assert not work.exists()
+
+
+def test_child_invoked_with_cleanup_keeps_the_directory(tmp_path, monkeypatch):
+    """Belt and braces: even a child that is handed --cleanup (an older parent) does not remove the directory."""
+    monkeypatch.setattr("tredparse_amd.engine.Engine", NoEvidenceEngine)
+    monkeypatch.chdir(tmp_path)
+    bam = os.path.join(GOLD, "bam", "t001.bam")
+    tasks = tmp_path / "tasks.json"
+    tasks.write_text(json.dumps([["z0", bam, None]]))
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "1")):
+        monkeypatch.setenv(k, v)
+    work = tmp_path / "w"
+    tredmod.main([bam, "--workdir", str(work), "--tred", "HD", "--cleanup", "--task-file", str(tasks)], quiet=True)
+    assert (work / "z0.json").exists()
+
+
+def test_rank_devices_follow_an_inherited_visibility_mask():
+    """A parent confined to HIP_VISIBLE_DEVICES=2,3 (or CUDA_VISIBLE_DEVICES) counts 2 devices; its children must get
+    entries 2 and 3 of that mask, not the absolute devices 0 and 1."""
+    env = shard.rank_env(0, 2, 1234, 0, base={"HIP_VISIBLE_DEVICES": "2,3"})
+    assert env["HIP_VISIBLE_DEVICES"] == "2" and env["TRED_RANK_DEVICE"] == "2" and env["LOCAL_RANK"] == "0"
+    assert shard.rank_env(1, 2, 1234, 1, base={"HIP_VISIBLE_DEVICES": "2,3"})["HIP_VISIBLE_DEVICES"] == "3"
+    assert shard.rank_env(2, 4, 1234, 2 % 2, base={"HIP_VISIBLE_DEVICES": "2,3"})["HIP_VISIBLE_DEVICES"] == "2"
+    env = shard.rank_env(1, 2, 1234, 1, base={"CUDA_VISIBLE_DEVICES": "5, 7"})
+    assert env["HIP_VISIBLE_DEVICES"] == "7" and "CUDA_VISIBLE_DEVICES" not in env
+    env = shard.rank_env(1, 2, 1234, 1, base={"HIP_VISIBLE_DEVICES": "4,6", "CUDA_VISIBLE_DEVICES": "0,1"})
+    assert env["HIP_VISIBLE_DEVICES"] == "6" and "CUDA_VISIBLE_DEVICES" not in env
+    env = shard.rank_env(3, 8, 1234, 3, base={"ROCR_VISIBLE_DEVICES": "0,1,2,3"})
+    assert env["HIP_VISIBLE_DEVICES"] == "3" and env["ROCR_VISIBLE_DEVICES"] == "0,1,2,3"
+    assert shard.rank_env(1, 2, 1234, None, base={"HIP_VISIBLE_DEVICES": "2,3"})["HIP_VISIBLE_DEVICES"] == "2,3"
+
+
+def test_tasks_with_different_options_go_in_separate_gpu_batches(tmp_path, monkeypatch):
+    """finish_batch groups a batch's tasks by the kernel-side options (maxinsert, fullsearch, clip, repeatpairs)
+    instead of applying the first task's to all."""
+    from tredparse_amd.meta import TREDsRepo
+    seen = []
+
+    class Recording(NoEvidenceEngine):
+        def genotype_packed(self, b):
+            seen.append((int(b.params["maxinsert"][0]), int(b.params["fullsearch"][0]), b.n_units))
+            assert len(set(b.params["maxinsert"].tolist())) == 1 and len(set(b.params["fullsearch"].tolist())) == 1
+            return NoEvidenceEngine.genotype_packed(self, b)
+
+    repo = TREDsRepo(ref="hg38", sites=str(tmp_path / "no_sites"))
+    bam = os.path.join(GOLD, "bam", "t001.bam")
+    args = [("a", bam, repo, ["HD", "DM1"], 300, False, False, True, True, "INFO"),
+            ("b", bam, repo, ["HD"], 60, True, False, True, True, "INFO"),
+            ("c", bam, repo, ["HD", "DM1"], 300, False, False, True, True, "INFO")]
+    scans = [tredmod.collect_sample(a) for a in args]
+    res = tredmod.finish_batch(Recording(), args, scans)
+    assert [r["samplekey"] for r in res] == ["a", "b", "c"]
+    assert sorted(seen) == [(60, 1, 1), (300, 0, 4)]

@@ -13,6 +13,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
+export TRED_BENCH_WORKERS=1     # no forked batch builders out of a process the profiler has put on the GPU
 BENCH="python3 $ROOT/bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline"
 
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"

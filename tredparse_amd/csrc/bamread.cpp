@@ -24,6 +24,7 @@
 #include <utility>
 #include <vector>
 
+#include "crc32_fold.h"
 #include "inflate_block.h"
 #include "tredbam.h"
 
@@ -145,6 +146,8 @@ int load_block(tredbam* b, int64_t coffset) {
     const uint8_t* comp = file_bytes(b, coffset + 12 + xlen, (size_t)dlen);
     if (!comp) return fail(b, -6, "truncated BGZF block");
     const uint32_t isize = le32(comp + dlen - 4);
+    // a BGZF block holds at most 64 KiB (SAM spec 4.1): a larger ISIZE is a damaged trailer, not a 4 GiB allocation
+    if (isize > 65536) return fail(b, -6, "BGZF block at %lld claims %u bytes", (long long)coffset, isize);
     std::unique_ptr<uint8_t[]> data(new uint8_t[(size_t)isize + tredbam_inflate::SLACK]);
     // own whole-block decoder first (1.3-1.6x zlib's speed on BAM data); zlib decides whenever it declines
     const bool done = isize > 0 && tredbam_inflate::inflate_block(comp, (size_t)(dlen - 8), data.get(), isize, b->inflate_tables);
@@ -160,6 +163,10 @@ int load_block(tredbam* b, int64_t coffset) {
         inflateEnd(&zs);
         if (rc != Z_STREAM_END || zs.total_out != isize) return fail(b, -7, "inflate failed at %lld", (long long)coffset);
     }
+    // the block's CRC-32 trailer, after either decoder (htslib checks it too: a damaged block that still inflates
+    // to ISIZE bytes must be an error, not a genotype)
+    if (tredbam_crc::crc32(0, data.get(), isize) != le32(comp + dlen - 8))
+        return fail(b, -7, "CRC mismatch in the BGZF block at %lld", (long long)coffset);
     b->block_clen = clen;
     if (b->cache.size() >= tredbam::CACHE_BLOCKS) {
         b->cache.erase(b->cache_order.front());
@@ -556,18 +563,23 @@ int tredbam_open(const char* path, tredbam** out) {
     };
     int rc = bg_seek(b, 0);
     if (rc < 0) return bail(rc);
+    b->err.clear();
+    auto truncated = [&]() {                       // keeps the block layer's reason (CRC mismatch, bad block, ...)
+        b->err = b->err.empty() ? std::string("truncated BAM header") : "truncated BAM header: " + b->err;
+        return bail(-6);
+    };
     uint8_t w[8];
     if (bg_read(b, w, 4) != 4 || memcmp(w, "BAM\1", 4) != 0) { b->err = "not a BAM file: " + p; return bail(-6); }
-    if (bg_read(b, w, 4) != 4) { b->err = "truncated BAM header"; return bail(-6); }
+    if (bg_read(b, w, 4) != 4) return truncated();
     const int32_t l_text = (int32_t)le32(w);
     std::vector<uint8_t> text((size_t)std::max(l_text, 0));
-    if (bg_read(b, text.data(), l_text) != l_text || bg_read(b, w, 4) != 4) { b->err = "truncated BAM header"; return bail(-6); }
+    if (bg_read(b, text.data(), l_text) != l_text || bg_read(b, w, 4) != 4) return truncated();
     const int32_t n_ref = (int32_t)le32(w);
     for (int32_t t = 0; t < n_ref; ++t) {
-        if (bg_read(b, w, 4) != 4) { b->err = "truncated BAM header"; return bail(-6); }
+        if (bg_read(b, w, 4) != 4) return truncated();
         const int32_t l_name = (int32_t)le32(w);
         std::vector<uint8_t> nm((size_t)std::max(l_name, 1));
-        if (bg_read(b, nm.data(), l_name) != l_name || bg_read(b, w, 4) != 4) { b->err = "truncated BAM header"; return bail(-6); }
+        if (bg_read(b, nm.data(), l_name) != l_name || bg_read(b, w, 4) != 4) return truncated();
         b->ref_names.emplace_back((const char*)nm.data(), (size_t)std::max(l_name - 1, 0));
         b->ref_lens.push_back((int32_t)le32(w));
         b->tid_of[b->ref_names.back()] = t;
@@ -678,6 +690,10 @@ int tredbam_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t o
     if (!tredbam_inflate::inflate_block(in, (size_t)n_in, buf.data(), (size_t)out_len, tables)) return 0;
     memcpy(out, buf.data(), (size_t)out_len);
     return 1;
+}
+
+uint32_t tredbam_crc32(uint32_t crc, const uint8_t* buf, int64_t len) {
+    return (buf && len > 0) ? tredbam_crc::crc32(crc, buf, (size_t)len) : crc;
 }
 
 int64_t tredbam_details_json(const uint8_t* seq4, const int64_t* seq4_off, const int32_t* read_len, const char* names,

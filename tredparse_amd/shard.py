@@ -84,18 +84,32 @@ def free_port():
     return port
 
 
+def device_entry(index, env):
+    """The HIP_VISIBLE_DEVICES entry that selects this process's `index`-th visible device in a child.  Under an
+    inherited mask (HIP_VISIBLE_DEVICES, or CUDA_VISIBLE_DEVICES which the HIP runtime reads in its place) the devices
+    a parent counts are the mask's entries, not 0..n-1: a parent confined to "2,3" hands out 2 and 3 -- never someone
+    else's device 0.  ROCR_VISIBLE_DEVICES works one layer below (HIP indices are relative to it) and is inherited
+    untouched."""
+    mask = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES") or ""
+    entries = [e.strip() for e in mask.split(",") if e.strip()]
+    return entries[index % len(entries)] if entries else str(index)
+
+
 def rank_env(rank, world, port, device, base=None):
     """Environment of rank `rank`: the torchrun variables (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) plus
     HIP_VISIBLE_DEVICES = its one device (None: leave the visibility alone, e.g. CPU-only tests), so that inside the
-    child the device is always index 0.  TRED_RANK_DEVICE records which physical device that is."""
+    child the device is always index 0.  `device` counts the devices THIS process sees; under an inherited visibility
+    mask it is translated through the mask (device_entry).  TRED_RANK_DEVICE records which device that is."""
     import os
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK="0" if device is not None else str(rank), WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRED_SPAWNED_RANK="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if device is not None:
-        env["HIP_VISIBLE_DEVICES"] = str(device)
-        env["TRED_RANK_DEVICE"] = str(device)
+        entry = device_entry(device, env)
+        env["HIP_VISIBLE_DEVICES"] = entry
+        env.pop("CUDA_VISIBLE_DEVICES", None)       # one mask only: the two would be applied on top of each other
+        env["TRED_RANK_DEVICE"] = entry
     return env
 
 

@@ -221,11 +221,19 @@ def finish_batch(engine, task_args, scans, lazy_details=False):
     (dict-like) instead of lists and dicts; to_json prints both natively."""
     if not task_args:
         return []
-    o0 = _options(task_args[0])
     picks = [(si, s, [k for k in range(len(s.names)) if k not in s.dropped] if s.opened else [])
              for si, s in enumerate(scans)]
     t0 = time.perf_counter()
-    res = _genotype(engine, picks, o0)
+    # the kernel-side options of a GPU batch are the batch's: tasks that differ in them go in separate batches
+    # (the CLI's are uniform; API callers of run_many may mix them)
+    groups = {}
+    for pick, arg in zip(picks, task_args):
+        o = _options(arg)
+        key = (o["maxinsert"], o["fullsearch"], o["clip"], o["repeatpairs"] or o["clip"])
+        groups.setdefault(key, (o, []))[1].append(pick)
+    res = {}
+    for o, sub in groups.values():
+        res.update(_genotype(engine, sub, o))
     t1 = time.perf_counter()
     TIMING["gpu"] += t1 - t0
     results = []
@@ -433,7 +441,9 @@ def _fan_out(argv, n_gpus, samples, launch_dir, no_output, quiet, devices=None):
     with tempfile.NamedTemporaryFile("w", suffix=".json", prefix="tred_tasks_", delete=False) as fp:
         json.dump([list(s) for s in samples], fp)
     try:
-        cmd = [sys.executable, "-m", "tredparse_amd.tred"] + list(argv) + ["--task-file", fp.name]
+        # --cleanup is the parent's: a child removing the shared working directory would take its siblings' files
+        child_argv = [a for a in argv if a != "--cleanup"]
+        cmd = [sys.executable, "-m", "tredparse_amd.tred"] + child_argv + ["--task-file", fp.name]
         codes = shard.spawn_ranks(cmd, n_gpus, devices, env=env, cwd=launch_dir)
     finally:
         os.unlink(fp.name)
@@ -498,8 +508,8 @@ def main(args, quiet=False):
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
         os.chdir(cwd)
-    if args.cleanup:
-        shutil.rmtree(args.workdir)
+    if args.cleanup and not args.task_file:        # a --gpus child never removes the directory its siblings write to
+        shutil.rmtree(args.workdir, ignore_errors=True)
 
 
 if __name__ == "__main__":
