@@ -77,10 +77,31 @@ def ladder_cells(batch):
     return total
 
 
+WORKLOADS = {
+    # BASELINE.json configs[2] (the headline) and configs[4]; `samples` is the default per-GPU batch
+    "config3": {"what": "synthetic 30x samples x 30 TRED loci per GPU (BASELINE configs[2])",
+                "alleles": "uniform 5..60 units (SURVEY 8d)", "synth": {}},
+    "config5": {"what": "synthetic 100x samples x 30 TRED loci per GPU, one allele expanded up to 200 repeats in "
+                        "80 % of the units (BASELINE configs[4]: large (h1,h2) grids, repeat-only reads)",
+                "alleles": "uniform 5..60 units, the longer one 60..200 in 80 % of the units",
+                "synth": {"coverage": 100.0, "expanded_max": 200, "expanded_frac": 0.8}},
+}
+
+
+def rows_per_lane(readlen):
+    """The sw_cont_kernel instantiation a maximum read length selects (csrc/capi.hip rows_for)."""
+    return 4 if readlen <= 64 else 7 if readlen <= 112 else 10 if readlen <= 160 else 16
+
+
 def make_batch(args, rank, world):
     from tredparse_amd import synth
     loci = bench_loci(synth.load_loci())
-    p = synth.SynthParams(coverage=args.coverage, readlen=150)
+    kw = dict(coverage=args.coverage, readlen=args.readlen)
+    kw.update(WORKLOADS[args.workload]["synth"])
+    if args.coverage_set:
+        kw["coverage"] = args.coverage
+    p = synth.SynthParams(**kw)
+    args.coverage_used = p.coverage
     from tredparse_amd import shard
     # TRED_BENCH_WORKERS=1 (tools/profile_round.sh): under rocprofv3 the profiler's preloaded library has initialised
     # the GPU before Python starts, and a GPU-initialised process must not fork workers -- build the batch in-process
@@ -220,7 +241,7 @@ def rank_main(args):
     d_pref = torch.zeros((g, hs), dtype=torch.int32, device=dev)
     d_rept = torch.zeros((g, hs), dtype=torch.int32, device=dev)
     d_calls = torch.zeros(g * _lib.CALL_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    params = _lib.default_sw_params(max_read_len=150)
+    params = _lib.default_sw_params(max_read_len=args.readlen)
     torch.cuda.synchronize()
 
     def one_step():
@@ -276,7 +297,8 @@ def rank_main(args):
         cols = (cnt["trunk_cols"] + cnt["continuation_cols"]) / launches
         # a swept column = one DP column of every read of the quad: read rows only (no padding rows, no empty slots)
         swept = cnt["read_cols"] / launches * batch.readlen
-        lanes = cols * 4 * 160                     # cells the wavefronts occupy: 4 read slots x 16 lanes x 10 rows
+        rpl = rows_per_lane(args.readlen)
+        lanes = cols * 4 * 16 * rpl                # cells the wavefronts occupy: 4 read slots x 16 lanes x R rows
         alg_bytes = int(batch.packed.nbytes + n * 12 + n * 5)  # packed reads + offsets/lengths in, tag/h/score out
         traffic, traffic_src = None, None
         if os.path.exists(PMC_SUMMARY):
@@ -287,17 +309,17 @@ def rank_main(args):
                 traffic = k["hbm_bytes_per_launch"]
                 traffic_src = "profiles/r02_pmc_summary.json ({})".format(pm.get("how", "rocprofv3 --pmc passes"))
         out = {
-            "metric": "sample x TRED genotypes/sec at 30x 150bp",
+            "metric": "sample x TRED genotypes/sec at {:g}x {}bp".format(args.coverage_used, args.readlen),
             "value": value, "unit": "genotypes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32 (SW) + f64 (likelihood)", "data": "synthetic",
-            "config": {"workload": "{} synthetic 30x 150bp samples x 30 TRED loci per GPU (BASELINE configs[2]); "
-                                   "fused SW+tagging -> histograms -> (h1,h2) grid, inputs resident in HBM"
-                                   .format(args.samples),
-                       "units_per_step_per_gpu": g, "reads_per_step_per_gpu": n, "coverage": args.coverage,
-                       "readlen": 150, "maxinsert": 300, "alleles": "uniform 5..60 units (SURVEY 8d)",
+            "config": {"workload": "{} {} at {} bp; fused SW+tagging -> histograms -> (h1,h2) grid, inputs resident "
+                                   "in HBM".format(args.samples, WORKLOADS[args.workload]["what"], args.readlen),
+                       "name": args.workload,
+                       "units_per_step_per_gpu": g, "reads_per_step_per_gpu": n, "coverage": args.coverage_used,
+                       "readlen": args.readlen, "maxinsert": 300, "alleles": WORKLOADS[args.workload]["alleles"],
                        "parallelism": "sample-sharded x{} (no collective)".format(world)},
-            "roofline": {"kernel": "sw_cont_kernel<10,4>", "bound": "valu",
+            "roofline": {"kernel": "sw_cont_kernel<{},{}>".format(rpl, {4: 6, 7: 4, 10: 4, 16: 2}[rpl]), "bound": "valu",
                          "achieved": swept / sw_s / 1e12, "peak": PEAK_TCUPS, "unit": "TCUPS",
                          "frac": swept / sw_s / 1e12 / PEAK_TCUPS,
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -474,7 +496,10 @@ def run_ranks(args, n, n_devices):
     """Start n ranks of this script (rank r on device r mod n_devices) and return (rank 0's line, per-rank records)."""
     from tredparse_amd import shard
     argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
-            str(args.warmup), "--samples", str(args.samples), "--coverage", str(args.coverage), "--seed", str(args.seed)]
+            str(args.warmup), "--samples", str(args.samples), "--seed", str(args.seed), "--readlen", str(args.readlen),
+            "--workload", args.workload]
+    if args.coverage_set:
+        argv += ["--coverage", str(args.coverage)]
     if args.stub:
         argv.append("--stub")
     with tempfile.TemporaryDirectory(prefix="tredbench_") as out_dir:
@@ -541,7 +566,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=1000, help="synthetic samples per GPU (x 30 loci)")
-    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--coverage", type=float, default=None, help="override the workload's coverage (30x / 100x)")
+    ap.add_argument("--readlen", type=int, default=150, choices=(100, 150, 250),
+                    help="read length: selects the sw_cont_kernel instantiation (R = 7 / 10 / 16 rows per lane)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3",
+                    help="config3 = BASELINE configs[2] (the headline); config5 = configs[4] (100x, expanded alleles)")
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds per CPU baseline leg")
@@ -555,6 +584,10 @@ def main():
     ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 5; also run with 1)")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    args.coverage_set = args.coverage is not None
+    if args.coverage is None:
+        args.coverage = WORKLOADS[args.workload]["synth"].get("coverage", 30.0)
+    args.coverage_used = args.coverage
     if args.e2e_child:
         return e2e_main(args)
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:     # a rank (torch.distributed.run or our launcher)

@@ -21,8 +21,8 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libssw.so")
 @pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref (the compiled reference ssw.c) is not built")
 def test_fuzz_parity_slice():
     import fuzz_parity
-    res = fuzz_parity.campaign(rounds=40, seed=20270301)
-    assert res["reads"] > 50000 and res["template_pairs"] > 100000
+    res = fuzz_parity.campaign(rounds=80, seed=20270301)
+    assert res["reads"] > 100000 and res["template_pairs"] > 200000
     assert res["mismatches"] == 0 and res["pair_mismatches"] == 0, res
 
 
@@ -42,6 +42,6 @@ def test_fuzz_hist_slice():
 
 def test_fuzz_grid_slice():
     import fuzz_grid
-    res = fuzz_grid.campaign(rounds=3, seed=20270304, max_pairs=6000)
-    assert res["units_checked"] > 20
+    res = fuzz_grid.campaign(rounds=12, seed=20270304, max_pairs=6000)
+    assert res["units_checked"] > 50
     assert res["mismatches"] == 0 and res["max_abs_diff_lik_or_pp"] <= 1e-6, res

@@ -278,8 +278,8 @@ __device__ __forceinline__ int letter_from(int words_vgpr, int idx) {
 // every row, the weight and the end cell of the best continuation
 //     WH[i]: the alignment leaves trunk cell (i, c) by a match at (i+1, c+1)
 //     WE[i]: it leaves inside a horizontal gap (trunk E[i][c+1], next match in row i+1)
-// and a template's result is max(trunk best, max_i H[i][c] + WH[i], max_i E[i][c+1] + WE[i], best alignment
-// inside the suffix alone) -- about one column's worth of work per template instead of |suffix| columns.
+// and a template's result is max(trunk best, max_i H[i][c] + WX[i], max_i E[i][c+1] + WE[i], best alignment
+// inside the suffix alone), WX = max(WH, WE - (go - ge)): the horizontal gap that opens from the trunk cell itself -- about one column's worth of work per template instead of |suffix| columns.
 // Packing makes the tie rules carry over: the reversed alignment's "start" payload (largest reversed column,
 // largest reversed row) is the forward end cell with the smallest column, then the smallest row; the start
 // coordinates travel in the trunk values' payload.  The reversed pass uses the unrestricted recurrences (E fed
@@ -566,6 +566,12 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             // cost was charged on the reversed side too: + go - ge in the scaled domain
             mirror_up<R>(D, 0, wb, PS);
             mirror_up<R>(E, c0, wb + R * PS, PS);
+            // A horizontal gap into the suffix may also open from the trunk cell itself (H - go, incl. cells reached by a
+            // vertical gap): that candidate has H's start payload and the key H + (WE - c0) -- so it folds into the
+            // H-candidate's vector once per strand, WX = max(WH, WE - c0), instead of a max(E, H - c0) per row and
+            // template end.  (c0 is a multiple of K: the end cell in the low bits is untouched.)
+#pragma unroll
+            for (int r = 0; r < R; ++r) wb[r * PS] = max(wb[r * PS], wb[(R + r) * PS] - c0);
             cnt_cols += (uint32_t)blen << 16;
         }
         build_profile<R>(J, a, read_base(), L, row0, false, mK, xK, geK);
@@ -616,10 +622,9 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
                 *slot = (long long)NEG * (1LL << 32);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int ef = max(E[r], H[r] - c0);   // the gap may also open from a cell reached by a vertical gap
-                    const int sh = (H[r] & ~PAYMASK) + wb[r * PS], se = (ef & ~PAYMASK) + wb[(R + r) * PS];
+                    const int sh = (H[r] & ~PAYMASK) + wb[r * PS], se = (E[r] & ~PAYMASK) + wb[(R + r) * PS];
                     atomicMax(slot, (long long)(((unsigned long long)(uint32_t)sh << 32) | (uint32_t)(H[r] & PAYMASK)));
-                    atomicMax(slot, (long long)(((unsigned long long)(uint32_t)se << 32) | (uint32_t)(ef & PAYMASK)));
+                    atomicMax(slot, (long long)(((unsigned long long)(uint32_t)se << 32) | (uint32_t)(E[r] & PAYMASK)));
                 }
                 const long long won = *slot;
                 int m = (int)(won >> 32);
