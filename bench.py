@@ -47,7 +47,30 @@ PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9      # int32 VALU lane-ops/s: 256 CU x 4 SI
 OPS_PER_CELL = 10.0                        # minimum VALU ops of one affine-gap local-alignment cell
 PEAK_TCUPS = PEAK_LANE_OPS / OPS_PER_CELL / 1e12
 HBM_PEAK_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_GLOB = os.path.join(ROOT, "profiles", "r*_pmc_summary.json")
+
+
+def pmc_traffic(kernel, library_version):
+    """(HBM bytes per launch of `kernel`, source) from the rocprofv3 PMC summaries under profiles/ -- only from a
+    summary taken on THIS build: tools/pmc_to_json.py records the library's tredgpu_version() (which carries a hash
+    of the kernel sources), and a summary of any other build is not evidence for the kernels being timed."""
+    import glob
+    seen = []
+    for path in sorted(glob.glob(PMC_GLOB), reverse=True):
+        try:
+            with open(path) as fp:
+                pm = json.load(fp)
+        except (OSError, ValueError):
+            continue
+        seen.append(os.path.basename(path))
+        if pm.get("library_version") != library_version:
+            continue
+        k = pm.get("kernels", {}).get(kernel, {})
+        if "hbm_bytes_per_launch" in k:
+            return k["hbm_bytes_per_launch"], "profiles/{} ({}; build {})".format(
+                os.path.basename(path), pm.get("how", "rocprofv3 --pmc passes"), library_version)
+    return None, "no PMC summary of this build ({}) under profiles/ (found: {})".format(library_version,
+                                                                                       ", ".join(seen) or "none")
 
 
 def bench_loci(loci):
@@ -300,19 +323,14 @@ def rank_main(args):
         rpl = rows_per_lane(args.readlen)
         lanes = cols * 4 * 16 * rpl                # cells the wavefronts occupy: 4 read slots x 16 lanes x R rows
         alg_bytes = int(batch.packed.nbytes + n * 12 + n * 5)  # packed reads + offsets/lengths in, tag/h/score out
-        traffic, traffic_src = None, None
-        if os.path.exists(PMC_SUMMARY):
-            with open(PMC_SUMMARY) as fp:
-                pm = json.load(fp)
-            k = pm.get("kernels", {}).get("sw_cont_kernel", {})
-            if "hbm_bytes_per_launch" in k:
-                traffic = k["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r02_pmc_summary.json ({})".format(pm.get("how", "rocprofv3 --pmc passes"))
+        traffic, traffic_src = (None, "counters of the 1 000-sample 150 bp config3 batch only") \
+            if (args.workload, args.readlen, args.samples) != ("config3", 150, 1000) else pmc_traffic("sw_cont_kernel", _lib.version())
         out = {
             "metric": "sample x TRED genotypes/sec at {:g}x {}bp".format(args.coverage_used, args.readlen),
             "value": value, "unit": "genotypes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32 (SW) + f64 (likelihood)", "data": "synthetic",
+            "library": _lib.version(),
             "config": {"workload": "{} {} at {} bp; fused SW+tagging -> histograms -> (h1,h2) grid, inputs resident "
                                    "in HBM".format(args.samples, WORKLOADS[args.workload]["what"], args.readlen),
                        "name": args.workload,
@@ -393,6 +411,8 @@ def e2e_main(args):
     with open(os.path.join(args.e2e_child, "truth.json")) as fp:
         truth = json.load(fp)
     bams = sorted(glob.glob(os.path.join(args.e2e_child, "*.bam")))
+    if args.e2e_limit > 0:
+        bams = bams[:args.e2e_limit]
     import torch
     torch.cuda.init()
     from tredparse_amd import shard, synth_bam, tred
@@ -431,7 +451,8 @@ def e2e_main(args):
         os.chdir(cwd)
     units = sum(sum(1 for n in names if n + ".1" in r["tredCalls"]) for r in done)
     hits = [r["tredCalls"].get(n + ".1") == truth[r["samplekey"]][k][0] for r in done for k, n in enumerate(names)]
-    rec = {"rank": rank, "units": units, "seconds": dt, "samples": len(tasks), "host_threads": threads,
+    rec = {"rank": rank, "device": os.environ.get("TRED_RANK_DEVICE", "0"), "units": units, "seconds": dt,
+           "samples": len(tasks), "host_threads": threads,
            "driver_seconds": {k: round(v, 4) for k, v in tred.TIMING.items()},
            "short_ok": int(sum(hits)), "short_n": len(hits), "bam_bytes": sum(os.path.getsize(b) for b in bams[lo:hi])}
     with open(os.path.join(out_dir, "e2e_rank{}.json".format(rank)), "w") as fp:
@@ -442,51 +463,80 @@ def e2e_main(args):
     shutil.rmtree(work, ignore_errors=True)
 
 
-def run_e2e(args):
-    """Launcher side of the end-to-end leg: make the BAMs (process pool, no GPU), run one child over them."""
-    from tredparse_amd import shard, synth_bam
+def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0):
+    """[(ranks, threads per rank)] of the end-to-end legs on n_devices GPUs with `usable` host CPUs: one driver per
+    GPU, and as many drivers per GPU as keep ~4 scan threads busy each (a driver formats while its threads scan).
+    Rank r works on device r mod n_devices; every rank gets an equal share of the CPUs."""
+    per_gpu = drivers_opt or max(1, usable // (5 * max(1, n_devices)))
+    plans = []
+    for dpg in sorted(set([1, per_gpu])):
+        ranks = dpg * n_devices
+        threads = threads_opt or max(1, (usable - ranks) // ranks)
+        plans.append((ranks, threads))
+    return plans
+
+
+def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
+    """Launcher side of the end-to-end legs: make the BAMs once (process pool, no GPU), then for every device count n
+    and every plan of e2e_plan start the driver ranks over the first n * per_gpu of them -- rank r on device r mod n
+    (shard.spawn_ranks), each with its block of the samples and its share of the host CPUs.  Returns {n: record}.
+    (spawn / make_bams: stand-ins for the CPU test of the launcher.)"""
+    from tredparse_amd import shard
     import shutil
+    if make_bams is None:
+        from tredparse_amd import synth_bam
+        make_bams = synth_bam.make_bams
+    spawn = spawn or shard.spawn_ranks
     root = tempfile.mkdtemp(prefix="tredbench_e2e_")
+    device_counts = sorted(set(device_counts))
+    # weak scaling: --e2e-samples per GPU, capped so that the largest leg stays at 512 files
+    per_gpu = {n: max(1, min(args.e2e_samples, 512 // n)) for n in device_counts}
     try:
         t0 = time.perf_counter()
-        made = synth_bam.make_bams(root, args.e2e_samples, seed=args.seed, workers=shard.usable_cpus())
+        made = make_bams(root, max(n * per_gpu[n] for n in device_counts), seed=args.seed, workers=shard.usable_cpus())
         gen_s = time.perf_counter() - t0
         with open(os.path.join(root, "truth.json"), "w") as fp:
             json.dump({key: h.tolist() for key, _, h in made}, fp)
-        argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(args.e2e_batch),
-                "--e2e-threads", str(args.e2e_threads)]
-        legs = []
-        many = args.e2e_drivers or max(1, shard.usable_cpus() // 5)   # ~4 scan threads keep one formatting driver busy
-        for drivers in sorted(set([1, many])):
-            out_dir = os.path.join(root, "out{}".format(drivers))
-            os.makedirs(out_dir)
-            env = dict(os.environ, TREDBENCH_OUT=out_dir)
-            codes = shard.spawn_ranks(argv, drivers, 1, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
-            if any(codes):
-                legs.append({"drivers": drivers, "error": "exit codes {}".format(codes)})
-                continue
-            ranks = []
-            for r in range(drivers):
-                with open(os.path.join(out_dir, "e2e_rank{}.json".format(r))) as fp:
-                    ranks.append(json.load(fp))
-            units, secs = sum(r["units"] for r in ranks), max(r["seconds"] for r in ranks)
-            nbytes = sum(r["bam_bytes"] for r in ranks)
-            legs.append({"drivers": drivers, "value": units / secs, "unit": "genotypes/s", "units": units,
-                         "seconds": secs, "samples": sum(r["samples"] for r in ranks),
-                         "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,
-                         "per_driver": [{"seconds": round(r["seconds"], 3), **r["driver_seconds"]} for r in ranks],
-                         "bam_MBps": nbytes / 1e6 / secs,
-                         "short_allele_exact_frac": sum(r["short_ok"] for r in ranks) / max(1, sum(r["short_n"] for r in ranks))})
-        best = max((l for l in legs if "value" in l), key=lambda l: l["value"], default=None)
-        rec = dict(best) if best else {"error": "no end-to-end leg finished"}
-        rec["legs"] = legs
-        rec["samples_per_gpu_batch"] = args.e2e_batch
-        rec["bam_generation_seconds"] = gen_s
-        rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
-                       "native scan (BGZF inflate, BAI queries, read selection, pair lengths, depth) in host threads -> GPU "
-                       "batches -> tredCalls -> JSON + VCF files; `drivers` processes share ONE GPU, each with its block of "
-                       "the samples (tred.py --gpus N uses the same fan-out, rank r on device r mod devices)")
-        return rec
+        out = {}
+        for n_devices in device_counts:
+            legs = []
+            n_files = n_devices * per_gpu[n_devices]
+            for drivers, threads in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads):
+                argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(args.e2e_batch),
+                        "--e2e-threads", str(threads), "--e2e-limit", str(n_files)]
+                out_dir = os.path.join(root, "out{}x{}".format(n_devices, drivers))
+                os.makedirs(out_dir)
+                env = dict(os.environ, TREDBENCH_OUT=out_dir)
+                codes = spawn(argv, drivers, n_devices, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
+                if any(codes):
+                    legs.append({"drivers": drivers, "devices": n_devices, "error": "exit codes {}".format(codes)})
+                    continue
+                ranks = []
+                for r in range(drivers):
+                    with open(os.path.join(out_dir, "e2e_rank{}.json".format(r))) as fp:
+                        ranks.append(json.load(fp))
+                units, secs = sum(r["units"] for r in ranks), max(r["seconds"] for r in ranks)
+                nbytes = sum(r["bam_bytes"] for r in ranks)
+                legs.append({"drivers": drivers, "devices": n_devices, "value": units / secs, "unit": "genotypes/s",
+                             "units": units, "seconds": secs, "samples": sum(r["samples"] for r in ranks),
+                             "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,
+                             "per_driver": [{"seconds": round(r["seconds"], 3), "device": r.get("device", "0"),
+                                             **r["driver_seconds"]} for r in ranks],
+                             "bam_MBps": nbytes / 1e6 / secs,
+                             "short_allele_exact_frac": sum(r["short_ok"] for r in ranks) / max(1, sum(r["short_n"] for r in ranks))})
+            best = max((l for l in legs if "value" in l), key=lambda l: l["value"], default=None)
+            rec = dict(best) if best else {"error": "no end-to-end leg finished"}
+            rec["legs"] = legs
+            rec["devices"] = n_devices
+            rec["samples_per_gpu_batch"] = args.e2e_batch
+            rec["bam_generation_seconds"] = gen_s
+            rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
+                           "native scan (BGZF inflate, BAI queries, read selection, pair lengths, depth) in host threads -> "
+                           "GPU batches -> tredCalls -> JSON + VCF files; `drivers` processes over `devices` GPUs (rank r on "
+                           "device r mod devices), each with its block of the samples and its share of the host CPUs "
+                           "(tred.py --gpus N uses the same fan-out)")
+            out[n_devices] = rec
+        return out
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -547,7 +597,42 @@ def launcher_main(args):
     out["scaling_sweep"] = scaling
     out["gpus_visible"] = n_devices
     if args.e2e_samples > 0 and not args.stub:
-        out["end_to_end"] = run_e2e(args)
+        # the product path from BAM files at every device count of the sweep that the box really has (a 1-GPU box:
+        # n = 1 only); the line's own record is that of --gpus
+        counts = sorted(set(r["n"] for r in scaling if not r.get("oversubscribed")) | {min(args.gpus, n_devices)})
+        e2e = run_e2e(args, counts)
+        out["end_to_end"] = e2e[min(args.gpus, n_devices)]
+        for r in scaling:
+            if r["n"] in e2e and not r.get("oversubscribed"):
+                rec = e2e[r["n"]]
+                r["end_to_end"] = {k: rec[k] for k in ("value", "unit", "drivers", "devices", "samples", "seconds",
+                                                       "host_threads_per_driver") if k in rec}
+    if args.legs and not args.stub:
+        # the configurations that otherwise only have correctness tests, one rank each on device 0: BASELINE
+        # configs[4] and the other read lengths (their own sw_cont_kernel instantiations)
+        out["legs"] = []
+        for spec in args.legs.split(","):
+            workload, readlen, samples = spec.split(":")
+            leg_args = argparse.Namespace(**vars(args))
+            leg_args.workload, leg_args.readlen, leg_args.samples = workload, int(readlen), int(samples)
+            leg_args.steps, leg_args.warmup, leg_args.coverage_set = min(args.steps, 5), 1, False
+            leg_args.coverage = WORKLOADS[workload]["synth"].get("coverage", 30.0)
+            try:
+                line, _ = run_ranks(leg_args, 1, n_devices)
+            except Exception as e:
+                out["legs"].append({"leg": spec, "error": str(e)})
+                continue
+            r = line["roofline"]
+            out["legs"].append({"leg": spec, "metric": line["metric"], "value": line["value"], "unit": line["unit"],
+                                "ms_per_step": line["ms_per_step"], "steps": line["steps"],
+                                "workload": line["config"]["workload"],
+                                "units_per_step": line["config"]["units_per_step_per_gpu"],
+                                "reads_per_step": line["config"]["reads_per_step_per_gpu"],
+                                "kernels_ms_per_step": line["kernels_ms_per_step"],
+                                "mean_grid_pairs": line["check"]["mean_grid_pairs"],
+                                "max_grid_pairs": line["check"]["max_grid_pairs"], "units_ok": line["check"]["units_ok"],
+                                "roofline": {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                               "avg_launch_ms", "lane_occupancy", "effective_TCUPS")}})
     if not args.no_cpu_baseline and not args.stub:
         loci, batch = make_batch(args, 0, 1)
         from tredparse_amd import shard as _shard
@@ -582,7 +667,10 @@ def main():
     ap.add_argument("--e2e-batch", type=int, default=16, help="samples per GPU batch in the end-to-end leg")
     ap.add_argument("--e2e-threads", type=int, default=0, help="host threads per driver in the end-to-end leg (0: cores / drivers)")
     ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 5; also run with 1)")
+    ap.add_argument("--legs", default="config5:150:200,config3:100:500,config3:250:500",
+                    help="extra one-GPU legs workload:readlen:samples, comma separated ('' for none)")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
+    ap.add_argument("--e2e-limit", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     args.coverage_set = args.coverage is not None
     if args.coverage is None:

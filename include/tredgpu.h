@@ -81,6 +81,8 @@ const char* tredgpu_last_error(const tredgpu_ctx* ctx);  /* ctx may be NULL: las
 int tredgpu_sync(tredgpu_ctx* ctx);
 /* the HIP stream (hipStream_t) all work of this context is enqueued on */
 void* tredgpu_get_stream(tredgpu_ctx* ctx);
+/* "tredgpu <ver> (gfx950) src <16 hex digits>": the hash of the kernel sources this library was built from (csrc/Makefile);
+ * the PMC summaries under profiles/ carry the same hash and bench.py cites their counters only when the two agree */
 const char* tredgpu_version(void);
 
 /* ---- static tables ------------------------------------------------------------------------ */

@@ -51,3 +51,62 @@ def test_rank_env_pins_one_device_per_rank():
     assert e["HIP_VISIBLE_DEVICES"] == "1" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29500"
     e = shard.rank_env(1, 2, 1, None, base={})
     assert "HIP_VISIBLE_DEVICES" not in e and e["LOCAL_RANK"] == "1"
+
+
+def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
+    """run_e2e on an 8-GPU box (stub ranks): one set of BAMs, a leg per device count of the sweep, ranks = drivers per
+    GPU x GPUs with rank r on device r mod n and an equal share of the CPUs each; on a 1-GPU box the plan is the one of
+    earlier rounds (1 driver x 15 threads, 3 drivers x 4 threads on 16 CPUs)."""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    from tredparse_amd import shard
+    assert bench.e2e_plan(1, 16) == [(1, 15), (3, 4)]
+    assert bench.e2e_plan(8, 128) == [(8, 15), (24, 4)]
+    assert bench.e2e_plan(8, 16) == [(8, 1)]
+    assert bench.e2e_plan(2, 16, drivers_opt=2, threads_opt=3) == [(2, 3), (4, 3)]
+    monkeypatch.setattr(shard, "usable_cpus", lambda: 64)
+    made, spawned = [], []
+
+    def fake_bams(root, n, seed=0, workers=1):
+        made.append(n)
+        import numpy as np
+        return [("s{:04d}".format(i), os.path.join(root, "s{:04d}.bam".format(i)), np.zeros((30, 2), int)) for i in range(n)]
+
+    def fake_spawn(argv, world, n_devices, timeout=None, env=None, stdout=None, cwd=None):
+        limit = int(argv[argv.index("--e2e-limit") + 1])
+        threads = int(argv[argv.index("--e2e-threads") + 1])
+        spawned.append((world, n_devices, limit, threads))
+        for r in range(world):
+            lo, hi = shard.shard_range(limit, r, world)
+            dev = shard.rank_env(r, world, 1, r % n_devices, base={})["TRED_RANK_DEVICE"]
+            with open(os.path.join(env["TREDBENCH_OUT"], "e2e_rank{}.json".format(r)), "w") as fp:
+                json.dump({"rank": r, "device": dev, "units": 30 * (hi - lo), "seconds": 1.0 + 0.01 * r, "samples": hi - lo,
+                           "host_threads": threads, "driver_seconds": {"gpu": 0.1}, "short_ok": 1, "short_n": 1,
+                           "bam_bytes": 1000 * (hi - lo)}, fp)
+        return [0] * world
+
+    args = argparse.Namespace(e2e_samples=128, seed=1, e2e_drivers=0, e2e_threads=0, e2e_batch=16, rank_timeout=60)
+    recs = bench.run_e2e(args, [1, 2, 8], spawn=fake_spawn, make_bams=fake_bams)
+    assert made == [512]                                            # one set of files: 8 GPUs x 64 (capped at 512)
+    assert sorted(recs) == [1, 2, 8]
+    # (ranks, devices, files, threads per rank): 64 CPUs -> 12 drivers per GPU at one GPU, 6 at two, 1 at eight
+    assert spawned == [(1, 1, 128, 63), (12, 1, 128, 4), (2, 2, 256, 31), (12, 2, 256, 4), (8, 8, 512, 7)]
+    eight = recs[8]
+    assert eight["devices"] == 8 and eight["drivers"] == 8 and eight["samples"] == 512
+    assert sorted(d["device"] for d in eight["per_driver"]) == [str(i) for i in range(8)]
+    assert abs(eight["value"] - 30 * 512 / 1.07) < 1e-6              # all ranks' units / the slowest rank's time
+
+
+def test_pmc_traffic_is_only_cited_for_the_build_it_was_taken_from(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "PMC_GLOB", str(tmp_path / "r*_pmc_summary.json"))
+    (tmp_path / "r02_pmc_summary.json").write_text(json.dumps(
+        {"kernels": {"sw_cont_kernel": {"hbm_bytes_per_launch": 111.0}}}))                      # no build recorded
+    (tmp_path / "r03_pmc_summary.json").write_text(json.dumps(
+        {"library_version": "tredgpu 0.3 (gfx950) src aaaa", "kernels": {"sw_cont_kernel": {"hbm_bytes_per_launch": 222.0}}}))
+    got, src = bench.pmc_traffic("sw_cont_kernel", "tredgpu 0.3 (gfx950) src aaaa")
+    assert got == 222.0 and "r03_pmc_summary.json" in src and "src aaaa" in src
+    got, src = bench.pmc_traffic("sw_cont_kernel", "tredgpu 0.3 (gfx950) src bbbb")
+    assert got is None and "no PMC summary of this build" in src and "r02_pmc_summary.json" in src

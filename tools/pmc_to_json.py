@@ -27,6 +27,13 @@ def main(root):
     out = {"how": "rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python3 bench.py --steps 3 --warmup 1 "
                   "--no-cpu-baseline (RANK=0 WORLD_SIZE=1); FETCH_SIZE and WRITE_SIZE in separate passes, KiB x 1024",
            "kernels": {}}
+    # which build the counters belong to: the library's own report of its source hash (tredgpu_version)
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from tredparse_amd import _lib
+        out["library_version"] = _lib.version()
+    except Exception as e:                      # (summarising on a box without the library)
+        out["library_version"] = "unavailable: {}".format(e)
     ks = os.path.join(root, "kernel_stats.csv")
     if os.path.exists(ks):
         for r in csv.DictReader(open(ks)):

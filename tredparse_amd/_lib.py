@@ -162,6 +162,11 @@ def pack_codes(codes, lengths=None):
     return packed, woff, rlen
 
 
+def version():
+    """The library's version string incl. the hash of the kernel sources it was built from (csrc/Makefile)."""
+    return load().tredgpu_version().decode()
+
+
 class Context:
     """One GPU + one HIP stream (tredgpu_ctx)."""
 

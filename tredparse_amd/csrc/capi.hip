@@ -213,7 +213,10 @@ int copy_back(tredgpu_ctx* c, T* host, const T* dev, size_t n) {
 
 extern "C" {
 
-const char* tredgpu_version(void) { return "tredgpu 0.1 (gfx950)"; }
+#ifndef TREDGPU_SRC_HASH
+#define TREDGPU_SRC_HASH "unknown"
+#endif
+const char* tredgpu_version(void) { return "tredgpu 0.3 (gfx950) src " TREDGPU_SRC_HASH; }
 
 int tredgpu_create(int device_id, tredgpu_ctx** out) {
     if (!out) return fail(nullptr, -2, "out is NULL");
