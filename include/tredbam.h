@@ -164,6 +164,24 @@ int64_t tredbam_details_json(const uint8_t* seq4, const int64_t* seq4_off, const
  * is not finite, a key listed twice) -- the caller's generic encoder then decides; -2: bad arguments. */
 int64_t tredbam_sparse_json(const int32_t* a, const int32_t* b, const double* values, int64_t n, int32_t depth,
                             char* out, int64_t cap);
+/* The two calls above for many items at once (a sample's 30 `details` lists and 90 distributions: one call each
+ * instead of 120).  Item k covers entries off[k] .. off[k+1] of reads/tags/hs (a/b/values); two_part[k] != 0: keys
+ * "a,b".  Item k's text is out[out_off[k] .. out_off[k+1]); status[k] = 0, or -1 where the single call would return -1
+ * (empty text: the caller's generic encoder prints that item).  Return the bytes written, -3: cap too small, -2: bad
+ * arguments. */
+int64_t tredbam_sparse_json_many(const int32_t* a, const int32_t* b, const double* values, const int64_t* off,
+                                 const uint8_t* two_part, int64_t n_items, int32_t depth, char* out, int64_t cap,
+                                 int64_t* out_off, int8_t* status);
+int64_t tredbam_details_json_many(const uint8_t* seq4, const int64_t* seq4_off, const int32_t* read_len, const char* names,
+                                  const int64_t* name_off, const int64_t* reads, const uint8_t* tags, const int32_t* hs,
+                                  const int64_t* off, int64_t n_items, char* out, int64_t cap, int64_t* out_off,
+                                  int8_t* status);
+/* Per slice pool[first[k] .. first[k] + count[k]) of a pair-length pool: mean, population standard deviation (0 for an
+ * empty slice) and the 40-bin histogram of the values in [0, 1000] (bin = value / 25, the last bin closed) -- the numbers
+ * the JSON's PEG / PET ("346+/-78bp") and P_PEG / P_PET ("0:0,25:0,...") strings are printed from
+ * (tredparse/models.py:87-98), for all loci of a sample in one call.  hist: n x 40 ints.  0, or -2 on bad arguments. */
+int tredbam_pair_stats(const int32_t* pool, const int64_t* first, const int32_t* count, int64_t n, double* mean,
+                       double* sd, int32_t* hist);
 /* repr(float) of one value into out (>= 32 bytes); returns the length, -1 for a value that is not finite (test hook) */
 int tredbam_float_repr(double value, char* out);
 

@@ -406,3 +406,35 @@ def test_long_read_drops_only_its_unit():
     s.read_len[a] = 150
     s.readlen = 500                                    # ladder of 18 + 3 * 167 + 18 columns
     assert sorted(bam_parser.admit(s)) == [0, 1, 2] and "ladder" in s.dropped[0]
+
+
+def test_lazy_views_print_through_the_batched_native_calls():
+    """A sample's `details` (bam_parser.Details over the scan's pools) and distributions (models.SparseDist) go
+    through ONE native call each (tredbam_details_json_many / tredbam_sparse_json_many): same bytes as json.dumps of
+    the plain lists and dicts, incl. an empty list, an empty distribution and a one-part next to a two-part one."""
+    import numpy as np
+    from tredparse_amd import bam_parser, models
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    scan = bam_parser.scan_sample(os.path.join(GOLD, "bam", "t001.bam"), repo, ["HD", "DM1", "SCA1"])
+    rng = np.random.default_rng(3)
+    calls, plain = {"inferredGender": "Female", "depthY": 0.0, "readLen": 150}, {}
+    for k, name in enumerate(scan.names):
+        a, b = scan.reads_of(k)
+        n = b - a
+        tags = rng.integers(0, 6, n).astype(np.uint8)
+        hs = rng.integers(0, 51, n).astype(np.int16)
+        _, det, _ = bam_parser.tally(scan, k, tags, hs, lazy=True)
+        calls[name + ".details"] = det
+        m = rng.random(60) * (rng.random(60) < 0.3)
+        m[7] = 1e-7
+        calls[name + ".P_h1"] = models.sparsify_marginal(m + 0.0, lazy=True) if k != 2 else models.SparseDist(
+            np.zeros(0, np.int64), None, np.zeros(0))
+        trip = np.array([[3 * i, 3 * j, rng.random()] for i in range(1, 9) for j in range(i, 9)])
+        calls[name + ".P_h1h2"] = models.sparsify_joint_triples(trip, float(trip[:, 2].sum()), 3, lazy=True)
+        calls[name + ".PP"] = float(rng.random())
+    for key, v in calls.items():
+        plain[key] = v.items() if isinstance(v, bam_parser.Details) else (v.as_dict() if isinstance(v, models.SparseDist) else v)
+    assert sum(len(plain[n + ".details"]) for n in scan.names) > 20 and plain["SCA1.details"] == []
+    lazy = {"samplekey": "t001", "bam": "x.bam", "tredCalls": calls}
+    eager = {"samplekey": "t001", "bam": "x.bam", "tredCalls": plain}
+    assert tredmod.dumps_result(lazy) == json.dumps(eager, sort_keys=True, indent=4, separators=(",", ": "))

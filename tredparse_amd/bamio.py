@@ -364,6 +364,14 @@ def _native():
             lib.tredbam_details_json.restype = C.c_int64
             lib.tredbam_sparse_json.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
             lib.tredbam_sparse_json.restype = C.c_int64
+            lib.tredbam_pair_stats.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 3
+            lib.tredbam_pair_stats.restype = C.c_int
+            lib.tredbam_sparse_json_many.argtypes = [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                                                                          C.c_void_p, C.c_void_p]
+            lib.tredbam_sparse_json_many.restype = C.c_int64
+            lib.tredbam_details_json_many.argtypes = [C.c_void_p] * 9 + [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                                                          C.c_void_p]
+            lib.tredbam_details_json_many.restype = C.c_int64
             _lib = lib
     return _lib or None
 
@@ -422,6 +430,94 @@ def details_json(seq4, seq4_off, read_len, names, name_off, reads, tags, hs):
     if got < 0:
         raise RuntimeError("tredbam_details_json failed ({})".format(got))
     return buf.raw[:got].decode("ascii")
+
+
+def pair_stats(pool, first, count):
+    """tredbam_pair_stats: (mean[g], sd[g], hist[g, 40]) of the slices pool[first[k] : first[k] + count[k]], or None
+    (library absent)."""
+    lib = _native()
+    if lib is None:
+        return None
+    g = len(first)
+    pool = np.ascontiguousarray(pool, np.int32)
+    first = np.ascontiguousarray(first, np.int64)
+    count = np.ascontiguousarray(count, np.int32)
+    mean, sd, hist = np.empty(g), np.empty(g), np.empty((g, 40), np.int32)
+    rc = lib.tredbam_pair_stats(pool.ctypes.data if len(pool) else None, first.ctypes.data, count.ctypes.data, g,
+                                mean.ctypes.data, sd.ctypes.data, hist.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("tredbam_pair_stats failed ({})".format(rc))
+    return mean, sd, hist
+
+
+def _texts(buf, got, out_off, status):
+    """[text or None] of the items of a *_many call."""
+    raw = buf[:got].tobytes().decode("ascii")
+    o = out_off.tolist()
+    return [raw[o[k]:o[k + 1]] if st == 0 else None for k, st in enumerate(status.tolist())]
+
+
+def sparse_json_many(dists, depth):
+    """tredbam_sparse_json_many: the texts of many distributions [(a, b or None, values)] in one native call (a sample
+    has 90 of them); an entry is None where the generic encoder has to print that one.  None: library absent."""
+    lib = _native()
+    if lib is None:
+        return None
+    if not dists:
+        return []
+    sizes = np.fromiter((len(d[2]) for d in dists), np.int64, len(dists))
+    off = np.zeros(len(dists) + 1, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    total = int(off[-1])
+    a = np.empty(total, np.int32)
+    b = np.zeros(total, np.int32)
+    v = np.empty(total, np.float64)
+    two = np.zeros(len(dists), np.uint8)
+    for k, (da, db, dv) in enumerate(dists):
+        lo, hi = int(off[k]), int(off[k + 1])
+        a[lo:hi] = da
+        v[lo:hi] = dv
+        if db is not None:
+            b[lo:hi] = db
+            two[k] = 1
+    cap = 64 * len(dists) + total * (4 * (depth + 1) + 80)
+    buf = np.empty(cap, np.uint8)
+    out_off = np.empty(len(dists) + 1, np.int64)
+    status = np.empty(len(dists), np.int8)
+    got = lib.tredbam_sparse_json_many(a.ctypes.data, b.ctypes.data, v.ctypes.data, off.ctypes.data, two.ctypes.data,
+                                       len(dists), depth, buf.ctypes.data, cap, out_off.ctypes.data, status.ctypes.data)
+    if got < 0:
+        raise RuntimeError("tredbam_sparse_json_many failed ({})".format(got))
+    return _texts(buf, got, out_off, status)
+
+
+def details_json_many(seq4, seq4_off, read_len, names, name_off, lists):
+    """tredbam_details_json_many: the texts of many `details` lists [(reads, tags, hs)] over ONE scan's pools in one
+    native call; an entry is None where the generic encoder has to print that list.  None: library absent."""
+    lib = _native()
+    if lib is None:
+        return None
+    if not lists:
+        return []
+    sizes = np.fromiter((len(x[0]) for x in lists), np.int64, len(lists))
+    off = np.zeros(len(lists) + 1, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    cat = lambda i, dt: (np.ascontiguousarray(np.concatenate([x[i] for x in lists]), dt) if int(off[-1])
+                         else np.zeros(1, dt))
+    reads, tags, hs = cat(0, np.int64), cat(1, np.uint8), cat(2, np.int32)
+    n = int(off[-1])
+    name_len = int((name_off[reads[:n] + 1] - name_off[reads[:n]]).sum()) if n else 0
+    cap = 64 * len(lists) + 200 * n + 2 * name_len + (int(read_len[reads[:n]].sum()) if n else 0)
+    buf = np.empty(cap, np.uint8)
+    out_off = np.empty(len(lists) + 1, np.int64)
+    status = np.empty(len(lists), np.int8)
+    got = lib.tredbam_details_json_many(seq4.ctypes.data, seq4_off.ctypes.data, read_len.ctypes.data, names,
+                                        name_off.ctypes.data, reads.ctypes.data, tags.ctypes.data, hs.ctypes.data,
+                                        off.ctypes.data, len(lists), buf.ctypes.data, cap, out_off.ctypes.data,
+                                        status.ctypes.data)
+    if got < 0:
+        raise RuntimeError("tredbam_details_json_many failed ({})".format(got))
+    return _texts(buf, got, out_off, status)
 
 
 class ScanOpts(C.Structure):

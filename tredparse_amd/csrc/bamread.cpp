@@ -819,6 +819,80 @@ int64_t tredbam_sparse_json(const int32_t* a, const int32_t* b, const double* va
     return p - out;
 }
 
+// Many distributions / many details lists in one call (a sample's 90 + 30 of them: the per-call cost of the binding
+// was a third of the driver thread's time per sample).  Item k covers entries off[k] .. off[k+1] of the input arrays;
+// its text lands at out[out_off[k] .. out_off[k+1]); status[k] = 0, or the single call's -1 (text left empty: the
+// caller's generic encoder takes that item).  Returns the bytes written, -3 when cap is too small, -2 on bad arguments.
+int64_t tredbam_sparse_json_many(const int32_t* a, const int32_t* b, const double* values, const int64_t* off,
+                                 const uint8_t* two_part, int64_t n_items, int32_t depth, char* out, int64_t cap,
+                                 int64_t* out_off, int8_t* status) {
+    if (n_items < 0 || !off || !two_part || !out || !out_off || !status) return -2;
+    int64_t at = 0;
+    out_off[0] = 0;
+    for (int64_t k = 0; k < n_items; ++k) {
+        const int64_t n = off[k + 1] - off[k];
+        if (n < 0 || (two_part[k] && !b)) return -2;
+        const int64_t got = tredbam_sparse_json(a ? a + off[k] : nullptr, two_part[k] ? b + off[k] : nullptr,
+                                                values ? values + off[k] : nullptr, n, depth, out + at, cap - at);
+        if (got == -3 || got == -2) return got;
+        status[k] = got < 0 ? -1 : 0;
+        if (got > 0) at += got;
+        out_off[k + 1] = at;
+    }
+    return at;
+}
+
+int64_t tredbam_details_json_many(const uint8_t* seq4, const int64_t* seq4_off, const int32_t* read_len, const char* names,
+                                  const int64_t* name_off, const int64_t* reads, const uint8_t* tags, const int32_t* hs,
+                                  const int64_t* off, int64_t n_items, char* out, int64_t cap, int64_t* out_off,
+                                  int8_t* status) {
+    if (n_items < 0 || !off || !out || !out_off || !status) return -2;
+    int64_t at = 0;
+    out_off[0] = 0;
+    for (int64_t k = 0; k < n_items; ++k) {
+        const int64_t n = off[k + 1] - off[k];
+        if (n < 0) return -2;
+        const int64_t got = tredbam_details_json(seq4, seq4_off, read_len, names, name_off, reads ? reads + off[k] : nullptr,
+                                                 tags ? tags + off[k] : nullptr, hs ? hs + off[k] : nullptr, n, out + at,
+                                                 cap - at);
+        if (got == -3 || got == -2) return got;
+        status[k] = got < 0 ? -1 : 0;
+        if (got > 0) at += got;
+        out_off[k + 1] = at;
+    }
+    return at;
+}
+
+// Mean, population standard deviation and the 40-bin histogram over [0, 1000] of many slices of a pair-length pool
+// (the numbers behind the JSON's PEG / PET / P_PEG / P_PET strings, models.py:87-98 of the reference: mean_std and
+// histogram per list), all loci of a sample in one pass.  Sums run in pool order in double precision.
+int tredbam_pair_stats(const int32_t* pool, const int64_t* first, const int32_t* count, int64_t n, double* mean,
+                       double* sd, int32_t* hist) {
+    if (n < 0 || (n > 0 && (!first || !count || !mean || !sd || !hist))) return -2;
+    constexpr int BINS = 40, SPAN = 1000, WIDTH = SPAN / BINS;
+    for (int64_t k = 0; k < n; ++k) {
+        const int32_t c = count[k];
+        int32_t* h = hist + k * BINS;
+        for (int j = 0; j < BINS; ++j) h[j] = 0;
+        mean[k] = sd[k] = 0;
+        if (c <= 0) continue;
+        if (!pool) return -2;
+        const int32_t* x = pool + first[k];
+        double sum = 0;
+        for (int32_t i = 0; i < c; ++i) sum += (double)x[i];
+        const double m = sum / (double)c;
+        double q = 0;
+        for (int32_t i = 0; i < c; ++i) {
+            const double d = (double)x[i] - m;
+            q += d * d;
+            if (x[i] >= 0 && x[i] <= SPAN) ++h[std::min(x[i] / WIDTH, BINS - 1)];
+        }
+        mean[k] = m;
+        sd[k] = std::sqrt(q / (double)c);
+    }
+    return 0;
+}
+
 int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out) {
     if (!b || !out) return -2;
     int rc = bg_seek(b, b->first_record);

@@ -165,6 +165,13 @@ def _pool_strings(pool, first, count):
     these small integers are exact in float64, the bins of np.histogram over (0, SPAN) are x // 25 for integers."""
     g = len(first)
     count = np.asarray(count, np.int64)
+    from . import bamio
+    native = bamio.pair_stats(pool, first, count) if g else None
+    if native is not None:                  # the same numbers from one native pass over the pool
+        mean, std, hist = native
+        ms = ["%.0f+/-%.0fbp" % (m, sd) if c else "" for m, sd, c in zip(mean.tolist(), std.tolist(), count.tolist())]
+        hs = [",".join([a + str(b) for a, b in zip(_HIST_LEFT, row)]) if c else "" for row, c in zip(hist.tolist(), count.tolist())]
+        return ms, hs
     lo, hi = (int(first[0]), int(first[-1] + count[-1])) if g else (0, 0)
     x = np.asarray(pool[lo:hi], np.int64)
     unit = np.repeat(np.arange(g), count)

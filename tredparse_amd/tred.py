@@ -28,7 +28,7 @@ from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from datetime import date, timedelta
 
-from . import __version__
+from . import __version__, bamio
 from .bam_parser import Details, scan_sample, tally
 from .meta import BUILDS, TREDsRepo
 from .models import GridError, SparseDist, format_call, pair_summaries
@@ -340,17 +340,34 @@ def dumps_result(results):
     if scalars:
         lines = json.dumps(scalars, sort_keys=True, separators=(sep, ": "))[1:-1].split(sep)
         entry = dict(zip(sorted(scalars), lines))
+    # all distributions of the sample in one native call, all `details` lists (they share the sample's scan) in another
+    native = {}
+    dist_keys = [k for k, v in calls.items() if isinstance(v, SparseDist)]
+    if dist_keys:
+        texts = bamio.sparse_json_many([(calls[k].a, calls[k].b, calls[k].values) for k in dist_keys], 2)
+        if texts is not None:
+            native.update(zip(dist_keys, texts))
+    det_keys = [k for k, v in calls.items() if isinstance(v, Details)]
+    if det_keys and all(calls[k].scan is calls[det_keys[0]].scan for k in det_keys):
+        sc = calls[det_keys[0]].scan
+        texts = bamio.details_json_many(sc.seq4, sc.seq4_off, sc.read_len, sc.name_blob, sc.name_off,
+                                        [(calls[k].reads, calls[k].tags, calls[k].hs) for k in det_keys])
+        if texts is not None:
+            native.update(zip(det_keys, texts))
     for key, v in calls.items():
         if key in scalars:
             continue
-        if isinstance(v, dict):
+        text = native.get(key)
+        if text is not None:
+            pass
+        elif isinstance(v, dict):
             text = _flat(v, 2)
         elif isinstance(v, SparseDist):
-            text = v.json_text(2)
+            text = v.json_text(2) if key not in native else None
             if text is None:
                 text = _flat(v.as_dict(), 2)
         elif isinstance(v, Details):
-            text = v.json_text()
+            text = v.json_text() if key not in native else None
             if text is None:
                 text = _flat_list(v.items())
         else:
