@@ -335,19 +335,23 @@ def dumps_result(results):
     one line per sorted key), every flat dict in one call, `details` natively from the scan's pools."""
     calls = results["tredCalls"]
     sep = ",\n" + _P8
-    scalars = {k: v for k, v in calls.items() if not isinstance(v, (dict, list, Details, SparseDist))}
+    # (exact types first: an isinstance() against the Mapping / Sequence views costs an ABC check per key, 675 keys)
+    kinds = {k: type(v) for k, v in calls.items()}
+    plain = (int, float, str, bool, type(None))
+    scalars = {k: v for k, v in calls.items()
+               if kinds[k] in plain or not isinstance(v, (dict, list, Details, SparseDist))}
     entry = {}
     if scalars:
         lines = json.dumps(scalars, sort_keys=True, separators=(sep, ": "))[1:-1].split(sep)
         entry = dict(zip(sorted(scalars), lines))
     # all distributions of the sample in one native call, all `details` lists (they share the sample's scan) in another
     native = {}
-    dist_keys = [k for k, v in calls.items() if isinstance(v, SparseDist)]
+    dist_keys = [k for k, t in kinds.items() if t is SparseDist]
     if dist_keys:
         texts = bamio.sparse_json_many([(calls[k].a, calls[k].b, calls[k].values) for k in dist_keys], 2)
         if texts is not None:
             native.update(zip(dist_keys, texts))
-    det_keys = [k for k, v in calls.items() if isinstance(v, Details)]
+    det_keys = [k for k, t in kinds.items() if t is Details]
     if det_keys and all(calls[k].scan is calls[det_keys[0]].scan for k in det_keys):
         sc = calls[det_keys[0]].scan
         texts = bamio.details_json_many(sc.seq4, sc.seq4_off, sc.read_len, sc.name_blob, sc.name_off,
