@@ -445,7 +445,8 @@ def e2e_main(args):
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads, lazy_details=True)
+        tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads, lazy_details=True,
+                      background_sink=True)
         dt = time.perf_counter() - t0
     finally:
         os.chdir(cwd)
@@ -465,11 +466,13 @@ def e2e_main(args):
 
 def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0):
     """[(ranks, threads per rank)] of the end-to-end legs on n_devices GPUs with `usable` host CPUs: one driver per
-    GPU, and as many drivers per GPU as keep ~4 scan threads busy each (a driver formats while its threads scan).
+    GPU, and as many drivers per GPU as keep ~7 or ~4 scan threads busy each (a driver formats and hands its results
+    to a writer thread while its threads scan).
     Rank r works on device r mod n_devices; every rank gets an equal share of the CPUs."""
-    per_gpu = drivers_opt or max(1, usable // (5 * max(1, n_devices)))
+    g = max(1, n_devices)
+    tried = [drivers_opt] if drivers_opt else [max(1, usable // (8 * g)), max(1, usable // (5 * g))]
     plans = []
-    for dpg in sorted(set([1, per_gpu])):
+    for dpg in sorted(set([1] + tried)):
         ranks = dpg * n_devices
         threads = threads_opt or max(1, (usable - ranks) // ranks)
         plans.append((ranks, threads))

@@ -185,3 +185,25 @@ def test_tasks_with_different_options_go_in_separate_gpu_batches(tmp_path, monke
     res = tredmod.finish_batch(Recording(), args, scans)
     assert [r["samplekey"] for r in res] == ["a", "b", "c"]
     assert sorted(seen) == [(60, 1, 1), (300, 0, 4)]
+
+
+def test_results_reach_the_sink_in_order_from_the_writer_thread(tmp_path, monkeypatch):
+    """run_many(background_sink=True): the sink runs on one writer thread, every result once and in task order; an
+    exception in the sink surfaces in the driver."""
+    import threading
+    from tredparse_amd.meta import TREDsRepo
+    repo = TREDsRepo(ref="hg38", sites=str(tmp_path / "no_sites"))
+    bams = [os.path.join(GOLD, "bam", b) for b in ("t001.bam", "t002.bam")]
+    args = [("w{}".format(i), bams[i % 2], repo, ["HD", "DM1"], 300, False, False, True, True, "INFO") for i in range(7)]
+    seen, threads = [], set()
+
+    def sink(r):
+        seen.append(r["samplekey"])
+        threads.add(threading.current_thread().name)
+    out = tredmod.run_many(args, NoEvidenceEngine(), batch=3, sink=sink, threads=2, background_sink=True)
+    assert out == [] and seen == ["w{}".format(i) for i in range(7)] and threads == {"tred-writer"}
+
+    def bad(r):
+        raise OSError("disk full")
+    with pytest.raises(OSError, match="disk full"):
+        tredmod.run_many(args[:2], NoEvidenceEngine(), batch=2, sink=bad, threads=1, background_sink=True)

@@ -262,11 +262,46 @@ def run(arg, engine=None):
     return finish_batch(engine or Engine(), [arg], [collect_sample(arg)])[0]
 
 
-def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2):
+class _Writer(object):
+    """sink(result) calls moved off the driver thread: one worker thread takes them in order (JSON text, gzip and the
+    file writes spend most of their time outside the interpreter lock, so they overlap the driver's next GPU batch
+    and formatting); at most `depth` results wait.  An exception in the sink is re-raised by close()."""
+
+    def __init__(self, sink, depth=64):
+        import queue
+        import threading
+        self.sink, self.q, self.error = sink, queue.Queue(maxsize=depth), None
+        self.thread = threading.Thread(target=self._run, name="tred-writer", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if self.error is None:
+                try:
+                    self.sink(item)
+                except BaseException as e:      # handed to the driver thread
+                    self.error = e
+
+    def __call__(self, result):
+        self.q.put(result)
+
+    def close(self):
+        self.q.put(None)
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+
+
+def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
+             background_sink=False):
     """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
     executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in flight the
     scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
-    finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch."""
+    finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch.
+    background_sink: sink runs on a writer thread (in order) instead of the driver thread."""
     own = pool is None and threads > 1 and len(task_args) > 1
     # the first GPU batch is only as large as one round of the scan threads: nothing else can start before it is in
     # (only when there is more than one batch anyway: an extra GPU call costs more than it hides on small inputs)
@@ -275,6 +310,9 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     chunks = [c for c in chunks if c]
     ex = ThreadPoolExecutor(max_workers=threads) if own else pool
     out = []
+    writer = _Writer(sink) if (background_sink and sink is not None) else None
+    if writer is not None:
+        sink = writer
     try:
         submit = (lambda c: [ex.submit(collect_sample, a) for a in c]) if ex is not None else None
         ahead = deque()
@@ -297,6 +335,8 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     finally:
         if own:
             ex.shutdown()
+        if writer is not None:
+            writer.close()
     return out
 
 
@@ -525,7 +565,7 @@ def main(args, quiet=False):
                     if not args.no_output:
                         write_vcf_json(result, args.ref, repo, loci, quiet=quiet)
                 run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus),
-                         lazy_details=True)
+                         lazy_details=True, background_sink=args.cpus > 1)
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
         os.chdir(cwd)
