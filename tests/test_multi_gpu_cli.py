@@ -1,5 +1,6 @@
 """CPU: the product CLI's --gpus N fan-out (tredparse/tred.py:521-532 is the reference's per-sample Pool).
-The parent fixes the sample list, hands it to N children in a task file, child r takes shard_range(r) and writes
+The parent fixes the sample list and who takes which sample (balanced by BAM size), hands both to N children in a
+task file, child r takes its samples and writes
 those samples' JSON / VCF.  Here the children run in-process with a stand-in engine (no GPU): every sample is
 written exactly once, by the rank that owns it."""
 import gzip
@@ -64,8 +65,9 @@ def test_two_ranks_write_every_sample_exactly_once(tmp_path, monkeypatch):
     monkeypatch.setattr(shard, "visible_gpus", lambda: 2)
     tredmod.main(["samples.csv", "--workdir", str(work), "--gpus", "2", "--tred", "HD", "--tred", "DM1", "--cpus", "2"],
                  quiet=True)
-    # rank 0 owns k00..k02, rank 1 owns k03..k04 (block partition); nothing twice, nothing missing
-    assert [sorted(set(f.split(".")[0] for f in w)) for w in written] == [["k00", "k01", "k02"], ["k03", "k04"]]
+    # balanced by BAM size (t001.bam is the larger file: k00, k02, k04): rank 0 takes k00 and k04, rank 1 k02 and the
+    # two smaller ones; nothing twice, nothing missing
+    assert [sorted(set(f.split(".")[0] for f in w)) for w in written] == [["k00", "k04"], ["k01", "k02", "k03"]]
     assert sorted(os.listdir(work)) == sorted(k + s for k in ("k00", "k01", "k02", "k03", "k04")
                                               for s in (".json", ".tred.vcf.gz"))
     assert NoEvidenceEngine.made[-2:] == [0, 0]            # each child sees its one device as index 0
@@ -97,7 +99,7 @@ def test_checkexists_is_decided_by_the_parent(tmp_path, monkeypatch):
     assert "tasks" not in seen                              # nothing left to do: no children started
     os.remove(tmp_path / "t001.json")
     tredmod.main(["list.txt", "--gpus", "2", "--checkexists"], quiet=True)
-    assert seen["tasks"] == [["t001", bam, None]]
+    assert seen["tasks"] == {"samples": [["t001", bam, None]], "owner": [0]}
 
 
 def test_cleanup_with_gpus_is_the_parents(tmp_path, monkeypatch, capsys):

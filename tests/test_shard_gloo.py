@@ -60,3 +60,18 @@ def test_two_rank_aggregate_over_gloo():
         assert units == n_samples * 30           # every unit counted once across ranks
         assert elapsed == pytest.approx(0.75)    # max over ranks
         assert owned == [1] * n_samples          # every sample owned by exactly one rank
+
+
+def test_balanced_owners_spread_unequal_samples():
+    """--gpus N assigns samples by cost (BAM size): longest first, each to the least loaded rank; every sample has one
+    owner, equal costs degrade to round-robin, and one huge sample does not drag a block of others with it."""
+    assert shard.balanced_owners([5, 5, 5, 5, 5, 5], 3) == [0, 1, 2, 0, 1, 2]
+    owners = shard.balanced_owners([100, 1, 1, 1, 1, 1, 1, 1], 2)
+    assert owners[0] == 0 and owners[1:] == [1] * 7                   # the block partition would give rank 0 100 + 3
+    rng = np.random.default_rng(5)
+    costs = rng.integers(1, 1000, 200).tolist()
+    owners = shard.balanced_owners(costs, 8)
+    load = [sum(c for c, o in zip(costs, owners) if o == r) for r in range(8)]
+    assert sorted(set(owners)) == list(range(8)) and max(load) - min(load) <= max(costs)
+    assert max(load) <= 1.02 * sum(costs) / 8 + 1
+    assert shard.balanced_owners([], 4) == [] and shard.balanced_owners([0, 0, 0], 2) == [0, 1, 0]

@@ -25,6 +25,22 @@ def sample_owner(sample_index, n_samples, world):
     return extra + (sample_index - cut) // base
 
 
+def balanced_owners(costs, world):
+    """Rank of every sample when samples differ in cost (BAM size ~ coverage): longest-processing-time-first --
+    samples in order of decreasing cost, each to the rank with the least work so far (ties: lower rank, then input
+    order, so the assignment is deterministic).  With equal costs this is round-robin; shard_range's contiguous blocks
+    are kept for the benchmark, where samples are alike."""
+    if world < 1:
+        raise ValueError("bad world")
+    load = [0.0] * world
+    owner = [0] * len(costs)
+    for i in sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[i] = r
+        load[r] += max(float(costs[i]), 1.0)     # (unknown sizes count alike: round-robin)
+    return owner
+
+
 def aggregate(units_local, elapsed_local, dist=None, device=None):
     """Whole-job throughput: (sum of units over ranks) / (max of elapsed over ranks)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -486,7 +486,7 @@ def write_vcf_json(results, ref, repo, treds, store=None, quiet=False):
 # ---- driver -------------------------------------------------------------------------------------------------------
 def _fan_out(argv, n_gpus, samples, launch_dir, no_output, quiet, devices=None):
     """--gpus N: this process stays off the GPU and starts one child per GPU (shard.spawn_ranks) from the directory
-    the command was given in; child r genotypes its shard_range of `samples` -- the list is fixed here and handed
+    the command was given in; child r genotypes the samples the parent assigns it (balanced by BAM size) -- the list is fixed here and handed
     over in a file, so that every child partitions the same list -- and writes those samples' files.  Afterwards
     the JSONs are echoed in sample order."""
     import tempfile
@@ -499,8 +499,15 @@ def _fan_out(argv, n_gpus, samples, launch_dir, no_output, quiet, devices=None):
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
                                         [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p])
+    # which rank takes which sample: by BAM size, so that a cohort of mixed coverage keeps all GPUs busy to the end
+    def size_of(path):
+        try:
+            return os.path.getsize(path)
+        except OSError:
+            return 0
+    owners = shard.balanced_owners([size_of(s[1]) for s in samples], n_gpus)
     with tempfile.NamedTemporaryFile("w", suffix=".json", prefix="tred_tasks_", delete=False) as fp:
-        json.dump([list(s) for s in samples], fp)
+        json.dump({"samples": [list(s) for s in samples], "owner": owners}, fp)
     try:
         # --cleanup is the parent's: a child removing the shared working directory would take its siblings' files
         child_argv = [a for a in argv if a != "--cleanup"]
@@ -527,9 +534,14 @@ def main(args, quiet=False):
     if not infile:
         p.print_help()
         sys.exit(1)
-    if args.task_file:                         # a --gpus child: the parent's sample list
+    owners = None
+    if args.task_file:                         # a --gpus child: the parent's sample list (and who takes what)
         with open(args.task_file) as fp:
-            samples = [tuple(x) for x in json.load(fp)]
+            plan = json.load(fp)
+        if isinstance(plan, dict):
+            samples, owners = [tuple(x) for x in plan["samples"]], plan.get("owner")
+        else:
+            samples = [tuple(x) for x in plan]
     else:
         samples = read_csv(infile, args)       # paths become absolute here, before the working directory changes
     cwd = os.getcwd()
@@ -555,8 +567,13 @@ def main(args, quiet=False):
             device = args.gpu
             if spawned:                            # one of the --gpus children: its share of the samples, device 0
                 from .shard import shard_range
-                lo, hi = shard_range(len(tasks), int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
-                tasks, device, quiet = tasks[lo:hi], 0, True
+                rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+                if owners is not None and len(owners) == len(tasks):
+                    tasks = [t for t, o in zip(tasks, owners) if o == rank]
+                else:
+                    lo, hi = shard_range(len(tasks), rank, world)
+                    tasks = tasks[lo:hi]
+                device, quiet = 0, True
             if tasks:
                 from .engine import Engine
                 engine = Engine(device)
