@@ -113,7 +113,7 @@ WORKLOADS = {
 
 def rows_per_lane(readlen):
     """The sw_cont_kernel instantiation a maximum read length selects (csrc/capi.hip rows_for)."""
-    return 4 if readlen <= 64 else 7 if readlen <= 112 else 10 if readlen <= 160 else 16
+    return 4 if readlen <= 64 else 7 if readlen <= 112 else 10 if readlen <= 160 else 16 if readlen <= 256 else 20
 
 
 def make_batch(args, rank, world):
@@ -337,7 +337,7 @@ def rank_main(args):
                        "units_per_step_per_gpu": g, "reads_per_step_per_gpu": n, "coverage": args.coverage_used,
                        "readlen": args.readlen, "maxinsert": 300, "alleles": WORKLOADS[args.workload]["alleles"],
                        "parallelism": "sample-sharded x{} (no collective)".format(world)},
-            "roofline": {"kernel": "sw_cont_kernel<{},{}>".format(rpl, {4: 6, 7: 4, 10: 4, 16: 2}[rpl]), "bound": "valu",
+            "roofline": {"kernel": "sw_cont_kernel<{},{}>".format(rpl, {4: 6, 7: 4, 10: 4, 16: 2, 20: 2}[rpl]), "bound": "valu",
                          "achieved": swept / sw_s / 1e12, "peak": PEAK_TCUPS, "unit": "TCUPS",
                          "frac": swept / sw_s / 1e12 / PEAK_TCUPS,
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -655,8 +655,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=1000, help="synthetic samples per GPU (x 30 loci)")
     ap.add_argument("--coverage", type=float, default=None, help="override the workload's coverage (30x / 100x)")
-    ap.add_argument("--readlen", type=int, default=150, choices=(100, 150, 250),
-                    help="read length: selects the sw_cont_kernel instantiation (R = 7 / 10 / 16 rows per lane)")
+    ap.add_argument("--readlen", type=int, default=150, choices=(100, 150, 250, 300),
+                    help="read length: selects the sw_cont_kernel instantiation (R = 7 / 10 / 16 / 20 rows per lane)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3",
                     help="config3 = BASELINE configs[2] (the headline); config5 = configs[4] (100x, expanded alleles)")
     ap.add_argument("--seed", type=int, default=20260101)

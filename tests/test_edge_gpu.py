@@ -196,3 +196,42 @@ def test_error_reporting(ctx):
     with pytest.raises(_lib.TredGpuError):                            # ladder index out of range
         ctx.sw_classify(_lib.MEM_HOST, packed, woff, rlen, 1, np.array([0, 1], np.int32), np.array([3], np.int32), 1, p,
                         np.zeros(1, np.uint8), np.zeros(1, np.int16), np.zeros(1, np.int16))
+
+
+def test_300bp_reads_take_the_20_rows_per_lane_instantiation(ctx):
+    """2 x 300 bp runs (the reference has no length limit, ssw.c:780-871 / bam_parser.py:73): reads up to 320 bp are
+    held by sw_cont_kernel<20, 2>.  Per-template records against the oracle field by field, tags of a synthetic 300 bp
+    batch over loci of every period against the oracle, and reads beyond 320 bp flagged, not truncated."""
+    rng = np.random.default_rng(300)
+    mu = -(-300 // 3)
+    lad = (HD[0], "CAG", HD[2], mu)
+    flank = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    reads = [(flank(40) + HD[0] + "CAG" * 60 + HD[2] + flank(100))[:300],            # spanning
+             po.rc((flank(10) + HD[0] + "CAG" * 90 + HD[2] + flank(50))[:300]),       # prefix read, other strand
+             ("CAG" * 110)[:300], ("AGC" * 110)[1:299], "N" * 300,                     # inside the repeat; all N
+             (flank(150) + "CAG" * 20 + HD[2] + flank(100))[:300],                    # suffix read
+             ("CAG" * 99)[:297] + "TTT", flank(300), (HD[0] + "CAG" * 100)[:310]]      # 310 bp: still inside the limit
+    tag, h, sc, dump = _classify(ctx, [lad], reads, [0, len(reads)], [0], dump=True)
+    ls = po.LocusSet([lad])
+    cls = po.classify(reads, np.zeros(len(reads), np.int32), ls)
+    assert np.array_equal(tag, cls[:, 0]) and np.array_equal(h, cls[:, 1]) and np.array_equal(sc, cls[:, 2])
+    assert set(tag.tolist()) >= {_lib.TAG_FULL, _lib.TAG_REPT, _lib.TAG_NONE}
+    nt = 2 * mu
+    for r, read in enumerate(reads):
+        want = po.sw_pairs([read], ls.templates, [0] * nt, list(range(nt)))
+        assert np.array_equal(dump[r, :, :5].astype(np.int32), want), r
+    # a synthetic 300 bp batch over periods 3, 4, 5, 6 and 12 through the production (pruned) path
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM2", "SCA10", "SCA36", "ULD", "OPMD")]
+    b = synth.build_batch(301, loci, 2, synth.SynthParams(coverage=20, readlen=300, max_units=90))
+    ctx.set_ladders(b.ladders)
+    n = b.n_reads
+    t2 = np.zeros(n, np.uint8); h2 = np.zeros(n, np.int16); s2 = np.zeros(n, np.int16)
+    ctx.sw_classify(_lib.MEM_HOST, b.packed, b.read_off, b.read_len, n, b.unit_read_off, b.unit_ladder, b.n_units,
+                    _lib.default_sw_params(max_read_len=300), t2, h2, s2)
+    rs = [synth.decode(x) for x in b.codes]
+    c2 = po.classify(rs, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), po.LocusSet(b.ladders), threads=0)
+    assert np.array_equal(t2, c2[:, 0]) and np.array_equal(h2, c2[:, 1]) and np.array_equal(s2, c2[:, 2])
+    assert (t2 == _lib.TAG_FULL).sum() > 20 and (t2 == _lib.TAG_REPT).sum() > 0
+    # beyond 320 bp: flagged
+    t3, _, _, _ = _classify(ctx, [lad], [reads[0], (reads[0] * 2)[:330]], [0, 2], [0])
+    assert t3[1] == _lib.TAG_INVALID and t3[0] == tag[0]

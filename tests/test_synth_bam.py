@@ -158,3 +158,35 @@ def test_cli_two_rank_processes_equal_one(tmp_path):
             a, b = (json.load(open(tmp_path / d / f)) for d in ("one", "two"))
             assert a == b, f
             assert set(n + ".1" for n in NAMES) <= set(a["tredCalls"])
+
+
+@pytest.mark.gpu
+def test_2x300bp_sample_keeps_every_locus(tmp_path):
+    """A 2 x 300 bp sample through run(): no locus is dropped for its read length (round 2 lost every locus of such a
+    sample), READLEN comes out as 300, and the per-read tags equal the oracle's for the reads the scan selected."""
+    from oracle import pyoracle as po
+    from tredparse_amd import _lib, bam_parser, tred as tredmod
+    from tredparse_amd.engine import Engine
+    repo = TREDsRepo()
+    loci = [l for l in synth.load_loci() if l["name"] in NAMES]
+    p = synth.SynthParams(coverage=20, readlen=300, ins_mean=500.0, ins_sd=60.0, max_units=70)
+    made = sb.make_bams(str(tmp_path), 1, seed=930, loci=loci, p=p)
+    key, path, h_true = made[0]
+    names = [l["name"] for l in loci]
+    engine = Engine(0)
+    res = tredmod.run((key, path, repo, names, 300, False, False, True, True, "ERROR"), engine=engine)
+    calls = res["tredCalls"]
+    assert calls["readLen"] == 300
+    assert all(n + ".1" in calls and calls[n + ".label"] != "missing" for n in names)
+    assert sum(calls[n + ".1"] == int(h) for n, h in zip(names, h_true[:, 0])) >= 0.6 * len(names)
+    scan = bam_parser.scan_sample(path, repo, names)
+    assert not scan.dropped
+    for k, l in enumerate(loci):
+        a, b = scan.reads_of(k)
+        reads = [scan.sequence(i) for i in range(a, b)]
+        mu = -(-300 // len(l["repeat"]))
+        cls = po.classify(reads, np.zeros(len(reads), np.int32), po.LocusSet([(l["prefix"], l["repeat"], l["suffix"], mu)]))
+        want = sorted((int(h), _lib.TAG_NAMES[int(t)]) for t, h, _ in cls if int(t) in (1, 2, 3, 4))
+        got = sorted((d["h"], d["tag"]) for d in calls[l["name"] + ".details"])
+        assert got == want, l["name"]
+    engine.close()

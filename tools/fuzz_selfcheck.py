@@ -57,7 +57,7 @@ def campaign(rounds=20, seed=1):
         none = key[rows, at] < 0
         want = np.stack([np.where(none, _lib.TAG_NONE, dtag[rows, at]), np.where(none, 0, units[at]),
                          np.where(none, 0, score[rows, at])], 1)
-        too_long = np.asarray(rlen) > 16 * 16          # flagged, not aligned (TREDGPU_TAG_INVALID)
+        too_long = np.asarray(rlen) > 16 * 20          # flagged, not aligned (TREDGPU_TAG_INVALID)
         got = np.stack([tag, h, sc], 1).astype(np.int64)
         bad = np.nonzero(((got != want).any(1) | (tag != t2) | (h != h2) | (sc != s2)) & ~too_long)[0]
         n_reads += n

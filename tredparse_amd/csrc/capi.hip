@@ -169,7 +169,8 @@ int rows_for(int max_len) {
     if (max_len <= 64) return 4;
     if (max_len <= 112) return 7;
     if (max_len <= 160) return 10;
-    return 16;
+    if (max_len <= 256) return 16;
+    return 20;
 }
 
 // Every DP value is (score + (row + col) * gap_extend) << 18 | payload in an int32: the scaled score must stay

@@ -214,7 +214,8 @@ __device__ __forceinline__ void resolve_best(Track& T, int row0, int row0g, int 
     int m = NEG;
 #pragma unroll
     for (int r = 0; r < R; ++r) m = max(m, (rowbuf[r * 64] & ~PAYMASK) | (R - 1 - r));
-    const int st = rowbuf[(R - 1 - (m & 15)) * 64];
+    static_assert(R <= 32, "row index in five payload bits");
+    const int st = rowbuf[(R - 1 - (m & 31)) * 64];
     const int lane_scale = row0g + pcol * geK;
     // -> score<<18 | (511-col)<<9 | (511-row)
     const int cand = m - lane_scale + (((511 - pcol) << 9) + (511 - (R - 1)) - row0);
@@ -352,17 +353,23 @@ __device__ __forceinline__ void pair_step_lex(int& k, int& s) {
     s = c ? ts : s;
 }
 
-// Codes of R consecutive read rows i_lo .. i_lo+R-1 (R <= 16): they span at most two words of the 2-bit codes and
-// two words of the N mask (tredgpu.h read packing), so four loads fetch them all.  code2: 2 bits per row;
-// nmask: bit k = row i_lo+k is N.  Rows >= L hold garbage (the caller pads them).
+// Codes of R consecutive read rows i_lo .. i_lo+R-1 (R <= 24): they span at most three words of the 2-bit codes and
+// two words of the N mask (tredgpu.h read packing), so five loads fetch them all.  code2: 2 bits per row (32 rows'
+// worth); nmask: bit k = row i_lo+k is N.  Rows >= L hold garbage (the caller pads them).
 template <int R>
-__device__ __forceinline__ void load_rows(const SwArgs& a, int64_t off, int L, int i_lo, uint32_t& code2, uint32_t& nmask) {
+__device__ __forceinline__ void load_rows(const SwArgs& a, int64_t off, int L, int i_lo, uint64_t& code2, uint32_t& nmask) {
+    static_assert(R <= 24, "three code words cover 33 rows from any offset, the mask window 33");
     const int nb = (L + 15) >> 4, nm = (L + 31) >> 5;
     const int wl = max(nb - 1, 0), ml = max(nm - 1, 0);
     const int wi = i_lo >> 4, mi = i_lo >> 5;
     const uint32_t w0 = a.packed[off + min(wi, wl)], w1 = a.packed[off + min(wi + 1, wl)];
     const uint32_t m0 = a.packed[off + nb + min(mi, ml)], m1 = a.packed[off + nb + min(mi + 1, ml)];
-    code2 = (uint32_t)((((uint64_t)w1 << 32) | w0) >> ((i_lo & 15) * 2));
+    const int sh = (i_lo & 15) * 2;
+    code2 = (((uint64_t)w1 << 32) | w0) >> sh;
+    if (R > 16) {   // rows 17.. of the window sit in the third word
+        const uint32_t w2 = a.packed[off + min(wi + 2, wl)];
+        code2 |= sh ? (uint64_t)w2 << (64 - sh) : 0;
+    }
     nmask = (uint32_t)((((uint64_t)m1 << 32) | m0) >> (i_lo & 31));
 }
 
@@ -376,7 +383,8 @@ __device__ __forceinline__ void build_profile(Rows<R>& J, const SwArgs& a, int64
     asm volatile("" : "+v"(L), "+v"(off), "+v"(row0));   // (likewise the addresses and shifts of the four loads)
     J.rowc0 = row0 + row0 * geK;
     const int i_lo = reversed ? 16 * R - R - row0 : row0;
-    uint32_t code2, nmask;
+    uint64_t code2;
+    uint32_t nmask;
     load_rows<R>(a, off, L, i_lo, code2, nmask);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
         int kcap = 1 << 20;  // per read: upper bound of any score on this strand
         // (a 6-mer window starting in this lane ends at most 5 bases into the next lane's rows: needs R >= 5;
         //  with fewer rows per lane the per-read classes of read_class_kernel already removed hopeless strands)
-        if (R >= 5 && 2 * R + 10 <= 32 && !full_dump && kmer_thr > 0 && __builtin_amdgcn_readfirstlane(ld->kmer_ok) != 0) {
+        if constexpr (R >= 5 && 2 * R + 10 <= 32) if (!full_dump && kmer_thr > 0 && __builtin_amdgcn_readfirstlane(ld->kmer_ok) != 0) {
             const uint32_t* bm = a.seqw + __builtin_amdgcn_readfirstlane(ld->kmer_off[s]);
             // this lane's rows as 2-bit codes / N-or-padding flags, loaded here, per strand: they and the window
             // indices below depend on the read only, and hoisted out of the strand loop they would sit in 2R + 2
@@ -490,10 +498,11 @@ __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
             {
                 int L_s = L, row0_s = row0;
                 asm volatile("" : "+v"(L_s), "+v"(row0_s));
-                uint32_t code2, nmask;
+                uint64_t code2;
+                uint32_t nmask;
                 load_rows<R>(a, read_base(), L_s, row0_s, code2, nmask);
                 const int n_real = min(max(L_s - row0_s, 0), R);                 // rows of this lane inside the read
-                pk_s = code2 & ((1u << (2 * R)) - 1u);                             // (codes of N / padding rows are never
+                pk_s = (uint32_t)code2 & ((1u << (2 * R)) - 1u);                             // (codes of N / padding rows are never
                 nk_s = (nmask | ~((1u << n_real) - 1u)) & ((1u << R) - 1u);        //  looked at: their windows count as present)
             }
             const uint32_t pk_n = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk_s, 0x101, 0xF, 0xF, false);        // row_shl:1
@@ -1048,6 +1057,8 @@ hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, bool generic, in
         case 21: sw_cont_kernel<10, 4, true><<<blocks, 64, 0, s>>>(a); break;
         case 32: sw_cont_kernel<16, 2, false><<<blocks, 64, 0, s>>>(a); break;
         case 33: sw_cont_kernel<16, 2, true><<<blocks, 64, 0, s>>>(a); break;
+        case 40: sw_cont_kernel<20, 2, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 320 bp (2 x 300 bp runs)
+        case 41: sw_cont_kernel<20, 2, true><<<blocks, 64, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
