@@ -232,6 +232,6 @@ def test_300bp_reads_take_the_20_rows_per_lane_instantiation(ctx):
     c2 = po.classify(rs, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), po.LocusSet(b.ladders), threads=0)
     assert np.array_equal(t2, c2[:, 0]) and np.array_equal(h2, c2[:, 1]) and np.array_equal(s2, c2[:, 2])
     assert (t2 == _lib.TAG_FULL).sum() > 20 and (t2 == _lib.TAG_REPT).sum() > 0
-    # beyond 320 bp: flagged
-    t3, _, _, _ = _classify(ctx, [lad], [reads[0], (reads[0] * 2)[:330]], [0, 2], [0])
-    assert t3[1] == _lib.TAG_INVALID and t3[0] == tag[0]
+    # beyond 320 bp: refused by the call (host memory: the lengths are looked at), never truncated
+    with pytest.raises(_lib.TredGpuError, match="TREDGPU_MAX_READ_LEN"):
+        _classify(ctx, [lad], [reads[0], (reads[0] * 2)[:330]], [0, 2], [0])
