@@ -474,7 +474,9 @@ def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0):
     plans = []
     for dpg in sorted(set([1] + tried)):
         ranks = dpg * n_devices
-        threads = threads_opt or max(1, (usable - ranks) // ranks)
+        # one core is left to the drivers together: a driver thread (batches, formatting) is busy about a third of
+        # the time, its writer thread mostly outside the interpreter lock
+        threads = threads_opt or max(1, (usable - 1) // ranks)
         plans.append((ranks, threads))
     return plans
 

@@ -163,7 +163,8 @@ struct Bits {
 };
 
 // Inflate one raw-deflate stream of exactly out_len bytes into out (which has SLACK writable bytes beyond out_len).
-inline bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, Tables& T) {
+// (always inlined: the caller's target options -- bamread.cpp compiles it once per CPU clone -- apply to the loop)
+__attribute__((always_inline)) inline bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, Tables& T) {
     Bits b;
     b.p = in;
     b.end = in + in_len;
