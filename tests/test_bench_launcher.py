@@ -56,13 +56,13 @@ def test_rank_env_pins_one_device_per_rank():
 def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
     """run_e2e on an 8-GPU box (stub ranks): one set of BAMs, a leg per device count of the sweep, ranks = drivers per
     GPU x GPUs with rank r on device r mod n and an equal share of the CPUs each; on a 1-GPU box the plan is the one of
-    earlier rounds (1 driver x 15 threads, 3 drivers x 4 threads on 16 CPUs) plus 2 x 7."""
+    earlier rounds with one core left to the drivers (1 driver x 15 threads, 2 x 7, 3 x 5 on 16 CPUs)."""
     sys.path.insert(0, ROOT)
     import argparse
     import bench
     from tredparse_amd import shard
-    assert bench.e2e_plan(1, 16) == [(1, 15), (2, 7), (3, 4)]
-    assert bench.e2e_plan(8, 128) == [(8, 15), (16, 7), (24, 4)]
+    assert bench.e2e_plan(1, 16) == [(1, 15), (2, 7), (3, 5)]
+    assert bench.e2e_plan(8, 128) == [(8, 15), (16, 7), (24, 5)]
     assert bench.e2e_plan(8, 16) == [(8, 1)]
     assert bench.e2e_plan(2, 16, drivers_opt=2, threads_opt=3) == [(2, 3), (4, 3)]
     monkeypatch.setattr(shard, "usable_cpus", lambda: 64)
@@ -91,7 +91,7 @@ def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
     assert made == [512]                                            # one set of files: 8 GPUs x 64 (capped at 512)
     assert sorted(recs) == [1, 2, 8]
     # (ranks, devices, files, threads per rank): 64 CPUs -> 8 and 12 drivers per GPU at one GPU, 4 and 6 at two, 1 at eight
-    assert spawned == [(1, 1, 128, 63), (8, 1, 128, 7), (12, 1, 128, 4), (2, 2, 256, 31), (8, 2, 256, 7), (12, 2, 256, 4),
+    assert spawned == [(1, 1, 128, 63), (8, 1, 128, 7), (12, 1, 128, 5), (2, 2, 256, 31), (8, 2, 256, 7), (12, 2, 256, 5),
                        (8, 8, 512, 7)]
     eight = recs[8]
     assert eight["devices"] == 8 and eight["drivers"] == 8 and eight["samples"] == 512
