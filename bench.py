@@ -357,7 +357,10 @@ def rank_main(args):
                                  "achieved_GBps": alg_bytes / sw_s / 1e9, "peak_GBps": HBM_PEAK_GBS,
                                  "frac": alg_bytes / sw_s / 1e9 / HBM_PEAK_GBS}},
             "kernels_ms_per_step": {"sw_ladder": sw_ms / max(sw_n, 1), "tally": ta_ms / max(ta_n, 1),
-                                    "grid": gr_ms / max(gr_n, 1)},
+                                    "grid": gr_ms / max(gr_n, 1),
+                                    "grid_prepare": ctx.get_timing(_lib.KERNEL_GRID_PREPARE)[1] / max(gr_n, 1),
+                                    "grid_pairs": ctx.get_timing(_lib.KERNEL_GRID_PAIRS)[1] / max(gr_n, 1),
+                                    "grid_reduce": ctx.get_timing(_lib.KERNEL_GRID_REDUCE)[1] / max(gr_n, 1)},
             "check": {"units_ok": ok, "units": g, "short_allele_exact_frac": short_ok,
                       "mean_grid_pairs": float(calls["n_pairs"].mean()), "max_grid_pairs": int(calls["n_pairs"].max()),
                       "run_pe_frac": float(calls["run_pe"].mean())},

@@ -260,7 +260,10 @@ int tredgpu_pe_kde(tredgpu_ctx* ctx, int mem, const tredgpu_unit_params* units, 
  */
 #define TREDGPU_KERNEL_SW 0
 #define TREDGPU_KERNEL_TALLY 1
-#define TREDGPU_KERNEL_GRID 2
+#define TREDGPU_KERNEL_GRID 2          /* the three grid kernels of a call together ...   */
+#define TREDGPU_KERNEL_GRID_PREPARE 3  /* ... and one by one: tables, axes, KDE per unit  */
+#define TREDGPU_KERNEL_GRID_PAIRS 4    /*     the log-likelihood of every (h1, h2) pair   */
+#define TREDGPU_KERNEL_GRID_REDUCE 5   /*     arg-max, marginals, CI, PP per unit         */
 int tredgpu_reset_timing(tredgpu_ctx* ctx);
 int tredgpu_get_timing(tredgpu_ctx* ctx, int which, int64_t* launches, double* total_ms);
 /*

@@ -49,7 +49,7 @@ struct tredgpu_ctx {
         size_t used = 0;
         int64_t launches = 0;
         double total_ms = 0;
-    } timers[3];
+    } timers[6];
 };
 
 namespace {
@@ -295,7 +295,7 @@ int tredgpu_get_sw_counters(tredgpu_ctx* c, uint64_t out[8]) {
 
 int tredgpu_get_timing(tredgpu_ctx* c, int which, int64_t* launches, double* total_ms) {
     if (!c) return -2;
-    if (which < 0 || which > 2) return fail(c, -2, "which must be TREDGPU_KERNEL_SW/TALLY/GRID");
+    if (which < 0 || which > 5) return fail(c, -2, "which must be one of TREDGPU_KERNEL_*");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timer_flush(c->timers[which]);
@@ -682,8 +682,11 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     {
         ScopedTimer tm(c, TREDGPU_KERNEL_GRID);
         for (int pass = 0;; ++pass) {
-            HIPCHK(c, launch_grid_pass(a, pass, c->ws_gdesc.p, (double*)c->ws_grid.p, pool_bytes / sizeof(double), cap, cap,
-                                       c->ws_gtile.p, item_cap, c->ws_gctr.p, c->stream));
+            for (int ph = 0; ph < 3; ++ph) {     // prepare / pairs / reduce, each bracketed by its own events
+                ScopedTimer phase_tm(c, TREDGPU_KERNEL_GRID_PREPARE + ph);
+                HIPCHK(c, launch_grid_pass(a, pass, c->ws_gdesc.p, (double*)c->ws_grid.p, pool_bytes / sizeof(double), cap,
+                                           cap, c->ws_gtile.p, item_cap, c->ws_gctr.p, c->stream, 1 << ph));
+            }
             if (!may_defer) break;
             HIPCHK(c, hipMemcpyAsync(c->h_pin, (const char*)c->ws_gctr.p + grid_deferred_offset(), sizeof(int),
                                      hipMemcpyDeviceToHost, c->stream));

@@ -606,12 +606,23 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             rc = __builtin_amdgcn_readfirstlane(rc);
             if (rc) status = rc;
         }
+        // the spanning pairs' lengths index the rolled pdf (models.py:471-473): IndexError outside [-1000, 1000).
+        // Checked by all threads at once, and kept in LDS (behind the 37 step-size entries that S.kern holds once the
+        // KDE is done with it) for the roll tables below: read one by one from global memory by every thread they were a
+        // chain of ~n_target memory latencies per unit.
+        const bool tl_staged = u.n_target <= SPAN;
+        int* const tl_lds = reinterpret_cast<int*>(S.kern + 64);
+        static_assert(KERN2 >= 64 + SPAN / 2, "room for the staged pair lengths");
         if (status == 0 && run_pe) {
-            for (int i = 0; i < u.n_target; ++i) {
+            __syncthreads();   // (the KDE's last reads of S.kern)
+            int bad = 0;
+            for (int i = tid; i < u.n_target; i += NT) {
                 int x = a.target_lens[u.tl_off + i];
                 if (x < 0) x += SPAN;
-                if (x < 0 || x >= SPAN) status = -3;
+                if (x < 0 || x >= SPAN) bad = 1;
+                if (tl_staged) tl_lds[i] = x;
             }
+            if (__syncthreads_or(bad)) status = -3;
         }
 
         // ---- grid axes (models.py:239-257) ----
@@ -825,10 +836,14 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             //  thread with the targets in the inner loop, which is also what makes the transposed roll2 rows coalesced)
             const int nt = u.n_target, ntp = (nt + 31) & ~31;
             static_assert(NT % 32 == 0, "row sweep below");
+            auto target_x = [&](int t) {                 // spanning pair t as an index into the rolled pdf
+                if (tl_staged) return tl_lds[t];
+                int x = C.tl[t];
+                return x < 0 ? x + SPAN : x;
+            };
             for (int tb = 0; tb < ntp; tb += 32) {
                 const int t = tb + (tid & 31);
-                int x = t < nt ? C.tl[t] : 0;
-                if (x < 0) x += SPAN;
+                const int x = t < nt ? target_x(t) : 0;
                 for (int ai = tid >> 5; ai < nrow; ai += NT / 32) {
                     const int h = axis_value(ax1, S.obs.base, period, ai);
                     // the tables hold .5 * roll(h)[x]: the pair's factor is the plain sum of two entries (models.py:469)
@@ -839,8 +854,7 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
                 for (int ai = tid; ai < ncol; ai += NT) {
                     const int h = axis_value(ax2, S.obs.base, period, ai);
                     for (int t = 0; t < nt; ++t) {
-                        int x = C.tl[t];
-                        if (x < 0) x += SPAN;
+                        const int x = target_x(t);
                         slot[L.roll2 + (size_t)t * ncol + ai] = .5 * roll_at(C.pdf, C.ref_len, C.minpe, h, x, C.small);   // transposed
                     }
                 }
@@ -929,8 +943,14 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
             const int nq = min(TC, n - t0);   // spanning pairs of this pass (wave-uniform)
             double b[TC];
             if (tab && !haploid) {
+                // (all 32 loads in flight together: the index is clamped and the padding selected afterwards -- with a
+                //  branch per entry the compiler put a full vmcnt(0) wait in front of every load)
+                const double* col = slot + L.roll2 + jc;
+                const int last_t = n - 1 - t0;
 #pragma unroll
-                for (int q = 0; q < TC; ++q) b[q] = t0 + q < n ? slot[L.roll2 + (size_t)(t0 + q) * ncol + jc] : .5;
+                for (int q = 0; q < TC; ++q) b[q] = col[(size_t)(t0 + min(q, last_t)) * ncol];
+#pragma unroll
+                for (int q = 0; q < TC; ++q) b[q] = q <= last_t ? b[q] : .5;
             }
             auto load_row = [&](int i) {
                 RowIn r;
@@ -1372,21 +1392,27 @@ size_t grid_slot_doubles_max(int rows_cap, int cols_cap, int nt_max) {
 // n_deferred; the caller runs further passes (pass > 0 touches only those) until none is left.
 // items: item_cap ints (item -> unit), then item_cap arg-max records
 hipError_t launch_grid_pass(const GridArgs& a, int pass, void* descs, double* pool, size_t pool_doubles, int rows_cap,
-                            int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s) {
+                            int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s, int phases) {
+    // phases: bit 0 prepare (with the counter reset), bit 1 pairs, bit 2 reduce -- the caller may launch them one by
+    // one to time each (capi.hip brackets them with HIP events)
     if (a.n_units <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(counters, 0, sizeof(GridCounters), s);
-    if (e != hipSuccess) return e;
     UnitDesc* d = (UnitDesc*)descs;
     GridCounters* ctr = (GridCounters*)counters;
     int* item_unit = (int*)items;
     Best* item_best = (Best*)(item_unit + ((item_cap + 3) & ~(size_t)3));
-    const int pb = a.n_units < 1536 ? a.n_units : 1536;
-    grid_prepare_kernel<<<pb, NT, 0, s>>>(a, pass, d, pool, (unsigned long long)pool_doubles, rows_cap, cols_cap, item_unit,
-                                          ctr);
-    grid_pairs_kernel<<<2048, 256, 0, s>>>(a, d, pool, item_unit, item_best, ctr);
-    const int rb = a.n_units < 2048 ? a.n_units : 2048;
-    if (a.joint != nullptr) grid_reduce_kernel<true><<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
-    else grid_reduce_kernel<false><<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
+    if (phases & 1) {
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(GridCounters), s);
+        if (e != hipSuccess) return e;
+        const int pb = a.n_units < 1536 ? a.n_units : 1536;
+        grid_prepare_kernel<<<pb, NT, 0, s>>>(a, pass, d, pool, (unsigned long long)pool_doubles, rows_cap, cols_cap,
+                                              item_unit, ctr);
+    }
+    if (phases & 2) grid_pairs_kernel<<<2048, 256, 0, s>>>(a, d, pool, item_unit, item_best, ctr);
+    if (phases & 4) {
+        const int rb = a.n_units < 2048 ? a.n_units : 2048;
+        if (a.joint != nullptr) grid_reduce_kernel<true><<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
+        else grid_reduce_kernel<false><<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
+    }
     return hipGetLastError();
 }
 

@@ -122,6 +122,6 @@ size_t grid_items_cap(int rows_cap, int cols_cap);   // work items one unit can 
 size_t grid_item_bytes();                            // bytes per work item in the items buffer
 // One pass over all units (prepare -> pairs -> reduce); see grid.hip
 hipError_t launch_grid_pass(const GridArgs& a, int pass, void* descs, double* pool, size_t pool_doubles, int rows_cap,
-                            int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s);
+                            int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s, int phases = 7);
 
 }  // namespace tredgpu
