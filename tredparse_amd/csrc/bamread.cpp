@@ -43,6 +43,32 @@ struct RefIndex {
 
 }  // namespace
 
+// Buffers of inflated blocks are recycled per thread: a sample inflates ~550 blocks of 64 KiB, and handing 35 MB back
+// to the allocator at every close meant fresh pages (faults, zeroing) for every sample a scan thread takes next.
+namespace tredbam_pool {
+constexpr size_t BLOCK_BYTES = 65536 + tredbam_inflate::SLACK;
+constexpr size_t KEEP = 640;                     // buffers kept per thread (~42 MB)
+struct Pool {
+    std::vector<uint8_t*> free;
+    ~Pool() { for (uint8_t* p : free) delete[] p; }
+};
+inline Pool& pool() { static thread_local Pool p; return p; }
+inline uint8_t* take() {
+    Pool& p = pool();
+    if (p.free.empty()) return new uint8_t[BLOCK_BYTES];
+    uint8_t* b = p.free.back();
+    p.free.pop_back();
+    return b;
+}
+struct Give {
+    void operator()(uint8_t* b) const {
+        Pool& p = pool();
+        if (p.free.size() < KEEP) p.free.push_back(b); else delete[] b;
+    }
+};
+using Buffer = std::unique_ptr<uint8_t[], Give>;
+}  // namespace tredbam_pool
+
 struct tredbam {
     std::string path, err;
     FILE* fp = nullptr;
@@ -60,7 +86,7 @@ struct tredbam {
     // inflated blocks seen recently (compressed offset -> data, compressed length): the three queries of a locus
     // (depth, reads, pairs) and the alternative-locus queries of neighbouring loci walk the same blocks again.
     // An entry owns its buffer (no zero fill, never copied); the current block is used in place.
-    struct Cached { std::unique_ptr<uint8_t[]> data; size_t size; int64_t clen; };
+    struct Cached { tredbam_pool::Buffer data; size_t size; int64_t clen; };
     std::unordered_map<int64_t, Cached> cache;
     std::deque<int64_t> cache_order;
     static constexpr size_t CACHE_BLOCKS = 512;   // <= 32 MiB per open file
@@ -155,7 +181,7 @@ int load_block(tredbam* b, int64_t coffset) {
     const uint32_t isize = le32(comp + dlen - 4);
     // a BGZF block holds at most 64 KiB (SAM spec 4.1): a larger ISIZE is a damaged trailer, not a 4 GiB allocation
     if (isize > 65536) return fail(b, -6, "BGZF block at %lld claims %u bytes", (long long)coffset, isize);
-    std::unique_ptr<uint8_t[]> data(new uint8_t[(size_t)isize + tredbam_inflate::SLACK]);
+    tredbam_pool::Buffer data(tredbam_pool::take());     // (isize <= 65536: every block fits a pooled buffer)
     // own whole-block decoder first (1.3-1.6x zlib's speed on BAM data); zlib decides whenever it declines
     const bool done = isize > 0 && inflate_dispatch(comp, (size_t)(dlen - 8), data.get(), isize, b->inflate_tables);
     if (isize > 0 && !done) {
