@@ -671,7 +671,8 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="only --gpus ranks, no 1/2/4/8 sweep")
     ap.add_argument("--rank-timeout", type=float, default=1500.0)
     ap.add_argument("--stub", action="store_true", help="launcher self-test: ranks do no GPU work")
-    ap.add_argument("--e2e-samples", type=int, default=128, help="synthetic BAMs of the end-to-end leg (0: skip it)")
+    ap.add_argument("--e2e-samples", type=int, default=512,
+                    help="synthetic BAMs per GPU of the end-to-end legs (0: skip them); at most 512 files in all")
     ap.add_argument("--e2e-batch", type=int, default=16, help="samples per GPU batch in the end-to-end leg")
     ap.add_argument("--e2e-threads", type=int, default=0, help="host threads per driver in the end-to-end leg (0: cores / drivers)")
     ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 5; also run with 1)")
