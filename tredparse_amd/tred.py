@@ -469,7 +469,7 @@ def to_vcf(results, ref, repo, treds=("HD",), store=None):
     if not calls:
         return
     records = sorted(_vcf_line(t, calls, repo.get_info(t)) for t in treds if t + ".1" in calls)
-    with gzip.open(results["samplekey"] + ".tred.vcf.gz", "wt") as fw:
+    with gzip.open(results["samplekey"] + ".tred.vcf.gz", "wt", compresslevel=6) as fw:
         fw.write(vcfstanza(results["samplekey"], results["bam"], calls, ref) + "\n")
         for _, _, line in records:
             fw.write(line + "\n")
