@@ -3,7 +3,8 @@
 #   gpurun_out/prof_TAG/stats   --kernel-trace --stats of one rank of bench.py (per-kernel durations)
 #   gpurun_out/prof_TAG/pmc_*   one counter pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC passes
 #                               are never combined with any trace option other than --kernel-trace)
-#   gpurun_out/prof_TAG/pmc_summary.json + kernel_stats.csv + bench_under_rocprof.json + ubench_valu.txt
+#   gpurun_out/prof_TAG/pmc_summary.json (carries tredgpu_version(): the build the counters belong to) + kernel_stats.csv +
+#                               bench_under_rocprof.json + ubench_valu.txt
 # The profiled program is the rank body itself (RANK=0 WORLD_SIZE=1 in the environment): `python3 bench.py` directly
 # after `--`, no launcher hop.  Copy what should be judged into profiles/.
 set -u
