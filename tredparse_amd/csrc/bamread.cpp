@@ -443,7 +443,7 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
             }
             // overlap test first (cheap pass without storing), then store
             const size_t mark = b->out.size();
-            int32_t rend;
+            int32_t rend = -1;
             if ((rc = store ? emit_record(b, &rend, true) : record_end(b, &rend)) < 0) return rc;
             int64_t e = rend;
             if (rend < 0 || rend <= rpos) e = (int64_t)rpos + 1;   // placed-unmapped / zero length: one base (bam_endpos)
