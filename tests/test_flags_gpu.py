@@ -96,3 +96,32 @@ def test_cli_flags_reach_run(engine, bams, tmp_path, monkeypatch):
         tredmod.main(argv, quiet=True)
         got = json.load(open(work / "synf.json"))["tredCalls"]
         _compare(got, want[name]["tredCalls"], name)
+
+
+def test_all_loci_with_reads_match_reference(engine, tmp_path):
+    """BASELINE configs[1] (all TRED loci) with evidence at every locus: one synthetic 12x sample over the 30 distinct
+    loci, regenerated here from its seed (the record table's digest must equal the one the golden was made from), through
+    run() with default flags against the reference's run() on the same BAM (tests/golden/run_synall.json)."""
+    import hashlib
+    import numpy as np
+    from tredparse_amd import synth, synth_bam
+    gold = json.load(open(os.path.join(GOLD, "run_synall.json")))
+    loci = synth_bam.bench_loci()
+    assert [l["name"] for l in loci] == gold["loci"]
+    p = synth.SynthParams(coverage=gold["coverage"], expanded_max=120, expanded_frac=0.25)
+    recs, h_true = synth_bam.simulate_sample(gold["seed"], loci, p, alt_rate=0.3)
+    h = hashlib.sha256()
+    for k in recs.FIELDS:
+        h.update(np.ascontiguousarray(getattr(recs, k)).tobytes())
+    assert h.hexdigest() == gold["records_sha256"], "the synthetic generator no longer reproduces the golden's sample"
+    bam = str(tmp_path / "synall.bam")
+    synth_bam.write_bam(bam, recs, sample="synall", level=1)
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    got = tredmod.run(("synall", bam, repo, gold["loci"], 300, False, False, True, True, "INFO"), engine=engine)["tredCalls"]
+    want = gold["tredCalls"]
+    for k in list(got):
+        if k.endswith(".details"):
+            got[k] = [[d["id"], d["tag"], int(d["h"])] for d in got[k]]
+    _compare(got, want, "synall")
+    called = [n for n in gold["loci"] if want[n + ".1"] > 0]
+    assert len(called) == 30 and sum(want[n + ".label"] != "ok" for n in called) >= 1

@@ -453,6 +453,61 @@ def gen_flags(loci):
                                 "pysam replaced by tredparse_amd.bamio", "cases": cases}, fp)
 
 
+SYNALL_SEED, SYNALL_COVERAGE = 20260777, 12.0
+
+
+def synall_sample():
+    """One synthetic 12x sample over all 30 distinct loci (tredparse_amd.synth_bam, fixed seed): NOT committed as a
+    file -- the test regenerates the identical BAM from the seed (same numpy, same writer) and fails loudly if it cannot."""
+    from tredparse_amd import synth_bam
+    loci = synth_bam.bench_loci()
+    p = synth.SynthParams(coverage=SYNALL_COVERAGE, expanded_max=120, expanded_frac=0.25)
+    recs, h_true = synth_bam.simulate_sample(SYNALL_SEED, loci, p, alt_rate=0.3)
+    return loci, recs, h_true
+
+
+def records_digest(recs):
+    """sha256 over the record table (what the BAM says, whatever the compression)."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in recs.FIELDS:
+        h.update(np.ascontiguousarray(getattr(recs, k)).tobytes())
+    return h.hexdigest()
+
+
+def gen_synall(loci_unused):
+    """The reference's run() with default flags on a synthetic sample that has reads at EVERY locus (BASELINE
+    configs[1] asks for all TRED loci; the reference's two mini-BAMs cover one locus each)."""
+    import tempfile
+    from tredparse_amd import synth_bam
+    ref = _load_full_reference()
+    loci, recs, h_true = synall_sample()
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        bam = os.path.join(tmp, "synall.bam")
+        synth_bam.write_bam(bam, recs, sample="synall", level=1)
+        digest = records_digest(recs)
+        repo = ref.meta.TREDsRepo(ref="hg38", toy=False, sites=os.path.join(tmp, "sites"))
+        names = [l["name"] for l in loci]
+        res = ref.tred.run(("synall", bam, repo, names, 300, False, False, True, True, "INFO"))
+        calls = _plain(res["tredCalls"])
+        for k in list(calls):
+            if k.endswith(".details"):     # (the bases are in the regenerated BAM: keep what the reference decided)
+                calls[k] = [[d["id"], d["tag"], int(d["h"])] for d in calls[k]]
+    finally:
+        os.chdir(cwd)
+    called = sum(1 for n in names if calls.get(n + ".1", -1) > 0)
+    print("synall:", len(recs), "records,", called, "of", len(names), "loci called;",
+          sum(int(calls[n + ".1"] == h[0]) for n, h in zip(names, h_true.tolist())), "short alleles as simulated")
+    with open(os.path.join(GOLD, "run_synall.json"), "w") as fp:
+        json.dump({"generator": "tools/gen_golden.py synall: the reference's tredparse.tred.run() (v0.7.8 via tools/refshim.py) "
+                                "on the synthetic sample of synall_sample(); `details` entries as [id, tag, h]",
+                   "seed": SYNALL_SEED, "coverage": SYNALL_COVERAGE, "records_sha256": digest, "loci": names,
+                   "h_true": h_true.tolist(), "tredCalls": calls}, fp)
+
+
 class _TextGzip(object):
     """gzip whose open(path, "w") is text mode: the py2 writers print str into it (tred.py:367-372)."""
 
@@ -630,6 +685,8 @@ def main():
         gen_vcf(loci)
     if "report" in what:
         gen_report(loci)
+    if "synall" in what:
+        gen_synall(loci)
 
 
 if __name__ == "__main__":
