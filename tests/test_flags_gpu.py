@@ -98,30 +98,46 @@ def test_cli_flags_reach_run(engine, bams, tmp_path, monkeypatch):
         _compare(got, want[name]["tredCalls"], name)
 
 
-def test_all_loci_with_reads_match_reference(engine, tmp_path):
-    """BASELINE configs[1] (all TRED loci) with evidence at every locus: one synthetic 12x sample over the 30 distinct
-    loci, regenerated here from its seed (the record table's digest must equal the one the golden was made from), through
-    run() with default flags against the reference's run() on the same BAM (tests/golden/run_synall.json)."""
+# (seed, loci or None = the 30 distinct ones, SynthParams keywords, alt_rate) of tools/gen_golden.py SYN_SAMPLES
+SYN_SAMPLES = {
+    "synall": (None, dict(coverage=12.0, expanded_max=120, expanded_frac=0.25), 0.3),
+    "syn100": (["HD", "DM1", "SCA10", "DM2", "ULD", "FXS", "SCA36", "FRDA", "OPMD", "SCA3"],
+               dict(coverage=20.0, readlen=100, ins_mean=300.0, ins_sd=50.0, expanded_max=90, expanded_frac=0.3), 0.3),
+    "syn250": (["HD", "DM1", "SCA10", "DM2", "ULD", "FXS", "SCA36", "FRDA", "OPMD", "SCA3"],
+               dict(coverage=10.0, readlen=250, ins_mean=550.0, ins_sd=80.0, max_units=75, expanded_max=150, expanded_frac=0.3), 0.3),
+    "syn100x": (["HD", "DM1", "SCA1", "FXS"],
+                dict(coverage=100.0, min_units=42, max_units=60, expanded_max=200, expanded_frac=0.8), 0.4),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SYN_SAMPLES))
+def test_synthetic_samples_match_reference(engine, tmp_path, name):
+    """The reference's run() (default flags) on synthetic samples with reads at EVERY listed locus
+    (tests/golden/run_synall.json): all 30 distinct loci at 150 bp -- BASELINE configs[1] asks for all TRED loci, the
+    reference's mini-BAMs cover one each --, ten loci at 100 bp and at 250 bp (READLEN taken from the file, other
+    ladders and kernel instantiations), four loci at 100x with alleles up to 200 repeats (configs[4]).  The samples are
+    regenerated here from their seeds; the record table's digest must equal the one the golden was made from.  Every
+    key of the result is compared (`details` as id / tag / h)."""
     import hashlib
     import numpy as np
     from tredparse_amd import synth, synth_bam
-    gold = json.load(open(os.path.join(GOLD, "run_synall.json")))
-    loci = synth_bam.bench_loci()
+    gold = json.load(open(os.path.join(GOLD, "run_synall.json")))["samples"][name]
+    names, kw, alt_rate = SYN_SAMPLES[name]
+    loci = synth_bam.bench_loci() if names is None else [l for l in synth.load_loci() if l["name"] in names]
     assert [l["name"] for l in loci] == gold["loci"]
-    p = synth.SynthParams(coverage=gold["coverage"], expanded_max=120, expanded_frac=0.25)
-    recs, h_true = synth_bam.simulate_sample(gold["seed"], loci, p, alt_rate=0.3)
+    recs, h_true = synth_bam.simulate_sample(gold["seed"], loci, synth.SynthParams(**kw), alt_rate=alt_rate)
     h = hashlib.sha256()
     for k in recs.FIELDS:
         h.update(np.ascontiguousarray(getattr(recs, k)).tobytes())
     assert h.hexdigest() == gold["records_sha256"], "the synthetic generator no longer reproduces the golden's sample"
-    bam = str(tmp_path / "synall.bam")
-    synth_bam.write_bam(bam, recs, sample="synall", level=1)
+    bam = str(tmp_path / (name + ".bam"))
+    synth_bam.write_bam(bam, recs, sample=name, level=1)
     repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
-    got = tredmod.run(("synall", bam, repo, gold["loci"], 300, False, False, True, True, "INFO"), engine=engine)["tredCalls"]
+    got = tredmod.run((name, bam, repo, gold["loci"], 300, False, False, True, True, "INFO"), engine=engine)["tredCalls"]
     want = gold["tredCalls"]
     for k in list(got):
         if k.endswith(".details"):
             got[k] = [[d["id"], d["tag"], int(d["h"])] for d in got[k]]
-    _compare(got, want, "synall")
-    called = [n for n in gold["loci"] if want[n + ".1"] > 0]
-    assert len(called) == 30 and sum(want[n + ".label"] != "ok" for n in called) >= 1
+    _compare(got, want, name)
+    assert got["readLen"] == kw.get("readlen", 150)
+    assert all(want[n + ".1"] > 0 for n in gold["loci"])            # evidence and a call at every locus

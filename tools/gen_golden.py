@@ -453,16 +453,25 @@ def gen_flags(loci):
                                 "pysam replaced by tredparse_amd.bamio", "cases": cases}, fp)
 
 
-SYNALL_SEED, SYNALL_COVERAGE = 20260777, 12.0
+# Synthetic samples the reference is run on (default flags) -- NOT committed as files: the tests regenerate the identical
+# record table from the seed (same numpy, same generator; its digest is checked) and write the BAM themselves.
+#   name: (seed, loci or None = all 30 distinct ones, SynthParams keywords, alt_rate)
+SYN_SAMPLES = {
+    "synall": (20260777, None, dict(coverage=12.0, expanded_max=120, expanded_frac=0.25), 0.3),
+    "syn100": (20260778, ["HD", "DM1", "SCA10", "DM2", "ULD", "FXS", "SCA36", "FRDA", "OPMD", "SCA3"],
+               dict(coverage=20.0, readlen=100, ins_mean=300.0, ins_sd=50.0, expanded_max=90, expanded_frac=0.3), 0.3),
+    "syn250": (20260779, ["HD", "DM1", "SCA10", "DM2", "ULD", "FXS", "SCA36", "FRDA", "OPMD", "SCA3"],
+               dict(coverage=10.0, readlen=250, ins_mean=550.0, ins_sd=80.0, max_units=75, expanded_max=150, expanded_frac=0.3), 0.3),
+    "syn100x": (20260780, ["HD", "DM1", "SCA1", "FXS"],
+                dict(coverage=100.0, min_units=42, max_units=60, expanded_max=200, expanded_frac=0.8), 0.4),
+}
 
 
-def synall_sample():
-    """One synthetic 12x sample over all 30 distinct loci (tredparse_amd.synth_bam, fixed seed): NOT committed as a
-    file -- the test regenerates the identical BAM from the seed (same numpy, same writer) and fails loudly if it cannot."""
+def syn_sample(name):
     from tredparse_amd import synth_bam
-    loci = synth_bam.bench_loci()
-    p = synth.SynthParams(coverage=SYNALL_COVERAGE, expanded_max=120, expanded_frac=0.25)
-    recs, h_true = synth_bam.simulate_sample(SYNALL_SEED, loci, p, alt_rate=0.3)
+    seed, names, kw, alt_rate = SYN_SAMPLES[name]
+    loci = synth_bam.bench_loci() if names is None else [l for l in synth.load_loci() if l["name"] in names]
+    recs, h_true = synth_bam.simulate_sample(seed, loci, synth.SynthParams(**kw), alt_rate=alt_rate)
     return loci, recs, h_true
 
 
@@ -476,36 +485,41 @@ def records_digest(recs):
 
 
 def gen_synall(loci_unused):
-    """The reference's run() with default flags on a synthetic sample that has reads at EVERY locus (BASELINE
-    configs[1] asks for all TRED loci; the reference's two mini-BAMs cover one locus each)."""
+    """The reference's run() with default flags on synthetic samples with reads at every locus listed: all 30 loci at
+    150 bp (BASELINE configs[1] asks for all TRED loci; the reference's two mini-BAMs cover one locus each), ten loci at
+    100 bp and at 250 bp (READLEN from the file, other ladder lengths), four loci at 100x with alleles up to 200 repeats
+    (configs[4]: large grids, repeat-only reads, paired-end mode)."""
     import tempfile
     from tredparse_amd import synth_bam
     ref = _load_full_reference()
-    loci, recs, h_true = synall_sample()
-    cwd = os.getcwd()
-    tmp = tempfile.mkdtemp()
-    os.chdir(tmp)
-    try:
-        bam = os.path.join(tmp, "synall.bam")
-        synth_bam.write_bam(bam, recs, sample="synall", level=1)
-        digest = records_digest(recs)
-        repo = ref.meta.TREDsRepo(ref="hg38", toy=False, sites=os.path.join(tmp, "sites"))
-        names = [l["name"] for l in loci]
-        res = ref.tred.run(("synall", bam, repo, names, 300, False, False, True, True, "INFO"))
-        calls = _plain(res["tredCalls"])
-        for k in list(calls):
-            if k.endswith(".details"):     # (the bases are in the regenerated BAM: keep what the reference decided)
-                calls[k] = [[d["id"], d["tag"], int(d["h"])] for d in calls[k]]
-    finally:
-        os.chdir(cwd)
-    called = sum(1 for n in names if calls.get(n + ".1", -1) > 0)
-    print("synall:", len(recs), "records,", called, "of", len(names), "loci called;",
-          sum(int(calls[n + ".1"] == h[0]) for n, h in zip(names, h_true.tolist())), "short alleles as simulated")
+    out = {}
+    for name in SYN_SAMPLES:
+        loci, recs, h_true = syn_sample(name)
+        cwd = os.getcwd()
+        tmp = tempfile.mkdtemp()
+        os.chdir(tmp)
+        try:
+            bam = os.path.join(tmp, name + ".bam")
+            synth_bam.write_bam(bam, recs, sample=name, level=1)
+            repo = ref.meta.TREDsRepo(ref="hg38", toy=False, sites=os.path.join(tmp, "sites"))
+            names = [l["name"] for l in loci]
+            res = ref.tred.run((name, bam, repo, names, 300, False, False, True, True, "INFO"))
+            calls = _plain(res["tredCalls"])
+            for k in list(calls):
+                if k.endswith(".details"):     # (the bases are in the regenerated BAM: keep what the reference decided)
+                    calls[k] = [[d["id"], d["tag"], int(d["h"])] for d in calls[k]]
+        finally:
+            os.chdir(cwd)
+        called = sum(1 for n in names if calls.get(n + ".1", -1) > 0)
+        print(name + ":", len(recs), "records, readLen", calls.get("readLen"), ",", called, "of", len(names), "loci called;",
+              sum(int(calls.get(n + ".1") == h[0]) for n, h in zip(names, h_true.tolist())), "short alleles as simulated;",
+              "largest grid entries", max(len(calls.get(n + ".P_h1h2") or {}) for n in names))
+        out[name] = {"seed": SYN_SAMPLES[name][0], "records_sha256": records_digest(recs), "loci": names,
+                     "h_true": h_true.tolist(), "tredCalls": calls}
     with open(os.path.join(GOLD, "run_synall.json"), "w") as fp:
         json.dump({"generator": "tools/gen_golden.py synall: the reference's tredparse.tred.run() (v0.7.8 via tools/refshim.py) "
-                                "on the synthetic sample of synall_sample(); `details` entries as [id, tag, h]",
-                   "seed": SYNALL_SEED, "coverage": SYNALL_COVERAGE, "records_sha256": digest, "loci": names,
-                   "h_true": h_true.tolist(), "tredCalls": calls}, fp)
+                                "on the synthetic samples of SYN_SAMPLES; `details` entries as [id, tag, h]",
+                   "samples": out}, fp)
 
 
 class _TextGzip(object):
