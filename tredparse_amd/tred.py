@@ -35,7 +35,9 @@ from .models import GridError, SparseDist, format_call, pair_summaries
 
 logging.basicConfig()
 logger = logging.getLogger(__name__)
-TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0}   # seconds of the driver thread, accumulated over run_many calls
+# seconds accumulated over run_many calls: the driver thread's waits for scans, its GPU calls and its formatting; and
+# the writer thread's time in the sink (JSON / VCF text and files)
+TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0}
 
 # (ID, Number, Type, Description) of the VCF meta lines, in file order
 _VCF_INFO = (("RPA", "1", "String", "Repeats per allele"), ("END", "1", "Integer", "End position of variant"),
@@ -280,10 +282,12 @@ class _Writer(object):
             if item is None:
                 return
             if self.error is None:
+                t0 = time.perf_counter()
                 try:
                     self.sink(item)
                 except BaseException as e:      # handed to the driver thread
                     self.error = e
+                TIMING["write"] += time.perf_counter() - t0
 
     def __call__(self, result):
         self.q.put(result)
