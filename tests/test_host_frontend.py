@@ -440,3 +440,52 @@ def test_lazy_views_print_through_the_batched_native_calls():
     lazy = {"samplekey": "t001", "bam": "x.bam", "tredCalls": calls}
     eager = {"samplekey": "t001", "bam": "x.bam", "tredCalls": plain}
     assert tredmod.dumps_result(lazy) == json.dumps(eager, sort_keys=True, indent=4, separators=(",", ": "))
+
+
+def test_pair_stats_equal_the_reference_formulas():
+    """tredbam_pair_stats (all loci of a sample in one native pass) against the reference's per-list formulas
+    (models.py:87-98: mean_std = numpy mean / std, histogram = numpy.histogram over 40 bins of (0, 1000)) -- incl. an
+    empty slice, a single value, values on bin edges and at 1000, and values outside the histogram's range."""
+    rng = np.random.default_rng(9)
+    lists = [[], [208], rng.integers(150, 999, 2000).tolist(), [0, 25, 24, 999, 1000, 975, 974], [1000, 1001, -3, 500],
+             rng.integers(300, 420, 37).tolist()]
+    pool = np.array([x for l in lists for x in l], np.int32)
+    count = np.array([len(l) for l in lists], np.int32)
+    first = np.concatenate([[0], np.cumsum(count)[:-1]]).astype(np.int64)
+    mean, sd, hist = bamio.pair_stats(pool, first, count)
+    for k, l in enumerate(lists):
+        if not l:
+            assert mean[k] == 0 and sd[k] == 0 and hist[k].sum() == 0
+            continue
+        assert "%.0f+/-%.0fbp" % (mean[k], sd[k]) == mean_std(l)
+        assert abs(mean[k] - np.mean(l)) < 1e-9 and abs(sd[k] - np.std(l)) < 1e-9
+        want = np.histogram(l, bins=40, range=(0, 1000))[0]
+        assert hist[k].tolist() == want.tolist(), k
+        assert ",".join("%d:%d" % (25 * j, c) for j, c in enumerate(hist[k])) == histogram(l)
+
+
+def test_batched_json_calls_fall_back_per_item():
+    """tredbam_sparse_json_many / tredbam_details_json_many: an item the native writer cannot print (a duplicate key, a
+    value that is not finite, a name with a control character) comes back as None -- that item alone goes to the generic
+    encoder -- and the others are unaffected; empty items print as {} / []."""
+    from tredparse_amd import bam_parser
+    a = np.array([3, 5, 7], np.int32)
+    texts = bamio.sparse_json_many([(a, None, np.array([.1, .2, .3])), (a[:0], None, np.zeros(0)),
+                                    (np.array([4, 4], np.int32), None, np.array([.5, .5])),
+                                    (a[:2], np.array([9, 9], np.int32), np.array([1e-7, float("inf")])),
+                                    (a[:1], a[:1], np.array([0.25]))], 2)
+    assert texts[1] == "{}" and texts[2] is None and texts[3] is None
+    assert json.loads(texts[0]) == {"3": .1, "5": .2, "7": .3} and json.loads(texts[4]) == {"3,3": 0.25}
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    s = scan_sample(BAM1, repo, ["HD"])
+    a0, b0 = s.reads_of(0)
+    reads = np.arange(a0, a0 + 3, dtype=np.int64)
+    tags, hs = np.array([1, 2, 5], np.uint8), np.array([15, 7, 30], np.int32)
+    ok = bamio.details_json_many(s.seq4, s.seq4_off, s.read_len, s.name_blob, s.name_off,
+                                 [(reads, tags, hs), (reads[:0], tags[:0], hs[:0])])
+    assert ok[1] == "[]" and [d["h"] for d in json.loads(ok[0])] == [15, 7, 30]
+    blob = bytearray(s.name_blob)
+    blob[int(s.name_off[a0 + 1])] = 7                       # a control character in the second read's name
+    bad = bamio.details_json_many(s.seq4, s.seq4_off, s.read_len, bytes(blob), s.name_off,
+                                  [(reads[:1], tags[:1], hs[:1]), (reads, tags, hs)])
+    assert bad[1] is None and json.loads(bad[0])[0]["tag"] == "FULL"
