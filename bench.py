@@ -358,6 +358,7 @@ def rank_main(args):
                                  "frac": alg_bytes / sw_s / 1e9 / HBM_PEAK_GBS}},
             "kernels_ms_per_step": {"sw_ladder": sw_ms / max(sw_n, 1), "tally": ta_ms / max(ta_n, 1),
                                     "grid": gr_ms / max(gr_n, 1),
+                                    "grid_kde": ctx.get_timing(_lib.KERNEL_GRID_KDE)[1] / max(gr_n, 1),
                                     "grid_prepare": ctx.get_timing(_lib.KERNEL_GRID_PREPARE)[1] / max(gr_n, 1),
                                     "grid_pairs": ctx.get_timing(_lib.KERNEL_GRID_PAIRS)[1] / max(gr_n, 1),
                                     "grid_reduce": ctx.get_timing(_lib.KERNEL_GRID_REDUCE)[1] / max(gr_n, 1)},

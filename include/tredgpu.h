@@ -260,10 +260,11 @@ int tredgpu_pe_kde(tredgpu_ctx* ctx, int mem, const tredgpu_unit_params* units, 
  */
 #define TREDGPU_KERNEL_SW 0
 #define TREDGPU_KERNEL_TALLY 1
-#define TREDGPU_KERNEL_GRID 2          /* the three grid kernels of a call together ...   */
-#define TREDGPU_KERNEL_GRID_PREPARE 3  /* ... and one by one: tables, axes, KDE per unit  */
+#define TREDGPU_KERNEL_GRID 2          /* the four grid kernels of a call together ...    */
+#define TREDGPU_KERNEL_GRID_PREPARE 3  /* ... and one by one: tables and axes per unit    */
 #define TREDGPU_KERNEL_GRID_PAIRS 4    /*     the log-likelihood of every (h1, h2) pair   */
 #define TREDGPU_KERNEL_GRID_REDUCE 5   /*     arg-max, marginals, CI, PP per unit         */
+#define TREDGPU_KERNEL_GRID_KDE 6      /*     the paired-end KDEs (runs first)            */
 int tredgpu_reset_timing(tredgpu_ctx* ctx);
 int tredgpu_get_timing(tredgpu_ctx* ctx, int which, int64_t* launches, double* total_ms);
 /*

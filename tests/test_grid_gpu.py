@@ -288,3 +288,55 @@ def test_exact_tie_between_a_near_and_a_far_column(ctx):
     assert calls[0]["status"] == 0 and (int(calls[0]["h1"]), int(calls[0]["h2"])) == tuple(w["alleles"]) == (90, 102)
     got = dump[:, 2:].sum(1)
     assert (got == got.max()).sum() == (tot == tot.max()).sum()          # the tie is a tie on the device too
+
+
+def _run_grid(ctx, cases, hs=128, ms=512):
+    units, full, pref, rept, gl, tl = _case_inputs(cases, hs)
+    n = len(cases)
+    marg = np.zeros((n, 2, ms), np.float64)
+    calls = np.zeros(n, _lib.CALL_DTYPE)
+    ctx.likelihood_grid(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls, None, None, marg, ms)
+    return calls, marg
+
+
+def test_batch_of_many_units_equals_units_one_by_one(ctx):
+    """A unit's result does not depend on its batch: 120 units in shuffled order (the kernels hand units out through 16
+    ticket queues, carve their tables from 16 sub-pools and build the paired-end KDEs in a kernel of their own) against
+    the same cases run alone, bit for bit."""
+    _set_model(ctx)
+    alone = [_run_grid(ctx, [c]) for c in CASES]
+    order = np.random.default_rng(5).permutation(np.repeat(np.arange(len(CASES)), 5))
+    calls, marg = _run_grid(ctx, [CASES[i] for i in order])
+    for k, i in enumerate(order):
+        assert calls[k].tobytes() == alone[i][0][0].tobytes(), (k, CASES[i]["name"])
+        assert np.array_equal(marg[k], alone[i][1][0]), (k, CASES[i]["name"])
+
+
+def test_singular_pair_length_model_with_and_without_the_paired_end_term(ctx):
+    """The reference builds the KDE whenever a unit has its paired-end model (models.py:131-132) and fails on a singular
+    one whether or not the term is used afterwards: constant pair lengths give status -2 in both kinds of unit, and a
+    single different length lifts it."""
+    _set_model(ctx)
+    with_pe = [c for c in CASES if c["kde"] is not None and not c["expected"]["raised"]]
+    assert with_pe
+    used = with_pe[0]
+    unused = dict(used, partial={}, name=used["name"] + "/no PREF reads")   # no partial read: the term is not used
+    for base in (used, unused):
+        flat = dict(base, global_lens=[300] * len(base["global_lens"]))
+        bump = dict(flat, global_lens=[300] * (len(base["global_lens"]) - 1) + [301])
+        calls, _ = _run_grid(ctx, [flat, bump, base])
+        assert calls[0]["status"] == -2, base["name"]
+        assert calls[1]["status"] in (0, 1), base["name"]
+        assert calls[2]["status"] in (0, 1), base["name"]
+
+
+def test_grid_kernels_are_timed_one_by_one(ctx):
+    _set_model(ctx)
+    ctx.reset_timing()
+    _run_grid(ctx, CASES)
+    total = ctx.get_timing(_lib.KERNEL_GRID)
+    parts = [ctx.get_timing(k) for k in (_lib.KERNEL_GRID_KDE, _lib.KERNEL_GRID_PREPARE, _lib.KERNEL_GRID_PAIRS, _lib.KERNEL_GRID_REDUCE)]
+    assert total[0] == 1 and all(p[0] == 1 for p in parts)
+    assert all(p[1] > 0 for p in parts) and sum(p[1] for p in parts) <= total[1] * 1.01 + 0.05
+    with pytest.raises(_lib.TredGpuError):
+        ctx.get_timing(7)

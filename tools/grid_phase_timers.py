@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Per-phase cycle shares of grid_prepare_kernel / grid_reduce_kernel (how DESIGN section 7's percentages were measured).
 
-  python tools/grid_phase_timers.py build prepare|reduce
+  python tools/grid_phase_timers.py build kde|prepare|reduce
       writes tredparse_amd/csrc/_exp_grid_prof.hip -- grid.hip with a clock64() mark in thread 0 at every phase boundary
       of the chosen kernel, each mark adding the cycles since the previous one to a device counter -- and builds
       tredparse_amd/libtredgpu_prof.so from it (run here, no GPU needed).
-  TREDGPU_LIB=$PWD/tredparse_amd/libtredgpu_prof.so python tools/grid_phase_timers.py run prepare|reduce
+  TREDGPU_LIB=$PWD/tredparse_amd/libtredgpu_prof.so python tools/grid_phase_timers.py run kde|prepare|reduce
       on the GPU box: one rank of bench.py (4 steps), then the counters as shares.
 
 The marks perturb what they measure (12-13 global atomics per unit on shared counters), so the shares are a guide to
@@ -20,15 +20,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tredparse_amd", "csrc")
 
 PHASES = {
-    "prepare": ["loop wrap", "ticket", "params + lists", "pe / kde", "axes", "descriptor", "pool alloc", "obs copy",
+    "kde": ["loop wrap", "ticket", "params + clear", "histogram maxima", "lengths: loads + bins", "lengths: reductions",
+            "run_pe", "mean, variance", "sigma, kernel table", "bins copy", "convolution", "normalise + store", "outcome"],
+    "prepare": ["loop wrap", "ticket", "params + lists", "pe outcome + pair lengths", "axes", "descriptor", "pool alloc", "obs copy",
                 "far rows + scan", "near columns", "rept table", "roll tables", "descriptor write"],
     "reduce": ["loop wrap", "ticket", "descriptor load", "arg-max", "sweep", "P_h2", "block sums", "P_h1", "prefix sums",
                "CI marks", "call", "marginals out"],
 }
 ANCHORS = {
-    "prepare": ("__global__ __launch_bounds__(NT, 3) void grid_prepare_kernel", "// ---- kernel 2: every pair of every unit", [
+    # (the KDE's phases sit in the helpers kde_collect / kde_finish, in front of the kernel: its range starts there)
+    "kde": ("struct KdeLens {", "// ---- kernel 1: per-unit preparation", [
+        "        const tredgpu_unit_params u = uniform_unit(a.units + g);\n        if (!(u.n_global >= 100",
+        "        const int32_t* fc = a.full_cnt + (size_t)g * a.hist_stride;\n        const int32_t* pc = a.pref_cnt + (size_t)g * a.hist_stride;\n        int hf = 0",
+        "    double s = 0;\n    int vlo = INT_MAX",
+        "    for (int o = 32; o > 0; o >>= 1) {\n        vlo = min(vlo",
+        "        const int max_full = __builtin_amdgcn_readfirstlane(sh[1]) * u.period;\n",
+        "    const double mean = in.total / n;\n",
+        "    const double factor = pow((double)n, -1. / 5);\n",
+        "    for (int i = tid; i < SPAN + 2; i += NT) khist[kswz(i)]",
+        "    const int x0 = tid * XPER;\n",
+        "    double part = 0;\n#pragma unroll\n    for (int qx = 0; qx < XPER; ++qx)\n        if (x0 + qx < SPAN) part += acc[qx];",
+        "        if (tid == 0) a.unit_kde_rc[g] = rc;\n    }\n}"]),
+    "prepare": ("__global__ __launch_bounds__(NT, PREP_WAVES) void grid_prepare_kernel", "// ---- kernel 2: every pair of every unit", [
         "        const tredgpu_unit_params u = uniform_unit(a.units + g);\n",
-        "        // ---- paired-end model (models.py:131-132, 428-439) ----\n",
+        "        // ---- paired-end model (models.py:131-132, 428-439): built by grid_kde_kernel ----\n",
         "        // ---- grid axes (models.py:239-257) ----\n",
         "        UnitDesc d;\n        d.status = status;",
         "        // ---- room in the pool and a run of work items;",
@@ -53,21 +68,22 @@ ANCHORS = {
 
 
 def mark(k):
-    return ("        if (tid == 0) { const long long t_ = clock64(); atomicAdd(&g_prof[%d], (unsigned long long)(t_ - tprev));"
-            " tprev = t_; }\n" % k)
+    # (the previous mark's time lives in LDS: the KDE's phases are in helper functions, out of the kernel's scope)
+    return ("        if (threadIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_prof[%d], (unsigned long long)(t_ - g_tprev));"
+            " g_tprev = t_; }\n" % k)
 
 
 def build(which):
     s = open(os.path.join(SRC, "grid.hip")).read()
     head = "namespace tredgpu {\nnamespace {"
     assert head in s
-    s = s.replace(head, "namespace tredgpu {\n__device__ unsigned long long g_prof[16];\nnamespace {", 1)
+    s = s.replace(head, "namespace tredgpu {\n__device__ unsigned long long g_prof[16];\n__shared__ long long g_tprev;\nnamespace {", 1)
     first, last, anchors = ANCHORS[which]
     a, b = s.index(first), s.index(last)
     body = s[a:b]
     top = "    while (true) {\n        __syncthreads();\n"
     assert top in body
-    body = body.replace(top, "    long long tprev = clock64();\n" + top + mark(0), 1)
+    body = body.replace(top, "    if (threadIdx.x == 0) g_tprev = clock64();\n" + top + mark(0), 1)
     for k, anchor in enumerate(anchors, 1):
         assert anchor in body, anchor
         body = body.replace(anchor, mark(k) + anchor, 1)

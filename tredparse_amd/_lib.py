@@ -286,7 +286,7 @@ class Context:
 
 
 KERNEL_SW, KERNEL_TALLY, KERNEL_GRID = 0, 1, 2
-KERNEL_GRID_PREPARE, KERNEL_GRID_PAIRS, KERNEL_GRID_REDUCE = 3, 4, 5
+KERNEL_GRID_PREPARE, KERNEL_GRID_PAIRS, KERNEL_GRID_REDUCE, KERNEL_GRID_KDE = 3, 4, 5, 6
 
 
 def default_sw_params(clip=False, max_read_len=0):

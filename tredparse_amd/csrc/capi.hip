@@ -37,7 +37,7 @@ struct tredgpu_ctx {
     Buf d_model;
     bool have_model = false;
     // workspaces (grow-only, reused across calls)
-    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class, ws_gdesc, ws_gtile, ws_gctr, ws_ucnt, ws_bins;
+    Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class, ws_gdesc, ws_gtile, ws_gctr, ws_ucnt, ws_bins, ws_kde;
     int* h_pin = nullptr;  // pinned word for small read-backs
     size_t grid_pool_bytes = GRID_POOL_BYTES;   // TREDGPU_GRID_POOL_MB overrides (tuning / tests of the multi-pass path)
     Buf st[24];  // staging for HOST-memory calls
@@ -49,7 +49,7 @@ struct tredgpu_ctx {
         size_t used = 0;
         int64_t launches = 0;
         double total_ms = 0;
-    } timers[6];
+    } timers[7];
 };
 
 namespace {
@@ -247,7 +247,7 @@ void tredgpu_destroy(tredgpu_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (Buf* b : {&c->d_ladders, &c->d_seq, &c->d_model, &c->ws_quads, &c->ws_counter, &c->ws_drop,
-                   &c->ws_grid, &c->ws_stats, &c->ws_perm, &c->ws_class, &c->ws_gdesc, &c->ws_gtile, &c->ws_gctr, &c->ws_ucnt, &c->ws_bins, &c->ws_tag, &c->ws_h, &c->ws_score})
+                   &c->ws_grid, &c->ws_stats, &c->ws_perm, &c->ws_class, &c->ws_gdesc, &c->ws_gtile, &c->ws_gctr, &c->ws_ucnt, &c->ws_bins, &c->ws_kde, &c->ws_tag, &c->ws_h, &c->ws_score})
         release(*b);
     for (Buf& b : c->st) release(b);
     for (auto& t : c->timers)
@@ -295,7 +295,7 @@ int tredgpu_get_sw_counters(tredgpu_ctx* c, uint64_t out[8]) {
 
 int tredgpu_get_timing(tredgpu_ctx* c, int which, int64_t* launches, double* total_ms) {
     if (!c) return -2;
-    if (which < 0 || which > 5) return fail(c, -2, "which must be one of TREDGPU_KERNEL_*");
+    if (which < 0 || which > 6) return fail(c, -2, "which must be one of TREDGPU_KERNEL_*");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timer_flush(c->timers[which]);
@@ -649,14 +649,20 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     const int cap = std::min(std::max(hist_stride + 1 + std::max(max_insert, 0), 8), GRID_MAX_ROWS);
     const size_t slot_max = grid_slot_doubles_max(cap, cap, max_target) * sizeof(double);
     // the pool: everything the batch can ask for if that is small, else GRID_POOL_BYTES and as many passes
-    // as it takes (units that find the pool full are deferred to the next pass)
-    const size_t pool_bytes = std::max(std::min((size_t)n_units * slot_max, c->grid_pool_bytes), slot_max);
-    const bool may_defer = (size_t)n_units * slot_max > pool_bytes;
-    const size_t item_cap = (size_t)n_units * grid_items_cap(cap, cap);
+    // as it takes (units that find their sub-pool full are deferred to the next pass).  The kernels use it as up to 16
+    // sub-pools, unit g in sub-pool g % n: "everything" = the worst case of the fullest residue class, n times
+    const size_t slot_room = slot_max + 16 * sizeof(double);
+    const size_t all_bytes = 16 * grid_units_per_subpool(n_units, 16) * slot_room;
+    const size_t pool_bytes = std::max(std::min(all_bytes, c->grid_pool_bytes), slot_room);
+    const bool may_defer = all_bytes > pool_bytes;
+    const size_t item_cap = grid_item_slots(n_units, cap, cap);
     if ((rc = ensure(c, c->ws_grid, pool_bytes))) return rc;
     if ((rc = ensure(c, c->ws_gdesc, (size_t)n_units * grid_desc_bytes()))) return rc;
     if ((rc = ensure(c, c->ws_gtile, item_cap * grid_item_bytes() + 64))) return rc;
     if ((rc = ensure(c, c->ws_gctr, grid_counter_bytes()))) return rc;
+    // the units' paired-end KDEs (grid_kde_kernel -> grid_prepare_kernel): 1000 doubles + an outcome per unit
+    const size_t kde_pdf_bytes = (size_t)n_units * TREDGPU_SPAN * sizeof(double);
+    if ((rc = ensure(c, c->ws_kde, kde_pdf_bytes + (size_t)n_units * sizeof(int32_t)))) return rc;
     if (!c->h_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_pin, 64, hipHostMallocDefault));
     GridArgs a;
     a.units = units;
@@ -679,13 +685,19 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
     a.joint_total = joint_total;
     a.kde_pdf = nullptr;
     a.kde_status = nullptr;
+    a.unit_pdf = (double*)c->ws_kde.p;
+    a.unit_kde_rc = (int32_t*)((char*)c->ws_kde.p + kde_pdf_bytes);
+    a.max_target = max_target;
     {
         ScopedTimer tm(c, TREDGPU_KERNEL_GRID);
         for (int pass = 0;; ++pass) {
-            for (int ph = 0; ph < 3; ++ph) {     // prepare / pairs / reduce, each bracketed by its own events
-                ScopedTimer phase_tm(c, TREDGPU_KERNEL_GRID_PREPARE + ph);
+            // KDE (first pass only) / prepare / pairs / reduce, each bracketed by its own events
+            static const int PHASE[4][2] = {{8, TREDGPU_KERNEL_GRID_KDE}, {1, TREDGPU_KERNEL_GRID_PREPARE},
+                                            {2, TREDGPU_KERNEL_GRID_PAIRS}, {4, TREDGPU_KERNEL_GRID_REDUCE}};
+            for (int ph = pass == 0 ? 0 : 1; ph < 4; ++ph) {
+                ScopedTimer phase_tm(c, PHASE[ph][1]);
                 HIPCHK(c, launch_grid_pass(a, pass, c->ws_gdesc.p, (double*)c->ws_grid.p, pool_bytes / sizeof(double), cap,
-                                           cap, c->ws_gtile.p, item_cap, c->ws_gctr.p, c->stream, 1 << ph));
+                                           cap, c->ws_gtile.p, item_cap, c->ws_gctr.p, c->stream, PHASE[ph][0]));
             }
             if (!may_defer) break;
             HIPCHK(c, hipMemcpyAsync(c->h_pin, (const char*)c->ws_gctr.p + grid_deferred_offset(), sizeof(int),

@@ -22,6 +22,7 @@
 // intended differences are libm-vs-ocml last-bit effects in log/exp, the paired-end product-log (pairs kernel) and
 // the summation order of the marginals.
 #include <algorithm>
+#include <climits>
 #include <type_traits>
 
 #include "tredgpu_internal.h"
@@ -29,7 +30,19 @@
 namespace tredgpu {
 namespace {
 
-constexpr int NT = 128;   // threads per workgroup (one unit at a time); 6 workgroups per CU
+constexpr int NT = 128;   // threads per workgroup (one unit at a time)
+#ifndef KDE_WAVES
+#define KDE_WAVES 3
+#endif
+#ifndef PREP_WAVES
+#define PREP_WAVES 4
+#endif
+#ifndef PREP_BLOCKS
+#define PREP_BLOCKS 2048
+#endif
+#ifndef KDE_BLOCKS
+#define KDE_BLOCKS 2048
+#endif
 constexpr int XPER = (TREDGPU_SPAN + NT - 1) / NT;  // KDE x-values per thread
 constexpr int SPAN = TREDGPU_SPAN;
 constexpr int MAXOBS = 256;  // distinct FULL / PREF sizes per unit
@@ -101,7 +114,7 @@ struct PairCtx {
     const ModelConst* M;
     const double* step;  // step-size row of this period
     const Obs* obs;
-    const double* pdf;   // KDE (LDS) when run_pe
+    const double* pdf;   // the unit's KDE (global memory, written by grid_kde_kernel) when run_pe
     const int32_t* tl;   // target lens of the unit
     int n_target;
     int period, readlen, t1, t2, mp_eff, ref_len, minpe, n_rept;
@@ -229,7 +242,7 @@ __device__ __forceinline__ double wave_sum_to_last(double v) {
 }
 
 // block-wide sum; result valid in every thread
-__device__ double block_sum(double v, double* red) {
+__device__ __forceinline__ double block_sum(double v, double* red) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -250,28 +263,56 @@ __device__ double block_sum(double v, double* red) {
 constexpr int KERN2_RAW = 1040;   // |d| <= NT * XPER - 1 + 7 = 1030 is the largest index a window touches
 __device__ __forceinline__ int kswz(int i) { return i + (i >> 3); }
 constexpr int KERN2 = KERN2_RAW + KERN2_RAW / 8 + 1;
+constexpr int KHIST = SPAN + 2 + (SPAN + 2) / 8 + 1;   // the bins behind two zero guards, swizzled
 static_assert(XPER == 8, "the sliding window below is unrolled for 8 x-values per thread");
 static_assert(NT * XPER >= SPAN && NT * XPER + XPER <= KERN2_RAW && SPAN + XPER <= KERN2_RAW, "window indices stay inside kern2");
 
-__device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, double* pdf, double* red, int* flag) {
+// First half: the histogram of the lengths (hist, zeroed by the caller behind a barrier), their sum, smallest and
+// largest value; `bad` = some length outside [0, 1000).  The loads go out eight at a time (one after the other, each
+// behind the LDS atomic of the one before, they were a chain of n / NT memory latencies per unit); the sum keeps the
+// order of a plain strided walk.
+struct KdeLens {
+    double total;
+    int lo, hi, bad;
+};
+__device__ __forceinline__ KdeLens kde_collect(const int32_t* lens, int n, int* hist, double* red, int* flag) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < SPAN; i += NT) hist[i] = 0;
-    if (tid == 0) { flag[0] = 0; flag[1] = SPAN; flag[2] = -1; }
-    __syncthreads();
     double s = 0;
-    int vlo = SPAN, vhi = -1;
-    for (int i = tid; i < n; i += NT) {
-        const int v = lens[i];
-        if (v < 0 || v >= SPAN) atomicOr(&flag[0], 1);
-        else { atomicAdd(&hist[v], 1); vlo = min(vlo, v); vhi = max(vhi, v); }
-        s += (double)v;
+    int vlo = INT_MAX, vhi = INT_MIN, bad = 0;
+    for (int base = tid; base < n; base += NT * 8) {
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = lens[min(base + k * NT, n - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (base + k * NT < n) {
+                if (v[k] < 0 || v[k] >= SPAN) bad = 1;
+                else atomicAdd(&hist[v[k]], 1);
+                vlo = min(vlo, v[k]); vhi = max(vhi, v[k]);
+                s += (double)v[k];
+            }
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) { vlo = min(vlo, __shfl_down(vlo, o, 64)); vhi = max(vhi, __shfl_down(vhi, o, 64)); }
-    if ((tid & 63) == 0) { atomicMin(&flag[1], vlo); atomicMax(&flag[2], vhi); }
-    const double total = block_sum(s, red);
-    if (flag[0] || n >= 65536) return -6;
+    for (int o = 32; o > 0; o >>= 1) {
+        vlo = min(vlo, __shfl_down(vlo, o, 64)); vhi = max(vhi, __shfl_down(vhi, o, 64)); bad |= __shfl_down(bad, o, 64);
+    }
+    if ((tid & 63) == 0) { atomicMin(&flag[1], vlo); atomicMax(&flag[2], vhi); atomicOr(&flag[0], bad); }
+    KdeLens r;
+    r.total = block_sum(s, red);     // (its barriers publish the flags and the histogram)
+    r.lo = flag[1]; r.hi = flag[2]; r.bad = flag[0];
+    return r;
+}
+__device__ __forceinline__ void kde_clear(int* hist, int* flag) {   // the caller puts a barrier behind it
+    for (int i = threadIdx.x; i < SPAN; i += NT) hist[i] = 0;
+    if (threadIdx.x == 0) { flag[0] = 0; flag[1] = INT_MAX; flag[2] = INT_MIN; }
+}
+
+// Second half: from the histogram to the normalised pdf.
+__device__ __forceinline__ int kde_finish(const KdeLens& in, int n, const int* hist, double* kern2, double* khist, double* pdf, double* red) {
+    const int tid = threadIdx.x;
+    if (in.bad || n >= 65536) return -6;
     if (n < 2) return -2;
-    const double mean = total / n;
+    const double mean = in.total / n;
     double q = 0;
     for (int i = tid; i < SPAN; i += NT) {
         const double d = (double)i - mean;
@@ -283,18 +324,21 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
     const double sigma = sqrt(var) * factor;       // cho_cov
     const double norm = 1.0 / sqrt(2 * M_PI) / sigma;  // (2*pi)^(-d/2) / cho_cov
     const double w = 1.0 / n;                      // uniform weights
+    // only bins within W = 9 sigma of x are added up (see the loop below); the window reads K(d) for |d| < W + 2 XPER
+    const int W = (int)fmin((double)SPAN, ceil(9.0 * sigma));
+    const int kend = W + 2 * XPER;
     // K(d) = exp(-(d/sigma)^2 / 2) * norm for |d| < 1000, 0 beyond
-    for (int d = tid; d < SPAN; d += NT) {
+    for (int d = tid; d < min(SPAN, kend); d += NT) {
         const double r = (double)d / sigma;
         const double k = exp(-(r * r) / 2) * norm;
         kern2[kswz(d)] = k;
     }
-    for (int i = SPAN + tid; i < KERN2_RAW; i += NT) kern2[kswz(i)] = 0;
-    // the bins once more, swizzled (i + i/8: the lanes below read with a stride of XPER ints), in the memory of `pdf`
-    // (written only after the loop, behind a barrier); entry 0 and entry SPAN + 1 are zero guards, bin v sits at v + 1:
-    // a lane's out-of-range bins clamp onto a guard, so the load in the loop needs no branch
-    int* const khist = reinterpret_cast<int*>(pdf);
-    for (int i = tid; i < SPAN + 2; i += NT) khist[kswz(i)] = (i >= 1 && i <= SPAN) ? hist[i - 1] : 0;
+    for (int i = SPAN + tid; i < min(KERN2_RAW, kend); i += NT) kern2[kswz(i)] = 0;
+    // the bins once more, swizzled (i + i/8: the lanes below read with a stride of XPER ints); entry 0 and entry
+    // SPAN + 1 are zero guards, bin v sits at v + 1: a lane's out-of-range bins clamp onto a guard, so the load in the
+    // loop needs no branch
+    // (as weights count / n, in double: the loop then is loads and fused multiply-adds only)
+    for (int i = tid; i < SPAN + 2; i += NT) khist[kswz(i)] = (i >= 1 && i <= SPAN) ? hist[i - 1] * w : 0.0;
     __syncthreads();
     // A Gaussian term below 1e-17 of the kernel's peak cannot change a sum of at most 65 535 terms of that scale in
     // its 16th digit: only bins within W = 9 sigma of x are added up (exp(-81/2) = 2.6e-18).  Every thread owns XPER
@@ -304,7 +348,6 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
     // of the ~850 of the occupied range of pair lengths (grid_prepare_kernel: 2.62 -> 2.38 ms per 30 000 units).
     // The products are accumulated with explicit fused multiply-adds (the file is compiled with -ffp-contract=off,
     // which had left a multiply and an add per term: twice the fp64 issue slots of the loop).
-    const int W = (int)fmin((double)SPAN, ceil(9.0 * sigma));
     const int x0 = tid * XPER;
     double acc[XPER], win[XPER];
 #pragma unroll
@@ -315,47 +358,47 @@ __device__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, d
     // step st of a group handles d = db + st with the window rotated by st: K(qx - d) sits in win[(qx - st) & 7];
     // afterwards the slot of qx = 7 is refilled with K(0 - (d + 1))
     for (int db = -W; db <= W + XPER - 1; db += XPER) {
-        int cnt[XPER];
-        double nxt[XPER];
+        double wk[XPER], nxt[XPER];
 #pragma unroll
         for (int st = 0; st < XPER; ++st) {
             const int v = x0 + db + st;
-            cnt[st] = khist[kswz(min(max(v, -1), SPAN) + 1)];
+            wk[st] = khist[kswz(min(max(v, -1), SPAN) + 1)];
             nxt[st] = kern2[kswz(abs(db + st + 1))];
         }
 #pragma unroll
         for (int st = 0; st < XPER; ++st) {
-            const double wk = cnt[st] * w;
 #pragma unroll
-            for (int qx = 0; qx < XPER; ++qx) acc[qx] = __builtin_fma(wk, win[(qx - st) & 7], acc[qx]);
+            for (int qx = 0; qx < XPER; ++qx) acc[qx] = __builtin_fma(wk[st], win[(qx - st) & 7], acc[qx]);
             win[(7 - st) & 7] = nxt[st];
         }
     }
-    __syncthreads();     // khist lives in pdf's memory
     double part = 0;
 #pragma unroll
-    for (int qx = 0; qx < XPER; ++qx) {
-        const int x = x0 + qx;
-        if (x < SPAN) { pdf[x] = acc[qx]; part += acc[qx]; }
-    }
+    for (int qx = 0; qx < XPER; ++qx)
+        if (x0 + qx < SPAN) part += acc[qx];
     const double tot = block_sum(part, red);
 #pragma unroll
-    for (int qx = 0; qx < XPER; ++qx) {
-        const int x = x0 + qx;
-        if (x < SPAN) pdf[x] = pdf[x] / tot;
-    }
-    __syncthreads();
+    for (int qx = 0; qx < XPER; ++qx)
+        if (x0 + qx < SPAN) pdf[x0 + qx] = acc[qx] / tot;
     return 0;
+}
+
+__device__ __forceinline__ int kde_block(const int32_t* lens, int n, int* hist, double* kern2, double* khist, double* pdf, double* red, int* flag) {
+    kde_clear(hist, flag);
+    __syncthreads();
+    const KdeLens in = kde_collect(lens, n, hist, red, flag);
+    return kde_finish(in, n, hist, kern2, khist, pdf, red);
 }
 
 __global__ __launch_bounds__(NT) void pe_kde_kernel(GridArgs a) {
     __shared__ int hist[SPAN];
     __shared__ double kern[KERN2];
+    __shared__ double khist[KHIST];
     __shared__ double red[NT / 64];
     __shared__ int flag[4];
     const int g = blockIdx.x;
     const tredgpu_unit_params u = a.units[g];
-    const int rc = kde_block(a.global_lens + u.pe_off, u.n_global, hist, kern, a.kde_pdf + (size_t)g * SPAN, red, flag);
+    const int rc = kde_block(a.global_lens + u.pe_off, u.n_global, hist, kern, khist, a.kde_pdf + (size_t)g * SPAN, red, flag);
     if (threadIdx.x == 0) a.kde_status[g] = rc;
 }
 
@@ -413,21 +456,47 @@ struct UnitDesc {
     int32_t item_base, n_items;
 };
 
-// Device-side counters of one pass (zeroed by the launch); the item ticket sits on its own cache line
-struct GridCounters {
-    // every counter that many workgroups add to sits on its own 64-byte line (atomics on one line serialise)
-    unsigned long long pool_used;   // doubles handed out
-    int32_t pad0[14];
-    int32_t n_items;
-    int32_t pad1[15];
-    int32_t next_prepare;
-    int32_t pad2[15];
-    int32_t next_reduce, n_deferred;
-    int32_t pad3[14];
-    int32_t next_item;
-    int32_t pad4[15];
+// Device-side counters of one pass (zeroed by the launch).
+// Every counter that many workgroups add to exists TQ times, each copy on its own 64-byte line, and unit g (work item
+// t) belongs to copy g % TQ: 30 000 workgroups taking their tickets from ONE address cost the kernels 0.36 ms each --
+// device-scope atomics on one address are carried out one after the other, ~12 ns apiece, wherever they come from
+// (measured: a kernel that does nothing but take tickets, 0.372 ms for 30 000 units, 0.011 ms without the atomic).
+// A workgroup starts at queue blockIdx % TQ and moves on when a queue runs dry (next_ticket): balancing stays dynamic.
+// The scratch pool is split the same way into PQ <= TQ sub-pools (bump allocation per sub-pool; PQ = 1 when a single
+// unit could need more than a TQ-th of the pool), the work-item list into TQ regions.
+constexpr int TQ = 16;
+struct CounterLine {
+    int32_t v;
+    int32_t pad[15];
 };
-static_assert(sizeof(GridCounters) == 320, "counter block layout");
+struct CounterLine64 {
+    unsigned long long v;
+    int32_t pad[14];
+};
+struct GridCounters {
+    CounterLine64 pool_used[TQ];   // doubles handed out, per sub-pool
+    CounterLine n_items[TQ];       // work items of the units of queue q (the q-th region of the item list)
+    CounterLine next_kde[TQ], next_prepare[TQ], next_reduce[TQ], next_item[TQ];
+    CounterLine n_deferred;
+};
+static_assert(sizeof(CounterLine) == 64 && sizeof(CounterLine64) == 64 && sizeof(GridCounters) == 64 * (6 * TQ + 1), "counter block layout");
+
+// The next unit (or work item) of a kernel's ticket queues, n when all are taken.  Queue q hands out q, q + TQ, ...
+// (limit[q] entries when `limit` is given: the work items of a region); called by one thread per workgroup, which
+// keeps `q` and `tried` between calls.
+struct TicketState {
+    int q, tried;
+};
+__device__ __forceinline__ int next_ticket(CounterLine* queues, TicketState& ts, int n) {
+    while (ts.tried < TQ) {
+        const int g = atomicAdd(&queues[ts.q].v, 1) * TQ + ts.q;
+        if (g < n) return g;
+        ts.q = (ts.q + 1) & (TQ - 1);
+        ++ts.tried;
+    }
+    return n;
+}
+static_assert((TQ & (TQ - 1)) == 0, "queue index wraps by masking");
 
 constexpr int CB = 64;    // columns per work item of grid_pairs_kernel: one lane owns one h2 for all the item's rows
 constexpr int RG = 128;   // rows per item
@@ -465,13 +534,11 @@ __device__ __forceinline__ UnitDesc uniform_desc(const UnitDesc* p) {
 struct PrepShared {
     Obs obs;
     union {
-        int hist[SPAN];                    // raw histograms while the lists are built, then the KDE's bins ...
+        int hist[SPAN];                    // raw histograms while the lists are built ...
         int row_off[GRID_MAX_ROWS + 1];    // ... then the per-row pair counts / dump offsets
     };
-    double kern[KERN2];
-    double pdf[SPAN];
-    double red[NT / 64];
-    int kflag[4];
+    double step[40];                       // the step-size row of the unit's period
+    int tl[SPAN];                          // the spanning pairs' lengths as indices into the rolled pdf
     long long slot_off;
     int flag, status, unit;
 };
@@ -493,17 +560,79 @@ __device__ PairCtx make_ctx(const UnitDesc& d, const ModelConst& M, const Obs* o
     return C;
 }
 
+// ---- kernel 0: the paired-end model of every unit that has one (models.py:131-132, 428-439) ----------------
+// The KDE used to sit inside grid_prepare_kernel: its window registers and 17 KB of tables held that kernel at 168
+// VGPRs + a spill frame and 5 workgroups per CU although the rest of it waits on memory, not on arithmetic.  Here the
+// fp64 convolution has a kernel of its own; the pdf goes to unit_pdf[g][0..1000) and the reference's outcome
+// (0, -2 singular, -6 length out of range) to unit_kde_rc[g].  Whether the paired-end term is used at all
+// (`run_pe`, models.py:234-236) follows from the unit's histograms alone: the largest FULL / PREF sizes and the
+// PREF reads above max_full + period -- the same numbers grid_prepare_kernel derives from its sparse lists (where
+// those overflow, the unit fails with -9 and never looks at this result).  Units whose model exists but is not
+// used only get the singularity check (the reference builds the KDE regardless, and raises).
+__global__ __launch_bounds__(NT, KDE_WAVES) void grid_kde_kernel(GridArgs a, GridCounters* ctr) {
+    __shared__ int hist[SPAN];
+    __shared__ double kern[KERN2];
+    __shared__ double khist[KHIST];
+    __shared__ double red[NT / 64];
+    __shared__ int flag[4];
+    __shared__ int sh[4];
+    const int tid = threadIdx.x;
+    TicketState ts = {(int)(blockIdx.x & (TQ - 1)), 0};
+    while (true) {
+        __syncthreads();
+        if (tid == 0) { sh[0] = next_ticket(ctr->next_kde, ts, a.n_units); sh[1] = 0; sh[2] = 0; sh[3] = 0; }
+        __syncthreads();
+        const int g = __builtin_amdgcn_readfirstlane(sh[0]);
+        if (g >= a.n_units) break;
+        const tredgpu_unit_params u = uniform_unit(a.units + g);
+        if (!(u.n_global >= 100 && u.n_target >= 5)) {
+            if (tid == 0) a.unit_kde_rc[g] = 0;
+            continue;
+        }
+        // the unit's histograms (is the paired-end term used?) and its pair lengths are fetched together
+        kde_clear(hist, flag);
+        __syncthreads();
+        const int32_t* fc = a.full_cnt + (size_t)g * a.hist_stride;
+        const int32_t* pc = a.pref_cnt + (size_t)g * a.hist_stride;
+        int hf = 0, hp = 0;
+        for (int h = tid; h < a.hist_stride; h += NT) {
+            if (fc[h] > 0) hf = h;
+            if (pc[h] > 0) hp = h;
+        }
+        for (int o = 32; o > 0; o >>= 1) { hf = max(hf, __shfl_down(hf, o, 64)); hp = max(hp, __shfl_down(hp, o, 64)); }
+        if ((tid & 63) == 0) { atomicMax(&sh[1], hf); atomicMax(&sh[2], hp); }
+        const KdeLens in = kde_collect(a.global_lens + u.pe_off, u.n_global, hist, red, flag);   // (barriers inside)
+        const int max_full = __builtin_amdgcn_readfirstlane(sh[1]) * u.period;
+        const int max_partial = __builtin_amdgcn_readfirstlane(sh[2]) * u.period;
+        int above = 0;
+        for (int h = tid; h < a.hist_stride; h += NT)
+            if (h * u.period > max_full + u.period) above += pc[h];
+        for (int o = 32; o > 0; o >>= 1) above += __shfl_down(above, o, 64);
+        if ((tid & 63) == 0) atomicAdd(&sh[3], above);
+        __syncthreads();
+        const bool run_pe = max_partial >= u.readlen - 27 && __builtin_amdgcn_readfirstlane(sh[3]) > 1;
+        int rc;
+        // model not used: only the singularity check matters.  The lengths are integers, so their sum and -- when they
+        // are all equal -- their mean are exact: the variance is zero exactly when smallest = largest
+        if (!run_pe) rc = in.lo == in.hi ? -2 : 0;
+        else rc = kde_finish(in, u.n_global, hist, kern, khist, a.unit_pdf + (size_t)g * SPAN, red);
+        if (tid == 0) a.unit_kde_rc[g] = rc;
+    }
+}
+
 // ---- kernel 1: per-unit preparation -------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pass, UnitDesc* descs, double* pool,
-                                                          unsigned long long pool_doubles, int rows_cap, int cols_cap,
-                                                          int* item_unit, GridCounters* ctr) {
+__global__ __launch_bounds__(NT, PREP_WAVES) void grid_prepare_kernel(GridArgs a, int pass, UnitDesc* descs, double* pool,
+                                                          unsigned long long subpool_doubles, int n_subpools, int rows_cap,
+                                                          int cols_cap, int* item_unit, int item_region,
+                                                          GridCounters* ctr) {
     __shared__ PrepShared S;
     const int tid = threadIdx.x;
     const ModelConst& M = *a.model;
+    TicketState ts = {(int)(blockIdx.x & (TQ - 1)), 0};
     while (true) {
         __syncthreads();
         if (tid == 0) {
-            S.unit = atomicAdd(&ctr->next_prepare, 1);
+            S.unit = next_ticket(ctr->next_prepare, ts, a.n_units);
             S.status = 0;
             if (pass > 0 && S.unit < a.n_units && a.calls[S.unit].status != UNIT_DEFERRED) S.status = UNIT_SKIP;
         }
@@ -583,38 +712,22 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         reads_above_full = __builtin_amdgcn_readfirstlane(reads_above_full);
         // observation sizes index the 1000-vectors (models.py:198,206): IndexError past the end
         if (status == 0 && (max_full >= SPAN || max_partial >= SPAN)) status = -3;
-        __syncthreads();  // S.hist is reused by the KDE below
+        __syncthreads();
 
-        // ---- paired-end model (models.py:131-132, 428-439) ----
+        // ---- paired-end model (models.py:131-132, 428-439): built by grid_kde_kernel ----
         const bool have_pe = u.n_global >= 100 && u.n_target >= 5;
         const bool run_pe = max_partial >= t3 && reads_above_full > 1 && have_pe;  // :234-236
         if (status == 0 && have_pe) {
             // the reference builds the KDE whenever the model exists; a singular one raises there
-            int rc;
-            if (!run_pe) {
-                // only the singularity check matters: all lengths equal <=> zero variance
-                double sum = 0;
-                const int32_t* gl = a.global_lens + u.pe_off;
-                for (int i = tid; i < u.n_global; i += NT) sum += (double)gl[i];
-                const double mean = block_sum(sum, S.red) / u.n_global;
-                double q = 0;
-                for (int i = tid; i < u.n_global; i += NT) { const double d = gl[i] - mean; q += d * d; }
-                rc = block_sum(q, S.red) > 0 ? 0 : -2;
-            } else {
-                rc = kde_block(a.global_lens + u.pe_off, u.n_global, S.hist, S.kern, S.pdf, S.red, S.kflag);
-            }
-            rc = __builtin_amdgcn_readfirstlane(rc);
+            const int rc = __builtin_amdgcn_readfirstlane(a.unit_kde_rc[g]);
             if (rc) status = rc;
         }
         // the spanning pairs' lengths index the rolled pdf (models.py:471-473): IndexError outside [-1000, 1000).
-        // Checked by all threads at once, and kept in LDS (behind the 37 step-size entries that S.kern holds once the
-        // KDE is done with it) for the roll tables below: read one by one from global memory by every thread they were a
-        // chain of ~n_target memory latencies per unit.
+        // Checked by all threads at once, and kept in LDS for the roll tables below: read one by one from global memory
+        // by every thread they were a chain of ~n_target memory latencies per unit.
         const bool tl_staged = u.n_target <= SPAN;
-        int* const tl_lds = reinterpret_cast<int*>(S.kern + 64);
-        static_assert(KERN2 >= 64 + SPAN / 2, "room for the staged pair lengths");
+        int* const tl_lds = S.tl;
         if (status == 0 && run_pe) {
-            __syncthreads();   // (the KDE's last reads of S.kern)
             int bad = 0;
             for (int i = tid; i < u.n_target; i += NT) {
                 int x = a.target_lens[u.tl_off + i];
@@ -708,11 +821,12 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
         d.lay = unit_layout(nrow, ncol, u.n_target, run_pe, haploid, dmax, d.n_near);
         d.n_items = unit_items(nrow, ncol);
         if (tid == 0) {
-            const unsigned long long off = atomicAdd(&ctr->pool_used, (unsigned long long)d.lay.total);
-            S.flag = off + d.lay.total <= pool_doubles;
-            S.slot_off = (long long)off;
-            if (S.flag) S.status = atomicAdd(&ctr->n_items, d.n_items);
-            else atomicAdd(&ctr->n_deferred, 1);
+            const int sp = g & (n_subpools - 1), q = g & (TQ - 1);
+            const unsigned long long off = atomicAdd(&ctr->pool_used[sp].v, (unsigned long long)d.lay.total);
+            S.flag = off + d.lay.total <= subpool_doubles;
+            S.slot_off = (long long)(sp * subpool_doubles + off);
+            if (S.flag) S.status = q * item_region + atomicAdd(&ctr->n_items[q].v, d.n_items);
+            else atomicAdd(&ctr->n_deferred.v, 1);
         }
         __syncthreads();
         if (!__builtin_amdgcn_readfirstlane(S.flag)) {
@@ -736,12 +850,12 @@ __global__ __launch_bounds__(NT, 3) void grid_prepare_kernel(GridArgs a, int pas
             int* dst = reinterpret_cast<int*>(gobs);
             for (int k = tid; k < (int)(sizeof(Obs) / sizeof(int)); k += NT) dst[k] = src[k];
         }
-        // the step-size row of this period in LDS (the KDE's kernel table is dead by now): every spanning / partial term
-        // of the row and near tables below looks it up, and from global memory each look-up sat in the terms' chain
-        for (int k = tid; k < 37; k += NT) S.kern[k] = M.step[d.period <= 6 ? d.period - 1 : 5][k];
+        // the step-size row of this period in LDS: every spanning / partial term of the row and near tables below looks
+        // it up, and from global memory each look-up sat in the terms' chain
+        for (int k = tid; k < 37; k += NT) S.step[k] = M.step[d.period <= 6 ? d.period - 1 : 5][k];
         __syncthreads();
-        PairCtx C = make_ctx(d, M, &S.obs, S.pdf, a.target_lens);
-        C.step = S.kern;
+        PairCtx C = make_ctx(d, M, &S.obs, a.unit_pdf + (size_t)g * SPAN, a.target_lens);
+        C.step = S.step;
 
         // ---- rows: count of valid h2 per h1 (h1 <= h2), dump offsets; per-row "far" terms ----
         // For h2 >= h_far the spanning and partial terms no longer depend on h2 (S(k|h2) = 0 for every
@@ -888,10 +1002,12 @@ struct RowIn {
 };
 
 __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitDesc* descs, double* pool,
-                                                         const int* item_unit, Best* item_best, GridCounters* ctr) {
+                                                         const int* item_unit, Best* item_best, int item_region,
+                                                         GridCounters* ctr) {
     const int lane = threadIdx.x & 63;
+    int q = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (TQ - 1))), tried = 0;
+    const int region_items = lane < TQ ? ctr->n_items[lane].v : 0;   // lane q: the items of region q
     const double small = a.model->small;
-    const int total = ctr->n_items;
     // the row's 32 roll(h1) values, one buffer per wavefront: written by the wave, read back as LDS broadcasts (the
     // same address in every lane) -- an LDS instruction per value instead of two v_readlane on the VALU, which is
     // what the kernel is short of
@@ -899,10 +1015,17 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
     static_assert(TC == 32, "rowvals is written by lane & 31");
     double* const myrow = rowvals[threadIdx.x >> 6];
     while (true) {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(&ctr->next_item, 1);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= total) break;
+        // (queue q hands out the items of region q one by one; q and tried are wave-uniform, lane 0 takes the ticket)
+        int t = -1;
+        while (tried < TQ) {
+            int k = 0;
+            if (lane == 0) k = atomicAdd(&ctr->next_item[q].v, 1);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k < __builtin_amdgcn_readlane(region_items, q)) { t = q * item_region + k; break; }
+            q = (q + 1) & (TQ - 1);
+            ++tried;
+        }
+        if (t < 0) break;
         const int g = __builtin_amdgcn_readfirstlane(item_unit[t]);
         const UnitDesc d = uniform_desc(descs + g);   // by value, in scalar registers across the stores below
         const SlotLayout L = d.lay;
@@ -1055,7 +1178,7 @@ struct ReduceShared {
     int base[MAXOBS + 1];   // the unit's observed sizes (base part of the axes)
 };
 
-__device__ double block_sum_r(double v, double* red) {
+__device__ __forceinline__ double block_sum_r(double v, double* red) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -1070,9 +1193,10 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
                                                          const Best* item_best, GridCounters* ctr) {
     __shared__ ReduceShared S;
     const int tid = threadIdx.x;
+    TicketState ts = {(int)(blockIdx.x & (TQ - 1)), 0};
     while (true) {
         __syncthreads();
-        if (tid == 0) S.unit = atomicAdd(&ctr->next_reduce, 1);
+        if (tid == 0) S.unit = next_ticket(ctr->next_reduce, ts, a.n_units);
         __syncthreads();
         const int g = __builtin_amdgcn_readfirstlane(S.unit);
         if (g >= a.n_units) break;
@@ -1390,24 +1514,35 @@ size_t grid_slot_doubles_max(int rows_cap, int cols_cap, int nt_max) {
 // One pass over all units: prepare (takes pool room per unit) -> pairs -> reduce, all on stream s.  Units that
 // found the pool full are marked UNIT_DEFERRED in calls[].status and counted in the counter block's
 // n_deferred; the caller runs further passes (pass > 0 touches only those) until none is left.
-// items: item_cap ints (item -> unit), then item_cap arg-max records
+// items: item_cap ints (item -> unit), then item_cap arg-max records; item_cap = grid_item_slots(n_units, ...): TQ
+// regions.  pool_doubles is used as grid_subpools() sub-pools of equal size.
 hipError_t launch_grid_pass(const GridArgs& a, int pass, void* descs, double* pool, size_t pool_doubles, int rows_cap,
                             int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s, int phases) {
-    // phases: bit 0 prepare (with the counter reset), bit 1 pairs, bit 2 reduce -- the caller may launch them one by
-    // one to time each (capi.hip brackets them with HIP events)
+    // phases: bit 0 prepare (with the counter reset), bit 1 pairs, bit 2 reduce, bit 3 the paired-end KDEs (first, and
+    // in pass 0 only: deferred units keep theirs) -- the caller may launch them one by one to time each (capi.hip
+    // brackets them with HIP events)
     if (a.n_units <= 0) return hipSuccess;
     UnitDesc* d = (UnitDesc*)descs;
     GridCounters* ctr = (GridCounters*)counters;
     int* item_unit = (int*)items;
     Best* item_best = (Best*)(item_unit + ((item_cap + 3) & ~(size_t)3));
+    const int item_region = (int)(item_cap / TQ);
+    const int n_sub = grid_subpools(pool_doubles, rows_cap, cols_cap, a.max_target);
+    const unsigned long long sub_doubles = (pool_doubles / n_sub) & ~(unsigned long long)15;   // slots start on 128-byte lines
+    if ((phases & 8) && pass == 0) {
+        hipError_t e = hipMemsetAsync(counters, 0, sizeof(GridCounters), s);
+        if (e != hipSuccess) return e;
+        const int kb = a.n_units < KDE_BLOCKS ? a.n_units : KDE_BLOCKS;
+        grid_kde_kernel<<<kb, NT, 0, s>>>(a, ctr);
+    }
     if (phases & 1) {
         hipError_t e = hipMemsetAsync(counters, 0, sizeof(GridCounters), s);
         if (e != hipSuccess) return e;
-        const int pb = a.n_units < 1536 ? a.n_units : 1536;
-        grid_prepare_kernel<<<pb, NT, 0, s>>>(a, pass, d, pool, (unsigned long long)pool_doubles, rows_cap, cols_cap,
-                                              item_unit, ctr);
+        const int pb = a.n_units < PREP_BLOCKS ? a.n_units : PREP_BLOCKS;
+        grid_prepare_kernel<<<pb, NT, 0, s>>>(a, pass, d, pool, sub_doubles, n_sub, rows_cap, cols_cap, item_unit,
+                                              item_region, ctr);
     }
-    if (phases & 2) grid_pairs_kernel<<<2048, 256, 0, s>>>(a, d, pool, item_unit, item_best, ctr);
+    if (phases & 2) grid_pairs_kernel<<<2048, 256, 0, s>>>(a, d, pool, item_unit, item_best, item_region, ctr);
     if (phases & 4) {
         const int rb = a.n_units < 2048 ? a.n_units : 2048;
         if (a.joint != nullptr) grid_reduce_kernel<true><<<rb, NR, 0, s>>>(a, d, pool, item_best, ctr);
@@ -1417,5 +1552,22 @@ hipError_t launch_grid_pass(const GridArgs& a, int pass, void* descs, double* po
 }
 
 int grid_deferred_offset() { return (int)offsetof(GridCounters, n_deferred); }
+
+// Sub-pools the scratch pool is used as: as many (a power of two, at most TQ) as still leave room for the largest slot
+// in each -- a unit is never too big for its sub-pool, so every pass settles at least one unit per sub-pool.
+int grid_subpools(size_t pool_doubles, int rows_cap, int cols_cap, int nt_max) {
+    const size_t slot = grid_slot_doubles_max(rows_cap, cols_cap, nt_max) + 16;
+    int n = TQ;
+    while (n > 1 && pool_doubles / n < slot) n >>= 1;
+    return n;
+}
+
+// Entries of the work-item list for n_units units: TQ regions, each with room for the units of its queue
+size_t grid_item_slots(int n_units, int rows_cap, int cols_cap) {
+    return (size_t)TQ * (((size_t)n_units + TQ - 1) / TQ) * grid_items_cap(rows_cap, cols_cap);
+}
+
+// Units a sub-pool can be asked to hold at most (the units of one residue class mod the sub-pool count)
+size_t grid_units_per_subpool(int n_units, int n_sub) { return ((size_t)n_units + n_sub - 1) / n_sub; }
 
 }  // namespace tredgpu

@@ -821,6 +821,42 @@ constexpr int SW_LEVELS = 32;
 constexpr int UNIT_BINS = 3 * SW_LEVELS;   // bins one unit can feed
 __device__ __forceinline__ int class_slot(int cls) { return cls == 1 ? 0 : (cls == 3 ? 1 : 2); }
 
+// The read's 6-mers present in the two strands' template bitmaps (windows with an N count as present).  `rec` = the
+// read's packed record, bm = the two 128-word bitmaps (LDS).  One word of 16 bases per trip: the
+// window ending at base j is one bit-field extract of the word (an alignbit with the previous word for j < 5), its
+// two presence bits are collected into one mask per strand, the N rule and the first-five / past-the-end positions
+// are applied to the masks once per word -- ~7 VALU instructions per base where the base-by-base loop (shift register,
+// run length since the last N, two compares) took ~25: 0.35 -> 0.25 ms per 30 000 units (staging the records in LDS
+// and 64-bit entries holding both strands' words were tried on top: no gain).
+__device__ __forceinline__ void kmer_counts(const uint32_t* rec, int L, const uint32_t* bm, int& cnt0, int& cnt1) {
+    const int nb = (L + 15) >> 4;
+    uint32_t prev = 0, mprev = 0;
+    cnt0 = cnt1 = 0;
+    for (int wi = 0; wi < nb; ++wi) {
+        const uint32_t w = rec[wi];
+        const uint32_t m = (rec[nb + (wi >> 1)] >> ((wi & 1) * 16)) & 0xffffu;
+        uint32_t b0 = 0, b1 = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            // bases j-5 .. j of this word, base j-5 in the low bits (bam_parser's 6-mer index)
+            const uint32_t win = (j >= 5 ? w >> (2 * (j - 5)) : __builtin_amdgcn_alignbit(w, prev, 32 - 2 * (5 - j))) & 0xfffu;
+            b0 |= ((bm[win >> 5] >> (win & 31)) & 1u) << j;
+            b1 |= ((bm[128 + (win >> 5)] >> (win & 31)) & 1u) << j;
+        }
+        // N flags of bases -5 .. 15 of this word at bits 0 .. 20; window j holds an N when one of bits j .. j+5 is set
+        const uint32_t mm = m << 5 | mprev >> 11;
+        const uint32_t hn = mm | mm >> 1 | mm >> 2 | mm >> 3 | mm >> 4 | mm >> 5;
+        // counted: read positions 5 .. L-1
+        const int left = L - wi * 16;
+        uint32_t cm = left >= 16 ? 0xffffu : (1u << left) - 1u;
+        if (wi == 0) cm &= ~0x1fu;
+        cnt0 += __builtin_popcount((b0 | hn) & cm);
+        cnt1 += __builtin_popcount((b1 | hn) & cm);
+        prev = w;
+        mprev = m;
+    }
+}
+
 __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_class, int32_t* unit_cnt, int32_t* bin_total) {
     const int g = blockIdx.x;
     if (g >= a.n_units) return;
@@ -845,24 +881,8 @@ __global__ __launch_bounds__(64) void read_class_kernel(SwArgs a, uint8_t* read_
         int level = SW_LEVELS - 1;
         const int L = a.read_len[rd];
         if (filt && L <= a.max_rows) {   // over-long reads go to the SW kernel, which flags them
-            const int64_t off = a.read_off[rd];
-            const int nb = (L + 15) >> 4;
-            const uint32_t* bm0 = bm[0];
-            const uint32_t* bm1 = bm[1];
-            int cnt0 = 0, cnt1 = 0, since_n = 0;
-            uint32_t win = 0, w = 0, m = 0;
-            for (int i = 0; i < L; ++i) {
-                if ((i & 15) == 0) w = a.packed[off + (i >> 4)];
-                if ((i & 31) == 0) m = a.packed[off + nb + (i >> 5)];
-                const bool isn = (m >> (i & 31)) & 1u;
-                win = (win >> 2) | (((w >> ((i & 15) * 2)) & 3u) << 10);   // base i-5 ends up in the low bits
-                since_n = isn ? 0 : since_n + 1;
-                if (i >= 5) {
-                    const bool has_n = since_n < 6;
-                    cnt0 += has_n || ((bm0[win >> 5] >> (win & 31)) & 1u);
-                    cnt1 += has_n || ((bm1[win >> 5] >> (win & 31)) & 1u);
-                }
-            }
+            int cnt0, cnt1;
+            kmer_counts(a.packed + a.read_off[rd], L, &bm[0][0], cnt0, cnt1);
             cls = (cnt0 >= thr ? 1 : 0) | (cnt1 >= thr ? 2 : 0);
             level = min(SW_LEVELS - 1, max(cls & 1 ? cnt0 : 0, cls & 2 ? cnt1 : 0) / 6);
         }

@@ -105,6 +105,9 @@ struct GridArgs {
     double* joint_total;        // sum over the unit's distinct pairs
     double* kde_pdf;      // tredgpu_pe_kde only: [n_units][1000] output
     int32_t* kde_status;  // tredgpu_pe_kde only: [n_units]
+    double* unit_pdf;      // grid passes: [n_units][1000] KDEs of the units whose paired-end term is used (grid_kde_kernel)
+    int32_t* unit_kde_rc;  // grid passes: [n_units] outcome of the unit's KDE (0, -2, -6)
+    int32_t max_target;    // grid passes: largest n_target of the batch (bounds a unit's slot, grid_subpools)
 };
 constexpr int GRID_MAX_ROWS = 1024;  // |h1range| / |h2range| the grid kernels accept (status -5 beyond)
 constexpr int GRID_MAX_COLS = 1024;
@@ -120,8 +123,11 @@ int grid_deferred_offset();                          // byte offset of the defer
 size_t grid_slot_doubles_max(int rows_cap, int cols_cap, int nt_max);
 size_t grid_items_cap(int rows_cap, int cols_cap);   // work items one unit can make at most
 size_t grid_item_bytes();                            // bytes per work item in the items buffer
+size_t grid_item_slots(int n_units, int rows_cap, int cols_cap);   // entries of the work-item list (16 regions, one per ticket queue)
+int grid_subpools(size_t pool_doubles, int rows_cap, int cols_cap, int nt_max);   // sub-pools the scratch pool is used as
+size_t grid_units_per_subpool(int n_units, int n_sub);
 // One pass over all units (prepare -> pairs -> reduce); see grid.hip
 hipError_t launch_grid_pass(const GridArgs& a, int pass, void* descs, double* pool, size_t pool_doubles, int rows_cap,
-                            int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s, int phases = 7);
+                            int cols_cap, void* items, size_t item_cap, void* counters, hipStream_t s, int phases = 15);
 
 }  // namespace tredgpu
