@@ -31,18 +31,10 @@ namespace tredgpu {
 namespace {
 
 constexpr int NT = 128;   // threads per workgroup (one unit at a time)
-#ifndef KDE_WAVES
-#define KDE_WAVES 3
-#endif
-#ifndef PREP_WAVES
-#define PREP_WAVES 4
-#endif
-#ifndef PREP_BLOCKS
-#define PREP_BLOCKS 2048
-#endif
-#ifndef KDE_BLOCKS
-#define KDE_BLOCKS 2048
-#endif
+// waves per SIMD the two per-unit front kernels are compiled for, and the workgroups their launches keep resident
+// (256 CUs x what registers and LDS admit per CU; further units come through the ticket queues)
+constexpr int KDE_WAVES = 3, KDE_BLOCKS = 1536;     // 160 VGPRs: the convolution's window registers
+constexpr int PREP_WAVES = 4, PREP_BLOCKS = 2048;   // 128 VGPRs (3 waves: 1.16 ms per 30 000 units, 4 waves: 1.02)
 constexpr int XPER = (TREDGPU_SPAN + NT - 1) / NT;  // KDE x-values per thread
 constexpr int SPAN = TREDGPU_SPAN;
 constexpr int MAXOBS = 256;  // distinct FULL / PREF sizes per unit
@@ -114,7 +106,7 @@ struct PairCtx {
     const ModelConst* M;
     const double* step;  // step-size row of this period
     const Obs* obs;
-    const double* pdf;   // the unit's KDE (global memory, written by grid_kde_kernel) when run_pe
+    const double* pdf;   // the unit's KDE (LDS copy of grid_kde_kernel's output) when run_pe
     const int32_t* tl;   // target lens of the unit
     int n_target;
     int period, readlen, t1, t2, mp_eff, ref_len, minpe, n_rept;
@@ -202,12 +194,16 @@ __device__ void eval_reads(const PairCtx& C, int h1, int h2, double& ml1, double
 
 // repeat-only term (models.py:209-221); a function of dsum = max(h1-L,1) + max(h2-L,1) only.
 // scipy poisson.pmf = exp(xlogy(k,mu) - gammaln(k+1) - mu)
-__device__ double rept_term(const PairCtx& C, int dsum) {
+// (both logarithms through pos_log: its argument range -- positive, finite, normal -- is checked for mu and holds for
+//  a probability in [e^-100, 1]; the device library's log cost half of the table's time, which was a quarter of
+//  grid_prepare_kernel's)
+__device__ __forceinline__ double rept_term(const PairCtx& C, int dsum) {
     const double mu = dsum * C.half_depth / C.readlen;
-    const double xl = C.n_rept == 0 ? 0.0 : C.n_rept * log(mu);
+    double xl = 0.0;
+    if (C.n_rept != 0) xl = C.n_rept * ((mu >= 2.3e-308 && mu <= 1.7e308) ? pos_log(mu) : log(mu));
     double prob = exp(xl - C.lgam_rept - mu);
     if (!(prob > C.really_small)) prob = C.really_small;
-    return log(prob);
+    return pos_log(prob);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -539,6 +535,7 @@ struct PrepShared {
     };
     double step[40];                       // the step-size row of the unit's period
     int tl[SPAN];                          // the spanning pairs' lengths as indices into the rolled pdf
+    double pdf[SPAN];                      // the unit's KDE (copied from grid_kde_kernel's output when the term is used)
     long long slot_off;
     int flag, status, unit;
 };
@@ -728,6 +725,8 @@ __global__ __launch_bounds__(NT, PREP_WAVES) void grid_prepare_kernel(GridArgs a
         const bool tl_staged = u.n_target <= SPAN;
         int* const tl_lds = S.tl;
         if (status == 0 && run_pe) {
+            // (a gather from LDS per roll-table entry instead of one from global memory: 1.03 -> 0.97 ms per 30 000 units)
+            for (int i = tid; i < SPAN; i += NT) S.pdf[i] = a.unit_pdf[(size_t)g * SPAN + i];
             int bad = 0;
             for (int i = tid; i < u.n_target; i += NT) {
                 int x = a.target_lens[u.tl_off + i];
@@ -854,7 +853,7 @@ __global__ __launch_bounds__(NT, PREP_WAVES) void grid_prepare_kernel(GridArgs a
         // it up, and from global memory each look-up sat in the terms' chain
         for (int k = tid; k < 37; k += NT) S.step[k] = M.step[d.period <= 6 ? d.period - 1 : 5][k];
         __syncthreads();
-        PairCtx C = make_ctx(d, M, &S.obs, a.unit_pdf + (size_t)g * SPAN, a.target_lens);
+        PairCtx C = make_ctx(d, M, &S.obs, S.pdf, a.target_lens);
         C.step = S.step;
 
         // ---- rows: count of valid h2 per h1 (h1 <= h2), dump offsets; per-row "far" terms ----
