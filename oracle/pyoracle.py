@@ -115,8 +115,12 @@ def sw_pairs(reads, refs, pair_read, pair_ref, scoring=(1, 5, 7, 2), threads=0):
     return _pairs(lib().oracle_sw_pairs, reads, refs, pair_read, pair_ref, scoring, threads)
 
 
+REF_CRASHED = -9998   # oracle/ref_driver.c: the reference's ssw_align faulted on this pair (its CIGAR pass, ssw.c:549-633)
+
+
 def ref_sw_pairs(reads, refs, pair_read, pair_ref, scoring=(1, 5, 7, 2), threads=0):
-    """Same, computed by the reference's compiled ssw.c (ssw_wrap.py:177-227 call pattern)."""
+    """Same, computed by the reference's compiled ssw.c (ssw_wrap.py:177-227 call pattern).  A pair the reference
+    faults on comes back as five REF_CRASHED."""
     return _pairs(ref().ref_sw_pairs, reads, refs, pair_read, pair_ref, scoring, threads)
 
 
@@ -156,7 +160,7 @@ def classify(reads, read_locus, locus_set, clip=False, scoring=(1, 5, 7, 2), thr
 
 
 def ref_classify(reads, read_locus, locus_set, clip=False, scoring=(1, 5, 7, 2), threads=0):
-    """Same, every alignment computed by the reference's compiled ssw.c."""
+    """Same, every alignment computed by the reference's compiled ssw.c (tag -1: the reference faulted on the read)."""
     return _classify(ref().ref_classify_batch, reads, read_locus, locus_set, clip, scoring, threads)
 
 

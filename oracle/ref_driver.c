@@ -11,7 +11,17 @@
  *
  * Used to (1) generate/verify golden SW vectors, (2) time the reference's CPU path natively as
  * bench.py's cpu_baseline kind="reference".
+ *
+ * The reference's CIGAR pass can fault: banded_sw (/root/reference/src/ssw.c:549-633) doubles its band until the banded
+ * score reaches the striped one (`width_d * readLen * 3` in 32-bit ints, :580); with cheap gaps and a periodic 300-base read against a
+ * 336-base template it never gets there and runs off its buffers (found by tools/fuzz_parity.py, seed 20271201 round
+ * 334: scoring 1/3/2/2, a (CTG)n read on the DM1 ladder).  The product computes no CIGAR.  So that a campaign
+ * survives such an input, every ssw_align call runs under a SIGSEGV / SIGBUS guard: a faulting call is abandoned
+ * (its allocations leak) and reported as REF_CRASHED -- per pair in ref_sw_pairs, as tag -1 for the read in
+ * ref_classify_batch -- and the callers leave those out of the comparison and count them.
  */
+#include <setjmp.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,11 +36,47 @@ static void make_mat(int match, int mismatch, int8_t mat[25]) {
             mat[a * 5 + b] = (int8_t)((a == 4 || b == 4) ? 0 : (a == b ? match : -mismatch));
 }
 
+#define REF_CRASHED (-9998)
+static __thread sigjmp_buf guard_jmp;
+static __thread volatile sig_atomic_t guard_armed;
+static struct sigaction guard_old[2];
+
+static void guard_handler(int sig) {
+    if (guard_armed) siglongjmp(guard_jmp, 1);
+    /* not ours: hand the signal back to whoever had it (Python's faulthandler, or the default action) */
+    sigaction(sig, &guard_old[sig == SIGSEGV ? 0 : 1], NULL);
+    raise(sig);
+}
+
+static void guard_install(void) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = guard_handler;
+    sigemptyset(&sa.sa_mask);
+    sa.sa_flags = SA_NODEFER;
+    sigaction(SIGSEGV, &sa, &guard_old[0]);
+    sigaction(SIGBUS, &sa, &guard_old[1]);
+}
+
+static void guard_remove(void) {
+    sigaction(SIGSEGV, &guard_old[0], NULL);
+    sigaction(SIGBUS, &guard_old[1], NULL);
+}
+
 static void ref_align_one(const int8_t* read, int L, const int8_t* ref, int T, const int8_t* mat,
                           int go, int ge, int32_t out[5]) {
     s_profile* p = ssw_init(read, L, mat, 5, 2);
     int mask_len = L > 30 ? L / 2 : 15;
-    s_align* a = ssw_align(p, ref, T, (uint8_t)go, (uint8_t)ge, 1, 0, 0, mask_len);
+    s_align* volatile a = NULL;
+    if (sigsetjmp(guard_jmp, 1) == 0) {
+        guard_armed = 1;
+        a = ssw_align(p, ref, T, (uint8_t)go, (uint8_t)ge, 1, 0, 0, mask_len);
+        guard_armed = 0;
+    } else {   /* the reference faulted inside ssw_align */
+        guard_armed = 0;
+        out[0] = out[1] = out[2] = out[3] = out[4] = REF_CRASHED;
+        return;
+    }
     if (a) {
         out[0] = a->score1;
         out[1] = a->ref_begin1;
@@ -50,6 +96,7 @@ int ref_sw_pairs(const int8_t* reads, const int64_t* read_off, const int8_t* ref
                  int n_threads) {
     int8_t mat[25];
     make_mat(match, mismatch, mat);
+    guard_install();
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel for schedule(dynamic, 64)
@@ -60,6 +107,7 @@ int ref_sw_pairs(const int8_t* reads, const int64_t* read_off, const int8_t* ref
                       refs + ref_off[t], (int)(ref_off[t + 1] - ref_off[t]), mat, go, ge,
                       out + 5 * k);
     }
+    guard_remove();
     return 0;
 }
 
@@ -83,6 +131,7 @@ int ref_classify_batch(const int8_t* reads, const int64_t* read_off, const int32
                        int32_t* out, int n_threads) {
     int8_t mat[25];
     make_mat(match, mismatch, mat);
+    guard_install();
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel for schedule(dynamic, 4)
@@ -93,12 +142,13 @@ int ref_classify_batch(const int8_t* reads, const int64_t* read_off, const int32
         const int8_t* read = reads + read_off[r];
         int L = (int)(read_off[r + 1] - read_off[r]);
         int period = locus_period[g];
-        int best_score = -1, best_units = 0, best_tag = TAG_NONE;
+        int best_score = -1, best_units = 0, best_tag = TAG_NONE, crashed = 0;
         for (int k = 0; k < 2 * read_maxunits[r]; k++) {
             int units = k / 2 + 1;
             int T = (int)(off[k + 1] - off[k]);
             int32_t al[5];
             ref_align_one(read, L, tmpl_codes + off[k], T, mat, go, ge, al);
+            if (al[0] == REF_CRASHED) { crashed = 1; break; }
             int min_len = (L < T ? L : T) / 2;
             int min_score = min_len > 30 ? min_len : 30;
             if (!(al[0] >= min_score && al[4] - al[3] + 1 >= min_len)) continue;
@@ -113,9 +163,10 @@ int ref_classify_batch(const int8_t* reads, const int64_t* read_off, const int32
                 best_score = al[0]; best_units = units; best_tag = tag;
             }
         }
-        out[3 * r] = best_tag;
-        out[3 * r + 1] = best_tag == TAG_NONE ? 0 : best_units;
-        out[3 * r + 2] = best_tag == TAG_NONE ? 0 : best_score;
+        out[3 * r] = crashed ? -1 : best_tag;
+        out[3 * r + 1] = crashed || best_tag == TAG_NONE ? 0 : best_units;
+        out[3 * r + 2] = crashed || best_tag == TAG_NONE ? 0 : best_score;
     }
+    guard_remove();
     return 0;
 }

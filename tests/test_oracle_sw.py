@@ -78,6 +78,30 @@ def test_oracle_matches_compiled_reference_random():
         assert np.array_equal(a, b), scoring
 
 
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref (compiled reference) not present")
+def test_reference_fault_in_its_cigar_pass_is_reported_not_fatal():
+    """tools/fuzz_parity.py seed 20271201, round 334: a 300-base (CTG)n read with a few errors against the DM1 ladder under
+    scoring 1/3/2/2 makes the reference's banded_sw (ssw.c:549-633) run off its buffers.  The driver reports the pair
+    as REF_CRASHED and the read as tag -1, the neighbours are unaffected, and the restatement -- which has no CIGAR
+    pass -- still answers."""
+    read = ("TGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCCGCTGCTGCT"
+            "GCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTG"
+            "CTGCTGCCGGTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTGCTNCTGCTGCTGCTGCTCCTGCTGCTGCTGCGGG")
+    lad = ("GCCCGGCCTGGCCACCGC", "CTG", "CGGGGGCCCCGAGCCGCC", 100)
+    ls = po.LocusSet([lad])
+    other = "GCCCGGCCTGGCCACCGC" + "CTG" * 20 + "CGGGGGCCCCGAGCCGCC"
+    cls = po.ref_classify([other, read, other], np.zeros(3, np.int32), ls, scoring=(1, 3, 2, 2), threads=1)
+    mine = po.classify([other, read, other], np.zeros(3, np.int32), ls, scoring=(1, 3, 2, 2), threads=1)
+    if cls[1, 0] >= 0:
+        pytest.skip("this build of the reference survives the input")
+    assert cls[1, 0] == -1 and np.array_equal(cls[[0, 2]], mine[[0, 2]]) and mine[1, 0] > 0
+    pairs = po.ref_sw_pairs([read, other], ls.templates, [0] * len(ls.templates) + [1], list(range(len(ls.templates))) + [38],
+                            scoring=(1, 3, 2, 2), threads=1)
+    assert (pairs[:-1, 0] == po.REF_CRASHED).any() and pairs[-1, 0] == 96
+    # under the default scoring the same read goes through
+    assert po.ref_classify([read], np.zeros(1, np.int32), ls, threads=1)[0, 0] >= 0
+
+
 def test_oracle_classification_matches_reference_golden():
     """(tag, h) per read and the FULL/PREF/REPT histograms of bam_parser._parseReadSW + tally_counts."""
     cases = json.load(open(os.path.join(GOLD, "classify.json")))["cases"]

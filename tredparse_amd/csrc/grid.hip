@@ -5,10 +5,13 @@
 //   evaluate_partial :200-207, evaluate_rept :209-221, evaluate :223-302, calc_CI :319-340,
 //   calc_PP :342-368, safe_log :418-423, PEMaxLikModel :426-473 (incl. scipy gaussian_kde).
 //
-// Three kernels per pass over the batch's units; every unit takes exactly the scratch it needs from one pool
-// (atomic bump allocation; a unit that finds the pool full is deferred to a further pass):
-//   grid_prepare_kernel  one workgroup per unit: sparse observation lists, grid axes, KDE (only when the
-//                        paired-end term is used), per-unit tables, per-row "far" terms -> UnitDesc + scratch
+// Four kernels per pass over the batch's units; every unit takes exactly the scratch it needs from one pool
+// (atomic bump allocation in 16 sub-pools; a unit that finds its sub-pool full is deferred to a further pass):
+//   grid_kde_kernel      one workgroup per unit that has a paired-end model: is the term used (from the histograms),
+//                        then the KDE -- an fp64 convolution -- or, when it is not, only the singularity check
+//                        (first pass only)
+//   grid_prepare_kernel  one workgroup per unit: sparse observation lists, grid axes, per-unit tables, per-row
+//                        "far" terms -> UnitDesc + scratch
 //   grid_pairs_kernel    one wavefront per work item = (unit, 64 columns, <= 128 rows), lane = column: the
 //                        log-likelihood of each pair -- a short sum over the unit's sparse observations, so only
 //                        the entries of the reference's dense 1000-vectors that are actually read are ever
@@ -16,7 +19,10 @@
 //   grid_reduce_kernel   one workgroup per unit: arg-max with the reference's tie-break over the items, then one
 //                        pass over the grid: exp(ml - max), PP sums, marginals, CI
 // (splitting keeps every kernel's register footprint at what its phase needs; the single-kernel version of
-// this path needed 168 VGPRs plus 400 B of spills per lane and ran at 15 ms against 9 ms per 30 000 units)
+// this path needed 168 VGPRs plus 400 B of spills per lane and ran at 15 ms against 9 ms per 30 000 units).
+// Units and work items are handed out dynamically through ticket queues (GridCounters).  Device helpers that more than
+// one kernel uses are __forceinline__: left to the compiler, kde_block and the block sums became real calls -- LDS
+// through flat addresses, an ABI spill frame in the caller -- and the KDE ran at a third of its present speed.
 //
 // Arithmetic mirrors the reference's operation order (compiled with -ffp-contract=off); the only
 // intended differences are libm-vs-ocml last-bit effects in log/exp, the paired-end product-log (pairs kernel) and

@@ -838,10 +838,12 @@ __device__ __forceinline__ void kmer_counts(const uint32_t* rec, int L, const ui
         uint32_t b0 = 0, b1 = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            // bases j-5 .. j of this word, base j-5 in the low bits (bam_parser's 6-mer index)
-            const uint32_t win = (j >= 5 ? w >> (2 * (j - 5)) : __builtin_amdgcn_alignbit(w, prev, 32 - 2 * (5 - j))) & 0xfffu;
-            b0 |= ((bm[win >> 5] >> (win & 31)) & 1u) << j;
-            b1 |= ((bm[128 + (win >> 5)] >> (win & 31)) & 1u) << j;
+            // bases j-5 .. j of this word, base j-5 in the low bits: the 6-mer's index is the low 12 bits of t (bitmap
+            // word = bits 5 .. 11, bit = bits 0 .. 4 -- v_bfe_u32 takes its offset from the low five bits by itself)
+            const uint32_t t = j > 5 ? w >> (2 * (j - 5)) : (j == 5 ? w : __builtin_amdgcn_alignbit(w, prev, 32 - 2 * (5 - j)));
+            const uint32_t at = __builtin_amdgcn_ubfe(t, 5, 7);
+            b0 = (__builtin_amdgcn_ubfe(bm[at], t, 1) << j) | b0;
+            b1 = (__builtin_amdgcn_ubfe(bm[128 + at], t, 1) << j) | b1;
         }
         // N flags of bases -5 .. 15 of this word at bits 0 .. 20; window j holds an N when one of bits j .. j+5 is set
         const uint32_t mm = m << 5 | mprev >> 11;
