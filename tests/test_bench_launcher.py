@@ -34,6 +34,20 @@ def test_no_sweep_runs_only_the_requested_rank_count():
     assert len(rec["scaling_sweep"][0]["ranks"]) == 3
 
 
+def test_eight_ranks_of_a_thousand_samples_each_configs3_shape():
+    """BASELINE configs[3] (8 000 samples x 30 loci over 8 GPUs) as the launcher would run it: eight rank processes with
+    1 000 samples each, weak scaling, the whole-job value = all ranks' units over the slowest rank's time."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--samples", "1000", "--steps", "1",
+                          "--no-cpu-baseline", "--gpus", "8", "--no-sweep"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 8 and rec["stub"] is True
+    ranks = rec["scaling_sweep"][0]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and all(r["units"] == 30000 for r in ranks)
+    # stub rank r takes 0.05 * (r + 1) s per step: 240 000 units / 0.4 s
+    assert rec["value"] == 600000.0
+
+
 def test_sweep_counts():
     sys.path.insert(0, ROOT)
     import bench
