@@ -277,6 +277,33 @@ int tredgpu_get_timing(tredgpu_ctx* ctx, int which, int64_t* launches, double* t
  */
 int tredgpu_get_sw_counters(tredgpu_ctx* ctx, uint64_t out[8]);
 
+/* ---- (4) BGZF block decoding for the read-selection front end --------------------------------------------------- */
+/*
+ * Raw DEFLATE (RFC 1951) decoding of many independent blocks of at most 64 KiB each in one launch: what htslib's
+ * bgzf_read -> zlib inflate does block by block under the reference's pysam fetch / pileup calls
+ * (tredparse/bam_parser.py:184-257, 316-369) -- two thirds of the host time of the from-BAM path.  The caller (the
+ * host BAM layer, include/tredbam.h: tredbam_plan / tredbam_preload) strips the gzip framing, lays the payloads out in
+ * the inflater's pinned staging buffer and checks CRC-32 / ISIZE on what comes back; this side only turns payloads
+ * into bytes.  One inflater = one HIP stream + its staging; use one per host thread.  Waiting for a call sleeps
+ * (blocking event), it does not spin: the host threads that wait are the ones whose cores the path is short of.
+ *
+ *   tredgpu_inflater_reserve  room for `comp_bytes` of payloads, `out_bytes` of output and n_blocks blocks; returns
+ *                             the pinned host buffers: comp_host (fill), out_host (read after the call),
+ *                             comp_off_host[n_blocks+1] / out_off_host[n_blocks+1] (fill: byte offsets into the two
+ *                             buffers; every payload starts on a 4-byte boundary; out sizes <= 65536).  The pointers
+ *                             stay valid until the next reserve that has to grow, or destroy.
+ *   tredgpu_inflate_blocks    copies in, decodes, copies out, waits.  status[k]: 0, -1 invalid stream (or it runs
+ *                             past its payload), -2 the stream ends before out_off[k+1]-out_off[k] bytes.  Returns
+ *                             the number of blocks with a non-zero status, or <0.
+ */
+typedef struct tredgpu_inflater tredgpu_inflater;
+int tredgpu_inflater_create(int device_id, tredgpu_inflater** out);
+void tredgpu_inflater_destroy(tredgpu_inflater* inf);
+const char* tredgpu_inflater_last_error(const tredgpu_inflater* inf);
+int tredgpu_inflater_reserve(tredgpu_inflater* inf, int64_t comp_bytes, int64_t out_bytes, int32_t n_blocks,
+                             uint8_t** comp_host, uint8_t** out_host, int64_t** comp_off_host, int64_t** out_off_host);
+int tredgpu_inflate_blocks(tredgpu_inflater* inf, int32_t n_blocks, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,132 @@
+"""GPU parity: the batch DEFLATE decoder (tredgpu_inflate_blocks) against zlib, byte for byte -- stored, fixed and
+dynamic blocks, every compression level, several deflate blocks per stream, the repository's BAM fixtures block by
+block, empty streams -- and its status codes on damaged streams."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from tredparse_amd import _lib
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _raw(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    if not flush_every:
+        return c.compress(data) + c.flush()
+    out = b""
+    for i in range(0, len(data), flush_every):
+        out += c.compress(data[i:i + flush_every]) + c.flush(zlib.Z_FULL_FLUSH)      # several deflate blocks
+    return out + c.flush()
+
+
+def _inflate(inf, payloads, sizes):
+    n = len(payloads)
+    offs = np.zeros(n + 1, np.int64)
+    for k, p in enumerate(payloads):
+        offs[k + 1] = (offs[k] + len(p) + 3) & ~3
+    comp, out, coff, ooff = inf.reserve(int(offs[-1]), int(sum(sizes)), n)
+    comp[:] = 0
+    for k, p in enumerate(payloads):
+        comp[offs[k]:offs[k] + len(p)] = np.frombuffer(p, np.uint8)
+    # (the decoder takes a payload's end from the next payload's start: ends are rounded up to the 4-byte grid, and a
+    #  stream that needs bytes beyond its own last one is caught by zlib-style checks on the host side, CRC included)
+    coff[:] = offs
+    ooff[0] = 0
+    ooff[1:] = np.cumsum(sizes)
+    status = inf.run(n)
+    return status, [bytes(out[ooff[k]:ooff[k + 1]]) for k in range(n)]
+
+
+@pytest.fixture(scope="module")
+def inf():
+    f = _lib.Inflater(0)
+    yield f
+    f.close()
+
+
+def _bam_like(rng, n):
+    rec = bytearray()
+    while len(rec) < n:
+        name = b"read%07d" % int(rng.integers(10 ** 7))
+        seq = bytes(rng.integers(0, 256, 75, dtype=np.uint8))
+        qual = bytes(rng.choice(np.array([2, 11, 25, 37], np.uint8), 150))
+        rec += struct.pack("<iiiIIiii", 300, 3, int(rng.integers(1 << 27)), 0x12345678, 0x0990000, 150, 3, 0) + name + b"\0" + seq + qual
+    return bytes(rec[:n])
+
+
+def test_random_streams_match_zlib(inf):
+    rng = np.random.default_rng(11)
+    datas, payloads = [], []
+    for k in range(300):
+        n = int(rng.choice([0, 1, 2, 100, 4000, 30000, 65280, 65536]))
+        kind = k % 5
+        if kind == 0:
+            d = bytes(rng.integers(0, 256, n, dtype=np.uint8))                      # incompressible
+        elif kind == 1:
+            d = bytes(rng.integers(0, 4, n, dtype=np.uint8))                        # few symbols, long codes elsewhere
+        elif kind == 2:
+            d = (b"CAG" * (n // 3 + 1))[:n]                                         # overlapping matches, distance 3
+        elif kind == 3:
+            d = _bam_like(rng, n)
+        else:
+            d = bytes(np.repeat(rng.integers(0, 256, max(n // 300, 1), dtype=np.uint8), 300)[:n])   # runs: distance 1
+        level = int(rng.choice([0, 1, 4, 6, 9]))
+        strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE][int(rng.integers(4))]
+        flush = int(rng.choice([0, 0, 5000]))
+        datas.append(d)
+        payloads.append(_raw(d, level, strategy, flush))
+    status, got = _inflate(inf, payloads, [len(d) for d in datas])
+    assert (status == 0).all(), np.nonzero(status)[0][:10]
+    for k, d in enumerate(datas):
+        assert got[k] == d, k
+
+
+def _bgzf_blocks(path):
+    raw = open(path, "rb").read()
+    pos, blocks = 0, []
+    while pos < len(raw):
+        xlen = struct.unpack_from("<H", raw, pos + 10)[0]
+        bsize = struct.unpack_from("<H", raw, pos + 16)[0] + 1          # (the fixtures carry BC as their first extra field)
+        payload = raw[pos + 12 + xlen:pos + bsize - 8]
+        crc, isize = struct.unpack_from("<II", raw, pos + bsize - 8)
+        blocks.append((payload, crc, isize))
+        pos += bsize
+    return blocks
+
+
+@pytest.mark.parametrize("name", ["t001.bam", "t002.bam", "synf.bam"])
+def test_every_block_of_the_bam_fixtures(inf, name):
+    blocks = _bgzf_blocks(os.path.join(GOLD, "bam", name))
+    status, got = _inflate(inf, [b[0] for b in blocks], [b[2] for b in blocks])
+    assert (status == 0).all()
+    for (payload, crc, isize), data in zip(blocks, got):
+        assert len(data) == isize and zlib.crc32(data) == crc
+        assert data == zlib.decompress(payload, -15)
+
+
+def test_damaged_streams_are_reported_per_block(inf):
+    rng = np.random.default_rng(3)
+    good = _bam_like(rng, 20000)
+    p = _raw(good)
+    cases = [p, p[:len(p) // 2], b"\x07" + p[1:], p, bytes(8)]     # ok, truncated, reserved block type, wrong size, stored with bad LEN
+    sizes = [len(good), len(good), len(good), len(good) + 5, 10]
+    status, got = _inflate(inf, cases, sizes)
+    assert status[0] == 0 and got[0] == good
+    assert status[1] != 0 and status[2] == -1 and status[3] == -2 and status[4] == -1
+    # a second call on the same inflater is clean again
+    status, got = _inflate(inf, [p], [len(good)])
+    assert status[0] == 0 and got[0] == good
+
+
+def test_many_blocks_in_one_call(inf):
+    rng = np.random.default_rng(5)
+    datas = [_bam_like(rng, 65280) for _ in range(40)]
+    payloads = [_raw(d) for d in datas] * 25                      # 1 000 blocks, 65 MB of output
+    status, got = _inflate(inf, payloads, [65280] * len(payloads))
+    assert (status == 0).all()
+    assert all(got[k] == datas[k % 40] for k in range(0, len(payloads), 37))

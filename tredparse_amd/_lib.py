@@ -56,7 +56,9 @@ EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_s
            "tredgpu_version", "tredgpu_set_ladders", "tredgpu_set_model", "tredgpu_pack_reads",
            "tredgpu_sw_classify", "tredgpu_tally", "tredgpu_likelihood_grid", "tredgpu_likelihood_grid_joint",
            "tredgpu_genotype_batch",
-           "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing", "tredgpu_get_sw_counters")
+           "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing", "tredgpu_get_sw_counters",
+           "tredgpu_inflater_create", "tredgpu_inflater_destroy", "tredgpu_inflater_last_error",
+           "tredgpu_inflater_reserve", "tredgpu_inflate_blocks")
 
 _lib = None
 
@@ -99,6 +101,13 @@ def load():
     lib.tredgpu_reset_timing.argtypes = [vp]
     lib.tredgpu_get_timing.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
     lib.tredgpu_get_sw_counters.argtypes = [vp, vp]
+    lib.tredgpu_inflater_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.tredgpu_inflater_destroy.argtypes = [vp]
+    lib.tredgpu_inflater_destroy.restype = None
+    lib.tredgpu_inflater_last_error.argtypes = [vp]
+    lib.tredgpu_inflater_last_error.restype = C.c_char_p
+    lib.tredgpu_inflater_reserve.argtypes = [vp, i64, i64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.tredgpu_inflate_blocks.argtypes = [vp, i32, vp]
     _lib = lib
     return lib
 
@@ -292,3 +301,47 @@ KERNEL_GRID_PREPARE, KERNEL_GRID_PAIRS, KERNEL_GRID_REDUCE, KERNEL_GRID_KDE = 3,
 def default_sw_params(clip=False, max_read_len=0):
     """bam_parser.py:95-98 scoring (1/5/7/2), FLANKMATCH 9 (bam_parser.py:30)."""
     return SwParams(1, 5, 7, 2, 9, int(bool(clip)), int(max_read_len), 0)
+
+
+class Inflater:
+    """Batch DEFLATE decoder on the GPU (include/tredgpu.h section 4): one HIP stream with pinned staging; one per host
+    thread.  ``reserve`` hands out numpy views of the staging buffers -- compressed payloads and their offsets are
+    written into them, the inflated bytes are read from ``out`` in place after ``run``."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        rc = self._lib.tredgpu_inflater_create(device, C.byref(self._h))
+        if rc != 0:
+            raise TredGpuError("tredgpu_inflater_create: %s (rc=%d)" % (self._lib.tredgpu_inflater_last_error(None).decode(), rc))
+        self.comp_addr = self.out_addr = 0
+
+    def close(self):
+        if self._h:
+            self._lib.tredgpu_inflater_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise TredGpuError("%s: %s (rc=%d)" % (what, self._lib.tredgpu_inflater_last_error(self._h).decode(), rc))
+        return rc
+
+    def reserve(self, comp_bytes, out_bytes, n_blocks):
+        """(comp, out, comp_off, out_off): uint8 views of comp_bytes / out_bytes bytes, int64 views of n_blocks + 1."""
+        ptr = [C.c_void_p() for _ in range(4)]
+        self._check(self._lib.tredgpu_inflater_reserve(self._h, comp_bytes, out_bytes, n_blocks, *[C.byref(p) for p in ptr]),
+                    "tredgpu_inflater_reserve")
+        self.comp_addr, self.out_addr = ptr[0].value, ptr[1].value
+
+        def view(p, ctype, n):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(max(n, 1),))[:n]
+        return (view(ptr[0], C.c_uint8, comp_bytes), view(ptr[1], C.c_uint8, out_bytes),
+                view(ptr[2], C.c_int64, n_blocks + 1), view(ptr[3], C.c_int64, n_blocks + 1))
+
+    def run(self, n_blocks):
+        """Decodes the n_blocks blocks laid out in the reserved buffers; returns the int32 status per block."""
+        status = np.zeros(max(n_blocks, 1), np.int32)
+        self._check(self._lib.tredgpu_inflate_blocks(self._h, n_blocks, status.ctypes.data), "tredgpu_inflate_blocks")
+        return status[:n_blocks]
