@@ -51,15 +51,21 @@ __constant__ uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12
 
 struct Bits {
     const uint32_t* p;
-    int idx, nwords;      // next dword, dwords that hold payload
+    int idx, nwords;      // next dword to fetch, dwords that hold payload
     uint64_t buf;
     int cnt;
+    uint32_t ahead;       // dword idx - 1, fetched one refill early: its latency passes while the bits before it are used
+    __device__ __forceinline__ void start(const uint32_t* at, int words) {
+        p = at; nwords = words; buf = 0; cnt = 0;
+        ahead = words > 0 ? at[0] : 0u;
+        idx = 1;
+    }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32) {
-            const uint32_t w = idx < nwords ? p[idx] : 0u;   // past the payload: zeros (the overrun is caught at the end)
-            ++idx;
-            buf |= (uint64_t)w << cnt;
+            buf |= (uint64_t)ahead << cnt;
             cnt += 32;
+            ahead = idx < nwords ? p[idx] : 0u;   // past the payload: zeros (the overrun is caught at the end)
+            ++idx;
         }
     }
     __device__ __forceinline__ uint32_t get(int n) {   // n <= 16
@@ -69,7 +75,7 @@ struct Bits {
         cnt -= n;
         return v;
     }
-    __device__ __forceinline__ long long consumed_bits() const { return (long long)idx * 32 - cnt; }
+    __device__ __forceinline__ long long consumed_bits() const { return (long long)(idx - 1) * 32 - cnt; }
 };
 
 // one symbol of a canonical code: the direct table on the next FB bits, else canonical decoding from length FB + 1
@@ -189,11 +195,7 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
     uint8_t* o = out + out_off[g];
     const int olen = (int)(out_off[g + 1] - out_off[g]);
     Bits b;
-    b.p = comp + (c0 >> 2);
-    b.idx = 0;
-    b.nwords = (int)((c1 - c0 + 3) >> 2);
-    b.buf = 0;
-    b.cnt = 0;
+    b.start(comp + (c0 >> 2), (int)((c1 - c0 + 3) >> 2));
     int st = (c1 - c0) > 0 ? ST_HDR : ST_ERR;
     int opos = 0, last = 0, mlen = 0, mdist = 0, mspan = 0;
     while (st < ST_DONE) {
