@@ -317,11 +317,15 @@ class Inflater:
         self.comp_addr = self.out_addr = 0
 
     def close(self):
-        if self._h:
-            self._lib.tredgpu_inflater_destroy(self._h)
-            self._h = C.c_void_p()
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.tredgpu_inflater_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the module globals may be gone
+            pass
 
     def _check(self, rc, what):
         if rc < 0:

@@ -359,6 +359,15 @@ def _native():
             lib.tredbam_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p]
             lib.tredbam_scan.restype = C.c_int
             lib.tredbam_scan_pools.argtypes = [C.c_void_p, C.POINTER(Pools)]
+            lib.tredbam_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts),
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+            lib.tredbam_plan.restype = C.c_int64
+            lib.tredbam_plan_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+            lib.tredbam_plan_fill.restype = C.c_int
+            lib.tredbam_preload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.tredbam_preload.restype = C.c_int
+            lib.tredbam_preload_clear.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+            lib.tredbam_preload_clear.restype = None
             lib.tredbam_scan_pools.restype = C.c_int
             lib.tredbam_details_json.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_int64]
             lib.tredbam_details_json.restype = C.c_int64
@@ -711,6 +720,41 @@ class NativeAlignmentFile(object):
                  "global_lens": _copy(p.global_lens, p.n_global, "<i4"),
                  "target_lens": _copy(p.target_lens, p.n_target, "<i4")}
         return units, pools
+
+    # ---- blocks inflated elsewhere (the GPU's batch decoder, _lib.Inflater) ----
+    def plan(self, sites, alts, readlen, pad=1000, flank=9, pe_reach=10000, span=1000, use_alts=True, want_depth=True,
+             want_pe=True):
+        """tredbam_plan: the BGZF blocks scan(...) with the same arguments will read -> (n_blocks, bytes their payloads
+        take in a staging buffer, bytes they inflate to)."""
+        sites = np.ascontiguousarray(sites, SITE_DTYPE)
+        alts = np.ascontiguousarray(alts if len(alts) else np.zeros(1, REGION_DTYPE), REGION_DTYPE)
+        o = ScanOpts(int(readlen), int(pad), int(flank), int(pe_reach), int(span), int(bool(use_alts)),
+                     int(bool(want_depth)), int(bool(want_pe)))
+        cb, ob = C.c_int64(), C.c_int64()
+        n = self._lib.tredbam_plan(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o), C.byref(cb), C.byref(ob))
+        if n < 0:
+            raise ValueError(self._err())
+        return int(n), cb.value, ob.value
+
+    def plan_fill(self, comp_addr, comp_base, out_base, comp_off, out_off):
+        """Copies the planned payloads into the staging buffer at comp_addr (from byte comp_base on) and writes this
+        sample's n + 1 entries of the two offset arrays (int64 numpy views of the inflater's)."""
+        if self._lib.tredbam_plan_fill(self._h, comp_addr, comp_base, out_base, comp_off.ctypes.data, out_off.ctypes.data) != 0:
+            raise ValueError(self._err())
+
+    def preload(self, out_addr, out_off, status):
+        """Hands the inflated blocks of the plan in (pointers only: the staging buffer must outlive the scan)."""
+        status = np.ascontiguousarray(status, np.int32)
+        n = self._lib.tredbam_preload(self._h, out_addr, out_off.ctypes.data, status.ctypes.data)
+        if n < 0:
+            raise ValueError(self._err())
+        return n
+
+    def preload_clear(self):
+        """Forgets the preloaded blocks; (block loads served from them, block loads inflated here) since preload."""
+        h, m = C.c_int64(), C.c_int64()
+        self._lib.tredbam_preload_clear(self._h, C.byref(h), C.byref(m))
+        return h.value, m.value
 
     def pe_lengths(self, chrom, start, end, tstart, tend, span):
         """(global_lens, target_lens) of PEextractor (bam_parser.py:316-369) for the window [start, end)."""

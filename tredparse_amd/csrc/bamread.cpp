@@ -90,6 +90,13 @@ struct tredbam {
     std::unordered_map<int64_t, Cached> cache;
     std::deque<int64_t> cache_order;
     static constexpr size_t CACHE_BLOCKS = 512;   // <= 32 MiB per open file
+    // blocks inflated elsewhere (tredbam_plan -> the GPU's batch decoder -> tredbam_preload): compressed offset -> the
+    // caller's bytes; load_block takes them from here (CRC checked at first use), anything else is inflated as usual
+    struct Planned { int64_t coffset, payload_off; int32_t payload_len; int64_t clen; uint32_t crc, isize; };
+    struct Preloaded { const uint8_t* data; uint32_t size; int64_t clen; uint32_t crc; bool checked; };
+    std::vector<Planned> plan;
+    std::unordered_map<int64_t, Preloaded> preloaded;
+    int64_t preload_hits = 0, preload_misses = 0;
     tredbam_inflate::Tables inflate_tables;        // decoding tables of the block decoder (inflate_block.h)
     // header
     std::vector<std::string> ref_names;
@@ -140,20 +147,11 @@ bool inflate_dispatch(const uint8_t* in, size_t in_len, uint8_t* out, size_t out
     return tredbam_inflate::inflate_block(in, in_len, out, out_len, T);
 }
 
-int load_block(tredbam* b, int64_t coffset) {
-    b->block_coffset = coffset;
-    {
-        const auto hit = b->cache.find(coffset);
-        if (hit != b->cache.end()) {
-            b->block = hit->second.data.get();
-            b->block_size = hit->second.size;
-            b->block_clen = hit->second.clen;
-            return 1;
-        }
-    }
-    b->block = nullptr;
-    b->block_size = 0;
-    b->block_clen = 0;
+// The frame of the BGZF block at compressed offset coffset: where its deflate payload lies, how long the block is, and
+// the trailer.  Returns 1, 0 at end of file, <0 on error.  *comp: the payload + trailer bytes (valid until the next
+// file_bytes call when the file is not mapped).
+struct BlockFrame { int64_t clen, payload_off, dlen; uint32_t crc, isize; };
+int block_frame(tredbam* b, int64_t coffset, BlockFrame& f, const uint8_t** comp) {
     uint8_t hdr[18];
     {
         const uint8_t* h = file_bytes(b, coffset, sizeof hdr);
@@ -173,14 +171,59 @@ int load_block(tredbam* b, int64_t coffset) {
         }
     }
     if (bsize < 0) return fail(b, -6, "BGZF block without BC field");
-    const int64_t clen = (int64_t)bsize + 1;
-    const int64_t dlen = clen - 12 - xlen;   // deflate data + CRC32 + ISIZE
-    if (dlen < 8) return fail(b, -6, "bad BGZF block size");
-    const uint8_t* comp = file_bytes(b, coffset + 12 + xlen, (size_t)dlen);
-    if (!comp) return fail(b, -6, "truncated BGZF block");
-    const uint32_t isize = le32(comp + dlen - 4);
+    f.clen = (int64_t)bsize + 1;
+    f.dlen = f.clen - 12 - xlen;   // deflate data + CRC32 + ISIZE
+    if (f.dlen < 8) return fail(b, -6, "bad BGZF block size");
+    f.payload_off = coffset + 12 + xlen;
+    const uint8_t* c = file_bytes(b, f.payload_off, (size_t)f.dlen);
+    if (!c) return fail(b, -6, "truncated BGZF block");
+    f.crc = le32(c + f.dlen - 8);
+    f.isize = le32(c + f.dlen - 4);
     // a BGZF block holds at most 64 KiB (SAM spec 4.1): a larger ISIZE is a damaged trailer, not a 4 GiB allocation
-    if (isize > 65536) return fail(b, -6, "BGZF block at %lld claims %u bytes", (long long)coffset, isize);
+    if (f.isize > 65536) return fail(b, -6, "BGZF block at %lld claims %u bytes", (long long)coffset, f.isize);
+    *comp = c;
+    return 1;
+}
+
+int load_block(tredbam* b, int64_t coffset) {
+    b->block_coffset = coffset;
+    {
+        const auto hit = b->cache.find(coffset);
+        if (hit != b->cache.end()) {
+            b->block = hit->second.data.get();
+            b->block_size = hit->second.size;
+            b->block_clen = hit->second.clen;
+            return 1;
+        }
+    }
+    b->block = nullptr;
+    b->block_size = 0;
+    b->block_clen = 0;
+    if (!b->preloaded.empty()) {
+        const auto pre = b->preloaded.find(coffset);
+        if (pre != b->preloaded.end()) {
+            tredbam::Preloaded& p = pre->second;
+            if (!p.checked) {      // the block's CRC-32, as for a block inflated here
+                if (tredbam_crc::crc32(0, p.data, p.size) != p.crc)
+                    return fail(b, -7, "CRC mismatch in the BGZF block at %lld", (long long)coffset);
+                p.checked = true;
+            }
+            b->block = p.data;
+            b->block_size = p.size;
+            b->block_clen = p.clen;
+            ++b->preload_hits;
+            return 1;
+        }
+        ++b->preload_misses;
+    }
+    BlockFrame fr;
+    const uint8_t* comp = nullptr;
+    {
+        const int rc = block_frame(b, coffset, fr, &comp);
+        if (rc <= 0) return rc;
+    }
+    const int64_t clen = fr.clen, dlen = fr.dlen;
+    const uint32_t isize = fr.isize;
     tredbam_pool::Buffer data(tredbam_pool::take());     // (isize <= 65536: every block fits a pooled buffer)
     // own whole-block decoder first (1.3-1.6x zlib's speed on BAM data); zlib decides whenever it declines
     const bool done = isize > 0 && inflate_dispatch(comp, (size_t)(dlen - 8), data.get(), isize, b->inflate_tables);
@@ -394,17 +437,16 @@ int load_index(tredbam* b) {
     return 0;
 }
 
-// Region walk shared by fetch and the depth sum.  visit(end) is called for every record overlapping the region
-// after emit_record() has parsed it (and stored it when `store`).
-template <typename F>
-int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool store, F visit) {
+// The merged index chunks (virtual offsets) a query of [start, end) on tid reads, like htslib's: reg2bins of the 5-level
+// scheme, every chunk cut at the linear index' offset of the 16 kb window that holds `start`.  0, or <0.
+int region_chunks(tredbam* b, int32_t tid, int64_t& start, int64_t& end, std::vector<std::pair<uint64_t, uint64_t>>& merged) {
     if (tid < 0 || tid >= (int32_t)b->ref_names.size()) return fail(b, -2, "invalid contig id %d", tid);
     start = std::max<int64_t>(0, start);
     if (end < 0) end = b->ref_lens[tid];
     if (start > end) return fail(b, -2, "invalid coordinates: start > end");
     int rc = load_index(b);
     if (rc) return rc;
-    int64_t n = 0;
+    merged.clear();
     if (tid >= (int32_t)b->index.size()) return 0;
     const RefIndex& ix = b->index[tid];
     uint64_t min_off = 0;
@@ -424,11 +466,21 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
     for (int l = 0; l < 5; ++l)
         for (int64_t k = start >> shifts[l]; k <= e1 >> shifts[l]; ++k) add_bin(bases[l] + (uint32_t)k);
     std::sort(chunks.begin(), chunks.end());
-    std::vector<std::pair<uint64_t, uint64_t>> merged;
     for (const auto& ch : chunks) {
         if (!merged.empty() && ch.first <= merged.back().second) merged.back().second = std::max(merged.back().second, ch.second);
         else merged.push_back(ch);
     }
+    return 0;
+}
+
+// Region walk shared by fetch and the depth sum.  visit(end) is called for every record overlapping the region
+// after emit_record() has parsed it (and stored it when `store`).
+template <typename F>
+int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool store, F visit) {
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    int rc = region_chunks(b, tid, start, end, merged);
+    if (rc) return rc;
+    int64_t n = 0;
     for (const auto& ch : merged) {
         if ((rc = bg_seek(b, ch.first)) < 0) return rc;
         while (bg_tell(b) < ch.second) {
@@ -1058,6 +1110,111 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
         }
     }
     return 0;
+}
+
+// ---- blocks inflated elsewhere (include/tredbam.h) ----------------------------------------------------------------
+// The BGZF blocks the region walks of tredbam_scan(sites ...) will read: every block from the start of a merged chunk to
+// its end -- or, sooner, to the linear index' offset two 16 kb windows behind the region's end (records from there on
+// start behind the region; a block left out by that cut is simply inflated by load_block when the walk gets there).
+int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
+                     const tredbam_scan_opts* o, int64_t* comp_bytes, int64_t* out_bytes) {
+    if (!b || !o || n_sites < 0 || (n_sites > 0 && !sites)) return -2;
+    b->plan.clear();
+    std::unordered_map<int64_t, bool> seen;
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    auto add_region = [&](int32_t tid, int64_t start, int64_t end) -> int {
+        if (region_chunks(b, tid, start, end, merged) != 0) return 0;     // (the scan reports what is wrong with it)
+        uint64_t cap = ~0ull;
+        if (tid < (int32_t)b->index.size()) {
+            const auto& lin = b->index[tid].linear;
+            const size_t w = (size_t)(std::max<int64_t>(end, 1) - 1 >> 14) + 2;
+            if (w < lin.size() && lin[w] != 0) cap = lin[w];
+        }
+        for (const auto& ch : merged) {
+            const int64_t last = (int64_t)(std::min(ch.second, cap) >> 16);
+            for (int64_t at = (int64_t)(ch.first >> 16); at <= last;) {
+                BlockFrame fr;
+                const uint8_t* comp = nullptr;
+                const int rc = block_frame(b, at, fr, &comp);
+                if (rc <= 0) break;                                        // end of file / damaged frame: left to the scan
+                if (fr.isize > 0 && !seen.count(at)) {
+                    seen[at] = true;
+                    b->plan.push_back({at, fr.payload_off, (int32_t)(fr.dlen - 8), fr.clen, fr.crc, fr.isize});
+                }
+                at += fr.clen;
+            }
+        }
+        return 0;
+    };
+    for (int32_t i = 0; i < n_sites; ++i) {
+        const tredbam_site& st = sites[i];
+        const int64_t win_lo = std::max<int64_t>(0, (int64_t)st.repeat_start - o->pad), win_hi = (int64_t)st.repeat_end + o->pad;
+        const int64_t p_lo = std::max<int64_t>((int64_t)st.repeat_start - o->pe_reach, 0), p_hi = (int64_t)st.repeat_end + o->pe_reach;
+        if (st.tid < 0) continue;
+        add_region(st.tid, win_lo, win_hi);
+        if (o->want_pe) add_region(st.tid, p_lo, p_hi);
+        if (o->use_alts && alts)
+            for (int32_t k = 0; k < st.n_alt; ++k) {
+                const tredbam_region& a = alts[st.alt_first + k];
+                if (a.tid >= 0) add_region(a.tid, a.start, a.end);
+            }
+    }
+    int64_t cb = 0, ob = 0;
+    for (const auto& p : b->plan) { cb += ((int64_t)p.payload_len + 3) & ~(int64_t)3; ob += p.isize; }
+    if (comp_bytes) *comp_bytes = cb;
+    if (out_bytes) *out_bytes = ob;
+    return (int64_t)b->plan.size();
+}
+
+// The planned blocks' deflate payloads, copied to comp + comp_off[k] (4-byte aligned, from comp_base on) with the
+// inflated sizes laid out from out_base on; comp_off / out_off receive the plan's n entries AND the end offsets as
+// entry n (the next sample's bases).
+int tredbam_plan_fill(tredbam* b, uint8_t* comp, int64_t comp_base, int64_t out_base, int64_t* comp_off, int64_t* out_off) {
+    if (!b || !comp || !comp_off || !out_off || comp_base < 0 || (comp_base & 3) != 0 || out_base < 0) return -2;
+    int64_t c = comp_base, o = out_base;
+    for (size_t k = 0; k < b->plan.size(); ++k) {
+        const tredbam::Planned& p = b->plan[k];
+        const uint8_t* src = file_bytes(b, p.payload_off, (size_t)p.payload_len);
+        if (!src) return fail(b, -6, "truncated BGZF block");
+        comp_off[k] = c;
+        out_off[k] = o;
+        memcpy(comp + c, src, (size_t)p.payload_len);
+        const int64_t padded = ((int64_t)p.payload_len + 3) & ~(int64_t)3;
+        memset(comp + c + p.payload_len, 0, (size_t)(padded - p.payload_len));
+        c += padded;
+        o += p.isize;
+    }
+    comp_off[b->plan.size()] = c;
+    out_off[b->plan.size()] = o;
+    return 0;
+}
+
+// out + out_off[k] holds the planned block k inflated (status[k] == 0; others are left to load_block).  The memory
+// stays the caller's and must live until tredbam_preload_clear or tredbam_close.
+int tredbam_preload(tredbam* b, const uint8_t* out, const int64_t* out_off, const int32_t* status) {
+    if (!b || !out || !out_off || !status) return -2;
+    b->preloaded.clear();
+    b->preloaded.reserve(b->plan.size() * 2);
+    b->preload_hits = b->preload_misses = 0;
+    int32_t n = 0;
+    for (size_t k = 0; k < b->plan.size(); ++k) {
+        const tredbam::Planned& p = b->plan[k];
+        if (status[k] != 0 || out_off[k + 1] - out_off[k] != (int64_t)p.isize) continue;
+        b->preloaded[p.coffset] = tredbam::Preloaded{out + out_off[k], p.isize, p.clen, p.crc, false};
+        ++n;
+    }
+    // blocks of an earlier scan in the handle's own cache stay valid; the current block pointer may not
+    b->block_coffset = -1; b->block = nullptr; b->block_size = 0; b->block_clen = 0; b->upos = 0;
+    return n;
+}
+
+void tredbam_preload_clear(tredbam* b, int64_t* hits, int64_t* misses) {
+    if (!b) return;
+    if (hits) *hits = b->preload_hits;
+    if (misses) *misses = b->preload_misses;
+    b->preloaded.clear();
+    b->plan.clear();
+    b->block_coffset = -1; b->block = nullptr; b->block_size = 0; b->block_clen = 0; b->upos = 0;
 }
 
 int tredbam_scan_pools(tredbam* b, tredbam_pools* p) {

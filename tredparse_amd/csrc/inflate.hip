@@ -19,6 +19,7 @@
 // returns bytes plus a status per block; gzip framing, CRC-32 and ISIZE stay with the host library (libtredbam).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -454,7 +455,15 @@ int tredgpu_inflate_blocks(tredgpu_inflater* f, int32_t n_blocks, int32_t* statu
     ICHK(f, hipMemcpyAsync(f->h_out, f->d_out, (size_t)ooff[n_blocks], hipMemcpyDeviceToHost, f->stream));
     ICHK(f, hipMemcpyAsync(f->h_status, f->d_status, (size_t)n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
     ICHK(f, hipEventRecord(f->done, f->stream));
-    ICHK(f, hipEventSynchronize(f->done));
+    // wait asleep: hipEventSynchronize spins even on a hipEventBlockingSync event here (measured: CPU time = wall time,
+    // and calls of other threads on other streams queue up behind the spinning one); the host threads that wait are the
+    // ones whose cores the path is short of, and a call takes tens of milliseconds
+    for (;;) {
+        const hipError_t q = hipEventQuery(f->done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return ifail(f, -10, "hipEventQuery", q);
+        usleep(200);
+    }
     int bad = 0;
     for (int32_t k = 0; k < n_blocks; ++k) { status[k] = f->h_status[k]; bad += status[k] != 0; }
     return bad;
