@@ -450,7 +450,7 @@ def e2e_main(args):
             dist.barrier()
         t0 = time.perf_counter()
         tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads, lazy_details=True,
-                      background_sink=True)
+                      background_sink=True, inflate_device=0 if args.e2e_gpu_inflate == "1" else None)
         dt = time.perf_counter() - t0
     finally:
         os.chdir(cwd)
@@ -510,15 +510,21 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
         for n_devices in device_counts:
             legs = []
             n_files = n_devices * per_gpu[n_devices]
-            for drivers, threads in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads):
-                argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(args.e2e_batch),
-                        "--e2e-threads", str(threads), "--e2e-limit", str(n_files)]
-                out_dir = os.path.join(root, "out{}x{}".format(n_devices, drivers))
+            plans = [(d, t, False) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads)]
+            if args.e2e_gpu_inflate in ("1", "both"):
+                # the same plans with the BGZF blocks inflated on the GPU, a batch of samples per launch
+                with_gpu = [(d, t, True) for d, t, _ in plans]
+                plans = with_gpu if args.e2e_gpu_inflate == "1" else plans + with_gpu
+            for drivers, threads, gpu_inflate in plans:
+                batch = args.e2e_inflate_batch if gpu_inflate else args.e2e_batch
+                argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
+                        "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0"]
+                out_dir = os.path.join(root, "out{}x{}{}".format(n_devices, drivers, "g" if gpu_inflate else ""))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
                 codes = spawn(argv, drivers, n_devices, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
                 if any(codes):
-                    legs.append({"drivers": drivers, "devices": n_devices, "error": "exit codes {}".format(codes)})
+                    legs.append({"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate, "error": "exit codes {}".format(codes)})
                     continue
                 ranks = []
                 for r in range(drivers):
@@ -526,7 +532,8 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
                         ranks.append(json.load(fp))
                 units, secs = sum(r["units"] for r in ranks), max(r["seconds"] for r in ranks)
                 nbytes = sum(r["bam_bytes"] for r in ranks)
-                legs.append({"drivers": drivers, "devices": n_devices, "value": units / secs, "unit": "genotypes/s",
+                legs.append({"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate, "samples_per_gpu_batch": batch,
+                             "value": units / secs, "unit": "genotypes/s",
                              "units": units, "seconds": secs, "samples": sum(r["samples"] for r in ranks),
                              "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,
                              "per_driver": [{"seconds": round(r["seconds"], 3), "device": r.get("device", "0"),
@@ -537,10 +544,10 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
             rec = dict(best) if best else {"error": "no end-to-end leg finished"}
             rec["legs"] = legs
             rec["devices"] = n_devices
-            rec["samples_per_gpu_batch"] = args.e2e_batch
+            rec.setdefault("samples_per_gpu_batch", args.e2e_batch)
             rec["bam_generation_seconds"] = gen_s
             rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
-                           "native scan (BGZF inflate, BAI queries, read selection, pair lengths, depth) in host threads -> "
+                           "native scan (BGZF inflate -- on the host, or on the GPU a batch of samples per launch in the `gpu_inflate` legs --, BAI queries, read selection, pair lengths, depth) in host threads -> "
                            "GPU batches -> tredCalls -> JSON + VCF files; `drivers` processes over `devices` GPUs (rank r on "
                            "device r mod devices), each with its block of the samples and its share of the host CPUs "
                            "(tred.py --gpus N uses the same fan-out)")
@@ -679,6 +686,10 @@ def main():
     ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 5; also run with 1)")
     ap.add_argument("--legs", default="config5:150:200,config3:100:500,config3:250:500",
                     help="extra one-GPU legs workload:readlen:samples, comma separated ('' for none)")
+    ap.add_argument("--e2e-gpu-inflate", choices=("0", "1", "both"), default="both",
+                    help="end-to-end legs with the BAMs' BGZF blocks inflated on the GPU (tred.run_many inflate_device): "
+                         "0 host only, 1 GPU only, both")
+    ap.add_argument("--e2e-inflate-batch", type=int, default=32, help="samples per GPU batch (and inflate launch) in those legs")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-limit", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -100,7 +100,8 @@ def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
                            "bam_bytes": 1000 * (hi - lo)}, fp)
         return [0] * world
 
-    args = argparse.Namespace(e2e_samples=128, seed=1, e2e_drivers=0, e2e_threads=0, e2e_batch=16, rank_timeout=60)
+    args = argparse.Namespace(e2e_samples=128, seed=1, e2e_drivers=0, e2e_threads=0, e2e_batch=16, rank_timeout=60,
+                              e2e_gpu_inflate="0", e2e_inflate_batch=32)
     recs = bench.run_e2e(args, [1, 2, 8], spawn=fake_spawn, make_bams=fake_bams)
     assert made == [512]                                            # one set of files: 8 GPUs x 64 (capped at 512)
     assert sorted(recs) == [1, 2, 8]
@@ -111,6 +112,20 @@ def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
     assert eight["devices"] == 8 and eight["drivers"] == 8 and eight["samples"] == 512
     assert sorted(d["device"] for d in eight["per_driver"]) == [str(i) for i in range(8)]
     assert abs(eight["value"] - 30 * 512 / 1.07) < 1e-6              # all ranks' units / the slowest rank's time
+
+
+    # with the GPU-inflate legs: every plan twice, the second time with the larger batch and the child flag
+    del spawned[:]
+    flags = []
+    plain_spawn = fake_spawn
+
+    def flag_spawn(argv, *a, **k):
+        flags.append((argv[argv.index("--e2e-gpu-inflate") + 1], argv[argv.index("--e2e-batch") + 1]))
+        return plain_spawn(argv, *a, **k)
+    args.e2e_gpu_inflate = "both"
+    recs = bench.run_e2e(args, [1], spawn=flag_spawn, make_bams=fake_bams)
+    assert flags == [("0", "16")] * 3 + [("1", "32")] * 3
+    assert [l["gpu_inflate"] for l in recs[1]["legs"]] == [False] * 3 + [True] * 3
 
 
 def test_pmc_traffic_is_only_cited_for_the_build_it_was_taken_from(tmp_path, monkeypatch):

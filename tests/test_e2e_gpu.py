@@ -85,3 +85,28 @@ def test_run_many_batches_samples_into_one_gpu_call(engine):
         assert [r["samplekey"] for r in got] == ["t001", "t002", "t001"]
         for a, b in zip(got, one_by_one):
             assert json.dumps(a["tredCalls"], sort_keys=True) == json.dumps(b["tredCalls"], sort_keys=True)
+
+
+def test_run_many_with_gpu_inflated_blocks_gives_the_same_results(engine, tmp_path):
+    """run_many(inflate_device=0): the samples' BGZF blocks are planned from the index, decoded on the GPU a chunk of
+    samples per launch and preloaded into the scans -- byte-identical tredCalls, and the scans did take (nearly) all
+    their blocks from the preloaded set."""
+    from tredparse_amd import synth, synth_bam
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    args = [(s, os.path.join(GOLD, "bam", s + ".bam"), repo, list(repo.names), 300, False, False, True, True, "INFO")
+            for s in ("t001", "t002", "t001", "t002", "t001")]
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1", "FRDA", "AR")]
+    made = synth_bam.make_bams(str(tmp_path), 5, seed=77, loci=loci, p=synth.SynthParams(coverage=30, expanded_max=120, expanded_frac=0.3))
+    srepo = TREDsRepo()
+    args += [(key, path, srepo, [l["name"] for l in loci], 300, False, False, True, True, "ERROR") for key, path, _ in made]
+    args.append(("missing", os.path.join(str(tmp_path), "no_such.bam"), repo, ["HD"], 300, False, False, True, True, "ERROR"))
+    plain = tredmod.run_many(args, engine, batch=4, threads=3)
+    for k in tredmod.TIMING:
+        tredmod.TIMING[k] = 0
+    helped = tredmod.run_many(args, engine, batch=4, threads=3, inflate_device=0)
+    assert [r["samplekey"] for r in helped] == [a[0] for a in args]
+    for a, b in zip(helped, plain):
+        assert tredmod.dumps_result(a) == tredmod.dumps_result(b)
+    t = tredmod.TIMING
+    assert t["inflate_blocks"] > 500 and t["inflate_failed"] == 0
+    assert t["inflate_hits"] > 20 * max(t["inflate_misses"], 1)

@@ -37,7 +37,8 @@ logging.basicConfig()
 logger = logging.getLogger(__name__)
 # seconds accumulated over run_many calls: the driver thread's waits for scans, its GPU calls and its formatting; and
 # the writer thread's time in the sink (JSON / VCF text and files)
-TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0}
+TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
+          "inflate_hits": 0, "inflate_misses": 0}
 
 # (ID, Number, Type, Description) of the VCF meta lines, in file order
 _VCF_INFO = (("RPA", "1", "String", "Repeats per allele"), ("END", "1", "Integer", "End position of variant"),
@@ -152,6 +153,131 @@ def collect_sample(arg):
     """Host half of a sample (thread-safe, no GPU): the native scan of its BAM."""
     o = _options(arg)
     return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"])
+
+
+# ---- scans over GPU-inflated blocks -----------------------------------------------------------------------------------
+# Two thirds of a scan's host time is DEFLATE decoding of ~550 BGZF blocks per 30x sample, and the host's cores, not
+# the GPU, bound the from-BAM rate.  With `inflate_device` set, run_many plans every sample's blocks from its index
+# (bamio plan), has the GPU decode a whole chunk of samples in ONE launch (_lib.Inflater: one lane per block; kernels of
+# different streams do not overlap on this GPU, so the batch is what fills it) and lets the scans take the blocks from
+# the inflater's pinned output (bamio preload).  Blocks a plan misses, or the decoder rejects, are inflated by the scan
+# itself as before: the results cannot differ.
+def _plan_sample(arg):
+    """Thread: open the BAM and list the blocks its scan will read.  None: no GPU help for this sample."""
+    from .bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays, open_bam
+    o = _options(arg)
+    try:
+        f = open_bam(o["bam"])
+    except (IOError, ValueError):
+        return None                                    # scan_sample reports the file
+    try:
+        if not hasattr(f, "plan"):
+            raise ValueError("no native BAM layer")
+        readlen = f.max_read_len(101)
+        loci = [o["repo"][n] for n in o["names"]]
+        sites, regions = _site_arrays(o["repo"], o["names"], loci, f)
+        n, cbytes, obytes = f.plan(sites, regions, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN,
+                                   use_alts=o["alts"] and not o["clip"])
+        return {"handle": f, "readlen": readlen, "n": n, "cbytes": cbytes, "obytes": obytes}
+    except Exception:
+        f.close()
+        return None
+
+
+def _scan_planned(arg, plan, out_addr, out_off, status):
+    """Thread: the sample's scan with its planned blocks preloaded from the inflater's output."""
+    o = _options(arg)
+    f = plan["handle"]
+    try:
+        if status is not None:
+            f.preload(out_addr, out_off, status)
+        return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"], readlen=plan["readlen"], handle=f)
+    finally:
+        if status is not None:
+            hits, misses = f.preload_clear()
+            TIMING["inflate_hits"] += hits
+            TIMING["inflate_misses"] += misses
+        f.close()
+
+
+class _InflateFeeder(object):
+    """Feeds run_many's chunks through plan -> GPU inflate -> scan, one chunk ahead of the consumer: next(chunk index)
+    returns the chunk's scan futures.  Two inflaters alternate; one is reused only when every scan that reads its output
+    has finished."""
+
+    def __init__(self, chunks, ex, device):
+        import queue
+        import threading
+        from ._lib import Inflater
+        self.chunks, self.ex = chunks, ex
+        self.inflaters = [Inflater(device), Inflater(device)]
+        self.busy = [[], []]
+        self.q = queue.Queue(maxsize=2)
+        self.thread = threading.Thread(target=self._run, name="tred-inflate", daemon=True)
+        self.thread.start()
+
+    def _chunk(self, ci, chunk):
+        import numpy as np
+        inf, slot = self.inflaters[ci % 2], ci % 2
+        for fut in self.busy[slot]:
+            fut.exception()                            # (waits; the consumer sees the error itself)
+        plans = [fut.result() for fut in [self.ex.submit(_plan_sample, a) for a in chunk]]
+        live = [p for p in plans if p is not None and p["n"] > 0]
+        t0 = time.perf_counter()
+        status = None
+        if live:
+            try:
+                n_all = sum(p["n"] for p in live)
+                comp, out, coff, ooff = inf.reserve(sum(p["cbytes"] for p in live), sum(p["obytes"] for p in live), n_all)
+                at = cb = ob = 0
+                fills = []
+                for p in live:
+                    p["first"] = at
+                    fills.append(self.ex.submit(p["handle"].plan_fill, inf.comp_addr, cb, ob, coff[at:at + p["n"] + 1],
+                                                ooff[at:at + p["n"] + 1]))
+                    at, cb, ob = at + p["n"], cb + p["cbytes"], ob + p["obytes"]
+                for fut in fills:
+                    fut.result()
+                # (every sample wrote its own end as entry n: the next sample's first entry is the same number)
+                status = inf.run(n_all)
+                TIMING["inflate_blocks"] += n_all
+                TIMING["inflate_failed"] += int((status != 0).sum())
+            except Exception as e:     # no GPU help for this chunk: the scans inflate for themselves
+                logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
+                status = None
+        TIMING["inflate"] += time.perf_counter() - t0
+        futs = []
+        for a, p in zip(chunk, plans):
+            if p is None:
+                futs.append(self.ex.submit(collect_sample, a))
+            elif status is None or p["n"] == 0:
+                futs.append(self.ex.submit(_scan_planned, a, p, 0, None, None))
+            else:
+                k = p["first"]
+                futs.append(self.ex.submit(_scan_planned, a, p, inf.out_addr, ooff[k:k + p["n"] + 1], status[k:k + p["n"]]))
+        self.busy[slot] = futs
+        return futs
+
+    def _run(self):
+        try:
+            for ci, chunk in enumerate(self.chunks):
+                self.q.put(self._chunk(ci, chunk))
+        except BaseException as e:     # hand the failure to the consumer instead of leaving it waiting
+            self.q.put(e)
+
+    def next(self):
+        item = self.q.get()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        self.thread.join(timeout=60)
+        for slot in self.busy:
+            for fut in slot:
+                fut.exception()
+        for inf in self.inflaters:
+            inf.close()
 
 
 def _skeleton(o, scan):
@@ -300,12 +426,14 @@ class _Writer(object):
 
 
 def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
-             background_sink=False):
+             background_sink=False, inflate_device=None):
     """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
     executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in flight the
     scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
     finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch.
-    background_sink: sink runs on a writer thread (in order) instead of the driver thread."""
+    background_sink: sink runs on a writer thread (in order) instead of the driver thread.
+    inflate_device: GPU that inflates the samples' BGZF blocks, a chunk of samples per launch (None: the scans inflate on
+    the host); needs scan threads."""
     own = pool is None and threads > 1 and len(task_args) > 1
     # the first GPU batch is only as large as one round of the scan threads: nothing else can start before it is in
     # (only when there is more than one batch anyway: an extra GPU call costs more than it hides on small inputs)
@@ -317,12 +445,18 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     writer = _Writer(sink) if (background_sink and sink is not None) else None
     if writer is not None:
         sink = writer
+    feeder = _InflateFeeder(chunks, ex, inflate_device) if (inflate_device is not None and ex is not None) else None
     try:
         submit = (lambda c: [ex.submit(collect_sample, a) for a in c]) if ex is not None else None
         ahead = deque()
         nxt = 0
         for i, chunk in enumerate(chunks):
-            if ex is not None:
+            if feeder is not None:
+                futs = feeder.next()
+                t0 = time.perf_counter()
+                scans = [f.result() for f in futs]
+                TIMING["scan_wait"] += time.perf_counter() - t0
+            elif ex is not None:
                 while nxt < len(chunks) and nxt <= i + max(1, ahead_batches):
                     ahead.append(submit(chunks[nxt]))
                     nxt += 1
@@ -337,6 +471,8 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
                 else:
                     out.append(r)
     finally:
+        if feeder is not None:
+            feeder.close()
         if own:
             ex.shutdown()
         if writer is not None:
