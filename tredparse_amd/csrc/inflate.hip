@@ -58,14 +58,18 @@ struct Bits {
     uint32_t ahead;       // dword idx - 1, fetched one refill early: its latency passes while the bits before it are used
     __device__ __forceinline__ void start(const uint32_t* at, int words) {
         p = at; nwords = words; buf = 0; cnt = 0;
-        ahead = words > 0 ? at[0] : 0u;
+        ahead = at[0];
         idx = 1;
     }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32) {
-            buf |= (uint64_t)ahead << cnt;
+            // past the payload: zeros (the overrun is caught at the end).  The fetch itself is unconditional -- the staging
+            // buffer has 64 bytes of slack -- so that the loaded dword lands in `ahead`'s own register: behind a select the
+            // compiler loaded into a temporary, and the move out of it waited for the load on the spot
+            const uint32_t w = idx - 1 < nwords ? ahead : 0u;
+            buf |= (uint64_t)w << cnt;
             cnt += 32;
-            ahead = idx < nwords ? p[idx] : 0u;   // past the payload: zeros (the overrun is caught at the end)
+            ahead = p[idx];
             ++idx;
         }
     }
