@@ -204,6 +204,10 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
     int st = (c1 - c0) > 0 ? ST_HDR : ST_ERR;
     int opos = 0, last = 0, mlen = 0, mdist = 0, mspan = 0;
     while (st < ST_DONE) {
+        // (the three states are tried one after the other in every trip: a match decoded in this trip makes its first
+        //  copy step in it -- most matches of a BAM block are shorter than one step --, an end-of-block code goes on to
+        //  the next header: 25.5 -> 21.4 ms per 556-block sample.  Several literals per trip were slower: 24 ms with two,
+        //  27 with three -- the lanes that have a match wait)
         if (st == ST_SYM) {
             int sym = decode<FASTL>(b, tab, T_LFAST, T_LCONT, T_LCNT, T_LSYM);
             if (sym < 0) st = ST_ERR;
@@ -227,13 +231,15 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
                     }
                 }
             }
-        } else if (st == ST_COPY) {
+        }
+        if (st == ST_COPY) {
             // up to 16 bytes of the match per trip, taken from `mspan` bytes back: mspan is a multiple of the distance
             // (the bytes since opos - distance repeat with that period), starts as the distance itself and doubles
             // with every full span copied until it covers a trip -- source and destination of one trip never overlap,
             // so the trip is two independent wide loads and two wide stores instead of a chain of byte loads each
             // waiting for the store before it (which was 90 % of the kernel's time: some lane of the 64 is in a match
-            // in nearly every trip)
+            // in nearly every trip).  (Writing the 16 bytes a trip later, so that the loads' latency passes under the next
+            // trip's decoding, was slower: 23.5 ms -- the exact-length stores and the shared vmcnt cost more.)
             const int n = min(min(mlen, 16), mspan);
             uint8_t* dst = o + opos;
             const uint8_t* src = dst - mspan;
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
             opos += n;
             mlen -= n;
             if (mlen == 0) st = ST_SYM;
-        } else {   // ST_HDR: a deflate block header (and, for a stored block, its bytes)
+        } else if (st == ST_HDR) {   // a deflate block header (and, for a stored block, its bytes)
             last = (int)b.get(1);
             const int type = (int)b.get(2);
             if (type == 0) {
