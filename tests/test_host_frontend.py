@@ -489,3 +489,49 @@ def test_batched_json_calls_fall_back_per_item():
     bad = bamio.details_json_many(s.seq4, s.seq4_off, s.read_len, bytes(blob), s.name_off,
                                   [(reads[:1], tags[:1], hs[:1]), (reads, tags, hs)])
     assert bad[1] is None and json.loads(bad[0])[0]["tag"] == "FULL"
+
+
+def test_scan_over_blocks_inflated_elsewhere_equals_the_plain_scan():
+    """tredbam_plan lists the BGZF blocks a scan will read, tredbam_plan_fill hands out their deflate payloads on 4-byte
+    boundaries, tredbam_preload takes the inflated bytes back (zlib stands in for the GPU's batch decoder here): the scan
+    then reads (nearly) all its blocks from there and returns exactly what the plain scan returns; a block that is
+    missing from the set, refused by the decoder or damaged on the way is inflated by the scan itself / reported."""
+    import zlib
+    from tredparse_amd import bam_parser
+    from tredparse_amd.meta import TREDsRepo
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    names = list(repo.names)
+    for sample in ("t001", "t002"):
+        path = os.path.join(GOLD, "bam", sample + ".bam")
+        ref = bam_parser.scan_sample(path, repo, names)
+        f = bam_parser.open_bam(path)
+        sites, regions = bam_parser._site_arrays(repo, names, [repo[n] for n in names], f)
+        n, cbytes, obytes = f.plan(sites, regions, ref.readlen)
+        assert n > 30 and cbytes % 4 == 0 and obytes > cbytes
+        comp, out = np.zeros(cbytes + 64, np.uint8), np.zeros(obytes + 64, np.uint8)
+        coff, ooff = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        f.plan_fill(comp.ctypes.data, 0, 0, coff, ooff)
+        assert coff[-1] == cbytes and ooff[-1] == obytes and (coff % 4 == 0).all()
+        for k in range(n):
+            data = zlib.decompressobj(-15).decompress(bytes(comp[coff[k]:coff[k + 1]]))
+            assert len(data) == ooff[k + 1] - ooff[k]
+            out[ooff[k]:ooff[k + 1]] = np.frombuffer(data, np.uint8)
+        status = np.zeros(n, np.int32)
+        status[3] = -1                                       # one block the decoder refused: left to the scan
+        assert f.preload(out.ctypes.data, ooff, status) == n - 1
+        got = bam_parser.scan_sample(path, repo, names, handle=f, readlen=ref.readlen)
+        hits, misses = f.preload_clear()
+        assert hits > 10 * max(misses, 1) and misses >= 1
+        for field in ("packed", "word_off", "read_len", "global_lens", "target_lens", "name_id", "unit", "depth"):
+            assert np.array_equal(getattr(ref, field), getattr(got, field)), (sample, field)
+        assert ref.name_blob == got.name_blob
+        # a damaged block among the preloaded ones fails its CRC like a block inflated here would
+        status[:] = 0
+        out[ooff[:-1] + 7] ^= 0x20                            # (every block: whichever the walks read first)
+        assert f.preload(out.ctypes.data, ooff, status) == 0  # preload_clear dropped the plan with the blocks: plan again
+        assert f.plan(sites, regions, ref.readlen)[0] == n
+        assert f.preload(out.ctypes.data, ooff, status) == n
+        bad = bam_parser.scan_sample(path, repo, names, handle=f, readlen=ref.readlen)
+        f.preload_clear()
+        assert (bad.unit["status"] & 2).any() or (bad.unit["depth_status"] != 0).any()
+        f.close()

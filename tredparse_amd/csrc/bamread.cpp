@@ -1159,16 +1159,6 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
                 if (a.tid >= 0) add_region(a.tid, a.start, a.end);
             }
     }
-    // (experiment) TREDBAM_PLAN_PERCENT: only that share of the blocks goes to the GPU, the rest stays with the scan
-    if (const char* pct = getenv("TREDBAM_PLAN_PERCENT")) {
-        const int keep = atoi(pct);
-        if (keep >= 0 && keep < 100) {
-            std::vector<tredbam::Planned> kept;
-            for (size_t k = 0; k < b->plan.size(); ++k)
-                if ((int)((k * 37) % 100) < keep) kept.push_back(b->plan[k]);
-            b->plan.swap(kept);
-        }
-    }
     int64_t cb = 0, ob = 0;
     for (const auto& p : b->plan) { cb += ((int64_t)p.payload_len + 3) & ~(int64_t)3; ob += p.isize; }
     if (comp_bytes) *comp_bytes = cb;

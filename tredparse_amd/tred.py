@@ -85,6 +85,9 @@ def set_argparse():
     g.add_argument("--gpus", type=int, default=1, help="GPUs to spread the samples over (one process each)")
     g.add_argument("--gpu", type=int, default=0, help="device index when --gpus is 1")
     g.add_argument("--batch-samples", type=int, default=64, help="samples per GPU batch")
+    g.add_argument("--gpu-inflate", action="store_true",
+                   help="inflate the BAMs' BGZF blocks on the GPU, --batch-samples samples per launch (needs --cpus > 1; "
+                        "pays when several driver processes share the host's cores: see DESIGN.md 4.4)")
     g.add_argument("--maxinsert", type=int, default=300, help="largest allele considered, in repeat units")
     g.add_argument("--fullsearch", action="store_true", help="evaluate every allele pair up to --maxinsert")
     g = p.add_argument_group("I/O options")
@@ -722,7 +725,8 @@ def main(args, quiet=False):
                     if not args.no_output:
                         write_vcf_json(result, args.ref, repo, loci, quiet=quiet)
                 run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus),
-                         lazy_details=True, background_sink=args.cpus > 1)
+                         lazy_details=True, background_sink=args.cpus > 1,
+                         inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None)
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
         os.chdir(cwd)
