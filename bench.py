@@ -426,6 +426,7 @@ def e2e_main(args):
     repo = TREDsRepo("hg38", sites=os.path.join(args.e2e_child, "no_sites"))
     names = [l["name"] for l in synth_bam.bench_loci()]
     tasks = [(os.path.basename(b)[:-4], b, repo, names, 300, False, False, True, True, "ERROR") for b in bams[lo:hi]]
+    tasks = tasks * max(1, args.e2e_repeat)       # a longer cohort out of the same files (outputs are rewritten)
     threads = max(1, min(args.e2e_threads or max(1, (shard.usable_cpus() - world) // world), max(len(tasks), 1)))
     engine = Engine(0)
     work = os.path.join(args.e2e_child, "work{}".format(rank))
@@ -518,7 +519,8 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
             for drivers, threads, gpu_inflate in plans:
                 batch = args.e2e_inflate_batch if gpu_inflate else args.e2e_batch
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
-                        "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0"]
+                        "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
+                        "--e2e-repeat", str(args.e2e_repeat)]
                 out_dir = os.path.join(root, "out{}x{}{}".format(n_devices, drivers, "g" if gpu_inflate else ""))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
@@ -546,6 +548,7 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
             rec["devices"] = n_devices
             rec.setdefault("samples_per_gpu_batch", args.e2e_batch)
             rec["bam_generation_seconds"] = gen_s
+            rec["cohort"] = "{} BAM files x {} passes per leg".format(n_files, max(1, args.e2e_repeat))
             rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
                            "native scan (BGZF inflate -- on the host, or on the GPU a batch of samples per launch in the `gpu_inflate` legs --, BAI queries, read selection, pair lengths, depth) in host threads -> "
                            "GPU batches -> tredCalls -> JSON + VCF files; `drivers` processes over `devices` GPUs (rank r on "
@@ -689,7 +692,8 @@ def main():
     ap.add_argument("--e2e-gpu-inflate", choices=("0", "1", "both"), default="both",
                     help="end-to-end legs with the BAMs' BGZF blocks inflated on the GPU (tred.run_many inflate_device): "
                          "0 host only, 1 GPU only, both")
-    ap.add_argument("--e2e-inflate-batch", type=int, default=32, help="samples per GPU batch (and inflate launch) in those legs")
+    ap.add_argument("--e2e-repeat", type=int, default=3, help="every driver goes over its BAMs this many times (a longer cohort from the same files)")
+    ap.add_argument("--e2e-inflate-batch", type=int, default=28, help="samples per GPU batch (and inflate launch) in those legs")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-limit", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -142,8 +142,8 @@ typedef struct tredbam_pools {   /* memory owned by the handle, valid until its 
 
 /* Blocks inflated elsewhere -- on the GPU, include/tredgpu.h section 4 -- instead of by the scan itself (two thirds of a
  * scan's time is DEFLATE decoding):
- *   tredbam_plan       the BGZF blocks the region walks of tredbam_scan(sites, alts, opts) will read, from the index
- *                      alone; returns their number, *comp_bytes = room their payloads take when each starts on a 4-byte
+ *   tredbam_plan       the BGZF blocks the region walks of tredbam_scan(sites, alts, opts) -- and of the caller's other
+ *                      queries over the `extra` regions -- will read, from the index alone; returns their number, *comp_bytes = room their payloads take when each starts on a 4-byte
  *                      boundary, *out_bytes = their inflated size.
  *   tredbam_plan_fill  copies the payloads to comp + comp_off[k] from comp_base on and lays the outputs out from
  *                      out_base on; entry n of both offset arrays receives the end (= the next sample's bases).
@@ -154,7 +154,8 @@ typedef struct tredbam_pools {   /* memory owned by the handle, valid until its 
  *   tredbam_preload_clear  forgets them (before the caller reuses the memory); reports how many block loads of the
  *                      scans since tredbam_preload were served from the preloaded set / were not. */
 int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
-                     const tredbam_scan_opts* o, int64_t* comp_bytes, int64_t* out_bytes);
+                     const tredbam_scan_opts* o, const tredbam_region* extra, int32_t n_extra, int64_t* comp_bytes,
+                     int64_t* out_bytes);
 int tredbam_plan_fill(tredbam* b, uint8_t* comp, int64_t comp_base, int64_t out_base, int64_t* comp_off, int64_t* out_off);
 int tredbam_preload(tredbam* b, const uint8_t* out, const int64_t* out_off, const int32_t* status);
 void tredbam_preload_clear(tredbam* b, int64_t* hits, int64_t* misses);

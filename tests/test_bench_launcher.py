@@ -101,7 +101,7 @@ def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
         return [0] * world
 
     args = argparse.Namespace(e2e_samples=128, seed=1, e2e_drivers=0, e2e_threads=0, e2e_batch=16, rank_timeout=60,
-                              e2e_gpu_inflate="0", e2e_inflate_batch=32)
+                              e2e_gpu_inflate="0", e2e_inflate_batch=32, e2e_repeat=1)
     recs = bench.run_e2e(args, [1, 2, 8], spawn=fake_spawn, make_bams=fake_bams)
     assert made == [512]                                            # one set of files: 8 GPUs x 64 (capped at 512)
     assert sorted(recs) == [1, 2, 8]

@@ -89,19 +89,29 @@ class SampleScan(object):
         return self.global_lens[g0:g0 + int(u["n_global"])], self.target_lens[t0:t0 + int(u["n_target"])]
 
 
+_y_region_cache = {}
+
+
+def y_regions(build):
+    """(contig, start, end) of the first five usable single-copy chrY regions of the build's table."""
+    if build not in _y_region_cache:
+        table = os.path.join(_PKG, "data", "chrY.{}.unique_ccn.tsv".format(build.split("_")[0]))
+        out = []
+        with open(table) as fp:
+            for i, line in enumerate(fp):
+                if i in _Y_SKIP:
+                    continue
+                if len(out) == 5:
+                    break
+                contig, lo, hi = line.split()[:3]
+                out.append((contig, int(lo), int(hi)))
+        _y_region_cache[build] = out
+    return _y_region_cache[build]
+
+
 def _y_depth(f, build):
     """Median pileup depth of the first five usable single-copy chrY regions (sex inference)."""
-    table = os.path.join(_PKG, "data", "chrY.{}.unique_ccn.tsv".format(build.split("_")[0]))
-    depths = []
-    with open(table) as fp:
-        for i, line in enumerate(fp):
-            if i in _Y_SKIP:
-                continue
-            if len(depths) == 5:
-                break
-            contig, lo, hi = line.split()[:3]
-            lo, hi = int(lo), int(hi)
-            depths.append(f.pileup_depth_sum(contig, lo, hi) / float(hi - lo + 1))
+    depths = [f.pileup_depth_sum(contig, lo, hi) / float(hi - lo + 1) for contig, lo, hi in y_regions(build)]
     return float(np.median(depths))
 
 

@@ -359,7 +359,7 @@ def _native():
             lib.tredbam_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p]
             lib.tredbam_scan.restype = C.c_int
             lib.tredbam_scan_pools.argtypes = [C.c_void_p, C.POINTER(Pools)]
-            lib.tredbam_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts),
+            lib.tredbam_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p, C.c_int32,
                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
             lib.tredbam_plan.restype = C.c_int64
             lib.tredbam_plan_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
@@ -723,15 +723,19 @@ class NativeAlignmentFile(object):
 
     # ---- blocks inflated elsewhere (the GPU's batch decoder, _lib.Inflater) ----
     def plan(self, sites, alts, readlen, pad=1000, flank=9, pe_reach=10000, span=1000, use_alts=True, want_depth=True,
-             want_pe=True):
+             want_pe=True, extra=()):
         """tredbam_plan: the BGZF blocks scan(...) with the same arguments will read -> (n_blocks, bytes their payloads
-        take in a staging buffer, bytes they inflate to)."""
+        take in a staging buffer, bytes they inflate to).  extra: (contig, start, end) of other queries to cover."""
         sites = np.ascontiguousarray(sites, SITE_DTYPE)
         alts = np.ascontiguousarray(alts if len(alts) else np.zeros(1, REGION_DTYPE), REGION_DTYPE)
         o = ScanOpts(int(readlen), int(pad), int(flank), int(pe_reach), int(span), int(bool(use_alts)),
                      int(bool(want_depth)), int(bool(want_pe)))
         cb, ob = C.c_int64(), C.c_int64()
-        n = self._lib.tredbam_plan(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o), C.byref(cb), C.byref(ob))
+        ex = np.zeros(max(len(extra), 1), REGION_DTYPE)
+        for k, (contig, lo, hi) in enumerate(extra):
+            ex[k] = (self._tid.get(contig, -1), lo, hi)
+        n = self._lib.tredbam_plan(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o), ex.ctypes.data, len(extra),
+                                   C.byref(cb), C.byref(ob))
         if n < 0:
             raise ValueError(self._err())
         return int(n), cb.value, ob.value

@@ -216,7 +216,7 @@ int load_block(tredbam* b, int64_t coffset) {
         }
         ++b->preload_misses;
     }
-    BlockFrame fr;
+    BlockFrame fr = {};
     const uint8_t* comp = nullptr;
     {
         const int rc = block_frame(b, coffset, fr, &comp);
@@ -1115,10 +1115,14 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
 // ---- blocks inflated elsewhere (include/tredbam.h) ----------------------------------------------------------------
 // The BGZF blocks the region walks of tredbam_scan(sites ...) will read: every block from the start of a merged chunk to
 // its end -- or, sooner, to the linear index' offset two 16 kb windows behind the region's end (records from there on
-// start behind the region; a block left out by that cut is simply inflated by load_block when the walk gets there).
+// start behind the region; a block left out by that cut is simply inflated by load_block when the walk gets there:
+// on the bench's BAMs, whose index repeats the last offset in empty windows, the cut leaves a sixth of the block
+// loads to the host -- and the end-to-end rate is higher for it, 12.9 k against 11.8 k genotypes/s, because the GPU's
+// decoder, not the host, is the busier side there).
 int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
-                     const tredbam_scan_opts* o, int64_t* comp_bytes, int64_t* out_bytes) {
-    if (!b || !o || n_sites < 0 || (n_sites > 0 && !sites)) return -2;
+                     const tredbam_scan_opts* o, const tredbam_region* extra, int32_t n_extra, int64_t* comp_bytes,
+                     int64_t* out_bytes) {
+    if (!b || !o || n_sites < 0 || (n_sites > 0 && !sites) || n_extra < 0 || (n_extra > 0 && !extra)) return -2;
     b->plan.clear();
     std::unordered_map<int64_t, bool> seen;
     std::vector<std::pair<uint64_t, uint64_t>> merged;
@@ -1127,13 +1131,13 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
         uint64_t cap = ~0ull;
         if (tid < (int32_t)b->index.size()) {
             const auto& lin = b->index[tid].linear;
-            const size_t w = (size_t)(std::max<int64_t>(end, 1) - 1 >> 14) + 2;
+            const size_t w = (size_t)((std::max<int64_t>(end, 1) - 1) >> 14) + 2;
             if (w < lin.size() && lin[w] != 0) cap = lin[w];
         }
         for (const auto& ch : merged) {
             const int64_t last = (int64_t)(std::min(ch.second, cap) >> 16);
             for (int64_t at = (int64_t)(ch.first >> 16); at <= last;) {
-                BlockFrame fr;
+                BlockFrame fr = {};
                 const uint8_t* comp = nullptr;
                 const int rc = block_frame(b, at, fr, &comp);
                 if (rc <= 0) break;                                        // end of file / damaged frame: left to the scan
@@ -1159,6 +1163,8 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
                 if (a.tid >= 0) add_region(a.tid, a.start, a.end);
             }
     }
+    for (int32_t k = 0; k < n_extra; ++k)          // other queries of the caller on this handle (the chrY depth windows)
+        if (extra[k].tid >= 0) add_region(extra[k].tid, extra[k].start, extra[k].end);
     int64_t cb = 0, ob = 0;
     for (const auto& p : b->plan) { cb += ((int64_t)p.payload_len + 3) & ~(int64_t)3; ob += p.isize; }
     if (comp_bytes) *comp_bytes = cb;

@@ -390,7 +390,11 @@ int tredgpu_inflater_create(int device_id, tredgpu_inflater** out) {
     if (device_id < 0 || device_id >= n) return ifail(nullptr, -2, "device out of range");
     tredgpu_inflater* f = new tredgpu_inflater();
     f->device = device_id;
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess ||
+    // the lowest stream priority: a genotyping launch of the same or another driver process should not queue up behind
+    // several of these (kernels of different streams run one after the other here, and one of these takes 20-40 ms)
+    int lo_prio = 0, hi_prio = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, lo_prio)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&f->done, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) {
         if (f->stream) (void)hipStreamDestroy(f->stream);
         delete f;

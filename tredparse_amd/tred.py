@@ -167,7 +167,7 @@ def collect_sample(arg):
 # itself as before: the results cannot differ.
 def _plan_sample(arg):
     """Thread: open the BAM and list the blocks its scan will read.  None: no GPU help for this sample."""
-    from .bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays, open_bam
+    from .bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays, open_bam, y_regions
     o = _options(arg)
     try:
         f = open_bam(o["bam"])
@@ -179,8 +179,9 @@ def _plan_sample(arg):
         readlen = f.max_read_len(101)
         loci = [o["repo"][n] for n in o["names"]]
         sites, regions = _site_arrays(o["repo"], o["names"], loci, f)
+        sexed = any(t.is_xlinked for t in loci)          # scan_sample then asks for the chrY depth windows too
         n, cbytes, obytes = f.plan(sites, regions, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN,
-                                   use_alts=o["alts"] and not o["clip"])
+                                   use_alts=o["alts"] and not o["clip"], extra=y_regions(o["repo"].ref) if sexed else ())
         return {"handle": f, "readlen": readlen, "n": n, "cbytes": cbytes, "obytes": obytes}
     except Exception:
         f.close()
