@@ -469,13 +469,16 @@ def e2e_main(args):
     shutil.rmtree(work, ignore_errors=True)
 
 
-def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0):
+def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0, dense=False):
     """[(ranks, threads per rank)] of the end-to-end legs on n_devices GPUs with `usable` host CPUs: one driver per
     GPU, and as many drivers per GPU as keep ~7 or ~4 scan threads busy each (a driver formats and hands its results
-    to a writer thread while its threads scan).
+    to a writer thread while its threads scan); dense: also one driver per four CPUs (the legs whose BGZF blocks the GPU
+    inflates leave the host a third of the work per sample: the drivers' own threads become the bound sooner).
     Rank r works on device r mod n_devices; every rank gets an equal share of the CPUs."""
     g = max(1, n_devices)
     tried = [drivers_opt] if drivers_opt else [max(1, usable // (8 * g)), max(1, usable // (5 * g))]
+    if dense and not drivers_opt:
+        tried.append(max(1, usable // (4 * g)))
     plans = []
     for dpg in sorted(set([1] + tried)):
         ranks = dpg * n_devices
@@ -513,8 +516,8 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
             n_files = n_devices * per_gpu[n_devices]
             plans = [(d, t, False) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads)]
             if args.e2e_gpu_inflate in ("1", "both"):
-                # the same plans with the BGZF blocks inflated on the GPU, a batch of samples per launch
-                with_gpu = [(d, t, True) for d, t, _ in plans]
+                # the same plans (and a denser one) with the BGZF blocks inflated on the GPU, a batch of samples per launch
+                with_gpu = [(d, t, True) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads, dense=True)]
                 plans = with_gpu if args.e2e_gpu_inflate == "1" else plans + with_gpu
             for drivers, threads, gpu_inflate in plans:
                 batch = args.e2e_inflate_batch if gpu_inflate else args.e2e_batch
@@ -693,7 +696,7 @@ def main():
                     help="end-to-end legs with the BAMs' BGZF blocks inflated on the GPU (tred.run_many inflate_device): "
                          "0 host only, 1 GPU only, both")
     ap.add_argument("--e2e-repeat", type=int, default=3, help="every driver goes over its BAMs this many times (a longer cohort from the same files)")
-    ap.add_argument("--e2e-inflate-batch", type=int, default=28, help="samples per GPU batch (and inflate launch) in those legs")
+    ap.add_argument("--e2e-inflate-batch", type=int, default=16, help="samples per GPU batch (and inflate launch) in those legs")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-limit", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -214,6 +214,9 @@ class _InflateFeeder(object):
         import threading
         from ._lib import Inflater
         self.chunks, self.ex = chunks, ex
+        # plans and fills have threads of their own: queued behind a chunk's 28 scans in the scan pool they started only
+        # when those were done, and the pool then idled through the next chunk's decode
+        self.prep = ThreadPoolExecutor(max_workers=2)
         self.inflaters = [Inflater(device), Inflater(device)]
         self.busy = [[], []]
         self.q = queue.Queue(maxsize=2)
@@ -225,7 +228,7 @@ class _InflateFeeder(object):
         inf, slot = self.inflaters[ci % 2], ci % 2
         for fut in self.busy[slot]:
             fut.exception()                            # (waits; the consumer sees the error itself)
-        plans = [fut.result() for fut in [self.ex.submit(_plan_sample, a) for a in chunk]]
+        plans = [fut.result() for fut in [self.prep.submit(_plan_sample, a) for a in chunk]]
         live = [p for p in plans if p is not None and p["n"] > 0]
         t0 = time.perf_counter()
         status = None
@@ -237,7 +240,7 @@ class _InflateFeeder(object):
                 fills = []
                 for p in live:
                     p["first"] = at
-                    fills.append(self.ex.submit(p["handle"].plan_fill, inf.comp_addr, cb, ob, coff[at:at + p["n"] + 1],
+                    fills.append(self.prep.submit(p["handle"].plan_fill, inf.comp_addr, cb, ob, coff[at:at + p["n"] + 1],
                                                 ooff[at:at + p["n"] + 1]))
                     at, cb, ob = at + p["n"], cb + p["cbytes"], ob + p["obytes"]
                 for fut in fills:
@@ -280,6 +283,7 @@ class _InflateFeeder(object):
         for slot in self.busy:
             for fut in slot:
                 fut.exception()
+        self.prep.shutdown()
         for inf in self.inflaters:
             inf.close()
 
