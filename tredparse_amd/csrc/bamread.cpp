@@ -1117,8 +1117,8 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
 // its end -- or, sooner, to the linear index' offset two 16 kb windows behind the region's end (records from there on
 // start behind the region; a block left out by that cut is simply inflated by load_block when the walk gets there:
 // on the bench's BAMs, whose index repeats the last offset in empty windows, the cut leaves a sixth of the block
-// loads to the host -- and the end-to-end rate is higher for it, 12.9 k against 11.8 k genotypes/s, because the GPU's
-// decoder, not the host, is the busier side there).
+// loads to the host -- and the end-to-end rate was higher for it when measured, 12.9 k against 11.8 k genotypes/s:
+// the decode launches, not the host, were the busier side).
 int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
                      const tredbam_scan_opts* o, const tredbam_region* extra, int32_t n_extra, int64_t* comp_bytes,
                      int64_t* out_bytes) {
