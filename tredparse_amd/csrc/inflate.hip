@@ -33,7 +33,13 @@ constexpr int MAXBITS = 15, MAXL = 288, MAXD = 32, MAXLENS = 320;
 // uint16 entries per lane: count[16] + symbol[288] for literal/length codes, count[16] + symbol[32] for distances,
 // then per code where canonical decoding resumes behind the direct table (first code and symbol index at length
 // FAST + 1) and the direct tables: the next FAST bits of the stream -> symbol | length << 9 (0: a longer code)
-constexpr int FASTL = 9, FASTD = 7;
+// (7 / 4 bits make it 64 KB per wavefront and two wavefronts per CU: 809 samples/s with 56 samples per launch against
+//  664, but 608 against 660 with 28, and 25 ms instead of 21 for a single sample)
+#ifndef FASTL_BITS
+#define FASTL_BITS 9
+#define FASTD_BITS 7
+#endif
+constexpr int FASTL = FASTL_BITS, FASTD = FASTD_BITS;
 constexpr int T_LCNT = 0, T_LSYM = 16, T_DCNT = 16 + MAXL, T_DSYM = 32 + MAXL, T_LCONT = 32 + MAXL + MAXD, T_DCONT = T_LCONT + 2,
               T_LFAST = T_DCONT + 2, T_DFAST = T_LFAST + (1 << FASTL), T_ENTRIES = T_DFAST + (1 << FASTD);
 static_assert(T_ENTRIES * LANES * 2 <= 160 * 1024, "one wavefront's tables fit the CU's LDS");
