@@ -110,3 +110,18 @@ def test_run_many_with_gpu_inflated_blocks_gives_the_same_results(engine, tmp_pa
     t = tredmod.TIMING
     assert t["inflate_blocks"] > 500 and t["inflate_failed"] == 0
     assert t["inflate_hits"] > 20 * max(t["inflate_misses"], 1)
+
+
+def test_cli_gpu_inflate_writes_the_same_files(engine, tmp_path, monkeypatch):
+    """python -m tredparse_amd.tred ... --cpus 3 --gpu-inflate against the plain run: the same bytes in every output."""
+    rows = "".join("{0},{1}/{2}.bam,{3}\n".format(key, os.path.join(GOLD, "bam"), bam, tred)
+                   for key, bam, tred in (("a", "t001", "HD"), ("b", "t002", "DM1"), ("c", "t001", "HD"), ("d", "t002", "DM1")))
+    csv = tmp_path / "samples.csv"
+    csv.write_text("#SampleKey,BAM,TRED\n" + rows)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr("tredparse_amd.engine.Engine", lambda *a, **k: engine)
+    tredmod.main([str(csv), "--workdir", str(tmp_path / "plain"), "--cpus", "3", "--batch-samples", "2"], quiet=True)
+    tredmod.main([str(csv), "--workdir", str(tmp_path / "helped"), "--cpus", "3", "--batch-samples", "2", "--gpu-inflate"], quiet=True)
+    for key in "abcd":
+        assert open(tmp_path / "plain" / (key + ".json")).read() == open(tmp_path / "helped" / (key + ".json")).read()
+        assert gzip.open(tmp_path / "plain" / (key + ".tred.vcf.gz")).read() == gzip.open(tmp_path / "helped" / (key + ".tred.vcf.gz")).read()

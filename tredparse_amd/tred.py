@@ -453,7 +453,12 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     writer = _Writer(sink) if (background_sink and sink is not None) else None
     if writer is not None:
         sink = writer
-    feeder = _InflateFeeder(chunks, ex, inflate_device) if (inflate_device is not None and ex is not None) else None
+    feeder = None
+    if inflate_device is not None and ex is not None:
+        try:
+            feeder = _InflateFeeder(chunks, ex, inflate_device)
+        except Exception as e:       # no pinned memory, no device ...: the scans inflate for themselves
+            logging.getLogger("tredparse_amd").warning("GPU inflate not available (%s): BGZF blocks are inflated on the host", e)
     try:
         submit = (lambda c: [ex.submit(collect_sample, a) for a in c]) if ex is not None else None
         ahead = deque()
