@@ -130,3 +130,42 @@ def test_many_blocks_in_one_call(inf):
     status, got = _inflate(inf, payloads, [65280] * len(payloads))
     assert (status == 0).all()
     assert all(got[k] == datas[k % 40] for k in range(0, len(payloads), 37))
+
+
+def test_corrupted_streams_never_write_or_read_out_of_bounds(inf):
+    """Bit flips, truncations and garbage -- also in the last payload of the staging buffer, where a stream that keeps
+    asking for bits would run off the end: every block comes back with a status, blocks that zlib still inflates to the
+    expected size are byte-identical, the neighbours of a damaged block are untouched."""
+    rng = np.random.default_rng(17)
+    good = [_bam_like(rng, int(rng.choice([3000, 20000, 65280]))) for _ in range(24)]
+    payloads, sizes, want = [], [], []
+    for k in range(400):
+        d = good[k % len(good)]
+        p = bytearray(_raw(d, int(rng.choice([1, 6, 9]))))
+        kind = k % 5
+        if kind == 1:
+            for _ in range(int(rng.integers(1, 4))):
+                p[int(rng.integers(len(p)))] ^= 1 << int(rng.integers(8))
+        elif kind == 2:
+            p = p[:int(rng.integers(1, len(p)))]
+        elif kind == 3:
+            p = bytearray(rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8).tobytes())
+        payloads.append(bytes(p))
+        sizes.append(len(d))
+        try:
+            got = zlib.decompressobj(-15).decompress(bytes(p))
+            want.append(got if len(got) == len(d) else None)
+        except zlib.error:
+            want.append(None)
+    for last in (2, 3, 1):                                    # a truncated / garbage / bit-flipped stream last in the buffer
+        order = [k for k in range(400) if k % 5 != last] + [k for k in range(400) if k % 5 == last]
+        status, got = _inflate(inf, [payloads[k] for k in order], [sizes[k] for k in order])
+        for j, k in enumerate(order):
+            if k % 5 in (0, 4):
+                assert status[j] == 0 and got[j] == good[k % len(good)], k
+            elif status[j] == 0 and want[k] is not None:
+                assert got[j] == want[k], k                   # (a flip the stream survives: same bytes as zlib's)
+            elif want[k] is None and status[j] == 0:
+                # zlib refuses what the decoder took: only possible where zlib asks for more than a valid prefix
+                # (trailing garbage / a missing end); the host's CRC-32 check is what catches these
+                assert len(got[j]) == sizes[k]

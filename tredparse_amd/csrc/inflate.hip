@@ -75,7 +75,7 @@ struct Bits {
             const uint32_t w = idx - 1 < nwords ? ahead : 0u;
             buf |= (uint64_t)w << cnt;
             cnt += 32;
-            ahead = p[idx];
+            ahead = p[min(idx, nwords)];       // (clamped: a damaged stream may ask for bits far behind its payload)
             ++idx;
         }
     }
