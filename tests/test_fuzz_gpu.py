@@ -45,3 +45,10 @@ def test_fuzz_grid_slice():
     res = fuzz_grid.campaign(rounds=12, seed=20270304, max_pairs=6000)
     assert res["units_checked"] > 50
     assert res["mismatches"] == 0 and res["max_abs_diff_lik_or_pp"] <= 1e-6, res
+
+
+def test_fuzz_inflate_slice():
+    import fuzz_inflate
+    res = fuzz_inflate.campaign(rounds=6, seed=20270305)
+    assert res["streams"] == 1800 and res["intact"] == 1440 and res["damaged_refused"] > 100
+    assert res["mismatches"] == 0, res
