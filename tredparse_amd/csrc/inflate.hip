@@ -91,8 +91,17 @@ struct Bits {
 
 // one symbol of a canonical code: the direct table on the next FB bits, else canonical decoding from length FB + 1
 // on (count[len] at tab[(cnt0 + len) * LANES], symbols sorted by code at tab[(sym0 + k) * LANES]); -1: no such code
+// What canonical decoding needs for the codes longer than the direct table's FB bits, in registers (the kernel runs one
+// wavefront per SIMD: registers are free, and with 64 lanes some lane has a long code in most trips; from LDS the six
+// counts of a literal/length look-up were a chain of six LDS latencies -- worth 2 % of the kernel, 21.0 -> 20.6 ms)
 template <int FB>
-__device__ __forceinline__ int decode(Bits& b, const uint16_t* tab, int fast0, int cont0, int cnt0, int sym0) {
+struct LongCodes {
+    int first, index;            // first code and symbol index at length FB + 1
+    int count[MAXBITS - FB];     // codes of length FB + 1 .. 15
+};
+
+template <int FB>
+__device__ __forceinline__ int decode(Bits& b, const uint16_t* tab, int fast0, const LongCodes<FB>& C, int sym0) {
     b.refill();
     const uint32_t bits = (uint32_t)b.buf;
     const uint32_t e = tab[(fast0 + (int)(bits & ((1u << FB) - 1u))) * LANES];
@@ -103,23 +112,24 @@ __device__ __forceinline__ int decode(Bits& b, const uint16_t* tab, int fast0, i
         return (int)(e & 511u);
     }
     int code = (int)(__builtin_bitreverse32(bits) >> (32 - FB)) << 1;   // the first FB bits as a code, room for the next
-    int first = tab[(cont0 + 0) * LANES], index = tab[(cont0 + 1) * LANES];
+    int first = C.first, index = C.index;
     uint32_t rest = bits >> FB;
+    int found = -1, flen = 0;
+#pragma unroll
     for (int len = FB + 1; len <= MAXBITS; ++len) {
         code |= (int)(rest & 1u);
         rest >>= 1;
-        const int count = tab[(cnt0 + len) * LANES];
-        if (code - count < first) {
-            b.buf >>= len;
-            b.cnt -= len;
-            return tab[(sym0 + index + (code - first)) * LANES];
-        }
+        const int count = C.count[len - FB - 1];
+        if (found < 0 && code - count < first) { found = index + (code - first); flen = len; }
         index += count;
         first += count;
         first <<= 1;
         code <<= 1;
     }
-    return -1;
+    if (found < 0) return -1;
+    b.buf >>= flen;
+    b.cnt -= flen;
+    return tab[(sym0 + found) * LANES];
 }
 
 // the code-length code (19 symbols, at most 7 bits): plain canonical decoding, bit by bit
@@ -166,7 +176,7 @@ __device__ int construct(uint16_t* tab, int cnt0, int sym0, const uint8_t* lens,
 // the direct table of a code already constructed: every code of at most FB bits fills the 2^(FB - len) entries whose
 // low bits are its bits in stream order; and where canonical decoding resumes for the longer ones
 template <int FB>
-__device__ void construct_fast(uint16_t* tab, int fast0, int cont0, int cnt0, const uint8_t* lens, int n) {
+__device__ void construct_fast(uint16_t* tab, int fast0, LongCodes<FB>& C, int cnt0, const uint8_t* lens, int n) {
     for (int k = 0; k < (1 << FB); ++k) tab[(fast0 + k) * LANES] = 0;
     uint16_t next[FB + 2];
     int first = 0, index = 0;
@@ -176,8 +186,10 @@ __device__ void construct_fast(uint16_t* tab, int fast0, int cont0, int cnt0, co
         index += count;
         first = (first + count) << 1;
     }
-    tab[(cont0 + 0) * LANES] = (uint16_t)first;
-    tab[(cont0 + 1) * LANES] = (uint16_t)index;
+    C.first = first;
+    C.index = index;
+#pragma unroll
+    for (int l = FB + 1; l <= MAXBITS; ++l) C.count[l - FB - 1] = tab[(cnt0 + l) * LANES];
     for (int s = 0; s < n; ++s) {
         const int l = lens[s];
         if (l == 0 || l > FB) continue;
@@ -209,13 +221,15 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
     b.start(comp + (c0 >> 2), (int)((c1 - c0 + 3) >> 2));
     int st = (c1 - c0) > 0 ? ST_HDR : ST_ERR;
     int opos = 0, last = 0, mlen = 0, mdist = 0, mspan = 0;
+    LongCodes<FASTL> longL = {};
+    LongCodes<FASTD> longD = {};
     while (st < ST_DONE) {
         // (the three states are tried one after the other in every trip: a match decoded in this trip makes its first
         //  copy step in it -- most matches of a BAM block are shorter than one step --, an end-of-block code goes on to
         //  the next header: 25.5 -> 21.4 ms per 556-block sample.  Several literals per trip were slower: 24 ms with two,
         //  27 with three -- the lanes that have a match wait)
         if (st == ST_SYM) {
-            int sym = decode<FASTL>(b, tab, T_LFAST, T_LCONT, T_LCNT, T_LSYM);
+            int sym = decode<FASTL>(b, tab, T_LFAST, longL, T_LSYM);
             if (sym < 0) st = ST_ERR;
             else if (sym < 256) {
                 if (opos < olen) o[opos++] = (uint8_t)sym; else st = ST_ERR;
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
                     int base, extra;
                     len_code(sym, base, extra);
                     mlen = base + (int)b.get(extra);
-                    const int ds = decode<FASTD>(b, tab, T_DFAST, T_DCONT, T_DCNT, T_DSYM);
+                    const int ds = decode<FASTD>(b, tab, T_DFAST, longD, T_DSYM);
                     if (ds < 0 || ds >= 30) st = ST_ERR;
                     else {
                         dist_code(ds, base, extra);
@@ -279,10 +293,10 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
                 for (int s = 256; s < 280; ++s) lens[s] = 7;
                 for (int s = 280; s < MAXL; ++s) lens[s] = 8;
                 construct(tab, T_LCNT, T_LSYM, lens, MAXL);
-                construct_fast<FASTL>(tab, T_LFAST, T_LCONT, T_LCNT, lens, MAXL);
+                construct_fast<FASTL>(tab, T_LFAST, longL, T_LCNT, lens, MAXL);
                 for (int s = 0; s < 30; ++s) lens[s] = 5;
                 construct(tab, T_DCNT, T_DSYM, lens, 30);
-                construct_fast<FASTD>(tab, T_DFAST, T_DCONT, T_DCNT, lens, 30);
+                construct_fast<FASTD>(tab, T_DFAST, longD, T_DCNT, lens, 30);
                 st = ST_SYM;
             } else if (type == 2) {
                 const int nlen = (int)b.get(5) + 257, ndist = (int)b.get(5) + 1, ncode = (int)b.get(4) + 4;
@@ -321,8 +335,8 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
                                 err = construct(tab, T_DCNT, T_DSYM, lens + nlen, ndist);
                                 if (err < 0 || (err > 0 && ndist - tab[(T_DCNT + 0) * LANES] != 1)) st = ST_ERR;
                                 else {
-                                    construct_fast<FASTL>(tab, T_LFAST, T_LCONT, T_LCNT, lens, nlen);
-                                    construct_fast<FASTD>(tab, T_DFAST, T_DCONT, T_DCNT, lens + nlen, ndist);
+                                    construct_fast<FASTL>(tab, T_LFAST, longL, T_LCNT, lens, nlen);
+                                    construct_fast<FASTD>(tab, T_DFAST, longD, T_DCNT, lens + nlen, ndist);
                                     st = ST_SYM;
                                 }
                             }
