@@ -1114,11 +1114,9 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
 
 // ---- blocks inflated elsewhere (include/tredbam.h) ----------------------------------------------------------------
 // The BGZF blocks the region walks of tredbam_scan(sites ...) will read: every block from the start of a merged chunk to
-// its end -- or, sooner, to the linear index' offset two 16 kb windows behind the region's end (records from there on
-// start behind the region; a block left out by that cut is simply inflated by load_block when the walk gets there:
-// on the bench's BAMs, whose index repeats the last offset in empty windows, the cut leaves a sixth of the block
-// loads to the host -- and the end-to-end rate was higher for it when measured, 12.9 k against 11.8 k genotypes/s:
-// the decode launches, not the host, were the busier side).
+// its end -- or, sooner, to the linear index' offset two 16 kb windows behind the region's end when that window has a
+// record of its own (records from there on start behind the region).  A block the plan leaves out is simply inflated by
+// load_block when a walk gets there.
 int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
                      const tredbam_scan_opts* o, const tredbam_region* extra, int32_t n_extra, int64_t* comp_bytes,
                      int64_t* out_bytes) {
@@ -1132,7 +1130,8 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
         if (tid < (int32_t)b->index.size()) {
             const auto& lin = b->index[tid].linear;
             const size_t w = (size_t)((std::max<int64_t>(end, 1) - 1) >> 14) + 2;
-            if (w < lin.size() && lin[w] != 0) cap = lin[w];
+            // (an entry equal to its predecessor is a window without a record of its own, filled in from before it)
+            if (w < lin.size() && lin[w] != 0 && lin[w] > lin[w - 1]) cap = lin[w];
         }
         for (const auto& ch : merged) {
             const int64_t last = (int64_t)(std::min(ch.second, cap) >> 16);
