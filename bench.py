@@ -704,6 +704,11 @@ def main():
     if args.coverage is None:
         args.coverage = WORKLOADS[args.workload]["synth"].get("coverage", 30.0)
     args.coverage_used = args.coverage
+    if args.e2e_child or ("RANK" in os.environ and "WORLD_SIZE" in os.environ):
+        # a rank: onto the CPUs of its GPU's NUMA node (TRED_CPUSET from shard.spawn_ranks) before anything touches the
+        # GPU or allocates pinned memory
+        from tredparse_amd import shard as _sh
+        _sh.apply_rank_cpuset()
     if args.e2e_child:
         return e2e_main(args)
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:     # a rank (torch.distributed.run or our launcher)

@@ -148,8 +148,9 @@ typedef struct tredbam_pools {   /* memory owned by the handle, valid until its 
  *   tredbam_plan_fill  copies the payloads to comp + comp_off[k] from comp_base on and lays the outputs out from
  *                      out_base on; entry n of both offset arrays receives the end (= the next sample's bases).
  *   tredbam_preload    hands the inflated blocks in: block k at out + out_off[k] when status[k] == 0.  The handle keeps
- *                      pointers only; the next scan takes these blocks from there (CRC-32 checked at first use) and
- *                      inflates whatever else it needs itself, so a plan may miss blocks without harm.  Returns the
+ *                      pointers only; the next scan takes these blocks from there (CRC-32 checked at first use; a
+ *                      block that fails it is dropped and inflated by the scan) and inflates whatever else it
+ *                      needs itself, so a plan may miss blocks without harm.  Returns the
  *                      number of blocks taken.
  *   tredbam_preload_clear  forgets them (before the caller reuses the memory); reports how many block loads of the
  *                      scans since tredbam_preload were served from the preloaded set / were not. */
@@ -158,6 +159,10 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
                      int64_t* out_bytes);
 int tredbam_plan_fill(tredbam* b, uint8_t* comp, int64_t comp_base, int64_t out_base, int64_t* comp_off, int64_t* out_off);
 int tredbam_preload(tredbam* b, const uint8_t* out, const int64_t* out_off, const int32_t* status);
+/* The same when the decoder also delivers the CRC-32 of every block it wrote (tredgpu_inflate_blocks_crc): a block whose
+ * checksum equals its BGZF trailer's is taken as verified -- the scan does not walk its bytes again --, one whose
+ * checksum differs is not taken at all and is inflated and checked by the scan itself. */
+int tredbam_preload_crc(tredbam* b, const uint8_t* out, const int64_t* out_off, const int32_t* status, const uint32_t* crc);
 void tredbam_preload_clear(tredbam* b, int64_t* hits, int64_t* misses);
 
 int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,

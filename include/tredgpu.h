@@ -292,7 +292,8 @@ int tredgpu_get_sw_counters(tredgpu_ctx* ctx, uint64_t out[8]);
  *                             comp_off_host[n_blocks+1] / out_off_host[n_blocks+1] (fill: byte offsets into the two
  *                             buffers; every payload starts on a 4-byte boundary; out sizes <= 65536).  The pointers
  *                             stay valid until the next reserve that has to grow, or destroy.
- *   tredgpu_inflate_blocks    copies in, decodes, copies out, waits.  status[k]: 0, -1 invalid stream (or it runs
+ *   tredgpu_inflate_blocks    copies in, decodes, copies out (in slices: the copy-out of one slice runs beside the
+ *                             decoding of the next), waits.  status[k]: 0, -1 invalid stream (or it runs
  *                             past its payload), -2 the stream ends before out_off[k+1]-out_off[k] bytes.  Returns
  *                             the number of blocks with a non-zero status, or <0.
  */
@@ -303,6 +304,17 @@ const char* tredgpu_inflater_last_error(const tredgpu_inflater* inf);
 int tredgpu_inflater_reserve(tredgpu_inflater* inf, int64_t comp_bytes, int64_t out_bytes, int32_t n_blocks,
                              uint8_t** comp_host, uint8_t** out_host, int64_t** comp_off_host, int64_t** out_off_host);
 int tredgpu_inflate_blocks(tredgpu_inflater* inf, int32_t n_blocks, int32_t* status);
+/*
+ * The same, and the CRC-32 of every block's inflated bytes (0 where status != 0), computed on the device by the
+ * wavefront that wrote them: the caller compares it with the BGZF trailer instead of walking the bytes again
+ * (htslib checks the CRC inside bgzf_read, bgzf.c: the reference pays it in every pysam fetch).
+ */
+int tredgpu_inflate_blocks_crc(tredgpu_inflater* inf, int32_t n_blocks, int32_t* status, uint32_t* crc);
+/*
+ * Device time of the last call in milliseconds: from the first copy-in to the last copy-out, and the decode launches
+ * alone (a call is cut into slices whose copies and launches overlap on two streams, so kernel_ms <= total_ms).
+ */
+int tredgpu_inflater_timing(tredgpu_inflater* inf, double* total_ms, double* kernel_ms);
 
 #ifdef __cplusplus
 }

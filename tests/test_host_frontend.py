@@ -525,13 +525,31 @@ def test_scan_over_blocks_inflated_elsewhere_equals_the_plain_scan():
         for field in ("packed", "word_off", "read_len", "global_lens", "target_lens", "name_id", "unit", "depth"):
             assert np.array_equal(getattr(ref, field), getattr(got, field)), (sample, field)
         assert ref.name_blob == got.name_blob
-        # a damaged block among the preloaded ones fails its CRC like a block inflated here would
+        # a damaged block among the preloaded ones fails its CRC at first use, is dropped and inflated by the scan itself,
+        # like a block the plan missed: only what the file holds can fail a scan
         status[:] = 0
+        good = out.copy()
         out[ooff[:-1] + 7] ^= 0x20                            # (every block: whichever the walks read first)
         assert f.preload(out.ctypes.data, ooff, status) == 0  # preload_clear dropped the plan with the blocks: plan again
         assert f.plan(sites, regions, ref.readlen)[0] == n
         assert f.preload(out.ctypes.data, ooff, status) == n
-        bad = bam_parser.scan_sample(path, repo, names, handle=f, readlen=ref.readlen)
-        f.preload_clear()
-        assert (bad.unit["status"] & 2).any() or (bad.unit["depth_status"] != 0).any()
+        again = bam_parser.scan_sample(path, repo, names, handle=f, readlen=ref.readlen)
+        hits, misses = f.preload_clear()
+        assert hits == 0 and misses > 10
+        for field in ("packed", "read_len", "global_lens", "target_lens", "unit", "depth"):
+            assert np.array_equal(getattr(ref, field), getattr(again, field)), (sample, field)
+        # with the decoder's own checksums (tredbam_preload_crc): blocks whose checksum equals the trailer's are taken as
+        # verified -- the scan does not walk their bytes again, so even a byte damaged AFTER the checksum was taken is
+        # not looked for --, a block whose checksum differs is not taken at all
+        f.close()
+        f = bam_parser.open_bam(path)                         # (a fresh handle: the last scan left its blocks in the old one's cache)
+        assert f.plan(sites, regions, ref.readlen)[0] == n
+        crc = np.array([zlib.crc32(bytes(good[ooff[k]:ooff[k + 1]])) for k in range(n)], np.uint32)
+        crc[5] ^= 1
+        assert f.preload(good.ctypes.data, ooff, status, crc) == n - 1
+        got = bam_parser.scan_sample(path, repo, names, handle=f, readlen=ref.readlen)
+        hits, misses = f.preload_clear()
+        assert hits > 10 * max(misses, 1)
+        for field in ("packed", "read_len", "global_lens", "target_lens", "unit", "depth"):
+            assert np.array_equal(getattr(ref, field), getattr(got, field)), (sample, field)
         f.close()

@@ -24,7 +24,7 @@ def _raw(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0):
     return out + c.flush()
 
 
-def _inflate(inf, payloads, sizes):
+def _inflate(inf, payloads, sizes, crc=False):
     n = len(payloads)
     offs = np.zeros(n + 1, np.int64)
     for k, p in enumerate(payloads):
@@ -38,6 +38,9 @@ def _inflate(inf, payloads, sizes):
     coff[:] = offs
     ooff[0] = 0
     ooff[1:] = np.cumsum(sizes)
+    if crc:
+        status, sums = inf.run(n, crc=True)
+        return status, [bytes(out[ooff[k]:ooff[k + 1]]) for k in range(n)], sums
     status = inf.run(n)
     return status, [bytes(out[ooff[k]:ooff[k + 1]]) for k in range(n)]
 
@@ -169,3 +172,23 @@ def test_corrupted_streams_never_write_or_read_out_of_bounds(inf):
                 # zlib refuses what the decoder took: only possible where zlib asks for more than a valid prefix
                 # (trailing garbage / a missing end); the host's CRC-32 check is what catches these
                 assert len(got[j]) == sizes[k]
+
+
+def test_device_crc_matches_zlib(inf):
+    """The CRC-32 the decoding wavefront computes over its own output (tredgpu_inflate_blocks_crc) is zlib's, for every
+    size class of the chunking (64 equal power-of-two chunks padded in front), and 0 for blocks that failed."""
+    rng = np.random.default_rng(23)
+    sizes = [0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1000, 4095, 4096, 4097, 16384, 30000, 61440, 61441, 65279, 65280, 65535, 65536]
+    datas = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) if k % 2 else _bam_like(rng, n) for k, n in enumerate(sizes * 3)]
+    payloads = [_raw(d, int(rng.choice([1, 6]))) for d in datas]
+    payloads.append(payloads[-1][:len(payloads[-1]) // 2])          # a damaged one: no checksum
+    datas.append(datas[-1])
+    status, got, sums = _inflate(inf, payloads, [len(d) for d in datas], crc=True)
+    assert (status[:-1] == 0).all() and status[-1] != 0 and sums[-1] == 0
+    for k, d in enumerate(datas[:-1]):
+        assert got[k] == d and int(sums[k]) == zlib.crc32(d), (k, len(d))
+    blocks = _bgzf_blocks(os.path.join(GOLD, "bam", "t001.bam"))
+    status, got, sums = _inflate(inf, [b[0] for b in blocks], [b[2] for b in blocks], crc=True)
+    assert (status == 0).all() and [int(c) for c in sums] == [b[1] for b in blocks]
+    total, kernel = inf.timing()
+    assert 0 < kernel <= total

@@ -70,8 +70,16 @@ def main():
         for _ in range(reps):
             inf.run(len(blocks) * m)
         dt, dc = (time.perf_counter() - t0) / reps, (time.process_time() - c0) / reps
+        dev_ms, kernel_ms = inf.timing()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            st, sums = inf.run(len(blocks) * m, crc=True)
+        dt_crc = (time.perf_counter() - t0) / reps
+        assert (st == 0).all() and all(int(sums[k]) == blocks[k % len(blocks)][1] for k in range(len(blocks) * m))
         rec["launches"].append({"samples": m, "blocks": len(blocks) * m, "ms_per_call": dt * 1e3, "host_cpu_ms_per_call": dc * 1e3,
-                                "samples_per_s": m / dt, "output_GBps": m * rec["inflated_MB"] / 1e3 / dt})
+                                "device_ms": dev_ms, "kernel_ms": kernel_ms, "kernel_ms_with_crc": inf.timing()[1], "ms_per_call_with_crc": dt_crc * 1e3,
+                                "samples_per_s": m / dt, "output_GBps": m * rec["inflated_MB"] / 1e3 / dt,
+                                "kernel_samples_per_s": m / (kernel_ms * 1e-3), "kernel_output_GBps": m * rec["inflated_MB"] / kernel_ms})
     # the host's side of one sample: plain scan vs plan + fill + scan over preloaded blocks
     repo = TREDsRepo("hg38", sites=os.path.join(root, "no_sites"))
     names = [l["name"] for l in synth_bam.bench_loci()]

@@ -58,7 +58,7 @@ EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_s
            "tredgpu_genotype_batch",
            "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing", "tredgpu_get_sw_counters",
            "tredgpu_inflater_create", "tredgpu_inflater_destroy", "tredgpu_inflater_last_error",
-           "tredgpu_inflater_reserve", "tredgpu_inflate_blocks")
+           "tredgpu_inflater_reserve", "tredgpu_inflate_blocks", "tredgpu_inflate_blocks_crc", "tredgpu_inflater_timing")
 
 _lib = None
 
@@ -108,6 +108,8 @@ def load():
     lib.tredgpu_inflater_last_error.restype = C.c_char_p
     lib.tredgpu_inflater_reserve.argtypes = [vp, i64, i64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.tredgpu_inflate_blocks.argtypes = [vp, i32, vp]
+    lib.tredgpu_inflate_blocks_crc.argtypes = [vp, i32, vp, vp]
+    lib.tredgpu_inflater_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -344,8 +346,19 @@ class Inflater:
         return (view(ptr[0], C.c_uint8, comp_bytes), view(ptr[1], C.c_uint8, out_bytes),
                 view(ptr[2], C.c_int64, n_blocks + 1), view(ptr[3], C.c_int64, n_blocks + 1))
 
-    def run(self, n_blocks):
-        """Decodes the n_blocks blocks laid out in the reserved buffers; returns the int32 status per block."""
+    def run(self, n_blocks, crc=False):
+        """Decodes the n_blocks blocks laid out in the reserved buffers; returns the int32 status per block -- with
+        ``crc=True`` (status, uint32 CRC-32 of every block's inflated bytes, computed on the device)."""
         status = np.zeros(max(n_blocks, 1), np.int32)
-        self._check(self._lib.tredgpu_inflate_blocks(self._h, n_blocks, status.ctypes.data), "tredgpu_inflate_blocks")
-        return status[:n_blocks]
+        if not crc:
+            self._check(self._lib.tredgpu_inflate_blocks(self._h, n_blocks, status.ctypes.data), "tredgpu_inflate_blocks")
+            return status[:n_blocks]
+        sums = np.zeros(max(n_blocks, 1), np.uint32)
+        self._check(self._lib.tredgpu_inflate_blocks_crc(self._h, n_blocks, status.ctypes.data, sums.ctypes.data), "tredgpu_inflate_blocks_crc")
+        return status[:n_blocks], sums[:n_blocks]
+
+    def timing(self):
+        """(total_ms, kernel_ms) of the last call on the device."""
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.tredgpu_inflater_timing(self._h, C.byref(a), C.byref(b)), "tredgpu_inflater_timing")
+        return a.value, b.value

@@ -366,6 +366,8 @@ def _native():
             lib.tredbam_plan_fill.restype = C.c_int
             lib.tredbam_preload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             lib.tredbam_preload.restype = C.c_int
+            lib.tredbam_preload_crc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.tredbam_preload_crc.restype = C.c_int
             lib.tredbam_preload_clear.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
             lib.tredbam_preload_clear.restype = None
             lib.tredbam_scan_pools.restype = C.c_int
@@ -746,10 +748,16 @@ class NativeAlignmentFile(object):
         if self._lib.tredbam_plan_fill(self._h, comp_addr, comp_base, out_base, comp_off.ctypes.data, out_off.ctypes.data) != 0:
             raise ValueError(self._err())
 
-    def preload(self, out_addr, out_off, status):
-        """Hands the inflated blocks of the plan in (pointers only: the staging buffer must outlive the scan)."""
+    def preload(self, out_addr, out_off, status, crc=None):
+        """Hands the inflated blocks of the plan in (pointers only: the staging buffer must outlive the scan).  crc: the
+        decoder's CRC-32 of every block it wrote -- blocks whose checksum equals their trailer's count as verified,
+        the others are left to the scan."""
         status = np.ascontiguousarray(status, np.int32)
-        n = self._lib.tredbam_preload(self._h, out_addr, out_off.ctypes.data, status.ctypes.data)
+        if crc is not None:
+            crc = np.ascontiguousarray(crc, np.uint32)
+            n = self._lib.tredbam_preload_crc(self._h, out_addr, out_off.ctypes.data, status.ctypes.data, crc.ctypes.data)
+        else:
+            n = self._lib.tredbam_preload(self._h, out_addr, out_off.ctypes.data, status.ctypes.data)
         if n < 0:
             raise ValueError(self._err())
         return n

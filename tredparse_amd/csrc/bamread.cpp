@@ -203,16 +203,18 @@ int load_block(tredbam* b, int64_t coffset) {
         const auto pre = b->preloaded.find(coffset);
         if (pre != b->preloaded.end()) {
             tredbam::Preloaded& p = pre->second;
-            if (!p.checked) {      // the block's CRC-32, as for a block inflated here
-                if (tredbam_crc::crc32(0, p.data, p.size) != p.crc)
-                    return fail(b, -7, "CRC mismatch in the BGZF block at %lld", (long long)coffset);
+            // the block's CRC-32, as for a block inflated here (already compared when the decoder delivered one).  A
+            // preloaded block that fails it is dropped and inflated here like a block the plan missed: only what the
+            // file itself holds can fail a scan
+            if (p.checked || tredbam_crc::crc32(0, p.data, p.size) == p.crc) {
                 p.checked = true;
+                b->block = p.data;
+                b->block_size = p.size;
+                b->block_clen = p.clen;
+                ++b->preload_hits;
+                return 1;
             }
-            b->block = p.data;
-            b->block_size = p.size;
-            b->block_clen = p.clen;
-            ++b->preload_hits;
-            return 1;
+            b->preloaded.erase(pre);
         }
         ++b->preload_misses;
     }
@@ -1196,7 +1198,7 @@ int tredbam_plan_fill(tredbam* b, uint8_t* comp, int64_t comp_base, int64_t out_
 
 // out + out_off[k] holds the planned block k inflated (status[k] == 0; others are left to load_block).  The memory
 // stays the caller's and must live until tredbam_preload_clear or tredbam_close.
-int tredbam_preload(tredbam* b, const uint8_t* out, const int64_t* out_off, const int32_t* status) {
+int tredbam_preload_crc(tredbam* b, const uint8_t* out, const int64_t* out_off, const int32_t* status, const uint32_t* crc) {
     if (!b || !out || !out_off || !status) return -2;
     b->preloaded.clear();
     b->preloaded.reserve(b->plan.size() * 2);
@@ -1205,12 +1207,17 @@ int tredbam_preload(tredbam* b, const uint8_t* out, const int64_t* out_off, cons
     for (size_t k = 0; k < b->plan.size(); ++k) {
         const tredbam::Planned& p = b->plan[k];
         if (status[k] != 0 || out_off[k + 1] - out_off[k] != (int64_t)p.isize) continue;
-        b->preloaded[p.coffset] = tredbam::Preloaded{out + out_off[k], p.isize, p.clen, p.crc, false};
+        if (crc && crc[k] != p.crc) continue;          // the decoder's checksum of its own output is not the trailer's
+        b->preloaded[p.coffset] = tredbam::Preloaded{out + out_off[k], p.isize, p.clen, p.crc, crc != nullptr};
         ++n;
     }
     // blocks of an earlier scan in the handle's own cache stay valid; the current block pointer may not
     b->block_coffset = -1; b->block = nullptr; b->block_size = 0; b->block_clen = 0; b->upos = 0;
     return n;
+}
+
+int tredbam_preload(tredbam* b, const uint8_t* out, const int64_t* out_off, const int32_t* status) {
+    return tredbam_preload_crc(b, out, out_off, status, nullptr);
 }
 
 void tredbam_preload_clear(tredbam* b, int64_t* hits, int64_t* misses) {

@@ -26,7 +26,8 @@
 //     stores of a batch fall into a handful of cache lines.
 //   * Tables are built by the wavefront together: code-length histogram by LDS atomics, symbols ranked within their
 //     length by ballot + prefix popcount, direct-table entries decoded canonically entry-parallel.
-//   * LDS: 6.3 KB per wavefront (25 wavefronts per CU instead of one); no per-block workspace in global memory.
+//   * LDS: 5.8 KB per wavefront and at most 72 VGPRs: 28 wavefronts per CU instead of one -- a wavefront is a chain of
+//     short dependent steps, what fills the CU is how many are resident; no per-block workspace in global memory.
 // Nothing here knows BAM: the C ABI (include/tredgpu.h, tredgpu_inflate_*) takes payload offsets and sizes and
 // returns bytes plus a status per block; gzip framing and ISIZE stay with the host library (libtredbam).
 #include <hip/hip_runtime.h>
@@ -43,22 +44,29 @@ namespace {
 constexpr int LANES = 64;
 constexpr int MAXBITS = 15, MAXL = 288, MAXD = 32;
 #ifndef ROOTL_BITS
-#define ROOTL_BITS 11
-#define ROOTD_BITS 9
+#define ROOTL_BITS 10
+#define ROOTD_BITS 7
 #endif
 constexpr int ROOTL = ROOTL_BITS, ROOTD = ROOTD_BITS;
 
-// one wavefront's tables (one block in flight per wavefront)
+// one wavefront's tables (one block in flight per wavefront).  5.8 KB: 28 wavefronts per CU -- the decoder is a chain
+// of short dependent steps per wavefront, and what fills the CU is how many of them are resident
 struct WaveLds {
-    uint16_t fastL[1 << ROOTL];   // next ROOTL bits of the stream -> symbol | code length << 9 (0: a longer code, or none)
-    uint16_t fastD[1 << ROOTD];
+    uint32_t fastL[1 << ROOTL];   // direct tables on the next ROOTL / ROOTD bits of the stream (entries: see entry_L / entry_D)
+    uint32_t fastD[1 << ROOTD];
     uint16_t symL[MAXL];          // symbols sorted by (code length, symbol): canonical decoding of the longer codes
     uint16_t symD[MAXD];
-    uint32_t cnt[16];             // codes per length of the alphabet under construction
-    uint8_t lens[MAXL + MAXD];    // code lengths as the block header gives them
-    uint8_t clsym[32];            // the code-length code: sorted symbols and its 7-bit direct table (symbol | length << 5)
-    uint8_t clfast[128];
-    uint32_t queue[2 * LANES];    // decoded symbols in stream order, waiting to be executed 64 at a time
+    int32_t longL[2 + MAXBITS - ROOTL], longD[2 + MAXBITS - ROOTD];   // canonical decoding of the longer codes: first code and
+                                                                      // symbol index at length ROOT + 1, codes per length
+    union {
+        uint32_t queue[2 * LANES];    // decoded symbols in stream order, waiting to be executed 64 at a time
+        struct {                      // what only the block header needs (the queue is empty then)
+            uint32_t cnt[16];             // codes per length of the alphabet under construction
+            uint8_t lens[MAXL + MAXD];    // code lengths as the header gives them
+            uint8_t clsym[20];            // the code-length code: sorted symbols and its 7-bit direct table (symbol | length << 5)
+            uint8_t clfast[128];
+        } hdr;
+    };
 };
 
 // packed symbol: [31:25] bits consumed, [24:23] kind, [22:8] distance - 1, [7:0] literal or match length - 3.  The
@@ -119,25 +127,47 @@ struct UBits {
     __device__ __forceinline__ int pos() const { return idx * 32 - cnt; }
 };
 
-// what canonical decoding needs for the codes longer than the direct table's ROOT bits (wave-uniform)
-template <int ROOT>
-struct LongCodes {
-    int first, index;               // first code and symbol index at length ROOT + 1
-    int count[MAXBITS - ROOT];      // codes of length ROOT + 1 .. 15
-};
+// Direct-table entries (one dword) carry everything a lane needs, so that the window's look-ups are a handful of
+// instructions per lane:
+//   literal / length table:  literal      -> the packed symbol itself
+//                            end of block -> the packed symbol itself
+//                            length code  -> [31:25] code length + extra bits, [24:23] K_MATCH, [22:20] extra bits,
+//                                            [19:16] code length, [7:0] base length - 3
+//   distance table:          [31:25] code length + extra bits, [23:20] extra bits, [19:16] code length, [14:0] base - 1
+//   both:                    SLOW_SYMBOL = the code is longer than the table's ROOT bits, or there is none: the walk asks
+//                            for the canonical decoding only if it gets there (4-5 % of the real symbols; most windows
+//                            never do);  BAD_SYMBOL = a symbol no stream may use.  Both read as "64 bits consumed, kind
+//                            K_BAD": no valid entry has its top bit set, and the walk stops at them by itself.
+constexpr uint32_t SLOW_SYMBOL = BAD_SYMBOL | 1u;
+
+__device__ __forceinline__ uint32_t entry_L(int sym, int clen) {
+    if (sym < 256) return (uint32_t)clen << P_BITS | K_LIT << P_KIND | (uint32_t)sym;
+    if (sym == 256) return 64u << P_BITS | K_END << P_KIND | (uint32_t)clen;
+    const int c = sym - 257;
+    if (c >= 29) return BAD_SYMBOL;
+    int base, extra;
+    len_code(c, base, extra);
+    return (uint32_t)(clen + extra) << P_BITS | K_MATCH << P_KIND | (uint32_t)extra << 20 | (uint32_t)clen << 16 | (uint32_t)(base - 3);
+}
+__device__ __forceinline__ uint32_t entry_D(int sym, int clen) {
+    if (sym >= 30) return BAD_SYMBOL;
+    int base, extra;
+    dist_code(sym, base, extra);
+    return (uint32_t)(clen + extra) << P_BITS | (uint32_t)extra << 20 | (uint32_t)clen << 16 | (uint32_t)(base - 1);
+}
 
 // count[] / sorted symbols / direct table of a canonical code from n code lengths in LDS, by the whole wavefront.
 // Returns <0 for an over-subscribed set, >0 for an incomplete one, 0 for a complete one (puff's `left`); zeros = the
 // number of unused symbols.
-template <int ROOT>
-__device__ int build_tables(WaveLds& S, const uint8_t* lens, int n, uint16_t* sym, uint16_t* fast, LongCodes<ROOT>& C, int& zeros, int lane) {
-    if (lane < 16) S.cnt[lane] = 0;
+template <int ROOT, bool DIST>
+__device__ int build_tables(WaveLds& S, const uint8_t* lens, int n, uint16_t* sym, uint32_t* fast, int32_t* longc, int& zeros, int lane) {
+    if (lane < 16) S.hdr.cnt[lane] = 0;
     __syncthreads();
-    for (int s = lane; s < n; s += LANES) atomicAdd(&S.cnt[lens[s]], 1u);
+    for (int s = lane; s < n; s += LANES) atomicAdd(&S.hdr.cnt[lens[s]], 1u);
     __syncthreads();
     int c[MAXBITS + 1];
 #pragma unroll
-    for (int l = 0; l <= MAXBITS; ++l) c[l] = (int)S.cnt[l];
+    for (int l = 0; l <= MAXBITS; ++l) c[l] = (int)S.hdr.cnt[l];
     zeros = c[0];
     int left = 1;
 #pragma unroll
@@ -177,34 +207,35 @@ __device__ int build_tables(WaveLds& S, const uint8_t* lens, int n, uint16_t* sy
             first <<= 1;
             code <<= 1;
         }
-        fast[t] = found < 0 ? (uint16_t)0 : (uint16_t)(sym[found] | flen << 9);
+        uint32_t e = SLOW_SYMBOL;
+        if (found >= 0) e = DIST ? entry_D((int)sym[found], flen) : entry_L((int)sym[found], flen);
+        fast[t] = e;
     }
     int first = 0, index = 0;
 #pragma unroll
     for (int l = 1; l <= ROOT; ++l) { index += c[l]; first = (first + c[l]) << 1; }
-    C.first = first;
-    C.index = index;
+    if (lane == 0) {
+        longc[0] = first;
+        longc[1] = index;
 #pragma unroll
-    for (int l = ROOT + 1; l <= MAXBITS; ++l) C.count[l - ROOT - 1] = c[l];
+        for (int l = ROOT + 1; l <= MAXBITS; ++l) longc[2 + l - ROOT - 1] = c[l];
+    }
     __syncthreads();
     return zeros == n ? 0 : left;        // no codes at all: complete, nothing decodes (as puff and zlib have it)
 }
 
-// the symbol whose code starts at bit 0 of `bits` (>= 15 valid bits): direct table, else canonically from length
-// ROOT + 1 on; -1: no such code.  Per lane: every lane asks for another offset of the stream.
+// a code longer than ROOT bits, canonically from the length counts; -1: no such code
 template <int ROOT>
-__device__ __forceinline__ int decode_at(uint32_t bits, const uint16_t* fast, const uint16_t* sym, const LongCodes<ROOT>& C, int& clen) {
-    const uint32_t e = fast[bits & ((1u << ROOT) - 1u)];
-    if (e != 0) { clen = (int)(e >> 9); return (int)(e & 511u); }
+__device__ __forceinline__ int decode_long(uint32_t bits, const uint16_t* sym, const int32_t* longc, int& clen) {
     int code = (int)(__builtin_bitreverse32(bits) >> (32 - ROOT)) << 1;   // the first ROOT bits as a code, room for the next
-    int first = C.first, index = C.index;
+    int first = longc[0], index = longc[1];
     uint32_t rest = bits >> ROOT;
     int found = -1, flen = 0;
 #pragma unroll
     for (int len = ROOT + 1; len <= MAXBITS; ++len) {
         code |= (int)(rest & 1u);
         rest >>= 1;
-        const int count = C.count[len - ROOT - 1];
+        const int count = longc[2 + len - ROOT - 1];
         if (found < 0 && code - count < first) { found = index + (code - first); flen = len; }
         index += count;
         first += count;
@@ -215,26 +246,44 @@ __device__ __forceinline__ int decode_at(uint32_t bits, const uint16_t* fast, co
     return found < 0 ? -1 : (int)sym[found];
 }
 
-// the complete symbol that starts at this lane's bit of the stream, packed
-__device__ __forceinline__ uint32_t symbol_at(uint64_t view, const WaveLds& S, const LongCodes<ROOTL>& CL, const LongCodes<ROOTD>& CD) {
-    int clen;
-    const int sym = decode_at<ROOTL>((uint32_t)view, S.fastL, S.symL, CL, clen);
-    if (sym < 0) return BAD_SYMBOL;
-    if (sym < 256) return (uint32_t)clen << P_BITS | K_LIT << P_KIND | (uint32_t)sym;
-    if (sym == 256) return 64u << P_BITS | K_END << P_KIND | (uint32_t)clen;
-    const int c = sym - 257;
-    if (c >= 29) return BAD_SYMBOL;
-    int base, extra;
-    len_code(c, base, extra);
-    const int mlen = base + (int)((uint32_t)(view >> clen) & ((1u << extra) - 1u));
-    const int used = clen + extra;                        // <= 20
-    const uint64_t v2 = view >> used;                     // >= 37 valid bits left
-    int dlen;
-    const int ds = decode_at<ROOTD>((uint32_t)v2, S.fastD, S.symD, CD, dlen);
-    if (ds < 0 || ds >= 30) return BAD_SYMBOL;
-    dist_code(ds, base, extra);
-    const int dist = base + (int)((uint32_t)(v2 >> dlen) & ((1u << extra) - 1u));
-    return (uint32_t)(used + dlen + extra) << P_BITS | K_MATCH << P_KIND | (uint32_t)(dist - 1) << P_DIST | (uint32_t)(mlen - 3);
+// a match from its two entries: length's extra bits, distance's extra bits, everything packed
+__device__ __forceinline__ uint32_t pack_match(uint64_t view, uint32_t eL, uint32_t eD) {
+    const uint32_t lx = (uint32_t)(view >> ((eL >> 16) & 15u)) & ~(~0u << ((eL >> 20) & 7u));
+    const uint64_t v2 = view >> ((eL >> P_BITS) & 63u);
+    const uint32_t dx = (uint32_t)(v2 >> ((eD >> 16) & 15u)) & ~(~0u << ((eD >> 20) & 15u));
+    return ((eL & 0xFF8000FFu) + lx) + (eD & 0xFE000000u) + (((eD & 0x7FFFu) + dx) << P_DIST);
+}
+
+// the complete symbol that starts at this lane's bit of the stream (57 valid bits in view), packed; SLOW_SYMBOL where a
+// code is longer than its direct table.  No branches: every lane makes both look-ups (the second with whatever bits
+// its first entry says follow -- in range by construction) and selects.
+__device__ __forceinline__ uint32_t symbol_at(uint64_t view, const WaveLds& S) {
+    const uint32_t eL = S.fastL[(uint32_t)view & ((1u << ROOTL) - 1u)];
+    const uint32_t eD = S.fastD[(uint32_t)(view >> ((eL >> P_BITS) & 63u)) & ((1u << ROOTD) - 1u)];
+    const uint32_t m = pack_match(view, eL, eD);
+    const bool is_match = ((eL >> P_KIND) & 3u) == K_MATCH;
+    return is_match ? ((int32_t)eD < 0 ? eD : m) : eL;        // (SLOW / BAD entries of either table pass through as they are)
+}
+
+// the same with the long codes resolved (only the lanes that reported SLOW_SYMBOL come here)
+__device__ uint32_t symbol_slow(uint64_t view, const WaveLds& S) {
+    uint32_t eL = S.fastL[(uint32_t)view & ((1u << ROOTL) - 1u)];
+    if (eL == SLOW_SYMBOL) {
+        int clen;
+        const int sym = decode_long<ROOTL>((uint32_t)view, S.symL, S.longL, clen);
+        if (sym < 0) return BAD_SYMBOL;
+        eL = entry_L(sym, clen);
+    }
+    if (((eL >> P_KIND) & 3u) != K_MATCH) return eL;
+    const uint64_t v2 = view >> (eL >> P_BITS);
+    uint32_t eD = S.fastD[(uint32_t)v2 & ((1u << ROOTD) - 1u)];
+    if (eD == SLOW_SYMBOL) {
+        int dlen;
+        const int ds = decode_long<ROOTD>((uint32_t)v2, S.symD, S.longD, dlen);
+        if (ds < 0) return BAD_SYMBOL;
+        eD = entry_D(ds, dlen);
+    }
+    return (int32_t)eD < 0 ? eD : pack_match(view, eL, eD);
 }
 
 // Executes the queue: lane k holds symbol k (k < nsym).  Returns 0, or -1 when the output or a distance is out of range.
@@ -250,24 +299,28 @@ __device__ __forceinline__ int run_queue(uint8_t* o, int olen, int& opos, uint32
     const int dst = opos + incl - len;
     if (__builtin_amdgcn_ballot_w64(is_match && dist > dst) != 0) return -1;
     if (valid && !is_match) o[dst] = (uint8_t)val;
-    // a match whose source ends before the batch begins depends on nothing in the batch
-    const bool own = is_match && dst - dist + len <= opos && len <= 16;
+    // a match whose source ends before the batch begins depends on nothing in the batch: those of at most 64 bytes copy
+    // themselves, 16 bytes per trip, all of them side by side (one memory round trip per trip for the wavefront; the
+    // destinations of a batch are consecutive, so the stores fall into few cache lines)
+    const bool own = is_match && dst - dist + len <= opos && len <= 64;
     if (own) {
         const uint8_t* src = o + dst - dist;
         uint8_t* d = o + dst;
-        const uint64_t lo = *reinterpret_cast<const U64*>(src);
-        if (len >= 8) {
-            const uint64_t hi = *reinterpret_cast<const U64*>(src + 8);
-            const int sh = (len - 8) * 8;                  // bytes [len - 8, len) of hi:lo
-            const uint64_t tail = sh == 0 ? lo : (sh == 64 ? hi : (lo >> sh) | (hi << (64 - sh)));
-            *reinterpret_cast<U64*>(d) = lo;
-            *reinterpret_cast<U64*>(d + len - 8) = tail;
-        } else if (len >= 4) {
-            *reinterpret_cast<U32*>(d) = (uint32_t)lo;
-            *reinterpret_cast<U32*>(d + len - 4) = (uint32_t)(lo >> ((len - 4) * 8));
-        } else {                                           // 3
-            *reinterpret_cast<U16*>(d) = (uint16_t)lo;
-            d[2] = (uint8_t)(lo >> 16);
+        for (int left = len; left > 0; left -= 16, src += 16, d += 16) {
+            const uint64_t lo = *reinterpret_cast<const U64*>(src);
+            if (left >= 8) {
+                const uint64_t hi = *reinterpret_cast<const U64*>(src + 8);
+                const int n = min(left, 16), sh = (n - 8) * 8;     // bytes [n - 8, n) of hi:lo
+                const uint64_t tail = sh == 0 ? lo : (sh == 64 ? hi : (lo >> sh) | (hi << (64 - sh)));
+                *reinterpret_cast<U64*>(d) = lo;
+                *reinterpret_cast<U64*>(d + n - 8) = tail;         // (overlaps the first store: exactly n bytes are written)
+            } else if (left >= 4) {
+                *reinterpret_cast<U32*>(d) = (uint32_t)lo;
+                *reinterpret_cast<U32*>(d + left - 4) = (uint32_t)(lo >> ((left - 4) * 8));
+            } else {
+                if (left >= 2) *reinterpret_cast<U16*>(d) = (uint16_t)lo;
+                if (left != 2) d[left - 1] = (uint8_t)(lo >> ((left - 1) * 8));
+            }
         }
     }
     // the others in stream order, 64 bytes per step by all lanes (a wavefront's memory operations are carried out in
@@ -295,12 +348,199 @@ __device__ __forceinline__ int run_queue(uint8_t* o, int olen, int& opos, uint32
     return 0;
 }
 
-__global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
-                                                        uint8_t* out, const int64_t* __restrict__ out_off, int n_blocks,
-                                                        int32_t* __restrict__ status) {
+// ---- CRC-32 of a block's inflated bytes (the BGZF trailer's check), by the wavefront that wrote them -------------------
+// 64 lanes take 64 equal chunks of the block, padded IN FRONT with zero bytes to 64 * C bytes, C a power of two (a CRC
+// register that is still zero stays zero over zero bytes, so the padding changes nothing; the register is set to all
+// ones where the data begins, as the standard has it).  Slice-by-4 tables in LDS; the 64 registers are folded by a
+// tree, crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B), whose shifts x^(8 C 2^level) come from a table.
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+__host__ __device__ constexpr uint32_t multmodp(uint32_t a, uint32_t b) {   // a * b mod P, x^0 at bit 31 (zlib's convention)
+    uint32_t p = 0;
+    for (int i = 31; i >= 0; --i) {
+        p ^= ((a >> i) & 1u) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
+    }
+    return p;
+}
+struct CrcTables {
+    uint32_t t[4][256];     // slice-by-4
+    uint32_t x8n[24];       // x^(8 * 2^k) mod P
+};
+constexpr CrcTables make_crc_tables() {
+    CrcTables c = {};
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t r = i;
+        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ ((r & 1u) ? CRC_POLY : 0u);
+        c.t[0][i] = r;
+    }
+    for (int k = 1; k < 4; ++k)
+        for (uint32_t i = 0; i < 256; ++i) c.t[k][i] = (c.t[k - 1][i] >> 8) ^ c.t[0][c.t[k - 1][i] & 255u];
+    uint32_t p = 0x40000000u;                          // x^1
+    for (int k = 0; k < 3; ++k) p = multmodp(p, p);    // x^8
+    for (int k = 0; k < 24; ++k) { c.x8n[k] = p; p = multmodp(p, p); }
+    return c;
+}
+__constant__ CrcTables CRC = make_crc_tables();
+
+__device__ __forceinline__ uint32_t crc_byte(const uint32_t* T, uint32_t crc, uint32_t byte) { return T[(crc ^ byte) & 255u] ^ (crc >> 8); }
+__device__ __forceinline__ uint32_t crc_word(const uint32_t* T, uint32_t crc, uint32_t word) {
+    crc ^= word;
+    return T[768 + (crc & 255u)] ^ T[512 + ((crc >> 8) & 255u)] ^ T[256 + ((crc >> 16) & 255u)] ^ T[crc >> 24];
+}
+
+__device__ uint32_t block_crc(WaveLds& S, const uint8_t* o, int olen, int lane) {
+    if (olen == 0) return 0u;
+    uint32_t* T = reinterpret_cast<uint32_t*>(S.fastL);      // (the direct table of the literal/length code is dead by now)
+    static_assert(sizeof(S.fastL) >= 4 * 256 * sizeof(uint32_t), "the CRC tables go where the direct table was");
+    __syncthreads();
+    for (int k = lane; k < 1024; k += LANES) T[k] = CRC.t[k >> 8][k & 255];
+    __syncthreads();
+    int lg = 2;                                               // C = 2^lg >= olen / 64
+    while ((LANES << lg) < olen) ++lg;
+    const int C = 1 << lg;
+    int d = lane * C - (LANES * C - olen);                    // the lane's first byte in data coordinates
+    const int dend = d + C;
+    uint32_t crc = 0;
+    if (dend > 0) {
+        if (d <= 0) { d = 0; crc = 0xFFFFFFFFu; }             // the data begins inside this lane's chunk
+        while (d < dend && ((dend - d) & 15) != 0) { crc = crc_byte(T, crc, o[d]); ++d; }
+        for (; d < dend; d += 16) {
+            const uint32_t w0 = *reinterpret_cast<const U32*>(o + d), w1 = *reinterpret_cast<const U32*>(o + d + 4),
+                           w2 = *reinterpret_cast<const U32*>(o + d + 8), w3 = *reinterpret_cast<const U32*>(o + d + 12);
+            crc = crc_word(T, crc, w0);
+            crc = crc_word(T, crc, w1);
+            crc = crc_word(T, crc, w2);
+            crc = crc_word(T, crc, w3);
+        }
+    }
+    for (int l = 0; l < 6; ++l) {
+        const uint32_t right = (uint32_t)__shfl_down((int)crc, 1 << l, LANES);
+        if ((lane & ((2 << l) - 1)) == 0) crc = multmodp(CRC.x8n[lg + l], crc) ^ right;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)crc) ^ 0xFFFFFFFFu;
+}
+
+#ifdef INFLATE_PROF     // cycle counters per phase and block (tools/inflate_prof.hip); the product build has none of this
+__device__ unsigned long long* g_prof;
+struct Prof {
+    unsigned long long t, t0, acc[8];
+    __device__ void start() { t = t0 = clock64(); for (int k = 0; k < 8; ++k) acc[k] = 0; }
+    __device__ void mark(int k) { const unsigned long long now = clock64(); acc[k] += now - t; t = now; }
+    __device__ void count(int k, int n) { acc[k] += n; }
+    __device__ void out(int g, int lane) { if (lane == 0 && g_prof) { acc[7] = clock64() - t0; for (int k = 0; k < 8; ++k) g_prof[(size_t)g * 8 + k] = acc[k]; } }
+};
+#define SYMBOLS_FN __device__ __forceinline__
+#else
+struct Prof {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void count(int, int) {}
+    __device__ __forceinline__ void out(int, int) {}
+};
+// a function of its own, really called: the header code around it (tables built from uniform arrays, the run-length decoder)
+// is large and cold, and inlined into one loop nest with it the compiler shuffled its state through the hot loop
+#define SYMBOLS_FN __device__ __noinline__
+#endif
+
+struct SymbolsEnd { int rc, opos, bit; };
+
+// Across a real call every argument arrives in vector registers and pointers lose their address space: the callee
+// says again that they are wave-uniform (scalar registers, scalar branches) and global (global_load, not flat_load).
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+typedef const uint8_t __attribute__((address_space(1)))* GlobalBytesIn;
+typedef uint8_t __attribute__((address_space(1)))* GlobalBytes;
+template <typename G, typename T>
+__device__ __forceinline__ G uniform_global(T* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint64_t u = (uint64_t)(uint32_t)uniform((int)(uint32_t)v) | (uint64_t)(uint32_t)uniform((int)(uint32_t)(v >> 32)) << 32;
+    return (G)(T*)u;
+}
+
+// The symbols of one deflate block from bit `bit` of the payload on (tables in S): decodes and executes them until the
+// end-of-block code.  rc 0 / -1; opos and bit move on.
+SYMBOLS_FN SymbolsEnd decode_symbols(WaveLds& S, const uint8_t* p8_, int nbytes, uint8_t* o_, int olen, int opos, int bit, Prof& P) {
+    // (cast back to plain pointers: the compiler follows the address space through them to every load and store)
+    const uint8_t* p8 = (const uint8_t*)uniform_global<GlobalBytesIn>(p8_);
+    uint8_t* o = (uint8_t*)uniform_global<GlobalBytes>(o_);
+    nbytes = uniform(nbytes); olen = uniform(olen); opos = uniform(opos); bit = uniform(bit);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    // window = the 64 bit offsets bit0 .. bit0 + 63; pos = where the next symbol starts, relative to bit0
+    int bit0 = bit, pos = 0, nsym = 0, end = 0, rc = 0;
+    uint64_t raw = *reinterpret_cast<const U64*>(p8 + ((bit0 + lane) >> 3));
+    uint64_t raw1 = *reinterpret_cast<const U64*>(p8 + ((bit0 + LANES + lane) >> 3));
+    while (!end) {
+        if (bit0 > nbytes * 8) { rc = -1; break; }         // a symbol would start behind the payload
+        const uint64_t view = raw >> ((bit0 + lane) & 7);
+        raw = raw1;
+        raw1 = *reinterpret_cast<const U64*>(p8 + ((bit0 + 2 * LANES + lane) >> 3));   // the window after the next, early
+        uint32_t sp = symbol_at(view, S);
+        P.mark(1);
+        // the walk: from symbol start to symbol start, on the scalar unit
+        uint64_t starts = 0;
+        uint32_t e;
+        for (;;) {
+            // (four steps per trip of the loop: a taken branch costs a lone wavefront as much as the step itself)
+#define WALK_STEP                                                        \
+                e = (uint32_t)__builtin_amdgcn_readlane((int)sp, pos);   \
+                asm("s_bitset1_b64 %0, %1" : "+s"(starts) : "s"(pos));   \
+                pos += (int)(e >> P_BITS);
+            for (;;) {
+                WALK_STEP
+                if (pos >= LANES) break;
+                WALK_STEP
+                if (pos >= LANES) break;
+                WALK_STEP
+                if (pos >= LANES) break;
+                WALK_STEP
+                if (pos >= LANES) break;
+            }
+#undef WALK_STEP
+            if (e != SLOW_SYMBOL) break;
+            pos -= LANES;                                  // a long code at a real symbol start: resolve those, walk on
+            if (sp == SLOW_SYMBOL) {
+                uint64_t again = view;
+                asm volatile("" : "+v"(again));            // (keeps the canonical decoding in here: hoisted, every window paid for it)
+                sp = symbol_slow(again, S);
+            }
+        }
+        P.mark(2);
+        P.count(6, 1);
+        const uint32_t kind = (e >> P_KIND) & 3u;
+        if (kind >= K_END) {                               // the last symbol of the block (or nothing decodable): not queued
+            if (kind == K_BAD) { rc = -1; break; }
+            const int at = pos - LANES;
+            starts &= ~(1ull << at);
+            bit = bit0 + at + (int)(e & 255u);
+            end = 1;
+        }
+        // the lanes that hold a real symbol append it to the queue, in stream order
+        if ((starts >> lane) & 1ull) S.queue[nsym + lanes_below(starts)] = sp;
+        nsym += (int)__popcll(starts);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (one wavefront: its LDS operations are carried out in order)
+        P.mark(3);
+        while (nsym >= LANES || (end && nsym > 0)) {
+            const int n = min(nsym, LANES);
+            const uint32_t q = S.queue[lane];
+            const uint32_t q2 = S.queue[LANES + lane];
+            if (run_queue(o, olen, opos, q, n, lane) != 0) { rc = -1; end = 1; break; }
+            nsym -= n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < nsym) S.queue[lane] = q2;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            P.mark(4);
+        }
+        pos -= LANES;
+        bit0 += LANES;
+    }
+    return SymbolsEnd{rc, opos, bit};
+}
+
+__global__ __launch_bounds__(LANES, 7) void inflate_kernel(const uint32_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
+                                                        uint8_t* out, const int64_t* __restrict__ out_off, int first_block,
+                                                        int32_t* __restrict__ status, uint32_t* __restrict__ crc_out) {
     __shared__ WaveLds S;
     const int lane = threadIdx.x;
-    const int g = blockIdx.x;
+    const int g = first_block + blockIdx.x;
     const int64_t c0 = comp_off[g], c1 = comp_off[g + 1];
     uint8_t* o = out + out_off[g];
     const int olen = (int)(out_off[g + 1] - out_off[g]);
@@ -309,8 +549,8 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
     const int nbytes = (int)(c1 - c0);
     const int nwords = (nbytes + 3) >> 2;
     int bit = 0, opos = 0, rc = nbytes > 0 ? 0 : -1, last = 0;
-    LongCodes<ROOTL> CL = {};
-    LongCodes<ROOTD> CD = {};
+    Prof P;
+    P.start();
     while (rc == 0 && !last) {
         // ---- a deflate block header ----
         UBits b;
@@ -330,8 +570,8 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
         if (type == 3) { rc = -1; break; }
         int nlen = MAXL, ndist = MAXD;                     // (the fixed codes are complete over 288 / 32 symbols: the
         if (type == 1) {                                   //  symbols no stream may use are refused where they turn up)
-            for (int s = lane; s < MAXL; s += LANES) S.lens[s] = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
-            if (lane < MAXD) S.lens[MAXL + lane] = 5;
+            for (int s = lane; s < MAXL; s += LANES) S.hdr.lens[s] = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
+            if (lane < MAXD) S.hdr.lens[MAXL + lane] = 5;
         } else {
             nlen = (int)b.get(5) + 257;
             ndist = (int)b.get(5) + 1;
@@ -355,7 +595,7 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
                 if (left < 0) break;
             }
             if (left != 0) { rc = -1; break; }             // a complete code is required (as zlib does)
-            if (mycl != 0) S.clsym[myrank] = (uint8_t)lane;
+            if (mycl != 0) S.hdr.clsym[myrank] = (uint8_t)lane;
             __syncthreads();
             for (int t = lane; t < 128; t += LANES) {
                 int code = 0, first = 0, index = 0, found = -1, flen = 0;
@@ -369,19 +609,19 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
                     first <<= 1;
                     code <<= 1;
                 }
-                S.clfast[t] = found < 0 ? (uint8_t)0 : (uint8_t)(S.clsym[found] | flen << 5);
+                S.hdr.clfast[t] = found < 0 ? (uint8_t)0 : (uint8_t)(S.hdr.clsym[found] | flen << 5);
             }
             __syncthreads();
             // the nlen + ndist code lengths, run-length coded
             int idx = 0, prev = 0;
             const int total = nlen + ndist;
             while (idx < total) {
-                const uint32_t e = S.clfast[b.peek(7)];
+                const uint32_t e = S.hdr.clfast[b.peek(7)];
                 if (e == 0) { rc = -1; break; }
                 b.skip((int)(e >> 5));
                 const int sym = (int)(e & 31u);
                 if (sym < 16) {
-                    if (lane == 0) S.lens[idx] = (uint8_t)sym;
+                    if (lane == 0) S.hdr.lens[idx] = (uint8_t)sym;
                     prev = sym;
                     ++idx;
                 } else {
@@ -392,69 +632,30 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
                     } else if (sym == 17) { prev = 0; rep = 3 + (int)b.get(3); }
                     else { prev = 0; rep = 11 + (int)b.get(7); }
                     if (idx + rep > total) { rc = -1; break; }
-                    for (int j = lane; j < rep; j += LANES) S.lens[idx + j] = (uint8_t)prev;
+                    for (int j = lane; j < rep; j += LANES) S.hdr.lens[idx + j] = (uint8_t)prev;
                     idx += rep;
                 }
             }
             if (rc != 0) break;
             __syncthreads();
-            if (S.lens[256] == 0) { rc = -1; break; }      // no end-of-block code
+            if (S.hdr.lens[256] == 0) { rc = -1; break; }      // no end-of-block code
             // the distance lengths follow the literal/length lengths directly: move them to their own place
-            const int dl = lane < ndist ? (int)S.lens[nlen + lane] : 0;
+            const int dl = lane < ndist ? (int)S.hdr.lens[nlen + lane] : 0;
             __syncthreads();
-            if (lane < MAXD) S.lens[MAXL + lane] = (uint8_t)dl;
+            if (lane < MAXD) S.hdr.lens[MAXL + lane] = (uint8_t)dl;
         }
         bit = b.pos();
         __syncthreads();
         int zeros;
-        int err = build_tables<ROOTL>(S, S.lens, nlen, S.symL, S.fastL, CL, zeros, lane);
+        int err = build_tables<ROOTL, false>(S, S.hdr.lens, nlen, S.symL, S.fastL, S.longL, zeros, lane);
         if (err < 0 || (err > 0 && nlen - zeros != 1)) { rc = -1; break; }
-        err = build_tables<ROOTD>(S, S.lens + MAXL, ndist, S.symD, S.fastD, CD, zeros, lane);
+        err = build_tables<ROOTD, true>(S, S.hdr.lens + MAXL, ndist, S.symD, S.fastD, S.longD, zeros, lane);
         if (err < 0 || (err > 0 && ndist - zeros != 1)) { rc = -1; break; }
 
+        P.mark(0);
         // ---- the block's symbols ----
-        // window = the 64 bit offsets bit0 .. bit0 + 63; pos = where the next symbol starts, relative to bit0
-        int bit0 = bit, pos = 0, nsym = 0, end = 0;
-        uint64_t raw = *reinterpret_cast<const U64*>(p8 + ((bit0 + lane) >> 3));
-        while (!end) {
-            if (bit0 > nbytes * 8) { rc = -1; break; }     // a symbol would start behind the payload
-            const uint64_t view = raw >> ((bit0 + lane) & 7);
-            raw = *reinterpret_cast<const U64*>(p8 + ((bit0 + LANES + lane) >> 3));   // the next window's bytes, early
-            const uint32_t sp = symbol_at(view, S, CL, CD);
-            // the walk: from symbol start to symbol start, on the scalar unit
-            uint64_t starts = 0;
-            uint32_t e;
-            int at;
-            do {
-                at = pos;
-                e = (uint32_t)__builtin_amdgcn_readlane((int)sp, at);
-                starts |= 1ull << at;
-                pos += (int)(e >> P_BITS);
-            } while (pos < LANES);
-            const uint32_t kind = (e >> P_KIND) & 3u;
-            if (kind >= K_END) {                           // the last symbol of the block (or nothing decodable): not queued
-                if (kind == K_BAD) { rc = -1; break; }
-                starts &= ~(1ull << at);
-                bit = bit0 + at + (int)(e & 255u);
-                end = 1;
-            }
-            // the lanes that hold a real symbol append it to the queue, in stream order
-            if ((starts >> lane) & 1ull) S.queue[nsym + lanes_below(starts)] = sp;
-            nsym += (int)__popcll(starts);
-            __syncthreads();
-            while (nsym >= LANES || (end && nsym > 0)) {
-                const int n = min(nsym, LANES);
-                const uint32_t q = S.queue[lane];
-                const uint32_t q2 = S.queue[LANES + lane];
-                if (run_queue(o, olen, opos, q, n, lane) != 0) { rc = -1; end = 1; break; }
-                nsym -= n;
-                __syncthreads();
-                if (lane < nsym) S.queue[lane] = q2;
-                __syncthreads();
-            }
-            pos -= LANES;
-            bit0 += LANES;
-        }
+        const SymbolsEnd r = decode_symbols(S, p8, nbytes, o, olen, opos, bit, P);
+        rc = r.rc; opos = r.opos; bit = r.bit;
         if (rc != 0) break;
         __syncthreads();                                   // the tables are rebuilt by the next header
     }
@@ -462,19 +663,33 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const uint32_t* __restri
         if (opos != olen) rc = -2;                         // fewer bytes than the trailer's ISIZE
         else if (bit > nbytes * 8) rc = -1;                // ran past the payload
     }
+    P.mark(3);
+    if (crc_out) {
+        const uint32_t crc = rc == 0 ? block_crc(S, o, olen, lane) : 0u;
+        if (lane == 0) crc_out[g] = crc;
+    }
+    P.mark(5);
+    P.out(g, lane);
     if (lane == 0) status[g] = rc;
 }
 
 }  // namespace
 
 // ---- C ABI (include/tredgpu.h) ------------------------------------------------------------------------------------
+// A call is cut into slices of blocks that alternate between two streams: the copy-in and the decoding of slice k + 1
+// run beside the copy-out of slice k (the copy-out is the long pole: four bytes leave for every byte that arrives).
+constexpr int MAX_SLICES = 8;
+constexpr int SLICE_BLOCKS = 4096;      // >= 4 096 wavefronts per launch: 16 per CU, and two launches run side by side
+
 struct tredgpu_inflater {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;          // created with hipEventBlockingSync: waiting for a call sleeps, it does not spin
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};   // waited for asleep (polled): see tredgpu_inflate_blocks
+    hipEvent_t t0[2] = {}, t1[2] = {}, k0[MAX_SLICES] = {}, k1[MAX_SLICES] = {};   // timing (tredgpu_inflater_timing)
+    int last_slices = 0, last_streams = 0;
     uint8_t *h_comp = nullptr, *h_out = nullptr;      // pinned staging the caller fills / reads in place
     int64_t *h_off = nullptr;                         // pinned: comp_off[n+1] then out_off[n+1]
-    int32_t* h_status = nullptr;
+    int32_t* h_status = nullptr;                      // pinned: status[n] then crc[n]
     size_t cap_comp = 0, cap_out = 0, cap_blocks = 0;
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     int64_t* d_off = nullptr;
@@ -509,6 +724,12 @@ void release(tredgpu_inflater* f) {
     f->d_comp = f->d_out = nullptr; f->d_off = nullptr; f->d_status = nullptr;
     f->cap_comp = f->cap_out = f->cap_blocks = 0;
 }
+
+void destroy_handles(tredgpu_inflater* f) {
+    for (hipEvent_t e : {f->done[0], f->done[1], f->t0[0], f->t0[1], f->t1[0], f->t1[1]}) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < MAX_SLICES; ++k) { if (f->k0[k]) (void)hipEventDestroy(f->k0[k]); if (f->k1[k]) (void)hipEventDestroy(f->k1[k]); }
+    for (hipStream_t st : f->stream) if (st) (void)hipStreamDestroy(st);
+}
 }  // namespace
 
 extern "C" {
@@ -523,12 +744,22 @@ int tredgpu_inflater_create(int device_id, tredgpu_inflater** out) {
     tredgpu_inflater* f = new tredgpu_inflater();
     f->device = device_id;
     // the lowest stream priority: a genotyping launch of the same or another driver process should not queue up behind
-    // several of these (kernels of different streams run one after the other here, and one of these takes 20-40 ms)
+    // several of these
     int lo_prio = 0, hi_prio = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, lo_prio)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&f->done, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) {
-        if (f->stream) (void)hipStreamDestroy(f->stream);
+    e = hipSetDevice(device_id);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipStreamCreateWithPriority(&f->stream[k], hipStreamNonBlocking, lo_prio);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->done[k], hipEventBlockingSync | hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreate(&f->t0[k]);
+        if (e == hipSuccess) e = hipEventCreate(&f->t1[k]);
+    }
+    for (int k = 0; k < MAX_SLICES && e == hipSuccess; ++k) {
+        e = hipEventCreate(&f->k0[k]);
+        if (e == hipSuccess) e = hipEventCreate(&f->k1[k]);
+    }
+    if (e != hipSuccess) {
+        destroy_handles(f);
         delete f;
         return ifail(nullptr, -10, "stream / event creation", e);
     }
@@ -539,10 +770,9 @@ int tredgpu_inflater_create(int device_id, tredgpu_inflater** out) {
 void tredgpu_inflater_destroy(tredgpu_inflater* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    (void)hipStreamSynchronize(f->stream);
+    for (hipStream_t st : f->stream) (void)hipStreamSynchronize(st);
     release(f);
-    (void)hipEventDestroy(f->done);
-    (void)hipStreamDestroy(f->stream);
+    destroy_handles(f);
     delete f;
 }
 
@@ -556,18 +786,18 @@ int tredgpu_inflater_reserve(tredgpu_inflater* f, int64_t comp_bytes, int64_t ou
     ICHK(f, hipSetDevice(f->device));
     const size_t need_c = (size_t)comp_bytes + 64, need_o = (size_t)out_bytes + 64, need_b = (size_t)n_blocks + 1;
     if (need_c > f->cap_comp || need_o > f->cap_out || need_b > f->cap_blocks) {
-        ICHK(f, hipStreamSynchronize(f->stream));
+        for (hipStream_t st : f->stream) ICHK(f, hipStreamSynchronize(st));
         const size_t cc = std::max(need_c, f->cap_comp + f->cap_comp / 2), co = std::max(need_o, f->cap_out + f->cap_out / 2),
                      cb = std::max(need_b, f->cap_blocks + f->cap_blocks / 2);
         release(f);
         ICHK(f, hipHostMalloc((void**)&f->h_comp, cc, hipHostMallocDefault));
         ICHK(f, hipHostMalloc((void**)&f->h_out, co, hipHostMallocDefault));
         ICHK(f, hipHostMalloc((void**)&f->h_off, 2 * cb * sizeof(int64_t), hipHostMallocDefault));
-        ICHK(f, hipHostMalloc((void**)&f->h_status, cb * sizeof(int32_t), hipHostMallocDefault));
+        ICHK(f, hipHostMalloc((void**)&f->h_status, 2 * cb * sizeof(int32_t), hipHostMallocDefault));
         ICHK(f, hipMalloc((void**)&f->d_comp, cc));
         ICHK(f, hipMalloc((void**)&f->d_out, co));
         ICHK(f, hipMalloc((void**)&f->d_off, 2 * cb * sizeof(int64_t)));
-        ICHK(f, hipMalloc((void**)&f->d_status, cb * sizeof(int32_t)));
+        ICHK(f, hipMalloc((void**)&f->d_status, 2 * cb * sizeof(int32_t)));
         f->cap_comp = cc; f->cap_out = co; f->cap_blocks = cb;
     }
     *comp_host = f->h_comp;
@@ -577,7 +807,7 @@ int tredgpu_inflater_reserve(tredgpu_inflater* f, int64_t comp_bytes, int64_t ou
     return 0;
 }
 
-int tredgpu_inflate_blocks(tredgpu_inflater* f, int32_t n_blocks, int32_t* status) {
+int tredgpu_inflate_blocks_crc(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t* crc) {
     if (!f) return -2;
     if (n_blocks < 0 || (size_t)n_blocks + 1 > f->cap_blocks || (n_blocks > 0 && !status)) return ifail(f, -2, "bad arguments (reserve first)");
     if (n_blocks == 0) return 0;
@@ -590,28 +820,69 @@ int tredgpu_inflate_blocks(tredgpu_inflater* f, int32_t n_blocks, int32_t* statu
     }
     if ((size_t)coff[n_blocks] + 64 > f->cap_comp || (size_t)ooff[n_blocks] + 64 > f->cap_out) return ifail(f, -2, "offsets beyond the reserved buffers");
     ICHK(f, hipSetDevice(f->device));
-    const size_t cbytes = ((size_t)coff[n_blocks] + 3) & ~(size_t)3;
-    ICHK(f, hipMemcpyAsync(f->d_comp, f->h_comp, cbytes, hipMemcpyHostToDevice, f->stream));
-    ICHK(f, hipMemcpyAsync(f->d_off, f->h_off, ((size_t)n_blocks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->stream));
-    ICHK(f, hipMemcpyAsync(f->d_off + f->cap_blocks, f->h_off + f->cap_blocks, ((size_t)n_blocks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->stream));
-    inflate_kernel<<<n_blocks, LANES, 0, f->stream>>>((const uint32_t*)f->d_comp, f->d_off, f->d_out, f->d_off + f->cap_blocks, n_blocks,
-                                                     f->d_status);
-    ICHK(f, hipGetLastError());
-    ICHK(f, hipMemcpyAsync(f->h_out, f->d_out, (size_t)ooff[n_blocks], hipMemcpyDeviceToHost, f->stream));
-    ICHK(f, hipMemcpyAsync(f->h_status, f->d_status, (size_t)n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
-    ICHK(f, hipEventRecord(f->done, f->stream));
+    const int slices = std::min(MAX_SLICES, std::max(1, n_blocks / SLICE_BLOCKS));
+    const int nstreams = slices > 1 ? 2 : 1;
+    int64_t* d_coff = f->d_off;
+    int64_t* d_ooff = f->d_off + f->cap_blocks;
+    int32_t* d_crc = f->d_status + f->cap_blocks;
+    // the two streams never wait for each other: each copies the offsets in for itself (both write the same values)
+    for (int s = 0; s < nstreams; ++s) {
+        ICHK(f, hipEventRecord(f->t0[s], f->stream[s]));
+        ICHK(f, hipMemcpyAsync(d_coff, coff, ((size_t)n_blocks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->stream[s]));
+        ICHK(f, hipMemcpyAsync(d_ooff, ooff, ((size_t)n_blocks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->stream[s]));
+    }
+    for (int k = 0; k < slices; ++k) {
+        hipStream_t st = f->stream[k % nstreams];
+        const int32_t b0 = (int32_t)((int64_t)n_blocks * k / slices), b1 = (int32_t)((int64_t)n_blocks * (k + 1) / slices);
+        const size_t c_from = (size_t)coff[b0], c_to = std::min(((size_t)coff[b1] + 3) & ~(size_t)3, f->cap_comp);
+        ICHK(f, hipMemcpyAsync(f->d_comp + c_from, f->h_comp + c_from, c_to - c_from, hipMemcpyHostToDevice, st));
+        ICHK(f, hipEventRecord(f->k0[k], st));
+        inflate_kernel<<<b1 - b0, LANES, 0, st>>>((const uint32_t*)f->d_comp, d_coff, f->d_out, d_ooff, b0, f->d_status, crc ? (uint32_t*)d_crc : nullptr);
+        ICHK(f, hipGetLastError());
+        ICHK(f, hipEventRecord(f->k1[k], st));
+        ICHK(f, hipMemcpyAsync(f->h_out + ooff[b0], f->d_out + ooff[b0], (size_t)(ooff[b1] - ooff[b0]), hipMemcpyDeviceToHost, st));
+        ICHK(f, hipMemcpyAsync(f->h_status + b0, f->d_status + b0, (size_t)(b1 - b0) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (crc) ICHK(f, hipMemcpyAsync(f->h_status + f->cap_blocks + b0, d_crc + b0, (size_t)(b1 - b0) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
+    f->last_slices = slices;
+    f->last_streams = nstreams;
+    for (int s = 0; s < nstreams; ++s) {
+        ICHK(f, hipEventRecord(f->t1[s], f->stream[s]));
+        ICHK(f, hipEventRecord(f->done[s], f->stream[s]));
+    }
     // wait asleep: hipEventSynchronize spins even on a hipEventBlockingSync event here (measured: CPU time = wall time,
     // and calls of other threads on other streams queue up behind the spinning one); the host threads that wait are the
-    // ones whose cores the path is short of, and a call takes tens of milliseconds
-    for (;;) {
-        const hipError_t q = hipEventQuery(f->done);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) return ifail(f, -10, "hipEventQuery", q);
-        usleep(200);
+    // ones whose cores the path is short of
+    for (int s = 0; s < nstreams; ++s) {
+        for (;;) {
+            const hipError_t q = hipEventQuery(f->done[s]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return ifail(f, -10, "hipEventQuery", q);
+            usleep(100);
+        }
     }
     int bad = 0;
     for (int32_t k = 0; k < n_blocks; ++k) { status[k] = f->h_status[k]; bad += status[k] != 0; }
+    if (crc) for (int32_t k = 0; k < n_blocks; ++k) crc[k] = (uint32_t)f->h_status[f->cap_blocks + k];
     return bad;
+}
+
+int tredgpu_inflate_blocks(tredgpu_inflater* f, int32_t n_blocks, int32_t* status) { return tredgpu_inflate_blocks_crc(f, n_blocks, status, nullptr); }
+
+int tredgpu_inflater_timing(tredgpu_inflater* f, double* total_ms, double* kernel_ms) {
+    if (!f || !total_ms || !kernel_ms) return -2;
+    *total_ms = *kernel_ms = 0.0;
+    if (f->last_slices == 0) return 0;
+    ICHK(f, hipSetDevice(f->device));
+    float ms = 0.f;
+    for (int s = 0; s < f->last_streams; ++s) {
+        ICHK(f, hipEventElapsedTime(&ms, f->t0[0], f->t1[s]));
+        *total_ms = std::max(*total_ms, (double)ms);
+    }
+    for (int k = 0; k < f->last_slices; ++k) {
+        if (hipEventElapsedTime(&ms, f->k0[k], f->k1[k]) == hipSuccess) *kernel_ms += ms;
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -91,6 +91,140 @@ def usable_cpus():
     return max(1, n)
 
 
+# ---- which host CPUs a rank should live on -------------------------------------------------------------------
+# The from-BAM path is host-bound: on a two-socket 8-GPU node a rank whose scan threads and pinned staging
+# float across sockets pays the inter-socket link on every inflated byte.  The GPU-less parent reads the topology
+# from sysfs (no HIP call: it must stay off the GPU), gives every rank a CPU set on its GPU's NUMA node, and the child
+# applies it with sched_setaffinity before anything touches the GPU -- its pinned buffers are allocated afterwards
+# and land on that node (first touch).
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(cpus))
+
+
+def format_cpulist(cpus):
+    cpus = sorted(set(cpus))
+    runs, k = [], 0
+    while k < len(cpus):
+        j = k
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        runs.append(str(cpus[k]) if j == k else "{}-{}".format(cpus[k], cpus[j]))
+        k = j + 1
+    return ",".join(runs)
+
+
+def gpu_numa_nodes(root="/"):
+    """NUMA node of every GPU in HIP's device order, read from sysfs alone: the KFD topology lists the compute
+    nodes in the order the runtime enumerates them (nodes with simd_count > 0 are GPUs), each with the minor of its
+    DRM render node, whose PCI device carries numa_node.  [] when the tree is not there; -1 for an unknown node."""
+    import os
+    base = os.path.join(root, "sys/class/kfd/kfd/topology/nodes")
+    try:
+        ids = sorted((int(d) for d in os.listdir(base) if d.isdigit()))
+    except OSError:
+        return []
+    nodes = []
+    for i in ids:
+        props = {}
+        try:
+            with open(os.path.join(base, str(i), "properties")) as fp:
+                for line in fp:
+                    key, _, val = line.strip().partition(" ")
+                    props[key] = val
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue                                   # a CPU node
+        node = -1
+        try:
+            with open(os.path.join(root, "sys/class/drm/renderD{}/device/numa_node".format(int(props["drm_render_minor"])))) as fp:
+                node = int(fp.read().strip())
+        except (OSError, KeyError, ValueError):
+            pass
+        nodes.append(node)
+    return nodes
+
+
+def numa_cpus(root="/"):
+    """{node: [cpus]} from /sys/devices/system/node/node*/cpulist."""
+    import os
+    base = os.path.join(root, "sys/devices/system/node")
+    out = {}
+    try:
+        names = os.listdir(base)
+    except OSError:
+        return out
+    for d in names:
+        if d.startswith("node") and d[4:].isdigit():
+            try:
+                with open(os.path.join(base, d, "cpulist")) as fp:
+                    out[int(d[4:])] = parse_cpulist(fp.read())
+            except (OSError, ValueError):
+                pass
+    return out
+
+
+def rank_cpusets(world, n_devices, allowed=None, gpu_nodes=None, node_cpus=None, visible=None):
+    """CPU set of every rank (rank r works on device r mod n_devices): the CPUs of its GPU's NUMA node that this
+    process may use, cut into disjoint, equal slices among the ranks that share the node; ranks whose GPU's node is
+    unknown (or has no allowed CPU) share what is left over the same way.  `visible`: the HIP_VISIBLE_DEVICES entries
+    when they are plain indices (device d of this process is physical device visible[d])."""
+    import os
+    if allowed is None:
+        allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    gpu_nodes = gpu_numa_nodes() if gpu_nodes is None else gpu_nodes
+    node_cpus = numa_cpus() if node_cpus is None else node_cpus
+    allowed_set = set(allowed)
+    node_of = []
+    for r in range(world):
+        d = r % n_devices if n_devices > 0 else -1
+        if d >= 0 and visible and d < len(visible):
+            d = visible[d]
+        node = gpu_nodes[d] if 0 <= d < len(gpu_nodes) else -1
+        if node not in node_cpus or not (allowed_set & set(node_cpus[node])):
+            node = -1
+        node_of.append(node)
+    taken = set()
+    for node in set(node_of) - {-1}:
+        taken |= allowed_set & set(node_cpus[node])
+    pools = {node: sorted(allowed_set & set(node_cpus[node])) for node in set(node_of) - {-1}}
+    if -1 in node_of:
+        pools[-1] = sorted(allowed_set - taken)
+        if not pools[-1]:                  # nothing is left for the ranks without a node: no topology at all, then --
+            node_of = [-1] * world         # every rank an equal, disjoint slice of what this process may use
+            pools = {-1: sorted(allowed_set)}
+    sets = [None] * world
+    for node, pool in pools.items():
+        members = [r for r in range(world) if node_of[r] == node]
+        for k, r in enumerate(members):
+            lo, hi = shard_range(len(pool), k, len(members))
+            sets[r] = pool[lo:hi] or pool              # (more ranks than CPUs: they share the pool)
+    return sets
+
+
+def apply_rank_cpuset(env=None):
+    """In a rank: confine this process to TRED_CPUSET (set by spawn_ranks) -- call it before the first GPU call and
+    before any pinned allocation.  Returns the CPUs, or None when there is nothing to apply."""
+    import os
+    text = (os.environ if env is None else env).get("TRED_CPUSET", "")
+    if not text or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = parse_cpulist(text)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return cpus
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -129,19 +263,32 @@ def rank_env(rank, world, port, device, base=None):
     return env
 
 
-def spawn_ranks(argv, world, n_devices, timeout=None, env=None, stdout=None, cwd=None):
+def _visible_indices(env):
+    mask = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES") or ""
+    entries = [e.strip() for e in mask.split(",") if e.strip()]
+    return [int(e) for e in entries] if entries and all(e.isdigit() for e in entries) else None
+
+
+def spawn_ranks(argv, world, n_devices, timeout=None, env=None, stdout=None, cwd=None, cpusets="auto"):
     """Start `world` child processes running `argv` (a full command line), rank r on device r mod n_devices
-    (n_devices = 0: no device pinning), wait for all of them and return their exit codes.  The children find each
+    (n_devices = 0: no device pinning), wait for all of them and return their exit codes.  Every rank is handed the
+    CPUs of its GPU's NUMA node in TRED_CPUSET (rank_cpusets; cpusets=None: leave the affinity alone, or a list).  The children find each
     other through RANK / WORLD_SIZE / MASTER_PORT exactly as under torch.distributed.run; nothing is exchanged
     on the data path (sample x locus units are independent), so no RCCL is involved -- the ranks only meet in a
     barrier and a (sum units, max time) reduction when they want one.
     The reference fans out the same way, one worker per sample (tredparse/tred.py:521-532)."""
     import subprocess
+    import os
     port = free_port()
     procs = []
+    if cpusets == "auto":
+        cpusets = rank_cpusets(world, n_devices, visible=_visible_indices(os.environ if env is None else env)) if n_devices > 0 else None
     for r in range(world):
         dev = (r % n_devices) if n_devices > 0 else None
-        procs.append(subprocess.Popen(argv, env=rank_env(r, world, port, dev, env), stdout=stdout, cwd=cwd))
+        renv = rank_env(r, world, port, dev, env)
+        if cpusets and cpusets[r]:
+            renv["TRED_CPUSET"] = format_cpulist(cpusets[r])
+        procs.append(subprocess.Popen(argv, env=renv, stdout=stdout, cwd=cwd))
     codes = []
     try:
         for p in procs:

@@ -23,6 +23,7 @@ import logging
 import os
 import shutil
 import sys
+import threading
 import time
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
@@ -39,6 +40,16 @@ logger = logging.getLogger(__name__)
 # the writer thread's time in the sink (JSON / VCF text and files)
 TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
           "inflate_hits": 0, "inflate_misses": 0}
+_TIMING_LOCK = threading.Lock()
+
+
+def timing_add(**kw):
+    """TIMING[key] += value for every keyword, under a lock: the scan pool, the feeder and the writer thread all
+    report here while the driver thread does too (a lost update would show up in bench.py's driver_seconds)."""
+    with _TIMING_LOCK:
+        for k, v in kw.items():
+            TIMING[k] += v
+
 
 # (ID, Number, Type, Description) of the VCF meta lines, in file order
 _VCF_INFO = (("RPA", "1", "String", "Repeats per allele"), ("END", "1", "Integer", "End position of variant"),
@@ -81,7 +92,9 @@ def set_argparse():
     p.add_argument("--version", action="version", version="%(prog)s " + __version__)
     p.add_argument("--toy", action="store_true", help=argparse.SUPPRESS)
     g = p.add_argument_group("Performance options")
-    g.add_argument("--cpus", type=int, default=1, help="host threads scanning BAMs (per GPU)")
+    g.add_argument("--cpus", type=int, default=None,
+                   help="host threads scanning BAMs, per GPU (default: the usable CPUs -- affinity mask and cgroup quota -- "
+                        "shared among the --gpus ranks; the reference's default is cpu_count() workers)")
     g.add_argument("--gpus", type=int, default=1, help="GPUs to spread the samples over (one process each)")
     g.add_argument("--gpu", type=int, default=0, help="device index when --gpus is 1")
     g.add_argument("--batch-samples", type=int, default=64, help="samples per GPU batch")
@@ -188,26 +201,28 @@ def _plan_sample(arg):
         return None
 
 
-def _scan_planned(arg, plan, out_addr, out_off, status):
-    """Thread: the sample's scan with its planned blocks preloaded from the inflater's output."""
+def _scan_planned(arg, plan, out_addr, out_off, status, crc=None):
+    """Thread: the sample's scan with its planned blocks preloaded from the inflater's output (crc: the decoder's
+    checksums of those blocks -- the scan then does not walk the bytes for the BGZF CRC again)."""
     o = _options(arg)
     f = plan["handle"]
     try:
         if status is not None:
-            f.preload(out_addr, out_off, status)
+            f.preload(out_addr, out_off, status, crc)
         return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"], readlen=plan["readlen"], handle=f)
     finally:
         if status is not None:
             hits, misses = f.preload_clear()
-            TIMING["inflate_hits"] += hits
-            TIMING["inflate_misses"] += misses
+            timing_add(inflate_hits=hits, inflate_misses=misses)
         f.close()
 
 
 class _InflateFeeder(object):
     """Feeds run_many's chunks through plan -> GPU inflate -> scan, one chunk ahead of the consumer: next(chunk index)
     returns the chunk's scan futures.  Two inflaters alternate; one is reused only when every scan that reads its output
-    has finished."""
+    has finished.  close() can be called at any time -- also while the consumer is unwinding from an error: the thread
+    is told to stop, whatever it has planned but not handed to a scan is closed, and the inflaters go only after
+    every scan that reads their buffers has ended."""
 
     def __init__(self, chunks, ex, device):
         import queue
@@ -220,57 +235,86 @@ class _InflateFeeder(object):
         self.inflaters = [Inflater(device), Inflater(device)]
         self.busy = [[], []]
         self.q = queue.Queue(maxsize=2)
+        self.stop = threading.Event()
         self.thread = threading.Thread(target=self._run, name="tred-inflate", daemon=True)
         self.thread.start()
 
     def _chunk(self, ci, chunk):
-        import numpy as np
         inf, slot = self.inflaters[ci % 2], ci % 2
         for fut in self.busy[slot]:
             fut.exception()                            # (waits; the consumer sees the error itself)
         plans = [fut.result() for fut in [self.prep.submit(_plan_sample, a) for a in chunk]]
-        live = [p for p in plans if p is not None and p["n"] > 0]
-        t0 = time.perf_counter()
-        status = None
-        if live:
+        handed = False
+        try:
+            if self.stop.is_set():
+                return None
+            live = [p for p in plans if p is not None and p["n"] > 0]
+            t0 = time.perf_counter()
+            status = crc = None
+            if live:
+                try:
+                    n_all = sum(p["n"] for p in live)
+                    comp, out, coff, ooff = inf.reserve(sum(p["cbytes"] for p in live), sum(p["obytes"] for p in live), n_all)
+                    at = cb = ob = 0
+                    fills = []
+                    for p in live:
+                        p["first"] = at
+                        fills.append(self.prep.submit(p["handle"].plan_fill, inf.comp_addr, cb, ob, coff[at:at + p["n"] + 1],
+                                                    ooff[at:at + p["n"] + 1]))
+                        at, cb, ob = at + p["n"], cb + p["cbytes"], ob + p["obytes"]
+                    for fut in fills:
+                        fut.result()
+                    # (every sample wrote its own end as entry n: the next sample's first entry is the same number)
+                    status, crc = inf.run(n_all, crc=True)
+                    timing_add(inflate_blocks=n_all, inflate_failed=int((status != 0).sum()))
+                except Exception as e:     # no GPU help for this chunk: the scans inflate for themselves
+                    logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
+                    status = crc = None
+            timing_add(inflate=time.perf_counter() - t0)
+            if self.stop.is_set():
+                return None
+            futs = []
+            for a, p in zip(chunk, plans):
+                if p is None:
+                    futs.append(self.ex.submit(collect_sample, a))
+                elif status is None or p["n"] == 0:
+                    futs.append(self.ex.submit(_scan_planned, a, p, 0, None, None))
+                else:
+                    k = p["first"]
+                    futs.append(self.ex.submit(_scan_planned, a, p, inf.out_addr, ooff[k:k + p["n"] + 1], status[k:k + p["n"]],
+                                               crc[k:k + p["n"]]))
+            handed = True                                  # (each scan closes its own handle)
+            self.busy[slot] = futs
+            return futs
+        finally:
+            if not handed:
+                for p in plans:
+                    if p is not None:
+                        try:
+                            p["handle"].close()
+                        except Exception:
+                            pass
+
+    def _put(self, item):
+        import queue
+        while not self.stop.is_set():
             try:
-                n_all = sum(p["n"] for p in live)
-                comp, out, coff, ooff = inf.reserve(sum(p["cbytes"] for p in live), sum(p["obytes"] for p in live), n_all)
-                at = cb = ob = 0
-                fills = []
-                for p in live:
-                    p["first"] = at
-                    fills.append(self.prep.submit(p["handle"].plan_fill, inf.comp_addr, cb, ob, coff[at:at + p["n"] + 1],
-                                                ooff[at:at + p["n"] + 1]))
-                    at, cb, ob = at + p["n"], cb + p["cbytes"], ob + p["obytes"]
-                for fut in fills:
-                    fut.result()
-                # (every sample wrote its own end as entry n: the next sample's first entry is the same number)
-                status = inf.run(n_all)
-                TIMING["inflate_blocks"] += n_all
-                TIMING["inflate_failed"] += int((status != 0).sum())
-            except Exception as e:     # no GPU help for this chunk: the scans inflate for themselves
-                logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
-                status = None
-        TIMING["inflate"] += time.perf_counter() - t0
-        futs = []
-        for a, p in zip(chunk, plans):
-            if p is None:
-                futs.append(self.ex.submit(collect_sample, a))
-            elif status is None or p["n"] == 0:
-                futs.append(self.ex.submit(_scan_planned, a, p, 0, None, None))
-            else:
-                k = p["first"]
-                futs.append(self.ex.submit(_scan_planned, a, p, inf.out_addr, ooff[k:k + p["n"] + 1], status[k:k + p["n"]]))
-        self.busy[slot] = futs
-        return futs
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def _run(self):
         try:
             for ci, chunk in enumerate(self.chunks):
-                self.q.put(self._chunk(ci, chunk))
+                if self.stop.is_set():
+                    return
+                futs = self._chunk(ci, chunk)
+                if futs is None or not self._put(futs):
+                    return
         except BaseException as e:     # hand the failure to the consumer instead of leaving it waiting
-            self.q.put(e)
+            self._put(e)
 
     def next(self):
         item = self.q.get()
@@ -279,10 +323,17 @@ class _InflateFeeder(object):
         return item
 
     def close(self):
-        self.thread.join(timeout=60)
+        import queue
+        self.stop.set()
+        while True:                                        # make room: a put in progress returns at once
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                break
+        self.thread.join()                                 # (bounded: the thread checks the flag between every two steps)
         for slot in self.busy:
             for fut in slot:
-                fut.exception()
+                fut.exception()                            # scans still reading the staging buffers: let them end
         self.prep.shutdown()
         for inf in self.inflaters:
             inf.close()
@@ -371,7 +422,7 @@ def finish_batch(engine, task_args, scans, lazy_details=False):
     for o, sub in groups.values():
         res.update(_genotype(engine, sub, o))
     t1 = time.perf_counter()
-    TIMING["gpu"] += t1 - t0
+    timing_add(gpu=t1 - t0)
     results = []
     for si, (arg, scan) in enumerate(zip(task_args, scans)):
         o = _options(arg)
@@ -386,7 +437,7 @@ def finish_batch(engine, task_args, scans, lazy_details=False):
             except GridError as e:
                 logger.error("Exception on `%s` %s (%s)", o["bam"], scan.names[k], e)
         results.append(result)
-    TIMING["format"] += time.perf_counter() - t1
+    timing_add(format=time.perf_counter() - t1)
     return results
 
 
@@ -421,7 +472,7 @@ class _Writer(object):
                     self.sink(item)
                 except BaseException as e:      # handed to the driver thread
                     self.error = e
-                TIMING["write"] += time.perf_counter() - t0
+                timing_add(write=time.perf_counter() - t0)
 
     def __call__(self, result):
         self.q.put(result)
@@ -468,14 +519,14 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
                 futs = feeder.next()
                 t0 = time.perf_counter()
                 scans = [f.result() for f in futs]
-                TIMING["scan_wait"] += time.perf_counter() - t0
+                timing_add(scan_wait=time.perf_counter() - t0)
             elif ex is not None:
                 while nxt < len(chunks) and nxt <= i + max(1, ahead_batches):
                     ahead.append(submit(chunks[nxt]))
                     nxt += 1
                 t0 = time.perf_counter()
                 scans = [f.result() for f in ahead.popleft()]
-                TIMING["scan_wait"] += time.perf_counter() - t0
+                timing_add(scan_wait=time.perf_counter() - t0)
             else:
                 scans = [collect_sample(a) for a in chunk]
             for r in finish_batch(engine, chunk, scans, lazy_details=lazy_details):
@@ -483,13 +534,24 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
                     sink(r)
                 else:
                     out.append(r)
-    finally:
+    except BaseException:
+        # unwinding from an error: stop the helpers, keep THIS exception (a sink that also failed must not replace it)
         if feeder is not None:
             feeder.close()
         if own:
             ex.shutdown()
         if writer is not None:
-            writer.close()
+            try:
+                writer.close()
+            except BaseException:
+                pass
+        raise
+    if feeder is not None:
+        feeder.close()
+    if own:
+        ex.shutdown()
+    if writer is not None:
+        writer.close()
     return out
 
 
@@ -676,10 +738,24 @@ def _fan_out(argv, n_gpus, samples, launch_dir, no_output, quiet, devices=None):
     return max(codes) if codes else 0
 
 
+def default_cpus(gpus, pinned, usable=None):
+    """--cpus when it is not given: the reference starts cpu_count() workers (tredparse/tred.py:88); here the CPUs this
+    process may really keep busy (affinity mask, cgroup quota) shared among the --gpus ranks, and in a rank never more
+    than its CPU set holds."""
+    from . import shard
+    share = max(1, (shard.usable_cpus() if usable is None else usable) // max(1, gpus))
+    return max(1, min(share, len(pinned))) if pinned else share
+
+
 def main(args, quiet=False):
     argv = list(args)
     p = set_argparse()
     args = p.parse_args(argv)
+    from . import shard
+    usable = shard.usable_cpus()               # (of the inherited mask: what the whole job has, before this rank is pinned)
+    pinned = shard.apply_rank_cpuset() if args.task_file else None   # a --gpus child: its GPU's NUMA node, before any GPU call
+    if args.cpus is None:
+        args.cpus = default_cpus(args.gpus, pinned, usable)
     logger.setLevel(getattr(logging, args.log))
     logging.getLogger("tredparse_amd.bam").setLevel(getattr(logging, args.log))
     t0 = time.time()
