@@ -225,6 +225,13 @@ def rank_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     spawned = os.environ.get("TRED_SPAWNED_RANK") == "1"       # started by this script's launcher, not by torchrun
     loci, batch = make_batch(args, rank, world)                 # process pool first, before this process touches the GPU
+    stream_batches = []
+    if getattr(args, "streamed", 0) > 0:                        # distinct batches of the streamed leg: other seeds
+        seed0 = args.seed
+        for i in range(args.streamed):
+            args.seed = seed0 + 7919 * (i + 1)
+            stream_batches.append(make_batch(args, rank, world)[1])
+        args.seed = seed0
 
     import torch
     from tredparse_amd import _lib
@@ -300,6 +307,7 @@ def rank_main(args):
     sw_n, sw_ms = ctx.get_timing(_lib.KERNEL_SW)
     gr_n, gr_ms = ctx.get_timing(_lib.KERNEL_GRID)
     ta_n, ta_ms = ctx.get_timing(_lib.KERNEL_TALLY)
+    streamed = streamed_leg(ctx, torch, dev, stream_batches, args, params, g * args.steps / elapsed_local) if stream_batches else None
     calls = np.frombuffer(d_calls.cpu().numpy().tobytes(), _lib.CALL_DTYPE)
     ok = int((calls["status"] == 0).sum())
     # sanity: the genotypes are real (most simulated alleles recovered exactly on the short allele)
@@ -364,8 +372,15 @@ def rank_main(args):
                                     "grid_reduce": ctx.get_timing(_lib.KERNEL_GRID_REDUCE)[1] / max(gr_n, 1)},
             "check": {"units_ok": ok, "units": g, "short_allele_exact_frac": short_ok,
                       "mean_grid_pairs": float(calls["n_pairs"].mean()), "max_grid_pairs": int(calls["n_pairs"].max()),
+                      # how the (h1, h2) rectangles are distributed: units whose grid would fit a 32 KB / 128 KB LDS slice, and
+                      # the share of all pairs those units hold (why the ml rectangle stays in HBM)
+                      "grid_pairs_percentiles": {str(q): int(np.percentile(calls["n_pairs"], q)) for q in (10, 50, 75, 90, 99)},
+                      "units_le_4096_pairs": float(np.mean(calls["n_pairs"] <= 4096)), "pairs_in_units_le_4096": float(calls["n_pairs"][calls["n_pairs"] <= 4096].sum() / max(1, calls["n_pairs"].sum())),
+                      "units_le_16384_pairs": float(np.mean(calls["n_pairs"] <= 16384)), "pairs_in_units_le_16384": float(calls["n_pairs"][calls["n_pairs"] <= 16384].sum() / max(1, calls["n_pairs"].sum())),
                       "run_pe_frac": float(calls["run_pe"].mean())},
         }
+        if streamed is not None:
+            out["streamed"] = streamed
         if out_dir:
             with open(os.path.join(out_dir, "line.json"), "w") as fp:
                 json.dump(out, fp)
@@ -373,6 +388,87 @@ def rank_main(args):
             print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def streamed_leg(ctx, torch, dev, batches, args, params, resident_rate):
+    """The same step fed from the host: K distinct batches sit in PINNED host memory; while batch k runs on the
+    context's stream, batch k + 1 is copied in on a copy stream into the other of two device buffer sets, and the calls
+    of batch k - 1 are copied back.  Every step moves its whole input over PCIe (the resident headline replays one
+    batch that is already in HBM); the calls of every step are checked against the simulated alleles.  Returns the
+    record of the `streamed` leg (value = this rank's genotypes/s)."""
+    from tredparse_amd import _lib
+    K = len(batches)
+    hs = max(b.hist_stride for b in batches)
+    names = ("packed", "read_off", "read_len", "unit_read_off", "unit_ladder", "units", "global_lens", "target_lens")
+
+    def arrays(b):
+        return (b.packed.view(np.int32), b.read_off, b.read_len, b.unit_read_off, b.unit_ladder, b.units.view(np.uint8),
+                b.global_lens if len(b.global_lens) else np.zeros(1, np.int32),
+                b.target_lens if len(b.target_lens) else np.zeros(1, np.int32))
+    pinned = [[torch.from_numpy(np.ascontiguousarray(a)).pin_memory() for a in arrays(b)] for b in batches]
+    sets = []
+    for _ in range(2):
+        bufs = [torch.empty(max(p[k].numel() for p in pinned), dtype=pinned[0][k].dtype, device=dev) for k in range(len(names))]
+        nmax, gmax = max(b.n_reads for b in batches), max(b.n_units for b in batches)
+        outs = {"tag": torch.zeros(nmax, dtype=torch.uint8, device=dev), "h": torch.zeros(nmax, dtype=torch.int16, device=dev),
+                "sc": torch.zeros(nmax, dtype=torch.int16, device=dev),
+                "full": torch.zeros((gmax, hs), dtype=torch.int32, device=dev), "pref": torch.zeros((gmax, hs), dtype=torch.int32, device=dev),
+                "rept": torch.zeros((gmax, hs), dtype=torch.int32, device=dev),
+                "calls": torch.zeros(gmax * _lib.CALL_DTYPE.itemsize, dtype=torch.uint8, device=dev)}
+        sets.append((bufs, outs))
+    h_calls = [torch.zeros(b.n_units * _lib.CALL_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for b in batches]
+    copy = torch.cuda.Stream(device=dev)
+    compute = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+    in_bytes = [sum(t.numel() * t.element_size() for t in p) for p in pinned]
+
+    def copy_in(step):
+        i, slot = step % K, step % 2
+        with torch.cuda.stream(copy):
+            if step >= 2:
+                copy.wait_event(done[slot])            # the step that read this buffer set has finished
+            for k in range(len(names)):
+                sets[slot][0][k][:pinned[i][k].numel()].copy_(pinned[i][k], non_blocking=True)
+            ready[slot].record(copy)
+
+    def run(step):
+        i, slot = step % K, step % 2
+        b, (bufs, o) = batches[i], sets[slot]
+        compute.wait_event(ready[slot])
+        ctx.genotype_batch(_lib.MEM_DEVICE, bufs[0], bufs[1], bufs[2], b.n_reads, bufs[3], bufs[4], bufs[5], b.n_units, params, None,
+                           bufs[6], len(b.global_lens), bufs[7], len(b.target_lens), o["tag"], o["h"], o["sc"], hs,
+                           o["full"], o["pref"], o["rept"], o["calls"])
+        done[slot].record(compute)
+        with torch.cuda.stream(copy):                  # the calls go back behind the next batch's copy-in
+            copy.wait_event(done[slot])
+            h_calls[i].copy_(o["calls"][:h_calls[i].numel()], non_blocking=True)
+
+    def loop(steps):
+        copy_in(0)
+        for s in range(steps):
+            if s + 1 < steps:
+                copy_in(s + 1)
+            run(s)
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    loop(min(K, 2))                                    # warm-up (allocations inside the library, first touches)
+    steps = max(args.steps, K)            # (the first batch's copy-in is inside the timed region, un-overlapped: the pipeline's fill)
+    t0 = time.perf_counter()
+    loop(steps)
+    dt = time.perf_counter() - t0
+    units = sum(batches[s % K].n_units for s in range(steps))
+    exact = []
+    for b, hc in zip(batches, h_calls):
+        calls = np.frombuffer(hc.numpy().tobytes(), _lib.CALL_DTYPE)
+        exact.append(float(np.mean((calls["h1"] // b.units["period"]) == b.h_true[:, 0])))
+    return {"what": "{} distinct batches in pinned host memory, two device buffer sets: copy-in of batch k + 1 and copy-back "
+                    "of the calls of batch k - 1 on a copy stream while batch k runs; every step's input crosses PCIe".format(K),
+            "value": units / dt, "unit": "genotypes/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "distinct_batches": K, "input_MB_per_step": float(np.mean(in_bytes)) / 1e6,
+            "resident_value_same_run": resident_rate, "fraction_of_resident": units / dt / resident_rate,
+            "short_allele_exact_frac_per_batch": exact}
 
 
 def stub_rank_main(args):
@@ -439,9 +535,13 @@ def e2e_main(args):
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    first_pass = {"n": len(tasks) // max(1, args.e2e_repeat), "t": None}
+
     def sink(result):
         tred.write_vcf_json(result, "hg38", repo, names, quiet=True)
         done.append(result)
+        if len(done) == first_pass["n"]:
+            first_pass["t"] = time.perf_counter()
     try:
         tred.run_many(tasks[:2], engine, batch=2, sink=sink, threads=2, lazy_details=True)          # warm-up: HIP context, ladders, caches
         del done[:]
@@ -459,6 +559,7 @@ def e2e_main(args):
     hits = [r["tredCalls"].get(n + ".1") == truth[r["samplekey"]][k][0] for r in done for k, n in enumerate(names)]
     rec = {"rank": rank, "device": os.environ.get("TRED_RANK_DEVICE", "0"), "units": units, "seconds": dt,
            "samples": len(tasks), "host_threads": threads,
+           "first_pass_seconds": (first_pass["t"] - t0) if first_pass["t"] else dt, "first_pass_samples": first_pass["n"],
            "driver_seconds": {k: round(v, 4) for k, v in tred.TIMING.items()},
            "short_ok": int(sum(hits)), "short_n": len(hits), "bam_bytes": sum(os.path.getsize(b) for b in bams[lo:hi])}
     with open(os.path.join(out_dir, "e2e_rank{}.json".format(rank)), "w") as fp:
@@ -472,13 +573,14 @@ def e2e_main(args):
 def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0, dense=False):
     """[(ranks, threads per rank)] of the end-to-end legs on n_devices GPUs with `usable` host CPUs: one driver per
     GPU, and as many drivers per GPU as keep ~7 or ~4 scan threads busy each (a driver formats and hands its results
-    to a writer thread while its threads scan); dense: also one driver per four CPUs (the legs whose BGZF blocks the GPU
-    inflates leave the host a third of the work per sample: the drivers' own threads become the bound sooner).
+    to a writer thread while its threads scan); dense: also one driver per four and per three CPUs (the legs whose BGZF
+    blocks the GPU inflates leave the host a quarter of the work per sample: a driver's own Python threads -- formatting,
+    the writer, the GPU calls -- become the bound, and more processes is what spreads those).
     Rank r works on device r mod n_devices; every rank gets an equal share of the CPUs."""
     g = max(1, n_devices)
     tried = [drivers_opt] if drivers_opt else [max(1, usable // (8 * g)), max(1, usable // (5 * g))]
     if dense and not drivers_opt:
-        tried.append(max(1, usable // (4 * g)))
+        tried += [max(1, usable // (4 * g)), max(1, usable // (3 * g))]
     plans = []
     for dpg in sorted(set([1] + tried)):
         ranks = dpg * n_devices
@@ -541,6 +643,8 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
                              "value": units / secs, "unit": "genotypes/s",
                              "units": units, "seconds": secs, "samples": sum(r["samples"] for r in ranks),
                              "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,
+                             "first_pass_value": sum(r.get("first_pass_samples", 0) for r in ranks) * units / max(1, sum(r["samples"] for r in ranks))
+                                                 / max(max(r.get("first_pass_seconds", secs) for r in ranks), 1e-9),
                              "per_driver": [{"seconds": round(r["seconds"], 3), "device": r.get("device", "0"),
                                              **r["driver_seconds"]} for r in ranks],
                              "bam_MBps": nbytes / 1e6 / secs,
@@ -552,6 +656,13 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
             rec.setdefault("samples_per_gpu_batch", args.e2e_batch)
             rec["bam_generation_seconds"] = gen_s
             rec["cohort"] = "{} BAM files x {} passes per leg".format(n_files, max(1, args.e2e_repeat))
+            rec["page_cache"] = ("the files were written moments before the legs by this run: EVERY pass, the first included, reads them "
+                                 "from the page cache (`first_pass_value` = the rate up to the last result of a driver's first pass; "
+                                 "later passes also rewrite the same output files).  Not a cold-storage number; `value` is the best leg "
+                                 "over all passes, the leg with gpu_inflate false and one driver is the one that compares across rounds")
+            host_one = [l for l in legs if "value" in l and not l["gpu_inflate"] and l["drivers"] == n_devices]
+            if host_one:
+                rec["host_only_one_driver_per_gpu"] = {k: host_one[0][k] for k in ("value", "first_pass_value", "seconds", "samples")}
             rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
                            "native scan (BGZF inflate -- on the host, or on the GPU a batch of samples per launch in the `gpu_inflate` legs --, BAI queries, read selection, pair lengths, depth) in host threads -> "
                            "GPU batches -> tredCalls -> JSON + VCF files; `drivers` processes over `devices` GPUs (rank r on "
@@ -572,6 +683,8 @@ def run_ranks(args, n, n_devices):
             "--workload", args.workload]
     if args.coverage_set:
         argv += ["--coverage", str(args.coverage)]
+    if getattr(args, "streamed", 0) > 0:
+        argv += ["--streamed", str(args.streamed)]
     if args.stub:
         argv.append("--stub")
     with tempfile.TemporaryDirectory(prefix="tredbench_") as out_dir:
@@ -634,6 +747,20 @@ def launcher_main(args):
         # configs[4] and the other read lengths (their own sw_cont_kernel instantiations)
         out["legs"] = []
         for spec in args.legs.split(","):
+            if spec.startswith("streamed"):
+                # the headline's step with its input arriving over PCIe: distinct batches, copies beside the kernels
+                leg_args = argparse.Namespace(**vars(args))
+                leg_args.streamed = int(spec.split(":")[1]) if ":" in spec else 4
+                leg_args.steps, leg_args.warmup = max(args.steps, 4 * leg_args.streamed), 1
+                try:
+                    line, _ = run_ranks(leg_args, 1, n_devices)
+                    rec = dict(line["streamed"])
+                    rec.update(leg="streamed", metric=line["metric"], workload=line["config"]["workload"],
+                               units_per_step=line["config"]["units_per_step_per_gpu"])
+                    out["legs"].append(rec)
+                except Exception as e:
+                    out["legs"].append({"leg": spec, "error": str(e)})
+                continue
             workload, readlen, samples = spec.split(":")
             leg_args = argparse.Namespace(**vars(args))
             leg_args.workload, leg_args.readlen, leg_args.samples = workload, int(readlen), int(samples)
@@ -690,13 +817,16 @@ def main():
     ap.add_argument("--e2e-batch", type=int, default=16, help="samples per GPU batch in the end-to-end leg")
     ap.add_argument("--e2e-threads", type=int, default=0, help="host threads per driver in the end-to-end leg (0: cores / drivers)")
     ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 5; also run with 1)")
-    ap.add_argument("--legs", default="config5:150:200,config3:100:500,config3:250:500",
+    ap.add_argument("--legs", default="streamed:4,config5:150:200,config3:100:500,config3:250:500",
                     help="extra one-GPU legs workload:readlen:samples, comma separated ('' for none)")
     ap.add_argument("--e2e-gpu-inflate", choices=("0", "1", "both"), default="both",
                     help="end-to-end legs with the BAMs' BGZF blocks inflated on the GPU (tred.run_many inflate_device): "
                          "0 host only, 1 GPU only, both")
     ap.add_argument("--e2e-repeat", type=int, default=3, help="every driver goes over its BAMs this many times (a longer cohort from the same files)")
     ap.add_argument("--e2e-inflate-batch", type=int, default=16, help="samples per GPU batch (and inflate launch) in those legs")
+    ap.add_argument("--streamed", type=int, default=0,
+                    help="also time the step fed from pinned host memory: this many distinct batches, double-buffered "
+                         "copy-in beside the kernels (the default run adds it as the `streamed` leg with 4 batches)")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-limit", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -118,10 +118,36 @@ def sw_pairs(reads, refs, pair_read, pair_ref, scoring=(1, 5, 7, 2), threads=0):
 REF_CRASHED = -9998   # oracle/ref_driver.c: the reference's ssw_align faulted on this pair (its CIGAR pass, ssw.c:549-633)
 
 
+def _in_fresh_process(func, *args):
+    """func(*args) of this module in a newly started interpreter (spawn): a process in which the reference has faulted
+    once has run off its heap buffers and is not trusted with further reference results."""
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(1) as pool:
+        return pool.apply(func, args)
+
+
+def _ref_sw_pairs_once(reads, refs, pair_read, pair_ref, scoring, threads):
+    return _pairs(ref().ref_sw_pairs, reads, refs, pair_read, pair_ref, scoring, threads)
+
+
 def ref_sw_pairs(reads, refs, pair_read, pair_ref, scoring=(1, 5, 7, 2), threads=0):
     """Same, computed by the reference's compiled ssw.c (ssw_wrap.py:177-227 call pattern).  A pair the reference
-    faults on comes back as five REF_CRASHED."""
-    return _pairs(ref().ref_sw_pairs, reads, refs, pair_read, pair_ref, scoring, threads)
+    faults on comes back as five REF_CRASHED -- and every OTHER pair of that call is then computed again in a fresh
+    process without the faulting ones: the fault is a heap overrun inside the reference (ref_driver.c), after which
+    the results of the same process, other threads' included, are not evidence."""
+    out = _ref_sw_pairs_once(reads, refs, pair_read, pair_ref, scoring, threads)
+    crashed = out[:, 0] == REF_CRASHED
+    while crashed.any() and not crashed.all():
+        keep = np.nonzero(~crashed)[0]
+        pr, pt = np.asarray(pair_read, np.int32)[keep], np.asarray(pair_ref, np.int32)[keep]
+        again = _in_fresh_process(_ref_sw_pairs_once, list(reads), list(refs), pr, pt, tuple(scoring), threads)
+        out[keep] = again
+        more = np.zeros_like(crashed)
+        more[keep] = again[:, 0] == REF_CRASHED
+        if not more.any():
+            break
+        crashed |= more
+    return out
 
 
 class LocusSet:
@@ -141,6 +167,7 @@ class LocusSet:
         self.max_units = np.asarray([l[3] for l in loci], np.int32)
         self.templates = tmpls
         self.lad_off = lad_off
+        self.loci = [tuple(l) for l in loci]
 
 
 def _classify(fn, reads, read_locus, locus_set, clip, scoring, threads):
@@ -159,9 +186,27 @@ def classify(reads, read_locus, locus_set, clip=False, scoring=(1, 5, 7, 2), thr
     return _classify(lib().oracle_classify_batch, reads, read_locus, locus_set, clip, scoring, threads)
 
 
+def _ref_classify_once(reads, read_locus, loci, clip, scoring, threads):
+    return _classify(ref().ref_classify_batch, reads, read_locus, LocusSet(loci), clip, scoring, threads)
+
+
 def ref_classify(reads, read_locus, locus_set, clip=False, scoring=(1, 5, 7, 2), threads=0):
-    """Same, every alignment computed by the reference's compiled ssw.c (tag -1: the reference faulted on the read)."""
-    return _classify(ref().ref_classify_batch, reads, read_locus, locus_set, clip, scoring, threads)
+    """Same, every alignment computed by the reference's compiled ssw.c (tag -1: the reference faulted on the read; the
+    other reads of the call are then classified again in a fresh process, see ref_sw_pairs)."""
+    out = _classify(ref().ref_classify_batch, reads, read_locus, locus_set, clip, scoring, threads)
+    crashed = out[:, 0] == -1
+    loci = getattr(locus_set, "loci", None)
+    while loci is not None and crashed.any() and not crashed.all():
+        keep = np.nonzero(~crashed)[0]
+        again = _in_fresh_process(_ref_classify_once, [reads[i] for i in keep], np.asarray(read_locus, np.int32)[keep], loci,
+                                  bool(clip), tuple(scoring), threads)
+        out[keep] = again
+        more = np.zeros_like(crashed)
+        more[keep] = again[:, 0] == -1
+        if not more.any():
+            break
+        crashed |= more
+    return out
 
 
 def ladder_model(read, prefix, repeat, suffix, max_units, scoring=(1, 5, 7, 2)):

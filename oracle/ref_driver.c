@@ -18,7 +18,9 @@
  * 334: scoring 1/3/2/2, a (CTG)n read on the DM1 ladder).  The product computes no CIGAR.  So that a campaign
  * survives such an input, every ssw_align call runs under a SIGSEGV / SIGBUS guard: a faulting call is abandoned
  * (its allocations leak) and reported as REF_CRASHED -- per pair in ref_sw_pairs, as tag -1 for the read in
- * ref_classify_batch -- and the callers leave those out of the comparison and count them.
+ * ref_classify_batch -- and the callers leave those out of the comparison and count them.  The fault is a heap
+ * overrun, so nothing else the same process computed in that call is trusted either: oracle/pyoracle.py computes the
+ * call's other items again in a fresh process.
  */
 #include <setjmp.h>
 #include <signal.h>
@@ -48,7 +50,12 @@ static void guard_handler(int sig) {
     raise(sig);
 }
 
-static void guard_install(void) {
+/* installed ONCE per process and left in place (two Python threads may be inside the driver at the same time: a handler
+ * that is put in and taken out per call would save and restore the other call's handler); a fault that is not the
+ * driver's goes back to whoever had the signal before */
+#include <pthread.h>
+static pthread_once_t guard_once = PTHREAD_ONCE_INIT;
+static void guard_install_once(void) {
     struct sigaction sa;
     memset(&sa, 0, sizeof sa);
     sa.sa_handler = guard_handler;
@@ -57,11 +64,8 @@ static void guard_install(void) {
     sigaction(SIGSEGV, &sa, &guard_old[0]);
     sigaction(SIGBUS, &sa, &guard_old[1]);
 }
-
-static void guard_remove(void) {
-    sigaction(SIGSEGV, &guard_old[0], NULL);
-    sigaction(SIGBUS, &guard_old[1], NULL);
-}
+static void guard_install(void) { pthread_once(&guard_once, guard_install_once); }
+static void guard_remove(void) {}
 
 static void ref_align_one(const int8_t* read, int L, const int8_t* ref, int T, const int8_t* mat,
                           int go, int ge, int32_t out[5]) {

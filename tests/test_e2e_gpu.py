@@ -125,3 +125,27 @@ def test_cli_gpu_inflate_writes_the_same_files(engine, tmp_path, monkeypatch):
     for key in "abcd":
         assert open(tmp_path / "plain" / (key + ".json")).read() == open(tmp_path / "helped" / (key + ".json")).read()
         assert gzip.open(tmp_path / "plain" / (key + ".tred.vcf.gz")).read() == gzip.open(tmp_path / "helped" / (key + ".tred.vcf.gz")).read()
+
+
+def test_log_debug_prints_the_references_diagnostics(engine, caplog):
+    """--log DEBUG: the per-read tag lines (bam_parser.py:177-178) and the per-pair `*** (h1, h2) ml1 ml2 ml3 ml4 ml` lines
+    (models.py:270-272) of the reference's run() on t001 / HD (tests/golden/debug_t001_HD.json, captured from the
+    reference's own loggers): same reads in the same order with the same tags, same pairs in the same order, every
+    term within 1e-6; Python 2's str(float) layout (12 significant digits)."""
+    import logging
+    tred = tredmod
+    want = json.load(open(os.path.join(GOLD, "debug_t001_HD.json")))
+    repo = TREDsRepo("hg38", sites=os.path.join(GOLD, "no_sites"))
+    with caplog.at_level(logging.DEBUG):
+        res = tred.run(("t001", os.path.join(GOLD, "bam", "t001.bam"), repo, ["HD"], 300, False, False, True, True, "DEBUG"), engine=engine)
+    assert (res["tredCalls"]["HD.1"], res["tredCalls"]["HD.2"]) == (15, 41)
+    reads = [r.getMessage() for r in caplog.records if r.name == "BamParser"]
+    pairs = [r.getMessage() for r in caplog.records if r.name == "IntegratedCaller"]
+    assert reads == ["{}: h={:>3}, seq={}".format(t, h, s) for t, h, s in want["reads"]]
+    assert len(pairs) == len(want["pairs"])
+    for line, w in zip(pairs, want["pairs"]):
+        f = line.split()
+        assert f[0] == "***" and (int(f[1].strip("(,")), int(f[2].strip(")"))) == (w[0], w[1])
+        got = [float(x) for x in f[3:]]
+        assert len(got) == 5 and max(abs(a - b) for a, b in zip(got, w[2:])) <= 1e-6
+    assert tred._py2_str(-61.0) == "-61.0" and tred._py2_str(1e-05) == "1e-05" and tred._py2_str(-0.020661398520546232) == "-0.0206613985205"

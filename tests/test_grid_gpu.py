@@ -98,6 +98,53 @@ def test_kde_matches_reference(ctx):
         assert abs(pdf[i].sum() - 1) < 1e-12
 
 
+def test_kde_of_equal_pair_lengths_follows_scipy(ctx):
+    """Zero-variance pair lengths (models.py:428-435 hands them to scipy): gaussian_kde raises LinAlgError when the
+    rounding of its weighted mean gives back the common value exactly, and otherwise builds a pdf that is 1 at that
+    value and 0 elsewhere -- which of the two is a pure function of (value, count).  The kernel reproduces numpy's
+    pairwise reduction for it (csrc/grid.hip kde_of_equal_lengths): same outcome as scipy here for every drawn case,
+    through both entry points (the KDE alone, and a unit of the grid whose model exists but is not used)."""
+    import warnings
+    from scipy.stats import gaussian_kde
+    _set_model(ctx)
+    rng = np.random.default_rng(5)
+    cases = [(int(n), int(c)) for n, c in zip(rng.integers(100, 3000, 160), rng.integers(1, 1000, 160))]
+    cases += [(100, 22), (100, 1), (128, 999), (129, 500), (256, 350), (2727, 390), (1000, 0)]
+    locus = CASES[0]["locus_rec"]
+    units = np.zeros(len(cases), _lib.UNIT_DTYPE)
+    gl, want = [], []
+    for i, (n, c) in enumerate(cases):
+        units[i] = synth.unit_params_for(locus, 150, 30.0, n, 5, len(gl), 0)
+        gl += [c] * n
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                pdf = gaussian_kde([c] * n).evaluate(np.arange(1000))
+                want.append(pdf / pdf.sum())
+            except np.linalg.LinAlgError:
+                want.append(None)
+    assert any(w is None for w in want) and any(w is not None for w in want)
+    gl = np.asarray(gl, np.int32)
+    pdf = np.zeros((len(cases), 1000))
+    st = np.zeros(len(cases), np.int32)
+    ctx.pe_kde(_lib.MEM_HOST, units, len(cases), gl, len(gl), pdf, st)
+    for i, w in enumerate(want):
+        assert st[i] == (-2 if w is None else 0), cases[i]
+        if w is not None:
+            assert np.array_equal(pdf[i], w), cases[i]
+    # the grid: a unit with five spanning pairs and equal pair lengths, no partial read near the read length -> the
+    # paired-end term is off, and the reference still dies in PEMaxLikModel when scipy raises (status -2), else calls
+    hs = 128
+    full, pref, rept = (np.zeros((len(cases), hs), np.int32) for _ in range(3))
+    full[:, 15] = 10
+    tl = np.full(5, 400, np.int32)
+    units["n_target"], units["tl_off"] = 5, 0
+    calls = np.zeros(len(cases), _lib.CALL_DTYPE)
+    ctx.likelihood_grid(_lib.MEM_HOST, units, len(cases), hs, full, pref, rept, gl, len(gl), tl, len(tl), calls, None, None, None, 0)
+    for i, w in enumerate(want):
+        assert calls[i]["status"] == (-2 if w is None else 0), cases[i]
+
+
 def test_fused_batch_matches_oracle_chain(ctx, loci):
     """SW -> tally -> grid on the GPU vs oracle classification + numpy likelihood, unit by unit."""
     _set_model(ctx)
@@ -314,20 +361,43 @@ def test_batch_of_many_units_equals_units_one_by_one(ctx):
 
 def test_singular_pair_length_model_with_and_without_the_paired_end_term(ctx):
     """The reference builds the KDE whenever a unit has its paired-end model (models.py:131-132) and fails on a singular
-    one whether or not the term is used afterwards: constant pair lengths give status -2 in both kinds of unit, and a
-    single different length lifts it."""
+    one whether or not the term is used afterwards.  With constant pair lengths scipy decides what "singular" means
+    (test_kde_of_equal_pair_lengths_follows_scipy): for a value it refuses the unit gets status -2 in both kinds of unit,
+    for a value it lets through the unit is called exactly as the oracle -- which asks scipy -- calls it; a single
+    different length lifts the singularity."""
+    import warnings
+    from scipy.stats import gaussian_kde
     _set_model(ctx)
     with_pe = [c for c in CASES if c["kde"] is not None and not c["expected"]["raised"]]
     assert with_pe
     used = with_pe[0]
     unused = dict(used, partial={}, name=used["name"] + "/no PREF reads")   # no partial read: the term is not used
+    n = len(used["global_lens"])
+    refused = passed = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for c in range(300, 400):
+            try:
+                gaussian_kde([c] * n)
+                passed = c if passed is None else passed
+            except np.linalg.LinAlgError:
+                refused = c if refused is None else refused
+    assert refused is not None and passed is not None
     for base in (used, unused):
-        flat = dict(base, global_lens=[300] * len(base["global_lens"]))
-        bump = dict(flat, global_lens=[300] * (len(base["global_lens"]) - 1) + [301])
-        calls, _ = _run_grid(ctx, [flat, bump, base])
+        flat_bad = dict(base, global_lens=[refused] * n)
+        flat_ok = dict(base, global_lens=[passed] * n)
+        bump = dict(flat_bad, global_lens=[refused] * (n - 1) + [refused + 1])
+        calls, _ = _run_grid(ctx, [flat_bad, bump, base, flat_ok])
         assert calls[0]["status"] == -2, base["name"]
         assert calls[1]["status"] in (0, 1), base["name"]
         assert calls[2]["status"] in (0, 1), base["name"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = oracle_caller(flat_ok).evaluate()
+        period = len(base["locus_rec"]["repeat"])
+        assert calls[3]["status"] == want["status"], base["name"]
+        if want["status"] == 0:
+            assert (calls[3]["h1"], calls[3]["h2"]) == tuple(want["alleles"]) and abs(calls[3]["lik"] - want["lik"]) <= ML_TOL, base["name"]
 
 
 def test_grid_kernels_are_timed_one_by_one(ctx):

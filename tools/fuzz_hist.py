@@ -60,12 +60,9 @@ def campaign(cases_n=300, seed=1):
     want = []
     for c in cases:
         l = c["locus_rec"]
-        if len(c["global_lens"]) >= 100 and len(c["target_lens"]) >= 5 and len(set(c["global_lens"])) == 1:
-            # zero-variance pair lengths: gaussian_kde raises LinAlgError -- unless the rounding of
-            # its weighted mean happens to leave a variance of ~1e-27, in which case scipy builds a delta-like
-            # pdf.  The kernel always reports the singular case (status -2).
-            want.append({"raised": "LinAlgError"})
-            continue
+        # (zero-variance pair lengths: gaussian_kde raises LinAlgError -- SURVEY 8a, a17 -- unless the rounding of its
+        #  weighted mean leaves a variance of ~1e-28, in which case it builds a one-hot pdf; the kernels follow scipy in
+        #  both, csrc/grid.hip kde_of_equal_lengths: the oracle below simply calls scipy)
         try:
             res = lo.Caller(len(l["repeat"]), c["readlen"], c["ploidy"], c["depth"], c["full"], c["partial"], c["rept"],
                             c["global_lens"], c["target_lens"], c["ref_len"], c["minpe"], maxinsert=c["maxinsert"],

@@ -676,6 +676,43 @@ def gen_report(loci):
                                 "listed per-sample JSON inputs".format(pd.__version__), **out}, fp)
 
 
+def gen_debug(loci):
+    """What the reference prints under --log DEBUG for t001 / HD: its per-read tag lines (bam_parser.py:177-178) and
+    per-pair `*** (h1, h2) ml1 ml2 ml3 ml4 ml` lines (models.py:270-272), captured from its own loggers."""
+    import tempfile
+    ref = refshim.load_reference(pysam_standin=PysamStandin(), full=True)
+    lines = []
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            lines.append((record.name, record.getMessage()))
+    h = Grab()
+    h.setLevel(logging.DEBUG)
+    root = logging.getLogger()
+    root.addHandler(h)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        repo = ref.meta.TREDsRepo(ref="hg38", toy=False, sites=os.path.join(tmp, "sites"))
+        ref.tred.run(("t001", os.path.join(refshim.REF, "tests", "t001.bam"), repo, ["HD"], 300, False, False, True, True, "DEBUG"))
+    finally:
+        os.chdir(cwd)
+        root.removeHandler(h)
+    reads, pairs = [], []
+    for name, msg in lines:
+        head = msg.split(":")[0]
+        if name == "BamParser" and head in ("FULL", "PREF", "POST", "REPT", "HANG") and ", seq=" in msg:
+            reads.append([head, int(msg.split("h=")[1].split(",")[0]), msg.split("seq=")[1]])
+        elif name == "IntegratedCaller" and msg.startswith("*** ("):
+            inside, rest = msg[5:].split(")", 1)
+            pairs.append([int(x) for x in inside.split(",")] + [float(x) for x in rest.split()])
+    print("debug: {} read lines, {} pair lines (of {} records)".format(len(reads), len(pairs), len(lines)))
+    with open(os.path.join(GOLD, "debug_t001_HD.json"), "w") as fp:
+        json.dump({"generator": "tools/gen_golden.py debug: the reference's run() on tests/t001.bam, HD, log=DEBUG; lines of its "
+                                "BamParser and IntegratedCaller loggers parsed into fields", "reads": reads, "pairs": pairs}, fp)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     loci = synth.load_loci()
@@ -701,6 +738,8 @@ def main():
         gen_report(loci)
     if "synall" in what:
         gen_synall(loci)
+    if "debug" in what:
+        gen_debug(loci)
 
 
 if __name__ == "__main__":

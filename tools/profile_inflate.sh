@@ -7,25 +7,24 @@
 #   gpurun_out/prof_TAG/pmc_summary.json   tools/pmc_to_json.py
 set -u
 TAG=${1:-r04_inflate}
-M=${2:-16}
+M=${2:-8}     # (counter passes serialise the dispatches: 56 samples per call did not finish in 25 minutes)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 BIN=$ROOT/tools/_ab/inflate_prof
 BAM=$ROOT/tools/_ab/syn0000.bam
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BIN $BAM $M 6 1 > "$OUT/run_stats.json" 2> "$OUT/stats.err"
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BIN $BAM $M 6 1 > "$OUT/run_stats.json" 2> "$OUT/stats.err"
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 pass() {
     local name=$1; shift
-    timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $BIN $BAM $M 3 1 > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err"
+    timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $BIN $BAM $M 2 1 > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err"
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE
 pass sq3 SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_IFETCH SQ_ACTIVE_INST_MISC
-pass occ SQ_LEVEL_WAVES SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_ACCUM_PREV_HIRES SQ_INSTS_FLAT
 python3 "$ROOT/tools/pmc_to_json.py" "$OUT" > "$OUT/pmc_summary.json" 2> "$OUT/pmc_summary.err"
 find "$OUT" -name '*kernel_trace.csv' -size +2M -delete
 find "$OUT" -name '*counter_collection.csv' -size +4M -delete

@@ -309,11 +309,66 @@ __device__ __forceinline__ void kde_clear(int* hist, int* flag) {   // the calle
     if (threadIdx.x == 0) { flag[0] = 0; flag[1] = INT_MAX; flag[2] = INT_MIN; }
 }
 
+// All pair lengths equal to c: what the reference does then is scipy's business.  gaussian_kde takes the covariance from
+// np.cov(data, aweights = 1/n each), i.e. from data - avg with avg = sum(c * w) / sum(w), both sums numpy's pairwise
+// reductions (blocks of at most 128 elements on eight accumulators, halves cut at multiples of eight above that).  When
+// that rounds to c exactly the covariance is 0 and the Cholesky factorisation raises LinAlgError (status -2); when it
+// does not, the covariance is ~1e-28, the factorisation succeeds, and the normalised pdf over 0..999 is 1 at c and 0
+// elsewhere.  Which of the two happens is a pure function of (c, n) -- 63 % of the pairs pass -- reproduced here step by
+// step (checked against scipy 1.15.3 / numpy 2.2.6 on 8 239 pairs, tools/fuzz_hist.py draws more); one thread, an
+// explicit stack for the halves (istack >= 48 ints, vstack >= 48 doubles).
+__device__ double numpy_pairwise_sum_of_equal(double v, int n, int* istack, double* vstack) {
+    int ni = 0, nv = 0;
+    istack[ni++] = n;
+    while (ni > 0) {
+        const int m = istack[--ni];
+        if (m < 0) {                                   // both halves of a block of -m are on the value stack
+            const double right = vstack[--nv], left = vstack[--nv];
+            vstack[nv++] = left + right;
+        } else if (m < 8) {
+            double r = 0.;
+            for (int i = 0; i < m; ++i) r += v;
+            vstack[nv++] = r;
+        } else if (m <= 128) {
+            double acc = v;                            // the eight accumulators hold the same number
+            for (int i = 8; i < m - (m % 8); i += 8) acc += v;
+            double r = ((acc + acc) + (acc + acc)) + ((acc + acc) + (acc + acc));
+            for (int i = 0; i < m % 8; ++i) r += v;
+            vstack[nv++] = r;
+        } else {
+            int n2 = m / 2;
+            n2 -= n2 % 8;
+            istack[ni++] = -m;
+            istack[ni++] = m - n2;                     // (popped after the left half)
+            istack[ni++] = n2;
+        }
+    }
+    return vstack[0];
+}
+// 0: scipy builds the (one-hot) KDE of n lengths all equal to c; -2: it raises.  Called by every thread of the block;
+// thread 0 works it out.
+__device__ int kde_of_equal_lengths(int c, int n, int* istack, double* vstack, int* flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double w = 1.0 / (double)n;
+        const double avg = numpy_pairwise_sum_of_equal((double)c * w, n, istack, vstack) / numpy_pairwise_sum_of_equal(w, n, istack, vstack);
+        flag[3] = ((double)c - avg) != 0.0 ? 0 : -2;
+    }
+    __syncthreads();
+    return flag[3];
+}
+
 // Second half: from the histogram to the normalised pdf.
-__device__ __forceinline__ int kde_finish(const KdeLens& in, int n, const int* hist, double* kern2, double* khist, double* pdf, double* red) {
+__device__ __forceinline__ int kde_finish(const KdeLens& in, int n, const int* hist, double* kern2, double* khist, double* pdf, double* red, int* flag) {
     const int tid = threadIdx.x;
     if (in.bad || n >= 65536) return -6;
     if (n < 2) return -2;
+    if (in.lo == in.hi) {                              // (integers: the variance is zero exactly when smallest = largest)
+        const int rc = kde_of_equal_lengths(in.lo, n, const_cast<int*>(hist), kern2, flag);
+        if (rc == 0)
+            for (int i = tid; i < SPAN; i += NT) pdf[i] = i == in.lo ? 1.0 : 0.0;
+        return rc;
+    }
     const double mean = in.total / n;
     double q = 0;
     for (int i = tid; i < SPAN; i += NT) {
@@ -389,7 +444,7 @@ __device__ __forceinline__ int kde_block(const int32_t* lens, int n, int* hist, 
     kde_clear(hist, flag);
     __syncthreads();
     const KdeLens in = kde_collect(lens, n, hist, red, flag);
-    return kde_finish(in, n, hist, kern2, khist, pdf, red);
+    return kde_finish(in, n, hist, kern2, khist, pdf, red, flag);
 }
 
 __global__ __launch_bounds__(NT) void pe_kde_kernel(GridArgs a) {
@@ -615,10 +670,10 @@ __global__ __launch_bounds__(NT, KDE_WAVES) void grid_kde_kernel(GridArgs a, Gri
         __syncthreads();
         const bool run_pe = max_partial >= u.readlen - 27 && __builtin_amdgcn_readfirstlane(sh[3]) > 1;
         int rc;
-        // model not used: only the singularity check matters.  The lengths are integers, so their sum and -- when they
-        // are all equal -- their mean are exact: the variance is zero exactly when smallest = largest
-        if (!run_pe) rc = in.lo == in.hi ? -2 : 0;
-        else rc = kde_finish(in, u.n_global, hist, kern, khist, a.unit_pdf + (size_t)g * SPAN, red);
+        // model not used: only the singularity check matters (the reference builds the KDE regardless, and raises when
+        // scipy does: kde_of_equal_lengths)
+        if (!run_pe) rc = in.lo == in.hi ? kde_of_equal_lengths(in.lo, u.n_global, hist, kern, flag) : 0;
+        else rc = kde_finish(in, u.n_global, hist, kern, khist, a.unit_pdf + (size_t)g * SPAN, red, flag);
         if (tid == 0) a.unit_kde_rc[g] = rc;
     }
 }

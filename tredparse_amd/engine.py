@@ -109,7 +109,7 @@ class PackedUnits(object):
 
 class BatchResult(object):
     """Arrays of one genotyped PackedUnits batch; unit(i) gives the per-unit view the callers format."""
-    __slots__ = ("batch", "tag", "h", "score", "full", "pref", "rept", "calls", "marg", "joint")
+    __slots__ = ("batch", "tag", "h", "score", "full", "pref", "rept", "calls", "marg", "joint", "grid", "grid_off")
 
     def unit(self, i):
         b = self.batch
@@ -120,6 +120,8 @@ class BatchResult(object):
         r.rept = int(self.rept[i].sum())
         r.call = self.calls[i]
         r.grid = None
+        if getattr(self, "grid", None) is not None and self.calls[i]["status"] == 0:
+            r.grid = self.grid[self.grid_off[i]:self.grid_off[i] + self.calls[i]["n_pairs"]]
         r.joint = self.joint[i] if self.calls[i]["status"] == 0 else None
         r.P_h1, r.P_h2 = self.marg[i, 0], self.marg[i, 1]
         return r
@@ -167,10 +169,12 @@ class Engine(object):
                                  _lib.default_sw_params(clip=b.clip), tag, h, sc, None, 0)
         return tag[:n], h[:n], sc[:n]
 
-    def genotype_packed(self, b):
-        """The whole path for a PackedUnits batch -> BatchResult (sparse joint distribution included)."""
+    def genotype_packed(self, b, dense=False):
+        """The whole path for a PackedUnits batch -> BatchResult (sparse joint distribution included).  dense: also the
+        four terms of every (h1, h2) pair (a second grid call with the dump; what --log DEBUG prints)."""
         r = BatchResult()
         r.batch = b
+        r.grid = r.grid_off = None
         r.tag, r.h, r.score = self.classify_packed(b)
         g, n = b.n_units, b.n_reads
         hs = b.max_units + 2
@@ -180,6 +184,15 @@ class Engine(object):
         ms = max(int(b.params["maxinsert"].max()) if g else 0, hs) + 2
         r.calls, r.marg, r.joint = self._grid_arrays(b.params, hs, r.full, r.pref, r.rept, b.global_lens,
                                                      b.target_lens, ms)
+        if dense and g:
+            gl = b.global_lens if len(b.global_lens) else np.zeros(1, np.int32)
+            tl = b.target_lens if len(b.target_lens) else np.zeros(1, np.int32)
+            r.grid_off = np.zeros(g + 1, np.int64)
+            r.grid_off[1:] = np.cumsum(np.maximum(r.calls["n_pairs"], 1))
+            r.grid = np.zeros((int(r.grid_off[-1]), 6), np.float64)
+            again = np.zeros(g, _lib.CALL_DTYPE)
+            self.ctx.likelihood_grid(_lib.MEM_HOST, b.params, g, hs, r.full, r.pref, r.rept, gl, len(b.global_lens), tl,
+                                     len(b.target_lens), again, r.grid_off, r.grid, None, 0)
         return r
 
     def _grid_arrays(self, up, hs, full, pref, rept, gl, tl, ms):

@@ -39,7 +39,7 @@ logger = logging.getLogger(__name__)
 # seconds accumulated over run_many calls: the driver thread's waits for scans, its GPU calls and its formatting; and
 # the writer thread's time in the sink (JSON / VCF text and files)
 TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
-          "inflate_hits": 0, "inflate_misses": 0}
+          "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0}
 _TIMING_LOCK = threading.Lock()
 
 
@@ -218,11 +218,14 @@ def _scan_planned(arg, plan, out_addr, out_off, status, crc=None):
 
 
 class _InflateFeeder(object):
-    """Feeds run_many's chunks through plan -> GPU inflate -> scan, one chunk ahead of the consumer: next(chunk index)
-    returns the chunk's scan futures.  Two inflaters alternate; one is reused only when every scan that reads its output
-    has finished.  close() can be called at any time -- also while the consumer is unwinding from an error: the thread
-    is told to stop, whatever it has planned but not handed to a scan is closed, and the inflaters go only after
-    every scan that reads their buffers has ended."""
+    """Feeds run_many's chunks through plan -> GPU inflate -> scan, ahead of the consumer: next() returns the next
+    chunk's scan futures.  Three stages overlap: while the GPU decodes chunk k (a thread of its own makes the call,
+    which sleeps through it), the feeder thread plans and fills chunk k + 1 into another inflater's staging, and the scan
+    pool still reads chunk k - 1's blocks out of a third -- so there are three inflaters, each reused only when every
+    scan that reads its output has finished.  close() can be called at any time -- also while the consumer is unwinding
+    from an error: the threads are told to stop, whatever was planned but never handed to a scan is closed, and the
+    inflaters go only after every scan that reads their buffers has ended."""
+    SLOTS = 3
 
     def __init__(self, chunks, ex, device):
         import queue
@@ -232,48 +235,75 @@ class _InflateFeeder(object):
         # plans and fills have threads of their own: queued behind a chunk's 28 scans in the scan pool they started only
         # when those were done, and the pool then idled through the next chunk's decode
         self.prep = ThreadPoolExecutor(max_workers=2)
-        self.inflaters = [Inflater(device), Inflater(device)]
-        self.busy = [[], []]
+        self.gpu = ThreadPoolExecutor(max_workers=1)       # the decode calls, one after the other, in chunk order
+        self.inflaters = [Inflater(device) for _ in range(self.SLOTS)]
+        self.busy = [[] for _ in range(self.SLOTS)]
+        self.decoding = [None] * self.SLOTS            # the slot's last decode job (it sets busy[slot] when it hands the scans out)
         self.q = queue.Queue(maxsize=2)
         self.stop = threading.Event()
         self.thread = threading.Thread(target=self._run, name="tred-inflate", daemon=True)
         self.thread.start()
 
-    def _chunk(self, ci, chunk):
-        inf, slot = self.inflaters[ci % 2], ci % 2
+    @staticmethod
+    def _close_plans(plans):
+        for p in plans:
+            if p is not None:
+                try:
+                    p["handle"].close()
+                except Exception:
+                    pass
+
+    def _prepare(self, ci, chunk):
+        """Feeder thread: the chunk's plans, and their payloads in the staging of inflater ci % SLOTS."""
+        slot = ci % self.SLOTS
+        inf = self.inflaters[slot]
+        if self.decoding[slot] is not None:
+            self.decoding[slot].exception()            # chunk ci - SLOTS has been decoded and its scans are known ...
         for fut in self.busy[slot]:
-            fut.exception()                            # (waits; the consumer sees the error itself)
+            fut.exception()                            # ... and have ended (waits; the consumer sees the error itself)
         plans = [fut.result() for fut in [self.prep.submit(_plan_sample, a) for a in chunk]]
-        handed = False
+        live = [p for p in plans if p is not None and p["n"] > 0]
+        t0 = time.perf_counter()
+        job = {"plans": plans, "live": live, "inf": inf, "slot": slot, "ooff": None, "n_all": 0}
+        if live and not self.stop.is_set():
+            try:
+                n_all = sum(p["n"] for p in live)
+                comp, out, coff, ooff = inf.reserve(sum(p["cbytes"] for p in live), sum(p["obytes"] for p in live), n_all)
+                at = cb = ob = 0
+                fills = []
+                for p in live:
+                    p["first"] = at
+                    fills.append(self.prep.submit(p["handle"].plan_fill, inf.comp_addr, cb, ob, coff[at:at + p["n"] + 1],
+                                                ooff[at:at + p["n"] + 1]))
+                    at, cb, ob = at + p["n"], cb + p["cbytes"], ob + p["obytes"]
+                for fut in fills:
+                    fut.result()
+                # (every sample wrote its own end as entry n: the next sample's first entry is the same number)
+                job["ooff"], job["n_all"] = ooff, n_all
+            except Exception as e:     # no GPU help for this chunk: the scans inflate for themselves
+                logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
+        timing_add(inflate=time.perf_counter() - t0)
+        return job
+
+    def _decode_and_scan(self, chunk, job):
+        """Decode thread: one launch for the chunk, then its scans go to the pool and their futures to the consumer."""
+        plans, inf, handed = job["plans"], job["inf"], False
         try:
             if self.stop.is_set():
-                return None
-            live = [p for p in plans if p is not None and p["n"] > 0]
-            t0 = time.perf_counter()
+                return
             status = crc = None
-            if live:
+            if job["ooff"] is not None:
+                t0 = time.perf_counter()
                 try:
-                    n_all = sum(p["n"] for p in live)
-                    comp, out, coff, ooff = inf.reserve(sum(p["cbytes"] for p in live), sum(p["obytes"] for p in live), n_all)
-                    at = cb = ob = 0
-                    fills = []
-                    for p in live:
-                        p["first"] = at
-                        fills.append(self.prep.submit(p["handle"].plan_fill, inf.comp_addr, cb, ob, coff[at:at + p["n"] + 1],
-                                                    ooff[at:at + p["n"] + 1]))
-                        at, cb, ob = at + p["n"], cb + p["cbytes"], ob + p["obytes"]
-                    for fut in fills:
-                        fut.result()
-                    # (every sample wrote its own end as entry n: the next sample's first entry is the same number)
-                    status, crc = inf.run(n_all, crc=True)
-                    timing_add(inflate_blocks=n_all, inflate_failed=int((status != 0).sum()))
-                except Exception as e:     # no GPU help for this chunk: the scans inflate for themselves
+                    status, crc = inf.run(job["n_all"], crc=True)
+                    timing_add(inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
+                except Exception as e:
                     logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
                     status = crc = None
-            timing_add(inflate=time.perf_counter() - t0)
+                timing_add(inflate_gpu=time.perf_counter() - t0)
             if self.stop.is_set():
-                return None
-            futs = []
+                return
+            futs, ooff = [], job["ooff"]
             for a, p in zip(chunk, plans):
                 if p is None:
                     futs.append(self.ex.submit(collect_sample, a))
@@ -284,16 +314,13 @@ class _InflateFeeder(object):
                     futs.append(self.ex.submit(_scan_planned, a, p, inf.out_addr, ooff[k:k + p["n"] + 1], status[k:k + p["n"]],
                                                crc[k:k + p["n"]]))
             handed = True                                  # (each scan closes its own handle)
-            self.busy[slot] = futs
-            return futs
+            self.busy[job["slot"]] = futs
+            self._put(futs)
+        except BaseException as e:     # hand the failure to the consumer instead of leaving it waiting
+            self._put(e)
         finally:
             if not handed:
-                for p in plans:
-                    if p is not None:
-                        try:
-                            p["handle"].close()
-                        except Exception:
-                            pass
+                self._close_plans(plans)
 
     def _put(self, item):
         import queue
@@ -310,10 +337,12 @@ class _InflateFeeder(object):
             for ci, chunk in enumerate(self.chunks):
                 if self.stop.is_set():
                     return
-                futs = self._chunk(ci, chunk)
-                if futs is None or not self._put(futs):
+                job = self._prepare(ci, chunk)
+                if self.stop.is_set():
+                    self._close_plans(job["plans"])
                     return
-        except BaseException as e:     # hand the failure to the consumer instead of leaving it waiting
+                self.decoding[job["slot"]] = self.gpu.submit(self._decode_and_scan, chunk, job)
+        except BaseException as e:
             self._put(e)
 
     def next(self):
@@ -330,7 +359,8 @@ class _InflateFeeder(object):
                 self.q.get_nowait()
             except queue.Empty:
                 break
-        self.thread.join()                                 # (bounded: the thread checks the flag between every two steps)
+        self.thread.join()                                 # (bounded: the threads check the flag between every two steps)
+        self.gpu.shutdown(wait=True)
         for slot in self.busy:
             for fut in slot:
                 fut.exception()                            # scans still reading the staging buffers: let them end
@@ -365,6 +395,38 @@ def _fill_unit(calls, scan, k, res, repeatpairs, pairs, lazy=False):
     calls[n + ".details"] = details
 
 
+def _py2_str(x):
+    """str(float) as Python 2 prints it (12 significant digits): the reference's DEBUG lines are built with str()."""
+    s = "%.12g" % x
+    return s if any(c in s for c in ".en") else s + ".0"       # ('nan' and 'inf' have an n)
+
+
+def debug_lines(scan, k, res):
+    """--log DEBUG: the reference's only diagnostics -- one line per tagged read, `TAG: h=  n, seq=...`
+    (bam_parser.py:177-178, logger BamParser; HANG reads included) and one per allele pair of the grid,
+    `*** (h1, h2) ml1 ml2 ml3 ml4 ml` in repeat units (models.py:270-272, logger IntegratedCaller); a term the
+    reference does not evaluate (no spanning reads, no partial reads, paired-end term off) prints as its literal 0."""
+    from ._lib import TAG_NAMES
+    rlog, glog = logging.getLogger("BamParser"), logging.getLogger("IntegratedCaller")
+    rlog.setLevel(logging.DEBUG)
+    glog.setLevel(logging.DEBUG)
+    a, _ = scan.reads_of(k)
+    for i, (t, h) in enumerate(zip(res.tags, res.hs)):
+        name = TAG_NAMES.get(int(t))
+        if name is not None:
+            rlog.debug("%s: h=%3d, seq=%s", name, int(h), scan.sequence(a + i))
+    if res.grid is None:
+        return
+    period = len(scan.loci[k].repeat)
+    has_full = any(int(t) == 1 for t in res.tags)
+    has_part = any(int(t) in (2, 3) for t in res.tags)
+    run_pe = bool(res.call["run_pe"])
+    for h1, h2, m1, m2, m3, m4 in res.grid:
+        glog.debug(" ".join(["***", str((int(h1) // period, int(h2) // period)), _py2_str(m1) if has_full else "0",
+                             _py2_str(m2) if has_part else "0", _py2_str(m3), _py2_str(m4) if run_pe else "0",
+                             _py2_str(((m1 + m2) + m3) + m4)]))
+
+
 def _genotype(engine, picks, o):
     """PackedUnits of `picks` through the GPU.  A batch that fails as a whole is retried sample by sample and then
     unit by unit, so that one unit the kernels reject costs only itself (the reference loses only the failing
@@ -379,7 +441,7 @@ def _genotype(engine, picks, o):
         batch = PackedUnits.from_scans([(s, ks) for _, s, ks in sub], **kw)
         if batch.n_units == 0:
             return
-        br = engine.genotype_packed(batch)
+        br = engine.genotype_packed(batch, dense=True) if o["log"] == "DEBUG" else engine.genotype_packed(batch)
         i = 0
         for si, _, ks in sub:
             for k in ks:
@@ -431,6 +493,8 @@ def finish_batch(engine, task_args, scans, lazy_details=False):
         for k in picks[si][2]:
             if (si, k) not in res:
                 continue
+            if o["log"] == "DEBUG":
+                debug_lines(scan, k, res[(si, k)])
             try:
                 _fill_unit(result["tredCalls"], scan, k, res[(si, k)], o["repeatpairs"] or o["clip"], pairs,
                            lazy=lazy_details)
