@@ -464,27 +464,28 @@ def _genotype(engine, picks, o):
     return out
 
 
-def finish_batch(engine, task_args, scans, lazy_details=False):
-    """GPU half + formatting for the scans of one batch; returns the result dicts in task order.  lazy_details:
-    `<locus>.details` as bam_parser.Details views (list-like) and the sparse distributions as models.SparseDist
-    (dict-like) instead of lists and dicts; to_json prints both natively."""
-    if not task_args:
-        return []
+def genotype_scans(engine, task_args, scans):
+    """GPU half of a batch: the kernels' results for every unit of the scans, (picks, {(scan index, k): UnitResult}).
+    The kernel-side options of a GPU batch are the batch's: tasks that differ in them go in separate batches (the CLI's
+    are uniform; API callers of run_many may mix them)."""
     picks = [(si, s, [k for k in range(len(s.names)) if k not in s.dropped] if s.opened else [])
              for si, s in enumerate(scans)]
     t0 = time.perf_counter()
-    # the kernel-side options of a GPU batch are the batch's: tasks that differ in them go in separate batches
-    # (the CLI's are uniform; API callers of run_many may mix them)
     groups = {}
     for pick, arg in zip(picks, task_args):
         o = _options(arg)
-        key = (o["maxinsert"], o["fullsearch"], o["clip"], o["repeatpairs"] or o["clip"])
+        key = (o["maxinsert"], o["fullsearch"], o["clip"], o["repeatpairs"] or o["clip"], o["log"] == "DEBUG")
         groups.setdefault(key, (o, []))[1].append(pick)
     res = {}
     for o, sub in groups.values():
         res.update(_genotype(engine, sub, o))
+    timing_add(gpu=time.perf_counter() - t0)
+    return picks, res
+
+
+def format_scans(task_args, scans, picks, res, lazy_details=False):
+    """Host half of a batch: the result dicts in task order from the kernels' results."""
     t1 = time.perf_counter()
-    timing_add(gpu=t1 - t0)
     results = []
     for si, (arg, scan) in enumerate(zip(task_args, scans)):
         o = _options(arg)
@@ -503,6 +504,16 @@ def finish_batch(engine, task_args, scans, lazy_details=False):
         results.append(result)
     timing_add(format=time.perf_counter() - t1)
     return results
+
+
+def finish_batch(engine, task_args, scans, lazy_details=False):
+    """GPU half + formatting for the scans of one batch; returns the result dicts in task order.  lazy_details:
+    `<locus>.details` as bam_parser.Details views (list-like) and the sparse distributions as models.SparseDist
+    (dict-like) instead of lists and dicts; to_json prints both natively."""
+    if not task_args:
+        return []
+    picks, res = genotype_scans(engine, task_args, scans)
+    return format_scans(task_args, scans, picks, res, lazy_details=lazy_details)
 
 
 def run(arg, engine=None):
@@ -549,7 +560,7 @@ class _Writer(object):
 
 
 def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
-             background_sink=False, inflate_device=None):
+             background_sink=False, inflate_device=None, overlap_gpu=False):
     """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
     executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in flight the
     scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
@@ -574,6 +585,20 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
             feeder = _InflateFeeder(chunks, ex, inflate_device)
         except Exception as e:       # no pinned memory, no device ...: the scans inflate for themselves
             logging.getLogger("tredparse_amd").warning("GPU inflate not available (%s): BGZF blocks are inflated on the host", e)
+    # (the GPU half of a batch on a thread of its own, beside the formatting of the previous batch: measured again in
+    #  round 4 with five driver processes, where a GPU call waits 40-70 ms -- 20.1-20.4 k genotypes/s against 20.5 k, and
+    #  15.5 k against 17.2 k with four: the two halves fight over the interpreter lock.  overlap_gpu stays off.)
+    gpu_ex = ThreadPoolExecutor(max_workers=1) if (overlap_gpu and ex is not None and len(chunks) > 1) else None
+    pending = None
+
+    def flush(item):
+        chunk_, scans_, fut_ = item
+        picks, res = fut_.result()
+        for r in format_scans(chunk_, scans_, picks, res, lazy_details=lazy_details):
+            if sink is not None:
+                sink(r)
+            else:
+                out.append(r)
     try:
         submit = (lambda c: [ex.submit(collect_sample, a) for a in c]) if ex is not None else None
         ahead = deque()
@@ -593,13 +618,26 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
                 timing_add(scan_wait=time.perf_counter() - t0)
             else:
                 scans = [collect_sample(a) for a in chunk]
-            for r in finish_batch(engine, chunk, scans, lazy_details=lazy_details):
-                if sink is not None:
-                    sink(r)
-                else:
-                    out.append(r)
+            if gpu_ex is None:
+                for r in finish_batch(engine, chunk, scans, lazy_details=lazy_details):
+                    if sink is not None:
+                        sink(r)
+                    else:
+                        out.append(r)
+                continue
+            # the GPU half of this chunk on a thread of its own (its calls mostly wait -- on the kernels, and with several
+            # driver processes on the other processes' copies) beside the formatting of the previous chunk
+            fut = gpu_ex.submit(genotype_scans, engine, chunk, scans)
+            if pending is not None:
+                flush(pending)
+            pending = (chunk, scans, fut)
+        if pending is not None:
+            flush(pending)
+            pending = None
     except BaseException:
         # unwinding from an error: stop the helpers, keep THIS exception (a sink that also failed must not replace it)
+        if gpu_ex is not None:
+            gpu_ex.shutdown(wait=True)
         if feeder is not None:
             feeder.close()
         if own:
@@ -610,6 +648,8 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
             except BaseException:
                 pass
         raise
+    if gpu_ex is not None:
+        gpu_ex.shutdown(wait=True)
     if feeder is not None:
         feeder.close()
     if own:
@@ -709,8 +749,8 @@ def to_json(results, ref=None, repo=None, treds=None, store=None, quiet=False):
     text = dumps_result(results)
     if not quiet:
         print(text)
-    with open(results["samplekey"] + ".json", "w") as fw:
-        fw.write(text + "\n")
+    with open(results["samplekey"] + ".json", "wb") as fw:      # (bytes: one encode, no text layer per write)
+        fw.write((text + "\n").encode("utf-8"))
 
 
 def vcfstanza(sampleid, bam, calls, ref):
@@ -748,10 +788,9 @@ def to_vcf(results, ref, repo, treds=("HD",), store=None):
     if not calls:
         return
     records = sorted(_vcf_line(t, calls, repo.get_info(t)) for t in treds if t + ".1" in calls)
-    with gzip.open(results["samplekey"] + ".tred.vcf.gz", "wt", compresslevel=6) as fw:
-        fw.write(vcfstanza(results["samplekey"], results["bam"], calls, ref) + "\n")
-        for _, _, line in records:
-            fw.write(line + "\n")
+    text = vcfstanza(results["samplekey"], results["bam"], calls, ref) + "\n" + "".join(line + "\n" for _, _, line in records)
+    with open(results["samplekey"] + ".tred.vcf.gz", "wb") as fw:   # (one gzip member written in one piece)
+        fw.write(gzip.compress(text.encode("utf-8"), compresslevel=6))
 
 
 def write_vcf_json(results, ref, repo, treds, store=None, quiet=False):
