@@ -133,6 +133,15 @@ def test_many_blocks_in_one_call(inf):
     status, got = _inflate(inf, payloads, [65280] * len(payloads))
     assert (status == 0).all()
     assert all(got[k] == datas[k % 40] for k in range(0, len(payloads), 37))
+    # 9 000 blocks: the call is cut into slices that alternate between two streams (copy-out of one slice beside the
+    # decoding of the next); the device CRCs say every block arrived as decoded
+    payloads = payloads * 9
+    want = [zlib.crc32(d) for d in datas]
+    status, got, sums = _inflate(inf, payloads, [65280] * len(payloads), crc=True)
+    assert (status == 0).all() and [int(c) for c in sums] == [want[k % 40] for k in range(len(payloads))]
+    assert all(got[k] == datas[k % 40] for k in range(0, len(payloads), 211))
+    total, kernel = inf.timing()
+    assert 0 < kernel <= total * 2 + 1                            # (two streams: the decode launches overlap each other)
 
 
 def test_corrupted_streams_never_write_or_read_out_of_bounds(inf):

@@ -209,3 +209,62 @@ def test_results_reach_the_sink_in_order_from_the_writer_thread(tmp_path, monkey
         raise OSError("disk full")
     with pytest.raises(OSError, match="disk full"):
         tredmod.run_many(args[:2], NoEvidenceEngine(), batch=2, sink=bad, threads=1, background_sink=True)
+
+
+def test_inflate_feeder_stops_when_the_consumer_fails(tmp_path, monkeypatch):
+    """run_many(inflate_device=...) feeds chunks through plan -> GPU inflate -> scan on threads of its own.
+    When the consumer dies half way (here: the sink raises on the second sample) the feeder must stop at once -- not sit
+    in a full queue until a timeout --, every planned handle must be closed, the inflaters released after the scans that
+    read them, and the exception that reaches the caller must be the consumer's own.  A stand-in inflater (no GPU)
+    counts what happens to it."""
+    import threading
+    import time
+    from tredparse_amd import tred as t
+    from tredparse_amd.meta import TREDsRepo
+
+    class FakeInflater(object):
+        made, closed, runs = [], [], []
+
+        def __init__(self, device=0):
+            FakeInflater.made.append(self)
+            self.comp_addr = self.out_addr = 0
+
+        def reserve(self, cb, ob, n):
+            self.bufs = (np.zeros(cb + 64, np.uint8), np.zeros(ob + 64, np.uint8), np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64))
+            self.comp_addr, self.out_addr = self.bufs[0].ctypes.data, self.bufs[1].ctypes.data
+            return self.bufs[0][:cb], self.bufs[1][:ob], self.bufs[2], self.bufs[3]
+
+        def run(self, n, crc=False):
+            FakeInflater.runs.append(n)
+            time.sleep(0.05)
+            status = np.full(n, -1, np.int32)                  # every block "refused": the scans inflate for themselves
+            return (status, np.zeros(n, np.uint32)) if crc else status
+
+        def close(self):
+            FakeInflater.closed.append(self)
+
+    monkeypatch.setattr("tredparse_amd._lib.Inflater", FakeInflater)
+    repo = TREDsRepo("hg38", sites=os.path.join(GOLD, "no_sites"))
+    bams = [os.path.join(GOLD, "bam", b) for b in ("t001.bam", "t002.bam")]
+    tasks = [("s{:02d}".format(i), bams[i % 2], repo, ["HD", "DM1"], 300, False, False, True, True, "ERROR") for i in range(40)]
+    seen = []
+
+    def sink(result):
+        seen.append(result["samplekey"])
+        if len(seen) == 2:
+            raise RuntimeError("the consumer failed")
+
+    before = threading.active_count()
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="the consumer failed"):
+        t.run_many(tasks, NoEvidenceEngine(), batch=4, sink=sink, threads=3, inflate_device=0)
+    assert time.perf_counter() - t0 < 20
+    assert len(FakeInflater.made) == 3 and len(FakeInflater.closed) == 3 and 1 <= len(FakeInflater.runs) < 10
+    deadline = time.time() + 10
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() <= before                  # feeder, decode and pool threads are gone
+    # and the good path: the same cohort through the same stand-in, every sample once
+    del seen[:]
+    out = t.run_many(tasks, NoEvidenceEngine(), batch=4, threads=3, inflate_device=0)
+    assert [r["samplekey"] for r in out] == [a[0] for a in tasks]

@@ -99,7 +99,7 @@ def campaign(cases_n=300, seed=1):
     calls_j = np.zeros(n, _lib.CALL_DTYPE)
     ctx.likelihood_grid_joint(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls_j, None, 0,
                               joff, trip, jn, jt)
-    bad = singular = empty = 0
+    bad = singular = empty = near_ties = 0
     worst = 0.0
     for i, (c, w) in enumerate(zip(cases, want)):
         call, l = calls[i], c["locus_rec"]
@@ -117,7 +117,18 @@ def campaign(cases_n=300, seed=1):
                 worst = max(worst, d)
                 ppv = lo.calc_PP(w["tot"], w["lik"], len(l["repeat"]), l["cutoff_risk"], l["mutation_nature"] == "increase",
                                  l["inheritance"][-1] == "R")
-                ok = (d <= 1e-6 and (call["h1"], call["h2"]) == tuple(w["alleles"]) and tuple(call["ci"]) == tuple(w["CI"])
+                same_call = (call["h1"], call["h2"]) == tuple(w["alleles"])
+                if not same_call and d <= 1e-6 and len(set(c["global_lens"])) == 1:
+                    # equal pair lengths that scipy lets through give a one-hot paired-end pdf: the paired-end term then takes
+                    # a handful of values (sums of log .5, log 1 and log e^-10 in the order of the spanning pairs) and whole
+                    # families of pairs tie to the last bits -- in the reference too, where the rounding of its left-to-right
+                    # sum decides.  A different pair whose likelihood is the reference's maximum to 1e-9 is such a tie
+                    exp_tot = exp[:, 2:].sum(axis=1)
+                    at = np.nonzero((exp[:, 0] == call["h1"]) & (exp[:, 1] == call["h2"]))[0]
+                    if len(at) and abs(exp_tot[at[0]] - exp_tot.max()) <= 1e-9:
+                        near_ties += 1
+                        same_call = True
+                ok = (d <= 1e-6 and same_call and tuple(call["ci"]) == tuple(w["CI"])
                       and abs(call["lik"] - w["lik"]) <= 1e-6 and abs(call["pp"] - ppv) <= 1e-9
                       and bool(call["run_pe"]) == w["run_pe"])
                 if ok:   # joint: same kept pairs, same normalised values
@@ -135,6 +146,7 @@ def campaign(cases_n=300, seed=1):
     ctx.close()
     return {"cases": n, "mismatches": bad, "cases_the_reference_raises_on": singular, "no_evidence_cases": empty,
             "pairs_compared": int(sum(len(w.get("mls", [])) for w in want)), "max_abs_diff_ml_terms": worst,
+            "equal_pair_length_ties_resolved_differently": near_ties,
             "seed": seed}
 
 
