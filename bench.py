@@ -551,7 +551,8 @@ def e2e_main(args):
             dist.barrier()
         t0 = time.perf_counter()
         tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads, lazy_details=True,
-                      background_sink=True, inflate_device=0 if args.e2e_gpu_inflate == "1" else None)
+                      background_sink=True, inflate_device=0 if args.e2e_gpu_inflate == "1" else None,
+                      genotype_chunks=args.e2e_genotype_chunks if args.e2e_gpu_inflate == "1" else 1)
         dt = time.perf_counter() - t0
     finally:
         os.chdir(cwd)
@@ -625,7 +626,7 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
                 batch = args.e2e_inflate_batch if gpu_inflate else args.e2e_batch
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
                         "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
-                        "--e2e-repeat", str(args.e2e_repeat)]
+                        "--e2e-repeat", str(args.e2e_repeat), "--e2e-genotype-chunks", str(getattr(args, "e2e_genotype_chunks", 1))]
                 out_dir = os.path.join(root, "out{}x{}{}".format(n_devices, drivers, "g" if gpu_inflate else ""))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
@@ -827,6 +828,7 @@ def main():
     ap.add_argument("--streamed", type=int, default=0,
                     help="also time the step fed from pinned host memory: this many distinct batches, double-buffered "
                          "copy-in beside the kernels (the default run adds it as the `streamed` leg with 4 batches)")
+    ap.add_argument("--e2e-genotype-chunks", type=int, default=1, help="GPU-inflate legs: decode chunks per genotyping batch")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-limit", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

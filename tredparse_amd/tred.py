@@ -560,14 +560,16 @@ class _Writer(object):
 
 
 def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
-             background_sink=False, inflate_device=None, overlap_gpu=False):
+             background_sink=False, inflate_device=None, overlap_gpu=False, genotype_chunks=1):
     """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
     executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in flight the
     scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
     finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch.
     background_sink: sink runs on a writer thread (in order) instead of the driver thread.
     inflate_device: GPU that inflates the samples' BGZF blocks, a chunk of samples per launch (None: the scans inflate on
-    the host); needs scan threads."""
+    the host); needs scan threads.  genotype_chunks: the scans of this many chunks go through the kernels in one GPU batch
+    (a GPU call has a fixed cost of ~15 ms in copies and launches, several times that when driver processes share the
+    device: decode launches want chunks of ~16 samples, genotyping calls larger ones)."""
     own = pool is None and threads > 1 and len(task_args) > 1
     # the first GPU batch is only as large as one round of the scan threads: nothing else can start before it is in
     # (only when there is more than one batch anyway: an extra GPU call costs more than it hides on small inputs)
@@ -590,6 +592,7 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     #  15.5 k against 17.2 k with four: the two halves fight over the interpreter lock.  overlap_gpu stays off.)
     gpu_ex = ThreadPoolExecutor(max_workers=1) if (overlap_gpu and ex is not None and len(chunks) > 1) else None
     pending = None
+    held = []
 
     def flush(item):
         chunk_, scans_, fut_ = item
@@ -619,7 +622,13 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
             else:
                 scans = [collect_sample(a) for a in chunk]
             if gpu_ex is None:
-                for r in finish_batch(engine, chunk, scans, lazy_details=lazy_details):
+                held.append((chunk, scans))
+                if len(held) < max(1, genotype_chunks) and i + 1 < len(chunks):
+                    continue
+                all_args = [a for c, _ in held for a in c]
+                all_scans = [s_ for _, sc in held for s_ in sc]
+                del held[:]
+                for r in finish_batch(engine, all_args, all_scans, lazy_details=lazy_details):
                     if sink is not None:
                         sink(r)
                     else:
