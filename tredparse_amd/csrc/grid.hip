@@ -1102,12 +1102,31 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
         const bool short_grid = nrow <= RS;
         const int rg = short_grid ? 0 : k / ncb;
         const int cb_begin = short_grid ? 0 : k - rg * ncb, cb_end = short_grid ? ncb : cb_begin + 1;
-        const int i_begin = rg * RG, i_end = min(nrow, i_begin + RG);
+        // the rows of a unit in equal groups (257 rows were 128 + 128 + 1: five one-row items per unit), and the column
+        // blocks aligned to the END of the axis: the grids that hold 97 % of all pairs are the upper triangles of
+        // 255 ... 257 x 255 ... 257 squares, where column j has j + 1 valid rows -- a partial block at the low end of
+        // the axis is done after its width in rows, at the high end it kept one or two lanes busy through every row
+        // (a quarter of such a unit's row steps).  Neither changes a number: every pair is computed as before.
+        const int nrg = (nrow + RG - 1) / RG, rgs = (nrow + nrg - 1) / nrg;
+        const int i_begin = rg * rgs, i_end = min(nrow, i_begin + rgs);
+        const int pad = ncb * CB - ncol;
         Best mine; mine.ml = 0; mine.h1 = 0; mine.pos = -1;
         for (int cb = cb_begin; cb < cb_end; ++cb) {
-        const int j = cb * CB + lane;
-        const bool jin = j < ncol;
-        const int jc = jin ? j : ncol - 1;
+        const int j = cb * CB + lane - pad;
+        const bool jin = j >= 0;
+        const int jc = jin ? j : 0;
+        int maxh2 = INT_MAX;                                               // the largest h2 of the block's columns
+        if (!haploid) {
+            // nothing of the item above the diagonal: the smallest h1 of its rows exceeds the largest h2 of its columns
+            // (an axis is its sorted base entries followed by an ascending arithmetic part)
+            const int j1 = cb * CB + CB - 1 - pad;                         // the block's last column (>= 0)
+            maxh2 = axis_value(d.ax2, obs->base, period, j1);
+            if (j1 >= d.ax2.nb && d.ax2.nb > 0 && cb * CB - pad < d.ax2.nb) maxh2 = max(maxh2, obs->base[d.ax2.nb - 1]);
+            maxh2 = __builtin_amdgcn_readfirstlane(maxh2);
+            int minh1 = axis_value(d.ax1, obs->base, period, i_begin);
+            if (i_begin < d.ax1.nb && i_end > d.ax1.nb) minh1 = min(minh1, d.ax1.start);
+            if (__builtin_amdgcn_readfirstlane(minh1) > maxh2) continue;
+        }
         const int h2col = haploid ? 0 : axis_value(d.ax2, obs->base, period, jc);
         // near column (h2 < h_far): its index in the near tables, else -1 (the row's far terms apply)
         int jn = -1;
@@ -1166,6 +1185,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                 Gathered gnxt = {0, 0, 0};
                 if (last && i + 1 < i_end) gnxt = gather_row(i + 1, nxt.h1);
                 const int h1r = __builtin_amdgcn_readfirstlane(cur.h1);
+                if (i >= d.ax1.nb && h1r > maxh2) break;      // (the arithmetic part ascends: no later row reaches the diagonal)
                 const int h2r = haploid ? h1r : h2col;
                 const bool ok = jin && h1r <= h2r;
                 if (__builtin_amdgcn_ballot_w64(ok) != 0) {   // else: row entirely below the diagonal here
