@@ -244,6 +244,7 @@ def test_inflate_feeder_stops_when_the_consumer_fails(tmp_path, monkeypatch):
             FakeInflater.closed.append(self)
 
     monkeypatch.setattr("tredparse_amd._lib.Inflater", FakeInflater)
+    t.release_inflaters()                                       # (none of another test's in the process's pool)
     repo = TREDsRepo("hg38", sites=os.path.join(GOLD, "no_sites"))
     bams = [os.path.join(GOLD, "bam", b) for b in ("t001.bam", "t002.bam")]
     tasks = [("s{:02d}".format(i), bams[i % 2], repo, ["HD", "DM1"], 300, False, False, True, True, "ERROR") for i in range(40)]
@@ -259,7 +260,8 @@ def test_inflate_feeder_stops_when_the_consumer_fails(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="the consumer failed"):
         t.run_many(tasks, NoEvidenceEngine(), batch=4, sink=sink, threads=3, inflate_device=0)
     assert time.perf_counter() - t0 < 20
-    assert len(FakeInflater.made) == 3 and len(FakeInflater.closed) == 3 and 1 <= len(FakeInflater.runs) < 10
+    # the three inflaters went back to the process's pool (their pinned staging is reused by the next cohort), unharmed
+    assert len(FakeInflater.made) == 3 and len(FakeInflater.closed) == 0 and 1 <= len(FakeInflater.runs) < 10
     deadline = time.time() + 10
     while threading.active_count() > before and time.time() < deadline:
         time.sleep(0.05)
@@ -268,3 +270,6 @@ def test_inflate_feeder_stops_when_the_consumer_fails(tmp_path, monkeypatch):
     del seen[:]
     out = t.run_many(tasks, NoEvidenceEngine(), batch=4, threads=3, inflate_device=0)
     assert [r["samplekey"] for r in out] == [a[0] for a in tasks]
+    assert len(FakeInflater.made) == 3                          # the same three again
+    t.release_inflaters()
+    assert len(FakeInflater.closed) == 3

@@ -17,6 +17,7 @@ Reference counterparts: flags tred.py:64-113; per-sample driver run() :180-278; 
 ignored) and the HLI-internal "@sample" lookup.
 """
 import argparse
+import atexit
 import gzip
 import json
 import logging
@@ -217,6 +218,39 @@ def _scan_planned(arg, plan, out_addr, out_off, status, crc=None):
         f.close()
 
 
+# Inflaters are kept between run_many calls of a process (their pinned staging is ~45 MB per sample of a chunk, and
+# page-locking it costs about a second per gigabyte): a feeder borrows three and gives them back.
+_INFLATERS = {}
+_INFLATERS_LOCK = threading.Lock()
+
+
+def _borrow_inflaters(device, n):
+    from ._lib import Inflater
+    with _INFLATERS_LOCK:
+        have = _INFLATERS.setdefault(device, [])
+        out = [have.pop() for _ in range(min(n, len(have)))]
+    while len(out) < n:
+        out.append(Inflater(device))
+    return out
+
+
+def _return_inflaters(device, infs):
+    with _INFLATERS_LOCK:
+        _INFLATERS.setdefault(device, []).extend(infs)
+
+
+def release_inflaters():
+    """Frees the pooled inflaters (their pinned and device buffers)."""
+    with _INFLATERS_LOCK:
+        infs = [i for v in _INFLATERS.values() for i in v]
+        _INFLATERS.clear()
+    for inf in infs:
+        inf.close()
+
+
+atexit.register(release_inflaters)
+
+
 class _InflateFeeder(object):
     """Feeds run_many's chunks through plan -> GPU inflate -> scan, ahead of the consumer: next() returns the next
     chunk's scan futures.  Three stages overlap: while the GPU decodes chunk k (a thread of its own makes the call,
@@ -229,14 +263,12 @@ class _InflateFeeder(object):
 
     def __init__(self, chunks, ex, device):
         import queue
-        import threading
-        from ._lib import Inflater
-        self.chunks, self.ex = chunks, ex
+        self.chunks, self.ex, self.device = chunks, ex, device
         # plans and fills have threads of their own: queued behind a chunk's 28 scans in the scan pool they started only
         # when those were done, and the pool then idled through the next chunk's decode
         self.prep = ThreadPoolExecutor(max_workers=2)
         self.gpu = ThreadPoolExecutor(max_workers=1)       # the decode calls, one after the other, in chunk order
-        self.inflaters = [Inflater(device) for _ in range(self.SLOTS)]
+        self.inflaters = _borrow_inflaters(device, self.SLOTS)
         self.busy = [[] for _ in range(self.SLOTS)]
         self.decoding = [None] * self.SLOTS            # the slot's last decode job (it sets busy[slot] when it hands the scans out)
         self.q = queue.Queue(maxsize=2)
@@ -365,8 +397,8 @@ class _InflateFeeder(object):
             for fut in slot:
                 fut.exception()                            # scans still reading the staging buffers: let them end
         self.prep.shutdown()
-        for inf in self.inflaters:
-            inf.close()
+        _return_inflaters(self.device, self.inflaters)     # (kept for the process's next cohort; release_inflaters frees them)
+        self.inflaters = []
 
 
 def _skeleton(o, scan):
