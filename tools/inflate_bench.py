@@ -93,9 +93,9 @@ def main():
             t = time.process_time(); n, cb, ob = f.plan(sites, regions, rl, extra=bam_parser.y_regions("hg38")); cost["plan"] += (time.process_time() - t) * rep
             comp, out, coff, ooff = inf.reserve(cb, ob, n)
             t = time.process_time(); f.plan_fill(inf.comp_addr, 0, 0, coff, ooff); cost["fill"] += (time.process_time() - t) * rep
-            t = time.process_time(); st = inf.run(n); cost["launch"] += (time.process_time() - t) * rep
+            t = time.process_time(); st, sums = inf.run(n, crc=True); cost["launch"] += (time.process_time() - t) * rep
             t = time.process_time()
-            f.preload(inf.out_addr, ooff, st)
+            f.preload(inf.out_addr, ooff, st, sums)            # (device checksums: the scan does not walk the bytes for the CRC again)
             s1 = bam_parser.scan_sample(b, repo, names, handle=f, readlen=rl)
             hits, misses = f.preload_clear()
             cost["scan_preloaded"] += (time.process_time() - t) * rep
