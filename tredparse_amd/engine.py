@@ -109,7 +109,8 @@ class PackedUnits(object):
 
 class BatchResult(object):
     """Arrays of one genotyped PackedUnits batch; unit(i) gives the per-unit view the callers format."""
-    __slots__ = ("batch", "tag", "h", "score", "full", "pref", "rept", "calls", "marg", "joint", "grid", "grid_off")
+    __slots__ = ("batch", "tag", "h", "score", "full", "pref", "rept", "calls", "marg", "joint", "grid", "grid_off",
+                 "joint_units")
 
     def unit(self, i):
         b = self.batch
@@ -123,6 +124,11 @@ class BatchResult(object):
         if getattr(self, "grid", None) is not None and self.calls[i]["status"] == 0:
             r.grid = self.grid[self.grid_off[i]:self.grid_off[i] + self.calls[i]["n_pairs"]]
         r.joint = self.joint[i] if self.calls[i]["status"] == 0 else None
+        ju = getattr(self, "joint_units", None)
+        r.joint_units = None
+        if ju is not None and self.calls[i]["status"] == 0:
+            a, b, v, lo, n = ju
+            r.joint_units = (a[lo[i]:lo[i] + n[i]], b[lo[i]:lo[i] + n[i]], v[lo[i]:lo[i] + n[i]])
         r.P_h1, r.P_h2 = self.marg[i, 0], self.marg[i, 1]
         return r
 
@@ -130,7 +136,8 @@ class BatchResult(object):
 class UnitResult(object):
     """grid: the dense dump {h1, h2, ml1..ml4} per pair (only when asked for); joint: (triples {h1, h2, exp(ml - max)}
     of the pairs >= e^-10, total over all distinct pairs) -- what P_h1h2 is printed from."""
-    __slots__ = ("tags", "hs", "scores", "full", "pref", "rept_hist", "rept", "call", "grid", "joint", "P_h1", "P_h2")
+    __slots__ = ("tags", "hs", "scores", "full", "pref", "rept_hist", "rept", "call", "grid", "joint", "P_h1", "P_h2",
+                 "joint_units")
 
 
 class Engine(object):
@@ -182,8 +189,8 @@ class Engine(object):
         self.ctx.tally(_lib.MEM_HOST, r.tag if n else np.zeros(1, np.uint8), r.h if n else np.zeros(1, np.int16), n,
                        b.unit_read_off, g, b.pair_id if n else None, hs, r.full, r.pref, r.rept)
         ms = max(int(b.params["maxinsert"].max()) if g else 0, hs) + 2
-        r.calls, r.marg, r.joint = self._grid_arrays(b.params, hs, r.full, r.pref, r.rept, b.global_lens,
-                                                     b.target_lens, ms)
+        r.calls, r.marg, r.joint, r.joint_units = self._grid_arrays(b.params, hs, r.full, r.pref, r.rept, b.global_lens,
+                                                                     b.target_lens, ms, units_form=True)
         if dense and g:
             gl = b.global_lens if len(b.global_lens) else np.zeros(1, np.int32)
             tl = b.target_lens if len(b.target_lens) else np.zeros(1, np.int32)
@@ -195,8 +202,11 @@ class Engine(object):
                                      len(b.target_lens), again, r.grid_off, r.grid, None, 0)
         return r
 
-    def _grid_arrays(self, up, hs, full, pref, rept, gl, tl, ms):
-        """likelihood_grid_joint over array inputs; grows the joint capacity when a flat surface needs it."""
+    def _grid_arrays(self, up, hs, full, pref, rept, gl, tl, ms, units_form=False):
+        """likelihood_grid_joint over array inputs; grows the joint capacity when a flat surface needs it.
+        units_form: also the joint entries of the whole batch as P_h1h2 prints them -- alleles in repeat units, values
+        divided by their unit's total -- computed in one pass over the batch's array (a unit's share is three slices;
+        per unit the same arithmetic was thirty small numpy calls per sample)."""
         g = len(up)
         ngl, ntl = len(gl), len(tl)
         gl = gl if ngl else np.zeros(1, np.int32)
@@ -214,7 +224,14 @@ class Engine(object):
             if (jn <= cap).all():
                 break
             cap = np.maximum(cap, jn)
-        return calls, marg, [(trip[joff[i]:joff[i] + jn[i]], float(jt[i])) for i in range(g)]
+        joint = [(trip[joff[i]:joff[i] + jn[i]], float(jt[i])) for i in range(g)]
+        if not units_form:
+            return calls, marg, joint
+        per = np.repeat(up["period"].astype(np.int64), cap)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ju = (trip[:, 0].astype(np.int64) // per, trip[:, 1].astype(np.int64) // per, trip[:, 2] / np.repeat(jt, cap),
+                  joff[:-1], jn)
+        return calls, marg, joint, ju
 
     # ---- (1) SW + tagging only -----------------------------------------------------------------------
     def classify(self, units, want_dump=False):

@@ -141,7 +141,10 @@ def format_call(tred, res, lazy=False):
         out["lik"], out["PP"] = float(call["lik"]), float(call["pp"])
         out["CI"] = "{}-{}|{}-{}".format(*(int(x) for x in call["ci"]))
         out["P_h1"], out["P_h2"] = sparsify_marginal(res.P_h1, lazy=lazy), sparsify_marginal(res.P_h2, lazy=lazy)
-        if getattr(res, "joint", None) is not None:
+        if getattr(res, "joint_units", None) is not None:    # (the batch's joint entries, already in units and normalised)
+            d = SparseDist(*res.joint_units)
+            out["P_h1h2"] = d if lazy else d.as_dict()
+        elif getattr(res, "joint", None) is not None:
             out["P_h1h2"] = sparsify_joint_triples(res.joint[0], res.joint[1], period, lazy=lazy)
         elif res.grid is not None:
             out["P_h1h2"] = sparsify_joint(res.grid, period)
