@@ -557,16 +557,18 @@ def run(arg, engine=None):
 
 
 class _Writer(object):
-    """sink(result) calls moved off the driver thread: one worker thread takes them in order (JSON text, gzip and the
+    """sink(result) calls moved off the driver thread: worker threads take them from a queue (JSON text, gzip and the
     file writes spend most of their time outside the interpreter lock, so they overlap the driver's next GPU batch
-    and formatting); at most `depth` results wait.  An exception in the sink is re-raised by close()."""
+    and formatting); at most `depth` results wait.  One worker keeps the order of the calls; with more (sinks whose
+    calls are independent, like one set of files per sample) a driver is no longer held to one thread's 3-5 ms per
+    sample.  An exception in the sink is re-raised by close()."""
 
-    def __init__(self, sink, depth=64):
+    def __init__(self, sink, depth=64, workers=1):
         import queue
-        import threading
         self.sink, self.q, self.error = sink, queue.Queue(maxsize=depth), None
-        self.thread = threading.Thread(target=self._run, name="tred-writer", daemon=True)
-        self.thread.start()
+        self.threads = [threading.Thread(target=self._run, name="tred-writer", daemon=True) for _ in range(max(1, workers))]
+        for t in self.threads:
+            t.start()
 
     def _run(self):
         while True:
@@ -585,19 +587,22 @@ class _Writer(object):
         self.q.put(result)
 
     def close(self):
-        self.q.put(None)
-        self.thread.join()
+        for _ in self.threads:
+            self.q.put(None)
+        for t in self.threads:
+            t.join()
         if self.error is not None:
             raise self.error
 
 
 def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
-             background_sink=False, inflate_device=None, overlap_gpu=False, genotype_chunks=1):
+             background_sink=False, inflate_device=None, overlap_gpu=False, genotype_chunks=1, sink_threads=1):
     """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
     executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in flight the
     scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
     finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch.
-    background_sink: sink runs on a writer thread (in order) instead of the driver thread.
+    background_sink: sink runs on a writer thread (in order) instead of the driver thread -- on sink_threads of them, in
+    any order, when that is more than one (the sink's calls must then be independent of each other).
     inflate_device: GPU that inflates the samples' BGZF blocks, a chunk of samples per launch (None: the scans inflate on
     the host); needs scan threads.  genotype_chunks: the scans of this many chunks go through the kernels in one GPU batch
     (a GPU call has a fixed cost of ~15 ms in copies and launches, several times that when driver processes share the
@@ -610,7 +615,7 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     chunks = [c for c in chunks if c]
     ex = ThreadPoolExecutor(max_workers=threads) if own else pool
     out = []
-    writer = _Writer(sink) if (background_sink and sink is not None) else None
+    writer = _Writer(sink, workers=sink_threads) if (background_sink and sink is not None) else None
     if writer is not None:
         sink = writer
     feeder = None
@@ -956,6 +961,7 @@ def main(args, quiet=False):
                         write_vcf_json(result, args.ref, repo, loci, quiet=quiet)
                 run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus),
                          lazy_details=True, background_sink=args.cpus > 1,
+                         sink_threads=2 if (quiet or args.no_output) else 1,     # (echoing to stdout keeps the sample order)
                          inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None)
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
