@@ -555,7 +555,8 @@ def e2e_main(args):
             dist.barrier()
         t0 = time.perf_counter()
         tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads, lazy_details=True,
-                      background_sink=True, sink_threads=2, inflate_device=0 if args.e2e_gpu_inflate == "1" else None,
+                      background_sink=True, sink_threads=2 if args.e2e_gpu_inflate == "1" else 1,
+                      inflate_device=0 if args.e2e_gpu_inflate == "1" else None,
                       genotype_chunks=args.e2e_genotype_chunks if args.e2e_gpu_inflate == "1" else 1)
         dt = time.perf_counter() - t0
     finally:

@@ -961,7 +961,8 @@ def main(args, quiet=False):
                         write_vcf_json(result, args.ref, repo, loci, quiet=quiet)
                 run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus),
                          lazy_details=True, background_sink=args.cpus > 1,
-                         sink_threads=2 if (quiet or args.no_output) else 1,     # (echoing to stdout keeps the sample order)
+                         # (echoing to stdout keeps the sample order; with the host inflating, its cores are the scans')
+                         sink_threads=2 if ((quiet or args.no_output) and args.gpu_inflate) else 1,
                          inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None)
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
