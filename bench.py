@@ -547,7 +547,8 @@ def e2e_main(args):
         # pinned staging (45 MB per sample of a chunk, three inflaters) stays with the process for the timed cohort
         warm = tasks[:2] if args.e2e_gpu_inflate != "1" else tasks[:min(len(tasks), 3 * args.e2e_batch)]
         tred.run_many(warm, engine, batch=2 if args.e2e_gpu_inflate != "1" else args.e2e_batch, sink=sink, threads=max(2, threads),
-                      lazy_details=True, inflate_device=0 if args.e2e_gpu_inflate == "1" else None)
+                      lazy_details=True, inflate_device=0 if args.e2e_gpu_inflate == "1" else None,
+                      gpu_walk=args.e2e_gpu_walk == "1")
         del done[:]
         for k in tred.TIMING:
             tred.TIMING[k] = 0.0
@@ -556,7 +557,7 @@ def e2e_main(args):
         t0 = time.perf_counter()
         tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads, lazy_details=True,
                       background_sink=True, sink_threads=2 if args.e2e_gpu_inflate == "1" else 1,
-                      inflate_device=0 if args.e2e_gpu_inflate == "1" else None,
+                      inflate_device=0 if args.e2e_gpu_inflate == "1" else None, gpu_walk=args.e2e_gpu_walk == "1",
                       genotype_chunks=args.e2e_genotype_chunks if args.e2e_gpu_inflate == "1" else 1)
         dt = time.perf_counter() - t0
     finally:
@@ -631,7 +632,8 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
                 batch = args.e2e_inflate_batch if gpu_inflate else args.e2e_batch
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
                         "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
-                        "--e2e-repeat", str(args.e2e_repeat), "--e2e-genotype-chunks", str(getattr(args, "e2e_genotype_chunks", 1))]
+                        "--e2e-repeat", str(args.e2e_repeat), "--e2e-genotype-chunks", str(getattr(args, "e2e_genotype_chunks", 1)),
+                        "--e2e-gpu-walk", args.e2e_gpu_walk if gpu_inflate else "0"]
                 out_dir = os.path.join(root, "out{}x{}{}".format(n_devices, drivers, "g" if gpu_inflate else ""))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
@@ -645,7 +647,8 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
                         ranks.append(json.load(fp))
                 units, secs = sum(r["units"] for r in ranks), max(r["seconds"] for r in ranks)
                 nbytes = sum(r["bam_bytes"] for r in ranks)
-                legs.append({"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate, "samples_per_gpu_batch": batch,
+                legs.append({"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate,
+                             "gpu_walk": bool(gpu_inflate and args.e2e_gpu_walk == "1"), "samples_per_gpu_batch": batch,
                              "value": units / secs, "unit": "genotypes/s",
                              "units": units, "seconds": secs, "samples": sum(r["samples"] for r in ranks),
                              "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,
@@ -828,6 +831,9 @@ def main():
     ap.add_argument("--e2e-gpu-inflate", choices=("0", "1", "both"), default="both",
                     help="end-to-end legs with the BAMs' BGZF blocks inflated on the GPU (tred.run_many inflate_device): "
                          "0 host only, 1 GPU only, both")
+    ap.add_argument("--e2e-gpu-walk", choices=("0", "1"), default="1",
+                    help="GPU-inflate legs: the pair-length walks run on the GPU too (tred.run_many gpu_walk), and only the "
+                         "blocks of the loci's windows and alternative loci come back")
     ap.add_argument("--e2e-repeat", type=int, default=3, help="every driver goes over its BAMs this many times (a longer cohort from the same files)")
     ap.add_argument("--e2e-inflate-batch", type=int, default=16, help="samples per GPU batch (and inflate launch) in those legs")
     ap.add_argument("--streamed", type=int, default=0,

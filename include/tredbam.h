@@ -169,6 +169,46 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
                  const tredbam_scan_opts* opts, tredbam_unit* units);
 int tredbam_scan_pools(tredbam* b, tredbam_pools* pools);
 
+/* ---- pair lengths computed where the blocks were inflated (the device: tredgpu_inflate_walk, tredgpu.h section 4) ----
+ * PEextractor's walk (bam_parser.py:316-369) is most of a scan's time once the blocks arrive inflated (4 000 records per
+ * locus, of which the read selection and the depth need a tenth), and its +-10 kb regions are two thirds of the blocks
+ * that cross the bus.  The walk can run where the blocks already are:
+ *   tredbam_plan_walks  after tredbam_plan: one task per site -- the region, the limits a pair is classified with, and the
+ *                       region's merged index chunks as (index of the planned block the chunk starts in, offset in it,
+ *                       end virtual offset).  n_chunks < 0: not walkable from the plan (unknown contig, no index, a chunk
+ *                       that starts in a block the plan does not hold): the scan then computes that site itself.
+ *                       Returns the number of chunks written, -3 when cap_chunks is too small.
+ *   tredbam_plan_blocks per planned block (the plan is in file order): compressed offset, compressed length, the trailer's
+ *                       CRC-32, and host[k] != 0 when the scan reads block k in any case (alternative loci, extra
+ *                       regions).  With the walks done elsewhere only those and the blocks between a result's win_vbeg
+ *                       and win_vend need to be handed to tredbam_preload.
+ *   tredbam_scan_pe     tredbam_scan with the pair lengths of site i taken from pe[i] (status == 0: n_global / n_target
+ *                       values from global_first / target_first of the two pools, in PEextractor's order); the scan
+ *                       then reads only the records between pe[i].win_vbeg and win_vend -- those of the locus' window,
+ *                       a tenth of the region's -- for the depth and the read selection.  Every other site is scanned
+ *                       as tredbam_scan scans it.  Results are those of tredbam_scan. */
+typedef struct tredbam_walk_task {
+    int32_t tid, start, end;        /* records of contig tid overlapping [start, end)                                    */
+    int32_t tstart, tend, span;     /* a pair spans the tract when a.start < tstart and b.end > tend; tlen >= span: dropped */
+    int32_t chunk_first, n_chunks;  /* its entries of chunks[]                                                           */
+    int32_t block_first, block_end; /* the sample's blocks among those of the call (tredbam_plan_walks: 0 .. plan size)  */
+    int32_t win_lo, win_hi;         /* the scan's own window [win_lo, win_hi) inside the region: see win_vbeg / win_vend  */
+} tredbam_walk_task;
+typedef struct tredbam_walk_chunk { int32_t begin_block, begin_upos; uint64_t end_voffset; } tredbam_walk_chunk;
+typedef struct tredbam_walk_result {
+    int32_t status;                 /* 0: walked; anything else: not done here, the scan walks the site itself            */
+    int32_t n_global, n_target;     /* pair lengths in PEextractor's order, from global_first / target_first of the pools  */
+    int32_t n_window;               /* records of the region that overlap [win_lo, win_hi)                                 */
+    int64_t global_first, target_first;
+    uint64_t win_vbeg, win_vend;    /* virtual offsets of the first such record and behind the last one (0, 0: none)      */
+} tredbam_walk_result;
+int64_t tredbam_plan_walks(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_scan_opts* opts,
+                           tredbam_walk_task* tasks, tredbam_walk_chunk* chunks, int64_t cap_chunks);
+int64_t tredbam_plan_blocks(tredbam* b, int64_t* coffset, int32_t* clen, uint32_t* crc, uint8_t* host);
+int tredbam_scan_pe(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
+                    const tredbam_scan_opts* opts, const tredbam_walk_result* pe, const int32_t* pe_global,
+                    const int32_t* pe_target, tredbam_unit* units);
+
 /* The JSON text of one locus' `details` list exactly as the driver prints it inside a sample's file (what
  * json.dumps(list, sort_keys=True, indent=4, separators=(',', ': ')) yields for the list at nesting depth 2:
  * elements {"h": int, "id": name, "seq": bases, "tag": "FULL" | "PREF" | "POST" | "REPT" | "HANG"}), written straight

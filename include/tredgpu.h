@@ -316,6 +316,51 @@ int tredgpu_inflate_blocks_crc(tredgpu_inflater* inf, int32_t n_blocks, int32_t*
  */
 int tredgpu_inflater_timing(tredgpu_inflater* inf, double* total_ms, double* kernel_ms);
 
+/*
+ * The pair-length walk where the blocks already are.  PEextractor (tredparse/bam_parser.py:316-369: the records of the
+ * +-10 kb region of a locus, paired by query name, pair lengths from the soft-clipped ends, "target" pairs that span the
+ * tract and "global" ones) reads 4 000 records per locus, ten times what the read selection and the depth need, and its
+ * regions are most of the blocks of a sample.  tredgpu_inflate_walk decodes as tredgpu_inflate_blocks_crc does, then walks
+ * the regions over the decoded blocks on the device (one region per wavefront) and brings back the pair lengths and,
+ * per region, between which virtual offsets the records of the locus' own window lie; NO block is copied back.
+ * tredgpu_inflater_fetch then copies the blocks the host asks for -- those between these offsets, a fifth of them -- to
+ * their places in the pinned output.  include/tredbam.h (tredbam_plan_walks, tredbam_plan_blocks, tredbam_scan_pe) is the
+ * host's half; the structs have the layouts of tredbam_walk_task / _chunk / _result.
+ *   results[t].status  0: walked.  1 a block the walk needs is not among the sample's (or the file ends), 2 a block the
+ *                      decoder rejected or whose CRC-32 is not blk_crc, 3 a record that makes no sense, 4 more than 8 192
+ *                      query names in the region, 5 a pair whose second read has no alignment end (the reference dies
+ *                      there), 6 the pools are full: the host walks that region itself (tredbam_scan_pe does).
+ */
+typedef struct tredgpu_walk_task {
+    int32_t tid, start, end;        /* records of contig tid overlapping [start, end)                                     */
+    int32_t tstart, tend, span;     /* a pair spans the tract when a.start < tstart and b.end > tend; tlen >= span: dropped */
+    int32_t chunk_first, n_chunks;  /* its entries of chunks[]; n_chunks < 0: not walkable (status 1)                      */
+    int32_t block_first, block_end; /* the blocks of the task's file among those of the call                              */
+    int32_t win_lo, win_hi;         /* the window whose records' offsets are reported                                      */
+} tredgpu_walk_task;
+typedef struct tredgpu_walk_chunk { int32_t begin_block, begin_upos; uint64_t end_voffset; } tredgpu_walk_chunk;
+typedef struct tredgpu_walk_result {
+    int32_t status, n_global, n_target, n_window;
+    int64_t global_first, target_first;     /* into the pools of the call                                                  */
+    uint64_t win_vbeg, win_vend;            /* virtual offsets of the first window record / behind the last (0, 0: none)  */
+} tredgpu_walk_result;
+typedef struct tredgpu_walk_args {
+    const int64_t* blk_coffset;             /* per block of the call: where it starts in its file                          */
+    const int32_t* blk_clen;                /*                        its compressed length there                          */
+    const uint32_t* blk_crc;                /*                        the CRC-32 its trailer promises                      */
+    const tredgpu_walk_task* tasks;   int32_t n_tasks;
+    const tredgpu_walk_chunk* chunks; int32_t n_chunks;
+    tredgpu_walk_result* results;           /* out: n_tasks                                                                */
+    int32_t* global_pool; int64_t cap_global;    /* out: the pair lengths (tasks take their room in any order)             */
+    int32_t* target_pool; int64_t cap_target;
+    int64_t n_global, n_target;             /* out: entries of the pools in use                                            */
+} tredgpu_walk_args;
+int tredgpu_inflate_walk(tredgpu_inflater* inf, int32_t n_blocks, int32_t* status, uint32_t* crc, tredgpu_walk_args* walk);
+/* copies the blocks with need[k] != 0 of the last tredgpu_inflate_walk to the pinned output; returns the number of copies */
+int tredgpu_inflater_fetch(tredgpu_inflater* inf, int32_t n_blocks, const uint8_t* need);
+/* device time of the last call's walk launch in milliseconds */
+int tredgpu_inflater_walk_ms(tredgpu_inflater* inf, double* walk_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,17 @@ def test_run_many_with_gpu_inflated_blocks_gives_the_same_results(engine, tmp_pa
     t = tredmod.TIMING
     assert t["inflate_blocks"] > 500 and t["inflate_failed"] == 0
     assert t["inflate_hits"] > 20 * max(t["inflate_misses"], 1)
+    # the same with the pair-length walks on the device: identical bytes again, from a fraction of the blocks
+    blocks = t["inflate_blocks"]
+    for k in tredmod.TIMING:
+        tredmod.TIMING[k] = 0
+    walked = tredmod.run_many(args, engine, batch=4, threads=3, inflate_device=0, gpu_walk=True)
+    for a, b in zip(walked, plain):
+        assert tredmod.dumps_result(a) == tredmod.dumps_result(b)
+    assert t["inflate_blocks"] == blocks and t["inflate_failed"] == 0
+    assert t["walk_regions"] > 100 and t["walk_declined"] == 0
+    assert 0 < t["walk_blocks_fetched"] < 0.8 * blocks
+    assert t["inflate_misses"] == 0 and t["inflate_hits"] > 0
 
 
 def test_cli_gpu_inflate_writes_the_same_files(engine, tmp_path, monkeypatch):
@@ -122,9 +133,11 @@ def test_cli_gpu_inflate_writes_the_same_files(engine, tmp_path, monkeypatch):
     monkeypatch.setattr("tredparse_amd.engine.Engine", lambda *a, **k: engine)
     tredmod.main([str(csv), "--workdir", str(tmp_path / "plain"), "--cpus", "3", "--batch-samples", "2"], quiet=True)
     tredmod.main([str(csv), "--workdir", str(tmp_path / "helped"), "--cpus", "3", "--batch-samples", "2", "--gpu-inflate"], quiet=True)
+    tredmod.main([str(csv), "--workdir", str(tmp_path / "walked"), "--cpus", "3", "--batch-samples", "2", "--gpu-inflate", "--gpu-walk"], quiet=True)
     for key in "abcd":
-        assert open(tmp_path / "plain" / (key + ".json")).read() == open(tmp_path / "helped" / (key + ".json")).read()
-        assert gzip.open(tmp_path / "plain" / (key + ".tred.vcf.gz")).read() == gzip.open(tmp_path / "helped" / (key + ".tred.vcf.gz")).read()
+        for other in ("helped", "walked"):
+            assert open(tmp_path / "plain" / (key + ".json")).read() == open(tmp_path / other / (key + ".json")).read()
+            assert gzip.open(tmp_path / "plain" / (key + ".tred.vcf.gz")).read() == gzip.open(tmp_path / other / (key + ".tred.vcf.gz")).read()
 
 
 def test_log_debug_prints_the_references_diagnostics(engine, caplog):

@@ -1,0 +1,205 @@
+"""The pair walk on the device (csrc/inflate.hip pair_walk_kernel, tredgpu_inflate_walk) against the host's file layer:
+per locus the two pair-length lists in PEextractor's order (tredparse/bam_parser.py:316-369, restated by
+bamread.cpp's PairTable and checked against the reference's own numbers in test_host_frontend.py), the virtual offsets
+between which the locus' window lies against a walk through the package's pure-Python BAM layer, and the whole scan with
+the device's results handed in (tredbam_scan_pe) against the plain scan -- reading only the blocks tredgpu_inflater_fetch
+brought back."""
+import os
+
+import numpy as np
+import pytest
+
+from tredparse_amd import _lib, bamio, synth, synth_bam
+from tredparse_amd.bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays, walk_need
+from tredparse_amd.meta import TREDsRepo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def inf():
+    f = _lib.Inflater(0)
+    yield f
+    f.close()
+
+
+@pytest.fixture(scope="module")
+def synthetic(tmp_path_factory):
+    root = tmp_path_factory.mktemp("walk")
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1", "FRDA", "AR", "FXS", "SCA17")]
+    made = synth_bam.make_bams(str(root), 2, seed=91, loci=loci, p=synth.SynthParams(coverage=30, expanded_max=120, expanded_frac=0.3))
+    return [(path, TREDsRepo(), [l["name"] for l in loci]) for _, path, _ in made]
+
+
+def _window_span(path, chrom, p_lo, p_hi, w_lo, w_hi):
+    """(n, vbeg, vend) of the records of [w_lo, w_hi) within the walk over [p_lo, p_hi), through the pure-Python layer
+    (bamio.PyAlignmentFile.fetch's loop with the position taken before and after every record)."""
+    f = bamio.PyAlignmentFile(path)
+    if chrom not in f._tid:
+        return 0, 0, 0
+    tid = f._tid[chrom]
+    f._load_index()
+    bins, lin = f._index[tid]
+    start, end = max(0, p_lo), p_hi
+    min_off = lin[min(start >> 14, len(lin) - 1)] if lin else 0
+    chunks = sorted((max(cb, min_off), ce) for b in bamio._reg2bins(start, max(end, start + 1)) for cb, ce in bins.get(b, ()) if ce > min_off)
+    merged = []
+    for cb, ce in chunks:
+        if merged and cb <= merged[-1][1]:
+            merged[-1] = (merged[-1][0], max(merged[-1][1], ce))
+        else:
+            merged.append((cb, ce))
+    n = vbeg = vend = 0
+    for cb, ce in merged:
+        f.bg.seek(cb)
+        while f.bg.tell() < ce:
+            at = f.bg.tell()
+            r = f._next()
+            if r is None:
+                break
+            if r.tid != tid or r.pos >= end:
+                if r.tid > tid or (r.tid == tid and r.pos >= end):
+                    break
+                continue
+            rend = r.reference_end
+            if rend is None or rend <= r.pos:
+                rend = r.pos + 1
+            if rend > start and r.pos < w_hi and rend > max(0, w_lo):
+                if n == 0:
+                    vbeg = at
+                n += 1
+                vend = f.bg.tell()
+    f.close()
+    return n, vbeg, vend
+
+
+def _lay_out(inf, handles, plans):
+    """The planned blocks of several files in one inflater, and the walk tables of the whole call."""
+    n_all = sum(p[0] for p in plans)
+    comp, out, coff, ooff = inf.reserve(sum(p[1] for p in plans), sum(p[2] for p in plans), n_all)
+    at = cb = ob = 0
+    firsts = []
+    for f, (n, cbytes, obytes) in zip(handles, plans):
+        f.plan_fill(inf.comp_addr, cb, ob, coff[at:at + n + 1], ooff[at:at + n + 1])
+        firsts.append(at)
+        at, cb, ob = at + n, cb + cbytes, ob + obytes
+    return n_all, comp, coff, ooff, firsts
+
+
+def _walk_inputs(handles, sites_of, readlens, firsts):
+    blk = [f.plan_blocks() for f in handles]
+    tasks, chunks, c0 = [], [], 0
+    for f, sites, rl, b0, (coff, _, _, _) in zip(handles, sites_of, readlens, firsts, blk):
+        t, c = f.plan_walks(sites, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+        t, c = t.copy(), c.copy()
+        t["chunk_first"] += c0
+        t["block_first"] += b0
+        t["block_end"] += b0
+        c["begin_block"][c["begin_block"] >= 0] += b0
+        tasks.append(t)
+        chunks.append(c)
+        c0 += len(c)
+    cat = lambda k: np.concatenate([b[k] for b in blk])      # noqa: E731
+    return cat(0), cat(1), cat(2), [b[3] for b in blk], [b[0] for b in blk], np.concatenate(tasks), np.concatenate(chunks), [len(t) for t in tasks]
+
+
+def _cases(synthetic):
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    out = [(os.path.join(GOLD, "bam", s + ".bam"), repo, sorted(repo.names)) for s in ("t001", "t002")]
+    return out + list(synthetic)
+
+
+def test_walked_pair_lengths_offsets_and_scan(inf, synthetic):
+    cases = _cases(synthetic)
+    handles = [bamio.AlignmentFile(p) for p, _, _ in cases]
+    sites_of, regions_of, readlens, plans = [], [], [], []
+    for f, (path, repo, names) in zip(handles, cases):
+        loci = [repo[n] for n in names]
+        sites, regions = _site_arrays(repo, names, loci, f)
+        rl = f.max_read_len(101)
+        plans.append(f.plan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN))
+        sites_of.append(sites); regions_of.append(regions); readlens.append(rl)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, handles, plans)
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, n_tasks = _walk_inputs(handles, sites_of, readlens, firsts)
+    status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks)
+    assert (status == 0).all() and (crc == bcrc).all()
+    assert inf.walk_ms() > 0
+    t0 = 0
+    total_pairs = total_window = 0
+    for f, (path, repo, names), sites, regions, rl, first, host, coff, nt in zip(handles, cases, sites_of, regions_of, readlens, firsts,
+                                                                                  host_of, coff_of, n_tasks):
+        r = res[t0:t0 + nt]
+        t0 += nt
+        plain_f = bamio.AlignmentFile(path)
+        units, pools = plain_f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+        for k, name in enumerate(names):
+            t = repo[name]
+            if sites["tid"][k] < 0:
+                assert r["status"][k] == 1                  # not walkable: the scan's business
+                continue
+            assert r["status"][k] == 0, (path, name, r[k])
+            g = gp[r["global_first"][k]:r["global_first"][k] + r["n_global"][k]]
+            tt = tp[r["target_first"][k]:r["target_first"][k] + r["n_target"][k]]
+            eg, et = plain_f.pe_lengths(t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE,
+                                        t.repeat_start - FLANKMATCH, t.repeat_end + FLANKMATCH, SPAN)
+            assert list(g) == eg and list(tt) == et, (path, name)
+            total_pairs += len(eg) + len(et)
+            n, vbeg, vend = _window_span(path, t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE,
+                                         t.repeat_start - SPAN, t.repeat_end + SPAN)
+            assert (int(r["n_window"][k]), int(r["win_vbeg"][k]), int(r["win_vend"][k])) == (n, vbeg, vend), (path, name)
+            total_window += n
+        # the scan with these results, over the fetched blocks only
+        need = walk_need(coff, host, r)
+        assert need.sum() < len(need) or len(need) < 8
+        full = np.zeros(n_all, np.uint8)
+        full[first:first + len(need)] = need
+        inf.fetch(full)
+        n_here = len(need)
+        f.preload(inf.out_addr, ooff[first:first + n_here + 1], np.where(need != 0, status[first:first + n_here], 1).astype(np.int32),
+                  crc[first:first + n_here])
+        u2, p2 = f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(r, gp, tp))
+        hits, misses = f.preload_clear()
+        for key in units.dtype.names:
+            assert (units[key] == u2[key]).all(), (path, key)
+        for key in pools:
+            assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), (path, key)
+        assert misses == 0 and hits > 0, (path, hits, misses)     # every block the scan read had been fetched
+        plain_f.close()
+    assert total_pairs > 2000 and total_window > 500
+    for f in handles:
+        f.close()
+
+
+def test_a_block_the_decoder_cannot_vouch_for_ends_the_task_not_the_sample(inf, synthetic):
+    """A payload damaged in the staging buffer (the file is fine): the block's status or CRC is off, the walks that touch
+    it end with status 2, every other region is walked, and the scan -- computing those sites itself -- gives the plain
+    scan's result."""
+    path, repo, names = synthetic[0]
+    f = bamio.AlignmentFile(path)
+    loci = [repo[n] for n in names]
+    sites, regions = _site_arrays(repo, names, loci, f)
+    rl = f.max_read_len(101)
+    plan = f.plan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    n_all, comp, comp_off, ooff, firsts = _lay_out(inf, [f], [plan])
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, _ = _walk_inputs([f], [sites], [rl], firsts)
+    # damage the middle of the payload of a block in the first task's first chunk
+    victim = int(chunks["begin_block"][tasks["chunk_first"][0]]) + 1
+    mid = int(comp_off[victim] + (comp_off[victim + 1] - comp_off[victim]) // 2)
+    comp[mid:mid + 8] ^= 0x5A
+    status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks)
+    assert status[victim] != 0 or crc[victim] != bcrc[victim]
+    assert res["status"][0] == 2 and (res["status"][1:] == 0).sum() >= len(res) - 2
+    need = walk_need(coff_of[0], host_of[0], res)
+    inf.fetch(need)
+    ok_status = np.where((need != 0) & (crc == bcrc), status, 1).astype(np.int32)
+    f.preload(inf.out_addr, ooff[:n_all + 1], ok_status, crc)
+    u2, p2 = f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(res, gp, tp))
+    f.preload_clear()
+    g = bamio.AlignmentFile(path)
+    units, pools = g.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    for key in units.dtype.names:
+        assert (units[key] == u2[key]).all(), key
+    for key in pools:
+        assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
+    f.close(); g.close()

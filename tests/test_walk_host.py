@@ -1,0 +1,98 @@
+"""run_many(gpu_walk=True) on the host side, without a GPU: the feeder's plan -> decode + walk -> fetch -> scan pipeline with
+tests/walk_model.ModelInflater in the inflater's place (zlib and a plain Python walk over the task tables).  Every scan
+must equal the plain scan_sample of the same file field for field, having read only blocks the model was asked to fetch --
+this pins tredbam_plan_walks / tredbam_plan_blocks / tredbam_scan_pe and the table arithmetic of _InflateFeeder; the
+kernel's own parity is test_pairwalk_gpu.py's business."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from tredparse_amd import bamio, synth, synth_bam
+from tredparse_amd import tred as t
+from tredparse_amd.bam_parser import scan_sample
+from tredparse_amd.meta import TREDsRepo
+
+from .walk_model import ModelInflater
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIELDS = ("packed", "word_off", "read_len", "seq4", "seq4_off", "name_blob", "name_off", "name_id", "global_lens", "target_lens",
+          "depth", "ploidy")
+
+
+def _same(a, b):
+    assert a.opened == b.opened and a.gender == b.gender and a.readlen == b.readlen
+    if not a.opened:
+        return
+    assert a.dropped == b.dropped
+    for key in a.unit.dtype.names:
+        assert (a.unit[key] == b.unit[key]).all(), key
+    for key in FIELDS:
+        x, y = getattr(a, key), getattr(b, key)
+        assert (x == y) if isinstance(x, bytes) else np.array_equal(x, y), key
+
+
+@pytest.fixture(scope="module")
+def cohort(tmp_path_factory):
+    root = tmp_path_factory.mktemp("walkhost")
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1", "AR")]
+    made = synth_bam.make_bams(str(root), 2, seed=5, loci=loci, p=synth.SynthParams(coverage=12, expanded_max=120, expanded_frac=0.3))
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    srepo = TREDsRepo()
+    args = [(s, os.path.join(GOLD, "bam", s + ".bam"), repo, sorted(repo.names), 300, False, False, True, True, "ERROR") for s in ("t001", "t002")]
+    args += [(key, path, srepo, [l["name"] for l in loci], 300, False, False, True, True, "ERROR") for key, path, _ in made]
+    args.append(("missing", os.path.join(str(root), "no_such.bam"), repo, ["HD"], 300, False, False, True, True, "ERROR"))
+    return args
+
+
+def test_feeder_with_walked_pair_lengths_gives_the_plain_scans(cohort, monkeypatch):
+    if not hasattr(bamio.AlignmentFile(cohort[0][1]), "plan_walks"):
+        pytest.skip("no native BAM layer")
+    monkeypatch.setattr("tredparse_amd._lib.Inflater", ModelInflater)
+    t.release_inflaters()
+    del ModelInflater.made[:]
+    for k in t.TIMING:
+        t.TIMING[k] = 0
+    chunks = [cohort[:2], cohort[2:4], cohort[4:]]
+    ex = ThreadPoolExecutor(max_workers=2)
+    feeder = t._InflateFeeder(chunks, ex, 0, walk=True)
+    try:
+        scans = [fut.result() for _ in chunks for fut in feeder.next()]
+    finally:
+        feeder.close()
+        ex.shutdown()
+        t.release_inflaters()
+    assert len(scans) == len(cohort)
+    for a, s in zip(cohort, scans):
+        o = t._options(a)
+        _same(s, scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"]))
+    tm = t.TIMING
+    assert tm["walk_regions"] == sum(len(a[3]) for a in cohort[:4]) and tm["walk_declined"] == 0
+    assert 0 < tm["walk_blocks_fetched"] < tm["inflate_blocks"]
+    assert tm["inflate_misses"] == 0 and tm["inflate_hits"] > 0          # no scan inflated a block for itself
+    assert sum(m.walks for m in ModelInflater.made) == 2                 # (the chunk with the missing file has nothing to decode)
+
+
+def test_regions_the_walker_declines_are_walked_by_the_scan(cohort, monkeypatch):
+    """Every region comes back with a status (here: the model pretends a damaged block in each): the scans compute the
+    pair lengths themselves, inflating what was not fetched, and nothing changes in the result."""
+    class Declining(ModelInflater):
+        def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048):
+            status, crc, res, gp, tp = ModelInflater.run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks)
+            res["status"][::2] = 2
+            return status, crc, res, gp, tp
+
+    monkeypatch.setattr("tredparse_amd._lib.Inflater", Declining)
+    t.release_inflaters()
+    ex = ThreadPoolExecutor(max_workers=2)
+    feeder = t._InflateFeeder([cohort[:4]], ex, 0, walk=True)
+    try:
+        scans = [fut.result() for fut in feeder.next()]
+    finally:
+        feeder.close()
+        ex.shutdown()
+        t.release_inflaters()
+    for a, s in zip(cohort[:4], scans):
+        o = t._options(a)
+        _same(s, scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"]))

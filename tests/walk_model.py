@@ -1,0 +1,178 @@
+"""Test infrastructure: a stand-in for _lib.Inflater on machines without a GPU -- zlib for the blocks and a plain Python
+walk over the inflated bytes that follows the task / chunk tables the way csrc/inflate.hip's pair_walk_kernel does
+(bamread.cpp walk_region + PairTable: tredparse/bam_parser.py:316-369).  Only tests use it: the host-side plumbing of
+run_many(gpu_walk=True) is exercised here, the kernel itself in test_pairwalk_gpu.py."""
+import struct
+import zlib
+
+import numpy as np
+
+from tredparse_amd import _lib
+
+REF_OPS = (0, 2, 3, 7, 8)      # M D N = X
+
+
+class ModelInflater(object):
+    made = []
+
+    def __init__(self, device=0):
+        ModelInflater.made.append(self)
+        self.comp_addr = self.out_addr = 0
+        self.walks = self.fetched = 0
+
+    def reserve(self, cb, ob, n):
+        self.bufs = (np.zeros(cb + 64, np.uint8), np.zeros(ob + 64, np.uint8), np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64))
+        self.comp_addr, self.out_addr = self.bufs[0].ctypes.data, self.bufs[1].ctypes.data
+        return self.bufs[0][:cb], self.bufs[1][:ob], self.bufs[2], self.bufs[3]
+
+    def _inflate(self, n):
+        comp, _, coff, ooff = self.bufs
+        self.dev = np.zeros(int(ooff[n]) + 64, np.uint8)
+        status, crc = np.zeros(n, np.int32), np.zeros(n, np.uint32)
+        for k in range(n):
+            try:
+                data = zlib.decompressobj(-15).decompress(bytes(comp[coff[k]:coff[k + 1]]))
+            except zlib.error:
+                status[k] = -1
+                continue
+            if len(data) != ooff[k + 1] - ooff[k]:
+                status[k] = -2
+                continue
+            self.dev[ooff[k]:ooff[k + 1]] = np.frombuffer(data, np.uint8)
+            crc[k] = zlib.crc32(data)
+        return status, crc
+
+    def run(self, n, crc=False):
+        status, sums = self._inflate(n)
+        self.bufs[1][:len(self.dev) - 64] = self.dev[:-64]
+        return (status, sums) if crc else status
+
+    def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048):
+        self.walks += 1
+        status, crc = self._inflate(n)
+        ooff = self.bufs[3]
+        out = self.dev.tobytes()
+        res = np.zeros(len(tasks), _lib.WALK_RESULT_DTYPE)
+        gp, tp = [], []
+        ok = lambda k: status[k] == 0 and crc[k] == xcrc[k]     # noqa: E731
+        for t, T in enumerate(tasks):
+            r = _walk(T, chunks, out, ooff, bcoff, bclen, ok)
+            if isinstance(r, int):
+                res["status"][t] = r
+                continue
+            g, tt, nwin, vbeg, vend = r
+            res[t] = (0, len(g), len(tt), nwin, len(gp), len(tp), vbeg, vend)
+            gp += g
+            tp += tt
+        return status, crc, res, np.array(gp, np.int32), np.array(tp, np.int32)
+
+    def fetch(self, need):
+        ooff = self.bufs[3]
+        for k in np.flatnonzero(np.asarray(need)):
+            self.bufs[1][ooff[k]:ooff[k + 1]] = self.dev[ooff[k]:ooff[k + 1]]
+        self.fetched += int(np.count_nonzero(need))
+        return 1
+
+    def close(self):
+        pass
+
+
+def _walk(T, chunks, out, ooff, bcoff, bclen, ok):
+    if T["n_chunks"] < 0:
+        return 1
+    size_of = lambda k: int(ooff[k + 1] - ooff[k])              # noqa: E731
+
+    def tell(k, upos):
+        return (int(bcoff[k]) + int(bclen[k])) << 16 if upos >= size_of(k) else (int(bcoff[k]) << 16) | upos
+
+    pairs, order = {}, []
+    nwin = vbeg = vend = 0
+    for c in range(int(T["chunk_first"]), int(T["chunk_first"]) + int(T["n_chunks"])):
+        k, upos, cend = int(chunks["begin_block"][c]), int(chunks["begin_upos"][c]), int(chunks["end_voffset"][c])
+        if k < T["block_first"] or k >= T["block_end"]:
+            return 1
+        if not ok(k):
+            return 2
+        while True:
+            at = tell(k, upos)
+            if at >= cend:
+                break
+            pieces = []
+            for n in (4, None):
+                if n is None:
+                    n = struct.unpack_from("<i", out, pieces[0])[0]
+                    if n < 32:
+                        return 3
+                addr = -1
+                while n > 0:
+                    if upos >= size_of(k):
+                        if k + 1 >= T["block_end"] or bcoff[k] + bclen[k] != bcoff[k + 1]:
+                            return 1
+                        k += 1
+                        if not ok(k):
+                            return 2
+                        upos = 0
+                    if addr < 0:
+                        addr = int(ooff[k]) + upos
+                    piece = min(n, size_of(k) - upos)
+                    upos += piece
+                    n -= piece
+                pieces.append(addr)
+            r = pieces[1]
+            size = struct.unpack_from("<i", out, pieces[0])[0]
+            tid, pos, l_name, _mq, _bin, n_cig, flag, l_seq = struct.unpack_from("<iiBBHHHi", out, r)
+            if tid != T["tid"] or pos >= T["end"]:
+                if tid > T["tid"] or (tid == T["tid"] and pos >= T["end"]):
+                    break
+                continue
+            if l_seq < 0 or 32 + l_name + 4 * n_cig + (l_seq + 1) // 2 > size:
+                return 3
+            cig = struct.unpack_from("<{}I".format(n_cig), out, r + 32 + l_name) if n_cig else ()
+            rend = -1
+            if not (flag & 4) and n_cig:
+                rend = pos + sum(c >> 4 for c in cig if (c & 15) in REF_OPS)
+            e = pos + 1 if (rend < 0 or rend <= pos) else rend
+            if not e > T["start"]:
+                continue
+            if pos < T["win_hi"] and e > T["win_lo"]:
+                if nwin == 0:
+                    vbeg = at
+                nwin += 1
+                vend = tell(k, upos)
+            if not (flag & 1) or (flag & 4) or (flag & 0x400):
+                continue
+            name = out[r + 32:r + 32 + max(l_name - 1, 0)]
+            p = pairs.get(name)
+            if p is None:
+                p = pairs[name] = []
+                order.append(name)
+            if len(p) < 2:
+                lead = trail = 0
+                for c in cig:
+                    if (c & 15) == 4:
+                        lead += c >> 4
+                    elif (c & 15) != 5:
+                        break
+                for c in reversed(cig):
+                    if (c & 15) == 4:
+                        trail += c >> 4
+                    elif (c & 15) != 5:
+                        break
+                p.append((pos, rend, bool(flag & 0x10), lead, trail))
+            else:
+                p.append(None)
+    g, t = [], []
+    for name in order:
+        p = pairs[name]
+        if len(p) < 2:
+            continue
+        a, b = p[0], p[1]
+        if a[2] or not b[2]:
+            continue
+        if b[1] < 0:
+            return 5
+        tlen = (b[1] + b[4]) - (a[0] - a[3])
+        if tlen >= T["span"]:
+            continue
+        (t if (a[0] < T["tstart"] and b[1] > T["tend"]) else g).append(tlen)
+    return g, t, nwin, vbeg, vend

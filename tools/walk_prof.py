@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Where the pair walk's cycles go (GPU box): runs tredgpu_inflate_walk of a -DWALK_PROF build of the library on m
+synthetic 30x samples and prints the mean cycles per region of each phase of the record loop.
+
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DWALK_PROF -shared -o tools/_ab/libtredgpu_walkprof.so \\
+        tredparse_amd/csrc/{capi,sw_ladder,grid,inflate}.hip
+  python tools/walk_prof.py [samples = 16] [library = tools/_ab/libtredgpu_walkprof.so]
+"""
+import glob
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    from tredparse_amd import _lib
+    m = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(__file__), "_ab", "libtredgpu_walkprof.so"))
+    from tredparse_amd import bam_parser, synth_bam
+    from tredparse_amd.meta import TREDsRepo
+    root = tempfile.mkdtemp(prefix="tred_walkprof_")
+    synth_bam.make_bams(root, 4, seed=7, workers=4)
+    bams = sorted(glob.glob(os.path.join(root, "*.bam")))
+    repo = TREDsRepo("hg38", sites=os.path.join(root, "no_sites"))
+    names = [l["name"] for l in synth_bam.bench_loci()]
+    loci = [repo[n] for n in names]
+    inf = _lib.Inflater(0)
+    hs = [bam_parser.open_bam(bams[k % len(bams)]) for k in range(m)]
+    plans, tabs = [], []
+    for f in hs:
+        sites, regions = bam_parser._site_arrays(repo, names, loci, f)
+        plans.append(f.plan(sites, regions, 150))
+        tabs.append((f.plan_walks(sites, 150), f.plan_blocks()))
+    n_all = sum(p[0] for p in plans)
+    comp, out, coff, ooff = inf.reserve(sum(p[1] for p in plans), sum(p[2] for p in plans), n_all)
+    at = cb = ob = c0 = 0
+    tasks, chunks = [], []
+    for f, p, ((t, c), _) in zip(hs, plans, tabs):
+        f.plan_fill(inf.comp_addr, cb, ob, coff[at:at + p[0] + 1], ooff[at:at + p[0] + 1])
+        t, c = t.copy(), c.copy()
+        t["chunk_first"] += c0; t["block_first"] += at; t["block_end"] += at
+        c["begin_block"][c["begin_block"] >= 0] += at
+        tasks.append(t); chunks.append(c)
+        at, cb, ob, c0 = at + p[0], cb + p[1], ob + p[2], c0 + len(c)
+    bcoff, bclen, bcrc = (np.concatenate([tb[1][k] for tb in tabs]) for k in range(3))
+    tasks, chunks = np.concatenate(tasks), np.concatenate(chunks)
+    for _ in range(3):
+        status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, pairs_per_task=8192)
+    ok = res["status"] == 0
+    phases = {"cursor (size word, block bookkeeping)": res["global_first"][ok], "window refill": res["target_first"][ok],
+              "head: fields, CIGAR, window test": res["win_vbeg"][ok].astype(np.int64), "name hash + table probe": res["win_vend"][ok].astype(np.int64),
+              "pair entry (clips, stores, count)": res["n_global"][ok].astype(np.int64) << 4, "finish (name checks, lists)": res["n_target"][ok].astype(np.int64) << 4}
+    total = sum(float(v.mean()) for v in phases.values())
+    print(json.dumps({"library": _lib.version(), "samples": m, "regions": int(ok.sum()), "records_per_region": float(res["n_window"][ok].mean()),
+                      "walk_kernel_ms": inf.walk_ms(), "mean_cycles_per_region": {k: round(float(v.mean())) for k, v in phases.items()},
+                      "total_cycles": round(total), "note": "s_memtime ticks (100 MHz on gfx950: 10 ns each)"}))
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,8 @@ EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_s
            "tredgpu_genotype_batch",
            "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing", "tredgpu_get_sw_counters",
            "tredgpu_inflater_create", "tredgpu_inflater_destroy", "tredgpu_inflater_last_error",
-           "tredgpu_inflater_reserve", "tredgpu_inflate_blocks", "tredgpu_inflate_blocks_crc", "tredgpu_inflater_timing")
+           "tredgpu_inflater_reserve", "tredgpu_inflate_blocks", "tredgpu_inflate_blocks_crc", "tredgpu_inflater_timing",
+           "tredgpu_inflate_walk", "tredgpu_inflater_fetch", "tredgpu_inflater_walk_ms")
 
 _lib = None
 
@@ -110,6 +111,9 @@ def load():
     lib.tredgpu_inflate_blocks.argtypes = [vp, i32, vp]
     lib.tredgpu_inflate_blocks_crc.argtypes = [vp, i32, vp, vp]
     lib.tredgpu_inflater_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.tredgpu_inflate_walk.argtypes = [vp, i32, vp, vp, C.POINTER(WalkArgs)]
+    lib.tredgpu_inflater_fetch.argtypes = [vp, i32, vp]
+    lib.tredgpu_inflater_walk_ms.argtypes = [vp, C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -305,6 +309,22 @@ def default_sw_params(clip=False, max_read_len=0):
     return SwParams(1, 5, 7, 2, 9, int(bool(clip)), int(max_read_len), 0)
 
 
+class WalkArgs(C.Structure):
+    """tredgpu_walk_args (include/tredgpu.h)."""
+    _fields_ = [("blk_coffset", C.c_void_p), ("blk_clen", C.c_void_p), ("blk_crc", C.c_void_p),
+                ("tasks", C.c_void_p), ("n_tasks", C.c_int32), ("chunks", C.c_void_p), ("n_chunks", C.c_int32),
+                ("results", C.c_void_p), ("global_pool", C.c_void_p), ("cap_global", C.c_int64),
+                ("target_pool", C.c_void_p), ("cap_target", C.c_int64), ("n_global", C.c_int64), ("n_target", C.c_int64)]
+
+
+# layouts of tredgpu_walk_task / _chunk / _result (the same as bamio.WALK_*_DTYPE: tredbam.h's structs)
+WALK_TASK_DTYPE = np.dtype([(k, "<i4") for k in ("tid", "start", "end", "tstart", "tend", "span", "chunk_first", "n_chunks",
+                                                 "block_first", "block_end", "win_lo", "win_hi")])
+WALK_CHUNK_DTYPE = np.dtype([("begin_block", "<i4"), ("begin_upos", "<i4"), ("end_voffset", "<u8")])
+WALK_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"), ("n_window", "<i4"),
+                              ("global_first", "<i8"), ("target_first", "<i8"), ("win_vbeg", "<u8"), ("win_vend", "<u8")])
+
+
 class Inflater:
     """Batch DEFLATE decoder on the GPU (include/tredgpu.h section 4): one HIP stream with pinned staging; one per host
     thread.  ``reserve`` hands out numpy views of the staging buffers -- compressed payloads and their offsets are
@@ -356,6 +376,37 @@ class Inflater:
         sums = np.zeros(max(n_blocks, 1), np.uint32)
         self._check(self._lib.tredgpu_inflate_blocks_crc(self._h, n_blocks, status.ctypes.data, sums.ctypes.data), "tredgpu_inflate_blocks_crc")
         return status[:n_blocks], sums[:n_blocks]
+
+    def run_walk(self, n_blocks, blk_coffset, blk_clen, blk_crc, tasks, chunks, pairs_per_task=2048):
+        """tredgpu_inflate_walk: decodes the blocks laid out in the reserved buffers and walks the pair-length regions
+        (tasks WALK_TASK_DTYPE, chunks WALK_CHUNK_DTYPE) over them on the device.  No block is copied back (fetch does
+        that).  Returns (status, crc, results WALK_RESULT_DTYPE, global pool, target pool)."""
+        status, sums = np.zeros(max(n_blocks, 1), np.int32), np.zeros(max(n_blocks, 1), np.uint32)
+        coff = np.ascontiguousarray(blk_coffset, np.int64)
+        clen = np.ascontiguousarray(blk_clen, np.int32)
+        xcrc = np.ascontiguousarray(blk_crc, np.uint32)
+        tasks = np.ascontiguousarray(tasks, WALK_TASK_DTYPE)
+        chunks = np.ascontiguousarray(chunks, WALK_CHUNK_DTYPE)
+        if not (len(coff) == len(clen) == len(xcrc) == n_blocks):
+            raise ValueError("one compressed offset / length / CRC per block")
+        res = np.zeros(max(len(tasks), 1), WALK_RESULT_DTYPE)
+        gp = np.zeros(len(tasks) * int(pairs_per_task) + 4096, np.int32)
+        tp = np.zeros(len(tasks) * max(int(pairs_per_task) // 8, 16) + 1024, np.int32)
+        a = WalkArgs(coff.ctypes.data, clen.ctypes.data, xcrc.ctypes.data, tasks.ctypes.data, len(tasks), chunks.ctypes.data,
+                     len(chunks), res.ctypes.data, gp.ctypes.data, len(gp), tp.ctypes.data, len(tp), 0, 0)
+        self._check(self._lib.tredgpu_inflate_walk(self._h, n_blocks, status.ctypes.data, sums.ctypes.data, C.byref(a)),
+                    "tredgpu_inflate_walk")
+        return status[:n_blocks], sums[:n_blocks], res[:len(tasks)], gp[:a.n_global], tp[:a.n_target]
+
+    def fetch(self, need):
+        """tredgpu_inflater_fetch: the blocks with need[k] != 0 of the last run_walk, to their places in ``out``."""
+        need = np.ascontiguousarray(need, np.uint8)
+        return self._check(self._lib.tredgpu_inflater_fetch(self._h, len(need), need.ctypes.data), "tredgpu_inflater_fetch")
+
+    def walk_ms(self):
+        a = C.c_double()
+        self._check(self._lib.tredgpu_inflater_walk_ms(self._h, C.byref(a)), "tredgpu_inflater_walk_ms")
+        return a.value
 
     def timing(self):
         """(total_ms, kernel_ms) of the last call on the device."""

@@ -371,6 +371,14 @@ def _native():
             lib.tredbam_preload_clear.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
             lib.tredbam_preload_clear.restype = None
             lib.tredbam_scan_pools.restype = C.c_int
+            lib.tredbam_plan_walks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(ScanOpts), C.c_void_p, C.c_void_p,
+                                               C.c_int64]
+            lib.tredbam_plan_walks.restype = C.c_int64
+            lib.tredbam_plan_blocks.argtypes = [C.c_void_p] * 5
+            lib.tredbam_plan_blocks.restype = C.c_int64
+            lib.tredbam_scan_pe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.tredbam_scan_pe.restype = C.c_int
             lib.tredbam_details_json.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_int64]
             lib.tredbam_details_json.restype = C.c_int64
             lib.tredbam_sparse_json.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
@@ -399,6 +407,12 @@ SCAN_UNIT_DTYPE = np.dtype([("status", "<i4"), ("n_reads", "<i4"), ("read_first"
                             ("depth_status", "<i4"), ("pe_status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"),
                             ("global_first", "<i8"), ("target_first", "<i8")])
 UNIT_NO_FETCH, UNIT_FAILED = 1, 2
+# the pair walks handed to the device (include/tredbam.h; the same layouts as tredgpu.h's tredgpu_walk_*)
+WALK_TASK_DTYPE = np.dtype([(k, "<i4") for k in ("tid", "start", "end", "tstart", "tend", "span", "chunk_first", "n_chunks",
+                                                 "block_first", "block_end", "win_lo", "win_hi")])
+WALK_CHUNK_DTYPE = np.dtype([("begin_block", "<i4"), ("begin_upos", "<i4"), ("end_voffset", "<u8")])
+WALK_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"), ("n_window", "<i4"),
+                              ("global_first", "<i8"), ("target_first", "<i8"), ("win_vbeg", "<u8"), ("win_vend", "<u8")])
 
 
 def sparse_json(a, b, values, depth):
@@ -544,6 +558,7 @@ class Pools(C.Structure):
 
 
 assert SITE_DTYPE.itemsize == 20 and REGION_DTYPE.itemsize == 12 and SCAN_UNIT_DTYPE.itemsize == 56
+assert WALK_TASK_DTYPE.itemsize == 48 and WALK_CHUNK_DTYPE.itemsize == 16 and WALK_RESULT_DTYPE.itemsize == 48
 
 
 def _copy(ptr, count, dtype):
@@ -700,16 +715,31 @@ class NativeAlignmentFile(object):
         return self._tid.get(chrom, -1)
 
     def scan(self, sites, alts, readlen, pad=1000, flank=9, pe_reach=10000, span=1000, use_alts=True,
-             want_depth=True, want_pe=True):
+             want_depth=True, want_pe=True, pe=None):
         """tredbam_scan: `sites` (SITE_DTYPE) and `alts` (REGION_DTYPE) -> (units SCAN_UNIT_DTYPE, dict of pool
-        arrays).  One native call; the GIL is released while it runs."""
+        arrays).  One native call; the GIL is released while it runs.  pe = (results WALK_RESULT_DTYPE per site, global
+        pool, target pool): pair lengths computed where the blocks were inflated (tredbam_scan_pe)."""
         sites = np.ascontiguousarray(sites, SITE_DTYPE)
         alts = np.ascontiguousarray(alts if len(alts) else np.zeros(1, REGION_DTYPE), REGION_DTYPE)
         units = np.zeros(len(sites), SCAN_UNIT_DTYPE)
         o = ScanOpts(int(readlen), int(pad), int(flank), int(pe_reach), int(span), int(bool(use_alts)),
                      int(bool(want_depth)), int(bool(want_pe)))
-        rc = self._lib.tredbam_scan(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o),
-                                    units.ctypes.data)
+        if pe is not None:
+            res = np.ascontiguousarray(pe[0], WALK_RESULT_DTYPE)
+            gp = np.ascontiguousarray(pe[1] if len(pe[1]) else np.zeros(1, np.int32), np.int32)
+            tp = np.ascontiguousarray(pe[2] if len(pe[2]) else np.zeros(1, np.int32), np.int32)
+            if len(res) != len(sites):
+                raise ValueError("one walk result per site")
+            ok = res["status"] == 0
+            if ok.any() and ((res["global_first"][ok] < 0).any() or (res["target_first"][ok] < 0).any()
+                             or (res["global_first"][ok] + res["n_global"][ok]).max() > len(pe[1])
+                             or (res["target_first"][ok] + res["n_target"][ok]).max() > len(pe[2])):
+                raise ValueError("walk results point outside their pools")
+            rc = self._lib.tredbam_scan_pe(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o),
+                                           res.ctypes.data, gp.ctypes.data, tp.ctypes.data, units.ctypes.data)
+        else:
+            rc = self._lib.tredbam_scan(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o),
+                                        units.ctypes.data)
         if rc != 0:
             raise ValueError(self._err())
         p = Pools()
@@ -741,6 +771,34 @@ class NativeAlignmentFile(object):
         if n < 0:
             raise ValueError(self._err())
         return int(n), cb.value, ob.value
+
+    def plan_walks(self, sites, readlen, pad=1000, flank=9, pe_reach=10000, span=1000):
+        """tredbam_plan_walks (after plan() with the same arguments): (tasks WALK_TASK_DTYPE per site, chunks
+        WALK_CHUNK_DTYPE) of the pair-length walks, for tredgpu's inflate_walk."""
+        sites = np.ascontiguousarray(sites, SITE_DTYPE)
+        o = ScanOpts(int(readlen), int(pad), int(flank), int(pe_reach), int(span), 0, 1, 1)
+        tasks = np.zeros(len(sites), WALK_TASK_DTYPE)
+        cap = 8 * len(sites) + 16
+        while True:
+            chunks = np.zeros(cap, WALK_CHUNK_DTYPE)
+            n = self._lib.tredbam_plan_walks(self._h, sites.ctypes.data, len(sites), C.byref(o), tasks.ctypes.data,
+                                             chunks.ctypes.data, cap)
+            if n == -3:
+                cap *= 4
+                continue
+            if n < 0:
+                raise ValueError(self._err())
+            return tasks, chunks[:n]
+
+    def plan_blocks(self):
+        """tredbam_plan_blocks: (compressed offset, compressed length, trailer CRC-32, read-by-the-scan-itself flag) of
+        the planned blocks, in the plan's (file) order."""
+        n = self._lib.tredbam_plan_blocks(self._h, None, None, None, None)
+        coff, clen = np.zeros(n, np.int64), np.zeros(n, np.int32)
+        crc, host = np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        if n:
+            self._lib.tredbam_plan_blocks(self._h, coff.ctypes.data, clen.ctypes.data, crc.ctypes.data, host.ctypes.data)
+        return coff, clen, crc, host
 
     def plan_fill(self, comp_addr, comp_base, out_base, comp_off, out_off):
         """Copies the planned payloads into the staging buffer at comp_addr (from byte comp_base on) and writes this

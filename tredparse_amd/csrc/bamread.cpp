@@ -92,7 +92,7 @@ struct tredbam {
     static constexpr size_t CACHE_BLOCKS = 512;   // <= 32 MiB per open file
     // blocks inflated elsewhere (tredbam_plan -> the GPU's batch decoder -> tredbam_preload): compressed offset -> the
     // caller's bytes; load_block takes them from here (CRC checked at first use), anything else is inflated as usual
-    struct Planned { int64_t coffset, payload_off; int32_t payload_len; int64_t clen; uint32_t crc, isize; };
+    struct Planned { int64_t coffset, payload_off; int32_t payload_len; int64_t clen; uint32_t crc, isize; bool host; };
     struct Preloaded { const uint8_t* data; uint32_t size; int64_t clen; uint32_t crc; bool checked; };
     std::vector<Planned> plan;
     std::unordered_map<int64_t, Preloaded> preloaded;
@@ -478,10 +478,9 @@ int region_chunks(tredbam* b, int32_t tid, int64_t& start, int64_t& end, std::ve
 // Region walk shared by fetch and the depth sum.  visit(end) is called for every record overlapping the region
 // after emit_record() has parsed it (and stored it when `store`).
 template <typename F>
-int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool store, F visit) {
-    std::vector<std::pair<uint64_t, uint64_t>> merged;
-    int rc = region_chunks(b, tid, start, end, merged);
-    if (rc) return rc;
+int64_t walk_chunks(tredbam* b, int32_t tid, int64_t start, int64_t end, const std::vector<std::pair<uint64_t, uint64_t>>& merged,
+                    bool store, F visit) {
+    int rc;
     int64_t n = 0;
     for (const auto& ch : merged) {
         if ((rc = bg_seek(b, ch.first)) < 0) return rc;
@@ -506,6 +505,32 @@ int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool st
         }
     }
     return n;
+}
+
+template <typename F>
+int64_t walk_region(tredbam* b, int32_t tid, int64_t start, int64_t end, bool store, F visit) {
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    const int rc = region_chunks(b, tid, start, end, merged);
+    if (rc) return rc;
+    return walk_chunks(b, tid, start, end, merged, store, visit);
+}
+
+// The records of [start, end) that lie between the virtual offsets vbeg and vend of the walk over the LARGER region
+// [outer_start, outer_end) on the same contig: a walker that went over the larger region before (the device's pair walk)
+// says where the first and behind the last record of the smaller one are, and this walk reads only the blocks in
+// between.  Every record of the small region is a record of the large one's chunks, in the same order.
+template <typename F>
+int64_t walk_region_between(tredbam* b, int32_t tid, int64_t outer_start, int64_t outer_end, int64_t start, int64_t end,
+                            uint64_t vbeg, uint64_t vend, F visit) {
+    std::vector<std::pair<uint64_t, uint64_t>> merged, cut;
+    const int rc = region_chunks(b, tid, outer_start, outer_end, merged);
+    if (rc) return rc;
+    start = std::max<int64_t>(0, start);
+    for (const auto& ch : merged) {
+        const uint64_t lo = std::max(ch.first, vbeg), hi = std::min(ch.second, vend);
+        if (lo < hi) cut.emplace_back(lo, hi);
+    }
+    return walk_chunks(b, tid, start, end, cut, false, visit);
 }
 
 
@@ -1035,8 +1060,14 @@ int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out) {
     return 0;
 }
 
-int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
-                 const tredbam_scan_opts* o, tredbam_unit* units) {
+}  // extern "C"
+
+namespace {
+// tredbam_scan / tredbam_scan_pe.  pe != nullptr: the pair lengths of site i are pe[i]'s slices of the two pools when
+// pe[i].status == 0, and the walk over that site covers its window's records only (pe[i].win_vbeg .. win_vend); every other
+// site is scanned as tredbam_scan scans it.
+int scan_impl(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts, const tredbam_scan_opts* o,
+              tredbam_unit* units, const tredbam_walk_result* pe, const int32_t* pe_global, const int32_t* pe_target) {
     if (!b || !o || n_sites < 0 || (n_sites > 0 && (!sites || !units))) return -2;
     b->out.clear();
     b->sc_packed.clear(); b->sc_read_len.clear(); b->sc_seq4.clear(); b->sc_names.clear(); b->sc_name_id.clear();
@@ -1065,11 +1096,14 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
         const bool with_pe = o->want_pe != 0;
         const int64_t p_lo = std::max<int64_t>((int64_t)st.repeat_start - o->pe_reach, 0);
         const int64_t p_hi = (int64_t)st.repeat_end + o->pe_reach;
-        const bool wide = with_pe && p_lo <= win_lo && p_hi >= win_hi;
+        // pair lengths from a walker that went over the +-pe_reach region where the blocks were inflated: it also says
+        // between which virtual offsets the window's records lie, and only those are walked here
+        const bool hinted = pe && with_pe && pe[i].status == 0 && pe[i].n_global >= 0 && pe[i].n_target >= 0 &&
+                            p_lo <= win_lo && p_hi >= win_hi;
+        const bool wide = with_pe && !hinted && p_lo <= win_lo && p_hi >= win_hi;
         PairTable pt;
         int64_t depth_total = 0;
-        const int64_t n = walk_region(b, st.tid, wide ? p_lo : win_lo, wide ? p_hi : win_hi, false,
-                                      [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
+        auto each = [&](int32_t rend, int32_t rpos, uint16_t flag, const uint8_t* r) {
             int64_t e = rend;
             if (rend < 0 || rend <= rpos) e = (int64_t)rpos + 1;
             if (rpos < win_hi && e > win_lo) {                           // the window's query would return it
@@ -1078,7 +1112,9 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
             }
             if (wide) pt.add(rend, rpos, flag, r);
             return true;
-        });
+        };
+        const int64_t n = hinted ? walk_region_between(b, st.tid, p_lo, p_hi, win_lo, win_hi, pe[i].win_vbeg, pe[i].win_vend, each)
+                                 : walk_region(b, st.tid, wide ? p_lo : win_lo, wide ? p_hi : win_hi, false, each);
         if (o->want_depth) {
             u.depth_status = n < 0 ? (int32_t)n : 0;
             u.depth_sum = n < 0 ? 0 : depth_total;
@@ -1103,8 +1139,15 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
             int rc;
             if (wide) rc = n < 0 ? (int)n : pt.finish(b, (int64_t)st.repeat_start - o->flank, (int64_t)st.repeat_end + o->flank,
                                                        o->span, b->sc_global, b->sc_target);
-            else rc = pair_lengths(b, st.tid, p_lo, p_hi, (int64_t)st.repeat_start - o->flank,
-                                   (int64_t)st.repeat_end + o->flank, o->span, b->sc_global, b->sc_target);
+            else if (hinted) {
+                rc = n < 0 ? (int)n : 0;                                    // computed elsewhere, in the same order
+                if (rc == 0) {
+                    b->sc_global.insert(b->sc_global.end(), pe_global + pe[i].global_first, pe_global + pe[i].global_first + pe[i].n_global);
+                    b->sc_target.insert(b->sc_target.end(), pe_target + pe[i].target_first, pe_target + pe[i].target_first + pe[i].n_target);
+                }
+            } else
+                rc = pair_lengths(b, st.tid, p_lo, p_hi, (int64_t)st.repeat_start - o->flank,
+                                  (int64_t)st.repeat_end + o->flank, o->span, b->sc_global, b->sc_target);
             if (rc < 0) { b->sc_global.resize(g0); b->sc_target.resize(t0); }
             u.pe_status = (rc == -2 || rc == -4) ? 0 : rc;     // unknown contig / no index: empty lists, as for the reads
             u.n_global = (int32_t)(b->sc_global.size() - g0);
@@ -1112,6 +1155,81 @@ int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const t
         }
     }
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
+                 const tredbam_scan_opts* o, tredbam_unit* units) {
+    return scan_impl(b, sites, n_sites, alts, o, units, nullptr, nullptr, nullptr);
+}
+
+int tredbam_scan_pe(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
+                    const tredbam_scan_opts* o, const tredbam_walk_result* pe, const int32_t* pe_global,
+                    const int32_t* pe_target, tredbam_unit* units) {
+    if (!pe || !pe_global || !pe_target) return -2;
+    return scan_impl(b, sites, n_sites, alts, o, units, pe, pe_global, pe_target);
+}
+
+// The pair walks of tredbam_scan(sites, o) as tasks for a walker that holds the planned blocks inflated (the device:
+// tredgpu_inflate_walk): per site the +-pe_reach region, its merged index chunks as (planned block, offset in it) ->
+// end virtual offset.  Call after tredbam_plan with the same arguments.
+int64_t tredbam_plan_walks(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_scan_opts* o,
+                           tredbam_walk_task* tasks, tredbam_walk_chunk* chunks, int64_t cap_chunks) {
+    if (!b || !o || n_sites < 0 || (n_sites > 0 && (!sites || !tasks)) || cap_chunks < 0 || (cap_chunks > 0 && !chunks)) return -2;
+    std::unordered_map<int64_t, int32_t> index_of;
+    index_of.reserve(b->plan.size() * 2);
+    for (size_t k = 0; k < b->plan.size(); ++k) index_of[b->plan[k].coffset] = (int32_t)k;
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    int64_t nc = 0;
+    for (int32_t i = 0; i < n_sites; ++i) {
+        const tredbam_site& st = sites[i];
+        tredbam_walk_task& t = tasks[i];
+        memset(&t, 0, sizeof t);
+        t.tid = st.tid;
+        t.chunk_first = (int32_t)nc;
+        t.n_chunks = -1;                                   // until proven walkable: the scan computes this site itself
+        t.block_first = 0;
+        t.block_end = (int32_t)b->plan.size();
+        int64_t start = std::max<int64_t>((int64_t)st.repeat_start - o->pe_reach, 0), end = (int64_t)st.repeat_end + o->pe_reach;
+        if (st.tid < 0 || region_chunks(b, st.tid, start, end, merged) != 0) continue;
+        if (end > INT32_MAX || (int64_t)merged.size() > cap_chunks - nc) {
+            if ((int64_t)merged.size() > cap_chunks - nc) return -3;
+            continue;
+        }
+        t.start = (int32_t)start;
+        t.end = (int32_t)end;
+        t.tstart = st.repeat_start - o->flank;
+        t.tend = st.repeat_end + o->flank;
+        t.span = o->span;
+        t.win_lo = (int32_t)std::max<int64_t>(0, (int64_t)st.repeat_start - o->pad);
+        t.win_hi = st.repeat_end + o->pad;
+        for (const auto& ch : merged) {
+            tredbam_walk_chunk& c = chunks[nc++];
+            const auto at = index_of.find((int64_t)(ch.first >> 16));
+            c.begin_block = at == index_of.end() ? -1 : at->second;
+            c.begin_upos = (int32_t)(ch.first & 0xFFFF);
+            c.end_voffset = ch.second;
+        }
+        t.n_chunks = (int32_t)merged.size();
+    }
+    return nc;
+}
+
+// Per planned block, in the plan's (file) order: where it starts in the file, how long it is there, the CRC-32 its
+// trailer promises, and whether the scan reads it in any case (alternative loci, extra regions) when the pair lengths
+// and the windows' offsets come from elsewhere (tredbam_scan_pe).
+int64_t tredbam_plan_blocks(tredbam* b, int64_t* coffset, int32_t* clen, uint32_t* crc, uint8_t* host) {
+    if (!b) return -2;
+    for (size_t k = 0; k < b->plan.size(); ++k) {
+        const tredbam::Planned& p = b->plan[k];
+        if (coffset) coffset[k] = p.coffset;
+        if (clen) clen[k] = (int32_t)p.clen;
+        if (crc) crc[k] = p.crc;
+        if (host) host[k] = p.host ? 1 : 0;
+    }
+    return (int64_t)b->plan.size();
 }
 
 // ---- blocks inflated elsewhere (include/tredbam.h) ----------------------------------------------------------------
@@ -1124,9 +1242,12 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
                      int64_t* out_bytes) {
     if (!b || !o || n_sites < 0 || (n_sites > 0 && !sites) || n_extra < 0 || (n_extra > 0 && !extra)) return -2;
     b->plan.clear();
-    std::unordered_map<int64_t, bool> seen;
+    // `host`: a block the scan reads in any case when the pair lengths and the windows' offsets come from elsewhere
+    // (tredbam_scan_pe): those of the alternative loci and of the caller's extra regions.  Which blocks of a +-pe_reach
+    // region hold its window's records is known only once the region has been walked (tredbam_walk_result)
+    std::unordered_map<int64_t, size_t> seen;
     std::vector<std::pair<uint64_t, uint64_t>> merged;
-    auto add_region = [&](int32_t tid, int64_t start, int64_t end) -> int {
+    auto add_region = [&](int32_t tid, int64_t start, int64_t end, bool host) -> int {
         if (region_chunks(b, tid, start, end, merged) != 0) return 0;     // (the scan reports what is wrong with it)
         uint64_t cap = ~0ull;
         if (tid < (int32_t)b->index.size()) {
@@ -1138,13 +1259,20 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
         for (const auto& ch : merged) {
             const int64_t last = (int64_t)(std::min(ch.second, cap) >> 16);
             for (int64_t at = (int64_t)(ch.first >> 16); at <= last;) {
+                const auto known = seen.find(at);
+                if (known != seen.end()) {                                 // framed before: only the flag can change
+                    tredbam::Planned& q = b->plan[known->second];
+                    q.host = q.host || host;
+                    at += q.clen;
+                    continue;
+                }
                 BlockFrame fr = {};
                 const uint8_t* comp = nullptr;
                 const int rc = block_frame(b, at, fr, &comp);
                 if (rc <= 0) break;                                        // end of file / damaged frame: left to the scan
-                if (fr.isize > 0 && !seen.count(at)) {
-                    seen[at] = true;
-                    b->plan.push_back({at, fr.payload_off, (int32_t)(fr.dlen - 8), fr.clen, fr.crc, fr.isize});
+                if (fr.isize > 0) {
+                    seen[at] = b->plan.size();
+                    b->plan.push_back({at, fr.payload_off, (int32_t)(fr.dlen - 8), fr.clen, fr.crc, fr.isize, host});
                 }
                 at += fr.clen;
             }
@@ -1156,16 +1284,19 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
         const int64_t win_lo = std::max<int64_t>(0, (int64_t)st.repeat_start - o->pad), win_hi = (int64_t)st.repeat_end + o->pad;
         const int64_t p_lo = std::max<int64_t>((int64_t)st.repeat_start - o->pe_reach, 0), p_hi = (int64_t)st.repeat_end + o->pe_reach;
         if (st.tid < 0) continue;
-        add_region(st.tid, win_lo, win_hi);
-        if (o->want_pe) add_region(st.tid, p_lo, p_hi);
+        add_region(st.tid, win_lo, win_hi, false);
+        if (o->want_pe) add_region(st.tid, p_lo, p_hi, false);
         if (o->use_alts && alts)
             for (int32_t k = 0; k < st.n_alt; ++k) {
                 const tredbam_region& a = alts[st.alt_first + k];
-                if (a.tid >= 0) add_region(a.tid, a.start, a.end);
+                if (a.tid >= 0) add_region(a.tid, a.start, a.end, true);
             }
     }
     for (int32_t k = 0; k < n_extra; ++k)          // other queries of the caller on this handle (the chrY depth windows)
-        if (extra[k].tid >= 0) add_region(extra[k].tid, extra[k].start, extra[k].end);
+        if (extra[k].tid >= 0) add_region(extra[k].tid, extra[k].start, extra[k].end, true);
+    // in file order: blocks that follow each other in the file then follow each other in the decoder's output, and a
+    // record that straddles two of them lies there in one piece (the device's pair walk reads it in place)
+    std::sort(b->plan.begin(), b->plan.end(), [](const tredbam::Planned& x, const tredbam::Planned& y) { return x.coffset < y.coffset; });
     int64_t cb = 0, ob = 0;
     for (const auto& p : b->plan) { cb += ((int64_t)p.payload_len + 3) & ~(int64_t)3; ob += p.isize; }
     if (comp_bytes) *comp_bytes = cb;

@@ -31,6 +31,7 @@
 // Nothing here knows BAM: the C ABI (include/tredgpu.h, tredgpu_inflate_*) takes payload offsets and sizes and
 // returns bytes plus a status per block; gzip framing and ISIZE stay with the host library (libtredbam).
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdint.h>
 #include <unistd.h>
 
@@ -673,6 +674,384 @@ __global__ __launch_bounds__(LANES, 7) void inflate_kernel(const uint32_t* __res
     if (lane == 0) status[g] = rc;
 }
 
+// ---- the pair walk: PEextractor over the blocks this decoder just wrote ---------------------------------------------------
+// tredparse/bam_parser.py:316-369 (PEextractor) as the host's file layer restates it (bamread.cpp: walk_region, PairTable):
+// the records of a +-10 kb region in file order; paired, mapped, non-duplicate reads grouped by query name in order of first
+// appearance; of every name seen twice the first two records must map +/-; tlen from the soft-clipped ends; a pair that
+// spans the tract goes to the target list, any other to the global one.
+//
+// One region = one wavefront.  Where the next record starts is written in this one, so the walk is a chain -- but a chain
+// through LDS, not through HBM: the wavefront copies 4 KB of the block stream at a time into LDS (one coalesced load for
+// ~11 records; a lane walking the records in global memory paid a miss of 1-2 us for each, and several per record: 24 ms
+// for a region of 4 000 records) and every lane then runs the same walk over it -- all values are uniform, the LDS reads
+// are broadcasts, the branches do not diverge.  The name table lives in LDS as well (16 384 slots of tag << 13 | pair
+// index, the pair's record count in a byte array beside it), so finding a record's mate costs no memory access either;
+// what a tag match does NOT prove -- that the two names are equal byte for byte -- is checked for all pairs at the end by
+// the 64 lanes in parallel, and a single mismatch there gives the region back to the host, as does anything else out of
+// the ordinary: a block the plan does not hold or the decoder rejected or whose CRC-32 is not its trailer's, a record that
+// makes no sense, more names than the table holds.  The host then walks that region itself, as it does without this
+// kernel, and reports what is wrong with the file.
+struct WalkView {
+    const uint8_t* out; const int64_t* ooff;          // the decoder's output and its block offsets
+    const int32_t* bstatus; const uint32_t* bcrc;     // what the decoder said about each block
+    const uint32_t* xcrc; const int64_t* bcoff; const int32_t* bclen;   // from the file: trailer CRC, compressed offset / length
+    int64_t out_end;                                  // bytes of `out` that may be read
+};
+struct WalkPair { int64_t name_at, name2_at; int32_t a_pos, a_lead, b_end, b_trail; uint16_t name_len; uint8_t a_rev, b_rev, pad[4]; };
+static_assert(sizeof(WalkPair) == 40, "WalkPair layout");
+struct WalkRepeat { int32_t pair; int32_t pad; int64_t name_at; };   // a third, fourth ... record under a pair's tag
+constexpr int WALK_PAIR_CAP = 8192;               // names per region (a +-10 kb window at 30x holds ~2 100)
+constexpr int WALK_SLOTS = 2 * WALK_PAIR_CAP;     // open addressing at a load below one half
+constexpr int WALK_REPEAT_CAP = 2048;
+constexpr int WALK_WINDOW = 4096;                 // bytes of the block stream in LDS
+constexpr int WALK_HEAD = 512;                    // a record's head (fixed fields, name, CIGAR) should lie in the window
+enum { WALK_OK = 0, WALK_NOT_PLANNED = 1, WALK_BAD_BLOCK = 2, WALK_BAD_RECORD = 3, WALK_TABLE_FULL = 4, WALK_NO_END = 5, WALK_POOL_FULL = 6,
+       WALK_TAG_CLASH = 7 };
+
+// The workgroup is one wavefront, and a wavefront's LDS instructions are carried out in the order they were issued: what
+// lane 0 writes is there when the next instruction of any lane reads it.  No s_barrier is needed -- and __syncthreads()
+// must not be used in the record loop: it also waits for every global store before it (vmcnt(0)), 1-2 us after each of the
+// pair entries lane 0 writes (measured: 2.5 us per record with it).  This only keeps the compiler from moving LDS
+// accesses across the point.
+__device__ inline void walk_lds_order() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+struct WalkLds {
+    uint32_t table[WALK_SLOTS];                   // 0: free; else tag << 13 | pair index, tag != 0
+    uint8_t seen[WALK_PAIR_CAP];                  // records under the pair's tag so far (saturates)
+    alignas(16) uint8_t window[WALK_WINDOW];
+};
+
+// Every lane holds the same value: say so (v_readfirstlane), and what is computed from it is computed once, on the
+// scalar unit, with scalar branches -- not 64 times on the vector unit with the exec mask rebuilt at every `if`.
+__device__ inline uint32_t walk_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ inline int64_t walk_uniform64(int64_t x) { return (int64_t)((uint64_t)walk_uniform((uint32_t)((uint64_t)x >> 32)) << 32 | walk_uniform((uint32_t)x)); }
+
+// the block stream through the LDS window; every lane calls these with the same arguments
+struct WalkReader {
+    const uint8_t* out; int64_t out_end; WalkLds* S; int64_t base; int lane;
+    __device__ void fill(int64_t at) {
+        base = at & ~(int64_t)15;
+        walk_lds_order();                                        // (earlier reads of the window are done)
+        for (int q = 0; q < WALK_WINDOW / (LANES * 16); ++q) {
+            const int o = (q * LANES + lane) * 16;
+            if (base + o + 16 <= out_end) *(uint4*)(S->window + o) = *(const uint4*)(out + base + o);
+        }
+        walk_lds_order();
+    }
+    __device__ bool inside(int64_t at, int n) const { return at >= base && at + n <= base + WALK_WINDOW; }
+    __device__ uint32_t u8(int64_t at) const { return walk_uniform(inside(at, 1) ? S->window[at - base] : out[at]); }
+    __device__ uint32_t u16(int64_t at) const { return u8(at) | (u8(at + 1) << 8); }
+    __device__ uint32_t u32(int64_t at) const {
+        if (inside(at, 4)) { const uint8_t* p = S->window + (at - base); return walk_uniform((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+        uint32_t v; __builtin_memcpy(&v, out + at, 4); return walk_uniform(v);
+    }
+};
+
+// A record's first 252 bytes (its length word, the fixed fields, the name and -- nearly always -- the CIGAR), one dword per
+// lane: one LDS read for the whole head, and every field is then a v_readlane or two (byte reads through the window cost
+// an LDS round trip each, ~50 of them per record: 2 us).  Every lane asks for the same field and gets the same value.
+struct WalkHead {
+    uint32_t w; int shift; int64_t a0; bool fast; const WalkReader* rd;
+    __device__ void load(const WalkReader& r, int64_t at) {      // the window holds [at, at + WALK_HEAD)
+        rd = &r; a0 = at; shift = (int)(at & 3);
+        w = *(const uint32_t*)(r.S->window + ((at & ~(int64_t)3) - r.base) + 4 * r.lane);
+        fast = true;
+    }
+    __device__ void need(int bytes) { fast = shift + bytes + 4 <= 4 * LANES; }   // else: through the window, byte by byte
+    __device__ uint32_t u32(int off) const {
+        if (!fast) return rd->u32(a0 + off);
+        const int o = shift + off;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)w, o >> 2), hi = (uint32_t)__builtin_amdgcn_readlane((int)w, (o >> 2) + 1);
+        return (uint32_t)(((uint64_t)hi << 32 | lo) >> (8 * (o & 3)));     // (scalar: both halves are in SGPRs)
+    }
+    __device__ uint32_t u16(int off) const { return u32(off) & 0xFFFFu; }
+    __device__ uint32_t u8(int off) const {
+        if (!fast) return rd->u8(a0 + off);
+        const int o = shift + off;
+        return ((uint32_t)__builtin_amdgcn_readlane((int)w, o >> 2) >> (8 * (o & 3))) & 0xFFu;
+    }
+};
+
+__device__ inline bool walk_block_ok(const WalkView& v, int k) { return v.bstatus[k] == 0 && v.bcrc[k] == v.xcrc[k]; }
+
+// Where the walk stands in the file: block k (its size, compressed offset and length held in registers: the tables are
+// read once per block, not once per record -- a load in the record loop would also wait for the stores before it) and
+// the offset in it.
+struct WalkCursor {
+    int k; int64_t upos, size, first, coff, clen;
+    __device__ int enter(const WalkView& v, int block) {
+        k = block;
+        if (!walk_block_ok(v, k)) return WALK_BAD_BLOCK;
+        first = walk_uniform64(v.ooff[k]);
+        size = walk_uniform64(v.ooff[k + 1]) - first;
+        coff = walk_uniform64(v.bcoff[k]);
+        clen = (int64_t)walk_uniform((uint32_t)v.bclen[k]);
+        return WALK_OK;
+    }
+    __device__ uint64_t tell() const {                                     // bamread.cpp bg_tell
+        return upos >= size ? (uint64_t)(coff + clen) << 16 : ((uint64_t)coff << 16) | (uint64_t)upos;
+    }
+    // the next n bytes of the file: blocks that follow each other in the file follow each other in `out`, so the bytes lie
+    // in one piece at *addr; the position moves as bamread.cpp's bg_read moves it
+    __device__ int take(const WalkView& v, const tredgpu_walk_task& T, int64_t n, int64_t* addr) {
+        *addr = -1;
+        while (n > 0) {
+            if (upos >= size) {
+                if (k + 1 >= T.block_end || coff + clen != v.bcoff[k + 1]) return WALK_NOT_PLANNED;   // (or the end of the file)
+                const int rc = enter(v, k + 1);
+                if (rc) return rc;
+                upos = 0;
+            }
+            if (*addr < 0) *addr = first + upos;
+            const int64_t piece = n < size - upos ? n : size - upos;
+            upos += piece;
+            n -= piece;
+        }
+        return WALK_OK;
+    }
+};
+
+// -DWALK_PROF: cycles per phase of the record loop instead of the result's offsets (tools/walk_prof.py)
+struct WalkProf {
+#ifdef WALK_PROF
+    uint64_t t, acc[6] = {};
+    __device__ void start() { t = __builtin_readcyclecounter(); }
+    __device__ void mark(int k) { const uint64_t n = __builtin_readcyclecounter(); acc[k] += n - t; t = n; }
+#else
+    __device__ void start() {}
+    __device__ void mark(int) {}
+#endif
+};
+
+// Every lane runs this with the same values (the region's walk); only lane 0 writes to global memory.
+__device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk* chunks, WalkLds& S, WalkReader& rd,
+                                   WalkPair* pairs, WalkRepeat* repeats, int* n_pairs, int* n_repeats, tredgpu_walk_result& R, int lane,
+                                   WalkProf& prof) {
+    if (T.n_chunks < 0) return WALK_NOT_PLANNED;
+    prof.start();
+    int np = 0, nrep = 0, nwin = 0;
+    uint64_t vbeg = 0, vend = 0;
+    for (int c = 0; c < T.n_chunks; ++c) {
+        const tredgpu_walk_chunk ch = chunks[T.chunk_first + c];
+        if (ch.begin_block < T.block_first || ch.begin_block >= T.block_end) return WALK_NOT_PLANNED;
+        WalkCursor cur;
+        int rc = cur.enter(v, ch.begin_block);
+        if (rc) return rc;
+        cur.upos = ch.begin_upos;
+        for (;;) {
+            const uint64_t at = cur.tell();
+            if (at >= ch.end_voffset) break;
+            int64_t a0, r;
+            if ((rc = cur.take(v, T, 4, &a0)) != 0) return rc;
+            prof.mark(0);
+            if (!rd.inside(a0, WALK_HEAD)) rd.fill(a0);
+            prof.mark(1);
+            WalkHead hd;
+            hd.load(rd, a0);                                               // offsets from a0: the record itself starts at 4
+            const int32_t size = (int32_t)hd.u32(0);
+            if (size < 32) return WALK_BAD_RECORD;
+            if ((rc = cur.take(v, T, size, &r)) != 0) return rc;
+            const int32_t rtid = (int32_t)hd.u32(4), rpos = (int32_t)hd.u32(8);
+            if (rtid != T.tid || rpos >= T.end) {
+                if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) break;
+                continue;
+            }
+            const uint32_t l_name = hd.u8(12), n_cigar = hd.u16(16), flag = hd.u16(18);
+            const int32_t l_seq = (int32_t)hd.u32(20);
+            if (l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)size) return WALK_BAD_RECORD;
+            hd.need(36 + (int)l_name + 4 * (int)n_cigar);
+            const int cig = 36 + (int)l_name;
+            int32_t rend = -1;
+            if (!(flag & 0x4) && n_cigar > 0) {
+                int64_t e = rpos;
+                for (uint32_t q = 0; q < n_cigar; ++q) {
+                    const uint32_t op = hd.u32(cig + 4 * (int)q);
+                    if ((0x18Du >> (op & 15)) & 1) e += op >> 4;           // M D N = X consume the reference
+                }
+                rend = (int32_t)e;
+            }
+            const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
+            if (!(e > T.start)) continue;
+            if (rpos < T.win_hi && e > T.win_lo) {                         // a record of the scan's own window
+                if (nwin == 0) vbeg = at;
+                ++nwin;
+                vend = cur.tell();
+            }
+            prof.mark(2);
+            // PairTable::add
+            if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) continue;
+            const uint32_t nlen = l_name > 0 ? l_name - 1 : 0;
+            uint32_t h = 2166136261u ^ nlen;
+            for (uint32_t q = 0; q < nlen; q += 4) {                       // four name bytes per step (any hash will do: the names
+                uint32_t word = hd.u32(36 + (int)q);                       // are compared byte for byte at the end)
+                if (nlen - q < 4) word &= (1u << (8 * (nlen - q))) - 1;
+                h = (h ^ word) * 0x9E3779B1u;
+                h ^= h >> 15;
+            }
+            h *= 0x2C1B3C6Du;
+            h ^= h >> 12;
+            uint32_t tag = h >> 13;
+            if (tag == 0) tag = 1;
+            uint32_t slot = h & (WALK_SLOTS - 1);
+            int idx = -1;
+            for (;; slot = (slot + 1) & (WALK_SLOTS - 1)) {
+                const uint32_t entry = walk_uniform(S.table[slot]);
+                if (entry == 0) break;
+                if ((entry >> 13) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); break; }
+            }
+            if (idx < 0) {
+                if (np >= WALK_PAIR_CAP) return WALK_TABLE_FULL;
+                idx = np++;
+                walk_lds_order();
+                if (lane == 0) { S.table[slot] = (tag << 13) | (uint32_t)idx; S.seen[idx] = 0; }
+                walk_lds_order();
+            }
+            const int seen = (int)walk_uniform(S.seen[idx]);
+            prof.mark(3);
+            if (seen < 2) {
+                int32_t clip = 0;
+                if (seen == 0) {
+                    for (uint32_t q = 0; q < n_cigar; ++q) {               // query_alignment_start: leading soft clips
+                        const uint32_t op = hd.u32(cig + 4 * (int)q);
+                        if ((op & 15) == 4) clip += (int32_t)(op >> 4);
+                        else if ((op & 15) == 5) continue;
+                        else break;
+                    }
+                } else {
+                    for (int q = (int)n_cigar - 1; q >= 0; --q) {          // query_length - query_alignment_end
+                        const uint32_t op = hd.u32(cig + 4 * q);
+                        if ((op & 15) == 4) clip += (int32_t)(op >> 4);
+                        else if ((op & 15) == 5) continue;
+                        else break;
+                    }
+                }
+                if (lane == 0) {
+                    WalkPair& P = pairs[idx];
+                    if (seen == 0) {
+                        P.name_at = r + 32; P.name_len = (uint16_t)nlen;
+                        P.a_pos = rpos; P.a_lead = clip; P.a_rev = (flag & 0x10) ? 1 : 0;
+                    } else {
+                        P.name2_at = r + 32;
+                        P.b_end = rend; P.b_trail = clip; P.b_rev = (flag & 0x10) ? 1 : 0;
+                    }
+                }
+            } else {                                                        // the pair is complete: only the name matters
+                if (nrep >= WALK_REPEAT_CAP) return WALK_TABLE_FULL;
+                if (lane == 0) { repeats[nrep].pair = idx; repeats[nrep].name_at = r + 32; }
+                ++nrep;
+            }
+            walk_lds_order();
+            if (lane == 0 && seen < 3) S.seen[idx] = (uint8_t)(seen + 1);
+            walk_lds_order();
+            prof.mark(4);
+        }
+    }
+    *n_pairs = np; *n_repeats = nrep;
+    R.n_window = nwin; R.win_vbeg = vbeg; R.win_vend = vend;
+    return WALK_OK;
+}
+
+__device__ inline bool walk_same_name(const uint8_t* out, int64_t a, int64_t b, uint32_t len) {
+    uint64_t diff = 0;
+    uint32_t q = 0;
+    for (; q + 8 <= len; q += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, out + a + q, 8);
+        __builtin_memcpy(&y, out + b + q, 8);
+        diff |= x ^ y;
+    }
+    for (; q < len; ++q) diff |= (uint64_t)(out[a + q] ^ out[b + q]);
+    return diff == 0;
+}
+
+__global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
+                                                          tredgpu_walk_result* results, WalkPair* pairs_all, WalkRepeat* repeats_all, int32_t* gpool,
+                                                          int64_t cap_g, int32_t* tpool, int64_t cap_t, unsigned long long* counters) {
+    __shared__ WalkLds S;
+    __shared__ int64_t firsts[2];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    for (int k = lane; k < WALK_SLOTS; k += LANES) S.table[k] = 0;
+    WalkPair* pairs = pairs_all + (size_t)t * WALK_PAIR_CAP;
+    WalkRepeat* repeats = repeats_all + (size_t)t * WALK_REPEAT_CAP;
+    const tredgpu_walk_task T = tasks[t];
+    WalkReader rd = {v.out, v.out_end, &S, (int64_t)1 << 60, lane};
+    tredgpu_walk_result R = {};
+    int np = 0, nrep = 0;
+    __syncthreads();
+    WalkProf prof;
+    int status = walk_region_records(v, T, chunks, S, rd, pairs, repeats, &np, &nrep, R, lane, prof);
+    __syncthreads();                                       // lane 0's pair entries are visible to the wavefront
+    // ---- PairTable::finish, 64 pairs at a time: are the names under one tag equal? which list does the pair go to? ----
+    int ng = 0, nt = 0;
+    if (status == WALK_OK) {
+        bool clash = false, no_end = false;
+        for (int q0 = 0; q0 < nrep; q0 += LANES) {
+            const int q = q0 + lane;
+            if (q < nrep) {
+                const WalkPair& P = pairs[repeats[q].pair];
+                clash |= !walk_same_name(v.out, P.name_at, repeats[q].name_at, P.name_len);
+            }
+        }
+        for (int q0 = 0; q0 < np; q0 += LANES) {
+            const int q = q0 + lane;
+            int cls = 0;                                   // 1 global, 2 target
+            if (q < np && S.seen[q] >= 2) {
+                const WalkPair P = pairs[q];
+                clash |= !walk_same_name(v.out, P.name_at, P.name2_at, P.name_len);
+                if (!P.a_rev && P.b_rev) {                 // mapped in +, - orientation
+                    if (P.b_end < 0) no_end = true;        // (the reference dies here: the host reports it)
+                    const int64_t tlen = ((int64_t)P.b_end + P.b_trail) - ((int64_t)P.a_pos - P.a_lead);
+                    if (tlen < T.span) cls = (P.a_pos < T.tstart && P.b_end > T.tend) ? 2 : 1;
+                }
+            }
+            ng += __popcll(__ballot(cls == 1));
+            nt += __popcll(__ballot(cls == 2));
+        }
+        if (__ballot(clash) != 0) status = WALK_TAG_CLASH;
+        else if (__ballot(no_end) != 0) status = WALK_NO_END;
+    }
+    if (status == WALK_OK) {
+        if (lane == 0) {
+            firsts[0] = (int64_t)atomicAdd(&counters[0], (unsigned long long)ng);
+            firsts[1] = (int64_t)atomicAdd(&counters[1], (unsigned long long)nt);
+        }
+        __syncthreads();
+        const int64_t gf = firsts[0], tf = firsts[1];
+        if (gf + ng > cap_g || tf + nt > cap_t) status = WALK_POOL_FULL;
+        else {
+            int go = 0, to = 0;
+            for (int q0 = 0; q0 < np; q0 += LANES) {
+                const int q = q0 + lane;
+                int cls = 0;
+                int32_t len32 = 0;
+                if (q < np && S.seen[q] >= 2) {
+                    const WalkPair P = pairs[q];
+                    if (!P.a_rev && P.b_rev) {
+                        const int64_t tlen = ((int64_t)P.b_end + P.b_trail) - ((int64_t)P.a_pos - P.a_lead);
+                        if (tlen < T.span) { cls = (P.a_pos < T.tstart && P.b_end > T.tend) ? 2 : 1; len32 = (int32_t)tlen; }
+                    }
+                }
+                const uint64_t mg = __ballot(cls == 1), mt = __ballot(cls == 2), below = ((uint64_t)1 << lane) - 1;
+                if (cls == 1) gpool[gf + go + __popcll(mg & below)] = len32;
+                if (cls == 2) tpool[tf + to + __popcll(mt & below)] = len32;
+                go += __popcll(mg);
+                to += __popcll(mt);
+            }
+            R.n_global = ng; R.n_target = nt; R.global_first = gf; R.target_first = tf;
+        }
+    }
+    prof.mark(5);
+#ifdef WALK_PROF
+    R.global_first = (int64_t)prof.acc[0]; R.target_first = (int64_t)prof.acc[1]; R.win_vbeg = prof.acc[2]; R.win_vend = prof.acc[3];
+    R.n_global = (int32_t)(prof.acc[4] >> 4); R.n_target = (int32_t)(prof.acc[5] >> 4);
+#endif
+    if (lane == 0) {
+        R.status = status;
+        if (status != WALK_OK) { R.n_global = R.n_target = R.n_window = 0; R.global_first = R.target_first = 0; R.win_vbeg = R.win_vend = 0; }
+        results[t] = R;
+    }
+}
+
 }  // namespace
 
 // ---- C ABI (include/tredgpu.h) ------------------------------------------------------------------------------------
@@ -694,6 +1073,17 @@ struct tredgpu_inflater {
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     int64_t* d_off = nullptr;
     int32_t* d_status = nullptr;
+    // the pair walk (tredgpu_inflate_walk): a stream of its own, the file's view of the blocks, tasks, per-task tables, pools
+    hipStream_t wstream = nullptr;
+    hipEvent_t wdone = nullptr, w0 = nullptr, w1 = nullptr, decoded[2] = {nullptr, nullptr};
+    bool walk_timed = false;
+    uint8_t* d_wblk = nullptr;  size_t cap_wblk = 0;        // bcoff[n] int64, then bclen[n] int32, then xcrc[n] uint32
+    uint8_t* h_wblk = nullptr;                               // pinned, same layout
+    uint8_t* d_wtask = nullptr; uint8_t* h_wtask = nullptr; size_t cap_wtask = 0;   // tasks then chunks
+    uint8_t* d_wres = nullptr;  uint8_t* h_wres = nullptr;  size_t cap_wres = 0;    // results then the two counters
+    WalkRepeat* d_wrepeats = nullptr; WalkPair* d_wpairs = nullptr; size_t cap_wscratch = 0;   // in tasks
+    int32_t *d_gpool = nullptr, *d_tpool = nullptr, *h_gpool = nullptr, *h_tpool = nullptr;
+    size_t cap_gpool = 0, cap_tpool = 0;
     std::string err;
 };
 
@@ -725,10 +1115,35 @@ void release(tredgpu_inflater* f) {
     f->cap_comp = f->cap_out = f->cap_blocks = 0;
 }
 
+void release_walk(tredgpu_inflater* f) {
+    for (void* p : {(void*)f->h_wblk, (void*)f->h_wtask, (void*)f->h_wres, (void*)f->h_gpool, (void*)f->h_tpool})
+        if (p) (void)hipHostFree(p);
+    for (void* p : {(void*)f->d_wblk, (void*)f->d_wtask, (void*)f->d_wres, (void*)f->d_wrepeats, (void*)f->d_wpairs, (void*)f->d_gpool, (void*)f->d_tpool})
+        if (p) (void)hipFree(p);
+    f->h_wblk = f->h_wtask = f->h_wres = nullptr; f->h_gpool = f->h_tpool = nullptr;
+    f->d_wblk = f->d_wtask = f->d_wres = nullptr; f->d_wrepeats = nullptr; f->d_wpairs = nullptr; f->d_gpool = f->d_tpool = nullptr;
+    f->cap_wblk = f->cap_wtask = f->cap_wres = f->cap_wscratch = f->cap_gpool = f->cap_tpool = 0;
+}
+
+// grow-only pairs of pinned host / device buffers for the walk's small arrays
+int grow_pair(tredgpu_inflater* f, uint8_t** host, uint8_t** dev, size_t* cap, size_t need) {
+    if (need <= *cap) return 0;
+    const size_t c = std::max(need, *cap + *cap / 2);
+    if (*host) (void)hipHostFree(*host);
+    if (*dev) (void)hipFree(*dev);
+    *host = nullptr; *dev = nullptr; *cap = 0;
+    ICHK(f, hipHostMalloc((void**)host, c, hipHostMallocDefault));
+    ICHK(f, hipMalloc((void**)dev, c));
+    *cap = c;
+    return 0;
+}
+
 void destroy_handles(tredgpu_inflater* f) {
     for (hipEvent_t e : {f->done[0], f->done[1], f->t0[0], f->t0[1], f->t1[0], f->t1[1]}) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < MAX_SLICES; ++k) { if (f->k0[k]) (void)hipEventDestroy(f->k0[k]); if (f->k1[k]) (void)hipEventDestroy(f->k1[k]); }
+    for (hipEvent_t e : {f->wdone, f->w0, f->w1, f->decoded[0], f->decoded[1]}) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : f->stream) if (st) (void)hipStreamDestroy(st);
+    if (f->wstream) (void)hipStreamDestroy(f->wstream);
 }
 }  // namespace
 
@@ -758,6 +1173,11 @@ int tredgpu_inflater_create(int device_id, tredgpu_inflater** out) {
         e = hipEventCreate(&f->k0[k]);
         if (e == hipSuccess) e = hipEventCreate(&f->k1[k]);
     }
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&f->wstream, hipStreamNonBlocking, lo_prio);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->wdone, hipEventBlockingSync | hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&f->w0);
+    if (e == hipSuccess) e = hipEventCreate(&f->w1);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->decoded[k], hipEventDisableTiming);
     if (e != hipSuccess) {
         destroy_handles(f);
         delete f;
@@ -771,7 +1191,9 @@ void tredgpu_inflater_destroy(tredgpu_inflater* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
     for (hipStream_t st : f->stream) (void)hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(f->wstream);
     release(f);
+    release_walk(f);
     destroy_handles(f);
     delete f;
 }
@@ -807,7 +1229,24 @@ int tredgpu_inflater_reserve(tredgpu_inflater* f, int64_t comp_bytes, int64_t ou
     return 0;
 }
 
-int tredgpu_inflate_blocks_crc(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t* crc) {
+}  // extern "C"
+
+namespace {
+int wait_asleep(tredgpu_inflater* f, hipEvent_t ev) {
+    // hipEventSynchronize spins even on a hipEventBlockingSync event here (measured: CPU time = wall time, and calls of
+    // other threads on other streams queue up behind the spinning one); the host threads that wait are the ones whose
+    // cores the path is short of
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return ifail(f, -10, "hipEventQuery", q);
+        usleep(100);
+    }
+}
+
+// copy in, decode (in slices on two streams); copy_out: every slice's blocks go back as soon as they are decoded.
+// w != nullptr: the pair walk follows the last slice on a stream of its own, and its results come back.
+int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t* crc, bool copy_out, tredgpu_walk_args* w) {
     if (!f) return -2;
     if (n_blocks < 0 || (size_t)n_blocks + 1 > f->cap_blocks || (n_blocks > 0 && !status)) return ifail(f, -2, "bad arguments (reserve first)");
     if (n_blocks == 0) return 0;
@@ -825,6 +1264,45 @@ int tredgpu_inflate_blocks_crc(tredgpu_inflater* f, int32_t n_blocks, int32_t* s
     int64_t* d_coff = f->d_off;
     int64_t* d_ooff = f->d_off + f->cap_blocks;
     int32_t* d_crc = f->d_status + f->cap_blocks;
+    const bool want_crc = crc != nullptr || w != nullptr;
+    // ---- the walk's inputs go first, on its own stream (nothing there depends on the decoding yet) ----
+    size_t n_tasks = 0, n_chunks = 0;
+    if (w) {
+        if (w->n_tasks < 0 || w->n_chunks < 0 || !w->blk_coffset || !w->blk_clen || !w->blk_crc || (w->n_tasks > 0 && (!w->tasks || !w->results)) ||
+            (w->n_chunks > 0 && !w->chunks) || w->cap_global < 0 || w->cap_target < 0 || (w->cap_global > 0 && !w->global_pool) ||
+            (w->cap_target > 0 && !w->target_pool))
+            return ifail(f, -2, "bad walk arguments");
+        n_tasks = (size_t)w->n_tasks; n_chunks = (size_t)w->n_chunks;
+        for (size_t t = 0; t < n_tasks; ++t) {
+            const tredgpu_walk_task& T = w->tasks[t];
+            if (T.n_chunks >= 0 && (T.chunk_first < 0 || (size_t)T.chunk_first + (size_t)T.n_chunks > n_chunks || T.block_first < 0 ||
+                                    T.block_end > n_blocks || T.block_first > T.block_end))
+                return ifail(f, -2, "walk task outside its chunks / blocks");
+        }
+        const size_t nb = (size_t)n_blocks;
+        if (grow_pair(f, &f->h_wblk, &f->d_wblk, &f->cap_wblk, nb * 16 + 64)) return -10;
+        if (grow_pair(f, &f->h_wtask, &f->d_wtask, &f->cap_wtask, n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk) + 64)) return -10;
+        if (grow_pair(f, &f->h_wres, &f->d_wres, &f->cap_wres, n_tasks * sizeof(tredgpu_walk_result) + 64)) return -10;
+        if (n_tasks > f->cap_wscratch) {
+            const size_t c = std::max(n_tasks, f->cap_wscratch + f->cap_wscratch / 2);
+            if (f->d_wrepeats) (void)hipFree(f->d_wrepeats);
+            if (f->d_wpairs) (void)hipFree(f->d_wpairs);
+            f->d_wrepeats = nullptr; f->d_wpairs = nullptr; f->cap_wscratch = 0;
+            ICHK(f, hipMalloc((void**)&f->d_wrepeats, c * WALK_REPEAT_CAP * sizeof(WalkRepeat)));
+            ICHK(f, hipMalloc((void**)&f->d_wpairs, c * WALK_PAIR_CAP * sizeof(WalkPair)));
+            f->cap_wscratch = c;
+        }
+        if (grow_pair(f, (uint8_t**)&f->h_gpool, (uint8_t**)&f->d_gpool, &f->cap_gpool, ((size_t)w->cap_global + 16) * 4)) return -10;
+        if (grow_pair(f, (uint8_t**)&f->h_tpool, (uint8_t**)&f->d_tpool, &f->cap_tpool, ((size_t)w->cap_target + 16) * 4)) return -10;
+        memcpy(f->h_wblk, w->blk_coffset, nb * 8);
+        memcpy(f->h_wblk + nb * 8, w->blk_clen, nb * 4);
+        memcpy(f->h_wblk + nb * 12, w->blk_crc, nb * 4);
+        memcpy(f->h_wtask, w->tasks, n_tasks * sizeof(tredgpu_walk_task));
+        memcpy(f->h_wtask + n_tasks * sizeof(tredgpu_walk_task), w->chunks, n_chunks * sizeof(tredgpu_walk_chunk));
+        ICHK(f, hipMemcpyAsync(f->d_wblk, f->h_wblk, nb * 16, hipMemcpyHostToDevice, f->wstream));
+        ICHK(f, hipMemcpyAsync(f->d_wtask, f->h_wtask, n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk), hipMemcpyHostToDevice, f->wstream));
+        ICHK(f, hipMemsetAsync(f->d_wres + n_tasks * sizeof(tredgpu_walk_result), 0, 16, f->wstream));
+    }
     // the two streams never wait for each other: each copies the offsets in for itself (both write the same values)
     for (int s = 0; s < nstreams; ++s) {
         ICHK(f, hipEventRecord(f->t0[s], f->stream[s]));
@@ -837,34 +1315,105 @@ int tredgpu_inflate_blocks_crc(tredgpu_inflater* f, int32_t n_blocks, int32_t* s
         const size_t c_from = (size_t)coff[b0], c_to = std::min(((size_t)coff[b1] + 3) & ~(size_t)3, f->cap_comp);
         ICHK(f, hipMemcpyAsync(f->d_comp + c_from, f->h_comp + c_from, c_to - c_from, hipMemcpyHostToDevice, st));
         ICHK(f, hipEventRecord(f->k0[k], st));
-        inflate_kernel<<<b1 - b0, LANES, 0, st>>>((const uint32_t*)f->d_comp, d_coff, f->d_out, d_ooff, b0, f->d_status, crc ? (uint32_t*)d_crc : nullptr);
+        inflate_kernel<<<b1 - b0, LANES, 0, st>>>((const uint32_t*)f->d_comp, d_coff, f->d_out, d_ooff, b0, f->d_status, want_crc ? (uint32_t*)d_crc : nullptr);
         ICHK(f, hipGetLastError());
         ICHK(f, hipEventRecord(f->k1[k], st));
-        ICHK(f, hipMemcpyAsync(f->h_out + ooff[b0], f->d_out + ooff[b0], (size_t)(ooff[b1] - ooff[b0]), hipMemcpyDeviceToHost, st));
+        if (copy_out) ICHK(f, hipMemcpyAsync(f->h_out + ooff[b0], f->d_out + ooff[b0], (size_t)(ooff[b1] - ooff[b0]), hipMemcpyDeviceToHost, st));
         ICHK(f, hipMemcpyAsync(f->h_status + b0, f->d_status + b0, (size_t)(b1 - b0) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        if (crc) ICHK(f, hipMemcpyAsync(f->h_status + f->cap_blocks + b0, d_crc + b0, (size_t)(b1 - b0) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (want_crc) ICHK(f, hipMemcpyAsync(f->h_status + f->cap_blocks + b0, d_crc + b0, (size_t)(b1 - b0) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     }
     f->last_slices = slices;
     f->last_streams = nstreams;
+    f->walk_timed = false;
+    if (w) {
+        // the walk reads every slice's blocks: its stream waits for the last launch of both decode streams
+        for (int s = 0; s < nstreams; ++s) {
+            ICHK(f, hipEventRecord(f->decoded[s], f->stream[s]));
+            ICHK(f, hipStreamWaitEvent(f->wstream, f->decoded[s], 0));
+        }
+        const size_t nb = (size_t)n_blocks;
+        WalkView v;
+        v.out = f->d_out; v.ooff = d_ooff; v.bstatus = f->d_status; v.bcrc = (const uint32_t*)d_crc;
+        v.bcoff = (const int64_t*)f->d_wblk; v.bclen = (const int32_t*)(f->d_wblk + nb * 8); v.xcrc = (const uint32_t*)(f->d_wblk + nb * 12);
+        v.out_end = ooff[n_blocks] + 48;                   // (the buffers hold 64 bytes more than reserved)
+        ICHK(f, hipEventRecord(f->w0, f->wstream));
+        if (n_tasks > 0) {
+            pair_walk_kernel<<<(unsigned)n_tasks, LANES, 0, f->wstream>>>(v, (const tredgpu_walk_task*)f->d_wtask,
+                (const tredgpu_walk_chunk*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task)), (tredgpu_walk_result*)f->d_wres, f->d_wpairs,
+                f->d_wrepeats, f->d_gpool, w->cap_global, f->d_tpool, w->cap_target, (unsigned long long*)(f->d_wres + n_tasks * sizeof(tredgpu_walk_result)));
+            ICHK(f, hipGetLastError());
+        }
+        ICHK(f, hipEventRecord(f->w1, f->wstream));
+        f->walk_timed = true;
+        ICHK(f, hipMemcpyAsync(f->h_wres, f->d_wres, n_tasks * sizeof(tredgpu_walk_result) + 16, hipMemcpyDeviceToHost, f->wstream));
+        ICHK(f, hipEventRecord(f->wdone, f->wstream));
+    }
     for (int s = 0; s < nstreams; ++s) {
         ICHK(f, hipEventRecord(f->t1[s], f->stream[s]));
         ICHK(f, hipEventRecord(f->done[s], f->stream[s]));
     }
-    // wait asleep: hipEventSynchronize spins even on a hipEventBlockingSync event here (measured: CPU time = wall time,
-    // and calls of other threads on other streams queue up behind the spinning one); the host threads that wait are the
-    // ones whose cores the path is short of
-    for (int s = 0; s < nstreams; ++s) {
-        for (;;) {
-            const hipError_t q = hipEventQuery(f->done[s]);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return ifail(f, -10, "hipEventQuery", q);
-            usleep(100);
-        }
-    }
+    for (int s = 0; s < nstreams; ++s)
+        if (wait_asleep(f, f->done[s])) return -10;
     int bad = 0;
     for (int32_t k = 0; k < n_blocks; ++k) { status[k] = f->h_status[k]; bad += status[k] != 0; }
     if (crc) for (int32_t k = 0; k < n_blocks; ++k) crc[k] = (uint32_t)f->h_status[f->cap_blocks + k];
+    if (w) {
+        if (wait_asleep(f, f->wdone)) return -10;
+        unsigned long long used[2];
+        memcpy(used, f->h_wres + n_tasks * sizeof(tredgpu_walk_result), 16);
+        memcpy(w->results, f->h_wres, n_tasks * sizeof(tredgpu_walk_result));
+        // (a task that found its pool full took its room all the same: the counters can exceed the capacities)
+        const size_t ng = (size_t)std::min<unsigned long long>(used[0], (unsigned long long)w->cap_global),
+                     nt = (size_t)std::min<unsigned long long>(used[1], (unsigned long long)w->cap_target);
+        if (ng) ICHK(f, hipMemcpyAsync(f->h_gpool, f->d_gpool, ng * 4, hipMemcpyDeviceToHost, f->wstream));
+        if (nt) ICHK(f, hipMemcpyAsync(f->h_tpool, f->d_tpool, nt * 4, hipMemcpyDeviceToHost, f->wstream));
+        ICHK(f, hipEventRecord(f->wdone, f->wstream));
+        if (wait_asleep(f, f->wdone)) return -10;
+        if (ng) memcpy(w->global_pool, f->h_gpool, ng * 4);
+        if (nt) memcpy(w->target_pool, f->h_tpool, nt * 4);
+        w->n_global = (int64_t)ng;
+        w->n_target = (int64_t)nt;
+    }
     return bad;
+}
+}  // namespace
+
+extern "C" {
+
+int tredgpu_inflate_blocks_crc(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t* crc) {
+    return run_inflate(f, n_blocks, status, crc, true, nullptr);
+}
+
+int tredgpu_inflate_walk(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t* crc, tredgpu_walk_args* walk) {
+    if (!walk) return f ? ifail(f, -2, "walk is NULL") : -2;
+    return run_inflate(f, n_blocks, status, crc, false, walk);
+}
+
+// The blocks with need[k] != 0 of the last tredgpu_inflate_walk, copied to their places in the pinned output (runs of
+// wanted blocks, and the unwanted ones between two runs when they are few, go in one copy).
+int tredgpu_inflater_fetch(tredgpu_inflater* f, int32_t n_blocks, const uint8_t* need) {
+    if (!f) return -2;
+    if (n_blocks < 0 || (size_t)n_blocks + 1 > f->cap_blocks || (n_blocks > 0 && !need)) return ifail(f, -2, "bad arguments");
+    if (n_blocks == 0) return 0;
+    const int64_t* ooff = f->h_off + f->cap_blocks;
+    ICHK(f, hipSetDevice(f->device));
+    constexpr int64_t GAP = 128 * 1024;           // a copy costs the host ~5 us: less than these bytes cost the bus
+    int copies = 0;
+    int32_t k = 0;
+    while (k < n_blocks) {
+        if (!need[k]) { ++k; continue; }
+        int32_t last = k;                          // the run [k, last]
+        for (int32_t j = k + 1; j < n_blocks && ooff[j] - ooff[last + 1] <= GAP; ++j)
+            if (need[j]) last = j;
+        ICHK(f, hipMemcpyAsync(f->h_out + ooff[k], f->d_out + ooff[k], (size_t)(ooff[last + 1] - ooff[k]), hipMemcpyDeviceToHost, f->stream[copies & 1]));
+        ++copies;
+        k = last + 1;
+    }
+    for (int s = 0; s < 2; ++s) {
+        ICHK(f, hipEventRecord(f->done[s], f->stream[s]));
+        if (wait_asleep(f, f->done[s])) return -10;
+    }
+    return copies;
 }
 
 int tredgpu_inflate_blocks(tredgpu_inflater* f, int32_t n_blocks, int32_t* status) { return tredgpu_inflate_blocks_crc(f, n_blocks, status, nullptr); }
@@ -882,6 +1431,17 @@ int tredgpu_inflater_timing(tredgpu_inflater* f, double* total_ms, double* kerne
     for (int k = 0; k < f->last_slices; ++k) {
         if (hipEventElapsedTime(&ms, f->k0[k], f->k1[k]) == hipSuccess) *kernel_ms += ms;
     }
+    return 0;
+}
+
+int tredgpu_inflater_walk_ms(tredgpu_inflater* f, double* walk_ms) {
+    if (!f || !walk_ms) return -2;
+    *walk_ms = 0.0;
+    if (!f->walk_timed) return 0;
+    ICHK(f, hipSetDevice(f->device));
+    float ms = 0.f;
+    ICHK(f, hipEventElapsedTime(&ms, f->w0, f->w1));
+    *walk_ms = ms;
     return 0;
 }
 

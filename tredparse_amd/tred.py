@@ -40,7 +40,8 @@ logger = logging.getLogger(__name__)
 # seconds accumulated over run_many calls: the driver thread's waits for scans, its GPU calls and its formatting; and
 # the writer thread's time in the sink (JSON / VCF text and files)
 TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
-          "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0}
+          "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0, "walk_regions": 0, "walk_declined": 0,
+          "walk_blocks_fetched": 0}
 _TIMING_LOCK = threading.Lock()
 
 
@@ -102,6 +103,9 @@ def set_argparse():
     g.add_argument("--gpu-inflate", action="store_true",
                    help="inflate the BAMs' BGZF blocks on the GPU, --batch-samples samples per launch (needs --cpus > 1; "
                         "pays when several driver processes share the host's cores: see DESIGN.md 4.4)")
+    g.add_argument("--gpu-walk", action="store_true",
+                   help="with --gpu-inflate: the pair-length walks (PEextractor's +-10 kb regions) run on the GPU over the "
+                        "blocks it inflated; only the blocks of the loci's windows and alternative loci come back to the host")
     g.add_argument("--maxinsert", type=int, default=300, help="largest allele considered, in repeat units")
     g.add_argument("--fullsearch", action="store_true", help="evaluate every allele pair up to --maxinsert")
     g = p.add_argument_group("I/O options")
@@ -179,8 +183,9 @@ def collect_sample(arg):
 # different streams do not overlap on this GPU, so the batch is what fills it) and lets the scans take the blocks from
 # the inflater's pinned output (bamio preload).  Blocks a plan misses, or the decoder rejects, are inflated by the scan
 # itself as before: the results cannot differ.
-def _plan_sample(arg):
-    """Thread: open the BAM and list the blocks its scan will read.  None: no GPU help for this sample."""
+def _plan_sample(arg, walk=False):
+    """Thread: open the BAM and list the blocks its scan will read -- with walk, also the pair-length regions as tasks
+    for the device's walk (bamio plan_walks / plan_blocks).  None: no GPU help for this sample."""
     from .bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays, open_bam, y_regions
     o = _options(arg)
     try:
@@ -196,21 +201,27 @@ def _plan_sample(arg):
         sexed = any(t.is_xlinked for t in loci)          # scan_sample then asks for the chrY depth windows too
         n, cbytes, obytes = f.plan(sites, regions, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN,
                                    use_alts=o["alts"] and not o["clip"], extra=y_regions(o["repo"].ref) if sexed else ())
-        return {"handle": f, "readlen": readlen, "n": n, "cbytes": cbytes, "obytes": obytes}
+        p = {"handle": f, "readlen": readlen, "n": n, "cbytes": cbytes, "obytes": obytes}
+        if walk and n > 0:
+            p["tasks"], p["chunks"] = f.plan_walks(sites, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+            p["coffset"], p["clen"], p["crc"], p["host"] = f.plan_blocks()
+        return p
     except Exception:
         f.close()
         return None
 
 
-def _scan_planned(arg, plan, out_addr, out_off, status, crc=None):
+def _scan_planned(arg, plan, out_addr, out_off, status, crc=None, pe=None):
     """Thread: the sample's scan with its planned blocks preloaded from the inflater's output (crc: the decoder's
-    checksums of those blocks -- the scan then does not walk the bytes for the BGZF CRC again)."""
+    checksums of those blocks -- the scan then does not walk the bytes for the BGZF CRC again; pe: the pair walks'
+    results from the device, see scan_sample)."""
     o = _options(arg)
     f = plan["handle"]
     try:
         if status is not None:
             f.preload(out_addr, out_off, status, crc)
-        return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"], readlen=plan["readlen"], handle=f)
+        return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"], readlen=plan["readlen"], handle=f,
+                           pe=pe)
     finally:
         if status is not None:
             hits, misses = f.preload_clear()
@@ -261,9 +272,9 @@ class _InflateFeeder(object):
     inflaters go only after every scan that reads their buffers has ended."""
     SLOTS = 3
 
-    def __init__(self, chunks, ex, device):
+    def __init__(self, chunks, ex, device, walk=False):
         import queue
-        self.chunks, self.ex, self.device = chunks, ex, device
+        self.chunks, self.ex, self.device, self.walk = chunks, ex, device, walk
         # plans and fills have threads of their own: queued behind a chunk's 28 scans in the scan pool they started only
         # when those were done, and the pool then idled through the next chunk's decode
         self.prep = ThreadPoolExecutor(max_workers=2)
@@ -293,7 +304,7 @@ class _InflateFeeder(object):
             self.decoding[slot].exception()            # chunk ci - SLOTS has been decoded and its scans are known ...
         for fut in self.busy[slot]:
             fut.exception()                            # ... and have ended (waits; the consumer sees the error itself)
-        plans = [fut.result() for fut in [self.prep.submit(_plan_sample, a) for a in chunk]]
+        plans = [fut.result() for fut in [self.prep.submit(_plan_sample, a, self.walk) for a in chunk]]
         live = [p for p in plans if p is not None and p["n"] > 0]
         t0 = time.perf_counter()
         job = {"plans": plans, "live": live, "inf": inf, "slot": slot, "ooff": None, "n_all": 0}
@@ -312,10 +323,31 @@ class _InflateFeeder(object):
                     fut.result()
                 # (every sample wrote its own end as entry n: the next sample's first entry is the same number)
                 job["ooff"], job["n_all"] = ooff, n_all
+                if self.walk:
+                    job["walk"] = self._walk_tables(live)
             except Exception as e:     # no GPU help for this chunk: the scans inflate for themselves
                 logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
         timing_add(inflate=time.perf_counter() - t0)
         return job
+
+    @staticmethod
+    def _walk_tables(live):
+        """The chunk's pair-walk tasks: every sample's tables (bamio plan_walks / plan_blocks) moved to the sample's
+        place among the call's blocks and chunks."""
+        import numpy as np
+        tasks, chunks, c0 = [], [], 0
+        for p in live:
+            t, c = p["tasks"].copy(), p["chunks"].copy()
+            t["chunk_first"] += c0
+            t["block_first"] += p["first"]
+            t["block_end"] += p["first"]
+            c["begin_block"][c["begin_block"] >= 0] += p["first"]
+            p["task_first"] = sum(len(x) for x in tasks)
+            tasks.append(t)
+            chunks.append(c)
+            c0 += len(c)
+        return {"coffset": np.concatenate([p["coffset"] for p in live]), "clen": np.concatenate([p["clen"] for p in live]),
+                "crc": np.concatenate([p["crc"] for p in live]), "tasks": np.concatenate(tasks), "chunks": np.concatenate(chunks)}
 
     def _decode_and_scan(self, chunk, job):
         """Decode thread: one launch for the chunk, then its scans go to the pool and their futures to the consumer."""
@@ -323,11 +355,14 @@ class _InflateFeeder(object):
         try:
             if self.stop.is_set():
                 return
-            status = crc = None
+            status = crc = walked = None
             if job["ooff"] is not None:
                 t0 = time.perf_counter()
                 try:
-                    status, crc = inf.run(job["n_all"], crc=True)
+                    if job.get("walk") is not None:
+                        status, crc, walked = self._run_walk(inf, job)
+                    else:
+                        status, crc = inf.run(job["n_all"], crc=True)
                     timing_add(inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
                 except Exception as e:
                     logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
@@ -343,8 +378,12 @@ class _InflateFeeder(object):
                     futs.append(self.ex.submit(_scan_planned, a, p, 0, None, None))
                 else:
                     k = p["first"]
+                    pe = None
+                    if walked is not None:
+                        res, gp, tp = walked
+                        pe = (res[p["task_first"]:p["task_first"] + len(p["tasks"])], gp, tp)
                     futs.append(self.ex.submit(_scan_planned, a, p, inf.out_addr, ooff[k:k + p["n"] + 1], status[k:k + p["n"]],
-                                               crc[k:k + p["n"]]))
+                                               crc[k:k + p["n"]], pe))
             handed = True                                  # (each scan closes its own handle)
             self.busy[job["slot"]] = futs
             self._put(futs)
@@ -353,6 +392,23 @@ class _InflateFeeder(object):
         finally:
             if not handed:
                 self._close_plans(plans)
+
+    @staticmethod
+    def _run_walk(inf, job):
+        """Decode, walk the pair-length regions on the device, fetch the blocks the scans still read.  Returns the
+        statuses as the scans should see them (a block that was not fetched counts as not delivered), the checksums and
+        the walk's (results, global pool, target pool)."""
+        import numpy as np
+        from .bam_parser import walk_need
+        w = job["walk"]
+        status, crc, res, gp, tp = inf.run_walk(job["n_all"], w["coffset"], w["clen"], w["crc"], w["tasks"], w["chunks"])
+        need = np.zeros(job["n_all"], np.uint8)
+        for p in job["live"]:
+            a = p["first"]
+            need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])])
+        inf.fetch(need)
+        timing_add(walk_regions=len(res), walk_declined=int((res["status"] != 0).sum()), walk_blocks_fetched=int(need.sum()))
+        return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp)
 
     def _put(self, item):
         import queue
@@ -596,7 +652,7 @@ class _Writer(object):
 
 
 def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
-             background_sink=False, inflate_device=None, overlap_gpu=False, genotype_chunks=1, sink_threads=1):
+             background_sink=False, inflate_device=None, overlap_gpu=False, genotype_chunks=1, sink_threads=1, gpu_walk=False):
     """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
     executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in flight the
     scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
@@ -604,7 +660,8 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     background_sink: sink runs on a writer thread (in order) instead of the driver thread -- on sink_threads of them, in
     any order, when that is more than one (the sink's calls must then be independent of each other).
     inflate_device: GPU that inflates the samples' BGZF blocks, a chunk of samples per launch (None: the scans inflate on
-    the host); needs scan threads.  genotype_chunks: the scans of this many chunks go through the kernels in one GPU batch
+    the host); needs scan threads.  gpu_walk: the pair-length walks (PEextractor) run on that GPU too, over the blocks it
+    just inflated; only the blocks of the loci's windows and of the alternative loci come back.  genotype_chunks: the scans of this many chunks go through the kernels in one GPU batch
     (a GPU call has a fixed cost of ~15 ms in copies and launches, several times that when driver processes share the
     device: decode launches want chunks of ~16 samples, genotyping calls larger ones)."""
     own = pool is None and threads > 1 and len(task_args) > 1
@@ -621,7 +678,7 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     feeder = None
     if inflate_device is not None and ex is not None:
         try:
-            feeder = _InflateFeeder(chunks, ex, inflate_device)
+            feeder = _InflateFeeder(chunks, ex, inflate_device, walk=gpu_walk)
         except Exception as e:       # no pinned memory, no device ...: the scans inflate for themselves
             logging.getLogger("tredparse_amd").warning("GPU inflate not available (%s): BGZF blocks are inflated on the host", e)
     # (the GPU half of a batch on a thread of its own, beside the formatting of the previous batch: measured again in
@@ -963,7 +1020,7 @@ def main(args, quiet=False):
                          lazy_details=True, background_sink=args.cpus > 1,
                          # (echoing to stdout keeps the sample order; with the host inflating, its cores are the scans')
                          sink_threads=2 if ((quiet or args.no_output) and args.gpu_inflate) else 1,
-                         inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None)
+                         inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None, gpu_walk=args.gpu_walk)
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
         os.chdir(cwd)
