@@ -587,13 +587,17 @@ def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0, dense=False):
     g = max(1, n_devices)
     tried = [drivers_opt] if drivers_opt else [max(1, usable // (8 * g)), max(1, usable // (5 * g))]
     if dense and not drivers_opt:
-        tried += [max(1, usable // (4 * g)), max(1, usable // (3 * g))]
+        # (... and one per 2.7 CPUs with three scan threads each: with the pair walks on the GPU a scan is a third of the
+        #  work, and what bounds a driver is its interpreter lock -- measured 25.2-25.6 k genotypes/s against 24.6 k)
+        tried += [max(1, usable // (4 * g)), max(1, usable // (3 * g)), max(1, (3 * usable) // (8 * g))]
     plans = []
     for dpg in sorted(set([1] + tried)):
         ranks = dpg * n_devices
         # one core is left to the drivers together: a driver thread (batches, formatting) is busy about a third of
         # the time, its writer thread mostly outside the interpreter lock
         threads = threads_opt or max(1, (usable - 1) // ranks)
+        if dense and not threads_opt and not drivers_opt and dpg == max(1, (3 * usable) // (8 * g)) and dpg > usable // (3 * g):
+            threads = max(threads, 3)
         plans.append((ranks, threads))
     return plans
 
@@ -633,7 +637,7 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
                         "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
                         "--e2e-repeat", str(args.e2e_repeat), "--e2e-genotype-chunks", str(getattr(args, "e2e_genotype_chunks", 1)),
-                        "--e2e-gpu-walk", args.e2e_gpu_walk if gpu_inflate else "0"]
+                        "--e2e-gpu-walk", getattr(args, "e2e_gpu_walk", "1") if gpu_inflate else "0"]
                 out_dir = os.path.join(root, "out{}x{}{}".format(n_devices, drivers, "g" if gpu_inflate else ""))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
@@ -648,7 +652,7 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
                 units, secs = sum(r["units"] for r in ranks), max(r["seconds"] for r in ranks)
                 nbytes = sum(r["bam_bytes"] for r in ranks)
                 legs.append({"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate,
-                             "gpu_walk": bool(gpu_inflate and args.e2e_gpu_walk == "1"), "samples_per_gpu_batch": batch,
+                             "gpu_walk": bool(gpu_inflate and getattr(args, "e2e_gpu_walk", "1") == "1"), "samples_per_gpu_batch": batch,
                              "value": units / secs, "unit": "genotypes/s",
                              "units": units, "seconds": secs, "samples": sum(r["samples"] for r in ranks),
                              "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,

@@ -52,13 +52,12 @@ def main():
     for _ in range(3):
         status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, pairs_per_task=8192)
     ok = res["status"] == 0
-    phases = {"cursor (size word, block bookkeeping)": res["global_first"][ok], "window refill": res["target_first"][ok],
-              "head: fields, CIGAR, window test": res["win_vbeg"][ok].astype(np.int64), "name hash + table probe": res["win_vend"][ok].astype(np.int64),
-              "pair entry (clips, stores, count)": res["n_global"][ok].astype(np.int64) << 4, "finish (name checks, lists)": res["n_target"][ok].astype(np.int64) << 4}
+    phases = {"chain (length words, block bookkeeping, window refills)": res["global_first"][ok], "parse (a lane per record)": res["target_first"][ok],
+              "resolve (ballots, pair table, stores)": res["win_vbeg"][ok].astype(np.int64), "finish (name checks, lists)": res["win_vend"][ok].astype(np.int64)}
     total = sum(float(v.mean()) for v in phases.values())
     print(json.dumps({"library": _lib.version(), "samples": m, "regions": int(ok.sum()), "records_per_region": float(res["n_window"][ok].mean()),
                       "walk_kernel_ms": inf.walk_ms(), "mean_cycles_per_region": {k: round(float(v.mean())) for k, v in phases.items()},
-                      "total_cycles": round(total), "note": "s_memtime ticks (100 MHz on gfx950: 10 ns each)"}))
+                      "total_cycles": round(total), "note": "shader clock cycles (s_memtime), ~2.2 GHz"}))
 
 
 if __name__ == "__main__":

@@ -41,6 +41,13 @@ struct tredgpu_ctx {
     int* h_pin = nullptr;  // pinned word for small read-backs
     size_t grid_pool_bytes = GRID_POOL_BYTES;   // TREDGPU_GRID_POOL_MB overrides (tuning / tests of the multi-pass path)
     Buf st[24];  // staging for HOST-memory calls
+    // pinned arena of the HOST-memory calls: copies from / to the caller's pageable arrays go through it, so that they are
+    // truly asynchronous (a hipMemcpyAsync on pageable memory is staged and waited for by the runtime, one by one -- with
+    // several driver processes on the device each of those waits queues behind the others' work: 25 per batch)
+    struct PinBlock { uint8_t* p; size_t cap, used; };
+    std::vector<PinBlock> pin;
+    struct PinOut { void* host; const void* pinned; size_t bytes; };
+    std::vector<PinOut> pin_out;       // read-backs to hand over at the next stream_sync
     // intermediates of the fused path
     Buf ws_tag, ws_h, ws_score;
     // HIP-event timing of the three main kernels
@@ -107,12 +114,37 @@ struct ScopedTimer {
     }
 };
 
+// `bytes` of pinned memory, valid until the next stream_sync (blocks are kept and reused; a call that needs more than the
+// arena holds gets a further block)
+void* pin_alloc(tredgpu_ctx* c, size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    for (auto& b : c->pin)
+        if (b.cap - b.used >= bytes) { void* at = b.p + b.used; b.used += bytes; return at; }
+    size_t cap = std::max<size_t>(bytes, (size_t)8 << 20);
+    if (!c->pin.empty()) cap = std::max(cap, c->pin.back().cap * 2);
+    uint8_t* p = nullptr;
+    if (hipHostMalloc((void**)&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    c->pin.push_back({p, cap, bytes});
+    return p;
+}
+
+// wait for the context's stream; then hand the read-backs that went through the pinned arena to their arrays and start
+// the arena afresh (nothing of it is in flight any more)
+hipError_t stream_sync(tredgpu_ctx* c) {
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        for (const auto& o : c->pin_out) memcpy(o.host, o.pinned, o.bytes);
+    c->pin_out.clear();
+    for (auto& b : c->pin) b.used = 0;
+    return e;
+}
+
 int ensure(tredgpu_ctx* c, Buf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return 0;
     if (b.p) {
         // the buffer may still be in use by enqueued work
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -191,7 +223,12 @@ template <typename T>
 int stage_in(tredgpu_ctx* c, Buf& b, const T* host, size_t n, const T** out) {
     int rc = ensure(c, b, n * sizeof(T));
     if (rc) return rc;
-    if (n) HIPCHK(c, hipMemcpyAsync(b.p, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    if (n) {
+        void* h = pin_alloc(c, n * sizeof(T));
+        if (!h) return fail(c, -10, "no pinned memory for a %zu-byte copy", n * sizeof(T));
+        memcpy(h, host, n * sizeof(T));
+        HIPCHK(c, hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    }
     *out = (const T*)b.p;
     return 0;
 }
@@ -206,7 +243,12 @@ int stage_out(tredgpu_ctx* c, Buf& b, size_t n, T** out) {
 
 template <typename T>
 int copy_back(tredgpu_ctx* c, T* host, const T* dev, size_t n) {
-    if (n && host) HIPCHK(c, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    if (n && host) {
+        void* h = pin_alloc(c, n * sizeof(T));
+        if (!h) return fail(c, -10, "no pinned memory for a %zu-byte copy", n * sizeof(T));
+        HIPCHK(c, hipMemcpyAsync(h, dev, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        c->pin_out.push_back({host, h, n * sizeof(T)});       // handed over by stream_sync
+    }
     return 0;
 }
 
@@ -245,7 +287,7 @@ int tredgpu_create(int device_id, tredgpu_ctx** out) {
 void tredgpu_destroy(tredgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_sync(c);
     for (Buf* b : {&c->d_ladders, &c->d_seq, &c->d_model, &c->ws_quads, &c->ws_counter, &c->ws_drop,
                    &c->ws_grid, &c->ws_stats, &c->ws_perm, &c->ws_class, &c->ws_gdesc, &c->ws_gtile, &c->ws_gctr, &c->ws_ucnt, &c->ws_bins, &c->ws_kde, &c->ws_tag, &c->ws_h, &c->ws_score})
         release(*b);
@@ -253,6 +295,8 @@ void tredgpu_destroy(tredgpu_ctx* c) {
     for (auto& t : c->timers)
         for (auto& ev : t.pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    for (auto& b : c->pin) (void)hipHostFree(b.p);
+    c->pin.clear();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -262,7 +306,7 @@ const char* tredgpu_last_error(const tredgpu_ctx* c) { return c ? c->err.c_str()
 int tredgpu_sync(tredgpu_ctx* c) {
     if (!c) return -2;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return 0;
 }
 
@@ -271,7 +315,7 @@ void* tredgpu_get_stream(tredgpu_ctx* c) { return c ? (void*)c->stream : nullptr
 int tredgpu_reset_timing(tredgpu_ctx* c) {
     if (!c) return -2;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     for (auto& t : c->timers) { t.used = 0; t.launches = 0; t.total_ms = 0; }
     if (c->ws_stats.p) HIPCHK(c, hipMemsetAsync(c->ws_stats.p, 0, SW_STAT_SLOTS * 8 * sizeof(unsigned long long), c->stream));
     return 0;
@@ -285,11 +329,11 @@ int tredgpu_get_sw_counters(tredgpu_ctx* c, uint64_t out[8]) {
         // the kernel spreads its per-wave updates over SW_STAT_SLOTS cache lines (one line of 8 counters each)
         std::vector<uint64_t> slots((size_t)SW_STAT_SLOTS * 8);
         HIPCHK(c, hipMemcpyAsync(slots.data(), c->ws_stats.p, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, stream_sync(c));
         for (int k = 0; k < SW_STAT_SLOTS; ++k)
             for (int i = 0; i < 8; ++i) out[i] += slots[(size_t)k * 8 + i];
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return 0;
 }
 
@@ -297,7 +341,7 @@ int tredgpu_get_timing(tredgpu_ctx* c, int which, int64_t* launches, double* tot
     if (!c) return -2;
     if (which < 0 || which > 6) return fail(c, -2, "which must be one of TREDGPU_KERNEL_*");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     timer_flush(c->timers[which]);
     if (launches) *launches = c->timers[which].launches;
     if (total_ms) *total_ms = c->timers[which].total_ms;
@@ -394,7 +438,7 @@ int tredgpu_set_ladders(tredgpu_ctx* c, int32_t n, const char* const* prefix, co
     int rc;
     if ((rc = ensure(c, c->d_ladders, lad.size() * sizeof(LadderDesc)))) return rc;
     if ((rc = ensure(c, c->d_seq, seq.size() * sizeof(uint32_t)))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     if (n) HIPCHK(c, hipMemcpy(c->d_ladders.p, lad.data(), lad.size() * sizeof(LadderDesc), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_seq.p, seq.data(), seq.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->h_ladders.swap(lad);
@@ -419,7 +463,7 @@ int tredgpu_set_model(tredgpu_ctx* c, const double* step_pdf, const double* stut
     for (int n = 0; n < GRID_LFACT; ++n) m.lfact[n] = std::lgamma((double)n + 1);
     int rc;
     if ((rc = ensure(c, c->d_model, sizeof m))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     HIPCHK(c, hipMemcpy(c->d_model.p, &m, sizeof m, hipMemcpyHostToDevice));
     c->have_model = true;
     return 0;
@@ -564,7 +608,7 @@ int tredgpu_sw_classify(tredgpu_ctx* c, int mem, const uint32_t* packed, const i
     if ((rc = copy_back(c, out_h, (const int16_t*)d_h, (size_t)n_reads))) return rc;
     if ((rc = copy_back(c, out_score, (const int16_t*)d_score, (size_t)n_reads))) return rc;
     if ((rc = copy_back(c, out_dump, (const int16_t*)d_dump, dump_n))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return 0;
 }
 
@@ -603,7 +647,7 @@ int tredgpu_tally(tredgpu_ctx* c, int mem, const uint8_t* tag, const int16_t* h,
     if ((rc = copy_back(c, full_cnt, (const int32_t*)d_f, hn))) return rc;
     if ((rc = copy_back(c, pref_cnt, (const int32_t*)d_p, hn))) return rc;
     if ((rc = copy_back(c, rept_cnt, (const int32_t*)d_r, hn))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return 0;
 }
 
@@ -626,7 +670,7 @@ static int query_max_insert(tredgpu_ctx* c, const tredgpu_unit_params* units, in
     int* d = (int32_t*)c->ws_counter.p + 12;
     HIPCHK(c, launch_unit_max(units, n_units, d, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_pin, d, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     out[0] = c->h_pin[0];   // largest maxinsert
     out[1] = c->h_pin[1];   // largest n_target
     return 0;
@@ -702,7 +746,7 @@ static int run_grid_device(tredgpu_ctx* c, const tredgpu_unit_params* units, int
             if (!may_defer) break;
             HIPCHK(c, hipMemcpyAsync(c->h_pin, (const char*)c->ws_gctr.p + grid_deferred_offset(), sizeof(int),
                                      hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, stream_sync(c));
             if (c->h_pin[0] == 0) break;
             if (pass >= 1000) return fail(c, -10, "likelihood grid: scratch pool passes do not converge");
         }
@@ -779,7 +823,7 @@ static int likelihood_grid_impl(tredgpu_ctx* c, int mem, const tredgpu_unit_para
     if ((rc = copy_back(c, calls, (const tredgpu_call*)d_calls, (size_t)n_units))) return rc;
     if ((rc = copy_back(c, grid_dump, (const double*)d_dump, dump_n))) return rc;
     if ((rc = copy_back(c, marg, (const double*)d_marg, marg_n))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return 0;
 }
 
@@ -836,7 +880,7 @@ int tredgpu_pe_kde(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, in
     HIPCHK(c, launch_pe_kde(a, c->stream));
     if ((rc = copy_back(c, pdf_out, (const double*)d_pdf, (size_t)n_units * TREDGPU_SPAN))) return rc;
     if ((rc = copy_back(c, status_out, (const int32_t*)d_st, (size_t)n_units))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_sync(c));
     return 0;
 }
 

@@ -681,16 +681,16 @@ __global__ __launch_bounds__(LANES, 7) void inflate_kernel(const uint32_t* __res
 // spans the tract goes to the target list, any other to the global one.
 //
 // One region = one wavefront.  Where the next record starts is written in this one, so the walk is a chain -- but a chain
-// through LDS, not through HBM: the wavefront copies 4 KB of the block stream at a time into LDS (one coalesced load for
-// ~11 records; a lane walking the records in global memory paid a miss of 1-2 us for each, and several per record: 24 ms
-// for a region of 4 000 records) and every lane then runs the same walk over it -- all values are uniform, the LDS reads
-// are broadcasts, the branches do not diverge.  The name table lives in LDS as well (16 384 slots of tag << 13 | pair
-// index, the pair's record count in a byte array beside it), so finding a record's mate costs no memory access either;
-// what a tag match does NOT prove -- that the two names are equal byte for byte -- is checked for all pairs at the end by
-// the 64 lanes in parallel, and a single mismatch there gives the region back to the host, as does anything else out of
-// the ordinary: a block the plan does not hold or the decoder rejected or whose CRC-32 is not its trailer's, a record that
-// makes no sense, more names than the table holds.  The host then walks that region itself, as it does without this
-// kernel, and reports what is wrong with the file.
+// through LDS, not through HBM: the wavefront copies 6 KB of the block stream at a time into LDS (one coalesced load for
+// ~16 records; a lane walking the records in global memory paid a miss of 1-2 us for each, and several per record: 24 ms
+// for a region of 4 000 records), follows the length words there, and then every lane parses ONE of the records found
+// (walk_region_records).  The name table lives in LDS as well (16 384 slots of tag << 13 | pair index, the pair's record
+// count in a byte array beside it), so finding a record's mate costs no memory access either; what a tag match does NOT
+// prove -- that the two names are equal byte for byte -- is checked for all pairs at the end by the 64 lanes in parallel,
+// and a single mismatch there gives the region back to the host, as does anything else out of the ordinary: a block the
+// plan does not hold or the decoder rejected or whose CRC-32 is not its trailer's, a record that makes no sense, more names
+// than the table holds.  The host then walks that region itself, as it does without this kernel, and reports what is wrong
+// with the file.
 struct WalkView {
     const uint8_t* out; const int64_t* ooff;          // the decoder's output and its block offsets
     const int32_t* bstatus; const uint32_t* bcrc;     // what the decoder said about each block
@@ -703,7 +703,7 @@ struct WalkRepeat { int32_t pair; int32_t pad; int64_t name_at; };   // a third,
 constexpr int WALK_PAIR_CAP = 8192;               // names per region (a +-10 kb window at 30x holds ~2 100)
 constexpr int WALK_SLOTS = 2 * WALK_PAIR_CAP;     // open addressing at a load below one half
 constexpr int WALK_REPEAT_CAP = 2048;
-constexpr int WALK_WINDOW = 4096;                 // bytes of the block stream in LDS
+constexpr int WALK_WINDOW = 6144;                 // bytes of the block stream in LDS
 constexpr int WALK_HEAD = 512;                    // a record's head (fixed fields, name, CIGAR) should lie in the window
 enum { WALK_OK = 0, WALK_NOT_PLANNED = 1, WALK_BAD_BLOCK = 2, WALK_BAD_RECORD = 3, WALK_TABLE_FULL = 4, WALK_NO_END = 5, WALK_POOL_FULL = 6,
        WALK_TAG_CLASH = 7 };
@@ -726,7 +726,11 @@ struct WalkLds {
 __device__ inline uint32_t walk_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ inline int64_t walk_uniform64(int64_t x) { return (int64_t)((uint64_t)walk_uniform((uint32_t)((uint64_t)x >> 32)) << 32 | walk_uniform((uint32_t)x)); }
 
-// the block stream through the LDS window; every lane calls these with the same arguments
+__device__ inline uint64_t walk_lane64(uint64_t x, int j) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), j) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, j);
+}
+
+// the block stream through the LDS window
 struct WalkReader {
     const uint8_t* out; int64_t out_end; WalkLds* S; int64_t base; int lane;
     __device__ void fill(int64_t at) {
@@ -739,36 +743,16 @@ struct WalkReader {
         walk_lds_order();
     }
     __device__ bool inside(int64_t at, int n) const { return at >= base && at + n <= base + WALK_WINDOW; }
+    // (per lane: its own address)
+    __device__ uint32_t vu8(int64_t at) const { return inside(at, 1) ? S->window[at - base] : out[at]; }
+    __device__ uint32_t vu16(int64_t at) const { return vu8(at) | (vu8(at + 1) << 8); }
+    __device__ uint32_t vu32(int64_t at) const { return vu16(at) | (vu16(at + 2) << 16); }
+    // (every lane the same address)
     __device__ uint32_t u8(int64_t at) const { return walk_uniform(inside(at, 1) ? S->window[at - base] : out[at]); }
     __device__ uint32_t u16(int64_t at) const { return u8(at) | (u8(at + 1) << 8); }
     __device__ uint32_t u32(int64_t at) const {
         if (inside(at, 4)) { const uint8_t* p = S->window + (at - base); return walk_uniform((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
         uint32_t v; __builtin_memcpy(&v, out + at, 4); return walk_uniform(v);
-    }
-};
-
-// A record's first 252 bytes (its length word, the fixed fields, the name and -- nearly always -- the CIGAR), one dword per
-// lane: one LDS read for the whole head, and every field is then a v_readlane or two (byte reads through the window cost
-// an LDS round trip each, ~50 of them per record: 2 us).  Every lane asks for the same field and gets the same value.
-struct WalkHead {
-    uint32_t w; int shift; int64_t a0; bool fast; const WalkReader* rd;
-    __device__ void load(const WalkReader& r, int64_t at) {      // the window holds [at, at + WALK_HEAD)
-        rd = &r; a0 = at; shift = (int)(at & 3);
-        w = *(const uint32_t*)(r.S->window + ((at & ~(int64_t)3) - r.base) + 4 * r.lane);
-        fast = true;
-    }
-    __device__ void need(int bytes) { fast = shift + bytes + 4 <= 4 * LANES; }   // else: through the window, byte by byte
-    __device__ uint32_t u32(int off) const {
-        if (!fast) return rd->u32(a0 + off);
-        const int o = shift + off;
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)w, o >> 2), hi = (uint32_t)__builtin_amdgcn_readlane((int)w, (o >> 2) + 1);
-        return (uint32_t)(((uint64_t)hi << 32 | lo) >> (8 * (o & 3)));     // (scalar: both halves are in SGPRs)
-    }
-    __device__ uint32_t u16(int off) const { return u32(off) & 0xFFFFu; }
-    __device__ uint32_t u8(int off) const {
-        if (!fast) return rd->u8(a0 + off);
-        const int o = shift + off;
-        return ((uint32_t)__builtin_amdgcn_readlane((int)w, o >> 2) >> (8 * (o & 3))) & 0xFFu;
     }
 };
 
@@ -778,7 +762,7 @@ __device__ inline bool walk_block_ok(const WalkView& v, int k) { return v.bstatu
 // read once per block, not once per record -- a load in the record loop would also wait for the stores before it) and
 // the offset in it.
 struct WalkCursor {
-    int k; int64_t upos, size, first, coff, clen;
+    int k; int64_t upos, size, first, coff, clen; uint64_t here, next;     // (here / next: this block's and the next one's virtual offsets)
     __device__ int enter(const WalkView& v, int block) {
         k = block;
         if (!walk_block_ok(v, k)) return WALK_BAD_BLOCK;
@@ -786,11 +770,11 @@ struct WalkCursor {
         size = walk_uniform64(v.ooff[k + 1]) - first;
         coff = walk_uniform64(v.bcoff[k]);
         clen = (int64_t)walk_uniform((uint32_t)v.bclen[k]);
+        here = (uint64_t)coff << 16;
+        next = (uint64_t)(coff + clen) << 16;
         return WALK_OK;
     }
-    __device__ uint64_t tell() const {                                     // bamread.cpp bg_tell
-        return upos >= size ? (uint64_t)(coff + clen) << 16 : ((uint64_t)coff << 16) | (uint64_t)upos;
-    }
+    __device__ uint64_t tell() const { return upos >= size ? next : here | (uint64_t)upos; }   // bamread.cpp bg_tell
     // the next n bytes of the file: blocks that follow each other in the file follow each other in `out`, so the bytes lie
     // in one piece at *addr; the position moves as bamread.cpp's bg_read moves it
     __device__ int take(const WalkView& v, const tredgpu_walk_task& T, int64_t n, int64_t* addr) {
@@ -823,7 +807,15 @@ struct WalkProf {
 #endif
 };
 
-// Every lane runs this with the same values (the region's walk); only lane 0 writes to global memory.
+// The region's walk, a batch of records at a time:
+//   chain    every lane alike, on the scalar unit: from the current position follow the length words through the window and
+//            note where up to BATCH records start (lane j keeps record j's place) -- all that is serial about a BAM;
+//   parse    lane j reads ITS record's head: fields, CIGAR (end on the reference, soft clips), name hash -- the ~600
+//            instructions a record costs are spent once per batch, not once per record (a lone wavefront issues an
+//            instruction every ~5 cycles: the all-lanes-alike walk took 4 600 cycles per record);
+//   resolve  ballots say where the walk stops, which records count for the window, which enter the pair table; only
+//            those go through the table one after the other (probe in LDS, the owning lane writes its fields out).
+constexpr int WALK_BATCH = 32;
 __device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk* chunks, WalkLds& S, WalkReader& rd,
                                    WalkPair* pairs, WalkRepeat* repeats, int* n_pairs, int* n_repeats, tredgpu_walk_result& R, int lane,
                                    WalkProf& prof) {
@@ -838,112 +830,139 @@ __device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T
         int rc = cur.enter(v, ch.begin_block);
         if (rc) return rc;
         cur.upos = ch.begin_upos;
-        for (;;) {
-            const uint64_t at = cur.tell();
-            if (at >= ch.end_voffset) break;
-            int64_t a0, r;
-            if ((rc = cur.take(v, T, 4, &a0)) != 0) return rc;
-            prof.mark(0);
-            if (!rd.inside(a0, WALK_HEAD)) rd.fill(a0);
-            prof.mark(1);
-            WalkHead hd;
-            hd.load(rd, a0);                                               // offsets from a0: the record itself starts at 4
-            const int32_t size = (int32_t)hd.u32(0);
-            if (size < 32) return WALK_BAD_RECORD;
-            if ((rc = cur.take(v, T, size, &r)) != 0) return rc;
-            const int32_t rtid = (int32_t)hd.u32(4), rpos = (int32_t)hd.u32(8);
-            if (rtid != T.tid || rpos >= T.end) {
-                if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) break;
-                continue;
-            }
-            const uint32_t l_name = hd.u8(12), n_cigar = hd.u16(16), flag = hd.u16(18);
-            const int32_t l_seq = (int32_t)hd.u32(20);
-            if (l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)size) return WALK_BAD_RECORD;
-            hd.need(36 + (int)l_name + 4 * (int)n_cigar);
-            const int cig = 36 + (int)l_name;
-            int32_t rend = -1;
-            if (!(flag & 0x4) && n_cigar > 0) {
-                int64_t e = rpos;
-                for (uint32_t q = 0; q < n_cigar; ++q) {
-                    const uint32_t op = hd.u32(cig + 4 * (int)q);
-                    if ((0x18Du >> (op & 15)) & 1) e += op >> 4;           // M D N = X consume the reference
+        bool chunk_done = false;
+        while (!chunk_done) {
+            // ---- chain ----
+            int nb = 0, err = WALK_OK;
+            int64_t my_a0 = 0;
+            uint64_t my_at = 0, my_after = 0;
+            int32_t my_size = 0;
+            while (nb < WALK_BATCH) {
+                const uint64_t at = cur.tell();
+                if (at >= ch.end_voffset) { chunk_done = true; break; }
+                int64_t a0, r;
+                const bool word_here = cur.upos + 4 <= cur.size;           // (nearly always: the length word lies in this block)
+                const WalkCursor before = cur;
+                if (word_here) { a0 = cur.first + cur.upos; cur.upos += 4; }
+                else if ((rc = cur.take(v, T, 4, &a0)) != 0) { err = rc; break; }
+                if (!rd.inside(a0, WALK_HEAD)) {
+                    if (nb > 0) { cur = before; break; }                   // the next batch starts with a fresh window
+                    rd.fill(a0);
                 }
-                rend = (int32_t)e;
+                const int32_t size = (int32_t)rd.u32(a0);
+                if (size < 32) { err = WALK_BAD_RECORD; break; }
+                if (cur.upos + size <= cur.size) cur.upos += size;         // (and so does the record)
+                else if ((rc = cur.take(v, T, size, &r)) != 0) { err = rc; break; }
+                const uint64_t after = cur.tell();
+                if (lane == nb) { my_a0 = a0; my_at = at; my_after = after; my_size = size; }
+                ++nb;
             }
+            if (err != WALK_OK) chunk_done = true;                         // (decided below: the walk may stop before that record)
+            prof.mark(0);
+            // ---- parse: lane j, record j ----
+            const bool mine = lane < nb;
+            int32_t rtid = 0, rpos = 0, rend = -1, lead = 0, trail = 0;
+            uint32_t flag = 0, nlen = 0, h = 0;
+            bool bad = false;
+            if (mine) {
+                const int64_t r = my_a0 + 4;
+                rtid = (int32_t)rd.vu32(r);
+                rpos = (int32_t)rd.vu32(r + 4);
+                const uint32_t l_name = rd.vu8(r + 8), n_cigar = rd.vu16(r + 12);
+                flag = rd.vu16(r + 14);
+                const int32_t l_seq = (int32_t)rd.vu32(r + 16);
+                bad = l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)my_size;
+                if (!bad) {
+                    const int64_t cig = r + 32 + l_name;
+                    if (!(flag & 0x4) && n_cigar > 0) {
+                        int64_t e = rpos;
+                        for (uint32_t q = 0; q < n_cigar; ++q) {
+                            const uint32_t op = rd.vu32(cig + 4 * q);
+                            if ((0x18Du >> (op & 15)) & 1) e += op >> 4;   // M D N = X consume the reference
+                        }
+                        rend = (int32_t)e;
+                    }
+                    for (uint32_t q = 0; q < n_cigar; ++q) {               // query_alignment_start: leading soft clips
+                        const uint32_t op = rd.vu32(cig + 4 * q);
+                        if ((op & 15) == 4) lead += (int32_t)(op >> 4);
+                        else if ((op & 15) == 5) continue;
+                        else break;
+                    }
+                    for (int q = (int)n_cigar - 1; q >= 0; --q) {          // query_length - query_alignment_end
+                        const uint32_t op = rd.vu32(cig + 4 * q);
+                        if ((op & 15) == 4) trail += (int32_t)(op >> 4);
+                        else if ((op & 15) == 5) continue;
+                        else break;
+                    }
+                    nlen = l_name > 0 ? l_name - 1 : 0;
+                    h = 2166136261u ^ nlen;                                // (any hash will do: names are compared byte for byte at the end)
+                    for (uint32_t q = 0; q < nlen; ++q) h = (h ^ rd.vu8(r + 32 + q)) * 16777619u;
+                    h ^= h >> 15;
+                    h *= 0x2C1B3C6Du;
+                    h ^= h >> 12;
+                }
+            }
+            prof.mark(1);
+            // ---- resolve ----
+            const bool off_region = mine && (rtid != T.tid || rpos >= T.end);
+            const bool stops = off_region && (rtid > T.tid || (rtid == T.tid && rpos >= T.end));
+            const uint64_t stop_mask = __ballot(stops), bad_mask = __ballot(mine && !off_region && bad);
+            const int first_stop = stop_mask ? __builtin_ctzll(stop_mask) : 64, first_bad = bad_mask ? __builtin_ctzll(bad_mask) : 64;
+            const int limit = first_stop < first_bad ? first_stop : first_bad;          // records [0, limit) count
             const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
-            if (!(e > T.start)) continue;
-            if (rpos < T.win_hi && e > T.win_lo) {                         // a record of the scan's own window
-                if (nwin == 0) vbeg = at;
-                ++nwin;
-                vend = cur.tell();
+            const bool keep = mine && lane < limit && !off_region && e > T.start;
+            const uint64_t win_mask = __ballot(keep && rpos < T.win_hi && e > T.win_lo);
+            if (win_mask) {                                                // records of the scan's own window
+                const int wf = __builtin_ctzll(win_mask), wl = 63 - __builtin_clzll(win_mask);
+                if (nwin == 0) vbeg = walk_lane64(my_at, wf);
+                vend = walk_lane64(my_after, wl);
+                nwin += __popcll(win_mask);
+            }
+            // PairTable::add, in file order
+            uint64_t todo = __ballot(keep && (flag & 0x1) && !(flag & 0x4) && !(flag & 0x400));
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
+                uint32_t tag = hj >> 13;
+                if (tag == 0) tag = 1;
+                uint32_t slot = hj & (WALK_SLOTS - 1);
+                int idx = -1;
+                for (;; slot = (slot + 1) & (WALK_SLOTS - 1)) {
+                    const uint32_t entry = walk_uniform(S.table[slot]);
+                    if (entry == 0) break;
+                    if ((entry >> 13) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); break; }
+                }
+                int seen = 0;
+                if (idx < 0) {
+                    if (np >= WALK_PAIR_CAP) return WALK_TABLE_FULL;
+                    idx = np++;
+                    if (lane == j) S.table[slot] = (tag << 13) | (uint32_t)idx;
+                } else {
+                    seen = (int)walk_uniform(S.seen[idx]);
+                }
+                if (seen >= 2 && nrep >= WALK_REPEAT_CAP) return WALK_TABLE_FULL;
+                if (lane == j) {
+                    if (seen == 0) {
+                        WalkPair& P = pairs[idx];
+                        P.name_at = my_a0 + 36; P.name_len = (uint16_t)nlen;
+                        P.a_pos = rpos; P.a_lead = lead; P.a_rev = (flag & 0x10) ? 1 : 0;
+                    } else if (seen == 1) {
+                        WalkPair& P = pairs[idx];
+                        P.name2_at = my_a0 + 36;
+                        P.b_end = rend; P.b_trail = trail; P.b_rev = (flag & 0x10) ? 1 : 0;
+                    } else {                                                // the pair is complete: only the name matters
+                        repeats[nrep].pair = idx; repeats[nrep].name_at = my_a0 + 36;
+                    }
+                    if (seen < 3) S.seen[idx] = (uint8_t)(seen + 1);
+                }
+                if (seen >= 2) ++nrep;
+                walk_lds_order();
             }
             prof.mark(2);
-            // PairTable::add
-            if (!(flag & 0x1) || (flag & 0x4) || (flag & 0x400)) continue;
-            const uint32_t nlen = l_name > 0 ? l_name - 1 : 0;
-            uint32_t h = 2166136261u ^ nlen;
-            for (uint32_t q = 0; q < nlen; q += 4) {                       // four name bytes per step (any hash will do: the names
-                uint32_t word = hd.u32(36 + (int)q);                       // are compared byte for byte at the end)
-                if (nlen - q < 4) word &= (1u << (8 * (nlen - q))) - 1;
-                h = (h ^ word) * 0x9E3779B1u;
-                h ^= h >> 15;
-            }
-            h *= 0x2C1B3C6Du;
-            h ^= h >> 12;
-            uint32_t tag = h >> 13;
-            if (tag == 0) tag = 1;
-            uint32_t slot = h & (WALK_SLOTS - 1);
-            int idx = -1;
-            for (;; slot = (slot + 1) & (WALK_SLOTS - 1)) {
-                const uint32_t entry = walk_uniform(S.table[slot]);
-                if (entry == 0) break;
-                if ((entry >> 13) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); break; }
-            }
-            if (idx < 0) {
-                if (np >= WALK_PAIR_CAP) return WALK_TABLE_FULL;
-                idx = np++;
-                walk_lds_order();
-                if (lane == 0) { S.table[slot] = (tag << 13) | (uint32_t)idx; S.seen[idx] = 0; }
-                walk_lds_order();
-            }
-            const int seen = (int)walk_uniform(S.seen[idx]);
-            prof.mark(3);
-            if (seen < 2) {
-                int32_t clip = 0;
-                if (seen == 0) {
-                    for (uint32_t q = 0; q < n_cigar; ++q) {               // query_alignment_start: leading soft clips
-                        const uint32_t op = hd.u32(cig + 4 * (int)q);
-                        if ((op & 15) == 4) clip += (int32_t)(op >> 4);
-                        else if ((op & 15) == 5) continue;
-                        else break;
-                    }
-                } else {
-                    for (int q = (int)n_cigar - 1; q >= 0; --q) {          // query_length - query_alignment_end
-                        const uint32_t op = hd.u32(cig + 4 * q);
-                        if ((op & 15) == 4) clip += (int32_t)(op >> 4);
-                        else if ((op & 15) == 5) continue;
-                        else break;
-                    }
-                }
-                if (lane == 0) {
-                    WalkPair& P = pairs[idx];
-                    if (seen == 0) {
-                        P.name_at = r + 32; P.name_len = (uint16_t)nlen;
-                        P.a_pos = rpos; P.a_lead = clip; P.a_rev = (flag & 0x10) ? 1 : 0;
-                    } else {
-                        P.name2_at = r + 32;
-                        P.b_end = rend; P.b_trail = clip; P.b_rev = (flag & 0x10) ? 1 : 0;
-                    }
-                }
-            } else {                                                        // the pair is complete: only the name matters
-                if (nrep >= WALK_REPEAT_CAP) return WALK_TABLE_FULL;
-                if (lane == 0) { repeats[nrep].pair = idx; repeats[nrep].name_at = r + 32; }
-                ++nrep;
-            }
-            walk_lds_order();
-            if (lane == 0 && seen < 3) S.seen[idx] = (uint8_t)(seen + 1);
-            walk_lds_order();
-            prof.mark(4);
+            if (first_bad < first_stop) return WALK_BAD_RECORD;
+            if (first_stop < 64) { chunk_done = true; err = WALK_OK; }     // the walk over this chunk ended before any trouble
+            if (err != WALK_OK) return err;
         }
     }
     *n_pairs = np; *n_repeats = nrep;
@@ -1042,8 +1061,7 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
     }
     prof.mark(5);
 #ifdef WALK_PROF
-    R.global_first = (int64_t)prof.acc[0]; R.target_first = (int64_t)prof.acc[1]; R.win_vbeg = prof.acc[2]; R.win_vend = prof.acc[3];
-    R.n_global = (int32_t)(prof.acc[4] >> 4); R.n_target = (int32_t)(prof.acc[5] >> 4);
+    R.global_first = (int64_t)prof.acc[0]; R.target_first = (int64_t)prof.acc[1]; R.win_vbeg = prof.acc[2]; R.win_vend = prof.acc[5];
 #endif
     if (lane == 0) {
         R.status = status;

@@ -363,7 +363,7 @@ class _InflateFeeder(object):
                         status, crc, walked = self._run_walk(inf, job)
                     else:
                         status, crc = inf.run(job["n_all"], crc=True)
-                    timing_add(inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
+                        timing_add(inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
                 except Exception as e:
                     logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
                     status = crc = None
@@ -407,7 +407,8 @@ class _InflateFeeder(object):
             a = p["first"]
             need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])])
         inf.fetch(need)
-        timing_add(walk_regions=len(res), walk_declined=int((res["status"] != 0).sum()), walk_blocks_fetched=int(need.sum()))
+        timing_add(walk_regions=len(res), walk_declined=int((res["status"] != 0).sum()), walk_blocks_fetched=int(need.sum()),
+                   inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
         return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp)
 
     def _put(self, item):
