@@ -627,18 +627,22 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
         for n_devices in device_counts:
             legs = []
             n_files = n_devices * per_gpu[n_devices]
-            plans = [(d, t, False) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads)]
+            walk_on = getattr(args, "e2e_gpu_walk", "1") == "1"
+            plans = [(d, t, False, False) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads)]
             if args.e2e_gpu_inflate in ("1", "both"):
-                # the same plans (and a denser one) with the BGZF blocks inflated on the GPU, a batch of samples per launch
-                with_gpu = [(d, t, True) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads, dense=True)]
+                # the same plans (and denser ones) with the BGZF blocks inflated on the GPU, a batch of samples per launch, and
+                # the pair-length walks done there too; the densest plan once more with the walks left to the host
+                with_gpu = [(d, t, True, walk_on) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads, dense=True)]
+                if walk_on and not args.e2e_drivers:
+                    with_gpu.append(with_gpu[-1][:3] + (False,))
                 plans = with_gpu if args.e2e_gpu_inflate == "1" else plans + with_gpu
-            for drivers, threads, gpu_inflate in plans:
+            for drivers, threads, gpu_inflate, gpu_walk in plans:
                 batch = args.e2e_inflate_batch if gpu_inflate else args.e2e_batch
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
                         "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
                         "--e2e-repeat", str(args.e2e_repeat), "--e2e-genotype-chunks", str(getattr(args, "e2e_genotype_chunks", 1)),
-                        "--e2e-gpu-walk", getattr(args, "e2e_gpu_walk", "1") if gpu_inflate else "0"]
-                out_dir = os.path.join(root, "out{}x{}{}".format(n_devices, drivers, "g" if gpu_inflate else ""))
+                        "--e2e-gpu-walk", "1" if gpu_walk else "0"]
+                out_dir = os.path.join(root, "out{}x{}{}{}".format(n_devices, drivers, "g" if gpu_inflate else "", "w" if gpu_walk else ""))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
                 codes = spawn(argv, drivers, n_devices, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
@@ -652,7 +656,7 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
                 units, secs = sum(r["units"] for r in ranks), max(r["seconds"] for r in ranks)
                 nbytes = sum(r["bam_bytes"] for r in ranks)
                 legs.append({"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate,
-                             "gpu_walk": bool(gpu_inflate and getattr(args, "e2e_gpu_walk", "1") == "1"), "samples_per_gpu_batch": batch,
+                             "gpu_walk": gpu_walk, "samples_per_gpu_batch": batch,
                              "value": units / secs, "unit": "genotypes/s",
                              "units": units, "seconds": secs, "samples": sum(r["samples"] for r in ranks),
                              "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,
@@ -677,7 +681,7 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
             if host_one:
                 rec["host_only_one_driver_per_gpu"] = {k: host_one[0][k] for k in ("value", "first_pass_value", "seconds", "samples")}
             rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
-                           "native scan (BGZF inflate -- on the host, or on the GPU a batch of samples per launch in the `gpu_inflate` legs --, BAI queries, read selection, pair lengths, depth) in host threads -> "
+                           "native scan (BGZF inflate -- on the host, or on the GPU a batch of samples per launch in the `gpu_inflate` legs --, BAI queries, read selection, pair lengths -- walked on the GPU over the inflated blocks in the `gpu_walk` legs, only the blocks of the loci's windows and alternative loci coming back --, depth) in host threads -> "
                            "GPU batches -> tredCalls -> JSON + VCF files; `drivers` processes over `devices` GPUs (rank r on "
                            "device r mod devices), each with its block of the samples and its share of the host CPUs "
                            "(tred.py --gpus N uses the same fan-out)")

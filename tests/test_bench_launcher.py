@@ -124,9 +124,9 @@ def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
         return plain_spawn(argv, *a, **k)
     args.e2e_gpu_inflate = "both"
     recs = bench.run_e2e(args, [1], spawn=flag_spawn, make_bams=fake_bams)
-    assert flags == [("0", "16")] * 3 + [("1", "32")] * 6           # (the GPU legs add plans with a driver per four, three and 2.7 CPUs)
-    assert [l["gpu_inflate"] for l in recs[1]["legs"]] == [False] * 3 + [True] * 6
-    assert [l["gpu_walk"] for l in recs[1]["legs"]] == [False] * 3 + [True] * 6
+    assert flags == [("0", "16")] * 3 + [("1", "32")] * 7           # (the GPU legs add plans with a driver per four, three and 2.7 CPUs)
+    assert [l["gpu_inflate"] for l in recs[1]["legs"]] == [False] * 3 + [True] * 7
+    assert [l["gpu_walk"] for l in recs[1]["legs"]] == [False] * 3 + [True] * 6 + [False]     # (the last plan again, walks on the host)
     assert bench.e2e_plan(1, 16, dense=True) == [(1, 15), (2, 7), (3, 5), (4, 3), (5, 3), (6, 3)]
 
 

@@ -29,7 +29,19 @@ def synthetic(tmp_path_factory):
     root = tmp_path_factory.mktemp("walk")
     loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1", "FRDA", "AR", "FXS", "SCA17")]
     made = synth_bam.make_bams(str(root), 2, seed=91, loci=loci, p=synth.SynthParams(coverage=30, expanded_max=120, expanded_frac=0.3))
-    return [(path, TREDsRepo(), [l["name"] for l in loci]) for _, path, _ in made]
+    out = [(path, TREDsRepo(), [l["name"] for l in loci]) for _, path, _ in made]
+    # the same kind of sample in blocks cut without regard to records (every record straddles 300-byte blocks; samtools'
+    # files look like the 20 000-byte one), some reads marked duplicate / unpaired / strand-flipped
+    recs, _ = synth_bam.simulate_sample(92, loci[:4], synth.SynthParams(coverage=20, expanded_max=120, expanded_frac=0.3))
+    rng = np.random.default_rng(92)
+    recs.flag[rng.random(len(recs.flag)) < 0.03] |= 0x400
+    recs.flag[rng.random(len(recs.flag)) < 0.02] &= ~0x1
+    recs.flag[rng.random(len(recs.flag)) < 0.05] ^= 0x10
+    for block in (300, 20000):
+        path = os.path.join(str(root), "cut{}.bam".format(block))
+        synth_bam.write_bam(path, recs, sample="cut", block=block, split_records=True)
+        out.append((path, TREDsRepo(), [l["name"] for l in loci[:4]]))
+    return out
 
 
 def _window_span(path, chrom, p_lo, p_hi, w_lo, w_hi):

@@ -42,6 +42,15 @@ def cohort(tmp_path_factory):
     srepo = TREDsRepo()
     args = [(s, os.path.join(GOLD, "bam", s + ".bam"), repo, sorted(repo.names), 300, False, False, True, True, "ERROR") for s in ("t001", "t002")]
     args += [(key, path, srepo, [l["name"] for l in loci], 300, False, False, True, True, "ERROR") for key, path, _ in made]
+    # blocks cut without regard to records: every record straddles the 300-byte ones
+    recs, _ = synth_bam.simulate_sample(6, loci[:2], synth.SynthParams(coverage=8, expanded_max=120, expanded_frac=0.3))
+    rng = np.random.default_rng(6)
+    recs.flag[rng.random(len(recs.flag)) < 0.03] |= 0x400
+    recs.flag[rng.random(len(recs.flag)) < 0.05] ^= 0x10
+    for block in (300, 20000):
+        path = os.path.join(str(root), "cut{}.bam".format(block))
+        synth_bam.write_bam(path, recs, sample="cut", block=block, split_records=True)
+        args.append(("cut{}".format(block), path, srepo, [l["name"] for l in loci[:2]], 300, False, False, True, True, "ERROR"))
     args.append(("missing", os.path.join(str(root), "no_such.bam"), repo, ["HD"], 300, False, False, True, True, "ERROR"))
     return args
 
@@ -54,7 +63,7 @@ def test_feeder_with_walked_pair_lengths_gives_the_plain_scans(cohort, monkeypat
     del ModelInflater.made[:]
     for k in t.TIMING:
         t.TIMING[k] = 0
-    chunks = [cohort[:2], cohort[2:4], cohort[4:]]
+    chunks = [cohort[:2], cohort[2:4], cohort[4:6], cohort[6:]]
     ex = ThreadPoolExecutor(max_workers=2)
     feeder = t._InflateFeeder(chunks, ex, 0, walk=True)
     try:
@@ -68,10 +77,10 @@ def test_feeder_with_walked_pair_lengths_gives_the_plain_scans(cohort, monkeypat
         o = t._options(a)
         _same(s, scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"]))
     tm = t.TIMING
-    assert tm["walk_regions"] == sum(len(a[3]) for a in cohort[:4]) and tm["walk_declined"] == 0
+    assert tm["walk_regions"] == sum(len(a[3]) for a in cohort[:6]) and tm["walk_declined"] == 0
     assert 0 < tm["walk_blocks_fetched"] < tm["inflate_blocks"]
     assert tm["inflate_misses"] == 0 and tm["inflate_hits"] > 0          # no scan inflated a block for itself
-    assert sum(m.walks for m in ModelInflater.made) == 2                 # (the chunk with the missing file has nothing to decode)
+    assert sum(m.walks for m in ModelInflater.made) == 3                 # (the chunk with the missing file has nothing to decode)
 
 
 def test_regions_the_walker_declines_are_walked_by_the_scan(cohort, monkeypatch):

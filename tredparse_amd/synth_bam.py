@@ -245,8 +245,10 @@ def _bgzf_block(data, level):
 _EOF_BLOCK = _bgzf_block(b"", 6)
 
 
-def write_bam(path, recs, sample="s", level=1, block=0xff00):
-    """Write `recs` (sorted) as <path> and <path>.bai.  Returns the number of uncompressed bytes."""
+def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False):
+    """Write `recs` (sorted) as <path> and <path>.bai.  Returns the number of uncompressed bytes.  split_records: cut the
+    record stream into blocks of `block` bytes wherever that falls (records then straddle blocks, as in files written by
+    samtools) instead of at record boundaries."""
     n = len(recs)
     L = recs.codes.shape[1]
     names = recs.names(sample)
@@ -297,6 +299,24 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00):
         header += struct.pack("<i", len(c) + 1) + c.encode() + b"\x00" + struct.pack("<i", CONTIG_LEN)
     # blocks: the header alone, then whole records
     blob = flat.tobytes()
+    if split_records:
+        starts = list(range(0, len(blob), block)) or [0]
+        voff = np.zeros(n + 1, np.int64)
+        with open(path, "wb") as fp:
+            fp.write(_bgzf_block(header, level))
+            co = []
+            for a in starts:
+                co.append(fp.tell())
+                fp.write(_bgzf_block(blob[a:a + block], level))
+            co.append(fp.tell())
+            fp.write(_EOF_BLOCK)
+        co = np.array(co, np.int64)
+        which = np.minimum(off // block, len(starts) - 1)                  # a position at a block's end is the next block's start
+        which = np.where(off >= len(blob), len(starts), which)
+        inside = np.where(which < len(starts), off - which * block, 0)
+        v = (co[which] << 16) | inside
+        _write_bai(path + ".bai", recs.tid, recs.pos.astype(np.int64), end_for_bin, bins, v[:-1], v[1:])
+        return len(blob)
     cuts = [0]
     while cuts[-1] < n:
         k = int(np.searchsorted(off, off[cuts[-1]] + block, side="right")) - 1
