@@ -4,7 +4,12 @@ synthetic 30x samples and prints the mean cycles per region of each phase of the
 
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DWALK_PROF -shared -o tools/_ab/libtredgpu_walkprof.so \\
         tredparse_amd/csrc/{capi,sw_ladder,grid,inflate}.hip
-  python tools/walk_prof.py [samples = 16] [library = tools/_ab/libtredgpu_walkprof.so]
+  python tools/walk_prof.py [samples = 16] [library = tools/_ab/libtredgpu_walkprof.so] [directory of BAMs made before]
+
+With the production library as second argument the phase columns are meaningless but the launch is the production one:
+`rocprofv3 --kernel-trace --stats -- python3 tools/walk_prof.py 56 tredparse_amd/libtredgpu.so <dir>` is how the kernel's
+rocprofv3 summary under profiles/ is taken (the BAMs made beforehand with `python tools/walk_prof.py make <dir>`: a
+process under the profiler must not fork the workers that write them).
 """
 import glob
 import json
@@ -18,13 +23,21 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "make":
+        from tredparse_amd import synth_bam
+        os.makedirs(sys.argv[2], exist_ok=True)
+        synth_bam.make_bams(sys.argv[2], 4, seed=7, workers=4)
+        return
     from tredparse_amd import _lib
     m = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     _lib.LIB_PATH = os.path.abspath(sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(__file__), "_ab", "libtredgpu_walkprof.so"))
     from tredparse_amd import bam_parser, synth_bam
     from tredparse_amd.meta import TREDsRepo
-    root = tempfile.mkdtemp(prefix="tred_walkprof_")
-    synth_bam.make_bams(root, 4, seed=7, workers=4)
+    if len(sys.argv) > 3:
+        root = sys.argv[3]
+    else:
+        root = tempfile.mkdtemp(prefix="tred_walkprof_")
+        synth_bam.make_bams(root, 4, seed=7, workers=4)
     bams = sorted(glob.glob(os.path.join(root, "*.bam")))
     repo = TREDsRepo("hg38", sites=os.path.join(root, "no_sites"))
     names = [l["name"] for l in synth_bam.bench_loci()]
