@@ -700,8 +700,11 @@ struct WalkView {
 struct WalkPair { int64_t name_at, name2_at; int32_t a_pos, a_lead, b_end, b_trail; uint16_t name_len; uint8_t a_rev, b_rev, pad[4]; };
 static_assert(sizeof(WalkPair) == 40, "WalkPair layout");
 struct WalkRepeat { int32_t pair; int32_t pad; int64_t name_at; };   // a third, fourth ... record under a pair's tag
-constexpr int WALK_PAIR_CAP = 8192;               // names per region (a +-10 kb window at 30x holds ~2 100)
-constexpr int WALK_SLOTS = 2 * WALK_PAIR_CAP;     // open addressing at a load below one half
+constexpr int WALK_PAIR_CAP = 8192;               // names per region at most (a +-10 kb window at 30x holds ~2 100) ...
+constexpr int WALK_PAIR_CAP_SMALL = 4096;         // ... and what a launch whose regions are all short is given: 42 instead of
+                                                  // 78 KB of LDS per wavefront, so that other kernels' workgroups -- the
+                                                  // decoder's, the genotyping kernels' of the other driver processes -- still
+                                                  // find LDS on the CUs a walk occupies (two walks of 78 KB fill a CU's 160 KB)
 constexpr int WALK_REPEAT_CAP = 2048;
 constexpr int WALK_WINDOW = 6144;                 // bytes of the block stream in LDS
 constexpr int WALK_HEAD = 512;                    // a record's head (fixed fields, name, CIGAR) should lie in the window
@@ -715,11 +718,18 @@ enum { WALK_OK = 0, WALK_NOT_PLANNED = 1, WALK_BAD_BLOCK = 2, WALK_BAD_RECORD = 
 // accesses across the point.
 __device__ inline void walk_lds_order() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
-struct WalkLds {
-    uint32_t table[WALK_SLOTS];                   // 0: free; else tag << 13 | pair index, tag != 0
-    uint8_t seen[WALK_PAIR_CAP];                  // records under the pair's tag so far (saturates)
-    alignas(16) uint8_t window[WALK_WINDOW];
+// (LDS pointers keep their address space through the struct: as plain pointers they became flat_load / flat_store)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef uint32_t walk_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) walk_u32x4 lds_u128;
+struct WalkLds {                                  // (views into the launch's dynamic LDS: walk_lds_bytes(cap))
+    lds_u32* table;                               // 2 * cap slots, open addressing at a load below one half.  0: free; else tag << 13 | pair index, tag != 0
+    lds_u8* seen;                                 // cap: records under the pair's tag so far (saturates)
+    lds_u8* window;                               // WALK_WINDOW bytes, 16-byte aligned
+    int cap; uint32_t mask;
 };
+constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 8 + (size_t)cap + WALK_WINDOW; }
 
 // Every lane holds the same value: say so (v_readfirstlane), and what is computed from it is computed once, on the
 // scalar unit, with scalar branches -- not 64 times on the vector unit with the exec mask rebuilt at every `if`.
@@ -738,7 +748,7 @@ struct WalkReader {
         walk_lds_order();                                        // (earlier reads of the window are done)
         for (int q = 0; q < WALK_WINDOW / (LANES * 16); ++q) {
             const int o = (q * LANES + lane) * 16;
-            if (base + o + 16 <= out_end) *(uint4*)(S->window + o) = *(const uint4*)(out + base + o);
+            if (base + o + 16 <= out_end) *(lds_u128*)(S->window + o) = *(const walk_u32x4*)(out + base + o);
         }
         walk_lds_order();
     }
@@ -751,7 +761,7 @@ struct WalkReader {
     __device__ uint32_t u8(int64_t at) const { return walk_uniform(inside(at, 1) ? S->window[at - base] : out[at]); }
     __device__ uint32_t u16(int64_t at) const { return u8(at) | (u8(at + 1) << 8); }
     __device__ uint32_t u32(int64_t at) const {
-        if (inside(at, 4)) { const uint8_t* p = S->window + (at - base); return walk_uniform((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+        if (inside(at, 4)) { const lds_u8* p = S->window + (at - base); return walk_uniform((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
         uint32_t v; __builtin_memcpy(&v, out + at, 4); return walk_uniform(v);
     }
 };
@@ -926,16 +936,16 @@ __device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T
                 const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
                 uint32_t tag = hj >> 13;
                 if (tag == 0) tag = 1;
-                uint32_t slot = hj & (WALK_SLOTS - 1);
+                uint32_t slot = hj & S.mask;
                 int idx = -1;
-                for (;; slot = (slot + 1) & (WALK_SLOTS - 1)) {
+                for (;; slot = (slot + 1) & S.mask) {
                     const uint32_t entry = walk_uniform(S.table[slot]);
                     if (entry == 0) break;
                     if ((entry >> 13) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); break; }
                 }
                 int seen = 0;
                 if (idx < 0) {
-                    if (np >= WALK_PAIR_CAP) return WALK_TABLE_FULL;
+                    if (np >= S.cap) return WALK_TABLE_FULL;
                     idx = np++;
                     if (lane == j) S.table[slot] = (tag << 13) | (uint32_t)idx;
                 } else {
@@ -985,11 +995,18 @@ __device__ inline bool walk_same_name(const uint8_t* out, int64_t a, int64_t b, 
 
 __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
                                                           tredgpu_walk_result* results, WalkPair* pairs_all, WalkRepeat* repeats_all, int32_t* gpool,
-                                                          int64_t cap_g, int32_t* tpool, int64_t cap_t, unsigned long long* counters) {
-    __shared__ WalkLds S;
+                                                          int64_t cap_g, int32_t* tpool, int64_t cap_t, unsigned long long* counters,
+                                                          int table_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t walk_lds[];
     __shared__ int64_t firsts[2];
     const int t = blockIdx.x, lane = threadIdx.x;
-    for (int k = lane; k < WALK_SLOTS; k += LANES) S.table[k] = 0;
+    WalkLds S;
+    S.cap = table_cap;
+    S.mask = 2u * (uint32_t)table_cap - 1;
+    S.window = (lds_u8*)walk_lds;
+    S.table = (lds_u32*)(S.window + WALK_WINDOW);
+    S.seen = S.window + WALK_WINDOW + (size_t)table_cap * 8;
+    for (int k = lane; k < 2 * table_cap; k += LANES) S.table[k] = 0;
     WalkPair* pairs = pairs_all + (size_t)t * WALK_PAIR_CAP;
     WalkRepeat* repeats = repeats_all + (size_t)t * WALK_REPEAT_CAP;
     const tredgpu_walk_task T = tasks[t];
@@ -1095,6 +1112,7 @@ struct tredgpu_inflater {
     hipStream_t wstream = nullptr;
     hipEvent_t wdone = nullptr, w0 = nullptr, w1 = nullptr, decoded[2] = {nullptr, nullptr};
     bool walk_timed = false;
+    int walk_table_cap = 0;
     uint8_t* d_wblk = nullptr;  size_t cap_wblk = 0;        // bcoff[n] int64, then bclen[n] int32, then xcrc[n] uint32
     uint8_t* h_wblk = nullptr;                               // pinned, same layout
     uint8_t* d_wtask = nullptr; uint8_t* h_wtask = nullptr; size_t cap_wtask = 0;   // tasks then chunks
@@ -1356,9 +1374,31 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         v.out_end = ooff[n_blocks] + 48;                   // (the buffers hold 64 bytes more than reserved)
         ICHK(f, hipEventRecord(f->w0, f->wstream));
         if (n_tasks > 0) {
-            pair_walk_kernel<<<(unsigned)n_tasks, LANES, 0, f->wstream>>>(v, (const tredgpu_walk_task*)f->d_wtask,
+            // the small table when every region is short: a region of up to 40 blocks (2.6 MB of records, ~8 000 of them)
+            // has at most ~4 000 names; one that has more after all is handed back to the host (status 4)
+            int table_cap = WALK_PAIR_CAP_SMALL;
+            for (size_t t = 0; t < n_tasks && table_cap == WALK_PAIR_CAP_SMALL; ++t) {
+                const tredgpu_walk_task& T = w->tasks[t];
+                int64_t span = 0;
+                for (int32_t q = 0; q < T.n_chunks; ++q) {
+                    const tredgpu_walk_chunk& ch = w->chunks[T.chunk_first + q];
+                    if (ch.begin_block < T.block_first || ch.begin_block >= T.block_end) continue;
+                    const int64_t* lo = w->blk_coffset + ch.begin_block;
+                    const int64_t* hi = std::upper_bound(lo, w->blk_coffset + T.block_end, (int64_t)(ch.end_voffset >> 16));
+                    span += hi - lo;
+                }
+                if (span > 40) table_cap = WALK_PAIR_CAP;
+            }
+            static bool big_lds_allowed = false;
+            if (!big_lds_allowed) {
+                ICHK(f, hipFuncSetAttribute((const void*)pair_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds_bytes(WALK_PAIR_CAP)));
+                big_lds_allowed = true;
+            }
+            f->walk_table_cap = table_cap;
+            pair_walk_kernel<<<(unsigned)n_tasks, LANES, walk_lds_bytes(table_cap), f->wstream>>>(v, (const tredgpu_walk_task*)f->d_wtask,
                 (const tredgpu_walk_chunk*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task)), (tredgpu_walk_result*)f->d_wres, f->d_wpairs,
-                f->d_wrepeats, f->d_gpool, w->cap_global, f->d_tpool, w->cap_target, (unsigned long long*)(f->d_wres + n_tasks * sizeof(tredgpu_walk_result)));
+                f->d_wrepeats, f->d_gpool, w->cap_global, f->d_tpool, w->cap_target, (unsigned long long*)(f->d_wres + n_tasks * sizeof(tredgpu_walk_result)),
+                table_cap);
             ICHK(f, hipGetLastError());
         }
         ICHK(f, hipEventRecord(f->w1, f->wstream));
