@@ -752,6 +752,26 @@ struct WalkReader {
         }
         walk_lds_order();
     }
+    // the next window, fetched while the batch at hand is parsed and resolved: the loads are issued (prefetch) once the
+    // chain knows where the next batch starts, and land in LDS (commit) when nothing reads the old window any more
+    walk_u32x4 ahead[WALK_WINDOW / (LANES * 16)];
+    int64_t ahead_base;
+    __device__ void prefetch(int64_t at) {
+        ahead_base = at & ~(int64_t)15;
+        for (int q = 0; q < WALK_WINDOW / (LANES * 16); ++q) {
+            const int o = (q * LANES + lane) * 16;
+            if (ahead_base + o + 16 <= out_end) ahead[q] = *(const walk_u32x4*)(out + ahead_base + o);
+        }
+    }
+    __device__ void commit() {
+        walk_lds_order();
+        for (int q = 0; q < WALK_WINDOW / (LANES * 16); ++q) {
+            const int o = (q * LANES + lane) * 16;
+            if (ahead_base + o + 16 <= out_end) *(lds_u128*)(S->window + o) = ahead[q];
+        }
+        base = ahead_base;
+        walk_lds_order();
+    }
     __device__ bool inside(int64_t at, int n) const { return at >= base && at + n <= base + WALK_WINDOW; }
     // (per lane: its own address)
     __device__ uint32_t vu8(int64_t at) const { return inside(at, 1) ? S->window[at - base] : out[at]; }
@@ -868,6 +888,8 @@ __device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T
                 ++nb;
             }
             if (err != WALK_OK) chunk_done = true;                         // (decided below: the walk may stop before that record)
+            const bool more = !chunk_done;
+            if (more) rd.prefetch(cur.first + cur.upos);                   // (at a block's end: the next block's first byte when it follows in the file)
             prof.mark(0);
             // ---- parse: lane j, record j ----
             const bool mine = lane < nb;
@@ -969,6 +991,7 @@ __device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T
                 if (seen >= 2) ++nrep;
                 walk_lds_order();
             }
+            if (more) rd.commit();
             prof.mark(2);
             if (first_bad < first_stop) return WALK_BAD_RECORD;
             if (first_stop < 64) { chunk_done = true; err = WALK_OK; }     // the walk over this chunk ended before any trouble
@@ -1010,7 +1033,8 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
     WalkPair* pairs = pairs_all + (size_t)t * WALK_PAIR_CAP;
     WalkRepeat* repeats = repeats_all + (size_t)t * WALK_REPEAT_CAP;
     const tredgpu_walk_task T = tasks[t];
-    WalkReader rd = {v.out, v.out_end, &S, (int64_t)1 << 60, lane};
+    WalkReader rd;
+    rd.out = v.out; rd.out_end = v.out_end; rd.S = &S; rd.base = (int64_t)1 << 60; rd.lane = lane; rd.ahead_base = (int64_t)1 << 60;
     tredgpu_walk_result R = {};
     int np = 0, nrep = 0;
     __syncthreads();
@@ -1315,6 +1339,8 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
                                     T.block_end > n_blocks || T.block_first > T.block_end))
                 return ifail(f, -2, "walk task outside its chunks / blocks");
         }
+        for (size_t q = 0; q < n_chunks; ++q)
+            if (w->chunks[q].begin_upos < 0 || w->chunks[q].begin_upos > 65536) return ifail(f, -2, "walk chunk starts outside a block");
         const size_t nb = (size_t)n_blocks;
         if (grow_pair(f, &f->h_wblk, &f->d_wblk, &f->cap_wblk, nb * 16 + 64)) return -10;
         if (grow_pair(f, &f->h_wtask, &f->d_wtask, &f->cap_wtask, n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk) + 64)) return -10;
