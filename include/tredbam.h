@@ -179,9 +179,9 @@ int tredbam_scan_pools(tredbam* b, tredbam_pools* pools);
  *                       that starts in a block the plan does not hold): the scan then computes that site itself.
  *                       Returns the number of chunks written, -3 when cap_chunks is too small.
  *   tredbam_plan_blocks per planned block (the plan is in file order): compressed offset, compressed length, the trailer's
- *                       CRC-32, and host[k] != 0 when the scan reads block k in any case (alternative loci, extra
- *                       regions).  With the walks done elsewhere only those and the blocks between a result's win_vbeg
- *                       and win_vend need to be handed to tredbam_preload.
+ *                       CRC-32, and host[k] != 0 when the scan reads block k in any case (bit 0: alternative loci, bit 1:
+ *                       extra regions).  With the walks done elsewhere only those and the blocks between a result's
+ *                       win_vbeg and win_vend need to be handed to tredbam_preload.
  *   tredbam_scan_pe     tredbam_scan with the pair lengths of site i taken from pe[i] (status == 0: n_global / n_target
  *                       values from global_first / target_first of the two pools, in PEextractor's order); the scan
  *                       then reads only the records between pe[i].win_vbeg and win_vend -- those of the locus' window,
@@ -204,6 +204,20 @@ typedef struct tredbam_walk_result {
 } tredbam_walk_result;
 int64_t tredbam_plan_walks(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_scan_opts* opts,
                            tredbam_walk_task* tasks, tredbam_walk_chunk* chunks, int64_t cap_chunks);
+/* The same for the walks over the alternative loci (BamParser.parse's mate rescue, bam_parser.py:226-243: per locus ~50
+ * small regions elsewhere in the genome, of whose records those count whose MATE lies in the locus' window): task
+ * alt_first + k of site i is the region alts[alt_first + k] with tstart = the site's contig and [win_lo, win_hi] = the
+ * window the mate must lie in (both ends included).  The walker returns per region the virtual offsets of the records
+ * that count (tredbam_alt_result, at most six: more, or any status, and the scan walks the region itself), and
+ * tredbam_scan_walked reads exactly those records -- each checked again to be what was promised.  In
+ * tredbam_plan_blocks' flags bit 0 marks the blocks of these regions (needed on the host only for regions the walker
+ * declined), bit 1 those of the caller's extra regions. */
+typedef struct tredbam_alt_result { int32_t status, n; uint64_t vbeg[6]; } tredbam_alt_result;
+int64_t tredbam_plan_alt_walks(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts, int32_t n_alts,
+                               const tredbam_scan_opts* opts, tredbam_walk_task* tasks, tredbam_walk_chunk* chunks, int64_t cap_chunks);
+int tredbam_scan_walked(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
+                        const tredbam_scan_opts* opts, const tredbam_walk_result* pe, const int32_t* pe_global,
+                        const int32_t* pe_target, const tredbam_alt_result* alt_results, tredbam_unit* units);
 int64_t tredbam_plan_blocks(tredbam* b, int64_t* coffset, int32_t* clen, uint32_t* crc, uint8_t* host);
 int tredbam_scan_pe(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
                     const tredbam_scan_opts* opts, const tredbam_walk_result* pe, const int32_t* pe_global,

@@ -354,7 +354,15 @@ typedef struct tredgpu_walk_args {
     int32_t* global_pool; int64_t cap_global;    /* out: the pair lengths (tasks take their room in any order)             */
     int32_t* target_pool; int64_t cap_target;
     int64_t n_global, n_target;             /* out: entries of the pools in use                                            */
+    /* the walks over the alternative loci (tredbam_plan_alt_walks; n_alt_tasks == 0: none): in a task tstart is the contig
+     * the MATE must lie on and [win_lo, win_hi] where (both ends included); results: status as above, and the virtual
+     * offsets of the records that count, in file order (more than six: status 6).  need[k] != 0: block k holds one.   */
+    const tredgpu_walk_task* alt_tasks;   int32_t n_alt_tasks;
+    const tredgpu_walk_chunk* alt_chunks; int32_t n_alt_chunks;
+    struct tredgpu_alt_result* alt_results; /* out: n_alt_tasks                                                            */
+    uint8_t* need;                          /* out: n_blocks                                                               */
 } tredgpu_walk_args;
+typedef struct tredgpu_alt_result { int32_t status, n; uint64_t vbeg[6]; } tredgpu_alt_result;
 int tredgpu_inflate_walk(tredgpu_inflater* inf, int32_t n_blocks, int32_t* status, uint32_t* crc, tredgpu_walk_args* walk);
 /* copies the blocks with need[k] != 0 of the last tredgpu_inflate_walk to the pinned output; returns the number of copies */
 int tredgpu_inflater_fetch(tredgpu_inflater* inf, int32_t n_blocks, const uint8_t* need);

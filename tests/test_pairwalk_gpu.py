@@ -116,6 +116,35 @@ def _walk_inputs(handles, sites_of, readlens, firsts):
     return cat(0), cat(1), cat(2), [b[3] for b in blk], [b[0] for b in blk], np.concatenate(tasks), np.concatenate(chunks), [len(t) for t in tasks]
 
 
+def _alt_inputs(handles, sites_of, regions_of, readlens, firsts):
+    tasks, chunks, c0 = [], [], 0
+    for f, sites, regions, rl, b0 in zip(handles, sites_of, regions_of, readlens, firsts):
+        t, c = f.plan_alt_walks(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+        t, c = t.copy(), c.copy()
+        t["chunk_first"] += c0
+        t["block_first"] += b0
+        t["block_end"] += b0
+        c["begin_block"][c["begin_block"] >= 0] += b0
+        tasks.append(t)
+        chunks.append(c)
+        c0 += len(c)
+    return np.concatenate(tasks), np.concatenate(chunks), [len(t) for t in tasks]
+
+
+def _zlib_blocks(handles, plans):
+    """The planned blocks of the files, inflated by zlib, in the layout of the call."""
+    import struct
+    import zlib
+    for f, (n, _, _) in zip(handles, plans):
+        coff, clen, _, _ = f.plan_blocks()
+        with open(f.path if hasattr(f, "path") else f.filename, "rb") as fp:
+            for c, l in zip(coff, clen):
+                fp.seek(int(c))
+                raw = fp.read(int(l))
+                xlen = struct.unpack_from("<H", raw, 10)[0]
+                yield zlib.decompressobj(-15).decompress(raw[12 + xlen:-8])
+
+
 def _cases(synthetic):
     repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
     out = [(os.path.join(GOLD, "bam", s + ".bam"), repo, sorted(repo.names)) for s in ("t001", "t002")]
@@ -134,15 +163,32 @@ def test_walked_pair_lengths_offsets_and_scan(inf, synthetic):
         sites_of.append(sites); regions_of.append(regions); readlens.append(rl)
     n_all, comp, _, ooff, firsts = _lay_out(inf, handles, plans)
     bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, n_tasks = _walk_inputs(handles, sites_of, readlens, firsts)
-    status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks)
+    alt_tasks, alt_chunks, n_alt = _alt_inputs(handles, sites_of, regions_of, readlens, firsts)
+    status, crc, res, gp, tp, ares, alt_need = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=alt_tasks, alt_chunks=alt_chunks)
     assert (status == 0).all() and (crc == bcrc).all()
     assert inf.walk_ms() > 0
-    t0 = 0
+    # the alternative loci: every region against the plain Python walk of the same task over zlib's bytes
+    from .walk_model import _walk
+    ooff_all = ooff[:n_all + 1]
+    out_bytes = b"".join(_zlib_blocks(handles, plans))
+    walkable = alt_tasks["n_chunks"] >= 0
+    assert walkable.sum() > 100 and (ares["status"][walkable] == 0).all() and (ares["status"][~walkable] == 1).all()
+    total_hits = 0
+    for t in np.flatnonzero(walkable):
+        hits = _walk(alt_tasks[t], alt_chunks, out_bytes, ooff_all, bcoff, bclen, lambda k: True, alt=True)
+        assert [h[0] for h in hits] == [int(v) for v in ares["vbeg"][t][:ares["n"][t]]], t
+        for _, kb, ka in hits:
+            assert alt_need[kb:ka + 1].all()
+        total_hits += len(hits)
+    assert total_hits > 20 and alt_need.sum() <= 3 * total_hits
+    t0 = a0 = 0
     total_pairs = total_window = 0
-    for f, (path, repo, names), sites, regions, rl, first, host, coff, nt in zip(handles, cases, sites_of, regions_of, readlens, firsts,
-                                                                                  host_of, coff_of, n_tasks):
+    for f, (path, repo, names), sites, regions, rl, first, host, coff, nt, na in zip(handles, cases, sites_of, regions_of, readlens, firsts,
+                                                                                      host_of, coff_of, n_tasks, n_alt):
         r = res[t0:t0 + nt]
         t0 += nt
+        ar = ares[a0:a0 + na]
+        a0 += na
         plain_f = bamio.AlignmentFile(path)
         units, pools = plain_f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
         for k, name in enumerate(names):
@@ -162,15 +208,16 @@ def test_walked_pair_lengths_offsets_and_scan(inf, synthetic):
             assert (int(r["n_window"][k]), int(r["win_vbeg"][k]), int(r["win_vend"][k])) == (n, vbeg, vend), (path, name)
             total_window += n
         # the scan with these results, over the fetched blocks only
-        need = walk_need(coff, host, r)
+        need = walk_need(coff, host, r, alt_need[first:first + len(coff)])
         assert need.sum() < len(need) or len(need) < 8
+        assert need.sum() <= (np.asarray(host) != 0).sum() + 4 * len(names) + 8      # (the alternative loci's blocks stay behind)
         full = np.zeros(n_all, np.uint8)
         full[first:first + len(need)] = need
         inf.fetch(full)
         n_here = len(need)
         f.preload(inf.out_addr, ooff[first:first + n_here + 1], np.where(need != 0, status[first:first + n_here], 1).astype(np.int32),
                   crc[first:first + n_here])
-        u2, p2 = f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(r, gp, tp))
+        u2, p2 = f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(r, gp, tp), alt=ar)
         hits, misses = f.preload_clear()
         for key in units.dtype.names:
             assert (units[key] == u2[key]).all(), (path, key)

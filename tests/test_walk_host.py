@@ -79,6 +79,7 @@ def test_feeder_with_walked_pair_lengths_gives_the_plain_scans(cohort, monkeypat
     tm = t.TIMING
     assert tm["walk_regions"] == sum(len(a[3]) for a in cohort[:6]) and tm["walk_declined"] == 0
     assert 0 < tm["walk_blocks_fetched"] < tm["inflate_blocks"]
+    assert tm["walk_alt_regions"] > 100 and tm["walk_alt_declined"] == 0   # the alternative loci were walked by the model too
     assert tm["inflate_misses"] == 0 and tm["inflate_hits"] > 0          # no scan inflated a block for itself
     assert sum(m.walks for m in ModelInflater.made) == 3                 # (the chunk with the missing file has nothing to decode)
 
@@ -87,10 +88,12 @@ def test_regions_the_walker_declines_are_walked_by_the_scan(cohort, monkeypatch)
     """Every region comes back with a status (here: the model pretends a damaged block in each): the scans compute the
     pair lengths themselves, inflating what was not fetched, and nothing changes in the result."""
     class Declining(ModelInflater):
-        def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048):
-            status, crc, res, gp, tp = ModelInflater.run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks)
+        def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None):
+            status, crc, res, gp, tp, ares, need = ModelInflater.run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, alt_tasks=alt_tasks,
+                                                                          alt_chunks=alt_chunks)
             res["status"][::2] = 2
-            return status, crc, res, gp, tp
+            ares["status"][1::3] = 2
+            return status, crc, res, gp, tp, ares, need
 
     monkeypatch.setattr("tredparse_amd._lib.Inflater", Declining)
     t.release_inflaters()

@@ -47,11 +47,11 @@ class ModelInflater(object):
         self.bufs[1][:len(self.dev) - 64] = self.dev[:-64]
         return (status, sums) if crc else status
 
-    def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048):
+    def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None):
         self.walks += 1
         status, crc = self._inflate(n)
         ooff = self.bufs[3]
-        out = self.dev.tobytes()
+        out = out_bytes = self.dev.tobytes()
         res = np.zeros(len(tasks), _lib.WALK_RESULT_DTYPE)
         gp, tp = [], []
         ok = lambda k: status[k] == 0 and crc[k] == xcrc[k]     # noqa: E731
@@ -64,7 +64,24 @@ class ModelInflater(object):
             res[t] = (0, len(g), len(tt), nwin, len(gp), len(tp), vbeg, vend)
             gp += g
             tp += tt
-        return status, crc, res, np.array(gp, np.int32), np.array(tp, np.int32)
+        out = (status, crc, res, np.array(gp, np.int32), np.array(tp, np.int32))
+        if alt_tasks is None:
+            return out
+        ares = np.zeros(len(alt_tasks), _lib.ALT_RESULT_DTYPE)
+        need = np.zeros(n, np.uint8)
+        for t, T in enumerate(alt_tasks):
+            r = _walk(T, alt_chunks, out_bytes, ooff, bcoff, bclen, ok, alt=True)
+            if isinstance(r, int):
+                ares["status"][t] = r
+                continue
+            if len(r) > 6:
+                ares["status"][t] = 6
+                continue
+            ares["n"][t] = len(r)
+            for m, (at, kb, ka) in enumerate(r):
+                ares["vbeg"][t][m] = at
+                need[kb:ka + 1] = 1
+        return out + (ares, need)
 
     def fetch(self, need):
         ooff = self.bufs[3]
@@ -77,9 +94,13 @@ class ModelInflater(object):
         pass
 
 
-def _walk(T, chunks, out, ooff, bcoff, bclen, ok):
+def _walk(T, chunks, out, ooff, bcoff, bclen, ok, alt=False):
+    """The pair walk of one region -> (global lens, target lens, window records, vbeg, vend), or -- alt -- the records
+    whose mate lies on contig tstart within [win_lo, win_hi] as [(virtual offset, first block, last block)]; an int: the
+    status the kernel ends the task with."""
     if T["n_chunks"] < 0:
         return 1
+    hits = []
     size_of = lambda k: int(ooff[k + 1] - ooff[k])              # noqa: E731
 
     def tell(k, upos):
@@ -97,6 +118,7 @@ def _walk(T, chunks, out, ooff, bcoff, bclen, ok):
             at = tell(k, upos)
             if at >= cend:
                 break
+            kb = k if upos < size_of(k) else k + 1
             pieces = []
             for n in (4, None):
                 if n is None:
@@ -134,6 +156,11 @@ def _walk(T, chunks, out, ooff, bcoff, bclen, ok):
             e = pos + 1 if (rend < 0 or rend <= pos) else rend
             if not e > T["start"]:
                 continue
+            if alt:
+                mtid, mpos = struct.unpack_from("<ii", out, r + 20)
+                if mtid == T["tstart"] and T["win_lo"] <= mpos <= T["win_hi"]:
+                    hits.append((at, kb, k))
+                continue
             if pos < T["win_hi"] and e > T["win_lo"]:
                 if nwin == 0:
                     vbeg = at
@@ -161,6 +188,8 @@ def _walk(T, chunks, out, ooff, bcoff, bclen, ok):
                 p.append((pos, rend, bool(flag & 0x10), lead, trail))
             else:
                 p.append(None)
+    if alt:
+        return hits
     g, t = [], []
     for name in order:
         p = pairs[name]

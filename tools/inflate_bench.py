@@ -113,33 +113,37 @@ def main():
         for f in hs:
             sites, regions = bam_parser._site_arrays(repo, names, loci, f)
             plans.append(f.plan(sites, regions, 150, extra=bam_parser.y_regions("hg38")))
-            tabs.append((f.plan_walks(sites, 150), f.plan_blocks()))
+            tabs.append((f.plan_walks(sites, 150), f.plan_blocks(), f.plan_alt_walks(sites, regions, 150)))
         c_plan = time.process_time() - c_plan
         n_all = sum(p[0] for p in plans)
         comp, out, coff, ooff = inf.reserve(sum(p[1] for p in plans), sum(p[2] for p in plans), n_all)
         at = cb = ob = c0 = 0
-        firsts, tasks, chunks = [], [], []
-        for f, p, ((t, c), _) in zip(hs, plans, tabs):
+        firsts, tasks, chunks, atasks, achunks, a0 = [], [], [], [], [], 0
+        for f, p, ((t, c), _, (ta, ca)) in zip(hs, plans, tabs):
             f.plan_fill(inf.comp_addr, cb, ob, coff[at:at + p[0] + 1], ooff[at:at + p[0] + 1])
-            t, c = t.copy(), c.copy()
+            t, c, ta, ca = t.copy(), c.copy(), ta.copy(), ca.copy()
             t["chunk_first"] += c0; t["block_first"] += at; t["block_end"] += at
             c["begin_block"][c["begin_block"] >= 0] += at
-            tasks.append(t); chunks.append(c); firsts.append(at)
-            at, cb, ob, c0 = at + p[0], cb + p[1], ob + p[2], c0 + len(c)
+            ta["chunk_first"] += a0; ta["block_first"] += at; ta["block_end"] += at
+            ca["begin_block"][ca["begin_block"] >= 0] += at
+            tasks.append(t); chunks.append(c); firsts.append(at); atasks.append(ta); achunks.append(ca)
+            at, cb, ob, c0, a0 = at + p[0], cb + p[1], ob + p[2], c0 + len(c), a0 + len(ca)
+        atasks, achunks = np.concatenate(atasks), np.concatenate(achunks)
         bcoff, bclen, bcrc = (np.concatenate([tb[1][k] for tb in tabs]) for k in range(3))
         tasks, chunks = np.concatenate(tasks), np.concatenate(chunks)
-        inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks)
+        inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=atasks, alt_chunks=achunks)
         reps = 3
         t0, c0_ = time.perf_counter(), time.process_time()
         for _ in range(reps):
-            status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks)
+            status, crc, res, gp, tp, ares, alt_need = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=atasks, alt_chunks=achunks)
         dt, dc = (time.perf_counter() - t0) / reps, (time.process_time() - c0_) / reps
         walk_ms, (dev_ms, kernel_ms) = inf.walk_ms(), inf.timing()
         assert (status == 0).all() and (res["status"] == 0).all(), np.unique(res["status"], return_counts=True)
         need = np.zeros(n_all, np.uint8)
-        nt = len(names)
-        for k, (p, (_, blk)) in enumerate(zip(plans, tabs)):
-            need[firsts[k]:firsts[k] + p[0]] = bam_parser.walk_need(blk[0], blk[3], res[k * nt:(k + 1) * nt])
+        nt, na = len(names), len(atasks) // m
+        assert (ares["status"][atasks["n_chunks"] >= 0] == 0).all()
+        for k, (p, (_, blk, _)) in enumerate(zip(plans, tabs)):
+            need[firsts[k]:firsts[k] + p[0]] = bam_parser.walk_need(blk[0], blk[3], res[k * nt:(k + 1) * nt], alt_need[firsts[k]:firsts[k] + p[0]])
         t0 = time.perf_counter()
         for _ in range(reps):
             copies = inf.fetch(need)
@@ -148,7 +152,7 @@ def main():
         for k, (f, p) in enumerate(zip(hs, plans)):
             a = firsts[k]
             f.preload(inf.out_addr, ooff[a:a + p[0] + 1], np.where(need[a:a + p[0]] != 0, status[a:a + p[0]], 1).astype(np.int32), crc[a:a + p[0]])
-            s1 = bam_parser.scan_sample(bams[k % len(bams)], repo, names, handle=f, readlen=150, pe=(res[k * nt:(k + 1) * nt], gp, tp))
+            s1 = bam_parser.scan_sample(bams[k % len(bams)], repo, names, handle=f, readlen=150, pe=(res[k * nt:(k + 1) * nt], gp, tp), alt=ares[k * na:(k + 1) * na])
             hits, misses = f.preload_clear()
             assert misses == 0
         c_scan = time.process_time() - c_scan
@@ -156,7 +160,8 @@ def main():
         assert np.array_equal(s0.packed, s1.packed) and np.array_equal(s0.global_lens, s1.global_lens) and np.array_equal(s0.target_lens, s1.target_lens)
         for f in hs:
             f.close()
-        rec["walk"].append({"samples": m, "blocks": n_all, "regions": len(tasks), "ms_per_call": dt * 1e3, "host_cpu_ms_per_call": dc * 1e3,
+        rec["walk"].append({"samples": m, "blocks": n_all, "regions": len(tasks), "alt_regions": int((atasks["n_chunks"] >= 0).sum()),
+                            "alt_records": int(ares["n"].sum()), "ms_per_call": dt * 1e3, "host_cpu_ms_per_call": dc * 1e3,
                             "decode_kernel_ms": kernel_ms, "walk_kernel_ms": walk_ms, "pairs": int(len(gp) + len(tp)),
                             "window_records": int(res["n_window"].sum()), "blocks_fetched": int(need.sum()), "fetch_copies": copies,
                             "fetch_ms": dt_fetch * 1e3, "fetched_MB_per_sample": float((np.diff(ooff[:n_all + 1])[need != 0]).sum()) / m / 1e6,

@@ -314,7 +314,9 @@ class WalkArgs(C.Structure):
     _fields_ = [("blk_coffset", C.c_void_p), ("blk_clen", C.c_void_p), ("blk_crc", C.c_void_p),
                 ("tasks", C.c_void_p), ("n_tasks", C.c_int32), ("chunks", C.c_void_p), ("n_chunks", C.c_int32),
                 ("results", C.c_void_p), ("global_pool", C.c_void_p), ("cap_global", C.c_int64),
-                ("target_pool", C.c_void_p), ("cap_target", C.c_int64), ("n_global", C.c_int64), ("n_target", C.c_int64)]
+                ("target_pool", C.c_void_p), ("cap_target", C.c_int64), ("n_global", C.c_int64), ("n_target", C.c_int64),
+                ("alt_tasks", C.c_void_p), ("n_alt_tasks", C.c_int32), ("alt_chunks", C.c_void_p), ("n_alt_chunks", C.c_int32),
+                ("alt_results", C.c_void_p), ("need", C.c_void_p)]
 
 
 # layouts of tredgpu_walk_task / _chunk / _result (the same as bamio.WALK_*_DTYPE: tredbam.h's structs)
@@ -323,6 +325,7 @@ WALK_TASK_DTYPE = np.dtype([(k, "<i4") for k in ("tid", "start", "end", "tstart"
 WALK_CHUNK_DTYPE = np.dtype([("begin_block", "<i4"), ("begin_upos", "<i4"), ("end_voffset", "<u8")])
 WALK_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"), ("n_window", "<i4"),
                               ("global_first", "<i8"), ("target_first", "<i8"), ("win_vbeg", "<u8"), ("win_vend", "<u8")])
+ALT_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n", "<i4"), ("vbeg", "<u8", (6,))])
 
 
 class Inflater:
@@ -377,10 +380,11 @@ class Inflater:
         self._check(self._lib.tredgpu_inflate_blocks_crc(self._h, n_blocks, status.ctypes.data, sums.ctypes.data), "tredgpu_inflate_blocks_crc")
         return status[:n_blocks], sums[:n_blocks]
 
-    def run_walk(self, n_blocks, blk_coffset, blk_clen, blk_crc, tasks, chunks, pairs_per_task=2048):
+    def run_walk(self, n_blocks, blk_coffset, blk_clen, blk_crc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None):
         """tredgpu_inflate_walk: decodes the blocks laid out in the reserved buffers and walks the pair-length regions
         (tasks WALK_TASK_DTYPE, chunks WALK_CHUNK_DTYPE) over them on the device.  No block is copied back (fetch does
-        that).  Returns (status, crc, results WALK_RESULT_DTYPE, global pool, target pool)."""
+        that).  Returns (status, crc, results WALK_RESULT_DTYPE, global pool, target pool) -- with alt_tasks / alt_chunks
+        (the alternative loci's walks) also (results ALT_RESULT_DTYPE, uint8 flags of the blocks that hold their records)."""
         status, sums = np.zeros(max(n_blocks, 1), np.int32), np.zeros(max(n_blocks, 1), np.uint32)
         coff = np.ascontiguousarray(blk_coffset, np.int64)
         clen = np.ascontiguousarray(blk_clen, np.int32)
@@ -392,11 +396,18 @@ class Inflater:
         res = np.zeros(max(len(tasks), 1), WALK_RESULT_DTYPE)
         gp = np.zeros(len(tasks) * int(pairs_per_task) + 4096, np.int32)
         tp = np.zeros(len(tasks) * max(int(pairs_per_task) // 8, 16) + 1024, np.int32)
+        n_alt = 0 if alt_tasks is None else len(alt_tasks)
+        at = np.ascontiguousarray(alt_tasks if n_alt else np.zeros(1, WALK_TASK_DTYPE), WALK_TASK_DTYPE)
+        ac = np.ascontiguousarray(alt_chunks if (n_alt and len(alt_chunks)) else np.zeros(1, WALK_CHUNK_DTYPE), WALK_CHUNK_DTYPE)
+        ares = np.zeros(max(n_alt, 1), ALT_RESULT_DTYPE)
+        need = np.zeros(max(n_blocks, 1), np.uint8)
         a = WalkArgs(coff.ctypes.data, clen.ctypes.data, xcrc.ctypes.data, tasks.ctypes.data, len(tasks), chunks.ctypes.data,
-                     len(chunks), res.ctypes.data, gp.ctypes.data, len(gp), tp.ctypes.data, len(tp), 0, 0)
+                     len(chunks), res.ctypes.data, gp.ctypes.data, len(gp), tp.ctypes.data, len(tp), 0, 0,
+                     at.ctypes.data, n_alt, ac.ctypes.data, len(alt_chunks) if n_alt else 0, ares.ctypes.data, need.ctypes.data)
         self._check(self._lib.tredgpu_inflate_walk(self._h, n_blocks, status.ctypes.data, sums.ctypes.data, C.byref(a)),
                     "tredgpu_inflate_walk")
-        return status[:n_blocks], sums[:n_blocks], res[:len(tasks)], gp[:a.n_global], tp[:a.n_target]
+        out = (status[:n_blocks], sums[:n_blocks], res[:len(tasks)], gp[:a.n_global], tp[:a.n_target])
+        return out if alt_tasks is None else out + (ares[:n_alt], need[:n_blocks])
 
     def fetch(self, need):
         """tredgpu_inflater_fetch: the blocks with need[k] != 0 of the last run_walk, to their places in ``out``."""

@@ -138,11 +138,15 @@ def _site_arrays(repo, names, loci, f):
     return hit
 
 
-def walk_need(coffset, host, results):
+def walk_need(coffset, host, results, alt_need=None):
     """Which planned blocks of a sample a scan with walked pair lengths reads (bamio plan_blocks / WALK_RESULT_DTYPE):
     those flagged `host` (alternative loci, extra regions) and, per walked site, the blocks between the virtual offsets
-    of its window's first record and the end of its last one."""
-    need = np.array(host, np.uint8, copy=True)
+    of its window's first record and the end of its last one.  alt_need: the alternative loci were walked elsewhere too
+    -- of their blocks only those flagged there (they hold the records that count) are read."""
+    if alt_need is None:
+        need = (np.asarray(host) != 0).astype(np.uint8)
+    else:
+        need = (((np.asarray(host) & 2) != 0) | (np.asarray(alt_need) != 0)).astype(np.uint8)
     ok = (results["status"] == 0) & (results["n_window"] > 0)
     lo = np.searchsorted(coffset, (results["win_vbeg"][ok] >> np.uint64(16)).astype(np.int64), side="left")
     hi = np.searchsorted(coffset, ((results["win_vend"][ok] - np.uint64(1)) >> np.uint64(16)).astype(np.int64), side="right")
@@ -151,11 +155,11 @@ def walk_need(coffset, host, results):
     return need
 
 
-def scan_sample(path, repo, names, clip=False, alts=True, readlen=None, want_sex=None, handle=None, pe=None):
+def scan_sample(path, repo, names, clip=False, alts=True, readlen=None, want_sex=None, handle=None, pe=None, alt=None):
     """Read one sample: sex and read length, then depth / reads / pair lengths of every locus in `names`.
     Never raises for a bad file: `opened` is False and nothing else is filled (the reference returns a result
     with only inferredGender / depthY for such a sample).  pe: (results, global pool, target pool) of the pair walks
-    done where the blocks were inflated (bamio scan)."""
+    done where the blocks were inflated, alt: those of the walks over the alternative loci (bamio scan)."""
     s = SampleScan()
     s.path, s.names, s.loci = path, list(names), [repo[n] for n in names]
     s.gender, s.ydepth, s.readlen, s.opened = "Unknown", -1, 150, False
@@ -182,7 +186,7 @@ def scan_sample(path, repo, names, clip=False, alts=True, readlen=None, want_sex
             pass
     sites, regions = _site_arrays(repo, s.names, s.loci, f)
     s.unit, pools = f.scan(sites, regions, s.readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN,
-                           use_alts=alts and not clip, **({"pe": pe} if pe is not None else {}))
+                           use_alts=alts and not clip, **({"pe": pe, "alt": alt} if pe is not None else {}))
     s.packed, s.word_off, s.read_len = pools["packed"], pools["word_off"], pools["read_len"]
     s.seq4, s.seq4_off = pools["seq4"], pools["seq4_off"]
     s.name_blob, s.name_off, s.name_id = pools["names"], pools["name_off"], pools["name_id"]

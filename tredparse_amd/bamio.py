@@ -379,6 +379,12 @@ def _native():
             lib.tredbam_scan_pe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
             lib.tredbam_scan_pe.restype = C.c_int
+            lib.tredbam_plan_alt_walks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(ScanOpts),
+                                                   C.c_void_p, C.c_void_p, C.c_int64]
+            lib.tredbam_plan_alt_walks.restype = C.c_int64
+            lib.tredbam_scan_walked.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.tredbam_scan_walked.restype = C.c_int
             lib.tredbam_details_json.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_int64]
             lib.tredbam_details_json.restype = C.c_int64
             lib.tredbam_sparse_json.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
@@ -558,6 +564,8 @@ class Pools(C.Structure):
 
 
 assert SITE_DTYPE.itemsize == 20 and REGION_DTYPE.itemsize == 12 and SCAN_UNIT_DTYPE.itemsize == 56
+ALT_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n", "<i4"), ("vbeg", "<u8", (6,))])
+assert ALT_RESULT_DTYPE.itemsize == 56
 assert WALK_TASK_DTYPE.itemsize == 48 and WALK_CHUNK_DTYPE.itemsize == 16 and WALK_RESULT_DTYPE.itemsize == 48
 
 
@@ -715,10 +723,11 @@ class NativeAlignmentFile(object):
         return self._tid.get(chrom, -1)
 
     def scan(self, sites, alts, readlen, pad=1000, flank=9, pe_reach=10000, span=1000, use_alts=True,
-             want_depth=True, want_pe=True, pe=None):
+             want_depth=True, want_pe=True, pe=None, alt=None):
         """tredbam_scan: `sites` (SITE_DTYPE) and `alts` (REGION_DTYPE) -> (units SCAN_UNIT_DTYPE, dict of pool
         arrays).  One native call; the GIL is released while it runs.  pe = (results WALK_RESULT_DTYPE per site, global
-        pool, target pool): pair lengths computed where the blocks were inflated (tredbam_scan_pe)."""
+        pool, target pool): pair lengths computed where the blocks were inflated (tredbam_scan_pe); alt (with pe): the
+        results ALT_RESULT_DTYPE of the walks over the alternative loci, one per entry of `alts` (tredbam_scan_walked)."""
         sites = np.ascontiguousarray(sites, SITE_DTYPE)
         alts = np.ascontiguousarray(alts if len(alts) else np.zeros(1, REGION_DTYPE), REGION_DTYPE)
         units = np.zeros(len(sites), SCAN_UNIT_DTYPE)
@@ -735,8 +744,17 @@ class NativeAlignmentFile(object):
                              or (res["global_first"][ok] + res["n_global"][ok]).max() > len(pe[1])
                              or (res["target_first"][ok] + res["n_target"][ok]).max() > len(pe[2])):
                 raise ValueError("walk results point outside their pools")
-            rc = self._lib.tredbam_scan_pe(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o),
-                                           res.ctypes.data, gp.ctypes.data, tp.ctypes.data, units.ctypes.data)
+            if alt is not None:
+                ar = np.ascontiguousarray(alt, ALT_RESULT_DTYPE)
+                if len(ar) < int((sites["alt_first"] + sites["n_alt"]).max() if len(sites) else 0):
+                    raise ValueError("one alternative-locus result per region")
+                if len(ar) == 0:
+                    ar = np.zeros(1, ALT_RESULT_DTYPE)
+                rc = self._lib.tredbam_scan_walked(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o),
+                                                   res.ctypes.data, gp.ctypes.data, tp.ctypes.data, ar.ctypes.data, units.ctypes.data)
+            else:
+                rc = self._lib.tredbam_scan_pe(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o),
+                                               res.ctypes.data, gp.ctypes.data, tp.ctypes.data, units.ctypes.data)
         else:
             rc = self._lib.tredbam_scan(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, C.byref(o),
                                         units.ctypes.data)
@@ -789,6 +807,26 @@ class NativeAlignmentFile(object):
             if n < 0:
                 raise ValueError(self._err())
             return tasks, chunks[:n]
+
+    def plan_alt_walks(self, sites, alts, readlen, pad=1000, flank=9, pe_reach=10000, span=1000, use_alts=True):
+        """tredbam_plan_alt_walks (after plan()): (tasks WALK_TASK_DTYPE, one per entry of `alts`; chunks) of the walks over
+        the alternative loci."""
+        sites = np.ascontiguousarray(sites, SITE_DTYPE)
+        n_alts = len(alts)
+        alts = np.ascontiguousarray(alts if n_alts else np.zeros(1, REGION_DTYPE), REGION_DTYPE)
+        o = ScanOpts(int(readlen), int(pad), int(flank), int(pe_reach), int(span), int(bool(use_alts)), 1, 1)
+        tasks = np.zeros(max(n_alts, 1), WALK_TASK_DTYPE)
+        cap = 4 * n_alts + 16
+        while True:
+            chunks = np.zeros(cap, WALK_CHUNK_DTYPE)
+            n = self._lib.tredbam_plan_alt_walks(self._h, sites.ctypes.data, len(sites), alts.ctypes.data, n_alts, C.byref(o),
+                                                 tasks.ctypes.data, chunks.ctypes.data, cap)
+            if n == -3:
+                cap *= 4
+                continue
+            if n < 0:
+                raise ValueError(self._err())
+            return tasks[:n_alts], chunks[:n]
 
     def plan_blocks(self):
         """tredbam_plan_blocks: (compressed offset, compressed length, trailer CRC-32, read-by-the-scan-itself flag) of

@@ -92,7 +92,7 @@ struct tredbam {
     static constexpr size_t CACHE_BLOCKS = 512;   // <= 32 MiB per open file
     // blocks inflated elsewhere (tredbam_plan -> the GPU's batch decoder -> tredbam_preload): compressed offset -> the
     // caller's bytes; load_block takes them from here (CRC checked at first use), anything else is inflated as usual
-    struct Planned { int64_t coffset, payload_off; int32_t payload_len; int64_t clen; uint32_t crc, isize; bool host; };
+    struct Planned { int64_t coffset, payload_off; int32_t payload_len; int64_t clen; uint32_t crc, isize; uint8_t host; };
     struct Preloaded { const uint8_t* data; uint32_t size; int64_t clen; uint32_t crc; bool checked; };
     std::vector<Planned> plan;
     std::unordered_map<int64_t, Preloaded> preloaded;
@@ -1063,11 +1063,38 @@ int tredbam_max_read_len(tredbam* b, int64_t first_n, int32_t* out) {
 }  // extern "C"
 
 namespace {
+// The records of an alternative locus whose mate lies in the window, handed in as virtual offsets by a walker that went
+// over the region elsewhere (tredbam_alt_result): every one is read where it is said to be and checked -- it is a record
+// of this region with its mate in the window -- before any is pooled.  false: not what was promised (the region is then
+// walked here as usual).
+bool pool_walked(tredbam* b, const tredbam_region& a, int32_t mate_tid, int64_t win_lo, int64_t win_hi, const tredbam_alt_result& res,
+                 std::unordered_map<std::string, int32_t>& names) {
+    if (res.n < 0 || res.n > (int32_t)(sizeof res.vbeg / sizeof res.vbeg[0])) return false;
+    const int64_t start = std::max<int64_t>(0, a.start);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int32_t m = 0; m < res.n; ++m) {
+            if (bg_seek(b, res.vbeg[m]) < 0 || next_record(b) <= 0) return false;
+            const uint8_t* r = b->recp;
+            if (pass == 0) {
+                const int32_t rtid = (int32_t)le32(r), rpos = (int32_t)le32(r + 4);
+                int32_t rend = -1;
+                if (rtid != a.tid || rpos >= a.end || record_end(b, &rend) < 0) return false;
+                const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
+                const int32_t mt = (int32_t)le32(r + 20), mp = (int32_t)le32(r + 24);
+                if (!(e > start) || mt != mate_tid || mp < win_lo || mp > win_hi) return false;
+                if (m > 0 && res.vbeg[m] <= res.vbeg[m - 1]) return false;       // in file order, none twice
+            } else
+                pool_read(b, r, names);
+        }
+    return true;
+}
+
 // tredbam_scan / tredbam_scan_pe.  pe != nullptr: the pair lengths of site i are pe[i]'s slices of the two pools when
 // pe[i].status == 0, and the walk over that site covers its window's records only (pe[i].win_vbeg .. win_vend); every other
 // site is scanned as tredbam_scan scans it.
 int scan_impl(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts, const tredbam_scan_opts* o,
-              tredbam_unit* units, const tredbam_walk_result* pe, const int32_t* pe_global, const int32_t* pe_target) {
+              tredbam_unit* units, const tredbam_walk_result* pe, const int32_t* pe_global, const int32_t* pe_target,
+              const tredbam_alt_result* alt_res) {
     if (!b || !o || n_sites < 0 || (n_sites > 0 && (!sites || !units))) return -2;
     b->out.clear();
     b->sc_packed.clear(); b->sc_read_len.clear(); b->sc_seq4.clear(); b->sc_names.clear(); b->sc_name_id.clear();
@@ -1125,6 +1152,9 @@ int scan_impl(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tred
             for (int32_t k = 0; k < st.n_alt; ++k) {
                 const tredbam_region& a = alts[st.alt_first + k];
                 if (a.tid < 0) continue;                                 // contig not in this file: skipped
+                if (alt_res && alt_res[st.alt_first + k].status == 0 &&
+                    pool_walked(b, a, st.tid, win_lo, win_hi, alt_res[st.alt_first + k], names))
+                    continue;                                            // its records were found where the blocks were inflated
                 walk_region(b, a.tid, a.start, a.end, false, [&](int32_t, int32_t, uint16_t, const uint8_t* r) {
                     const int32_t mate_tid = (int32_t)le32(r + 20), mate_pos = (int32_t)le32(r + 24);
                     if (mate_tid == st.tid && mate_pos >= win_lo && mate_pos <= win_hi) pool_read(b, r, names);
@@ -1162,14 +1192,66 @@ extern "C" {
 
 int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
                  const tredbam_scan_opts* o, tredbam_unit* units) {
-    return scan_impl(b, sites, n_sites, alts, o, units, nullptr, nullptr, nullptr);
+    return scan_impl(b, sites, n_sites, alts, o, units, nullptr, nullptr, nullptr, nullptr);
 }
 
 int tredbam_scan_pe(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
                     const tredbam_scan_opts* o, const tredbam_walk_result* pe, const int32_t* pe_global,
                     const int32_t* pe_target, tredbam_unit* units) {
     if (!pe || !pe_global || !pe_target) return -2;
-    return scan_impl(b, sites, n_sites, alts, o, units, pe, pe_global, pe_target);
+    return scan_impl(b, sites, n_sites, alts, o, units, pe, pe_global, pe_target, nullptr);
+}
+
+int tredbam_scan_walked(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
+                        const tredbam_scan_opts* o, const tredbam_walk_result* pe, const int32_t* pe_global,
+                        const int32_t* pe_target, const tredbam_alt_result* alt_res, tredbam_unit* units) {
+    if (!pe || !pe_global || !pe_target || !alt_res) return -2;
+    return scan_impl(b, sites, n_sites, alts, o, units, pe, pe_global, pe_target, alt_res);
+}
+
+// The walks over the alternative loci of tredbam_scan(sites, alts, o) as tasks for the same walker: task alt_first + k
+// of site i is the region alts[alt_first + k]; a record counts when its mate lies on the site's contig (tstart) within
+// [win_lo, win_hi] (the locus' window, both ends included: bam_parser.py:232-236).  n_chunks < 0: not walkable.
+int64_t tredbam_plan_alt_walks(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts, int32_t n_alts,
+                               const tredbam_scan_opts* o, tredbam_walk_task* tasks, tredbam_walk_chunk* chunks, int64_t cap_chunks) {
+    if (!b || !o || n_sites < 0 || n_alts < 0 || (n_sites > 0 && !sites) || (n_alts > 0 && (!alts || !tasks)) || cap_chunks < 0 ||
+        (cap_chunks > 0 && !chunks))
+        return -2;
+    std::unordered_map<int64_t, int32_t> index_of;
+    index_of.reserve(b->plan.size() * 2);
+    for (size_t k = 0; k < b->plan.size(); ++k) index_of[b->plan[k].coffset] = (int32_t)k;
+    for (int32_t k = 0; k < n_alts; ++k) { memset(&tasks[k], 0, sizeof tasks[k]); tasks[k].n_chunks = -1; tasks[k].tid = -1; }
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    int64_t nc = 0;
+    for (int32_t i = 0; i < n_sites; ++i) {
+        const tredbam_site& st = sites[i];
+        if (st.tid < 0 || !o->use_alts) continue;
+        for (int32_t k = 0; k < st.n_alt; ++k) {
+            if (st.alt_first + k < 0 || st.alt_first + k >= n_alts) return -2;
+            const tredbam_region& a = alts[st.alt_first + k];
+            tredbam_walk_task& t = tasks[st.alt_first + k];
+            t.chunk_first = (int32_t)nc;
+            t.block_end = (int32_t)b->plan.size();
+            int64_t start = a.start, end = a.end;
+            if (a.tid < 0 || region_chunks(b, a.tid, start, end, merged) != 0 || end > INT32_MAX) continue;
+            if ((int64_t)merged.size() > cap_chunks - nc) return -3;
+            t.tid = a.tid;
+            t.start = (int32_t)start;
+            t.end = (int32_t)end;
+            t.tstart = st.tid;
+            t.win_lo = (int32_t)std::max<int64_t>(0, (int64_t)st.repeat_start - o->pad);
+            t.win_hi = st.repeat_end + o->pad;
+            for (const auto& ch : merged) {
+                tredbam_walk_chunk& c = chunks[nc++];
+                const auto at = index_of.find((int64_t)(ch.first >> 16));
+                c.begin_block = at == index_of.end() ? -1 : at->second;
+                c.begin_upos = (int32_t)(ch.first & 0xFFFF);
+                c.end_voffset = ch.second;
+            }
+            t.n_chunks = (int32_t)merged.size();
+        }
+    }
+    return nc;
 }
 
 // The pair walks of tredbam_scan(sites, o) as tasks for a walker that holds the planned blocks inflated (the device:
@@ -1227,7 +1309,7 @@ int64_t tredbam_plan_blocks(tredbam* b, int64_t* coffset, int32_t* clen, uint32_
         if (coffset) coffset[k] = p.coffset;
         if (clen) clen[k] = (int32_t)p.clen;
         if (crc) crc[k] = p.crc;
-        if (host) host[k] = p.host ? 1 : 0;
+        if (host) host[k] = p.host;
     }
     return (int64_t)b->plan.size();
 }
@@ -1243,11 +1325,12 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
     if (!b || !o || n_sites < 0 || (n_sites > 0 && !sites) || n_extra < 0 || (n_extra > 0 && !extra)) return -2;
     b->plan.clear();
     // `host`: a block the scan reads in any case when the pair lengths and the windows' offsets come from elsewhere
-    // (tredbam_scan_pe): those of the alternative loci and of the caller's extra regions.  Which blocks of a +-pe_reach
-    // region hold its window's records is known only once the region has been walked (tredbam_walk_result)
+    // (tredbam_scan_pe): bit 0 those of the alternative loci (unless those walks are done elsewhere too:
+    // tredbam_scan_walked), bit 1 those of the caller's extra regions.  Which blocks of a +-pe_reach region hold its
+    // window's records is known only once the region has been walked (tredbam_walk_result)
     std::unordered_map<int64_t, size_t> seen;
     std::vector<std::pair<uint64_t, uint64_t>> merged;
-    auto add_region = [&](int32_t tid, int64_t start, int64_t end, bool host) -> int {
+    auto add_region = [&](int32_t tid, int64_t start, int64_t end, uint8_t host) -> int {
         if (region_chunks(b, tid, start, end, merged) != 0) return 0;     // (the scan reports what is wrong with it)
         uint64_t cap = ~0ull;
         if (tid < (int32_t)b->index.size()) {
@@ -1262,7 +1345,7 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
                 const auto known = seen.find(at);
                 if (known != seen.end()) {                                 // framed before: only the flag can change
                     tredbam::Planned& q = b->plan[known->second];
-                    q.host = q.host || host;
+                    q.host = (uint8_t)(q.host | host);
                     at += q.clen;
                     continue;
                 }
@@ -1284,16 +1367,16 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
         const int64_t win_lo = std::max<int64_t>(0, (int64_t)st.repeat_start - o->pad), win_hi = (int64_t)st.repeat_end + o->pad;
         const int64_t p_lo = std::max<int64_t>((int64_t)st.repeat_start - o->pe_reach, 0), p_hi = (int64_t)st.repeat_end + o->pe_reach;
         if (st.tid < 0) continue;
-        add_region(st.tid, win_lo, win_hi, false);
-        if (o->want_pe) add_region(st.tid, p_lo, p_hi, false);
+        add_region(st.tid, win_lo, win_hi, 0);
+        if (o->want_pe) add_region(st.tid, p_lo, p_hi, 0);
         if (o->use_alts && alts)
             for (int32_t k = 0; k < st.n_alt; ++k) {
                 const tredbam_region& a = alts[st.alt_first + k];
-                if (a.tid >= 0) add_region(a.tid, a.start, a.end, true);
+                if (a.tid >= 0) add_region(a.tid, a.start, a.end, 1);
             }
     }
     for (int32_t k = 0; k < n_extra; ++k)          // other queries of the caller on this handle (the chrY depth windows)
-        if (extra[k].tid >= 0) add_region(extra[k].tid, extra[k].start, extra[k].end, true);
+        if (extra[k].tid >= 0) add_region(extra[k].tid, extra[k].start, extra[k].end, 2);
     // in file order: blocks that follow each other in the file then follow each other in the decoder's output, and a
     // record that straddles two of them lies there in one piece (the device's pair walk reads it in place)
     std::sort(b->plan.begin(), b->plan.end(), [](const tredbam::Planned& x, const tredbam::Planned& y) { return x.coffset < y.coffset; });

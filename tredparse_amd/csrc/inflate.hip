@@ -1111,6 +1111,129 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
     }
 }
 
+// ---- the same walk over an alternative locus: the records whose mate lies in the locus' window -------------------------------
+// BamParser.parse's mate rescue (tredparse/bam_parser.py:226-243; bamread.cpp scan_impl): per locus ~50 regions of 300 bp
+// elsewhere in the genome; a record of such a region counts when its mate maps into the window of the locus.  1 500 tiny
+// walks per sample, each from the start of its 16 kb index bin -- on the host they were four fifths of what a scan still
+// cost once the pair walks had left it, and their blocks (every region somewhere else in the file) two thirds of what
+// still crossed the bus.  Chain and parse as above, no table: a ballot finds the records that count; their virtual offsets
+// go into the region's result (at most six: the region is the host's otherwise) and the blocks they lie in are marked
+// for the copy back.
+constexpr int ALT_MATCH_CAP = 6;
+__device__ int walk_alt_records(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk* chunks, WalkReader& rd,
+                                tredgpu_alt_result& R, uint8_t* need, int lane) {
+    if (T.n_chunks < 0) return WALK_NOT_PLANNED;
+    int found = 0;
+    for (int c = 0; c < T.n_chunks; ++c) {
+        const tredgpu_walk_chunk ch = chunks[T.chunk_first + c];
+        if (ch.begin_block < T.block_first || ch.begin_block >= T.block_end) return WALK_NOT_PLANNED;
+        WalkCursor cur;
+        int rc = cur.enter(v, ch.begin_block);
+        if (rc) return rc;
+        cur.upos = ch.begin_upos;
+        bool chunk_done = false;
+        while (!chunk_done) {
+            int nb = 0, err = WALK_OK;
+            int64_t my_a0 = 0;
+            uint64_t my_at = 0;
+            int32_t my_size = 0, my_kb = 0, my_ka = 0;
+            while (nb < WALK_BATCH) {
+                const uint64_t at = cur.tell();
+                if (at >= ch.end_voffset) { chunk_done = true; break; }
+                int64_t a0, r;
+                const bool word_here = cur.upos + 4 <= cur.size;
+                const WalkCursor before = cur;
+                const int kb = cur.upos < cur.size ? cur.k : cur.k + 1;   // the block the record starts in
+                if (word_here) { a0 = cur.first + cur.upos; cur.upos += 4; }
+                else if ((rc = cur.take(v, T, 4, &a0)) != 0) { err = rc; break; }
+                if (!rd.inside(a0, WALK_HEAD)) {
+                    if (nb > 0) { cur = before; break; }
+                    rd.fill(a0);
+                }
+                const int32_t size = (int32_t)rd.u32(a0);
+                if (size < 32) { err = WALK_BAD_RECORD; break; }
+                if (cur.upos + size <= cur.size) cur.upos += size;
+                else if ((rc = cur.take(v, T, size, &r)) != 0) { err = rc; break; }
+                if (lane == nb) { my_a0 = a0; my_at = at; my_size = size; my_kb = kb; my_ka = cur.k; }
+                ++nb;
+            }
+            if (err != WALK_OK) chunk_done = true;
+            const bool mine = lane < nb;
+            int32_t rtid = 0, rpos = 0, rend = -1, mtid = -1, mpos = -1;
+            bool bad = false;
+            if (mine) {
+                const int64_t r = my_a0 + 4;
+                rtid = (int32_t)rd.vu32(r);
+                rpos = (int32_t)rd.vu32(r + 4);
+                const uint32_t l_name = rd.vu8(r + 8), n_cigar = rd.vu16(r + 12), flag = rd.vu16(r + 14);
+                const int32_t l_seq = (int32_t)rd.vu32(r + 16);
+                mtid = (int32_t)rd.vu32(r + 20);
+                mpos = (int32_t)rd.vu32(r + 24);
+                bad = l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)my_size;
+                if (!bad && !(flag & 0x4) && n_cigar > 0 && rtid == T.tid && rpos < T.end) {
+                    const int64_t cig = r + 32 + l_name;
+                    int64_t e = rpos;
+                    for (uint32_t q = 0; q < n_cigar; ++q) {
+                        const uint32_t op = rd.vu32(cig + 4 * q);
+                        if ((0x18Du >> (op & 15)) & 1) e += op >> 4;
+                    }
+                    rend = (int32_t)e;
+                }
+            }
+            const bool off_region = mine && (rtid != T.tid || rpos >= T.end);
+            const bool stops = off_region && (rtid > T.tid || (rtid == T.tid && rpos >= T.end));
+            const uint64_t stop_mask = __ballot(stops), bad_mask = __ballot(mine && !off_region && bad);
+            const int first_stop = stop_mask ? __builtin_ctzll(stop_mask) : 64, first_bad = bad_mask ? __builtin_ctzll(bad_mask) : 64;
+            const int limit = first_stop < first_bad ? first_stop : first_bad;
+            const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
+            const bool keep = mine && lane < limit && !off_region && e > T.start;
+            uint64_t hits = __ballot(keep && mtid == T.tstart && mpos >= T.win_lo && mpos <= T.win_hi);
+            while (hits) {
+                const int j = __builtin_ctzll(hits);
+                hits &= hits - 1;
+                if (found >= ALT_MATCH_CAP) return WALK_POOL_FULL;
+                if (lane == j) {
+                    R.vbeg[found] = my_at;
+                    for (int k = my_kb; k <= my_ka; ++k) need[k] = 1;
+                }
+                ++found;
+            }
+            if (first_bad < first_stop) return WALK_BAD_RECORD;
+            if (first_stop < 64) { chunk_done = true; err = WALK_OK; }
+            if (err != WALK_OK) return err;
+        }
+    }
+    R.n = found;
+    return WALK_OK;
+}
+
+__global__ void __launch_bounds__(LANES) alt_walk_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
+                                                         tredgpu_alt_result* results, uint8_t* need) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t walk_lds[];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    WalkLds S;
+    S.cap = 0; S.mask = 0; S.table = nullptr; S.seen = nullptr;
+    S.window = (lds_u8*)walk_lds;
+    const tredgpu_walk_task T = tasks[t];
+    WalkReader rd;
+    rd.out = v.out; rd.out_end = v.out_end; rd.S = &S; rd.base = (int64_t)1 << 60; rd.lane = lane; rd.ahead_base = (int64_t)1 << 60;
+    // (every lane holds the result; the lane that owns a record writes that record's offset into ITS copy: gather them)
+    tredgpu_alt_result R = {};
+    const int status = walk_alt_records(v, T, chunks, rd, R, need, lane);
+    tredgpu_alt_result out = {};
+    out.status = status;
+    if (status == WALK_OK) {
+        out.n = R.n;
+        for (int m = 0; m < ALT_MATCH_CAP; ++m) {
+            // the owner's copy is the only non-zero one
+            uint64_t x = R.vbeg[m];
+            for (int d = 32; d >= 1; d >>= 1) x |= (uint64_t)__shfl_xor((unsigned long long)x, d, 64);
+            out.vbeg[m] = m < R.n ? x : 0;
+        }
+    }
+    if (lane == 0) results[t] = out;
+}
+
 }  // namespace
 
 // ---- C ABI (include/tredgpu.h) ------------------------------------------------------------------------------------
@@ -1142,6 +1265,8 @@ struct tredgpu_inflater {
     uint8_t* d_wtask = nullptr; uint8_t* h_wtask = nullptr; size_t cap_wtask = 0;   // tasks then chunks
     uint8_t* d_wres = nullptr;  uint8_t* h_wres = nullptr;  size_t cap_wres = 0;    // results then the two counters
     WalkRepeat* d_wrepeats = nullptr; WalkPair* d_wpairs = nullptr; size_t cap_wscratch = 0;   // in tasks
+    uint8_t* d_atask = nullptr; uint8_t* h_atask = nullptr; size_t cap_atask = 0;   // the alternative loci's tasks then chunks
+    uint8_t* d_ares = nullptr;  uint8_t* h_ares = nullptr;  size_t cap_ares = 0;    // their results, then the blocks' need flags
     int32_t *d_gpool = nullptr, *d_tpool = nullptr, *h_gpool = nullptr, *h_tpool = nullptr;
     size_t cap_gpool = 0, cap_tpool = 0;
     std::string err;
@@ -1176,13 +1301,13 @@ void release(tredgpu_inflater* f) {
 }
 
 void release_walk(tredgpu_inflater* f) {
-    for (void* p : {(void*)f->h_wblk, (void*)f->h_wtask, (void*)f->h_wres, (void*)f->h_gpool, (void*)f->h_tpool})
+    for (void* p : {(void*)f->h_wblk, (void*)f->h_wtask, (void*)f->h_wres, (void*)f->h_gpool, (void*)f->h_tpool, (void*)f->h_atask, (void*)f->h_ares})
         if (p) (void)hipHostFree(p);
-    for (void* p : {(void*)f->d_wblk, (void*)f->d_wtask, (void*)f->d_wres, (void*)f->d_wrepeats, (void*)f->d_wpairs, (void*)f->d_gpool, (void*)f->d_tpool})
+    for (void* p : {(void*)f->d_wblk, (void*)f->d_wtask, (void*)f->d_wres, (void*)f->d_wrepeats, (void*)f->d_wpairs, (void*)f->d_gpool, (void*)f->d_tpool, (void*)f->d_atask, (void*)f->d_ares})
         if (p) (void)hipFree(p);
-    f->h_wblk = f->h_wtask = f->h_wres = nullptr; f->h_gpool = f->h_tpool = nullptr;
-    f->d_wblk = f->d_wtask = f->d_wres = nullptr; f->d_wrepeats = nullptr; f->d_wpairs = nullptr; f->d_gpool = f->d_tpool = nullptr;
-    f->cap_wblk = f->cap_wtask = f->cap_wres = f->cap_wscratch = f->cap_gpool = f->cap_tpool = 0;
+    f->h_wblk = f->h_wtask = f->h_wres = f->h_atask = f->h_ares = nullptr; f->h_gpool = f->h_tpool = nullptr;
+    f->d_wblk = f->d_wtask = f->d_wres = f->d_atask = f->d_ares = nullptr; f->d_wrepeats = nullptr; f->d_wpairs = nullptr; f->d_gpool = f->d_tpool = nullptr;
+    f->cap_wblk = f->cap_wtask = f->cap_wres = f->cap_wscratch = f->cap_gpool = f->cap_tpool = f->cap_atask = f->cap_ares = 0;
 }
 
 // grow-only pairs of pinned host / device buffers for the walk's small arrays
@@ -1326,7 +1451,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
     int32_t* d_crc = f->d_status + f->cap_blocks;
     const bool want_crc = crc != nullptr || w != nullptr;
     // ---- the walk's inputs go first, on its own stream (nothing there depends on the decoding yet) ----
-    size_t n_tasks = 0, n_chunks = 0;
+    size_t n_tasks = 0, n_chunks = 0, n_alt = 0, n_alt_chunks = 0;
     if (w) {
         if (w->n_tasks < 0 || w->n_chunks < 0 || !w->blk_coffset || !w->blk_clen || !w->blk_crc || (w->n_tasks > 0 && (!w->tasks || !w->results)) ||
             (w->n_chunks > 0 && !w->chunks) || w->cap_global < 0 || w->cap_target < 0 || (w->cap_global > 0 && !w->global_pool) ||
@@ -1341,7 +1466,27 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         }
         for (size_t q = 0; q < n_chunks; ++q)
             if (w->chunks[q].begin_upos < 0 || w->chunks[q].begin_upos > 65536) return ifail(f, -2, "walk chunk starts outside a block");
+        n_alt = (size_t)std::max(w->n_alt_tasks, 0);
+        n_alt_chunks = (size_t)std::max(w->n_alt_chunks, 0);
+        if (w->n_alt_tasks < 0 || w->n_alt_chunks < 0 || (n_alt > 0 && (!w->alt_tasks || !w->alt_results || !w->need)) || (n_alt_chunks > 0 && !w->alt_chunks))
+            return ifail(f, -2, "bad walk arguments (alternative loci)");
+        for (size_t t = 0; t < n_alt; ++t) {
+            const tredgpu_walk_task& T = w->alt_tasks[t];
+            if (T.n_chunks >= 0 && (T.chunk_first < 0 || (size_t)T.chunk_first + (size_t)T.n_chunks > n_alt_chunks || T.block_first < 0 ||
+                                    T.block_end > n_blocks || T.block_first > T.block_end))
+                return ifail(f, -2, "walk task outside its chunks / blocks");
+        }
+        for (size_t q = 0; q < n_alt_chunks; ++q)
+            if (w->alt_chunks[q].begin_upos < 0 || w->alt_chunks[q].begin_upos > 65536) return ifail(f, -2, "walk chunk starts outside a block");
         const size_t nb = (size_t)n_blocks;
+        if (n_alt > 0) {
+            if (grow_pair(f, &f->h_atask, &f->d_atask, &f->cap_atask, n_alt * sizeof(tredgpu_walk_task) + n_alt_chunks * sizeof(tredgpu_walk_chunk) + 64)) return -10;
+            if (grow_pair(f, &f->h_ares, &f->d_ares, &f->cap_ares, n_alt * sizeof(tredgpu_alt_result) + nb + 64)) return -10;
+            memcpy(f->h_atask, w->alt_tasks, n_alt * sizeof(tredgpu_walk_task));
+            memcpy(f->h_atask + n_alt * sizeof(tredgpu_walk_task), w->alt_chunks, n_alt_chunks * sizeof(tredgpu_walk_chunk));
+            ICHK(f, hipMemcpyAsync(f->d_atask, f->h_atask, n_alt * sizeof(tredgpu_walk_task) + n_alt_chunks * sizeof(tredgpu_walk_chunk), hipMemcpyHostToDevice, f->wstream));
+            ICHK(f, hipMemsetAsync(f->d_ares + n_alt * sizeof(tredgpu_alt_result), 0, nb, f->wstream));
+        }
         if (grow_pair(f, &f->h_wblk, &f->d_wblk, &f->cap_wblk, nb * 16 + 64)) return -10;
         if (grow_pair(f, &f->h_wtask, &f->d_wtask, &f->cap_wtask, n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk) + 64)) return -10;
         if (grow_pair(f, &f->h_wres, &f->d_wres, &f->cap_wres, n_tasks * sizeof(tredgpu_walk_result) + 64)) return -10;
@@ -1427,8 +1572,15 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
                 table_cap);
             ICHK(f, hipGetLastError());
         }
+        if (n_alt > 0) {
+            alt_walk_kernel<<<(unsigned)n_alt, LANES, WALK_WINDOW, f->wstream>>>(v, (const tredgpu_walk_task*)f->d_atask,
+                (const tredgpu_walk_chunk*)(f->d_atask + n_alt * sizeof(tredgpu_walk_task)), (tredgpu_alt_result*)f->d_ares,
+                f->d_ares + n_alt * sizeof(tredgpu_alt_result));
+            ICHK(f, hipGetLastError());
+        }
         ICHK(f, hipEventRecord(f->w1, f->wstream));
         f->walk_timed = true;
+        if (n_alt > 0) ICHK(f, hipMemcpyAsync(f->h_ares, f->d_ares, n_alt * sizeof(tredgpu_alt_result) + nb, hipMemcpyDeviceToHost, f->wstream));
         ICHK(f, hipMemcpyAsync(f->h_wres, f->d_wres, n_tasks * sizeof(tredgpu_walk_result) + 16, hipMemcpyDeviceToHost, f->wstream));
         ICHK(f, hipEventRecord(f->wdone, f->wstream));
     }
@@ -1446,6 +1598,10 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         unsigned long long used[2];
         memcpy(used, f->h_wres + n_tasks * sizeof(tredgpu_walk_result), 16);
         memcpy(w->results, f->h_wres, n_tasks * sizeof(tredgpu_walk_result));
+        if (n_alt > 0) {
+            memcpy(w->alt_results, f->h_ares, n_alt * sizeof(tredgpu_alt_result));
+            memcpy(w->need, f->h_ares + n_alt * sizeof(tredgpu_alt_result), (size_t)n_blocks);
+        }
         // (a task that found its pool full took its room all the same: the counters can exceed the capacities)
         const size_t ng = (size_t)std::min<unsigned long long>(used[0], (unsigned long long)w->cap_global),
                      nt = (size_t)std::min<unsigned long long>(used[1], (unsigned long long)w->cap_target);

@@ -41,7 +41,7 @@ logger = logging.getLogger(__name__)
 # the writer thread's time in the sink (JSON / VCF text and files)
 TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
           "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0, "walk_regions": 0, "walk_declined": 0,
-          "walk_blocks_fetched": 0}
+          "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0}
 _TIMING_LOCK = threading.Lock()
 
 
@@ -204,6 +204,8 @@ def _plan_sample(arg, walk=False):
         p = {"handle": f, "readlen": readlen, "n": n, "cbytes": cbytes, "obytes": obytes}
         if walk and n > 0:
             p["tasks"], p["chunks"] = f.plan_walks(sites, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+            p["alt_tasks"], p["alt_chunks"] = f.plan_alt_walks(sites, regions, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE,
+                                                               span=SPAN, use_alts=o["alts"] and not o["clip"])
             p["coffset"], p["clen"], p["crc"], p["host"] = f.plan_blocks()
         return p
     except Exception:
@@ -211,7 +213,7 @@ def _plan_sample(arg, walk=False):
         return None
 
 
-def _scan_planned(arg, plan, out_addr, out_off, status, crc=None, pe=None):
+def _scan_planned(arg, plan, out_addr, out_off, status, crc=None, pe=None, alt=None):
     """Thread: the sample's scan with its planned blocks preloaded from the inflater's output (crc: the decoder's
     checksums of those blocks -- the scan then does not walk the bytes for the BGZF CRC again; pe: the pair walks'
     results from the device, see scan_sample)."""
@@ -221,7 +223,7 @@ def _scan_planned(arg, plan, out_addr, out_off, status, crc=None, pe=None):
         if status is not None:
             f.preload(out_addr, out_off, status, crc)
         return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"], readlen=plan["readlen"], handle=f,
-                           pe=pe)
+                           pe=pe, alt=alt)
     finally:
         if status is not None:
             hits, misses = f.preload_clear()
@@ -335,19 +337,24 @@ class _InflateFeeder(object):
         """The chunk's pair-walk tasks: every sample's tables (bamio plan_walks / plan_blocks) moved to the sample's
         place among the call's blocks and chunks."""
         import numpy as np
-        tasks, chunks, c0 = [], [], 0
-        for p in live:
-            t, c = p["tasks"].copy(), p["chunks"].copy()
-            t["chunk_first"] += c0
-            t["block_first"] += p["first"]
-            t["block_end"] += p["first"]
-            c["begin_block"][c["begin_block"] >= 0] += p["first"]
-            p["task_first"] = sum(len(x) for x in tasks)
-            tasks.append(t)
-            chunks.append(c)
-            c0 += len(c)
+        def moved(key_t, key_c, first_key):
+            tasks, chunks, c0, t0 = [], [], 0, 0
+            for p in live:
+                t, c = p[key_t].copy(), p[key_c].copy()
+                t["chunk_first"] += c0
+                t["block_first"] += p["first"]
+                t["block_end"] += p["first"]
+                c["begin_block"][c["begin_block"] >= 0] += p["first"]
+                p[first_key] = t0
+                tasks.append(t)
+                chunks.append(c)
+                c0, t0 = c0 + len(c), t0 + len(t)
+            return np.concatenate(tasks), np.concatenate(chunks)
+        tasks, chunks = moved("tasks", "chunks", "task_first")
+        alt_tasks, alt_chunks = moved("alt_tasks", "alt_chunks", "alt_first")
         return {"coffset": np.concatenate([p["coffset"] for p in live]), "clen": np.concatenate([p["clen"] for p in live]),
-                "crc": np.concatenate([p["crc"] for p in live]), "tasks": np.concatenate(tasks), "chunks": np.concatenate(chunks)}
+                "crc": np.concatenate([p["crc"] for p in live]), "tasks": tasks, "chunks": chunks, "alt_tasks": alt_tasks,
+                "alt_chunks": alt_chunks}
 
     def _decode_and_scan(self, chunk, job):
         """Decode thread: one launch for the chunk, then its scans go to the pool and their futures to the consumer."""
@@ -378,12 +385,13 @@ class _InflateFeeder(object):
                     futs.append(self.ex.submit(_scan_planned, a, p, 0, None, None))
                 else:
                     k = p["first"]
-                    pe = None
+                    pe = alt = None
                     if walked is not None:
-                        res, gp, tp = walked
+                        res, gp, tp, ares = walked
                         pe = (res[p["task_first"]:p["task_first"] + len(p["tasks"])], gp, tp)
+                        alt = ares[p["alt_first"]:p["alt_first"] + len(p["alt_tasks"])]
                     futs.append(self.ex.submit(_scan_planned, a, p, inf.out_addr, ooff[k:k + p["n"] + 1], status[k:k + p["n"]],
-                                               crc[k:k + p["n"]], pe))
+                                               crc[k:k + p["n"]], pe, alt))
             handed = True                                  # (each scan closes its own handle)
             self.busy[job["slot"]] = futs
             self._put(futs)
@@ -401,15 +409,19 @@ class _InflateFeeder(object):
         import numpy as np
         from .bam_parser import walk_need
         w = job["walk"]
-        status, crc, res, gp, tp = inf.run_walk(job["n_all"], w["coffset"], w["clen"], w["crc"], w["tasks"], w["chunks"])
+        status, crc, res, gp, tp, ares, alt_need = inf.run_walk(job["n_all"], w["coffset"], w["clen"], w["crc"], w["tasks"], w["chunks"],
+                                                                alt_tasks=w["alt_tasks"], alt_chunks=w["alt_chunks"])
         need = np.zeros(job["n_all"], np.uint8)
         for p in job["live"]:
             a = p["first"]
-            need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])])
+            need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])],
+                                           alt_need[a:a + p["n"]])
         inf.fetch(need)
+        walkable = w["alt_tasks"]["n_chunks"] >= 0
         timing_add(walk_regions=len(res), walk_declined=int((res["status"] != 0).sum()), walk_blocks_fetched=int(need.sum()),
+                   walk_alt_regions=int(walkable.sum()), walk_alt_declined=int((ares["status"][walkable] != 0).sum()),
                    inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
-        return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp)
+        return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp, ares)
 
     def _put(self, item):
         import queue
