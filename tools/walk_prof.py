@@ -48,27 +48,30 @@ def main():
     for f in hs:
         sites, regions = bam_parser._site_arrays(repo, names, loci, f)
         plans.append(f.plan(sites, regions, 150))
-        tabs.append((f.plan_walks(sites, 150), f.plan_blocks()))
+        tabs.append((f.plan_walks(sites, 150), f.plan_blocks(), f.plan_alt_walks(sites, regions, 150)))
     n_all = sum(p[0] for p in plans)
     comp, out, coff, ooff = inf.reserve(sum(p[1] for p in plans), sum(p[2] for p in plans), n_all)
     at = cb = ob = c0 = 0
-    tasks, chunks = [], []
-    for f, p, ((t, c), _) in zip(hs, plans, tabs):
+    tasks, chunks, atasks, achunks, a0 = [], [], [], [], 0
+    for f, p, ((t, c), _, (ta, ca)) in zip(hs, plans, tabs):
         f.plan_fill(inf.comp_addr, cb, ob, coff[at:at + p[0] + 1], ooff[at:at + p[0] + 1])
-        t, c = t.copy(), c.copy()
+        t, c, ta, ca = t.copy(), c.copy(), ta.copy(), ca.copy()
         t["chunk_first"] += c0; t["block_first"] += at; t["block_end"] += at
         c["begin_block"][c["begin_block"] >= 0] += at
-        tasks.append(t); chunks.append(c)
-        at, cb, ob, c0 = at + p[0], cb + p[1], ob + p[2], c0 + len(c)
+        ta["chunk_first"] += a0; ta["block_first"] += at; ta["block_end"] += at
+        ca["begin_block"][ca["begin_block"] >= 0] += at
+        tasks.append(t); chunks.append(c); atasks.append(ta); achunks.append(ca)
+        at, cb, ob, c0, a0 = at + p[0], cb + p[1], ob + p[2], c0 + len(c), a0 + len(ca)
+    atasks, achunks = np.concatenate(atasks), np.concatenate(achunks)
     bcoff, bclen, bcrc = (np.concatenate([tb[1][k] for tb in tabs]) for k in range(3))
     tasks, chunks = np.concatenate(tasks), np.concatenate(chunks)
     for _ in range(3):
-        status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, pairs_per_task=8192)
+        status, crc, res, gp, tp, ares, _ = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, pairs_per_task=8192, alt_tasks=atasks, alt_chunks=achunks)
     ok = res["status"] == 0
     phases = {"chain (length words, block bookkeeping, window refills)": res["global_first"][ok], "parse (a lane per record)": res["target_first"][ok],
               "resolve (ballots, pair table, stores)": res["win_vbeg"][ok].astype(np.int64), "finish (name checks, lists)": res["win_vend"][ok].astype(np.int64)}
     total = sum(float(v.mean()) for v in phases.values())
-    print(json.dumps({"library": _lib.version(), "samples": m, "regions": int(ok.sum()), "records_per_region": float(res["n_window"][ok].mean()),
+    print(json.dumps({"library": _lib.version(), "samples": m, "regions": int(ok.sum()), "alt_regions": int((atasks["n_chunks"] >= 0).sum()), "alt_records": int(ares["n"].sum()), "records_per_region": float(res["n_window"][ok].mean()),
                       "walk_kernel_ms": inf.walk_ms(), "mean_cycles_per_region": {k: round(float(v.mean())) for k, v in phases.items()},
                       "total_cycles": round(total), "note": "shader clock cycles (s_memtime), ~2.2 GHz"}))
 
