@@ -262,3 +262,17 @@ def test_a_block_the_decoder_cannot_vouch_for_ends_the_task_not_the_sample(inf, 
     for key in pools:
         assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
     f.close(); g.close()
+
+
+def test_a_short_random_campaign(capsys, monkeypatch):
+    """tools/fuzz_walk.py, three rounds: random loci / coverage / flags, blocks cut at random sizes without regard to
+    records -- no region and no scan may differ (the long campaigns are in profiles/r04_fuzz_walk_*.json)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import fuzz_walk
+    monkeypatch.setattr(sys, "argv", ["fuzz_walk.py", "3", "20261004"])
+    fuzz_walk.main()
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["samples"] >= 3 and out["regions_walked"] > 0 and out["alt_regions"] > 0
+    assert out["mismatching_regions"] == 0 and out["mismatching_scans"] == 0

@@ -1258,7 +1258,7 @@ struct tredgpu_inflater {
     // the pair walk (tredgpu_inflate_walk): a stream of its own, the file's view of the blocks, tasks, per-task tables, pools
     hipStream_t wstream = nullptr;
     hipEvent_t wdone = nullptr, w0 = nullptr, w1 = nullptr, decoded[2] = {nullptr, nullptr};
-    bool walk_timed = false;
+    bool walk_timed = false, big_lds_allowed = false;
     int walk_table_cap = 0;
     uint8_t* d_wblk = nullptr;  size_t cap_wblk = 0;        // bcoff[n] int64, then bclen[n] int32, then xcrc[n] uint32
     uint8_t* h_wblk = nullptr;                               // pinned, same layout
@@ -1560,10 +1560,9 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
                 }
                 if (span > 40) table_cap = WALK_PAIR_CAP;
             }
-            static bool big_lds_allowed = false;
-            if (!big_lds_allowed) {
+            if (!f->big_lds_allowed) {                 // (per inflater: each lives on one device, and a process may use several)
                 ICHK(f, hipFuncSetAttribute((const void*)pair_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds_bytes(WALK_PAIR_CAP)));
-                big_lds_allowed = true;
+                f->big_lds_allowed = true;
             }
             f->walk_table_cap = table_cap;
             pair_walk_kernel<<<(unsigned)n_tasks, LANES, walk_lds_bytes(table_cap), f->wstream>>>(v, (const tredgpu_walk_task*)f->d_wtask,
