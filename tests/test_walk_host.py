@@ -51,6 +51,9 @@ def cohort(tmp_path_factory):
         path = os.path.join(str(root), "cut{}.bam".format(block))
         synth_bam.write_bam(path, recs, sample="cut", block=block, split_records=True)
         args.append(("cut{}".format(block), path, srepo, [l["name"] for l in loci[:2]], 300, False, False, True, True, "ERROR"))
+    # the kernel-side options that change what a scan reads: --noalts (no alternative loci), --useclippedreads (neither)
+    args.append(("noalts", os.path.join(GOLD, "bam", "t001.bam"), repo, ["HD", "DM1", "AR"], 300, False, False, False, True, "ERROR"))
+    args.append(("clip", made[0][1], srepo, [l["name"] for l in loci], 300, False, True, True, True, "ERROR"))
     args.append(("missing", os.path.join(str(root), "no_such.bam"), repo, ["HD"], 300, False, False, True, True, "ERROR"))
     return args
 
@@ -63,7 +66,7 @@ def test_feeder_with_walked_pair_lengths_gives_the_plain_scans(cohort, monkeypat
     del ModelInflater.made[:]
     for k in t.TIMING:
         t.TIMING[k] = 0
-    chunks = [cohort[:2], cohort[2:4], cohort[4:6], cohort[6:]]
+    chunks = [cohort[:2], cohort[2:4], cohort[4:6], cohort[6:8], cohort[8:]]
     ex = ThreadPoolExecutor(max_workers=2)
     feeder = t._InflateFeeder(chunks, ex, 0, walk=True)
     try:
@@ -77,11 +80,11 @@ def test_feeder_with_walked_pair_lengths_gives_the_plain_scans(cohort, monkeypat
         o = t._options(a)
         _same(s, scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"]))
     tm = t.TIMING
-    assert tm["walk_regions"] == sum(len(a[3]) for a in cohort[:6]) and tm["walk_declined"] == 0
+    assert tm["walk_regions"] == sum(len(a[3]) for a in cohort[:8]) and tm["walk_declined"] == 0
     assert 0 < tm["walk_blocks_fetched"] < tm["inflate_blocks"]
     assert tm["walk_alt_regions"] > 100 and tm["walk_alt_declined"] == 0   # the alternative loci were walked by the model too
     assert tm["inflate_misses"] == 0 and tm["inflate_hits"] > 0          # no scan inflated a block for itself
-    assert sum(m.walks for m in ModelInflater.made) == 3                 # (the chunk with the missing file has nothing to decode)
+    assert sum(m.walks for m in ModelInflater.made) == 4                 # (the chunk with the missing file has nothing to decode)
 
 
 def test_regions_the_walker_declines_are_walked_by_the_scan(cohort, monkeypatch):
