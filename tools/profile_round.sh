@@ -20,12 +20,12 @@ export TRED_BENCH_WORKERS=1     # no forked batch builders out of a process the 
 BENCH="python3 $ROOT/bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
 PASSES=${PASSES:-fetch write sq sq2}
 
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+timeout -k 5 ${PASS_TIMEOUT:-900} rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 
 pass() {   # pass NAME counters...
     local name=$1; shift
-    timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $BENCH > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err"
+    timeout -k 5 ${PASS_TIMEOUT:-900} rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- $BENCH > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err"
 }
 case " $PASSES " in *" fetch "*) pass fetch FETCH_SIZE;; esac
 case " $PASSES " in *" write "*) pass write WRITE_SIZE;; esac
