@@ -111,3 +111,24 @@ def test_regions_the_walker_declines_are_walked_by_the_scan(cohort, monkeypatch)
     for a, s in zip(cohort[:4], scans):
         o = t._options(a)
         _same(s, scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"]))
+
+
+def test_walk_need_marks_the_windows_blocks_and_what_the_flags_say():
+    """bam_parser.walk_need: blocks between a walked site's window offsets (a position at a block's very start needs
+    the block before it only), the extra regions' blocks always, the alternative loci's only when those were not walked
+    elsewhere -- then the flags that walk returned instead."""
+    from tredparse_amd.bam_parser import walk_need
+    coff = np.array([100, 200, 300, 400, 500, 600], np.int64)
+    host = np.array([1, 0, 0, 2, 0, 3], np.uint8)              # bit 0: alternative loci, bit 1: extra regions
+    res = np.zeros(3, bamio.WALK_RESULT_DTYPE)
+    res[0] = (0, 0, 0, 5, 0, 0, (200 << 16) | 17, (300 << 16) | 9)      # records in blocks 200 .. 300
+    res[1] = (0, 0, 0, 2, 0, 0, (500 << 16) | 3, 600 << 16)             # ends exactly where block 600 starts: 500 only
+    res[2] = (2, 0, 0, 7, 0, 0, (100 << 16), (600 << 16) | 1)           # declined: its offsets mean nothing
+    assert walk_need(coff, host, res).tolist() == [1, 1, 1, 1, 1, 1]
+    assert walk_need(coff, host, res[2:]).tolist() == [1, 0, 0, 1, 0, 1]
+    alt_need = np.array([0, 0, 0, 0, 0, 0], np.uint8)
+    assert walk_need(coff, host, res, alt_need).tolist() == [0, 1, 1, 1, 1, 1]
+    alt_need[0] = 1
+    assert walk_need(coff, host, res[:1], alt_need).tolist() == [1, 1, 1, 1, 0, 1]
+    none = np.zeros(0, bamio.WALK_RESULT_DTYPE)
+    assert walk_need(coff, host, none, np.zeros(6, np.uint8)).tolist() == [0, 0, 0, 1, 0, 1]
