@@ -276,3 +276,112 @@ def test_a_short_random_campaign(capsys, monkeypatch):
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert out["samples"] >= 3 and out["regions_walked"] > 0 and out["alt_regions"] > 0
     assert out["mismatching_regions"] == 0 and out["mismatching_scans"] == 0
+
+
+def _odd_bam(path, rng, block):
+    """A BAM around the HD locus whose records have heads of every size: names of 1-250 characters, CIGARs of 1-220
+    operations (soft / hard clips at the ends, M I D N = X inside), secondary / supplementary copies under the same name,
+    duplicates, unmapped mates -- in blocks of `block` bytes cut without regard to records."""
+    import struct
+    t = TREDsRepo()["HD"]
+    tid = synth_bam.CONTIGS.index(t.chr)
+    recs = []
+    for i in range(700):
+        name = ("q%d_" % i + "x" * int(rng.integers(0, 245)))[:250]
+        pos = int(t.repeat_start + rng.integers(-11000, 11000))
+        for mate in range(int(rng.choice([1, 2, 2, 2, 3]))):
+            n_ops = int(rng.choice([1, 2, 3, 5, 40, 130, 220]))
+            ops = []
+            if rng.random() < 0.3:
+                ops.append((5, int(rng.integers(1, 30))))
+            if rng.random() < 0.5:
+                ops.append((4, int(rng.integers(1, 40))))
+            for _ in range(n_ops):
+                ops.append((int(rng.choice([0, 0, 0, 1, 2, 3, 7, 8])), int(rng.integers(1, 12))))
+            if rng.random() < 0.5:
+                ops.append((4, int(rng.integers(1, 40))))
+            if rng.random() < 0.2:
+                ops.append((5, int(rng.integers(1, 30))))
+            l_seq = sum(n for op, n in ops if op in (0, 1, 4, 7, 8))
+            flag = 0x1 | (0x10 if (mate == 1) != (rng.random() < 0.1) else 0) | (0x40 if mate == 0 else 0x80)
+            if rng.random() < 0.04:
+                flag |= 0x400
+            if rng.random() < 0.03:
+                flag |= 0x4
+                ops = []
+            if mate == 2:
+                flag |= 0x800
+            p = pos + (int(rng.integers(150, 700)) if mate else 0)
+            ref = sum(n for op, n in ops if op in (0, 2, 3, 7, 8))
+            mtid, mpos = (tid, int(t.repeat_start + rng.integers(-900, 900))) if rng.random() < 0.5 else (-1, -1)
+            recs.append((p, name, flag, ops, l_seq, ref, mtid, mpos))
+    recs.sort(key=lambda r: r[0])
+    blob, offs, ends = b"", [], []
+    for p, name, flag, ops, l_seq, ref, mtid, mpos in recs:
+        end = p + ref if (ref and not flag & 4) else p + 1
+        body = struct.pack("<iiBBHHHiiii", tid, p, len(name) + 1, 0 if flag & 4 else 60, int(synth_bam._reg2bin(np.array([p]), np.array([end]))[0]),
+                           len(ops), flag, l_seq, mtid, mpos, 0)
+        body += name.encode() + b"\0" + b"".join(struct.pack("<I", n << 4 | op) for op, n in ops)
+        body += bytes((l_seq + 1) // 2) + b"\xff" * l_seq
+        offs.append(len(blob))
+        blob += struct.pack("<i", len(body)) + body
+        ends.append(end)
+    offs.append(len(blob))
+    text = "@HD\tVN:1.5\tSO:coordinate\n" + "".join("@SQ\tSN:{}\tLN:{}\n".format(c, synth_bam.CONTIG_LEN) for c in synth_bam.CONTIGS)
+    header = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(synth_bam.CONTIGS))
+    for c in synth_bam.CONTIGS:
+        header += struct.pack("<i", len(c) + 1) + c.encode() + b"\x00" + struct.pack("<i", synth_bam.CONTIG_LEN)
+    starts = list(range(0, len(blob), block))
+    with open(path, "wb") as fp:
+        fp.write(synth_bam._bgzf_block(header, 1))
+        co = []
+        for a in starts:
+            co.append(fp.tell())
+            fp.write(synth_bam._bgzf_block(blob[a:a + block], 1))
+        co.append(fp.tell())
+        fp.write(synth_bam._EOF_BLOCK)
+    off = np.array(offs, np.int64)
+    co = np.array(co, np.int64)
+    which = np.where(off >= len(blob), len(starts), np.minimum(off // block, len(starts) - 1))
+    v = (co[which] << 16) | np.where(which < len(starts), off - which * block, 0)
+    pos = np.array([r[0] for r in recs], np.int64)
+    end = np.array(ends, np.int64)
+    synth_bam._write_bai(path + ".bai", np.full(len(recs), tid), pos, end, synth_bam._reg2bin(pos, end), v[:-1], v[1:])
+    return len(recs)
+
+
+@pytest.mark.parametrize("block", [500, 6000, 0xff00])
+def test_heads_longer_than_the_window_and_names_seen_three_times(inf, tmp_path, block):
+    """Records whose name and CIGAR do not fit the part of the LDS window a record is promised (512 bytes), CIGARs of
+    200 operations with clips at both ends, third records under a name, unmapped and duplicate reads: lists, offsets and the
+    scan as the host computes them."""
+    path = str(tmp_path / "odd.bam")
+    assert _odd_bam(path, np.random.default_rng(block), block) > 1000
+    repo, names = TREDsRepo(), ["HD"]
+    f = bamio.AlignmentFile(path)
+    sites, regions = _site_arrays(repo, names, [repo["HD"]], f)
+    plan = f.plan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, [f], [plan])
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, _ = _walk_inputs([f], [sites], [150], firsts)
+    alt_tasks, alt_chunks, _ = _alt_inputs([f], [sites], [regions], [150], firsts)
+    status, crc, res, gp, tp, ares, alt_need = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=alt_tasks, alt_chunks=alt_chunks)
+    assert (status == 0).all() and res["status"][0] == 0, res
+    t = repo["HD"]
+    g = bamio.AlignmentFile(path)
+    eg, et = g.pe_lengths(t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE, t.repeat_start - FLANKMATCH,
+                          t.repeat_end + FLANKMATCH, SPAN)
+    assert list(gp[res["global_first"][0]:][:res["n_global"][0]]) == eg and list(tp[res["target_first"][0]:][:res["n_target"][0]]) == et
+    assert len(eg) + len(et) > 20
+    n, vbeg, vend = _window_span(path, t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE, t.repeat_start - SPAN, t.repeat_end + SPAN)
+    assert (int(res["n_window"][0]), int(res["win_vbeg"][0]), int(res["win_vend"][0])) == (n, vbeg, vend) and n > 30
+    need = walk_need(coff_of[0], host_of[0], res, alt_need)
+    inf.fetch(need)
+    f.preload(inf.out_addr, ooff[:n_all + 1], np.where(need != 0, status, 1).astype(np.int32), crc)
+    u2, p2 = f.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(res, gp, tp), alt=ares)
+    f.preload_clear()
+    units, pools = g.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    for key in units.dtype.names:
+        assert (units[key] == u2[key]).all(), key
+    for key in pools:
+        assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
+    f.close(); g.close()
