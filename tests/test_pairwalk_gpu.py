@@ -278,7 +278,7 @@ def test_a_short_random_campaign(capsys, monkeypatch):
     assert out["mismatching_regions"] == 0 and out["mismatching_scans"] == 0
 
 
-def _odd_bam(path, rng, block):
+def _odd_bam(path, rng, block, no_end=False):
     """A BAM around the HD locus whose records have heads of every size: names of 1-250 characters, CIGARs of 1-220
     operations (soft / hard clips at the ends, M I D N = X inside), secondary / supplementary copies under the same name,
     duplicates, unmapped mates -- in blocks of `block` bytes cut without regard to records."""
@@ -289,7 +289,10 @@ def _odd_bam(path, rng, block):
     for i in range(700):
         name = ("q%d_" % i + "x" * int(rng.integers(0, 245)))[:250]
         pos = int(t.repeat_start + rng.integers(-11000, 11000))
-        for mate in range(int(rng.choice([1, 2, 2, 2, 3]))):
+        n_mates = int(rng.choice([1, 2, 2, 2, 3]))
+        if no_end and i == 350:
+            pos, n_mates = t.repeat_start - 200, 2
+        for mate in range(n_mates):
             n_ops = int(rng.choice([1, 2, 3, 5, 40, 130, 220]))
             ops = []
             if rng.random() < 0.3:
@@ -311,6 +314,10 @@ def _odd_bam(path, rng, block):
                 ops = []
             if mate == 2:
                 flag |= 0x800
+            if no_end and i == 350 and mate == 1:
+                flag, ops = (flag | 0x10) & ~0x404, []       # a mapped reverse mate without a CIGAR: no alignment end
+            if no_end and i == 350 and mate == 0:
+                flag &= ~0x414
             p = pos + (int(rng.integers(150, 700)) if mate else 0)
             ref = sum(n for op, n in ops if op in (0, 2, 3, 7, 8))
             mtid, mpos = (tid, int(t.repeat_start + rng.integers(-900, 900))) if rng.random() < 0.5 else (-1, -1)
@@ -380,6 +387,35 @@ def test_heads_longer_than_the_window_and_names_seen_three_times(inf, tmp_path, 
     u2, p2 = f.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(res, gp, tp), alt=ares)
     f.preload_clear()
     units, pools = g.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    for key in units.dtype.names:
+        assert (units[key] == u2[key]).all(), key
+    for key in pools:
+        assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
+    f.close(); g.close()
+
+
+def test_a_pair_without_alignment_end_is_the_hosts_to_report(inf, tmp_path):
+    """The reference dies in get_target_length when the second read of a +/- pair has no alignment end (`None - int`); the
+    kernel ends that region with status 5, the scan walks it itself and reports what the plain scan reports (pe_status
+    -9: the locus is dropped)."""
+    path = str(tmp_path / "noend.bam")
+    _odd_bam(path, np.random.default_rng(7), 6000, no_end=True)
+    repo, names = TREDsRepo(), ["HD"]
+    f = bamio.AlignmentFile(path)
+    sites, regions = _site_arrays(repo, names, [repo["HD"]], f)
+    plan = f.plan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, [f], [plan])
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, _ = _walk_inputs([f], [sites], [150], firsts)
+    status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks)
+    assert res["status"][0] == 5
+    need = walk_need(coff_of[0], host_of[0], res)
+    inf.fetch(need)
+    f.preload(inf.out_addr, ooff[:n_all + 1], np.where(need != 0, status, 1).astype(np.int32), crc)
+    u2, p2 = f.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(res, gp, tp))
+    f.preload_clear()
+    g = bamio.AlignmentFile(path)
+    units, pools = g.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    assert units["pe_status"][0] == -9 and u2["pe_status"][0] == -9
     for key in units.dtype.names:
         assert (units[key] == u2[key]).all(), key
     for key in pools:
