@@ -321,12 +321,18 @@ def _odd_bam(path, rng, block, no_end=False):
             p = pos + (int(rng.integers(150, 700)) if mate else 0)
             ref = sum(n for op, n in ops if op in (0, 2, 3, 7, 8))
             mtid, mpos = (tid, int(t.repeat_start + rng.integers(-900, 900))) if rng.random() < 0.5 else (-1, -1)
-            recs.append((p, name, flag, ops, l_seq, ref, mtid, mpos))
-    recs.sort(key=lambda r: r[0])
+            recs.append((tid, p, name, flag, ops, l_seq, ref, mtid, mpos))
+    # mates rescued from two of the locus' alternative loci: three in the first, nine (more than a result holds) in the second
+    for (contig, lo, hi), count in zip([a for a in t.alt if a[0] in synth_bam.CONTIGS][:2], (3, 9)):
+        for k in range(count + 4):
+            in_window = k < count
+            recs.append((synth_bam.CONTIGS.index(contig), int(lo + rng.integers(0, hi - lo - 60)), "alt%d_%d" % (lo, k), 0x1 | 0x40,
+                         [(0, 80)], 80, 80, tid if in_window else tid + 1, int(t.repeat_start + rng.integers(-800, 800))))
+    recs.sort(key=lambda r: (r[0], r[1]))
     blob, offs, ends = b"", [], []
-    for p, name, flag, ops, l_seq, ref, mtid, mpos in recs:
+    for rtid, p, name, flag, ops, l_seq, ref, mtid, mpos in recs:
         end = p + ref if (ref and not flag & 4) else p + 1
-        body = struct.pack("<iiBBHHHiiii", tid, p, len(name) + 1, 0 if flag & 4 else 60, int(synth_bam._reg2bin(np.array([p]), np.array([end]))[0]),
+        body = struct.pack("<iiBBHHHiiii", rtid, p, len(name) + 1, 0 if flag & 4 else 60, int(synth_bam._reg2bin(np.array([p]), np.array([end]))[0]),
                            len(ops), flag, l_seq, mtid, mpos, 0)
         body += name.encode() + b"\0" + b"".join(struct.pack("<I", n << 4 | op) for op, n in ops)
         body += bytes((l_seq + 1) // 2) + b"\xff" * l_seq
@@ -351,9 +357,9 @@ def _odd_bam(path, rng, block, no_end=False):
     co = np.array(co, np.int64)
     which = np.where(off >= len(blob), len(starts), np.minimum(off // block, len(starts) - 1))
     v = (co[which] << 16) | np.where(which < len(starts), off - which * block, 0)
-    pos = np.array([r[0] for r in recs], np.int64)
+    pos = np.array([r[1] for r in recs], np.int64)
     end = np.array(ends, np.int64)
-    synth_bam._write_bai(path + ".bai", np.full(len(recs), tid), pos, end, synth_bam._reg2bin(pos, end), v[:-1], v[1:])
+    synth_bam._write_bai(path + ".bai", np.array([r[0] for r in recs]), pos, end, synth_bam._reg2bin(pos, end), v[:-1], v[1:])
     return len(recs)
 
 
@@ -373,6 +379,11 @@ def test_heads_longer_than_the_window_and_names_seen_three_times(inf, tmp_path, 
     alt_tasks, alt_chunks, _ = _alt_inputs([f], [sites], [regions], [150], firsts)
     status, crc, res, gp, tp, ares, alt_need = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=alt_tasks, alt_chunks=alt_chunks)
     assert (status == 0).all() and res["status"][0] == 0, res
+    # the two alternative loci that hold rescued mates: three records found in the first, the second has more than a
+    # result holds and is left to the scan (status 6); every other region is empty
+    walkable = alt_tasks["n_chunks"] >= 0
+    assert sorted(ares["status"][walkable].tolist())[-2:] == [0, 6] and (ares["status"][walkable] != 0).sum() == 1
+    assert sorted(ares["n"][ares["status"] == 0].tolist())[-2:] == [0, 3]
     t = repo["HD"]
     g = bamio.AlignmentFile(path)
     eg, et = g.pe_lengths(t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE, t.repeat_start - FLANKMATCH,
