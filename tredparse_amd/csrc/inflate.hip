@@ -684,8 +684,9 @@ __global__ __launch_bounds__(LANES, 7) void inflate_kernel(const uint32_t* __res
 // through LDS, not through HBM: the wavefront copies 6 KB of the block stream at a time into LDS (one coalesced load for
 // ~16 records; a lane walking the records in global memory paid a miss of 1-2 us for each, and several per record: 24 ms
 // for a region of 4 000 records), follows the length words there, and then every lane parses ONE of the records found
-// (walk_region_records).  The name table lives in LDS as well (16 384 slots of tag << 13 | pair index, the pair's record
-// count in a byte array beside it), so finding a record's mate costs no memory access either; what a tag match does NOT
+// (walk_region_records).  The name table lives in LDS as well (slots of tag << 15 | records seen under the tag << 13 | pair
+// index: one LDS read finds a record's mate AND says whether it is the pair's second record), so finding a record's mate
+// costs no memory access either; what a tag match does NOT
 // prove -- that the two names are equal byte for byte -- is checked for all pairs at the end by the 64 lanes in parallel,
 // and a single mismatch there gives the region back to the host, as does anything else out of the ordinary: a block the
 // plan does not hold or the decoder rejected or whose CRC-32 is not its trailer's, a record that makes no sense, more names
@@ -697,14 +698,14 @@ struct WalkView {
     const uint32_t* xcrc; const int64_t* bcoff; const int32_t* bclen;   // from the file: trailer CRC, compressed offset / length
     int64_t out_end;                                  // bytes of `out` that may be read
 };
-struct WalkPair { int64_t name_at, name2_at; int32_t a_pos, a_lead, b_end, b_trail; uint16_t name_len; uint8_t a_rev, b_rev, pad[4]; };
+struct WalkPair { int64_t name_at, name2_at; int32_t a_pos, a_lead, b_end, b_trail; uint16_t name_len; uint8_t a_rev, b_rev, complete, pad[3]; };
 static_assert(sizeof(WalkPair) == 40, "WalkPair layout");
 struct WalkRepeat { int32_t pair; int32_t pad; int64_t name_at; };   // a third, fourth ... record under a pair's tag
 constexpr int WALK_PAIR_CAP = 8192;               // names per region at most (a +-10 kb window at 30x holds ~2 100) ...
-constexpr int WALK_PAIR_CAP_SMALL = 4096;         // ... and what a launch whose regions are all short is given: 42 instead of
-                                                  // 78 KB of LDS per wavefront, so that other kernels' workgroups -- the
+constexpr int WALK_PAIR_CAP_SMALL = 4096;         // ... and what a launch whose regions are all short is given: 38 instead of
+                                                  // 70 KB of LDS per wavefront, so that other kernels' workgroups -- the
                                                   // decoder's, the genotyping kernels' of the other driver processes -- still
-                                                  // find LDS on the CUs a walk occupies (two walks of 78 KB fill a CU's 160 KB)
+                                                  // find LDS on the CUs a walk occupies (two walks of 70 KB nearly fill a CU's 160 KB)
 constexpr int WALK_REPEAT_CAP = 2048;
 constexpr int WALK_WINDOW = 6144;                 // bytes of the block stream in LDS
 constexpr int WALK_HEAD = 512;                    // a record's head (fixed fields, name, CIGAR) should lie in the window
@@ -724,12 +725,12 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef uint32_t walk_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) walk_u32x4 lds_u128;
 struct WalkLds {                                  // (views into the launch's dynamic LDS: walk_lds_bytes(cap))
-    lds_u32* table;                               // 2 * cap slots, open addressing at a load below one half.  0: free; else tag << 13 | pair index, tag != 0
-    lds_u8* seen;                                 // cap: records under the pair's tag so far (saturates)
+    lds_u32* table;                               // 2 * cap slots, open addressing at a load below one half.  0: free; else
+                                                  // tag << 15 | records under the tag so far (saturates at 3) << 13 | pair index, tag != 0
     lds_u8* window;                               // WALK_WINDOW bytes, 16-byte aligned
     int cap; uint32_t mask;
 };
-constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 8 + (size_t)cap + WALK_WINDOW; }
+constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 8 + WALK_WINDOW; }
 
 // Every lane holds the same value: say so (v_readfirstlane), and what is computed from it is computed once, on the
 // scalar unit, with scalar branches -- not 64 times on the vector unit with the exec mask rebuilt at every `if`.
@@ -871,13 +872,20 @@ __device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T
                 const uint64_t at = cur.tell();
                 if (at >= ch.end_voffset) { chunk_done = true; break; }
                 int64_t a0, r;
-                const bool word_here = cur.upos + 4 <= cur.size;           // (nearly always: the length word lies in this block)
-                const WalkCursor before = cur;
-                if (word_here) { a0 = cur.first + cur.upos; cur.upos += 4; }
-                else if ((rc = cur.take(v, T, 4, &a0)) != 0) { err = rc; break; }
-                if (!rd.inside(a0, WALK_HEAD)) {
-                    if (nb > 0) { cur = before; break; }                   // the next batch starts with a fresh window
-                    rd.fill(a0);
+                if (cur.upos + 4 <= cur.size) {                            // (nearly always: the length word lies in this block)
+                    a0 = cur.first + cur.upos;
+                    if (!rd.inside(a0, WALK_HEAD)) {
+                        if (nb > 0) break;                                 // the next batch starts with a fresh window
+                        rd.fill(a0);
+                    }
+                    cur.upos += 4;
+                } else {
+                    const WalkCursor before = cur;
+                    if ((rc = cur.take(v, T, 4, &a0)) != 0) { err = rc; break; }
+                    if (!rd.inside(a0, WALK_HEAD)) {
+                        if (nb > 0) { cur = before; break; }
+                        rd.fill(a0);
+                    }
                 }
                 const int32_t size = (int32_t)rd.u32(a0);
                 if (size < 32) { err = WALK_BAD_RECORD; break; }
@@ -956,37 +964,33 @@ __device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
-                uint32_t tag = hj >> 13;
+                uint32_t tag = hj >> 15;
                 if (tag == 0) tag = 1;
                 uint32_t slot = hj & S.mask;
-                int idx = -1;
+                int idx = -1, seen = 0;
                 for (;; slot = (slot + 1) & S.mask) {
                     const uint32_t entry = walk_uniform(S.table[slot]);
                     if (entry == 0) break;
-                    if ((entry >> 13) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); break; }
+                    if ((entry >> 15) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); seen = (int)((entry >> 13) & 3); break; }
                 }
-                int seen = 0;
                 if (idx < 0) {
                     if (np >= S.cap) return WALK_TABLE_FULL;
                     idx = np++;
-                    if (lane == j) S.table[slot] = (tag << 13) | (uint32_t)idx;
-                } else {
-                    seen = (int)walk_uniform(S.seen[idx]);
                 }
                 if (seen >= 2 && nrep >= WALK_REPEAT_CAP) return WALK_TABLE_FULL;
                 if (lane == j) {
+                    if (seen < 3) S.table[slot] = (tag << 15) | ((uint32_t)(seen + 1) << 13) | (uint32_t)idx;
                     if (seen == 0) {
                         WalkPair& P = pairs[idx];
                         P.name_at = my_a0 + 36; P.name_len = (uint16_t)nlen;
-                        P.a_pos = rpos; P.a_lead = lead; P.a_rev = (flag & 0x10) ? 1 : 0;
+                        P.a_pos = rpos; P.a_lead = lead; P.a_rev = (flag & 0x10) ? 1 : 0; P.complete = 0;
                     } else if (seen == 1) {
                         WalkPair& P = pairs[idx];
                         P.name2_at = my_a0 + 36;
-                        P.b_end = rend; P.b_trail = trail; P.b_rev = (flag & 0x10) ? 1 : 0;
+                        P.b_end = rend; P.b_trail = trail; P.b_rev = (flag & 0x10) ? 1 : 0; P.complete = 1;
                     } else {                                                // the pair is complete: only the name matters
                         repeats[nrep].pair = idx; repeats[nrep].name_at = my_a0 + 36;
                     }
-                    if (seen < 3) S.seen[idx] = (uint8_t)(seen + 1);
                 }
                 if (seen >= 2) ++nrep;
                 walk_lds_order();
@@ -1028,7 +1032,6 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
     S.mask = 2u * (uint32_t)table_cap - 1;
     S.window = (lds_u8*)walk_lds;
     S.table = (lds_u32*)(S.window + WALK_WINDOW);
-    S.seen = S.window + WALK_WINDOW + (size_t)table_cap * 8;
     for (int k = lane; k < 2 * table_cap; k += LANES) S.table[k] = 0;
     WalkPair* pairs = pairs_all + (size_t)t * WALK_PAIR_CAP;
     WalkRepeat* repeats = repeats_all + (size_t)t * WALK_REPEAT_CAP;
@@ -1055,7 +1058,7 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
         for (int q0 = 0; q0 < np; q0 += LANES) {
             const int q = q0 + lane;
             int cls = 0;                                   // 1 global, 2 target
-            if (q < np && S.seen[q] >= 2) {
+            if (q < np && pairs[q].complete) {
                 const WalkPair P = pairs[q];
                 clash |= !walk_same_name(v.out, P.name_at, P.name2_at, P.name_len);
                 if (!P.a_rev && P.b_rev) {                 // mapped in +, - orientation
@@ -1084,7 +1087,7 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
                 const int q = q0 + lane;
                 int cls = 0;
                 int32_t len32 = 0;
-                if (q < np && S.seen[q] >= 2) {
+                if (q < np && pairs[q].complete) {
                     const WalkPair P = pairs[q];
                     if (!P.a_rev && P.b_rev) {
                         const int64_t tlen = ((int64_t)P.b_end + P.b_trail) - ((int64_t)P.a_pos - P.a_lead);
@@ -1212,7 +1215,7 @@ __global__ void __launch_bounds__(LANES) alt_walk_kernel(WalkView v, const tredg
     extern __shared__ __attribute__((aligned(16))) uint8_t walk_lds[];
     const int t = blockIdx.x, lane = threadIdx.x;
     WalkLds S;
-    S.cap = 0; S.mask = 0; S.table = nullptr; S.seen = nullptr;
+    S.cap = 0; S.mask = 0; S.table = nullptr;
     S.window = (lds_u8*)walk_lds;
     const tredgpu_walk_task T = tasks[t];
     WalkReader rd;
