@@ -347,7 +347,7 @@ def rank_main(args):
                        "parallelism": "sample-sharded x{} (no collective)".format(world)},
             "roofline": {"kernel": "sw_cont_kernel<{},{}>".format(rpl, {4: 6, 7: 4, 10: 4, 16: 2, 20: 2}[rpl]), "bound": "valu",
                          "achieved": swept / sw_s / 1e12, "peak": PEAK_TCUPS, "unit": "TCUPS",
-                         "frac": swept / sw_s / 1e12 / PEAK_TCUPS,
+                         "frac": swept / sw_s / 1e12 / PEAK_TCUPS, "mix_ceiling_frac": mix_ceiling(),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                          "note": "achieved = DP cells really swept per launch (read rows x columns of every read; "
@@ -498,16 +498,39 @@ def stub_rank_main(args):
                        "ms_per_step": elapsed / args.steps * 1e3, "stub": True}, fp)
 
 
-# ---- end to end from BAM files (one child process with the GPU; the launcher made the files) -----------------------
+# ---- end to end from BAM files (driver processes share the GPUs; the launcher made the files) -------------------------
+def _output_digests(work):
+    """{samplekey: sha256 over the sample's JSON bytes and its VCF text} of the files a driver wrote (the VCF is hashed
+    decompressed: the gzip header carries the time of writing)."""
+    import gzip
+    import hashlib
+    out = {}
+    for name in sorted(os.listdir(work)):
+        if not name.endswith(".json"):
+            continue
+        key = name[:-5]
+        h = hashlib.sha256()
+        with open(os.path.join(work, name), "rb") as fp:
+            h.update(fp.read())
+        vcf = os.path.join(work, key + ".tred.vcf.gz")
+        if os.path.exists(vcf):
+            with open(vcf, "rb") as fp:
+                h.update(gzip.decompress(fp.read()))
+        out[key] = h.hexdigest()
+    return out
+
+
 def e2e_main(args):
-    """The product path over synthetic BAMs: tred.run_many = native scans in host threads -> GPU batches -> tredCalls
-    -> <key>.json + <key>.tred.vcf.gz written to a scratch directory.  One or several driver processes (ranks) share
-    the GPU; each takes its block of the BAMs (shard_range), they start together (barrier) and the slowest one's
-    time counts."""
+    """One driver process of an end-to-end leg: the product path over synthetic BAMs -- tred.run_many = native scans in
+    host threads -> GPU batches -> tredCalls -> <key>.json + <key>.tred.vcf.gz in a scratch directory.  The drivers of a
+    leg each take a block of the BAMs (shard_range), start together (barrier) and go over their block again and again
+    until `--e2e-seconds` have passed (at least once in full); every finished sample is logged with its wall-clock time,
+    and the launcher reads the steady-state rate off those logs (steady_state)."""
     import glob
     import shutil
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     out_dir = os.environ["TREDBENCH_OUT"]
+    t_proc = time.time()
     with open(os.path.join(args.e2e_child, "truth.json")) as fp:
         truth = json.load(fp)
     bams = sorted(glob.glob(os.path.join(args.e2e_child, "*.bam")))
@@ -521,54 +544,65 @@ def e2e_main(args):
     lo, hi = shard.shard_range(len(bams), rank, world)
     repo = TREDsRepo("hg38", sites=os.path.join(args.e2e_child, "no_sites"))
     names = [l["name"] for l in synth_bam.bench_loci()]
-    tasks = [(os.path.basename(b)[:-4], b, repo, names, 300, False, False, True, True, "ERROR") for b in bams[lo:hi]]
-    tasks = tasks * max(1, args.e2e_repeat)       # a longer cohort out of the same files (outputs are rewritten)
-    threads = max(1, min(args.e2e_threads or max(1, (shard.usable_cpus() - world) // world), max(len(tasks), 1)))
+    mine = [(os.path.basename(b)[:-4], b, repo, names, 300, False, False, True, True, "ERROR") for b in bams[lo:hi]]
+    pinned = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else shard.usable_cpus()
+    # never more scan threads than this rank's CPU set holds (spawn_ranks pins a rank to its share of its GPU's node)
+    threads = max(1, min(args.e2e_threads or max(1, (shard.usable_cpus() - world) // world), max(len(mine), 1), max(1, pinned)))
     engine = Engine(0)
     work = os.path.join(args.e2e_child, "work{}".format(rank))
     os.makedirs(work, exist_ok=True)
     cwd = os.getcwd()
     os.chdir(work)
-    done = []
+    log = []                                     # (wall-clock time, units, short alleles right, short alleles) per sample
     dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    first_pass = {"n": len(tasks) // max(1, args.e2e_repeat), "t": None}
+    gpu_inflate, gpu_walk = args.e2e_gpu_inflate == "1", args.e2e_gpu_walk == "1"
+    sink_lock = __import__("threading").Lock()
 
     def sink(result):
         tred.write_vcf_json(result, "hg38", repo, names, quiet=True)
-        done.append(result)
-        if first_pass["t"] is None and len(done) >= first_pass["n"]:       # (two writer threads: whoever gets there first)
-            first_pass["t"] = time.perf_counter()
+        calls, tr = result["tredCalls"], truth[result["samplekey"]]
+        units = sum(1 for n in names if n + ".1" in calls)
+        hits = sum(1 for k, n in enumerate(names) if calls.get(n + ".1") == tr[k][0])
+        with sink_lock:
+            log.append((time.time(), units, hits, len(names)))
+
+    deadline = [None]
+
+    def cohort():
+        """The driver's block of samples, over and over: at least once, and until the deadline."""
+        passes = 0
+        while passes == 0 or time.time() < deadline[0]:
+            for t in mine:
+                if passes > 0 and time.time() >= deadline[0]:
+                    return
+                yield t
+            passes += 1
+    kw = dict(sink=sink, lazy_details=True, inflate_device=0 if gpu_inflate else None, gpu_walk=gpu_walk)
     try:
-        # warm-up: HIP context, ladders, caches -- and, for the GPU-inflate legs, one full chunk through the inflaters, whose
+        # warm-up: HIP context, ladders, caches -- and, for the GPU-inflate legs, one full chunk through each inflater, whose
         # pinned staging (45 MB per sample of a chunk, three inflaters) stays with the process for the timed cohort
-        warm = tasks[:2] if args.e2e_gpu_inflate != "1" else tasks[:min(len(tasks), 3 * args.e2e_batch)]
-        tred.run_many(warm, engine, batch=2 if args.e2e_gpu_inflate != "1" else args.e2e_batch, sink=sink, threads=max(2, threads),
-                      lazy_details=True, inflate_device=0 if args.e2e_gpu_inflate == "1" else None,
-                      gpu_walk=args.e2e_gpu_walk == "1")
-        del done[:]
+        warm = mine[:2] if not gpu_inflate else mine[:min(len(mine), 3 * args.e2e_batch)]
+        tred.run_many(warm, engine, batch=2 if not gpu_inflate else args.e2e_batch, threads=max(2, threads), **kw)
+        del log[:]
         for k in tred.TIMING:
             tred.TIMING[k] = 0.0
         if dist is not None:
             dist.barrier()
-        t0 = time.perf_counter()
-        tred.run_many(tasks, engine, batch=args.e2e_batch, sink=sink, threads=threads, lazy_details=True,
-                      background_sink=True, sink_threads=2 if args.e2e_gpu_inflate == "1" else 1,
-                      inflate_device=0 if args.e2e_gpu_inflate == "1" else None, gpu_walk=args.e2e_gpu_walk == "1",
-                      genotype_chunks=args.e2e_genotype_chunks if args.e2e_gpu_inflate == "1" else 1)
-        dt = time.perf_counter() - t0
+        t0 = time.time()
+        deadline[0] = t0 + args.e2e_seconds
+        tred.run_many(cohort(), engine, batch=args.e2e_batch, threads=threads, background_sink=2 if gpu_inflate else 1, **kw)
+        t1 = time.time()
     finally:
         os.chdir(cwd)
-    units = sum(sum(1 for n in names if n + ".1" in r["tredCalls"]) for r in done)
-    hits = [r["tredCalls"].get(n + ".1") == truth[r["samplekey"]][k][0] for r in done for k, n in enumerate(names)]
-    rec = {"rank": rank, "device": os.environ.get("TRED_RANK_DEVICE", "0"), "units": units, "seconds": dt,
-           "samples": len(tasks), "host_threads": threads,
-           "first_pass_seconds": (first_pass["t"] - t0) if first_pass["t"] else dt, "first_pass_samples": first_pass["n"],
+    log.sort()
+    np.save(os.path.join(out_dir, "e2e_log{}.npy".format(rank)), np.array(log, np.float64).reshape(-1, 4))
+    rec = {"rank": rank, "device": os.environ.get("TRED_RANK_DEVICE", "0"), "t_process": t_proc, "t_begin": t0, "t_end": t1,
+           "files": len(mine), "host_threads": threads, "first_chunk": min(args.e2e_batch, threads, max(1, len(mine))),
            "driver_seconds": {k: round(v, 4) for k, v in tred.TIMING.items()},
-           "short_ok": int(sum(hits)), "short_n": len(hits), "bam_bytes": sum(os.path.getsize(b) for b in bams[lo:hi])}
+           "bam_bytes": sum(os.path.getsize(b) for b in bams[lo:hi]), "digests": _output_digests(work)}
     with open(os.path.join(out_dir, "e2e_rank{}.json".format(rank)), "w") as fp:
         json.dump(rec, fp)
     if dist is not None:
@@ -577,24 +611,48 @@ def e2e_main(args):
     shutil.rmtree(work, ignore_errors=True)
 
 
+def steady_state(ranks, logs):
+    """The rates of one end-to-end leg from its drivers' records and per-sample logs (rows: time, units, hits, loci).
+      value            units finished inside the window in which EVERY driver is past its first chunk and none has
+                       finished, over that window's length: no pipeline fill, no drain
+      startup_s        from the common start (the barrier) to the window's start
+      whole_run_value  all units over (last finish - common start): fill and drain included
+      first_pass_value the units of every driver's first pass over its files, over the time the slowest driver took"""
+    t0 = min(r["t_begin"] for r in ranks)
+    w0 = max(float(l[min(r["first_chunk"], len(l)) - 1, 0]) for r, l in zip(ranks, logs))
+    w1 = min(float(l[-1, 0]) for l in logs)
+    every = np.concatenate(logs)
+    inside = (every[:, 0] > w0) & (every[:, 0] <= w1)
+    units_in = float(every[inside, 1].sum())
+    last = max(float(l[-1, 0]) for l in logs)
+    fp_units = sum(float(l[:r["files"], 1].sum()) for r, l in zip(ranks, logs))
+    fp_end = max(float(l[min(r["files"], len(l)) - 1, 0]) for r, l in zip(ranks, logs))
+    return {"value": units_in / max(w1 - w0, 1e-9), "seconds": w1 - w0, "units": units_in, "samples": int(inside.sum()),
+            "startup_s": w0 - t0, "whole_run_value": float(every[:, 1].sum()) / max(last - t0, 1e-9),
+            "whole_run_seconds": last - t0, "first_pass_value": fp_units / max(fp_end - t0, 1e-9),
+            "short_allele_exact_frac": float(every[:, 2].sum()) / max(1.0, float(every[:, 3].sum()))}
+
+
+def e2e_rule(n_devices, usable):
+    """THE plan of the end-to-end leg, fixed before anything runs, from (usable host CPUs, GPUs) alone -- the same rule
+    the product's command line applies when --drivers is left to it (shard.driver_plan): (ranks, threads per rank)."""
+    from tredparse_amd import shard
+    per_gpu, threads = shard.driver_plan(usable, n_devices)
+    return per_gpu * max(1, n_devices), threads
+
+
 def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0, dense=False):
-    """[(ranks, threads per rank)] of the end-to-end legs on n_devices GPUs with `usable` host CPUs: one driver per
-    GPU, and as many drivers per GPU as keep ~7 or ~4 scan threads busy each (a driver formats and hands its results
-    to a writer thread while its threads scan); dense: also one driver per four and per three CPUs (the legs whose BGZF
-    blocks the GPU inflates leave the host a quarter of the work per sample: a driver's own Python threads -- formatting,
-    the writer, the GPU calls -- become the bound, and more processes is what spreads those).
+    """--e2e-sweep only: [(ranks, threads per rank)] of the plans tried beside the rule's -- one driver per GPU, and as
+    many drivers per GPU as keep ~7 or ~4 scan threads busy each; dense: also one driver per four, per three and per 2.7
+    CPUs (the legs whose BGZF blocks the GPU inflates leave the host a quarter of the work per sample).
     Rank r works on device r mod n_devices; every rank gets an equal share of the CPUs."""
     g = max(1, n_devices)
     tried = [drivers_opt] if drivers_opt else [max(1, usable // (8 * g)), max(1, usable // (5 * g))]
     if dense and not drivers_opt:
-        # (... and one per 2.7 CPUs with three scan threads each: with the pair walks on the GPU a scan is a third of the
-        #  work, and what bounds a driver is its interpreter lock -- measured 25.2-25.6 k genotypes/s against 24.6 k)
         tried += [max(1, usable // (4 * g)), max(1, usable // (3 * g)), max(1, (3 * usable) // (8 * g))]
     plans = []
     for dpg in sorted(set([1] + tried)):
         ranks = dpg * n_devices
-        # one core is left to the drivers together: a driver thread (batches, formatting) is busy about a third of
-        # the time, its writer thread mostly outside the interpreter lock
         threads = threads_opt or max(1, (usable - 1) // ranks)
         if dense and not threads_opt and not drivers_opt and dpg == max(1, (3 * usable) // (8 * g)) and dpg > usable // (3 * g):
             threads = max(threads, 3)
@@ -602,93 +660,131 @@ def e2e_plan(n_devices, usable, drivers_opt=0, threads_opt=0, dense=False):
     return plans
 
 
-def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None):
-    """Launcher side of the end-to-end legs: make the BAMs once (process pool, no GPU), then for every device count n
-    and every plan of e2e_plan start the driver ranks over the first n * per_gpu of them -- rank r on device r mod n
-    (shard.spawn_ranks), each with its block of the samples and its share of the host CPUs.  Returns {n: record}.
-    (spawn / make_bams: stand-ins for the CPU test of the launcher.)"""
+def e2e_cohort(root, made, n_files):
+    """The first n_files names of a cohort of n_files BAMs made out of the `made` distinct ones: beyond them, hard
+    links under new sample keys (one inode, so one copy in the page cache; outputs are per key).  Returns
+    {key: true alleles} of the added names."""
+    extra = {}
+    k = 0
+    while len(made) + len(extra) < n_files:
+        key, path, h = made[k % len(made)]
+        new = "{}x{}".format(key, k // len(made) + 1)
+        for ext in (".bam", ".bam.bai"):
+            src, dst = os.path.join(root, key + ext), os.path.join(root, new + ext)
+            if os.path.exists(src) and not os.path.exists(dst):
+                os.link(src, dst)
+        extra[new] = h
+        k += 1
+    return extra
+
+
+def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None):
+    """Launcher side of the end-to-end legs: make the BAMs once (process pool, no GPU), then for every device count n:
+    the host-only leg with one driver per GPU (the one that compares across rounds) and THE plan of e2e_rule (BGZF
+    inflate and pair walks on the GPU) over n * per_gpu files -- a constant cohort per GPU; with --e2e-sweep also the
+    other plans of e2e_plan.  Every leg's outputs are hashed and must agree.  Returns {n: record}.
+    (spawn / make_bams / read_leg: stand-ins for the CPU test of the launcher.)"""
     from tredparse_amd import shard
+    import hashlib
     import shutil
     if make_bams is None:
         from tredparse_amd import synth_bam
         make_bams = synth_bam.make_bams
     spawn = spawn or shard.spawn_ranks
+    read_leg = read_leg or _read_leg
     root = tempfile.mkdtemp(prefix="tredbench_e2e_")
     device_counts = sorted(set(device_counts))
-    # weak scaling: --e2e-samples per GPU, capped so that the largest leg stays at 512 files
-    per_gpu = {n: max(1, min(args.e2e_samples, 512 // n)) for n in device_counts}
+    usable = shard.usable_cpus()
+    per_gpu = max(1, args.e2e_samples)
+    distinct = min(per_gpu * max(device_counts), max(1, args.e2e_distinct))
     try:
         t0 = time.perf_counter()
-        made = make_bams(root, max(n * per_gpu[n] for n in device_counts), seed=args.seed, workers=shard.usable_cpus())
+        made = make_bams(root, distinct, seed=args.seed, workers=usable)
         gen_s = time.perf_counter() - t0
+        truth = {key: np.asarray(h).tolist() for key, _, h in made}
+        truth.update({k: np.asarray(h).tolist() for k, h in e2e_cohort(root, made, per_gpu * max(device_counts)).items()})
         with open(os.path.join(root, "truth.json"), "w") as fp:
-            json.dump({key: h.tolist() for key, _, h in made}, fp)
+            json.dump(truth, fp)
         out = {}
         for n_devices in device_counts:
+            n_files = n_devices * per_gpu
+            # (ranks, threads, gpu_inflate, gpu_walk, seconds): the continuity leg, then the rule's plan
+            plans = [(n_devices, max(1, (usable - 1) // n_devices), False, False, args.e2e_seconds / 2)]
+            rule = e2e_rule(n_devices, usable)
+            if args.e2e_drivers:
+                rule = (args.e2e_drivers * n_devices, args.e2e_threads or max(1, (usable - 1) // (args.e2e_drivers * n_devices)))
+            on = args.e2e_gpu_inflate != "0"
+            plans.append(rule + (on, on and args.e2e_gpu_walk == "1", args.e2e_seconds))
+            if args.e2e_sweep:
+                plans += [(d, t, False, False, args.e2e_seconds / 2) for d, t in e2e_plan(n_devices, usable) if d != n_devices]
+                plans += [(d, t, True, True, args.e2e_seconds / 2) for d, t in e2e_plan(n_devices, usable, dense=True) if (d, t) != rule]
+                plans.append(rule + (True, False, args.e2e_seconds / 2))
             legs = []
-            n_files = n_devices * per_gpu[n_devices]
-            walk_on = getattr(args, "e2e_gpu_walk", "1") == "1"
-            plans = [(d, t, False, False) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads)]
-            if args.e2e_gpu_inflate in ("1", "both"):
-                # the same plans (and denser ones) with the BGZF blocks inflated on the GPU, a batch of samples per launch, and
-                # the pair-length walks done there too; the densest plan once more with the walks left to the host
-                with_gpu = [(d, t, True, walk_on) for d, t in e2e_plan(n_devices, shard.usable_cpus(), args.e2e_drivers, args.e2e_threads, dense=True)]
-                if walk_on and not args.e2e_drivers:
-                    with_gpu.append(with_gpu[-1][:3] + (False,))
-                plans = with_gpu if args.e2e_gpu_inflate == "1" else plans + with_gpu
-            for drivers, threads, gpu_inflate, gpu_walk in plans:
+            for li, (drivers, threads, gpu_inflate, gpu_walk, seconds) in enumerate(plans):
                 batch = args.e2e_inflate_batch if gpu_inflate else args.e2e_batch
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
                         "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
-                        "--e2e-repeat", str(args.e2e_repeat), "--e2e-genotype-chunks", str(getattr(args, "e2e_genotype_chunks", 1)),
-                        "--e2e-gpu-walk", "1" if gpu_walk else "0"]
-                out_dir = os.path.join(root, "out{}x{}{}{}".format(n_devices, drivers, "g" if gpu_inflate else "", "w" if gpu_walk else ""))
+                        "--e2e-seconds", str(seconds), "--e2e-gpu-walk", "1" if gpu_walk else "0"]
+                out_dir = os.path.join(root, "out{}_{}".format(n_devices, li))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
+                leg = {"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate, "gpu_walk": gpu_walk,
+                       "host_threads_per_driver": threads, "samples_per_gpu_batch": batch, "files": n_files,
+                       "role": "host_only_one_driver_per_gpu" if li == 0 else "plan" if li == 1 else "sweep"}
                 codes = spawn(argv, drivers, n_devices, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
                 if any(codes):
-                    legs.append({"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate, "error": "exit codes {}".format(codes)})
+                    leg["error"] = "exit codes {}".format(codes)
+                    legs.append(leg)
                     continue
-                ranks = []
-                for r in range(drivers):
-                    with open(os.path.join(out_dir, "e2e_rank{}.json".format(r))) as fp:
-                        ranks.append(json.load(fp))
-                units, secs = sum(r["units"] for r in ranks), max(r["seconds"] for r in ranks)
-                nbytes = sum(r["bam_bytes"] for r in ranks)
-                legs.append({"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate,
-                             "gpu_walk": gpu_walk, "samples_per_gpu_batch": batch,
-                             "value": units / secs, "unit": "genotypes/s",
-                             "units": units, "seconds": secs, "samples": sum(r["samples"] for r in ranks),
-                             "host_threads_per_driver": ranks[0]["host_threads"], "bam_MB": nbytes / 1e6,
-                             "first_pass_value": sum(r.get("first_pass_samples", 0) for r in ranks) * units / max(1, sum(r["samples"] for r in ranks))
-                                                 / max(max(r.get("first_pass_seconds", secs) for r in ranks), 1e-9),
-                             "per_driver": [{"seconds": round(r["seconds"], 3), "device": r.get("device", "0"),
-                                             **r["driver_seconds"]} for r in ranks],
-                             "bam_MBps": nbytes / 1e6 / secs,
-                             "short_allele_exact_frac": sum(r["short_ok"] for r in ranks) / max(1, sum(r["short_n"] for r in ranks))})
-            best = max((l for l in legs if "value" in l), key=lambda l: l["value"], default=None)
-            rec = dict(best) if best else {"error": "no end-to-end leg finished"}
+                ranks, logs = read_leg(out_dir, drivers)
+                leg.update(steady_state(ranks, logs))
+                leg["unit"] = "genotypes/s"
+                leg["host_threads_per_driver"] = ranks[0]["host_threads"]
+                leg["warmup_s"] = max(r["t_begin"] - r["t_process"] for r in ranks)
+                digests = {}
+                for r in ranks:
+                    digests.update(r.pop("digests", {}))
+                leg["outputs"] = len(digests)
+                leg["outputs_sha256"] = hashlib.sha256(json.dumps(sorted(digests.items())).encode()).hexdigest()
+                leg["per_driver"] = [{"seconds": round(r["t_end"] - r["t_begin"], 3), "device": r.get("device", "0"),
+                                      **r["driver_seconds"]} for r in ranks]
+                leg["bam_MB"] = sum(r["bam_bytes"] for r in ranks) / 1e6
+                legs.append(leg)
+            good = [l for l in legs if "value" in l]
+            plan = [l for l in good if l["role"] == "plan"]
+            rec = dict(plan[0]) if plan else {"error": "the planned end-to-end leg did not finish"}
+            rec.pop("per_driver", None)
             rec["legs"] = legs
             rec["devices"] = n_devices
-            rec.setdefault("samples_per_gpu_batch", args.e2e_batch)
+            rec["outputs_identical"] = bool(good) and len(set((l["outputs"], l["outputs_sha256"]) for l in good)) == 1 \
+                and all(l["outputs"] == n_files for l in good)
             rec["bam_generation_seconds"] = gen_s
-            rec["cohort"] = "{} BAM files x {} passes per leg".format(n_files, max(1, args.e2e_repeat))
-            rec["page_cache"] = ("the files were written moments before the legs by this run: EVERY pass, the first included, reads them "
-                                 "from the page cache (`first_pass_value` = the rate up to the last result of a driver's first pass; "
-                                 "later passes also rewrite the same output files).  Not a cold-storage number; `value` is the best leg "
-                                 "over all passes, the leg with gpu_inflate false and one driver is the one that compares across rounds")
-            host_one = [l for l in legs if "value" in l and not l["gpu_inflate"] and l["drivers"] == n_devices]
+            rec["cohort"] = "{} BAM files per GPU ({} distinct, the rest hard links under their own sample keys), gone over " \
+                            "repeatedly for {:g} s".format(per_gpu, distinct, args.e2e_seconds)
+            rec["page_cache"] = "the files were written moments before the legs by this run: every pass reads them from the " \
+                                "page cache and rewrites the same output files; not a cold-storage number"
+            host_one = [l for l in good if l["role"] == "host_only_one_driver_per_gpu"]
             if host_one:
-                rec["host_only_one_driver_per_gpu"] = {k: host_one[0][k] for k in ("value", "first_pass_value", "seconds", "samples")}
-            rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> "
-                           "native scan (BGZF inflate -- on the host, or on the GPU a batch of samples per launch in the `gpu_inflate` legs --, BAI queries, read selection, pair lengths -- walked on the GPU over the inflated blocks in the `gpu_walk` legs, only the blocks of the loci's windows and alternative loci coming back --, depth) in host threads -> "
-                           "GPU batches -> tredCalls -> JSON + VCF files; `drivers` processes over `devices` GPUs (rank r on "
-                           "device r mod devices), each with its block of the samples and its share of the host CPUs "
-                           "(tred.py --gpus N uses the same fan-out)")
+                rec["host_only_one_driver_per_gpu"] = {k: host_one[0][k] for k in ("value", "first_pass_value", "seconds", "samples", "startup_s")}
+            rec["what"] = ("synthetic 30x 150bp BAMs (tredparse_amd/synth_bam.py: +-10.5 kb around each of the 30 loci) -> native "
+                           "scan (BGZF inflate and the pair-length walks on the GPU in the planned leg, on the host in the "
+                           "host-only leg; BAI queries, read selection, depth) in host threads -> GPU batches -> tredCalls -> "
+                           "JSON + VCF files; `drivers` processes over `devices` GPUs (rank r on device r mod devices).  "
+                           "`value` = units finished between every driver's first chunk and the first driver's last sample, "
+                           "over that time; the plan is e2e_rule(GPUs, usable CPUs), fixed before the run")
             out[n_devices] = rec
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)
+
+
+def _read_leg(out_dir, drivers):
+    ranks, logs = [], []
+    for r in range(drivers):
+        with open(os.path.join(out_dir, "e2e_rank{}.json".format(r))) as fp:
+            ranks.append(json.load(fp))
+        logs.append(np.load(os.path.join(out_dir, "e2e_log{}.npy".format(r))))
+    return ranks, logs
 
 
 # ---- launcher ------------------------------------------------------------------------------------------------
@@ -729,6 +825,68 @@ def sweep_counts(n_target, n_devices, sweep):
     return ns
 
 
+MIX_CEILING_FRAC = 0.39     # what sw_cont_kernel's own instruction mix allows of the 10-op/cell peak: see mix_ceiling()
+
+
+def mix_ceiling():
+    """roofline.mix_ceiling_frac: the fraction of `peak` (2-cycle issue, 10 ops per cell) that the kernel's instruction
+    mix can reach at all on gfx950.  profiles/r04_ubench_valu.txt: v_max_i32 / v_max3_i32 / v_add3_u32 / DPP max / v_cmp
+    issue at 4.1 cycles per wave64, plain add / mov at 2.1; the kernel's mix (r04_pmc_summary.json: 16.0 lane-ops per
+    swept cell, about two thirds of them 4-cycle) averages 3.2 cycles per instruction = 0.31 instr/SIMD-cycle against
+    the 0.5 the peak assumes, and spends 16.0 instead of 10 ops per cell: 0.31 / 0.5 x 10 / 16.0 = 0.39."""
+    return MIX_CEILING_FRAC
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(out):
+    """The ONE line the driver parses (<= 4 KB): the contract's keys, the roofline and CPU-baseline objects, one small
+    object per leg.  Everything else -- per-driver stage times, counters, prose, every plan of a sweep -- is in
+    bench_detail.json next to this script (and on stderr)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "library", "stub", "gpus_visible")
+    line = {k: _r(out[k]) for k in keep if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "name", "units_per_step_per_gpu", "reads_per_step_per_gpu", "parallelism") if k in cfg}
+    r = out.get("roofline")
+    if r:
+        line["roofline"] = {k: _r(r.get(k), 5) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "mix_ceiling_frac",
+                                                      "traffic", "traffic_over_algorithmic", "avg_launch_ms", "effective_TCUPS")}
+    if "kernels_ms_per_step" in out:
+        line["kernels_ms_per_step"] = {k: _r(v, 3) for k, v in out["kernels_ms_per_step"].items()}
+    for key in ("cpu_baseline", "cpu_baseline_1core"):
+        c = out.get(key)
+        if c:
+            line[key] = {k: _r(c[k], 3) for k in ("value", "unit", "cores", "kind") if k in c}
+            if key == "cpu_baseline":
+                line[key]["sample"] = c.get("sample", "")[:160]
+    e = out.get("end_to_end")
+    if e:
+        line["end_to_end"] = {k: _r(e[k], 3) for k in ("value", "unit", "first_pass_value", "whole_run_value", "startup_s", "drivers",
+                                                       "devices", "host_threads_per_driver", "gpu_inflate", "gpu_walk", "seconds", "samples",
+                                                       "files", "outputs_identical", "error") if k in e}
+        h = e.get("host_only_one_driver_per_gpu")
+        if h:
+            line["end_to_end"]["host_only_one_driver_per_gpu"] = {k: _r(h[k], 3) for k in ("value", "first_pass_value", "seconds")}
+    if "legs" in out:
+        line["legs"] = [{k: _r(l[k], 4) for k in ("leg", "value", "ms_per_step", "frac", "error") if k in l} for l in out["legs"]]
+    if "scaling_sweep" in out:
+        line["scaling_sweep"] = [dict({k: _r(s_[k], 3) for k in ("n", "value", "ms_per_step", "devices", "oversubscribed") if k in s_},
+                                      **({"end_to_end": _r(s_["end_to_end"]["value"], 1)} if "value" in s_.get("end_to_end", {}) else {}))
+                                 for s_ in out["scaling_sweep"]]
+    line["detail"] = "bench_detail.json"
+    text = json.dumps(line)
+    if len(text) > 4000:                  # never let the line grow past what the driver reads: drop the optional parts
+        for key in ("scaling_sweep", "legs", "kernels_ms_per_step", "cpu_baseline_1core"):
+            line.pop(key, None)
+            text = json.dumps(line)
+            if len(text) <= 4000:
+                break
+    return text
+
+
 def launcher_main(args):
     from tredparse_amd import shard
     n_devices = 1 if args.stub else shard.visible_gpus()
@@ -758,7 +916,7 @@ def launcher_main(args):
             if r["n"] in e2e and not r.get("oversubscribed"):
                 rec = e2e[r["n"]]
                 r["end_to_end"] = {k: rec[k] for k in ("value", "unit", "drivers", "devices", "samples", "seconds",
-                                                       "host_threads_per_driver") if k in rec}
+                                                       "host_threads_per_driver", "outputs_identical") if k in rec}
     if args.legs and not args.stub:
         # the configurations that otherwise only have correctness tests, one rank each on device 0: BASELINE
         # configs[4] and the other read lengths (their own sw_cont_kernel instantiations)
@@ -790,7 +948,7 @@ def launcher_main(args):
                 continue
             r = line["roofline"]
             out["legs"].append({"leg": spec, "metric": line["metric"], "value": line["value"], "unit": line["unit"],
-                                "ms_per_step": line["ms_per_step"], "steps": line["steps"],
+                                "ms_per_step": line["ms_per_step"], "steps": line["steps"], "frac": r["frac"],
                                 "workload": line["config"]["workload"],
                                 "units_per_step": line["config"]["units_per_step_per_gpu"],
                                 "reads_per_step": line["config"]["reads_per_step_per_gpu"],
@@ -808,7 +966,18 @@ def launcher_main(args):
         out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         out["cpu_baseline"]["usable_cpus"] = cores
         out["cpu_baseline_1core"] = one
-    print(json.dumps(out), flush=True)
+    # the full record: a file next to the script (and gpurun_out/ when there is one: that directory travels back from
+    # the GPU box) and stderr; stdout carries the compact line alone, last
+    detail = json.dumps(out)
+    for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as fp:
+                    fp.write(detail + "\n")
+        except OSError:
+            pass
+    print("bench detail: " + detail, file=sys.stderr, flush=True)
+    print(compact_line(out), flush=True)
 
 
 def main():
@@ -830,24 +999,26 @@ def main():
     ap.add_argument("--rank-timeout", type=float, default=1500.0)
     ap.add_argument("--stub", action="store_true", help="launcher self-test: ranks do no GPU work")
     ap.add_argument("--e2e-samples", type=int, default=512,
-                    help="synthetic BAMs per GPU of the end-to-end legs (0: skip them); at most 512 files in all")
+                    help="BAM files per GPU of the end-to-end legs (0: skip them): the same number at every device count")
+    ap.add_argument("--e2e-distinct", type=int, default=512,
+                    help="distinct synthetic BAMs made; a larger cohort gets the rest as hard links under their own sample keys")
+    ap.add_argument("--e2e-seconds", type=float, default=12.0,
+                    help="how long the planned end-to-end leg's drivers keep going over their files (the host-only leg: half)")
+    ap.add_argument("--e2e-sweep", action="store_true", help="also run the other driver plans (they go to bench_detail.json)")
     ap.add_argument("--e2e-batch", type=int, default=16, help="samples per GPU batch in the end-to-end leg")
     ap.add_argument("--e2e-threads", type=int, default=0, help="host threads per driver in the end-to-end leg (0: cores / drivers)")
-    ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes sharing the GPU in the end-to-end leg (0: usable cores / 5; also run with 1)")
+    ap.add_argument("--e2e-drivers", type=int, default=0, help="driver processes per GPU in the planned end-to-end leg (0: shard.driver_plan's rule)")
     ap.add_argument("--legs", default="streamed:4,config5:150:200,config3:100:500,config3:250:500",
                     help="extra one-GPU legs workload:readlen:samples, comma separated ('' for none)")
-    ap.add_argument("--e2e-gpu-inflate", choices=("0", "1", "both"), default="both",
-                    help="end-to-end legs with the BAMs' BGZF blocks inflated on the GPU (tred.run_many inflate_device): "
-                         "0 host only, 1 GPU only, both")
+    ap.add_argument("--e2e-gpu-inflate", choices=("0", "1"), default="1",
+                    help="the planned end-to-end leg has the BAMs' BGZF blocks inflated on the GPU (tred.run_many inflate_device)")
     ap.add_argument("--e2e-gpu-walk", choices=("0", "1"), default="1",
                     help="GPU-inflate legs: the pair-length walks run on the GPU too (tred.run_many gpu_walk), and only the "
                          "blocks of the loci's windows and alternative loci come back")
-    ap.add_argument("--e2e-repeat", type=int, default=3, help="every driver goes over its BAMs this many times (a longer cohort from the same files)")
     ap.add_argument("--e2e-inflate-batch", type=int, default=16, help="samples per GPU batch (and inflate launch) in those legs")
     ap.add_argument("--streamed", type=int, default=0,
                     help="also time the step fed from pinned host memory: this many distinct batches, double-buffered "
                          "copy-in beside the kernels (the default run adds it as the `streamed` leg with 4 batches)")
-    ap.add_argument("--e2e-genotype-chunks", type=int, default=1, help="GPU-inflate legs: decode chunks per genotyping batch")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-limit", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

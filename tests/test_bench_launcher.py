@@ -13,14 +13,17 @@ def _run(*extra):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--samples", "10", "--steps", "2",
                           "--no-cpu-baseline"] + list(extra), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    detail = json.loads([l for l in out.stderr.splitlines() if l.startswith("bench detail: ")][-1][len("bench detail: "):])
+    assert abs(detail["value"] - line["value"]) < 1e-3 and detail["n_gpus"] == line["n_gpus"]
+    return detail
 
 
 def test_launcher_runs_n_ranks_and_sums_their_units():
     rec = _run("--gpus", "2")
     assert rec["n_gpus"] == 2 and rec["stub"] is True
     # stub ranks: 10 samples x 30 loci x 2 steps each, rank r takes 0.05 * (r + 1) s -> 1200 units / 0.1 s
-    assert rec["value"] == 12000.0
+    assert abs(rec["value"] - 12000.0) < 1e-6
     sweep = {s["n"]: s for s in rec["scaling_sweep"]}
     assert sorted(sweep) == [1, 2]
     assert [r["rank"] for r in sweep[2]["ranks"]] == [0, 1]
@@ -40,12 +43,13 @@ def test_eight_ranks_of_a_thousand_samples_each_configs3_shape():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--samples", "1000", "--steps", "1",
                           "--no-cpu-baseline", "--gpus", "8", "--no-sweep"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert json.loads(out.stdout.strip().splitlines()[-1])["value"] == 600000.0
+    rec = json.loads([l for l in out.stderr.splitlines() if l.startswith("bench detail: ")][-1][len("bench detail: "):])
     assert rec["n_gpus"] == 8 and rec["stub"] is True
     ranks = rec["scaling_sweep"][0]["ranks"]
     assert [r["rank"] for r in ranks] == list(range(8)) and all(r["units"] == 30000 for r in ranks)
     # stub rank r takes 0.05 * (r + 1) s per step: 240 000 units / 0.4 s
-    assert rec["value"] == 600000.0
+    assert abs(rec["value"] - 600000.0) < 1e-6
 
 
 def test_sweep_counts():
@@ -67,67 +71,171 @@ def test_rank_env_pins_one_device_per_rank():
     assert "HIP_VISIBLE_DEVICES" not in e and e["LOCAL_RANK"] == "1"
 
 
-def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
-    """run_e2e on an 8-GPU box (stub ranks): one set of BAMs, a leg per device count of the sweep, ranks = drivers per
-    GPU x GPUs with rank r on device r mod n and an equal share of the CPUs each; on a 1-GPU box the plan is the one of
-    earlier rounds with one core left to the drivers (1 driver x 15 threads, 2 x 7, 3 x 5 on 16 CPUs)."""
+def _fake_e2e(monkeypatch, usable=64):
+    """Stand-ins for run_e2e's helpers: no BAMs, no processes -- every driver 'finishes' a sample every 10 ms from 0.5 s
+    after the common start, for as long as its leg is told to run."""
     sys.path.insert(0, ROOT)
-    import argparse
     import bench
+    import numpy as np
     from tredparse_amd import shard
-    assert bench.e2e_plan(1, 16) == [(1, 15), (2, 7), (3, 5)]
-    assert bench.e2e_plan(8, 128) == [(8, 15), (16, 7), (24, 5)]
-    assert bench.e2e_plan(8, 16) == [(8, 1)]
-    assert bench.e2e_plan(2, 16, drivers_opt=2, threads_opt=3) == [(2, 3), (4, 3)]
-    monkeypatch.setattr(shard, "usable_cpus", lambda: 64)
-    made, spawned = [], []
+    monkeypatch.setattr(shard, "usable_cpus", lambda: usable)
+    made, spawned, legs = [], [], {}
 
     def fake_bams(root, n, seed=0, workers=1):
         made.append(n)
-        import numpy as np
-        return [("s{:04d}".format(i), os.path.join(root, "s{:04d}.bam".format(i)), np.zeros((30, 2), int)) for i in range(n)]
+        out = []
+        for i in range(n):
+            key = "s{:04d}".format(i)
+            for ext in (".bam", ".bam.bai"):
+                open(os.path.join(root, key + ext), "w").close()
+            out.append((key, os.path.join(root, key + ".bam"), np.zeros((30, 2), int)))
+        return out
 
     def fake_spawn(argv, world, n_devices, timeout=None, env=None, stdout=None, cwd=None):
-        limit = int(argv[argv.index("--e2e-limit") + 1])
-        threads = int(argv[argv.index("--e2e-threads") + 1])
-        spawned.append((world, n_devices, limit, threads))
+        get = lambda flag: argv[argv.index(flag) + 1]
+        limit, threads, seconds = int(get("--e2e-limit")), int(get("--e2e-threads")), float(get("--e2e-seconds"))
+        spawned.append((world, n_devices, limit, threads, get("--e2e-gpu-inflate"), get("--e2e-gpu-walk"), get("--e2e-batch")))
+        ranks, logs = [], []
+        names = sorted(f[:-4] for f in os.listdir(get("--e2e-child")) if f.endswith(".bam"))[:limit]
         for r in range(world):
             lo, hi = shard.shard_range(limit, r, world)
             dev = shard.rank_env(r, world, 1, r % n_devices, base={})["TRED_RANK_DEVICE"]
-            with open(os.path.join(env["TREDBENCH_OUT"], "e2e_rank{}.json".format(r)), "w") as fp:
-                json.dump({"rank": r, "device": dev, "units": 30 * (hi - lo), "seconds": 1.0 + 0.01 * r, "samples": hi - lo,
-                           "host_threads": threads, "driver_seconds": {"gpu": 0.1}, "short_ok": 1, "short_n": 1,
-                           "bam_bytes": 1000 * (hi - lo)}, fp)
+            t = 1000.0 + 0.5 + 0.01 * np.arange(1, int(seconds * 100) + 1)
+            logs.append(np.stack([t, np.full(len(t), 30.0), np.full(len(t), 25.0), np.full(len(t), 30.0)], axis=1))
+            ranks.append({"rank": r, "device": dev, "t_process": 990.0, "t_begin": 1000.0, "t_end": float(t[-1]), "files": hi - lo,
+                          "host_threads": threads, "first_chunk": 3, "driver_seconds": {"gpu": 0.1}, "bam_bytes": 1000 * (hi - lo),
+                          "digests": {k: "h" + k for k in names[lo:hi]}})
+        legs[env["TREDBENCH_OUT"]] = (ranks, logs)
         return [0] * world
 
-    args = argparse.Namespace(e2e_samples=128, seed=1, e2e_drivers=0, e2e_threads=0, e2e_batch=16, rank_timeout=60,
-                              e2e_gpu_inflate="0", e2e_inflate_batch=32, e2e_repeat=1)
-    recs = bench.run_e2e(args, [1, 2, 8], spawn=fake_spawn, make_bams=fake_bams)
-    assert made == [512]                                            # one set of files: 8 GPUs x 64 (capped at 512)
+    return bench, made, spawned, fake_bams, fake_spawn, (lambda out_dir, drivers: legs[out_dir])
+
+
+def _e2e_args(**kw):
+    import argparse
+    base = dict(e2e_samples=128, e2e_distinct=128, seed=1, e2e_drivers=0, e2e_threads=0, e2e_batch=16, rank_timeout=60,
+                e2e_gpu_inflate="1", e2e_gpu_walk="1", e2e_inflate_batch=32, e2e_seconds=12.0, e2e_sweep=False)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
+    """run_e2e on an 8-GPU box (stub ranks): one set of BAMs; per device count of the sweep TWO legs, both fixed before
+    anything runs -- one host-only driver per GPU, and the plan of shard.driver_plan(usable CPUs, GPUs) with inflate
+    and pair walks on the GPU -- over a cohort of the SAME size per GPU at every device count (n = 8: 8 x 128 files,
+    the ones beyond the distinct 128 hard-linked under their own keys)."""
+    from tredparse_amd import shard
+    bench, made, spawned, fake_bams, fake_spawn, read_leg = _fake_e2e(monkeypatch, usable=64)
+    per_gpu, threads = shard.driver_plan(64, 8)
+    assert bench.e2e_rule(8, 64) == (8 * per_gpu, threads)
+    assert shard.driver_plan(16, 1) == (shard.DRIVERS_PER_GPU, -(-16 // shard.DRIVERS_PER_GPU))
+    recs = bench.run_e2e(_e2e_args(), [1, 2, 8], spawn=fake_spawn, make_bams=fake_bams, read_leg=read_leg)
+    assert made == [128]                                            # the distinct files are made once
     assert sorted(recs) == [1, 2, 8]
-    # (ranks, devices, files, threads per rank): 64 CPUs -> 8 and 12 drivers per GPU at one GPU, 4 and 6 at two, 1 at eight
-    assert spawned == [(1, 1, 128, 63), (8, 1, 128, 7), (12, 1, 128, 5), (2, 2, 256, 31), (8, 2, 256, 7), (12, 2, 256, 5),
-                       (8, 8, 512, 7)]
+    # (ranks, devices, files, threads per rank, gpu_inflate, gpu_walk, batch): files = devices x 128, always
+    want = []
+    for n in (1, 2, 8):
+        d, t = shard.driver_plan(64, n)
+        want += [(n, n, 128 * n, 63 // n, "0", "0", "16"), (d * n, n, 128 * n, t, "1", "1", "32")]
+    assert spawned == want
     eight = recs[8]
-    assert eight["devices"] == 8 and eight["drivers"] == 8 and eight["samples"] == 512
-    assert sorted(d["device"] for d in eight["per_driver"]) == [str(i) for i in range(8)]
-    assert abs(eight["value"] - 30 * 512 / 1.07) < 1e-6              # all ranks' units / the slowest rank's time
+    assert eight["devices"] == 8 and eight["drivers"] == 8 * per_gpu and eight["files"] == 1024
+    assert eight["gpu_inflate"] and eight["gpu_walk"] and eight["outputs_identical"] is True and eight["outputs"] == 1024
+    assert [l["role"] for l in eight["legs"]] == ["host_only_one_driver_per_gpu", "plan"]
+    # steady state: every driver finishes 100 samples x 30 units a second; the window opens at the slowest driver's
+    # third sample (its first chunk) and closes at the first driver's last
+    assert abs(eight["value"] - 8 * per_gpu * 3000.0) < 1.0 and abs(eight["startup_s"] - 0.53) < 1e-6
+    assert abs(eight["seconds"] - (12.0 - 0.03)) < 1e-6
+    assert eight["host_only_one_driver_per_gpu"]["value"] > 0 and "per_driver" not in eight
 
 
-    # with the GPU-inflate legs: every plan twice, the second time with the larger batch and the child flag
-    del spawned[:]
-    flags = []
-    plain_spawn = fake_spawn
-
-    def flag_spawn(argv, *a, **k):
-        flags.append((argv[argv.index("--e2e-gpu-inflate") + 1], argv[argv.index("--e2e-batch") + 1]))
-        return plain_spawn(argv, *a, **k)
-    args.e2e_gpu_inflate = "both"
-    recs = bench.run_e2e(args, [1], spawn=flag_spawn, make_bams=fake_bams)
-    assert flags == [("0", "16")] * 3 + [("1", "32")] * 7           # (the GPU legs add plans with a driver per four, three and 2.7 CPUs)
-    assert [l["gpu_inflate"] for l in recs[1]["legs"]] == [False] * 3 + [True] * 7
-    assert [l["gpu_walk"] for l in recs[1]["legs"]] == [False] * 3 + [True] * 6 + [False]     # (the last plan again, walks on the host)
+def test_end_to_end_sweep_is_behind_its_flag(tmp_path, monkeypatch):
+    bench, made, spawned, fake_bams, fake_spawn, read_leg = _fake_e2e(monkeypatch, usable=16)
+    recs = bench.run_e2e(_e2e_args(e2e_sweep=True), [1], spawn=fake_spawn, make_bams=fake_bams, read_leg=read_leg)
+    roles = [l["role"] for l in recs[1]["legs"]]
+    assert roles[:2] == ["host_only_one_driver_per_gpu", "plan"] and set(roles[2:]) == {"sweep"} and len(roles) > 4
+    assert recs[1]["role"] == "plan"                  # the record is the plan's whatever the sweep finds
+    assert bench.e2e_plan(1, 16) == [(1, 15), (2, 7), (3, 5)]
     assert bench.e2e_plan(1, 16, dense=True) == [(1, 15), (2, 7), (3, 5), (4, 3), (5, 3), (6, 3)]
+
+
+def test_outputs_that_differ_between_legs_are_reported(tmp_path, monkeypatch):
+    bench, made, spawned, fake_bams, fake_spawn, read_leg = _fake_e2e(monkeypatch, usable=16)
+
+    def one_differs(out_dir, drivers):
+        ranks, logs = read_leg(out_dir, drivers)
+        if drivers > 1:
+            ranks[0]["digests"][sorted(ranks[0]["digests"])[0]] = "other"
+        return ranks, logs
+    recs = bench.run_e2e(_e2e_args(), [1], spawn=fake_spawn, make_bams=fake_bams, read_leg=one_differs)
+    assert recs[1]["outputs_identical"] is False
+
+
+def test_final_line_is_compact_and_parses():
+    """The driver reads bench.py's LAST stdout line: it must stay under 4 KB whatever the legs carry (round 4's had grown
+    to 29 KB and the driver's record came out unparsed), round-trip through JSON, and hold the contract's keys together with
+    roofline.frac and cpu_baseline.value."""
+    sys.path.insert(0, ROOT)
+    import bench
+    drivers = [{"seconds": 12.1, "device": "0", **{k: 1.234567 for k in ("scan_wait", "gpu", "format", "write", "inflate",
+                "inflate_blocks", "inflate_failed", "inflate_hits", "inflate_misses", "inflate_gpu", "walk_regions", "walk_declined")}}
+               for _ in range(48)]
+    leg = {"drivers": 48, "devices": 8, "gpu_inflate": True, "gpu_walk": True, "value": 201234.5678, "unit": "genotypes/s",
+           "first_pass_value": 190000.123, "whole_run_value": 195000.0, "startup_s": 0.7, "seconds": 11.2, "samples": 75000,
+           "files": 4096, "host_threads_per_driver": 3, "outputs_identical": True, "per_driver": drivers, "what": "x" * 900,
+           "page_cache": "y" * 400, "cohort": "z" * 100}
+    out = {"metric": "sample x TRED genotypes/sec at 30x 150bp", "value": 11234567.891, "unit": "genotypes/s", "n_gpus": 8,
+           "steps": 20, "warmup": 5, "ms_per_step": 21.2345678, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int32 (SW) + f64 (likelihood)", "data": "synthetic", "library": "tredgpu 0.5 (gfx950) src 0123abcd",
+           "config": {"workload": "1000 synthetic 30x samples x 30 TRED loci per GPU (BASELINE configs[2]) at 150 bp; fused "
+                                  "SW+tagging -> histograms -> (h1,h2) grid, inputs resident in HBM", "name": "config3",
+                      "units_per_step_per_gpu": 30000, "reads_per_step_per_gpu": 2400000, "coverage": 30.0, "readlen": 150,
+                      "maxinsert": 300, "alleles": "uniform", "parallelism": "sample-sharded x8 (no collective)"},
+           "roofline": {"kernel": "sw_cont_kernel<10,4>", "bound": "valu", "achieved": 2.7812345, "peak": 7.8643, "unit": "TCUPS",
+                        "frac": 0.35365, "mix_ceiling_frac": 0.39, "traffic": 450e6, "traffic_source": "s" * 300,
+                        "traffic_over_algorithmic": 2.0, "note": "n" * 900, "avg_launch_ms": 16.01, "effective_TCUPS": 275.0,
+                        "sw_counters": {"c{}".format(i): 123456789 for i in range(40)}, "hbm": {"frac": 0.001}},
+           "kernels_ms_per_step": {k: 1.23456 for k in ("sw_ladder", "tally", "grid", "grid_kde", "grid_prepare", "grid_pairs", "grid_reduce")},
+           "check": {"grid_pairs_percentiles": {str(q): q for q in range(10)}},
+           "scaling_sweep": [{"n": n, "value": 1.4e6 * n, "unit": "genotypes/s", "ms_per_step": 21.0, "devices": n,
+                              "ranks": [{"rank": r, "device": str(r), "units": 600000, "elapsed_s": 0.42} for r in range(n)],
+                              "end_to_end": {"value": 25000.0 * n}} for n in (1, 2, 4, 8)],
+           "gpus_visible": 8, "end_to_end": dict(leg, legs=[dict(leg) for _ in range(12)],
+                                                 host_only_one_driver_per_gpu={"value": 6500.0, "first_pass_value": 6000.0, "seconds": 5.9, "samples": 1300, "startup_s": 0.4}),
+           "legs": [{"leg": l, "value": 1.2e6, "ms_per_step": 12.3, "frac": 0.31, "workload": "w" * 200, "kernels_ms_per_step": {"a": 1.0},
+                     "roofline": {"frac": 0.31}} for l in ("streamed", "config5:150:200", "config3:100:500", "config3:250:500")],
+           "cpu_baseline": {"value": 59.9, "unit": "genotypes/s", "cores": 16, "kind": "reference", "sample": "q" * 400, "host_cpus": 256},
+           "cpu_baseline_1core": {"value": 2.68, "unit": "genotypes/s", "cores": 1, "kind": "reference", "sample": "q" * 400}}
+    assert len(json.dumps(out)) > 20000
+    text = bench.compact_line(out)
+    assert len(text) < 4096 and "\n" not in text
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "end_to_end", "legs"):
+        assert key in line, key
+    assert line["roofline"]["frac"] == 0.35365 and line["roofline"]["mix_ceiling_frac"] == 0.39 and line["roofline"]["bound"] == "valu"
+    assert line["cpu_baseline"]["value"] == 59.9 and line["cpu_baseline"]["cores"] == 16 and line["cpu_baseline"]["kind"] == "reference"
+    assert line["config"]["workload"].startswith("1000 synthetic") and "model" not in line["config"]
+    assert line["end_to_end"]["value"] == 201234.568 and line["end_to_end"]["outputs_identical"] is True
+    assert [l["leg"] for l in line["legs"]] == ["streamed", "config5:150:200", "config3:100:500", "config3:250:500"]
+    assert all(set(l) <= {"leg", "value", "ms_per_step", "frac", "error"} for l in line["legs"])
+    assert [s["n"] for s in line["scaling_sweep"]] == [1, 2, 4, 8] and line["scaling_sweep"][3]["end_to_end"] == 200000.0
+    # a record with even more in it still fits: the optional parts go first
+    out["legs"] = out["legs"] * 40
+    assert len(bench.compact_line(out)) < 4096
+
+
+def test_stub_launcher_prints_the_compact_line_last_and_writes_the_detail(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--samples", "10", "--steps", "2",
+                          "--no-cpu-baseline", "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096          # stdout carries the compact line alone
+    line = json.loads(lines[0])
+    assert line["detail"] == "bench_detail.json" and "bench detail: " in out.stderr
+    with open(os.path.join(ROOT, "bench_detail.json")) as fp:
+        detail = json.load(fp)
+    assert abs(detail["value"] - line["value"]) < 1e-3 and "ranks" in detail["scaling_sweep"][0]
 
 
 def test_pmc_traffic_is_only_cited_for_the_build_it_was_taken_from(tmp_path, monkeypatch):

@@ -69,7 +69,14 @@ def test_visibility_mask_and_restricted_affinity(tmp_path):
     nodes, cpus = shard.gpu_numa_nodes(root), shard.numa_cpus(root)
     # a parent confined to devices 4-7: its device 0 is physical device 4, on node 1
     sets = shard.rank_cpusets(4, 4, allowed=list(range(256)), gpu_nodes=nodes, node_cpus=cpus, visible=[4, 5, 6, 7])
-    assert all(set(cs) <= set(cpus[1]) for cs in sets) and len(set().union(*map(set, sets))) == 128
+    # every rank has its 32 CPUs of node 1, and node 0 -- no rank's GPU is there -- is dealt out on top, 32 CPUs each:
+    # the from-BAM path is host-bound, no allowed CPU stays idle
+    assert all(len(set(cs) & set(cpus[1])) == 32 and len(set(cs) & set(cpus[0])) == 32 for cs in sets)
+    assert len(set().union(*map(set, sets))) == 256 and sum(len(cs) for cs in sets) == 256
+    # one GPU of eight in use, six driver processes on it: node 0's CPUs in six local slices, node 1's dealt out too
+    sets = shard.rank_cpusets(6, 1, allowed=list(range(256)), gpu_nodes=nodes, node_cpus=cpus)
+    assert sorted(c for cs in sets for c in cs) == list(range(256))
+    assert all(20 <= len(set(cs) & set(cpus[0])) <= 22 and 20 <= len(set(cs) & set(cpus[1])) <= 22 for cs in sets)
     # a container that may only use 16 CPUs of node 0: the node-1 GPUs' ranks cannot be local -- every rank then gets
     # an equal, disjoint slice of what there is
     sets = shard.rank_cpusets(8, 8, allowed=list(range(16)), gpu_nodes=nodes, node_cpus=cpus)

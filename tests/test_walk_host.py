@@ -70,7 +70,7 @@ def test_feeder_with_walked_pair_lengths_gives_the_plain_scans(cohort, monkeypat
     ex = ThreadPoolExecutor(max_workers=2)
     feeder = t._InflateFeeder(chunks, ex, 0, walk=True)
     try:
-        scans = [fut.result() for _ in chunks for fut in feeder.next()]
+        scans = [fut.result() for _ in chunks for fut in feeder.next()[1]]
     finally:
         feeder.close()
         ex.shutdown()
@@ -103,7 +103,7 @@ def test_regions_the_walker_declines_are_walked_by_the_scan(cohort, monkeypatch)
     ex = ThreadPoolExecutor(max_workers=2)
     feeder = t._InflateFeeder([cohort[:4]], ex, 0, walk=True)
     try:
-        scans = [fut.result() for fut in feeder.next()]
+        scans = [fut.result() for fut in feeder.next()[1]]
     finally:
         feeder.close()
         ex.shutdown()

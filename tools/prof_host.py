@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""What a driver process costs the HOST per sample, measured without a GPU: real native scans of synthetic BAMs, the real
+packing, formatting and file writing -- only the three kernel calls are replaced by arrays of the same shapes and
+densities (a third of the reads tagged, marginals of 1-30 entries, ~80 joint entries per unit).  cProfile of the driver
+thread and of the writer thread plus their CPU times: the numbers behind DESIGN 6's "interpreter-lock work per sample".
+
+usage: python tools/prof_host.py [synthetic BAMs = 24] [scan threads = 4] [native emit = 1]
+"""
+import cProfile
+import glob
+import io
+import os
+import pstats
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tredparse_amd import _lib, engine as eng, shard, synth_bam, tred   # noqa: E402
+from tredparse_amd.meta import TREDsRepo                                  # noqa: E402
+
+
+class FakeEngine(object):
+    """engine.Engine.genotype_packed without the kernels."""
+
+    def __init__(self, seed=1):
+        self.rng = np.random.default_rng(seed)
+
+    def genotype_packed(self, b, dense=False):
+        rng = self.rng
+        r = eng.BatchResult()
+        r.batch, r.grid, r.grid_off = b, None, None
+        n, g = b.n_reads, b.n_units
+        r.tag = np.where(rng.random(n) < 0.33, rng.integers(1, 6, n), 0).astype(np.uint8)
+        r.h = rng.integers(1, 50, n).astype(np.int16)
+        r.score = rng.integers(30, 150, n).astype(np.int16)
+        hs = b.max_units + 2
+        r.full, r.pref, r.rept = (np.zeros((g, hs), np.int32) for _ in range(3))
+        r.calls = np.zeros(g, _lib.CALL_DTYPE)
+        per = b.params["period"]
+        r.calls["h1"], r.calls["h2"] = 15 * per, 41 * per
+        r.calls["ci"] = (15, 15, 41, 54)
+        r.calls["pp"], r.calls["lik"], r.calls["n_pairs"] = 0.5, -100.0, 521
+        ms = 302
+        r.marg = np.zeros((g, 2, ms), np.float64)
+        r.marg[:, 0, 15] = 1.0
+        r.marg[:, 1, 41:70] = rng.random((g, 29)) + 0.01
+        cap = 80
+        a = np.repeat(np.full(g, 15, np.int64), cap)
+        bb = np.tile(np.arange(41, 41 + cap, dtype=np.int64), g)
+        v = rng.random(g * cap)
+        r.joint = [None] * g
+        r.joint_units = (a, bb, v, np.arange(g, dtype=np.int64) * cap, np.full(g, cap, np.int32))
+        return r
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    native = (sys.argv[3] if len(sys.argv) > 3 else "1") == "1"
+    root = tempfile.mkdtemp(prefix="prof_host_")
+    synth_bam.make_bams(root, n, seed=7, workers=shard.usable_cpus())
+    bams = sorted(glob.glob(os.path.join(root, "*.bam")))
+    repo = TREDsRepo("hg38", sites=os.path.join(root, "no_sites"))
+    names = [l["name"] for l in synth_bam.bench_loci()]
+    tasks = [(os.path.basename(b)[:-4], b, repo, names, 300, False, False, True, True, "ERROR") for b in bams] * 4
+    engine = FakeEngine()
+    os.chdir(root)
+    wprof, wcpu = cProfile.Profile(), [0.0]
+
+    def sink(result):
+        c0 = time.thread_time()
+        wprof.enable()
+        tred.write_vcf_json(result, "hg38", repo, names, quiet=True)
+        wprof.disable()
+        wcpu[0] += time.thread_time() - c0
+    if not native and hasattr(tred, "NATIVE_EMIT"):
+        tred.NATIVE_EMIT = False
+    tred.run_many(tasks[:8], engine, batch=8, sink=sink, threads=threads, lazy_details=True)
+    wcpu[0] = 0.0
+    pr = cProfile.Profile()
+    t0, c0, p0 = time.perf_counter(), time.thread_time(), time.process_time()
+    pr.enable()
+    tred.run_many(tasks, engine, batch=16, sink=sink, threads=threads, lazy_details=True, background_sink=True)
+    pr.disable()
+    dt = time.perf_counter() - t0
+    k = len(tasks)
+    print("samples {}  wall {:.2f} s = {:.2f} ms/sample   driver thread cpu {:.2f} ms/sample   writer thread cpu {:.2f} ms/sample   "
+          "process cpu {:.2f} ms/sample".format(k, dt, 1e3 * dt / k, 1e3 * (time.thread_time() - c0) / k, 1e3 * wcpu[0] / k,
+                                                1e3 * (time.process_time() - p0) / k))
+    print({a: round(b, 3) for a, b in tred.TIMING.items() if b})
+    for name, prof in (("DRIVER", pr), ("WRITER", wprof)):
+        s = io.StringIO()
+        pstats.Stats(prof, stream=s).sort_stats("tottime").print_stats(25)
+        print(name, s.getvalue()[:5000])
+    import shutil
+    shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

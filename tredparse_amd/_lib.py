@@ -328,6 +328,20 @@ WALK_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_global", "<i4"), ("n_target
 ALT_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n", "<i4"), ("vbeg", "<u8", (6,))])
 
 
+MIN_PAIR_BYTES = 2 * (36 + 2 + 4 + 18)    # two BAM records of a pair at their smallest: fixed fields, name, one CIGAR op, 36 bases
+
+
+def walk_pool_pairs(tasks, out_off):
+    """Upper bound of the pair lengths the tasks of one walk call can produce: every pair needs two records among the
+    inflated bytes of its task's blocks (out_off: the call's block offsets), and a record of a read of >= 36 bases cannot
+    be smaller than MIN_PAIR_BYTES / 2.  Real 30-40x WGS regions sit near a quarter of this bound."""
+    if len(tasks) == 0:
+        return 0
+    off = np.asarray(out_off, np.int64)
+    nbytes = off[np.clip(tasks["block_end"], 0, len(off) - 1)] - off[np.clip(tasks["block_first"], 0, len(off) - 1)]
+    return int(np.maximum(nbytes, 0).sum() // MIN_PAIR_BYTES) + 64 * len(tasks)
+
+
 class Inflater:
     """Batch DEFLATE decoder on the GPU (include/tredgpu.h section 4): one HIP stream with pinned staging; one per host
     thread.  ``reserve`` hands out numpy views of the staging buffers -- compressed payloads and their offsets are
@@ -380,11 +394,14 @@ class Inflater:
         self._check(self._lib.tredgpu_inflate_blocks_crc(self._h, n_blocks, status.ctypes.data, sums.ctypes.data), "tredgpu_inflate_blocks_crc")
         return status[:n_blocks], sums[:n_blocks]
 
-    def run_walk(self, n_blocks, blk_coffset, blk_clen, blk_crc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None):
+    def run_walk(self, n_blocks, blk_coffset, blk_clen, blk_crc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None,
+                 pool_pairs=None):
         """tredgpu_inflate_walk: decodes the blocks laid out in the reserved buffers and walks the pair-length regions
         (tasks WALK_TASK_DTYPE, chunks WALK_CHUNK_DTYPE) over them on the device.  No block is copied back (fetch does
         that).  Returns (status, crc, results WALK_RESULT_DTYPE, global pool, target pool) -- with alt_tasks / alt_chunks
-        (the alternative loci's walks) also (results ALT_RESULT_DTYPE, uint8 flags of the blocks that hold their records)."""
+        (the alternative loci's walks) also (results ALT_RESULT_DTYPE, uint8 flags of the blocks that hold their records).
+        pool_pairs: room in the global pool for the whole call (walk_pool_pairs: a bound from the planned bytes, so that
+        no coverage makes a region fall back to the host for want of room); without it pairs_per_task per task."""
         status, sums = np.zeros(max(n_blocks, 1), np.int32), np.zeros(max(n_blocks, 1), np.uint32)
         coff = np.ascontiguousarray(blk_coffset, np.int64)
         clen = np.ascontiguousarray(blk_clen, np.int32)
@@ -394,8 +411,9 @@ class Inflater:
         if not (len(coff) == len(clen) == len(xcrc) == n_blocks):
             raise ValueError("one compressed offset / length / CRC per block")
         res = np.zeros(max(len(tasks), 1), WALK_RESULT_DTYPE)
-        gp = np.zeros(len(tasks) * int(pairs_per_task) + 4096, np.int32)
-        tp = np.zeros(len(tasks) * max(int(pairs_per_task) // 8, 16) + 1024, np.int32)
+        room = len(tasks) * int(pairs_per_task) if pool_pairs is None else int(pool_pairs)
+        gp = np.zeros(room + 4096, np.int32)
+        tp = np.zeros(max(room // 8, 16 * len(tasks)) + 1024, np.int32)
         n_alt = 0 if alt_tasks is None else len(alt_tasks)
         at = np.ascontiguousarray(alt_tasks if n_alt else np.zeros(1, WALK_TASK_DTYPE), WALK_TASK_DTYPE)
         ac = np.ascontiguousarray(alt_chunks if (n_alt and len(alt_chunks)) else np.zeros(1, WALK_CHUNK_DTYPE), WALK_CHUNK_DTYPE)

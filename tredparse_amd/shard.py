@@ -91,6 +91,24 @@ def usable_cpus():
     return max(1, n)
 
 
+def driver_plan(usable, n_gpus, gpu_inflate=True):
+    """(driver processes per GPU, scan threads per driver) for a host with `usable` CPUs feeding n_gpus GPUs -- the one
+    rule behind tred.py's `--drivers auto` and bench.py's end-to-end leg, a function of the two numbers alone.
+    With the BGZF blocks inflated and the pair lengths walked on the GPU a sample costs the host ~3 ms of scan and
+    ~1 ms of its driver's interpreter (the sample's JSON / VCF text is written natively, outside the lock): DRIVERS_PER_GPU
+    drivers per GPU, the CPUs shared among their scan threads.  Host-only, a scan is ~40 ms of a core and a driver keeps
+    about five scan threads fed: one driver per five CPUs."""
+    g = max(1, n_gpus)
+    if not gpu_inflate:
+        per_gpu = max(1, usable // (5 * g))
+        return per_gpu, max(1, (usable - 1) // (per_gpu * g))
+    per_gpu = max(1, min(DRIVERS_PER_GPU, usable // (2 * g)))
+    return per_gpu, max(1, min(8, (usable + per_gpu * g - 1) // (per_gpu * g)))
+
+
+DRIVERS_PER_GPU = 6
+
+
 # ---- which host CPUs a rank should live on -------------------------------------------------------------------
 # The from-BAM path is host-bound (DESIGN 6): on a two-socket 8-GPU node a rank whose scan threads and pinned staging
 # float across sockets pays the inter-socket link on every inflated byte.  The GPU-less parent reads the topology
@@ -175,7 +193,8 @@ def numa_cpus(root="/"):
 def rank_cpusets(world, n_devices, allowed=None, gpu_nodes=None, node_cpus=None, visible=None):
     """CPU set of every rank (rank r works on device r mod n_devices): the CPUs of its GPU's NUMA node that this
     process may use, cut into disjoint, equal slices among the ranks that share the node; ranks whose GPU's node is
-    unknown (or has no allowed CPU) share what is left over the same way.  `visible`: the HIP_VISIBLE_DEVICES entries
+    unknown (or has no allowed CPU) share what is left over the same way; CPUs of nodes without any rank's GPU are
+    dealt out to all ranks on top (no allowed CPU stays idle).  `visible`: the HIP_VISIBLE_DEVICES entries
     when they are plain indices (device d of this process is physical device visible[d])."""
     import os
     if allowed is None:
@@ -207,6 +226,13 @@ def rank_cpusets(world, n_devices, allowed=None, gpu_nodes=None, node_cpus=None,
         for k, r in enumerate(members):
             lo, hi = shard_range(len(pool), k, len(members))
             sets[r] = pool[lo:hi] or pool              # (more ranks than CPUs: they share the pool)
+    # CPUs of nodes that host no rank's GPU (one GPU in use on a two-socket box, a mask of one socket's GPUs): the
+    # from-BAM path is host-bound, and an idle socket costs more than a remote one -- they go to the ranks in equal,
+    # disjoint slices on top of the local ones
+    idle = sorted(allowed_set - set(c for pool in pools.values() for c in pool))
+    for r in range(world if idle else 0):
+        lo, hi = shard_range(len(idle), r, world)
+        sets[r] = sorted(set(sets[r]) | set(idle[lo:hi]))
     return sets
 
 

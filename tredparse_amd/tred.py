@@ -27,6 +27,7 @@ import sys
 import threading
 import time
 from collections import deque
+from itertools import islice
 from concurrent.futures import ThreadPoolExecutor
 from datetime import date, timedelta
 
@@ -95,9 +96,12 @@ def set_argparse():
     p.add_argument("--toy", action="store_true", help=argparse.SUPPRESS)
     g = p.add_argument_group("Performance options")
     g.add_argument("--cpus", type=int, default=None,
-                   help="host threads scanning BAMs, per GPU (default: the usable CPUs -- affinity mask and cgroup quota -- "
-                        "shared among the --gpus ranks; the reference's default is cpu_count() workers)")
-    g.add_argument("--gpus", type=int, default=1, help="GPUs to spread the samples over (one process each)")
+                   help="host threads scanning BAMs, per driver process (default: the usable CPUs -- affinity mask and cgroup "
+                        "quota -- shared among the drivers; the reference's default is cpu_count() workers)")
+    g.add_argument("--gpus", type=int, default=1, help="GPUs to spread the samples over")
+    g.add_argument("--drivers", default="auto",
+                   help="driver processes per GPU, each with --cpus scan threads and its share of the samples (auto: from "
+                        "the usable CPUs and --gpus by shard.driver_plan, never more than one per 32 samples)")
     g.add_argument("--gpu", type=int, default=0, help="device index when --gpus is 1")
     g.add_argument("--batch-samples", type=int, default=64, help="samples per GPU batch")
     g.add_argument("--gpu-inflate", action="store_true",
@@ -266,7 +270,7 @@ atexit.register(release_inflaters)
 
 class _InflateFeeder(object):
     """Feeds run_many's chunks through plan -> GPU inflate -> scan, ahead of the consumer: next() returns the next
-    chunk's scan futures.  Three stages overlap: while the GPU decodes chunk k (a thread of its own makes the call,
+    (chunk, its scan futures), None behind the last one.  Three stages overlap: while the GPU decodes chunk k (a thread of its own makes the call,
     which sleeps through it), the feeder thread plans and fills chunk k + 1 into another inflater's staging, and the scan
     pool still reads chunk k - 1's blocks out of a third -- so there are three inflaters, each reused only when every
     scan that reads its output has finished.  close() can be called at any time -- also while the consumer is unwinding
@@ -394,7 +398,7 @@ class _InflateFeeder(object):
                                                crc[k:k + p["n"]], pe, alt))
             handed = True                                  # (each scan closes its own handle)
             self.busy[job["slot"]] = futs
-            self._put(futs)
+            self._put((chunk, futs))
         except BaseException as e:     # hand the failure to the consumer instead of leaving it waiting
             self._put(e)
         finally:
@@ -409,8 +413,13 @@ class _InflateFeeder(object):
         import numpy as np
         from .bam_parser import walk_need
         w = job["walk"]
+        from ._lib import walk_pool_pairs
         status, crc, res, gp, tp, ares, alt_need = inf.run_walk(job["n_all"], w["coffset"], w["clen"], w["crc"], w["tasks"], w["chunks"],
-                                                                alt_tasks=w["alt_tasks"], alt_chunks=w["alt_chunks"])
+                                                                alt_tasks=w["alt_tasks"], alt_chunks=w["alt_chunks"],
+                                                                pool_pairs=walk_pool_pairs(w["tasks"], job["ooff"]))
+        full = int((res["status"] == 6).sum())
+        if full:                           # (WALK_POOL_FULL: cannot happen with the bound above; a wrong plan would show here)
+            logging.getLogger("tredparse_amd").warning("pair walk: %d of %d regions found the pair pool full and are walked on the host", full, len(res))
         need = np.zeros(job["n_all"], np.uint8)
         for p in job["live"]:
             a = p["first"]
@@ -443,6 +452,7 @@ class _InflateFeeder(object):
                     self._close_plans(job["plans"])
                     return
                 self.decoding[job["slot"]] = self.gpu.submit(self._decode_and_scan, chunk, job)
+            self.gpu.submit(self._put, None)           # the end of the cohort, behind the last chunk's scans
         except BaseException as e:
             self._put(e)
 
@@ -664,28 +674,42 @@ class _Writer(object):
             raise self.error
 
 
+def _chunked(task_args, first, batch):
+    """Lists of `first`, then `batch` tasks, taken lazily from any iterable."""
+    it = iter(task_args)
+    size = first
+    while True:
+        chunk = list(islice(it, size))
+        if not chunk:
+            return
+        yield chunk
+        size = batch
+
+
 def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
-             background_sink=False, inflate_device=None, overlap_gpu=False, genotype_chunks=1, sink_threads=1, gpu_walk=False):
-    """run() over many samples, `batch` samples per GPU batch.  BAMs are scanned by `threads` host threads (or the
-    executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in flight the
-    scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
+             background_sink=False, inflate_device=None, gpu_walk=False):
+    """run() over many samples, `batch` samples per GPU batch.  task_args: a list, or any iterable of run() argument
+    tuples (taken lazily, a chunk at a time: a cohort need not be known in advance).  BAMs are scanned by `threads` host
+    threads (or the executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in
+    flight the scan threads idle whenever a batch does not divide evenly among them, and while the driver formats).  Each
     finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch.
-    background_sink: sink runs on a writer thread (in order) instead of the driver thread -- on sink_threads of them, in
-    any order, when that is more than one (the sink's calls must then be independent of each other).
+    background_sink: sink runs on a writer thread (in order) instead of the driver thread; an integer > 1: on that many
+    writer threads, in any order (the sink's calls must then be independent of each other).
     inflate_device: GPU that inflates the samples' BGZF blocks, a chunk of samples per launch (None: the scans inflate on
     the host); needs scan threads.  gpu_walk: the pair-length walks (PEextractor) run on that GPU too, over the blocks it
-    just inflated; only the blocks of the loci's windows and of the alternative loci come back.  genotype_chunks: the scans of this many chunks go through the kernels in one GPU batch
-    (a GPU call has a fixed cost of ~15 ms in copies and launches, several times that when driver processes share the
-    device: decode launches want chunks of ~16 samples, genotyping calls larger ones)."""
-    own = pool is None and threads > 1 and len(task_args) > 1
+    just inflated; only the blocks of the loci's windows and of the alternative loci come back.
+    (Measured and removed: the GPU half of a batch on a thread of its own beside the formatting of the previous batch --
+    the two halves fight over the interpreter lock, 20.1-20.4 k against 20.5 k genotypes/s with five drivers, 23.2 k against
+    27.5 k with six --, and several decode chunks per genotyping batch, 14.7 / 11.0 k against 25 k: docs/history.)"""
+    n_known = len(task_args) if hasattr(task_args, "__len__") else None
+    own = pool is None and threads > 1 and (n_known is None or n_known > 1)
     # the first GPU batch is only as large as one round of the scan threads: nothing else can start before it is in
     # (only when there is more than one batch anyway: an extra GPU call costs more than it hides on small inputs)
-    first = min(batch, max(1, threads)) if (own or pool is not None) and len(task_args) > batch else batch
-    chunks = [task_args[:first]] + [task_args[i:i + batch] for i in range(first, len(task_args), batch)]
-    chunks = [c for c in chunks if c]
+    first = min(batch, max(1, threads)) if (own or pool is not None) and (n_known is None or n_known > batch) else batch
+    chunks = _chunked(task_args, first, batch)
     ex = ThreadPoolExecutor(max_workers=threads) if own else pool
     out = []
-    writer = _Writer(sink, workers=sink_threads) if (background_sink and sink is not None) else None
+    writer = _Writer(sink, workers=int(background_sink)) if (background_sink and sink is not None) else None
     if writer is not None:
         sink = writer
     feeder = None
@@ -694,82 +718,62 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
             feeder = _InflateFeeder(chunks, ex, inflate_device, walk=gpu_walk)
         except Exception as e:       # no pinned memory, no device ...: the scans inflate for themselves
             logging.getLogger("tredparse_amd").warning("GPU inflate not available (%s): BGZF blocks are inflated on the host", e)
-    # (the GPU half of a batch on a thread of its own, beside the formatting of the previous batch: measured again in
-    #  round 4 with five driver processes, where a GPU call waits 40-70 ms -- 20.1-20.4 k genotypes/s against 20.5 k, and
-    #  15.5 k against 17.2 k with four: the two halves fight over the interpreter lock.  overlap_gpu stays off.)
-    gpu_ex = ThreadPoolExecutor(max_workers=1) if (overlap_gpu and ex is not None and len(chunks) > 1) else None
-    pending = None
-    held = []
 
-    def flush(item):
-        chunk_, scans_, fut_ = item
-        picks, res = fut_.result()
-        for r in format_scans(chunk_, scans_, picks, res, lazy_details=lazy_details):
-            if sink is not None:
-                sink(r)
-            else:
-                out.append(r)
-    try:
-        submit = (lambda c: [ex.submit(collect_sample, a) for a in c]) if ex is not None else None
-        ahead = deque()
-        nxt = 0
-        for i, chunk in enumerate(chunks):
-            if feeder is not None:
-                futs = feeder.next()
+    def scanned():
+        """(chunk, its scans) in task order, the scans running ahead of the consumer."""
+        if feeder is not None:
+            while True:
+                item = feeder.next()
+                if item is None:
+                    return
+                chunk, futs = item
                 t0 = time.perf_counter()
                 scans = [f.result() for f in futs]
                 timing_add(scan_wait=time.perf_counter() - t0)
-            elif ex is not None:
-                while nxt < len(chunks) and nxt <= i + max(1, ahead_batches):
-                    ahead.append(submit(chunks[nxt]))
-                    nxt += 1
-                t0 = time.perf_counter()
-                scans = [f.result() for f in ahead.popleft()]
-                timing_add(scan_wait=time.perf_counter() - t0)
-            else:
-                scans = [collect_sample(a) for a in chunk]
-            if gpu_ex is None:
-                held.append((chunk, scans))
-                if len(held) < max(1, genotype_chunks) and i + 1 < len(chunks):
-                    continue
-                all_args = [a for c, _ in held for a in c]
-                all_scans = [s_ for _, sc in held for s_ in sc]
-                del held[:]
-                for r in finish_batch(engine, all_args, all_scans, lazy_details=lazy_details):
-                    if sink is not None:
-                        sink(r)
+                yield chunk, scans
+        elif ex is not None:
+            ahead = deque()
+            more = True
+            while True:
+                while more and len(ahead) <= max(1, ahead_batches):
+                    chunk = next(chunks, None)
+                    if chunk is None:
+                        more = False
                     else:
-                        out.append(r)
-                continue
-            # the GPU half of this chunk on a thread of its own (its calls mostly wait -- on the kernels, and with several
-            # driver processes on the other processes' copies) beside the formatting of the previous chunk
-            fut = gpu_ex.submit(genotype_scans, engine, chunk, scans)
-            if pending is not None:
-                flush(pending)
-            pending = (chunk, scans, fut)
-        if pending is not None:
-            flush(pending)
-            pending = None
-    except BaseException:
-        # unwinding from an error: stop the helpers, keep THIS exception (a sink that also failed must not replace it)
-        if gpu_ex is not None:
-            gpu_ex.shutdown(wait=True)
+                        ahead.append((chunk, [ex.submit(collect_sample, a) for a in chunk]))
+                if not ahead:
+                    return
+                chunk, futs = ahead.popleft()
+                t0 = time.perf_counter()
+                scans = [f.result() for f in futs]
+                timing_add(scan_wait=time.perf_counter() - t0)
+                yield chunk, scans
+        else:
+            for chunk in chunks:
+                yield chunk, [collect_sample(a) for a in chunk]
+
+    def shut_down():
         if feeder is not None:
             feeder.close()
         if own:
             ex.shutdown()
+    try:
+        for chunk, scans in scanned():
+            for r in finish_batch(engine, chunk, scans, lazy_details=lazy_details):
+                if sink is not None:
+                    sink(r)
+                else:
+                    out.append(r)
+    except BaseException:
+        # unwinding from an error: stop the helpers, keep THIS exception (a sink that also failed must not replace it)
+        shut_down()
         if writer is not None:
             try:
                 writer.close()
             except BaseException:
                 pass
         raise
-    if gpu_ex is not None:
-        gpu_ex.shutdown(wait=True)
-    if feeder is not None:
-        feeder.close()
-    if own:
-        ex.shutdown()
+    shut_down()
     if writer is not None:
         writer.close()
     return out
@@ -918,19 +922,24 @@ def write_vcf_json(results, ref, repo, treds, store=None, quiet=False):
 
 
 # ---- driver -------------------------------------------------------------------------------------------------------
-def _fan_out(argv, n_gpus, samples, launch_dir, no_output, quiet, devices=None):
-    """--gpus N: this process stays off the GPU and starts one child per GPU (shard.spawn_ranks) from the directory
-    the command was given in; child r genotypes the samples the parent assigns it (balanced by BAM size) -- the list is fixed here and handed
-    over in a file, so that every child partitions the same list -- and writes those samples' files.  Afterwards
-    the JSONs are echoed in sample order."""
+def _fan_out(argv, n_gpus, samples, launch_dir, no_output, quiet, devices=None, drivers=1, gpu=0):
+    """--gpus N x --drivers D: this process stays off the GPU and starts D driver processes per GPU
+    (shard.spawn_ranks, rank r on GPU r mod N) from the directory the command was given in; child r genotypes the samples
+    the parent assigns it (balanced by BAM size) -- the list is fixed here and handed over in a file, so that every child
+    partitions the same list -- and writes those samples' files.  Afterwards the JSONs are echoed in sample order."""
     import tempfile
     from . import shard
     if devices is None:
         devices = shard.visible_gpus()
     if devices < 1:
         raise SystemExit("tred.py: no GPU visible")
+    devices = min(devices, n_gpus)          # the drivers share --gpus devices, not every device of the box
+    n_gpus = n_gpus * max(1, drivers)       # (ranks from here on)
     samplekeys = [s[0] for s in samples]
     env = dict(os.environ)
+    if devices == 1 and gpu:                # --gpus 1 --gpu K with several drivers: all of them on device K
+        env["HIP_VISIBLE_DEVICES"] = shard.device_entry(gpu, env)
+        env.pop("CUDA_VISIBLE_DEVICES", None)
     env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
                                         [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p])
     # which rank takes which sample: by BAM size, so that a cohort of mixed coverage keeps all GPUs busy to the end
@@ -959,11 +968,29 @@ def _fan_out(argv, n_gpus, samples, launch_dir, no_output, quiet, devices=None):
 
 def default_cpus(gpus, pinned, usable=None):
     """--cpus when it is not given: the reference starts cpu_count() workers (tredparse/tred.py:88); here the CPUs this
-    process may really keep busy (affinity mask, cgroup quota) shared among the --gpus ranks, and in a rank never more
+    process may really keep busy (affinity mask, cgroup quota) shared among the ranks, and in a rank never more
     than its CPU set holds."""
     from . import shard
     share = max(1, (shard.usable_cpus() if usable is None else usable) // max(1, gpus))
     return max(1, min(share, len(pinned))) if pinned else share
+
+
+def plan_drivers(args, n_samples, usable):
+    """(driver processes per GPU, scan threads per driver) of this run: --drivers / --cpus where given, else
+    shard.driver_plan's rule -- with no more drivers than there are blocks of 32 samples for (a driver costs seconds
+    of start-up: interpreter, HIP context, pinned staging)."""
+    from . import shard
+    gpus = max(1, args.gpus)
+    if str(args.drivers) != "auto":
+        per_gpu = max(1, int(args.drivers))
+        threads = args.cpus or max(1, usable // (per_gpu * gpus))
+        return per_gpu, threads
+    per_gpu, threads = shard.driver_plan(usable, gpus, gpu_inflate=args.gpu_inflate)
+    fit = max(1, n_samples // (32 * gpus))
+    if per_gpu > fit:
+        per_gpu = fit
+        threads = max(1, min(usable // (per_gpu * gpus), 16))
+    return per_gpu, args.cpus or threads
 
 
 def main(args, quiet=False):
@@ -973,8 +1000,10 @@ def main(args, quiet=False):
     from . import shard
     usable = shard.usable_cpus()               # (of the inherited mask: what the whole job has, before this rank is pinned)
     pinned = shard.apply_rank_cpuset() if args.task_file else None   # a --gpus child: its GPU's NUMA node, before any GPU call
-    if args.cpus is None:
-        args.cpus = default_cpus(args.gpus, pinned, usable)
+    if args.cpus is None and args.task_file:
+        args.cpus = default_cpus(int(os.environ.get("WORLD_SIZE", "1")), pinned, usable)
+    elif args.cpus is not None and pinned:
+        args.cpus = max(1, min(args.cpus, len(pinned)))         # never more scan threads than this rank's CPU set holds
     logger.setLevel(getattr(logging, args.log))
     logging.getLogger("tredparse_amd.bam").setLevel(getattr(logging, args.log))
     t0 = time.time()
@@ -1007,8 +1036,12 @@ def main(args, quiet=False):
                   not args.noalts, not args.norepeatpairs, args.log) for key, bam, only in samples]
         if not tasks:
             return
-        if args.gpus > 1 and not spawned:
-            rc = _fan_out(argv, args.gpus, samples, cwd, args.no_output, quiet)
+        drivers = 1
+        if not spawned:
+            drivers, args.cpus = plan_drivers(args, len(tasks), usable)
+        if args.gpus * drivers > 1 and not spawned:
+            rc = _fan_out(argv + ["--cpus", str(args.cpus)], args.gpus, samples, cwd, args.no_output, quiet, drivers=drivers,
+                          gpu=args.gpu)
             if rc:
                 sys.exit(rc)
         else:
@@ -1030,9 +1063,9 @@ def main(args, quiet=False):
                     if not args.no_output:
                         write_vcf_json(result, args.ref, repo, loci, quiet=quiet)
                 run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus),
-                         lazy_details=True, background_sink=args.cpus > 1,
+                         lazy_details=True,
                          # (echoing to stdout keeps the sample order; with the host inflating, its cores are the scans')
-                         sink_threads=2 if ((quiet or args.no_output) and args.gpu_inflate) else 1,
+                         background_sink=0 if args.cpus <= 1 else 2 if ((quiet or args.no_output) and args.gpu_inflate) else 1,
                          inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None, gpu_walk=args.gpu_walk)
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
