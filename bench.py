@@ -561,7 +561,13 @@ def e2e_main(args):
     gpu_inflate, gpu_walk = args.e2e_gpu_inflate == "1", args.e2e_gpu_walk == "1"
     sink_lock = __import__("threading").Lock()
 
-    def sink(result):
+    def on_sample(done):                          # from the native writer's threads: the sample's files are written
+        tr = truth[done["samplekey"]]
+        hits = sum(1 for k, (p, a) in enumerate(zip(done["printed"], done["first_allele"])) if p and a == tr[k][0])
+        with sink_lock:
+            log.append((time.time(), sum(done["printed"]), hits, len(names)))
+
+    def sink(result):                             # --e2e-python-writer: the dict path (format_scans + to_json / to_vcf)
         tred.write_vcf_json(result, "hg38", repo, names, quiet=True)
         calls, tr = result["tredCalls"], truth[result["samplekey"]]
         units = sum(1 for n in names if n + ".1" in calls)
@@ -580,20 +586,30 @@ def e2e_main(args):
                     return
                 yield t
             passes += 1
-    kw = dict(sink=sink, lazy_details=True, inflate_device=0 if gpu_inflate else None, gpu_walk=gpu_walk)
+    kw = dict(lazy_details=True, inflate_device=0 if gpu_inflate else None, gpu_walk=gpu_walk)
+    emit = None
+    if args.e2e_python_writer:
+        kw.update(sink=sink, background_sink=2 if gpu_inflate else 1)
+    else:
+        emit = kw["emit"] = tred.Emitter("hg38", repo, names, workers=2, on_sample=on_sample)
     try:
         # warm-up: HIP context, ladders, caches -- and, for the GPU-inflate legs, one full chunk through each inflater, whose
         # pinned staging (45 MB per sample of a chunk, three inflaters) stays with the process for the timed cohort
         warm = mine[:2] if not gpu_inflate else mine[:min(len(mine), 3 * args.e2e_batch)]
         tred.run_many(warm, engine, batch=2 if not gpu_inflate else args.e2e_batch, threads=max(2, threads), **kw)
-        del log[:]
+        if emit is not None:
+            emit.drain()
+        with sink_lock:
+            del log[:]
         for k in tred.TIMING:
             tred.TIMING[k] = 0.0
         if dist is not None:
             dist.barrier()
         t0 = time.time()
         deadline[0] = t0 + args.e2e_seconds
-        tred.run_many(cohort(), engine, batch=args.e2e_batch, threads=threads, background_sink=2 if gpu_inflate else 1, **kw)
+        tred.run_many(cohort(), engine, batch=args.e2e_batch, threads=threads, **kw)
+        if emit is not None:
+            emit.close()
         t1 = time.time()
     finally:
         os.chdir(cwd)
@@ -725,6 +741,8 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None)
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
                         "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
                         "--e2e-seconds", str(seconds), "--e2e-gpu-walk", "1" if gpu_walk else "0"]
+                if getattr(args, "e2e_python_writer", False):
+                    argv.append("--e2e-python-writer")
                 out_dir = os.path.join(root, "out{}_{}".format(n_devices, li))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
@@ -892,6 +910,14 @@ def launcher_main(args):
     n_devices = 1 if args.stub else shard.visible_gpus()
     if n_devices < 1:
         raise SystemExit("bench.py: no HIP device visible (the hot path has no CPU fallback)")
+    if args.e2e_only:                       # tuning runs: the end-to-end legs alone, one line per leg
+        rec = run_e2e(args, [min(args.gpus, n_devices)])[min(args.gpus, n_devices)]
+        for l in rec.get("legs", []):
+            print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in l.items() if k != "per_driver"}), flush=True)
+            for d in l.get("per_driver", [])[:2]:
+                print("    " + json.dumps(d), flush=True)
+        print(json.dumps({"outputs_identical": rec.get("outputs_identical")}), flush=True)
+        return
     lines = {}
     scaling = []
     for n in sweep_counts(args.gpus, n_devices, not args.no_sweep):
@@ -969,7 +995,7 @@ def launcher_main(args):
     # the full record: a file next to the script (and gpurun_out/ when there is one: that directory travels back from
     # the GPU box) and stderr; stdout carries the compact line alone, last
     detail = json.dumps(out)
-    for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+    for path in (os.path.join(ROOT, "bench_detail.json"),) + (() if args.stub else (os.path.join(ROOT, "gpurun_out", "bench_detail.json"),)):
         try:
             if os.path.isdir(os.path.dirname(path)):
                 with open(path, "w") as fp:
@@ -998,7 +1024,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="only --gpus ranks, no 1/2/4/8 sweep")
     ap.add_argument("--rank-timeout", type=float, default=1500.0)
     ap.add_argument("--stub", action="store_true", help="launcher self-test: ranks do no GPU work")
-    ap.add_argument("--e2e-samples", type=int, default=512,
+    ap.add_argument("--e2e-samples", type=int, default=2048,
                     help="BAM files per GPU of the end-to-end legs (0: skip them): the same number at every device count")
     ap.add_argument("--e2e-distinct", type=int, default=512,
                     help="distinct synthetic BAMs made; a larger cohort gets the rest as hard links under their own sample keys")
@@ -1019,6 +1045,9 @@ def main():
     ap.add_argument("--streamed", type=int, default=0,
                     help="also time the step fed from pinned host memory: this many distinct batches, double-buffered "
                          "copy-in beside the kernels (the default run adds it as the `streamed` leg with 4 batches)")
+    ap.add_argument("--e2e-python-writer", action="store_true",
+                    help="end-to-end legs through the Python result dicts and writers instead of the native writer (A/B)")
+    ap.add_argument("--e2e-only", action="store_true", help="run the end-to-end legs alone and print one line per leg (tuning)")
     ap.add_argument("--e2e-child", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-limit", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

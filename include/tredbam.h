@@ -264,6 +264,66 @@ int tredbam_pair_stats(const int32_t* pool, const int64_t* first, const int32_t*
 /* repr(float) of one value into out (>= 32 bytes); returns the length, -1 for a value that is not finite (test hook) */
 int tredbam_float_repr(double value, char* out);
 
+
+/* ---- a sample's outputs written natively: <samplekey>.json and <samplekey>.tred.vcf.gz ---------------------------------
+ * What the reference's run() tail and its writers do per sample in Python (tredparse/tred.py:251-275 the tredCalls keys,
+ * :296-313 to_json: json.dumps(sort_keys=True, indent=4, separators=(',', ': ')), :316-374 to_vcf; bam_parser.py:174-182,
+ * 248-287 the per-read bookkeeping; models.py:87-98 mean_std / histogram, :304-317 sparsify, :370-392 calc_label) from the
+ * kernels' per-read and per-unit results and the scan's pools -- byte for byte the text tredparse_amd/tred.py's Python path
+ * prints (tests/test_emit_native.py compares the two), without the interpreter lock: a driver process's Python work per
+ * sample was what bounded the from-BAM rate. */
+typedef struct tredbam_emit_locus {   /* one locus of the run's list, constant over the cohort                           */
+    const char* name;                 /* "HD"                                                                            */
+    const char* motif;                /* the repeat unit                                                                 */
+    const char* chrom;                /* VCF CHROM                                                                       */
+    const char* info;                 /* VCF INFO column without RPA ("END=...;MOTIF=...;...;VT=STR")                    */
+    int32_t pos, ref_copy, period, cutoff_prerisk, cutoff_risk, is_expansion, is_recessive, in_vcf;
+} tredbam_emit_locus;
+
+typedef struct tredbam_emit_call {    /* = tredgpu_call (include/tredgpu.h)                                              */
+    int32_t status, n_pairs, h1, h2, ci[4], run_pe, pad;
+    double lik, pp;
+} tredbam_emit_call;
+
+typedef struct tredbam_emit_batch {   /* the arrays of one genotyped batch (host memory)                                 */
+    const uint8_t* tag; const int16_t* h;            /* per read of the batch                                            */
+    const int32_t* unit_read_off;                    /* reads of batch unit u: [unit_read_off[u], unit_read_off[u+1])    */
+    const tredbam_emit_call* calls;                  /* per batch unit                                                   */
+    const double* marg; int64_t marg_len;            /* [units][2][marg_len]: P_h1, P_h2 over alleles in repeat units    */
+    const int64_t* joint_a; const int64_t* joint_b; const double* joint_v;   /* sparse joint entries, normalised, in units */
+    const int64_t* joint_lo; const int32_t* joint_n; /* entries of unit u: [joint_lo[u], joint_lo[u] + joint_n[u])       */
+    int32_t repeatpairs, pad;                        /* 0: reads of names tagged REPT twice are removed (--norepeatpairs) */
+} tredbam_emit_batch;
+
+typedef struct tredbam_emit_sample {
+    const char* samplekey; const char* bam;          /* UTF-8                                                            */
+    const char* gender; double ydepth;               /* inferredGender; depthY (< 0: printed as the integer -1)          */
+    int32_t opened, readlen;                         /* opened == 0: only inferredGender / depthY are printed            */
+    const uint8_t* seq4; const int64_t* seq4_off; const int32_t* read_len; const char* names; const int64_t* name_off;
+    const int32_t* name_id; const int32_t* global_lens; const int32_t* target_lens;   /* the scan's pools                */
+    const tredbam_unit* unit; const double* depth;   /* per locus of the list                                            */
+    const int32_t* unit_index;                       /* per locus: its unit in the batch arrays, < 0: not genotyped      */
+} tredbam_emit_sample;
+
+typedef struct tredbam_emit_opts {
+    const char* ref; const char* source; const char* filedate;   /* VCF header: ##reference, ##source prefix, ##fileDate */
+    const char* vcf_meta;                            /* the ##INFO / ##FORMAT lines                                      */
+    int32_t write_json, write_vcf, gzip_level, pad;
+} tredbam_emit_opts;
+
+/* Writes <samplekey>.json and <samplekey>.tred.vcf.gz into the current directory.  locus_status[n_loci]: 0 printed, 1 not
+ * genotyped, < 0 the grid's status where the reference's grid raises (the locus is left out; the caller logs it).
+ * json_text / json_cap: when json_text != NULL the JSON text is also copied there (for the echo on stdout), *json_len its
+ * length (-(length) - 1 when json_cap is too small: nothing copied).  Returns 0; 1 when this sample needs the generic path (a name or key the fast printers do
+ * not cover: non-ASCII read names, duplicate distribution keys, invalid UTF-8) -- nothing was written then; < 0 on errors
+ * (-2 bad arguments, -5 a file could not be written: the message is in tredbam_emit_last_error()). */
+int tredbam_emit_sample_files(const tredbam_emit_locus* loci, int32_t n_loci, const tredbam_emit_batch* batch,
+                              const tredbam_emit_sample* sample, const tredbam_emit_opts* opts, int32_t* locus_status,
+                              char* json_text, int64_t json_cap, int64_t* json_len);
+const char* tredbam_emit_last_error(void);           /* of this thread                                                   */
+/* numpy's pairwise float64 sum of a contiguous array (what `P.sum()` computes in models.py:309): test hook */
+double tredbam_pairwise_sum(const double* a, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

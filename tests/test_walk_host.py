@@ -91,9 +91,9 @@ def test_regions_the_walker_declines_are_walked_by_the_scan(cohort, monkeypatch)
     """Every region comes back with a status (here: the model pretends a damaged block in each): the scans compute the
     pair lengths themselves, inflating what was not fetched, and nothing changes in the result."""
     class Declining(ModelInflater):
-        def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None):
+        def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None, pool_pairs=None):
             status, crc, res, gp, tp, ares, need = ModelInflater.run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, alt_tasks=alt_tasks,
-                                                                          alt_chunks=alt_chunks)
+                                                                          alt_chunks=alt_chunks, pool_pairs=pool_pairs)
             res["status"][::2] = 2
             ares["status"][1::3] = 2
             return status, crc, res, gp, tp, ares, need

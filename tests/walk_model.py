@@ -47,8 +47,9 @@ class ModelInflater(object):
         self.bufs[1][:len(self.dev) - 64] = self.dev[:-64]
         return (status, sums) if crc else status
 
-    def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None):
+    def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None, pool_pairs=None):
         self.walks += 1
+        self.pool_pairs = pool_pairs
         status, crc = self._inflate(n)
         ooff = self.bufs[3]
         out = out_bytes = self.dev.tobytes()
@@ -64,6 +65,8 @@ class ModelInflater(object):
             res[t] = (0, len(g), len(tt), nwin, len(gp), len(tp), vbeg, vend)
             gp += g
             tp += tt
+        # (tred._run_walk sizes the pools from the planned bytes: the bound must hold for every call)
+        assert pool_pairs is None or (len(gp) <= pool_pairs and len(tp) <= max(pool_pairs // 8, 16 * len(tasks)) + 1024), (len(gp), len(tp), pool_pairs)
         out = (status, crc, res, np.array(gp, np.int32), np.array(tp, np.int32))
         if alt_tasks is None:
             return out

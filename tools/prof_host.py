@@ -22,38 +22,7 @@ from tredparse_amd import _lib, engine as eng, shard, synth_bam, tred   # noqa: 
 from tredparse_amd.meta import TREDsRepo                                  # noqa: E402
 
 
-class FakeEngine(object):
-    """engine.Engine.genotype_packed without the kernels."""
-
-    def __init__(self, seed=1):
-        self.rng = np.random.default_rng(seed)
-
-    def genotype_packed(self, b, dense=False):
-        rng = self.rng
-        r = eng.BatchResult()
-        r.batch, r.grid, r.grid_off = b, None, None
-        n, g = b.n_reads, b.n_units
-        r.tag = np.where(rng.random(n) < 0.33, rng.integers(1, 6, n), 0).astype(np.uint8)
-        r.h = rng.integers(1, 50, n).astype(np.int16)
-        r.score = rng.integers(30, 150, n).astype(np.int16)
-        hs = b.max_units + 2
-        r.full, r.pref, r.rept = (np.zeros((g, hs), np.int32) for _ in range(3))
-        r.calls = np.zeros(g, _lib.CALL_DTYPE)
-        per = b.params["period"]
-        r.calls["h1"], r.calls["h2"] = 15 * per, 41 * per
-        r.calls["ci"] = (15, 15, 41, 54)
-        r.calls["pp"], r.calls["lik"], r.calls["n_pairs"] = 0.5, -100.0, 521
-        ms = 302
-        r.marg = np.zeros((g, 2, ms), np.float64)
-        r.marg[:, 0, 15] = 1.0
-        r.marg[:, 1, 41:70] = rng.random((g, 29)) + 0.01
-        cap = 80
-        a = np.repeat(np.full(g, 15, np.int64), cap)
-        bb = np.tile(np.arange(41, 41 + cap, dtype=np.int64), g)
-        v = rng.random(g * cap)
-        r.joint = [None] * g
-        r.joint_units = (a, bb, v, np.arange(g, dtype=np.int64) * cap, np.full(g, cap, np.int32))
-        return r
+from tests.fake_engine import FakeEngine                                   # noqa: E402
 
 
 def main():
@@ -66,7 +35,7 @@ def main():
     repo = TREDsRepo("hg38", sites=os.path.join(root, "no_sites"))
     names = [l["name"] for l in synth_bam.bench_loci()]
     tasks = [(os.path.basename(b)[:-4], b, repo, names, 300, False, False, True, True, "ERROR") for b in bams] * 4
-    engine = FakeEngine()
+    engine = FakeEngine(odd_units=False)
     os.chdir(root)
     wprof, wcpu = cProfile.Profile(), [0.0]
 
@@ -76,14 +45,22 @@ def main():
         tred.write_vcf_json(result, "hg38", repo, names, quiet=True)
         wprof.disable()
         wcpu[0] += time.thread_time() - c0
-    if not native and hasattr(tred, "NATIVE_EMIT"):
-        tred.NATIVE_EMIT = False
-    tred.run_many(tasks[:8], engine, batch=8, sink=sink, threads=threads, lazy_details=True)
+    def go(some, batch):
+        if not native:
+            return tred.run_many(some, engine, batch=batch, sink=sink, threads=threads, lazy_details=True, background_sink=True)
+        emit = tred.Emitter("hg38", repo, names, workers=2)
+        try:
+            tred.run_many(some, engine, batch=batch, threads=threads, lazy_details=True, emit=emit)
+        finally:
+            emit.close()
+    go(tasks[:8], 8)
     wcpu[0] = 0.0
+    for k in tred.TIMING:
+        tred.TIMING[k] = 0.0
     pr = cProfile.Profile()
     t0, c0, p0 = time.perf_counter(), time.thread_time(), time.process_time()
     pr.enable()
-    tred.run_many(tasks, engine, batch=16, sink=sink, threads=threads, lazy_details=True, background_sink=True)
+    go(tasks, 16)
     pr.disable()
     dt = time.perf_counter() - t0
     k = len(tasks)

@@ -397,6 +397,13 @@ def _native():
             lib.tredbam_details_json_many.argtypes = [C.c_void_p] * 9 + [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                                                           C.c_void_p]
             lib.tredbam_details_json_many.restype = C.c_int64
+            lib.tredbam_emit_sample_files.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+            lib.tredbam_emit_sample_files.restype = C.c_int
+            lib.tredbam_emit_last_error.argtypes = []
+            lib.tredbam_emit_last_error.restype = C.c_char_p
+            lib.tredbam_pairwise_sum.argtypes = [C.c_void_p, C.c_int64]
+            lib.tredbam_pairwise_sum.restype = C.c_double
             _lib = lib
     return _lib or None
 
@@ -549,6 +556,46 @@ def details_json_many(seq4, seq4_off, read_len, names, name_off, lists):
     if got < 0:
         raise RuntimeError("tredbam_details_json_many failed ({})".format(got))
     return _texts(buf, got, out_off, status)
+
+
+# ---- a sample's output files written natively (tredbam_emit_sample_files, include/tredbam.h) -------------------------
+class EmitLocus(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("motif", C.c_char_p), ("chrom", C.c_char_p), ("info", C.c_char_p)] + \
+               [(k, C.c_int32) for k in ("pos", "ref_copy", "period", "cutoff_prerisk", "cutoff_risk", "is_expansion",
+                                         "is_recessive", "in_vcf")]
+
+
+class EmitBatch(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("tag", "h", "unit_read_off", "calls", "marg")] + [("marg_len", C.c_int64)] + \
+               [(k, C.c_void_p) for k in ("joint_a", "joint_b", "joint_v", "joint_lo", "joint_n")] + \
+               [("repeatpairs", C.c_int32), ("pad", C.c_int32)]
+
+
+class EmitSample(C.Structure):
+    _fields_ = [("samplekey", C.c_char_p), ("bam", C.c_char_p), ("gender", C.c_char_p), ("ydepth", C.c_double),
+                ("opened", C.c_int32), ("readlen", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("seq4", "seq4_off", "read_len", "names", "name_off", "name_id", "global_lens",
+                                          "target_lens", "unit", "depth", "unit_index")]
+
+
+class EmitOpts(C.Structure):
+    _fields_ = [("ref", C.c_char_p), ("source", C.c_char_p), ("filedate", C.c_char_p), ("vcf_meta", C.c_char_p),
+                ("write_json", C.c_int32), ("write_vcf", C.c_int32), ("gzip_level", C.c_int32), ("pad", C.c_int32)]
+
+
+def emit_locus_table(repo, names):
+    """The tredbam_emit_locus array of a locus list (kept alive by the returned object's `.keep`)."""
+    arr = (EmitLocus * max(1, len(names)))()
+    keep = []
+    for k, n in enumerate(names):
+        t = repo[n]
+        chrom, pos, ref_copy, motif, info = repo.get_info(n)
+        texts = [x.encode("utf-8") for x in (t.name, motif, chrom, info)]
+        keep.append(texts)
+        arr[k] = EmitLocus(texts[0], texts[1], texts[2], texts[3], int(pos), int(ref_copy), int(t.period), int(t.cutoff_prerisk),
+                           int(t.cutoff_risk), int(bool(t.is_expansion)), int(bool(t.is_recessive)), 1)
+    arr.keep = keep
+    return arr
 
 
 class ScanOpts(C.Structure):

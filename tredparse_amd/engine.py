@@ -58,47 +58,64 @@ class PackedUnits(object):
       unit_read_off, ladder_keys[unit]      reads of each unit; its template ladder (prefix, repeat, suffix, max_units)
       params (UNIT_DTYPE)                   grid inputs; pe_off / tl_off index global_lens / target_lens
       pair_id                               per read, for --norepeatpairs (None otherwise)
-      origin                                (scan, k) of every unit, for the way back
     """
 
     @classmethod
     def from_scans(cls, picks, maxinsert=300, fullsearch=False, clip=False, repeatpairs=True):
-        """picks: [(SampleScan, [locus indices])] -- the listed loci of each scan, in that order."""
+        """picks: [(SampleScan, [locus indices])] -- the listed loci of each scan, in that order.  One pass of array
+        operations per scan (a unit at a time in Python this cost a driver 0.6-1.2 ms per sample, 30 units each)."""
         b = cls()
-        b.clip, b.origin, b.ladder_keys = bool(clip), [], []
-        words, lens, ids, gls, tls, n_reads = [], [], [], [], [], [0]
-        rows = []
-        n_gl = n_tl = 0
+        b.clip, b.ladder_keys = bool(clip), []
+        words, offs, lens, ids, gls, tls, rows, counts = [], [np.zeros(1, np.int64)], [], [], [], [], [], []
+        wbase = n_gl = n_tl = 0
         for scan, ks in picks:
-            for k in ks:
-                t, u = scan.loci[k], scan.unit[k]
-                a, e = scan.reads_of(k)
-                words.append((scan.packed[scan.word_off[a]:scan.word_off[e]], scan.word_off[a:e + 1] - scan.word_off[a]))
-                lens.append(scan.read_len[a:e])
-                ids.append(scan.name_id[a:e])
-                g, tl = scan.pair_lengths(k)
-                gls.append(g)
-                tls.append(tl)
-                n_reads.append(n_reads[-1] + (e - a))
-                period = len(t.repeat)
-                span = t.repeat_end - t.repeat_start
-                rows.append((period, scan.readlen, int(scan.ploidy[k]), maxinsert, int(fullsearch), span + 1,
-                             span + 20, int(t.cutoff_risk), int(t.is_expansion), int(t.is_recessive), n_gl, len(g),
-                             n_tl, len(tl), float(scan.depth[k]) / 2))
-                n_gl += len(g)
-                n_tl += len(tl)
-                b.ladder_keys.append((t.prefix, t.repeat, t.suffix, -(-scan.readlen // period)))
-                b.origin.append((scan, k))
-        b.n_units = len(rows)
-        b.params = np.array(rows, _lib.UNIT_DTYPE) if rows else np.zeros(0, _lib.UNIT_DTYPE)
-        b.unit_read_off = np.asarray(n_reads, np.int32)
-        b.n_reads = int(n_reads[-1])
-        wbase, offs = 0, [np.zeros(1, np.int64)]
-        for w, o in words:
-            offs.append(o[1:] + wbase)
-            wbase += len(w)
+            if not len(ks):
+                continue
+            ks = np.asarray(ks, np.int64)
+            st, u = _static(scan), scan.unit[ks]
+            first, n = u["read_first"].astype(np.int64), u["n_reads"].astype(np.int64)
+            reads = _ranges(first, n)                         # pool indices of the units' reads, unit after unit
+            if isinstance(reads, slice):
+                w0, w1 = int(scan.word_off[reads.start]), int(scan.word_off[reads.stop])
+                words.append(scan.packed[w0:w1])
+                offs.append(scan.word_off[reads.start + 1:reads.stop + 1] - w0 + wbase)
+                wbase += w1 - w0
+            else:
+                lo, hi = scan.word_off[reads], scan.word_off[reads + 1]
+                size = hi - lo
+                words.append(scan.packed[_ranges(lo, size, force=True)])
+                offs.append(np.cumsum(size) + wbase)
+                wbase += int(size.sum())
+            lens.append(scan.read_len[reads])
+            if not (repeatpairs or clip):
+                ids.append(scan.name_id[reads])
+            g, t = u["n_global"].astype(np.int64), u["n_target"].astype(np.int64)
+            gls.append(scan.global_lens[_ranges(u["global_first"].astype(np.int64), g)])
+            tls.append(scan.target_lens[_ranges(u["target_first"].astype(np.int64), t)])
+            r = np.zeros(len(ks), _lib.UNIT_DTYPE)
+            r["period"], r["readlen"], r["ploidy"] = st["period"][ks], scan.readlen, scan.ploidy[ks]
+            r["maxinsert"], r["fullsearch"] = maxinsert, int(fullsearch)
+            r["ref_len"], r["minpe"] = st["span"][ks] + 1, st["span"][ks] + 20
+            r["cutoff_risk"], r["is_expansion"], r["is_recessive"] = st["cutoff_risk"][ks], st["is_expansion"][ks], st["is_recessive"][ks]
+            r["pe_off"], r["n_global"] = n_gl + np.cumsum(g) - g, g
+            r["tl_off"], r["n_target"] = n_tl + np.cumsum(t) - t, t
+            r["half_depth"] = np.asarray(scan.depth, np.float64)[ks] / 2
+            rows.append(r)
+            counts.append(n)
+            n_gl += int(g.sum())
+            n_tl += int(t.sum())
+            keys = st["ladder"].get(scan.readlen)
+            if keys is None:
+                keys = st["ladder"][scan.readlen] = [(x.prefix, x.repeat, x.suffix, -(-scan.readlen // len(x.repeat))) for x in scan.loci]
+            b.ladder_keys += [keys[k] for k in ks.tolist()]
         cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts), dt) if parts else np.zeros(0, dt)
-        b.packed = cat([w for w, _ in words], np.uint32)
+        b.params = cat(rows, _lib.UNIT_DTYPE)
+        b.n_units = len(b.params)
+        b.unit_read_off = np.zeros(b.n_units + 1, np.int32)
+        if counts:
+            np.cumsum(np.concatenate(counts), out=b.unit_read_off[1:])
+        b.n_reads = int(b.unit_read_off[-1])
+        b.packed = cat(words, np.uint32)
         b.read_off = cat(offs, np.int64)
         b.read_len = cat(lens, np.int32)
         b.pair_id = None if (repeatpairs or clip) else cat(ids, np.int32)
@@ -107,10 +124,49 @@ class PackedUnits(object):
         return b
 
 
+def _ranges(first, count, force=False):
+    """The concatenation of arange(first[i], first[i] + count[i]) -- as a slice when the ranges follow each other
+    without a gap (the common case: a scan's pools hold its loci one after the other)."""
+    total = int(count.sum())
+    if total == 0:
+        return slice(0, 0) if not force else np.zeros(0, np.int64)
+    live = count > 0
+    f, c = first[live], count[live]
+    if not force and (len(f) == 1 or (f[1:] == f[:-1] + c[:-1]).all()):
+        return slice(int(f[0]), int(f[0]) + total)
+    starts = np.cumsum(c) - c
+    return np.repeat(f - starts, c) + np.arange(total, dtype=np.int64)
+
+
+def _static(scan):
+    """Per-locus constants of a scan's locus list as arrays (period, tract span, cut-off, inheritance flags) and its
+    template-ladder keys per read length -- the same for every sample of a cohort, so kept on the locus list's first
+    Locus object (scans of one repo and list share their Locus objects)."""
+    loci = scan.loci
+    if not loci:
+        return {"period": np.zeros(0, np.int32), "span": np.zeros(0, np.int32), "cutoff_risk": np.zeros(0, np.int32),
+                "is_expansion": np.zeros(0, np.int32), "is_recessive": np.zeros(0, np.int32), "ladder": {}}
+    key = tuple(id(t) for t in loci)
+    hit = _STATIC.get(key)
+    if hit is None or hit[0] is not loci[0]:
+        st = {"period": np.array([len(t.repeat) for t in loci], np.int32),
+              "span": np.array([t.repeat_end - t.repeat_start for t in loci], np.int32),
+              "cutoff_risk": np.array([int(t.cutoff_risk) for t in loci], np.int32),
+              "is_expansion": np.array([int(t.is_expansion) for t in loci], np.int32),
+              "is_recessive": np.array([int(t.is_recessive) for t in loci], np.int32), "ladder": {}}
+        if len(_STATIC) > 256:
+            _STATIC.clear()
+        hit = _STATIC[key] = (loci[0], st)
+    return hit[1]
+
+
+_STATIC = {}
+
+
 class BatchResult(object):
     """Arrays of one genotyped PackedUnits batch; unit(i) gives the per-unit view the callers format."""
     __slots__ = ("batch", "tag", "h", "score", "full", "pref", "rept", "calls", "marg", "joint", "grid", "grid_off",
-                 "joint_units")
+                 "joint_units", "repeatpairs", "_emit")
 
     def unit(self, i):
         b = self.batch

@@ -541,7 +541,8 @@ def debug_lines(scan, k, res):
 def _genotype(engine, picks, o):
     """PackedUnits of `picks` through the GPU.  A batch that fails as a whole is retried sample by sample and then
     unit by unit, so that one unit the kernels reject costs only itself (the reference loses only the failing
-    locus too).  Returns {(scan index, k): UnitResult}."""
+    locus too).  Returns {scan index: [(BatchResult, first unit of the sample in it, its locus indices)]} -- one piece
+    per sample unless the retries went down to single units."""
     from ._lib import TredGpuError
     from .engine import PackedUnits
     kw = dict(maxinsert=o["maxinsert"], fullsearch=o["fullsearch"], clip=o["clip"],
@@ -553,11 +554,12 @@ def _genotype(engine, picks, o):
         if batch.n_units == 0:
             return
         br = engine.genotype_packed(batch, dense=True) if o["log"] == "DEBUG" else engine.genotype_packed(batch)
+        br.repeatpairs = kw["repeatpairs"]
         i = 0
         for si, _, ks in sub:
-            for k in ks:
-                out[(si, k)] = br.unit(i)
-                i += 1
+            if ks:
+                out.setdefault(si, []).append((br, i, list(ks)))
+            i += len(ks)
 
     try:
         attempt(picks)
@@ -576,7 +578,8 @@ def _genotype(engine, picks, o):
 
 
 def genotype_scans(engine, task_args, scans):
-    """GPU half of a batch: the kernels' results for every unit of the scans, (picks, {(scan index, k): UnitResult}).
+    """GPU half of a batch: the kernels' results for every unit of the scans, (picks, parts) with parts as _genotype
+    returns them (unit_results turns them into per-unit views).
     The kernel-side options of a GPU batch are the batch's: tasks that differ in them go in separate batches (the CLI's
     are uniform; API callers of run_many may mix them)."""
     picks = [(si, s, [k for k in range(len(s.names)) if k not in s.dropped] if s.opened else [])
@@ -587,11 +590,23 @@ def genotype_scans(engine, task_args, scans):
         o = _options(arg)
         key = (o["maxinsert"], o["fullsearch"], o["clip"], o["repeatpairs"] or o["clip"], o["log"] == "DEBUG")
         groups.setdefault(key, (o, []))[1].append(pick)
-    res = {}
+    parts = {}
     for o, sub in groups.values():
-        res.update(_genotype(engine, sub, o))
+        parts.update(_genotype(engine, sub, o))
     timing_add(gpu=time.perf_counter() - t0)
-    return picks, res
+    return picks, parts
+
+
+def unit_results(parts, only=None):
+    """{(scan index, k): UnitResult} of genotype_scans' parts (only: that scan index alone)."""
+    res = {}
+    for si, pieces in parts.items():
+        if only is not None and si != only:
+            continue
+        for br, i0, ks in pieces:
+            for j, k in enumerate(ks):
+                res[(si, k)] = br.unit(i0 + j)
+    return res
 
 
 def format_scans(task_args, scans, picks, res, lazy_details=False):
@@ -623,8 +638,8 @@ def finish_batch(engine, task_args, scans, lazy_details=False):
     (dict-like) instead of lists and dicts; to_json prints both natively."""
     if not task_args:
         return []
-    picks, res = genotype_scans(engine, task_args, scans)
-    return format_scans(task_args, scans, picks, res, lazy_details=lazy_details)
+    picks, parts = genotype_scans(engine, task_args, scans)
+    return format_scans(task_args, scans, picks, unit_results(parts), lazy_details=lazy_details)
 
 
 def run(arg, engine=None):
@@ -633,6 +648,152 @@ def run(arg, engine=None):
     {'samplekey', 'bam', 'tredCalls'}."""
     from .engine import Engine
     return finish_batch(engine or Engine(), [arg], [collect_sample(arg)])[0]
+
+
+NATIVE_EMIT = True        # (tools/prof_host.py and the tests switch the native writer off to time / compare the Python path)
+
+
+class Emitter(object):
+    """Writes the samples' <key>.json and <key>.tred.vcf.gz straight from a batch's result arrays and the scans' pools,
+    natively (libtredbam.so tredbam_emit_sample_files, include/tredbam.h) on `workers` threads that run WITHOUT the
+    interpreter lock -- instead of building every sample's tredCalls dict (format_scans) and printing it (to_json,
+    to_vcf) in Python, which was what bounded a driver process.  The text is byte for byte the Python path's
+    (tests/test_emit_native.py).  A sample the native printers do not cover -- --log DEBUG, a BAM that did not open, a
+    batch the retries cut into single units, names outside ASCII -- goes through the Python path on the same thread.
+      echo      print each JSON on stdout as to_json does (one worker then: the order of the samples is kept)
+      on_sample called with {'samplekey', 'names', 'printed' (bool per locus), 'first_allele' (units, per locus)} after a
+                sample's files are written (bench.py checks the calls against the simulated alleles with it)"""
+
+    def __init__(self, ref, repo, treds, no_output=False, echo=False, workers=2, on_sample=None, depth=96):
+        from . import bamio
+        self.ref, self.repo, self.treds, self.no_output, self.echo, self.on_sample = ref, repo, list(treds), no_output, echo, on_sample
+        self.lib = bamio._native() if NATIVE_EMIT else None
+        self.tables = {}
+        self.error = None
+        self.pool = ThreadPoolExecutor(max_workers=1 if echo else max(1, workers), thread_name_prefix="tred-emit")
+        self.depth = depth
+        self.room = threading.BoundedSemaphore(depth)          # results in flight (each holds its scan and batch arrays)
+        self.meta = INFO.encode("utf-8")
+        self.source = __file__.encode("utf-8")
+
+    def _table(self, names):
+        from . import bamio
+        key = tuple(names)
+        if key not in self.tables:
+            ok = self.lib is not None and all(isinstance(self.repo[n].cutoff_risk, int) and isinstance(self.repo[n].cutoff_prerisk, int)
+                                              for n in names)
+            self.tables[key] = bamio.emit_locus_table(self.repo, names) if ok else None
+        return self.tables[key]
+
+    def submit(self, arg, scan, pieces):
+        """One sample of a genotyped batch (pieces: genotype_scans' parts for it)."""
+        self.room.acquire()
+        try:
+            self.pool.submit(self._run, arg, scan, pieces)
+        except BaseException:
+            self.room.release()
+            raise
+
+    def _run(self, arg, scan, pieces):
+        t0 = time.perf_counter()
+        try:
+            if self.error is None:
+                self._emit(arg, scan, pieces)
+        except BaseException as e:
+            self.error = e
+        finally:
+            self.room.release()
+            timing_add(write=time.perf_counter() - t0)
+
+    def _python_path(self, arg, scan, pieces):
+        """The sample through format_scans and the Python writers (what the native path must equal)."""
+        picks = [(0, scan, [k for _, _, ks in pieces for k in ks])]
+        result = format_scans([arg], [scan], picks, unit_results({0: pieces}), lazy_details=True)[0]
+        if not self.no_output:
+            write_vcf_json(result, self.ref, self.repo, self.treds, quiet=not self.echo)
+        if self.on_sample is not None:
+            calls = result["tredCalls"]
+            self.on_sample({"samplekey": result["samplekey"], "names": scan.names,
+                            "printed": [n + ".1" in calls for n in scan.names],
+                            "first_allele": [calls.get(n + ".1", -1) for n in scan.names]})
+
+    def _emit(self, arg, scan, pieces):
+        import ctypes as C
+        import numpy as np
+        from . import bamio
+        o = _options(arg)
+        native = scan.opened and len(pieces) == 1 and o["log"] != "DEBUG" and getattr(pieces[0][0], "joint_units", None) is not None
+        table = self._table(scan.names) if native else None
+        if table is None or (self.no_output and self.on_sample is None):
+            if not (self.no_output and self.on_sample is None and o["log"] != "DEBUG"):
+                self._python_path(arg, scan, pieces)
+            return
+        br, i0, ks = pieces[0]
+        eb = getattr(br, "_emit", None)
+        if eb is None:                       # the batch's arrays, once per batch (whichever sample's thread gets there first)
+            a, b, v, lo, n = br.joint_units
+            keep = [np.ascontiguousarray(x) for x in (br.tag, br.h, br.batch.unit_read_off, br.calls, br.marg, a, b, v, lo, n)]
+            eb = bamio.EmitBatch(*[x.ctypes.data for x in keep[:5]], br.marg.shape[2], *[x.ctypes.data for x in keep[5:]],
+                                 int(bool(br.repeatpairs)), 0)
+            eb.keep = keep
+            br._emit = eb
+        index = np.full(len(scan.names), -1, np.int32)
+        index[ks] = np.arange(i0, i0 + len(ks), dtype=np.int32)
+        depth = np.ascontiguousarray(scan.depth, np.float64)
+        key, bam = o["samplekey"].encode("utf-8"), o["bam"].encode("utf-8")
+        ydepth = float(scan.ydepth) if isinstance(scan.ydepth, float) else -1.0
+        es = bamio.EmitSample(key, bam, scan.gender.encode("utf-8"), ydepth, 1, int(scan.readlen),
+                              scan.seq4.ctypes.data, scan.seq4_off.ctypes.data, scan.read_len.ctypes.data,
+                              scan.name_blob if isinstance(scan.name_blob, int) else C.cast(C.c_char_p(scan.name_blob), C.c_void_p).value,
+                              scan.name_off.ctypes.data, scan.name_id.ctypes.data,
+                              scan.global_lens.ctypes.data, scan.target_lens.ctypes.data, scan.unit.ctypes.data, depth.ctypes.data,
+                              index.ctypes.data)
+        today = date.today()
+        eo = bamio.EmitOpts(self.ref.encode("utf-8"), self.source, "{}{:02d}{:02d}".format(today.year, today.month, today.day).encode(),
+                            self.meta, 0 if self.no_output else 1, 0 if self.no_output else 1, 6, 0)
+        status = np.zeros(max(1, len(scan.names)), np.int32)
+        cap = (1 << 22) if self.echo else 0
+        text = C.create_string_buffer(cap) if cap else None
+        got = C.c_int64(-1)
+        rc = self.lib.tredbam_emit_sample_files(C.addressof(table), len(scan.names), C.addressof(eb), C.addressof(es), C.addressof(eo),
+                                                status.ctypes.data, text, cap, C.byref(got))
+        if rc == 1:
+            return self._python_path(arg, scan, pieces)
+        if rc < 0:
+            print("Error writing: {} ({})".format(o["samplekey"], self.lib.tredbam_emit_last_error().decode("utf-8", "replace") or rc),
+                  file=sys.stderr)
+            return
+        from .models import STATUS_ERRORS
+        for k in np.nonzero(status[:len(scan.names)] < 0)[0].tolist():
+            st = int(status[k])
+            logger.error("Exception on `%s` %s (%s)", o["bam"], scan.names[k], STATUS_ERRORS.get(st, "status {}".format(st)))
+        if self.echo and not self.no_output:
+            if got.value >= 0:
+                print(text.raw[:got.value].decode("ascii"))
+            else:
+                with open(o["samplekey"] + ".json") as fp:
+                    sys.stdout.write(fp.read())
+        if self.on_sample is not None:
+            c = br.calls[i0:i0 + len(ks)]
+            per = np.array([len(scan.loci[k].repeat) for k in ks], np.int64)
+            first = np.full(len(scan.names), -1, np.int64)
+            first[ks] = np.where(c["status"] == 0, np.minimum(c["h1"], c["h2"]) // per, -1)
+            self.on_sample({"samplekey": o["samplekey"], "names": scan.names, "printed": (status[:len(scan.names)] == 0).tolist(),
+                            "first_allele": first.tolist()})
+
+    def drain(self):
+        """Waits until every submitted sample is written (a sample holds one of the `depth` places until it is)."""
+        for _ in range(self.depth):
+            self.room.acquire()
+        for _ in range(self.depth):
+            self.room.release()
+        if self.error is not None:
+            raise self.error
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+        if self.error is not None:
+            raise self.error
 
 
 class _Writer(object):
@@ -687,7 +848,7 @@ def _chunked(task_args, first, batch):
 
 
 def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
-             background_sink=False, inflate_device=None, gpu_walk=False):
+             background_sink=False, inflate_device=None, gpu_walk=False, emit=None):
     """run() over many samples, `batch` samples per GPU batch.  task_args: a list, or any iterable of run() argument
     tuples (taken lazily, a chunk at a time: a cohort need not be known in advance).  BAMs are scanned by `threads` host
     threads (or the executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in
@@ -695,6 +856,8 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     finished result goes to sink(result), or into the returned list.  lazy_details: see finish_batch.
     background_sink: sink runs on a writer thread (in order) instead of the driver thread; an integer > 1: on that many
     writer threads, in any order (the sink's calls must then be independent of each other).
+    emit: an Emitter -- the samples' output files are then written natively from the batch's arrays and no result dict
+    is built (sink is not called, nothing is returned).
     inflate_device: GPU that inflates the samples' BGZF blocks, a chunk of samples per launch (None: the scans inflate on
     the host); needs scan threads.  gpu_walk: the pair-length walks (PEextractor) run on that GPU too, over the blocks it
     just inflated; only the blocks of the loci's windows and of the alternative loci come back.
@@ -759,6 +922,13 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
             ex.shutdown()
     try:
         for chunk, scans in scanned():
+            if emit is not None:
+                picks, parts = genotype_scans(engine, chunk, scans)
+                t0 = time.perf_counter()
+                for si, (arg, scan) in enumerate(zip(chunk, scans)):
+                    emit.submit(arg, scan, parts.get(si, []))
+                timing_add(format=time.perf_counter() - t0)
+                continue
             for r in finish_batch(engine, chunk, scans, lazy_details=lazy_details):
                 if sink is not None:
                     sink(r)
@@ -1059,14 +1229,16 @@ def main(args, quiet=False):
                 from .engine import Engine
                 engine = Engine(device)
 
-                def sink(result):
-                    if not args.no_output:
-                        write_vcf_json(result, args.ref, repo, loci, quiet=quiet)
-                run_many(tasks, engine, batch=max(1, args.batch_samples), sink=sink, threads=max(1, args.cpus),
-                         lazy_details=True,
-                         # (echoing to stdout keeps the sample order; with the host inflating, its cores are the scans')
-                         background_sink=0 if args.cpus <= 1 else 2 if ((quiet or args.no_output) and args.gpu_inflate) else 1,
-                         inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None, gpu_walk=args.gpu_walk)
+                # the samples' files are written natively, from the batch's arrays, on threads of their own (Emitter); a
+                # sample the native printers do not cover takes the Python path there
+                emit = Emitter(args.ref, repo, loci, no_output=args.no_output, echo=not quiet,
+                               workers=2 if args.cpus > 1 else 1)
+                try:
+                    run_many(tasks, engine, batch=max(1, args.batch_samples), threads=max(1, args.cpus), lazy_details=True,
+                             inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None, gpu_walk=args.gpu_walk,
+                             emit=emit)
+                finally:
+                    emit.close()
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
         os.chdir(cwd)
