@@ -362,7 +362,7 @@ class _InflateFeeder(object):
 
     def _decode_and_scan(self, chunk, job):
         """Decode thread: one launch for the chunk, then its scans go to the pool and their futures to the consumer."""
-        plans, inf, handed = job["plans"], job["inf"], False
+        plans, inf, handed, futs = job["plans"], job["inf"], 0, []
         try:
             if self.stop.is_set():
                 return
@@ -381,7 +381,7 @@ class _InflateFeeder(object):
                 timing_add(inflate_gpu=time.perf_counter() - t0)
             if self.stop.is_set():
                 return
-            futs, ooff = [], job["ooff"]
+            ooff = job["ooff"]
             for a, p in zip(chunk, plans):
                 if p is None:
                     futs.append(self.ex.submit(collect_sample, a))
@@ -396,14 +396,15 @@ class _InflateFeeder(object):
                         alt = ares[p["alt_first"]:p["alt_first"] + len(p["alt_tasks"])]
                     futs.append(self.ex.submit(_scan_planned, a, p, inf.out_addr, ooff[k:k + p["n"] + 1], status[k:k + p["n"]],
                                                crc[k:k + p["n"]], pe, alt))
-            handed = True                                  # (each scan closes its own handle)
+                handed += 1                                # (that scan closes its own handle)
             self.busy[job["slot"]] = futs
             self._put((chunk, futs))
         except BaseException as e:     # hand the failure to the consumer instead of leaving it waiting
+            self.busy[job["slot"]] = futs         # (scans already running read the slot's buffers: close() waits for them)
             self._put(e)
         finally:
-            if not handed:
-                self._close_plans(plans)
+            # only the plans no scan was given are closed here: a handle a running scan still uses must not be freed under it
+            self._close_plans(plans[handed:])
 
     @staticmethod
     def _run_walk(inf, job):
