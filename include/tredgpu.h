@@ -366,6 +366,17 @@ typedef struct tredgpu_alt_result { int32_t status, n; uint64_t vbeg[6]; } tredg
 int tredgpu_inflate_walk(tredgpu_inflater* inf, int32_t n_blocks, int32_t* status, uint32_t* crc, tredgpu_walk_args* walk);
 /* copies the blocks with need[k] != 0 of the last tredgpu_inflate_walk to the pinned output; returns the number of copies */
 int tredgpu_inflater_fetch(tredgpu_inflater* inf, int32_t n_blocks, const uint8_t* need);
+/*
+ * The same without a pinned host copy of the whole output (45 MB per 30x sample and inflater, three inflaters per driver
+ * process: the walk brings back a fifth of the blocks).  tredgpu_inflater_host_out(inf, 0): reserve no longer allocates
+ * out_host (it returns NULL there; tredgpu_inflate_blocks[_crc] and tredgpu_inflater_fetch then fail with -2);
+ * tredgpu_inflater_fetch_dense copies the wanted blocks -- and, as tredgpu_inflater_fetch does, the blocks between two
+ * wanted ones that are fewer bytes than a copy costs -- one after the other into a pinned buffer of their own size:
+ * block k lies at (*host)[dense_off[k] .. dense_off[k+1]) (empty when it was not copied; dense_off has n_blocks + 1
+ * entries).  *host stays valid until the next fetch_dense of the inflater.  Returns the number of copies.
+ */
+int tredgpu_inflater_host_out(tredgpu_inflater* inf, int enabled);
+int tredgpu_inflater_fetch_dense(tredgpu_inflater* inf, int32_t n_blocks, const uint8_t* need, uint8_t** host, int64_t* dense_off);
 /* device time of the last call's walk launch in milliseconds */
 int tredgpu_inflater_walk_ms(tredgpu_inflater* inf, double* walk_ms);
 

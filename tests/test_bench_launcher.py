@@ -128,7 +128,8 @@ def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
     bench, made, spawned, fake_bams, fake_spawn, read_leg = _fake_e2e(monkeypatch, usable=64)
     per_gpu, threads = shard.driver_plan(64, 8)
     assert bench.e2e_rule(8, 64) == (8 * per_gpu, threads)
-    assert shard.driver_plan(16, 1) == (shard.DRIVERS_PER_GPU, -(-16 // shard.DRIVERS_PER_GPU))
+    assert shard.driver_plan(16, 1) == (3, 5) and shard.driver_plan(128, 8) == (3, 5) and shard.driver_plan(4, 1) == (2, 1)
+    assert shard.driver_plan(16, 1, gpu_inflate=False) == (3, 5) and shard.driver_plan(256, 8) == (3, 8)
     recs = bench.run_e2e(_e2e_args(), [1, 2, 8], spawn=fake_spawn, make_bams=fake_bams, read_leg=read_leg)
     assert made == [128]                                            # the distinct files are made once
     assert sorted(recs) == [1, 2, 8]

@@ -225,9 +225,10 @@ def test_inflate_feeder_stops_when_the_consumer_fails(tmp_path, monkeypatch):
     class FakeInflater(object):
         made, closed, runs = [], [], []
 
-        def __init__(self, device=0):
+        def __init__(self, device=0, host_out=True):
             FakeInflater.made.append(self)
             self.comp_addr = self.out_addr = 0
+            self.host_out = host_out
 
         def reserve(self, cb, ob, n):
             self.bufs = (np.zeros(cb + 64, np.uint8), np.zeros(ob + 64, np.uint8), np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64))

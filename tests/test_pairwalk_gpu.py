@@ -432,3 +432,68 @@ def test_a_pair_without_alignment_end_is_the_hosts_to_report(inf, tmp_path):
     for key in pools:
         assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
     f.close(); g.close()
+
+
+def test_dense_fetch_hands_over_the_same_blocks(synthetic):
+    """An inflater without a host copy of the whole output (tredgpu_inflater_host_out(0): 45 MB less pinned memory per
+    sample): tredgpu_inflater_fetch_dense packs the wanted blocks (and short gaps) one after the other -- every block it
+    says it copied is zlib's byte for byte, every wanted block is among them, and a scan preloaded from the dense buffer
+    equals the plain scan.  The calls that need the host copy refuse."""
+    import ctypes
+    inf = _lib.Inflater(0, host_out=False)
+    cases = _cases(synthetic)
+    handles = [bamio.AlignmentFile(p) for p, _, _ in cases]
+    sites_of, regions_of, readlens, plans = [], [], [], []
+    for f, (path, repo, names) in zip(handles, cases):
+        loci = [repo[n] for n in names]
+        sites, regions = _site_arrays(repo, names, loci, f)
+        rl = f.max_read_len(101)
+        plans.append(f.plan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN))
+        sites_of.append(sites); regions_of.append(regions); readlens.append(rl)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, handles, plans)
+    assert inf.out_addr == 0
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, n_tasks = _walk_inputs(handles, sites_of, readlens, firsts)
+    alt_tasks, alt_chunks, n_alt = _alt_inputs(handles, sites_of, regions_of, readlens, firsts)
+    status, crc, res, gp, tp, ares, alt_need = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=alt_tasks, alt_chunks=alt_chunks,
+                                                            pool_pairs=_lib.walk_pool_pairs(tasks, ooff))
+    assert (status == 0).all() and (crc == bcrc).all() and (res["status"][tasks["n_chunks"] >= 0] == 0).all()
+    with pytest.raises(_lib.TredGpuError):
+        inf.fetch(np.ones(n_all, np.uint8))
+    with pytest.raises(_lib.TredGpuError):
+        inf.run(n_all)
+    need = np.zeros(n_all, np.uint8)
+    t0 = 0
+    for first, host, coff, nt in zip(firsts, host_of, coff_of, n_tasks):
+        need[first:first + len(coff)] = walk_need(coff, host, res[t0:t0 + nt], alt_need[first:first + len(coff)])
+        t0 += nt
+    rng = np.random.default_rng(5)
+    need[rng.integers(0, n_all, 40)] = 1                              # (and some the walk did not ask for)
+    addr, off = inf.fetch_dense(need)
+    size = np.diff(off)
+    want = np.diff(ooff[:n_all + 1])
+    assert ((size == want) | (size == 0)).all() and (size[need != 0] == want[need != 0]).all()
+    assert need.sum() < size.astype(bool).sum() + 1 and off[-1] < 0.6 * ooff[n_all]      # (gaps are few; most bytes stay behind)
+    dense = np.ctypeslib.as_array(ctypes.cast(addr, ctypes.POINTER(ctypes.c_uint8)), shape=(int(off[-1]),))
+    for k, data in enumerate(_zlib_blocks(handles, plans)):
+        if size[k]:
+            assert dense[off[k]:off[k + 1]].tobytes() == data, k
+    t0 = a0 = 0
+    for f, (path, repo, names), sites, regions, rl, first, nt, na, coff in zip(handles, cases, sites_of, regions_of, readlens, firsts, n_tasks,
+                                                                              n_alt, coff_of):
+        r, ar = res[t0:t0 + nt], ares[a0:a0 + na]
+        t0, a0 = t0 + nt, a0 + na
+        n_here = len(coff)
+        f.preload(addr, off[first:first + n_here + 1], np.where(need[first:first + n_here] != 0, status[first:first + n_here], 1).astype(np.int32),
+                  crc[first:first + n_here])
+        u2, p2 = f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(r, gp, tp), alt=ar)
+        hits, misses = f.preload_clear()
+        plain_f = bamio.AlignmentFile(path)
+        units, pools = plain_f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+        plain_f.close()
+        for key in units.dtype.names:
+            assert (units[key] == u2[key]).all(), (path, key)
+        for key in pools:
+            assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), (path, key)
+        assert misses == 0 and hits > 0, (path, hits, misses)
+        f.close()
+    inf.close()

@@ -1,0 +1,40 @@
+"""CPU: profile hygiene.  Every rocprofv3 summary of the current round under profiles/ carries the library_version of the
+build it was taken on (tools/pmc_to_json.py asks the library itself), and all of them name ONE build: the tree's -- the
+hash tredparse_amd/csrc/Makefile bakes into libtredgpu.so from the kernel sources, recomputed here from the sources."""
+import glob
+import hashlib
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = "r05"
+
+
+def tree_hash():
+    csrc = os.path.join(ROOT, "tredparse_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ("capi.hip", "sw_ladder.hip", "grid.hip", "inflate.hip", "tredgpu_internal.h"):
+        with open(os.path.join(csrc, name), "rb") as fp:
+            h.update(fp.read())
+    with open(os.path.join(ROOT, "include", "tredgpu.h"), "rb") as fp:
+        h.update(fp.read())
+    return h.hexdigest()[:16]
+
+
+def test_makefile_hashes_the_files_this_test_hashes():
+    mk = open(os.path.join(ROOT, "tredparse_amd", "csrc", "Makefile")).read()
+    assert "SRCS := capi.hip sw_ladder.hip grid.hip inflate.hip" in mk and "HDRS := tredgpu_internal.h ../../include/tredgpu.h" in mk
+    assert "cat $(SRCS) $(HDRS) | sha256sum | cut -c1-16" in mk
+
+
+def test_round_summaries_come_from_one_build_the_trees():
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", ROUND + "_*pmc_summary.json")))
+    if not paths:
+        import pytest
+        pytest.skip("no {} summaries under profiles/ yet".format(ROUND))
+    versions = {}
+    for p in paths:
+        with open(p) as fp:
+            versions[os.path.basename(p)] = json.load(fp).get("library_version", "")
+    assert len(set(versions.values())) == 1, versions
+    assert all(v.endswith("src " + tree_hash()) for v in versions.values()), (versions, tree_hash())

@@ -15,10 +15,11 @@ REF_OPS = (0, 2, 3, 7, 8)      # M D N = X
 class ModelInflater(object):
     made = []
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, host_out=True):
         ModelInflater.made.append(self)
         self.comp_addr = self.out_addr = 0
         self.walks = self.fetched = 0
+        self.host_out = host_out
 
     def reserve(self, cb, ob, n):
         self.bufs = (np.zeros(cb + 64, np.uint8), np.zeros(ob + 64, np.uint8), np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64))
@@ -87,11 +88,26 @@ class ModelInflater(object):
         return out + (ares, need)
 
     def fetch(self, need):
+        assert self.host_out
         ooff = self.bufs[3]
         for k in np.flatnonzero(np.asarray(need)):
             self.bufs[1][ooff[k]:ooff[k + 1]] = self.dev[ooff[k]:ooff[k + 1]]
         self.fetched += int(np.count_nonzero(need))
         return 1
+
+    def fetch_dense(self, need):
+        """The wanted blocks one after the other in a buffer of their own (tredgpu_inflater_fetch_dense; no gap merging:
+        any superset of the wanted blocks is a valid answer)."""
+        assert not self.host_out
+        ooff, need = self.bufs[3], np.asarray(need)
+        size = np.where(need != 0, np.diff(ooff[:len(need) + 1]), 0)
+        off = np.zeros(len(need) + 1, np.int64)
+        np.cumsum(size, out=off[1:])
+        self.dense = np.zeros(int(off[-1]) + 64, np.uint8)
+        for k in np.flatnonzero(need):
+            self.dense[off[k]:off[k + 1]] = self.dev[ooff[k]:ooff[k + 1]]
+        self.fetched += int(np.count_nonzero(need))
+        return self.dense.ctypes.data, off
 
     def close(self):
         pass

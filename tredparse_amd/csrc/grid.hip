@@ -472,18 +472,11 @@ __device__ __forceinline__ bool better(const Best& x, const Best& y) {  // is x 
 }
 
 constexpr int NR = 256;     // threads per workgroup of grid_reduce_kernel
-#ifndef REDUCE_SKIP
-#define REDUCE_SKIP 1        // (0: A/B build without the skip of chunks below the diagonal, profiles/r05_grid_ab.txt)
-#endif
 
 // Where one unit's tables live in the scratch pool (offsets in doubles from the unit's base)
 struct SlotLayout {
-    int32_t obs, rowoff, far1, far2, near1, near2, rept, roll1, roll2, ml, ldml, total;
+    int32_t obs, rowoff, far1, far2, near1, near2, rept, roll1, roll2, ml, total;
 };
-// Row stride of the ml rectangle: rows of grids at least a wavefront wide start on a 128-byte line (a 257-column row of
-// 2 056 bytes started anywhere: every 512-byte access of the pairs and reduce kernels touched five lines instead of
-// four); narrow grids stay dense.
-__host__ __device__ inline int ml_stride(int ncol) { return ncol >= 64 ? (ncol + 15) & ~15 : ncol; }
 __device__ inline SlotLayout unit_layout(int nrow, int ncol, int nt, bool run_pe, bool haploid, int dmax, int n_near) {
     SlotLayout L;
     int o = 0;
@@ -496,9 +489,7 @@ __device__ inline SlotLayout unit_layout(int nrow, int ncol, int nt, bool run_pe
     L.rept = o;   o += dmax + 1;
     L.roll1 = o;  o += run_pe ? nrow * ((nt + 31) & ~31) : 0;   // rows padded to 32 entries
     L.roll2 = o;  o += run_pe && !haploid ? ncol * nt : 0;
-    L.ldml = ml_stride(ncol);
-    if (L.ldml != ncol) o = (o + 15) & ~15;
-    L.ml = o;     o += nrow * L.ldml;
+    L.ml = o;     o += nrow * ncol;
     L.total = (o + 15) & ~15;   // slots start on 128-byte lines
     return L;
 }
@@ -1215,17 +1206,16 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitD
                         lp = pos_log(prod);
                     }
                     if (ok) {
-                        const int pos = i * ncol + j;             // (the pair's place in the enumeration: the arg-max's tie rule)
-                        const int at = i * L.ldml + j;            // (its place in the padded rectangle)
-                        double m3 = pass == 0 ? 0.0 : mlbuf[at];
+                        const int pos = i * ncol + j;
+                        double m3 = pass == 0 ? 0.0 : mlbuf[pos];
                         if (tab) m3 += lp;
-                        if (!last) mlbuf[at] = m3;
+                        if (!last) mlbuf[pos] = m3;
                         else {
                             const double m0 = jn >= 0 ? gcur.n1 : cur.f1;
                             const double m1 = jn >= 0 ? gcur.n2 : cur.f2;
                             const double m2 = gcur.m2;
                             const double ml = m0 + m1 + m2 + m3;  // models.py:269
-                            mlbuf[at] = ml;
+                            mlbuf[pos] = ml;
                             Best bb; bb.ml = ml; bb.h1 = h1r; bb.pos = pos;
                             if (better(bb, mine)) mine = bb;
                             if (dump_base >= 0) {
@@ -1373,12 +1363,6 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
             double colacc[KC];
     #pragma unroll
             for (int k = 0; k < KC; ++k) colacc[k] = 0;
-            // the largest h2 of every chunk, wave-uniform: a row whose h1 exceeds it has nothing above the diagonal there and
-            // skips the chunk's loads and exps (97 % of all pairs sit in the upper triangles of 255 ... 257-wide squares: on
-            // average half of a row's chunks).  Adding the zeros it would have produced changes no sum.
-            int kmax[KC];
-    #pragma unroll
-            for (int k = 0; k < KC; ++k) kmax[k] = __builtin_amdgcn_readlane(wave_minmax_to_last<true>(h2k[k]), 63);
             // two rows of the wave per step (i and i + 4): two independent chains of loads, exps and the row-sum
             // reduction in one straight line of code -- the kernel's time per unit is this chain's latency
             auto one_row = [&](const int i) -> double {
@@ -1393,14 +1377,12 @@ __global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const Un
     #pragma unroll
                 for (int k = 0; k < KC; ++k) {
                     const bool ok = k0 + k < nk && (d.ploidy == 1 ? lane == 0 && k == 0 : h2k[k] >= h1);
-                    v[k] = 0.0;
-                    if (!REDUCE_SKIP || d.ploidy == 1 || kmax[k] >= h1) v[k] = ok ? mlbuf[i * L.ldml + lane + 64 * (k0 + k)] : 0.0;
+                    v[k] = ok ? mlbuf[i * ncol + lane + 64 * (k0 + k)] : 0.0;
                 }
                 double acc = 0;
     #pragma unroll
                 for (int k = 0; k < KC; ++k) {
                     if (k0 + k >= nk) break;
-                    if (REDUCE_SKIP && d.ploidy != 1 && kmax[k] < h1) continue;   // (wave-uniform: the whole chunk lies below the diagonal)
                     const bool ok = d.ploidy == 1 ? lane == 0 && k == 0 : h2k[k] >= h1;
                     const double e = ok ? exp(v[k] - max_ml) : 0.0;
                     acc += e;
@@ -1606,8 +1588,7 @@ size_t grid_item_bytes() { return sizeof(int) + sizeof(Best); }
 size_t grid_slot_doubles_max(int rows_cap, int cols_cap, int nt_max) {
     const size_t ntp = ((size_t)std::max(nt_max, 0) + 31) & ~(size_t)31;
     return (sizeof(Obs) + 7) / 8 + (size_t)rows_cap * 3 + 2 + 2 * (size_t)18 * MAXM + 2 + (size_t)rows_cap * ntp +
-           (size_t)cols_cap * (size_t)std::max(nt_max, 0) + 3 * (size_t)rows_cap * cols_cap + 16 +
-           (size_t)rows_cap * 16 + 32;   // (the ml rectangle's rows padded to whole lines, its start aligned)
+           (size_t)cols_cap * (size_t)std::max(nt_max, 0) + 3 * (size_t)rows_cap * cols_cap + 16;
 }
 
 // One pass over all units: prepare (takes pool room per unit) -> pairs -> reduce, all on stream s.  Units that

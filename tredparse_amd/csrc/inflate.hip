@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <string>
+#include <vector>
 
 #include "../../include/tredgpu.h"
 
@@ -730,7 +731,7 @@ struct WalkLds {                                  // (views into the launch's dy
     lds_u8* window;                               // WALK_WINDOW bytes, 16-byte aligned
     int cap; uint32_t mask;
 };
-constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 8 + WALK_WINDOW; }
+constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 8; }     // (pair_walk_kernel: the table alone; the window is the chain kernel's)
 
 // Every lane holds the same value: say so (v_readfirstlane), and what is computed from it is computed once, on the
 // scalar unit, with scalar branches -- not 64 times on the vector unit with the exec mask rebuilt at every `if`.
@@ -826,181 +827,202 @@ struct WalkCursor {
     }
 };
 
-// -DWALK_PROF: cycles per phase of the record loop instead of the result's offsets (tools/walk_prof.py)
-struct WalkProf {
-#ifdef WALK_PROF
-    uint64_t t, acc[6] = {};
-    __device__ void start() { t = __builtin_readcyclecounter(); }
-    __device__ void mark(int k) { const uint64_t n = __builtin_readcyclecounter(); acc[k] += n - t; t = n; }
-#else
-    __device__ void start() {}
-    __device__ void mark(int) {}
-#endif
-};
+// The region's walk in three launches (round 5; one wavefront walked, parsed and paired a region's ~4 000 records batch by
+// batch before: 4.06 ms for the 480 regions of 16 samples, on half of the chip's SIMDs, every step waiting for the one
+// before):
+//   chain    walk_chain_kernel, one wavefront per region: all that is serial about a BAM -- from the region's first record
+//            follow the length words through the LDS window, up to the first record beyond the region -- and NOTHING else:
+//            where every record lies (WalkRec), a batch of 64 per coalesced store;
+//   parse    walk_parse_kernel, one LANE per record, every record of every region of the call side by side (~2 million of
+//            them for 16 samples: the chip is full): fields, CIGAR (end on the reference, soft clips), name hash ->
+//            WalkFields, 32 bytes per record;
+//   resolve  pair_walk_kernel, one wavefront per region: 64 WalkFields per coalesced load, ballots say which records count
+//            for the window and which enter the pair table; only those go through the table one after the other (probe in
+//            LDS, the owning lane writes its fields out); then PairTable::finish as before.
+struct WalkRec { int64_t a0; uint64_t at, after; };             // where the record's length word lies in `out`; the virtual offsets of the record and of what follows it
+struct WalkFields { uint32_t h; int32_t rtid, rpos, rend, lead, trail; uint16_t flag, nlen; uint32_t bad; };
+static_assert(sizeof(WalkRec) == 24 && sizeof(WalkFields) == 32, "record tuples");
+struct WalkChained { int32_t status, n; };                       // per region: how the chain ended, records listed
 
-// The region's walk, a batch of records at a time:
-//   chain    every lane alike, on the scalar unit: from the current position follow the length words through the window and
-//            note where up to BATCH records start (lane j keeps record j's place) -- all that is serial about a BAM;
-//   parse    lane j reads ITS record's head: fields, CIGAR (end on the reference, soft clips), name hash -- the ~600
-//            instructions a record costs are spent once per batch, not once per record (a lone wavefront issues an
-//            instruction every ~5 cycles: the all-lanes-alike walk took 4 600 cycles per record);
-//   resolve  ballots say where the walk stops, which records count for the window, which enter the pair table; only
-//            those go through the table one after the other (probe in LDS, the owning lane writes its fields out).
-constexpr int WALK_BATCH = 32;
-__device__ int walk_region_records(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk* chunks, WalkLds& S, WalkReader& rd,
-                                   WalkPair* pairs, WalkRepeat* repeats, int* n_pairs, int* n_repeats, tredgpu_walk_result& R, int lane,
-                                   WalkProf& prof) {
-    if (T.n_chunks < 0) return WALK_NOT_PLANNED;
-    prof.start();
-    int np = 0, nrep = 0, nwin = 0;
-    uint64_t vbeg = 0, vend = 0;
-    for (int c = 0; c < T.n_chunks; ++c) {
+constexpr int CHAIN_BATCH = 64;
+constexpr int WALK_BATCH = 32;                    // (records per step of the alternative loci's walk)
+__global__ void __launch_bounds__(LANES) walk_chain_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
+                                                           const int64_t* rec_base, WalkRec* recs, WalkChained* chained) {
+    __shared__ __attribute__((aligned(16))) uint8_t window[WALK_WINDOW];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const tredgpu_walk_task T = tasks[t];
+    WalkLds S;
+    S.cap = 0; S.mask = 0; S.table = nullptr;
+    S.window = (lds_u8*)window;
+    WalkReader rd;
+    rd.out = v.out; rd.out_end = v.out_end; rd.S = &S; rd.base = (int64_t)1 << 60; rd.lane = lane; rd.ahead_base = (int64_t)1 << 60;
+    WalkRec* mine = recs + rec_base[t];
+    const int64_t cap = rec_base[t + 1] - rec_base[t];
+    int64_t n = 0;
+    int status = T.n_chunks < 0 ? WALK_NOT_PLANNED : WALK_OK;
+    for (int c = 0; status == WALK_OK && c < T.n_chunks; ++c) {
         const tredgpu_walk_chunk ch = chunks[T.chunk_first + c];
-        if (ch.begin_block < T.block_first || ch.begin_block >= T.block_end) return WALK_NOT_PLANNED;
+        if (ch.begin_block < T.block_first || ch.begin_block >= T.block_end) { status = WALK_NOT_PLANNED; break; }
         WalkCursor cur;
         int rc = cur.enter(v, ch.begin_block);
-        if (rc) return rc;
+        if (rc) { status = rc; break; }
         cur.upos = ch.begin_upos;
         bool chunk_done = false;
-        while (!chunk_done) {
-            // ---- chain ----
-            int nb = 0, err = WALK_OK;
+        while (!chunk_done && status == WALK_OK) {
+            int nb = 0;
             int64_t my_a0 = 0;
             uint64_t my_at = 0, my_after = 0;
-            int32_t my_size = 0;
-            while (nb < WALK_BATCH) {
+            while (nb < CHAIN_BATCH) {
                 const uint64_t at = cur.tell();
                 if (at >= ch.end_voffset) { chunk_done = true; break; }
                 int64_t a0, r;
-                if (cur.upos + 4 <= cur.size) {                            // (nearly always: the length word lies in this block)
-                    a0 = cur.first + cur.upos;
-                    if (!rd.inside(a0, WALK_HEAD)) {
-                        if (nb > 0) break;                                 // the next batch starts with a fresh window
-                        rd.fill(a0);
-                    }
-                    cur.upos += 4;
-                } else {
-                    const WalkCursor before = cur;
-                    if ((rc = cur.take(v, T, 4, &a0)) != 0) { err = rc; break; }
-                    if (!rd.inside(a0, WALK_HEAD)) {
-                        if (nb > 0) { cur = before; break; }
-                        rd.fill(a0);
-                    }
+                if (cur.upos + 4 <= cur.size) { a0 = cur.first + cur.upos; cur.upos += 4; }       // (nearly always)
+                else if ((rc = cur.take(v, T, 4, &a0)) != 0) { status = rc; break; }
+                if (!rd.inside(a0, 16)) {
+                    if (rd.ahead_base <= a0 && a0 + 16 <= rd.ahead_base + WALK_WINDOW) rd.commit(); else rd.fill(a0);
+                    rd.prefetch(rd.base + WALK_WINDOW - 16);       // (the window after this one, while this one is walked)
                 }
                 const int32_t size = (int32_t)rd.u32(a0);
-                if (size < 32) { err = WALK_BAD_RECORD; break; }
-                if (cur.upos + size <= cur.size) cur.upos += size;         // (and so does the record)
-                else if ((rc = cur.take(v, T, size, &r)) != 0) { err = rc; break; }
-                const uint64_t after = cur.tell();
-                if (lane == nb) { my_a0 = a0; my_at = at; my_after = after; my_size = size; }
+                if (size < 32) { status = WALK_BAD_RECORD; break; }
+                if (cur.upos + size <= cur.size) cur.upos += size;
+                else if ((rc = cur.take(v, T, size, &r)) != 0) { status = rc; break; }
+                const int32_t rtid = (int32_t)rd.u32(a0 + 4), rpos = (int32_t)rd.u32(a0 + 8);
+                if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { chunk_done = true; break; }   // beyond the region: the walk over this chunk ends
+                if (lane == nb) { my_a0 = a0; my_at = at; my_after = cur.tell(); }
                 ++nb;
             }
-            if (err != WALK_OK) chunk_done = true;                         // (decided below: the walk may stop before that record)
-            const bool more = !chunk_done;
-            if (more) rd.prefetch(cur.first + cur.upos);                   // (at a block's end: the next block's first byte when it follows in the file)
-            prof.mark(0);
-            // ---- parse: lane j, record j ----
-            const bool mine = lane < nb;
-            int32_t rtid = 0, rpos = 0, rend = -1, lead = 0, trail = 0;
-            uint32_t flag = 0, nlen = 0, h = 0;
-            bool bad = false;
-            if (mine) {
-                const int64_t r = my_a0 + 4;
-                rtid = (int32_t)rd.vu32(r);
-                rpos = (int32_t)rd.vu32(r + 4);
-                const uint32_t l_name = rd.vu8(r + 8), n_cigar = rd.vu16(r + 12);
-                flag = rd.vu16(r + 14);
-                const int32_t l_seq = (int32_t)rd.vu32(r + 16);
-                bad = l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)my_size;
-                if (!bad) {
-                    const int64_t cig = r + 32 + l_name;
-                    if (!(flag & 0x4) && n_cigar > 0) {
-                        int64_t e = rpos;
-                        for (uint32_t q = 0; q < n_cigar; ++q) {
-                            const uint32_t op = rd.vu32(cig + 4 * q);
-                            if ((0x18Du >> (op & 15)) & 1) e += op >> 4;   // M D N = X consume the reference
-                        }
-                        rend = (int32_t)e;
-                    }
-                    for (uint32_t q = 0; q < n_cigar; ++q) {               // query_alignment_start: leading soft clips
-                        const uint32_t op = rd.vu32(cig + 4 * q);
-                        if ((op & 15) == 4) lead += (int32_t)(op >> 4);
-                        else if ((op & 15) == 5) continue;
-                        else break;
-                    }
-                    for (int q = (int)n_cigar - 1; q >= 0; --q) {          // query_length - query_alignment_end
-                        const uint32_t op = rd.vu32(cig + 4 * q);
-                        if ((op & 15) == 4) trail += (int32_t)(op >> 4);
-                        else if ((op & 15) == 5) continue;
-                        else break;
-                    }
-                    nlen = l_name > 0 ? l_name - 1 : 0;
-                    h = 2166136261u ^ nlen;                                // (any hash will do: names are compared byte for byte at the end)
-                    for (uint32_t q = 0; q < nlen; ++q) h = (h ^ rd.vu8(r + 32 + q)) * 16777619u;
-                    h ^= h >> 15;
-                    h *= 0x2C1B3C6Du;
-                    h ^= h >> 12;
-                }
-            }
-            prof.mark(1);
-            // ---- resolve ----
-            const bool off_region = mine && (rtid != T.tid || rpos >= T.end);
-            const bool stops = off_region && (rtid > T.tid || (rtid == T.tid && rpos >= T.end));
-            const uint64_t stop_mask = __ballot(stops), bad_mask = __ballot(mine && !off_region && bad);
-            const int first_stop = stop_mask ? __builtin_ctzll(stop_mask) : 64, first_bad = bad_mask ? __builtin_ctzll(bad_mask) : 64;
-            const int limit = first_stop < first_bad ? first_stop : first_bad;          // records [0, limit) count
-            const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
-            const bool keep = mine && lane < limit && !off_region && e > T.start;
-            const uint64_t win_mask = __ballot(keep && rpos < T.win_hi && e > T.win_lo);
-            if (win_mask) {                                                // records of the scan's own window
-                const int wf = __builtin_ctzll(win_mask), wl = 63 - __builtin_clzll(win_mask);
-                if (nwin == 0) vbeg = walk_lane64(my_at, wf);
-                vend = walk_lane64(my_after, wl);
-                nwin += __popcll(win_mask);
-            }
-            // PairTable::add, in file order
-            uint64_t todo = __ballot(keep && (flag & 0x1) && !(flag & 0x4) && !(flag & 0x400));
-            while (todo) {
-                const int j = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
-                uint32_t tag = hj >> 15;
-                if (tag == 0) tag = 1;
-                uint32_t slot = hj & S.mask;
-                int idx = -1, seen = 0;
-                for (;; slot = (slot + 1) & S.mask) {
-                    const uint32_t entry = walk_uniform(S.table[slot]);
-                    if (entry == 0) break;
-                    if ((entry >> 15) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); seen = (int)((entry >> 13) & 3); break; }
-                }
-                if (idx < 0) {
-                    if (np >= S.cap) return WALK_TABLE_FULL;
-                    idx = np++;
-                }
-                if (seen >= 2 && nrep >= WALK_REPEAT_CAP) return WALK_TABLE_FULL;
-                if (lane == j) {
-                    if (seen < 3) S.table[slot] = (tag << 15) | ((uint32_t)(seen + 1) << 13) | (uint32_t)idx;
-                    if (seen == 0) {
-                        WalkPair& P = pairs[idx];
-                        P.name_at = my_a0 + 36; P.name_len = (uint16_t)nlen;
-                        P.a_pos = rpos; P.a_lead = lead; P.a_rev = (flag & 0x10) ? 1 : 0; P.complete = 0;
-                    } else if (seen == 1) {
-                        WalkPair& P = pairs[idx];
-                        P.name2_at = my_a0 + 36;
-                        P.b_end = rend; P.b_trail = trail; P.b_rev = (flag & 0x10) ? 1 : 0; P.complete = 1;
-                    } else {                                                // the pair is complete: only the name matters
-                        repeats[nrep].pair = idx; repeats[nrep].name_at = my_a0 + 36;
-                    }
-                }
-                if (seen >= 2) ++nrep;
-                walk_lds_order();
-            }
-            if (more) rd.commit();
-            prof.mark(2);
-            if (first_bad < first_stop) return WALK_BAD_RECORD;
-            if (first_stop < 64) { chunk_done = true; err = WALK_OK; }     // the walk over this chunk ended before any trouble
-            if (err != WALK_OK) return err;
+            if (n + nb > cap) { status = WALK_TABLE_FULL; break; }
+            if (lane < nb) mine[n + lane] = WalkRec{my_a0, my_at, my_after};
+            n += nb;
         }
+    }
+    if (lane == 0) chained[t] = WalkChained{status, (int32_t)n};
+}
+
+__device__ inline uint32_t g_u8(const uint8_t* out, int64_t at) { return out[at]; }
+__device__ inline uint32_t g_u16(const uint8_t* out, int64_t at) { uint16_t x; __builtin_memcpy(&x, out + at, 2); return x; }
+__device__ inline uint32_t g_u32(const uint8_t* out, int64_t at) { uint32_t x; __builtin_memcpy(&x, out + at, 4); return x; }
+
+// one lane per record of the call: slot g of the records' pool belongs to the region whose [rec_base[t], rec_base[t+1])
+// holds it (binary search), and is record g - rec_base[t] of it -- when that region's chain listed that many
+__global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks, const int64_t* rec_base, const WalkRec* recs,
+                                                          const WalkChained* chained, WalkFields* fields) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= rec_base[n_tasks]) return;
+    int lo = 0, hi = n_tasks;                              // the last t with rec_base[t] <= g
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rec_base[mid] <= g) lo = mid; else hi = mid;
+    }
+    const WalkChained C = chained[lo];
+    if (C.status != WALK_OK || g - rec_base[lo] >= C.n) return;
+    const uint8_t* out = v.out;
+    const int64_t a0 = recs[g].a0, r = a0 + 4;
+    const int32_t size = (int32_t)g_u32(out, a0);
+    WalkFields F;
+    F.rtid = (int32_t)g_u32(out, r);
+    F.rpos = (int32_t)g_u32(out, r + 4);
+    const uint32_t l_name = g_u8(out, r + 8), n_cigar = g_u16(out, r + 12);
+    F.flag = (uint16_t)g_u16(out, r + 14);
+    const int32_t l_seq = (int32_t)g_u32(out, r + 16);
+    F.rend = -1; F.lead = 0; F.trail = 0; F.nlen = 0; F.h = 0;
+    F.bad = (l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)size) ? 1u : 0u;
+    if (!F.bad) {
+        const int64_t cig = r + 32 + l_name;
+        if (!(F.flag & 0x4) && n_cigar > 0) {
+            int64_t e = F.rpos;
+            for (uint32_t q = 0; q < n_cigar; ++q) {
+                const uint32_t op = g_u32(out, cig + 4 * q);
+                if ((0x18Du >> (op & 15)) & 1) e += op >> 4;   // M D N = X consume the reference
+            }
+            F.rend = (int32_t)e;
+        }
+        for (uint32_t q = 0; q < n_cigar; ++q) {               // query_alignment_start: leading soft clips
+            const uint32_t op = g_u32(out, cig + 4 * q);
+            if ((op & 15) == 4) F.lead += (int32_t)(op >> 4);
+            else if ((op & 15) == 5) continue;
+            else break;
+        }
+        for (int q = (int)n_cigar - 1; q >= 0; --q) {          // query_length - query_alignment_end
+            const uint32_t op = g_u32(out, cig + 4 * q);
+            if ((op & 15) == 4) F.trail += (int32_t)(op >> 4);
+            else if ((op & 15) == 5) continue;
+            else break;
+        }
+        const uint32_t nlen = l_name > 0 ? l_name - 1 : 0;
+        F.nlen = (uint16_t)nlen;
+        uint32_t h = 2166136261u ^ nlen;                       // (any hash will do: names are compared byte for byte at the end)
+        for (uint32_t q = 0; q < nlen; ++q) h = (h ^ g_u8(out, r + 32 + q)) * 16777619u;
+        h ^= h >> 15;
+        h *= 0x2C1B3C6Du;
+        h ^= h >> 12;
+        F.h = h;
+    }
+    fields[g] = F;
+}
+
+// resolve: the listed records of the region, 64 at a time (lane j: record j of the batch)
+__device__ int walk_region_resolve(const tredgpu_walk_task& T, WalkLds& S, const WalkRec* recs, const WalkFields* fields, int n,
+                                   WalkPair* pairs, WalkRepeat* repeats, int* n_pairs, int* n_repeats, tredgpu_walk_result& R, int lane) {
+    int np = 0, nrep = 0, nwin = 0;
+    uint64_t vbeg = 0, vend = 0;
+    for (int i0 = 0; i0 < n; i0 += LANES) {
+        const bool mine = i0 + lane < n;
+        WalkFields F = {};
+        WalkRec me = {};
+        if (mine) { F = fields[i0 + lane]; me = recs[i0 + lane]; }
+        const int32_t rtid = F.rtid, rpos = F.rpos, rend = F.rend;
+        const uint32_t flag = F.flag, h = F.h;
+        const bool off_region = mine && (rtid != T.tid || rpos >= T.end);       // (rtid < T.tid: the chain ends at the others)
+        const uint64_t bad_mask = __ballot(mine && !off_region && F.bad != 0);
+        const int limit = bad_mask ? __builtin_ctzll(bad_mask) : 64;             // records [0, limit) of the batch count
+        const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
+        const bool keep = mine && lane < limit && !off_region && e > T.start;
+        const uint64_t win_mask = __ballot(keep && rpos < T.win_hi && e > T.win_lo);
+        if (win_mask) {                                                // records of the scan's own window
+            const int wf = __builtin_ctzll(win_mask), wl = 63 - __builtin_clzll(win_mask);
+            if (nwin == 0) vbeg = walk_lane64(me.at, wf);
+            vend = walk_lane64(me.after, wl);
+            nwin += __popcll(win_mask);
+        }
+        // PairTable::add, in file order
+        uint64_t todo = __ballot(keep && (flag & 0x1) && !(flag & 0x4) && !(flag & 0x400));
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
+            uint32_t tag = hj >> 15;
+            if (tag == 0) tag = 1;
+            uint32_t slot = hj & S.mask;
+            int idx = -1, seen = 0;
+            for (;; slot = (slot + 1) & S.mask) {
+                const uint32_t entry = walk_uniform(S.table[slot]);
+                if (entry == 0) break;
+                if ((entry >> 15) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); seen = (int)((entry >> 13) & 3); break; }
+            }
+            if (idx < 0) {
+                if (np >= S.cap) return WALK_TABLE_FULL;
+                idx = np++;
+            }
+            if (seen >= 2 && nrep >= WALK_REPEAT_CAP) return WALK_TABLE_FULL;
+            if (lane == j) {
+                if (seen < 3) S.table[slot] = (tag << 15) | ((uint32_t)(seen + 1) << 13) | (uint32_t)idx;
+                if (seen == 0) {
+                    WalkPair& P = pairs[idx];
+                    P.name_at = me.a0 + 36; P.name_len = F.nlen;
+                    P.a_pos = rpos; P.a_lead = F.lead; P.a_rev = (flag & 0x10) ? 1 : 0; P.complete = 0;
+                } else if (seen == 1) {
+                    WalkPair& P = pairs[idx];
+                    P.name2_at = me.a0 + 36;
+                    P.b_end = rend; P.b_trail = F.trail; P.b_rev = (flag & 0x10) ? 1 : 0; P.complete = 1;
+                } else {                                                // the pair is complete: only the name matters
+                    repeats[nrep].pair = idx; repeats[nrep].name_at = me.a0 + 36;
+                }
+            }
+            if (seen >= 2) ++nrep;
+            walk_lds_order();
+        }
+        if (bad_mask) return WALK_BAD_RECORD;
     }
     *n_pairs = np; *n_repeats = nrep;
     R.n_window = nwin; R.win_vbeg = vbeg; R.win_vend = vend;
@@ -1020,7 +1042,8 @@ __device__ inline bool walk_same_name(const uint8_t* out, int64_t a, int64_t b, 
     return diff == 0;
 }
 
-__global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
+__global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tredgpu_walk_task* tasks, const int64_t* rec_base,
+                                                          const WalkRec* recs_all, const WalkFields* fields_all, const WalkChained* chained,
                                                           tredgpu_walk_result* results, WalkPair* pairs_all, WalkRepeat* repeats_all, int32_t* gpool,
                                                           int64_t cap_g, int32_t* tpool, int64_t cap_t, unsigned long long* counters,
                                                           int table_cap) {
@@ -1030,19 +1053,18 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
     WalkLds S;
     S.cap = table_cap;
     S.mask = 2u * (uint32_t)table_cap - 1;
-    S.window = (lds_u8*)walk_lds;
-    S.table = (lds_u32*)(S.window + WALK_WINDOW);
+    S.window = nullptr;
+    S.table = (lds_u32*)walk_lds;
     for (int k = lane; k < 2 * table_cap; k += LANES) S.table[k] = 0;
     WalkPair* pairs = pairs_all + (size_t)t * WALK_PAIR_CAP;
     WalkRepeat* repeats = repeats_all + (size_t)t * WALK_REPEAT_CAP;
     const tredgpu_walk_task T = tasks[t];
-    WalkReader rd;
-    rd.out = v.out; rd.out_end = v.out_end; rd.S = &S; rd.base = (int64_t)1 << 60; rd.lane = lane; rd.ahead_base = (int64_t)1 << 60;
     tredgpu_walk_result R = {};
     int np = 0, nrep = 0;
     __syncthreads();
-    WalkProf prof;
-    int status = walk_region_records(v, T, chunks, S, rd, pairs, repeats, &np, &nrep, R, lane, prof);
+    const WalkChained C = chained[t];
+    int status = C.status;
+    if (status == WALK_OK) status = walk_region_resolve(T, S, recs_all + rec_base[t], fields_all + rec_base[t], C.n, pairs, repeats, &np, &nrep, R, lane);
     __syncthreads();                                       // lane 0's pair entries are visible to the wavefront
     // ---- PairTable::finish, 64 pairs at a time: are the names under one tag equal? which list does the pair go to? ----
     int ng = 0, nt = 0;
@@ -1103,10 +1125,6 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
             R.n_global = ng; R.n_target = nt; R.global_first = gf; R.target_first = tf;
         }
     }
-    prof.mark(5);
-#ifdef WALK_PROF
-    R.global_first = (int64_t)prof.acc[0]; R.target_first = (int64_t)prof.acc[1]; R.win_vbeg = prof.acc[2]; R.win_vend = prof.acc[5];
-#endif
     if (lane == 0) {
         R.status = status;
         if (status != WALK_OK) { R.n_global = R.n_target = R.n_window = 0; R.global_first = R.target_first = 0; R.win_vbeg = R.win_vend = 0; }
@@ -1252,6 +1270,9 @@ struct tredgpu_inflater {
     hipEvent_t t0[2] = {}, t1[2] = {}, k0[MAX_SLICES] = {}, k1[MAX_SLICES] = {};   // timing (tredgpu_inflater_timing)
     int last_slices = 0, last_streams = 0;
     uint8_t *h_comp = nullptr, *h_out = nullptr;      // pinned staging the caller fills / reads in place
+    bool host_out = true;                             // false (tredgpu_inflater_host_out): no pinned room for the whole output --
+                                                      // the blocks the host wants come through tredgpu_inflater_fetch_dense
+    uint8_t* h_dense = nullptr; size_t cap_dense = 0; // pinned: the fetched blocks, one after the other
     int64_t *h_off = nullptr;                         // pinned: comp_off[n+1] then out_off[n+1]
     int32_t* h_status = nullptr;                      // pinned: status[n] then crc[n]
     size_t cap_comp = 0, cap_out = 0, cap_blocks = 0;
@@ -1259,7 +1280,8 @@ struct tredgpu_inflater {
     int64_t* d_off = nullptr;
     int32_t* d_status = nullptr;
     // the pair walk (tredgpu_inflate_walk): a stream of its own, the file's view of the blocks, tasks, per-task tables, pools
-    hipStream_t wstream = nullptr;
+    hipStream_t wstream = nullptr, astream = nullptr;          // (astream: the alternative loci's walks, beside the pair walks)
+    hipEvent_t adone = nullptr;
     hipEvent_t wdone = nullptr, w0 = nullptr, w1 = nullptr, decoded[2] = {nullptr, nullptr};
     bool walk_timed = false, big_lds_allowed = false;
     int walk_table_cap = 0;
@@ -1268,6 +1290,8 @@ struct tredgpu_inflater {
     uint8_t* d_wtask = nullptr; uint8_t* h_wtask = nullptr; size_t cap_wtask = 0;   // tasks then chunks
     uint8_t* d_wres = nullptr;  uint8_t* h_wres = nullptr;  size_t cap_wres = 0;    // results then the two counters
     WalkRepeat* d_wrepeats = nullptr; WalkPair* d_wpairs = nullptr; size_t cap_wscratch = 0;   // in tasks
+    WalkRec* d_wrecs = nullptr; WalkFields* d_wfields = nullptr; size_t cap_wrecs = 0;          // in records: the chain's list, the parsed fields
+    WalkChained* d_wchained = nullptr; size_t cap_wchained = 0;
     uint8_t* d_atask = nullptr; uint8_t* h_atask = nullptr; size_t cap_atask = 0;   // the alternative loci's tasks then chunks
     uint8_t* d_ares = nullptr;  uint8_t* h_ares = nullptr;  size_t cap_ares = 0;    // their results, then the blocks' need flags
     int32_t *d_gpool = nullptr, *d_tpool = nullptr, *h_gpool = nullptr, *h_tpool = nullptr;
@@ -1294,6 +1318,8 @@ int ifail(tredgpu_inflater* f, int code, const char* what, hipError_t e = hipSuc
 void release(tredgpu_inflater* f) {
     if (f->h_comp) (void)hipHostFree(f->h_comp);
     if (f->h_out) (void)hipHostFree(f->h_out);
+    if (f->h_dense) (void)hipHostFree(f->h_dense);
+    f->h_dense = nullptr; f->cap_dense = 0;
     if (f->h_off) (void)hipHostFree(f->h_off);
     if (f->h_status) (void)hipHostFree(f->h_status);
     for (void* p : {(void*)f->d_comp, (void*)f->d_out, (void*)f->d_off, (void*)f->d_status})
@@ -1306,10 +1332,12 @@ void release(tredgpu_inflater* f) {
 void release_walk(tredgpu_inflater* f) {
     for (void* p : {(void*)f->h_wblk, (void*)f->h_wtask, (void*)f->h_wres, (void*)f->h_gpool, (void*)f->h_tpool, (void*)f->h_atask, (void*)f->h_ares})
         if (p) (void)hipHostFree(p);
-    for (void* p : {(void*)f->d_wblk, (void*)f->d_wtask, (void*)f->d_wres, (void*)f->d_wrepeats, (void*)f->d_wpairs, (void*)f->d_gpool, (void*)f->d_tpool, (void*)f->d_atask, (void*)f->d_ares})
+    for (void* p : {(void*)f->d_wblk, (void*)f->d_wtask, (void*)f->d_wres, (void*)f->d_wrepeats, (void*)f->d_wpairs, (void*)f->d_gpool, (void*)f->d_tpool, (void*)f->d_atask, (void*)f->d_ares,
+                    (void*)f->d_wrecs, (void*)f->d_wfields, (void*)f->d_wchained})
         if (p) (void)hipFree(p);
     f->h_wblk = f->h_wtask = f->h_wres = f->h_atask = f->h_ares = nullptr; f->h_gpool = f->h_tpool = nullptr;
     f->d_wblk = f->d_wtask = f->d_wres = f->d_atask = f->d_ares = nullptr; f->d_wrepeats = nullptr; f->d_wpairs = nullptr; f->d_gpool = f->d_tpool = nullptr;
+    f->d_wrecs = nullptr; f->d_wfields = nullptr; f->d_wchained = nullptr; f->cap_wrecs = f->cap_wchained = 0;
     f->cap_wblk = f->cap_wtask = f->cap_wres = f->cap_wscratch = f->cap_gpool = f->cap_tpool = f->cap_atask = f->cap_ares = 0;
 }
 
@@ -1332,6 +1360,8 @@ void destroy_handles(tredgpu_inflater* f) {
     for (hipEvent_t e : {f->wdone, f->w0, f->w1, f->decoded[0], f->decoded[1]}) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : f->stream) if (st) (void)hipStreamDestroy(st);
     if (f->wstream) (void)hipStreamDestroy(f->wstream);
+    if (f->astream) (void)hipStreamDestroy(f->astream);
+    if (f->adone) (void)hipEventDestroy(f->adone);
 }
 }  // namespace
 
@@ -1362,6 +1392,8 @@ int tredgpu_inflater_create(int device_id, tredgpu_inflater** out) {
         if (e == hipSuccess) e = hipEventCreate(&f->k1[k]);
     }
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&f->wstream, hipStreamNonBlocking, lo_prio);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&f->astream, hipStreamNonBlocking, lo_prio);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->adone, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->wdone, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&f->w0);
     if (e == hipSuccess) e = hipEventCreate(&f->w1);
@@ -1380,6 +1412,7 @@ void tredgpu_inflater_destroy(tredgpu_inflater* f) {
     (void)hipSetDevice(f->device);
     for (hipStream_t st : f->stream) (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(f->wstream);
+    if (f->astream) (void)hipStreamSynchronize(f->astream);
     release(f);
     release_walk(f);
     destroy_handles(f);
@@ -1401,7 +1434,7 @@ int tredgpu_inflater_reserve(tredgpu_inflater* f, int64_t comp_bytes, int64_t ou
                      cb = std::max(need_b, f->cap_blocks + f->cap_blocks / 2);
         release(f);
         ICHK(f, hipHostMalloc((void**)&f->h_comp, cc, hipHostMallocDefault));
-        ICHK(f, hipHostMalloc((void**)&f->h_out, co, hipHostMallocDefault));
+        if (f->host_out) ICHK(f, hipHostMalloc((void**)&f->h_out, co, hipHostMallocDefault));
         ICHK(f, hipHostMalloc((void**)&f->h_off, 2 * cb * sizeof(int64_t), hipHostMallocDefault));
         ICHK(f, hipHostMalloc((void**)&f->h_status, 2 * cb * sizeof(int32_t), hipHostMallocDefault));
         ICHK(f, hipMalloc((void**)&f->d_comp, cc));
@@ -1438,6 +1471,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
     if (!f) return -2;
     if (n_blocks < 0 || (size_t)n_blocks + 1 > f->cap_blocks || (n_blocks > 0 && !status)) return ifail(f, -2, "bad arguments (reserve first)");
     if (n_blocks == 0) return 0;
+    if (copy_out && !f->h_out) return ifail(f, -2, "this inflater keeps no host copy of the output (tredgpu_inflater_host_out): walk and fetch");
     const int64_t* coff = f->h_off;
     const int64_t* ooff = f->h_off + f->cap_blocks;
     for (int32_t k = 0; k < n_blocks; ++k) {
@@ -1454,7 +1488,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
     int32_t* d_crc = f->d_status + f->cap_blocks;
     const bool want_crc = crc != nullptr || w != nullptr;
     // ---- the walk's inputs go first, on its own stream (nothing there depends on the decoding yet) ----
-    size_t n_tasks = 0, n_chunks = 0, n_alt = 0, n_alt_chunks = 0;
+    size_t n_tasks = 0, n_chunks = 0, n_alt = 0, n_alt_chunks = 0, total_recs = 0;
     if (w) {
         if (w->n_tasks < 0 || w->n_chunks < 0 || !w->blk_coffset || !w->blk_clen || !w->blk_crc || (w->n_tasks > 0 && (!w->tasks || !w->results)) ||
             (w->n_chunks > 0 && !w->chunks) || w->cap_global < 0 || w->cap_target < 0 || (w->cap_global > 0 && !w->global_pool) ||
@@ -1487,11 +1521,40 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
             if (grow_pair(f, &f->h_ares, &f->d_ares, &f->cap_ares, n_alt * sizeof(tredgpu_alt_result) + nb + 64)) return -10;
             memcpy(f->h_atask, w->alt_tasks, n_alt * sizeof(tredgpu_walk_task));
             memcpy(f->h_atask + n_alt * sizeof(tredgpu_walk_task), w->alt_chunks, n_alt_chunks * sizeof(tredgpu_walk_chunk));
-            ICHK(f, hipMemcpyAsync(f->d_atask, f->h_atask, n_alt * sizeof(tredgpu_walk_task) + n_alt_chunks * sizeof(tredgpu_walk_chunk), hipMemcpyHostToDevice, f->wstream));
-            ICHK(f, hipMemsetAsync(f->d_ares + n_alt * sizeof(tredgpu_alt_result), 0, nb, f->wstream));
+            ICHK(f, hipMemcpyAsync(f->d_atask, f->h_atask, n_alt * sizeof(tredgpu_walk_task) + n_alt_chunks * sizeof(tredgpu_walk_chunk), hipMemcpyHostToDevice, f->astream));
+            ICHK(f, hipMemsetAsync(f->d_ares + n_alt * sizeof(tredgpu_alt_result), 0, nb, f->astream));
         }
         if (grow_pair(f, &f->h_wblk, &f->d_wblk, &f->cap_wblk, nb * 16 + 64)) return -10;
-        if (grow_pair(f, &f->h_wtask, &f->d_wtask, &f->cap_wtask, n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk) + 64)) return -10;
+        // tasks | chunks | rec_base[n_tasks + 1] (8-byte entries behind 8-byte-sized structs: aligned)
+        const size_t rb_at = n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk);
+        static_assert(sizeof(tredgpu_walk_task) % 8 == 0 && sizeof(tredgpu_walk_chunk) % 8 == 0, "rec_base stays 8-byte aligned");
+        if (grow_pair(f, &f->h_wtask, &f->d_wtask, &f->cap_wtask, rb_at + (n_tasks + 1) * sizeof(int64_t) + 64)) return -10;
+        // room for every region's record list: a record is never smaller than 64 bytes here (36 fixed bytes, a name, 36
+        // bases and their qualities: 100 and more) -- a region that has more is the host's (status 4)
+        int64_t* rec_base = (int64_t*)(f->h_wtask + rb_at);
+        rec_base[0] = 0;
+        for (size_t t = 0; t < n_tasks; ++t) {
+            const tredgpu_walk_task& T = w->tasks[t];
+            const int64_t bytes = T.n_chunks >= 0 ? ooff[T.block_end] - ooff[T.block_first] : 0;
+            rec_base[t + 1] = rec_base[t] + (T.n_chunks >= 0 ? bytes / 64 + 64 : 0);
+        }
+        total_recs = (size_t)rec_base[n_tasks];
+        if (total_recs > f->cap_wrecs) {
+            const size_t c = std::max(total_recs, f->cap_wrecs + f->cap_wrecs / 2);
+            if (f->d_wrecs) (void)hipFree(f->d_wrecs);
+            if (f->d_wfields) (void)hipFree(f->d_wfields);
+            f->d_wrecs = nullptr; f->d_wfields = nullptr; f->cap_wrecs = 0;
+            ICHK(f, hipMalloc((void**)&f->d_wrecs, c * sizeof(WalkRec)));
+            ICHK(f, hipMalloc((void**)&f->d_wfields, c * sizeof(WalkFields)));
+            f->cap_wrecs = c;
+        }
+        if (n_tasks > f->cap_wchained) {
+            const size_t c = std::max(n_tasks, f->cap_wchained + f->cap_wchained / 2);
+            if (f->d_wchained) (void)hipFree(f->d_wchained);
+            f->d_wchained = nullptr; f->cap_wchained = 0;
+            ICHK(f, hipMalloc((void**)&f->d_wchained, c * sizeof(WalkChained)));
+            f->cap_wchained = c;
+        }
         if (grow_pair(f, &f->h_wres, &f->d_wres, &f->cap_wres, n_tasks * sizeof(tredgpu_walk_result) + 64)) return -10;
         if (n_tasks > f->cap_wscratch) {
             const size_t c = std::max(n_tasks, f->cap_wscratch + f->cap_wscratch / 2);
@@ -1510,7 +1573,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         memcpy(f->h_wtask, w->tasks, n_tasks * sizeof(tredgpu_walk_task));
         memcpy(f->h_wtask + n_tasks * sizeof(tredgpu_walk_task), w->chunks, n_chunks * sizeof(tredgpu_walk_chunk));
         ICHK(f, hipMemcpyAsync(f->d_wblk, f->h_wblk, nb * 16, hipMemcpyHostToDevice, f->wstream));
-        ICHK(f, hipMemcpyAsync(f->d_wtask, f->h_wtask, n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk), hipMemcpyHostToDevice, f->wstream));
+        ICHK(f, hipMemcpyAsync(f->d_wtask, f->h_wtask, rb_at + (n_tasks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->wstream));
         ICHK(f, hipMemsetAsync(f->d_wres + n_tasks * sizeof(tredgpu_walk_result), 0, 16, f->wstream));
     }
     // the two streams never wait for each other: each copies the offsets in for itself (both write the same values)
@@ -1540,6 +1603,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         for (int s = 0; s < nstreams; ++s) {
             ICHK(f, hipEventRecord(f->decoded[s], f->stream[s]));
             ICHK(f, hipStreamWaitEvent(f->wstream, f->decoded[s], 0));
+            ICHK(f, hipStreamWaitEvent(f->astream, f->decoded[s], 0));
         }
         const size_t nb = (size_t)n_blocks;
         WalkView v;
@@ -1568,22 +1632,36 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
                 f->big_lds_allowed = true;
             }
             f->walk_table_cap = table_cap;
-            pair_walk_kernel<<<(unsigned)n_tasks, LANES, walk_lds_bytes(table_cap), f->wstream>>>(v, (const tredgpu_walk_task*)f->d_wtask,
-                (const tredgpu_walk_chunk*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task)), (tredgpu_walk_result*)f->d_wres, f->d_wpairs,
+            const tredgpu_walk_task* d_tasks = (const tredgpu_walk_task*)f->d_wtask;
+            const tredgpu_walk_chunk* d_chunks = (const tredgpu_walk_chunk*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task));
+            const int64_t* d_rec_base = (const int64_t*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk));
+            walk_chain_kernel<<<(unsigned)n_tasks, LANES, 0, f->wstream>>>(v, d_tasks, d_chunks, d_rec_base, f->d_wrecs, f->d_wchained);
+            ICHK(f, hipGetLastError());
+            if (total_recs > 0) {
+                walk_parse_kernel<<<(unsigned)((total_recs + 255) / 256), 256, 0, f->wstream>>>(v, (int)n_tasks, d_rec_base, f->d_wrecs, f->d_wchained, f->d_wfields);
+                ICHK(f, hipGetLastError());
+            }
+            pair_walk_kernel<<<(unsigned)n_tasks, LANES, walk_lds_bytes(table_cap), f->wstream>>>(v, d_tasks, d_rec_base, f->d_wrecs, f->d_wfields,
+                f->d_wchained, (tredgpu_walk_result*)f->d_wres, f->d_wpairs,
                 f->d_wrepeats, f->d_gpool, w->cap_global, f->d_tpool, w->cap_target, (unsigned long long*)(f->d_wres + n_tasks * sizeof(tredgpu_walk_result)),
                 table_cap);
             ICHK(f, hipGetLastError());
         }
+        ICHK(f, hipEventRecord(f->w1, f->wstream));
+        f->walk_timed = true;
+        ICHK(f, hipMemcpyAsync(f->h_wres, f->d_wres, n_tasks * sizeof(tredgpu_walk_result) + 16, hipMemcpyDeviceToHost, f->wstream));
+        // the alternative loci's walks on a stream of their own, beside the pair walks: 480 pair-walk wavefronts leave half
+        // of the SIMDs without one, and one after the other the two launches were 4.1 + 1.9 ms of every call
+        // (also wblk / the walk view they read: copied in on wstream -- astream waits for that copy below)
         if (n_alt > 0) {
-            alt_walk_kernel<<<(unsigned)n_alt, LANES, WALK_WINDOW, f->wstream>>>(v, (const tredgpu_walk_task*)f->d_atask,
+            ICHK(f, hipStreamWaitEvent(f->astream, f->w0, 0));
+            alt_walk_kernel<<<(unsigned)n_alt, LANES, WALK_WINDOW, f->astream>>>(v, (const tredgpu_walk_task*)f->d_atask,
                 (const tredgpu_walk_chunk*)(f->d_atask + n_alt * sizeof(tredgpu_walk_task)), (tredgpu_alt_result*)f->d_ares,
                 f->d_ares + n_alt * sizeof(tredgpu_alt_result));
             ICHK(f, hipGetLastError());
+            ICHK(f, hipMemcpyAsync(f->h_ares, f->d_ares, n_alt * sizeof(tredgpu_alt_result) + nb, hipMemcpyDeviceToHost, f->astream));
         }
-        ICHK(f, hipEventRecord(f->w1, f->wstream));
-        f->walk_timed = true;
-        if (n_alt > 0) ICHK(f, hipMemcpyAsync(f->h_ares, f->d_ares, n_alt * sizeof(tredgpu_alt_result) + nb, hipMemcpyDeviceToHost, f->wstream));
-        ICHK(f, hipMemcpyAsync(f->h_wres, f->d_wres, n_tasks * sizeof(tredgpu_walk_result) + 16, hipMemcpyDeviceToHost, f->wstream));
+        ICHK(f, hipEventRecord(f->adone, f->astream));
         ICHK(f, hipEventRecord(f->wdone, f->wstream));
     }
     for (int s = 0; s < nstreams; ++s) {
@@ -1596,7 +1674,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
     for (int32_t k = 0; k < n_blocks; ++k) { status[k] = f->h_status[k]; bad += status[k] != 0; }
     if (crc) for (int32_t k = 0; k < n_blocks; ++k) crc[k] = (uint32_t)f->h_status[f->cap_blocks + k];
     if (w) {
-        if (wait_asleep(f, f->wdone)) return -10;
+        if (wait_asleep(f, f->wdone) || wait_asleep(f, f->adone)) return -10;
         unsigned long long used[2];
         memcpy(used, f->h_wres + n_tasks * sizeof(tredgpu_walk_result), 16);
         memcpy(w->results, f->h_wres, n_tasks * sizeof(tredgpu_walk_result));
@@ -1637,6 +1715,7 @@ int tredgpu_inflater_fetch(tredgpu_inflater* f, int32_t n_blocks, const uint8_t*
     if (!f) return -2;
     if (n_blocks < 0 || (size_t)n_blocks + 1 > f->cap_blocks || (n_blocks > 0 && !need)) return ifail(f, -2, "bad arguments");
     if (n_blocks == 0) return 0;
+    if (!f->h_out) return ifail(f, -2, "this inflater keeps no host copy of the output: tredgpu_inflater_fetch_dense");
     const int64_t* ooff = f->h_off + f->cap_blocks;
     ICHK(f, hipSetDevice(f->device));
     constexpr int64_t GAP = 128 * 1024;           // a copy costs the host ~5 us: less than these bytes cost the bus
@@ -1674,6 +1753,59 @@ int tredgpu_inflater_timing(tredgpu_inflater* f, double* total_ms, double* kerne
         if (hipEventElapsedTime(&ms, f->k0[k], f->k1[k]) == hipSuccess) *kernel_ms += ms;
     }
     return 0;
+}
+
+int tredgpu_inflater_host_out(tredgpu_inflater* f, int enabled) {
+    if (!f) return -2;
+    if ((enabled != 0) != f->host_out) {
+        ICHK(f, hipSetDevice(f->device));
+        for (hipStream_t st : f->stream) ICHK(f, hipStreamSynchronize(st));
+        release(f);                                    // (the next reserve allocates what the new mode needs)
+        f->host_out = enabled != 0;
+    }
+    return 0;
+}
+
+int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const uint8_t* need, uint8_t** host, int64_t* dense_off) {
+    if (!f) return -2;
+    if (n_blocks < 0 || (size_t)n_blocks + 1 > f->cap_blocks || !host || !dense_off || (n_blocks > 0 && !need)) return ifail(f, -2, "bad arguments");
+    const int64_t* ooff = f->h_off + f->cap_blocks;
+    constexpr int64_t GAP = 128 * 1024;           // a copy costs the host ~5 us: less than these bytes cost the bus
+    // the runs: a wanted block, and on to the next wanted one while the blocks in between are fewer bytes than GAP
+    struct Run { int32_t first, last; };
+    std::vector<Run> runs;
+    int64_t total = 0;
+    dense_off[0] = 0;
+    int32_t k = 0;
+    while (k < n_blocks) {
+        if (!need[k]) { dense_off[k + 1] = total; ++k; continue; }
+        int32_t last = k;
+        for (int32_t j = k + 1; j < n_blocks && ooff[j] - ooff[last + 1] <= GAP; ++j)
+            if (need[j]) last = j;
+        for (int32_t j = k; j <= last; ++j) { total += ooff[j + 1] - ooff[j]; dense_off[j + 1] = total; }
+        runs.push_back(Run{k, last});
+        k = last + 1;
+    }
+    ICHK(f, hipSetDevice(f->device));
+    if ((size_t)total + 64 > f->cap_dense) {
+        const size_t c = std::max((size_t)total + 64, f->cap_dense + f->cap_dense / 2);
+        if (f->h_dense) (void)hipHostFree(f->h_dense);
+        f->h_dense = nullptr; f->cap_dense = 0;
+        ICHK(f, hipHostMalloc((void**)&f->h_dense, c, hipHostMallocDefault));
+        f->cap_dense = c;
+    }
+    *host = f->h_dense;
+    int copies = 0;
+    for (const Run& r : runs) {
+        ICHK(f, hipMemcpyAsync(f->h_dense + dense_off[r.first], f->d_out + ooff[r.first], (size_t)(ooff[r.last + 1] - ooff[r.first]),
+                               hipMemcpyDeviceToHost, f->stream[copies & 1]));
+        ++copies;
+    }
+    for (int s = 0; s < 2; ++s) {
+        ICHK(f, hipEventRecord(f->done[s], f->stream[s]));
+        if (wait_asleep(f, f->done[s])) return -10;
+    }
+    return copies;
 }
 
 int tredgpu_inflater_walk_ms(tredgpu_inflater* f, double* walk_ms) {

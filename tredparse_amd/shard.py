@@ -94,19 +94,21 @@ def usable_cpus():
 def driver_plan(usable, n_gpus, gpu_inflate=True):
     """(driver processes per GPU, scan threads per driver) for a host with `usable` CPUs feeding n_gpus GPUs -- the one
     rule behind tred.py's `--drivers auto` and bench.py's end-to-end leg, a function of the two numbers alone.
-    With the BGZF blocks inflated and the pair lengths walked on the GPU a sample costs the host ~3 ms of scan and
-    ~1 ms of its driver's interpreter (the sample's JSON / VCF text is written natively, outside the lock): DRIVERS_PER_GPU
-    drivers per GPU, the CPUs shared among their scan threads.  Host-only, a scan is ~40 ms of a core and a driver keeps
-    about five scan threads fed: one driver per five CPUs."""
+    With the BGZF blocks inflated and the pair lengths walked on the GPU, and a sample's JSON / VCF written natively,
+    a driver's interpreter costs ~1.5 ms per sample and the device's own front-end time (decode + walks, ~0.8 ms per
+    sample) is what bounds the rate: DRIVERS_PER_GPU processes keep the GPU's front end fed (measured on 16 CPUs and one
+    GPU, profiles/r05_e2e_grid.txt: 1 x 14 threads 14.1 k genotypes/s, 2 x 8 32.0 k, 3 x 5 37.9 k, 4 x 4 35.0 k,
+    6 x 3 34.6 k), the CPUs but one shared among their scan threads.  Host-only, a scan is ~40 ms of a core and a
+    driver keeps about five scan threads fed: one driver per five CPUs."""
     g = max(1, n_gpus)
     if not gpu_inflate:
         per_gpu = max(1, usable // (5 * g))
         return per_gpu, max(1, (usable - 1) // (per_gpu * g))
     per_gpu = max(1, min(DRIVERS_PER_GPU, usable // (2 * g)))
-    return per_gpu, max(1, min(8, (usable + per_gpu * g - 1) // (per_gpu * g)))
+    return per_gpu, max(1, min(8, (usable - 1) // (per_gpu * g)))
 
 
-DRIVERS_PER_GPU = 6
+DRIVERS_PER_GPU = 3
 
 
 # ---- which host CPUs a rank should live on -------------------------------------------------------------------

@@ -241,19 +241,20 @@ _INFLATERS = {}
 _INFLATERS_LOCK = threading.Lock()
 
 
-def _borrow_inflaters(device, n):
+def _borrow_inflaters(device, n, host_out=True):
     from ._lib import Inflater
     with _INFLATERS_LOCK:
-        have = _INFLATERS.setdefault(device, [])
+        have = _INFLATERS.setdefault((device, host_out), [])
         out = [have.pop() for _ in range(min(n, len(have)))]
     while len(out) < n:
-        out.append(Inflater(device))
+        out.append(Inflater(device, host_out=host_out))
     return out
 
 
 def _return_inflaters(device, infs):
     with _INFLATERS_LOCK:
-        _INFLATERS.setdefault(device, []).extend(infs)
+        for inf in infs:
+            _INFLATERS.setdefault((device, getattr(inf, "host_out", True)), []).append(inf)
 
 
 def release_inflaters():
@@ -285,7 +286,9 @@ class _InflateFeeder(object):
         # when those were done, and the pool then idled through the next chunk's decode
         self.prep = ThreadPoolExecutor(max_workers=2)
         self.gpu = ThreadPoolExecutor(max_workers=1)       # the decode calls, one after the other, in chunk order
-        self.inflaters = _borrow_inflaters(device, self.SLOTS)
+        # (with the walks on the device only a fifth of the blocks come back: those inflaters keep no pinned copy of the whole
+        #  output -- 45 MB per sample of a chunk -- and hand the wanted blocks over densely packed)
+        self.inflaters = _borrow_inflaters(device, self.SLOTS, host_out=not walk)
         self.busy = [[] for _ in range(self.SLOTS)]
         self.decoding = [None] * self.SLOTS            # the slot's last decode job (it sets busy[slot] when it hands the scans out)
         self.q = queue.Queue(maxsize=2)
@@ -367,11 +370,12 @@ class _InflateFeeder(object):
             if self.stop.is_set():
                 return
             status = crc = walked = None
+            out_addr, out_off = inf.out_addr, job["ooff"]
             if job["ooff"] is not None:
                 t0 = time.perf_counter()
                 try:
                     if job.get("walk") is not None:
-                        status, crc, walked = self._run_walk(inf, job)
+                        status, crc, walked, out_addr, out_off = self._run_walk(inf, job)
                     else:
                         status, crc = inf.run(job["n_all"], crc=True)
                         timing_add(inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
@@ -381,7 +385,6 @@ class _InflateFeeder(object):
                 timing_add(inflate_gpu=time.perf_counter() - t0)
             if self.stop.is_set():
                 return
-            ooff = job["ooff"]
             for a, p in zip(chunk, plans):
                 if p is None:
                     futs.append(self.ex.submit(collect_sample, a))
@@ -394,7 +397,7 @@ class _InflateFeeder(object):
                         res, gp, tp, ares = walked
                         pe = (res[p["task_first"]:p["task_first"] + len(p["tasks"])], gp, tp)
                         alt = ares[p["alt_first"]:p["alt_first"] + len(p["alt_tasks"])]
-                    futs.append(self.ex.submit(_scan_planned, a, p, inf.out_addr, ooff[k:k + p["n"] + 1], status[k:k + p["n"]],
+                    futs.append(self.ex.submit(_scan_planned, a, p, out_addr, out_off[k:k + p["n"] + 1], status[k:k + p["n"]],
                                                crc[k:k + p["n"]], pe, alt))
                 handed += 1                                # (that scan closes its own handle)
             self.busy[job["slot"]] = futs
@@ -410,7 +413,7 @@ class _InflateFeeder(object):
     def _run_walk(inf, job):
         """Decode, walk the pair-length regions on the device, fetch the blocks the scans still read.  Returns the
         statuses as the scans should see them (a block that was not fetched counts as not delivered), the checksums and
-        the walk's (results, global pool, target pool)."""
+        the walk's (results, global pool, target pool), and where the fetched blocks lie (address, offsets per block)."""
         import numpy as np
         from .bam_parser import walk_need
         w = job["walk"]
@@ -426,12 +429,16 @@ class _InflateFeeder(object):
             a = p["first"]
             need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])],
                                            alt_need[a:a + p["n"]])
-        inf.fetch(need)
+        if getattr(inf, "host_out", True):
+            inf.fetch(need)
+            out_addr, out_off = inf.out_addr, job["ooff"]
+        else:
+            out_addr, out_off = inf.fetch_dense(need)
         walkable = w["alt_tasks"]["n_chunks"] >= 0
         timing_add(walk_regions=len(res), walk_declined=int((res["status"] != 0).sum()), walk_blocks_fetched=int(need.sum()),
                    walk_alt_regions=int(walkable.sum()), walk_alt_declined=int((ares["status"][walkable] != 0).sum()),
                    inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
-        return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp, ares)
+        return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp, ares), out_addr, out_off
 
     def _put(self, item):
         import queue
