@@ -242,6 +242,21 @@ int tredgpu_genotype_batch(tredgpu_ctx* ctx, int mem, const uint32_t* packed,
                            int32_t* rept_cnt, tredgpu_call* calls);
 
 /*
+ * The same for HOST memory with everything the product's writers print -- per-read tags, the calls, both marginals and the
+ * sparse joint distribution (as tredgpu_likelihood_grid_joint returns them; a unit whose joint_n exceeds its room needs a
+ * second call with more) -- in ONE call with ONE wait: tags, histograms and calls stay on the device between the stages.
+ * rept_cnt (n_units x hist_stride, may be NULL) is the only histogram a caller still needs (the RR count).
+ */
+int tredgpu_genotype_batch_joint(tredgpu_ctx* ctx, const uint32_t* packed, const int64_t* read_off, const int32_t* read_len,
+                                 int64_t n_reads, const int32_t* unit_read_off, const int32_t* unit_ladder,
+                                 const tredgpu_unit_params* units, int32_t n_units, const tredgpu_sw_params* params,
+                                 const int32_t* read_pair_id, const int32_t* global_lens, int64_t n_global_total,
+                                 const int32_t* target_lens, int64_t n_target_total, uint8_t* out_tag, int16_t* out_h,
+                                 int16_t* out_score, int32_t hist_stride, int32_t* rept_cnt, tredgpu_call* calls, double* marg,
+                                 int32_t marg_stride, const int64_t* joint_off, double* joint, int32_t* joint_n,
+                                 double* joint_total);
+
+/*
  * KDE of the paired-end model alone (replaces gaussian_kde(global_lens).evaluate(arange(1000))
  * normalised to sum 1, models.py:428-435): pdf_out[n_units][1000]; units with fewer than 2
  * lengths or zero variance get status -2 in status_out.

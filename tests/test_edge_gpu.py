@@ -235,3 +235,32 @@ def test_300bp_reads_take_the_20_rows_per_lane_instantiation(ctx):
     # beyond 320 bp: refused by the call (host memory: the lengths are looked at), never truncated
     with pytest.raises(_lib.TredGpuError, match="TREDGPU_MAX_READ_LEN"):
         _classify(ctx, [lad], [reads[0], (reads[0] * 2)[:330]], [0, 2], [0])
+
+
+@pytest.mark.parametrize("repeatpairs", [True, False])
+def test_fused_host_call_equals_the_three_separate_calls(tmp_path, repeatpairs):
+    """tredgpu_genotype_batch_joint (SW -> tally -> grid with marginals and sparse joint composed on the device, one wait:
+    what engine.genotype_packed calls for every product batch) against tredgpu_sw_classify + tredgpu_tally +
+    tredgpu_likelihood_grid_joint one after the other: the same tags, calls, marginals and joint entries bit for bit."""
+    from tredparse_amd import bam_parser, synth_bam
+    from tredparse_amd.engine import Engine, PackedUnits
+    from tredparse_amd.meta import TREDsRepo
+    made = synth_bam.make_bams(str(tmp_path), 3, seed=41, workers=1)
+    repo = TREDsRepo("hg38", sites=str(tmp_path / "no_sites"))
+    names = [l["name"] for l in synth_bam.bench_loci()]
+    scans = [bam_parser.scan_sample(path, repo, names) for _, path, _ in made]
+    b = PackedUnits.from_scans([(s, list(range(len(names)))) for s in scans], repeatpairs=repeatpairs)
+    eng = Engine(0)
+    one, three = eng.genotype_packed(b), eng._genotype_packed_stepwise(b)
+    assert b.n_units == 90 and b.n_reads > 5000
+    for key in ("tag", "h", "score", "rept", "marg"):
+        assert np.array_equal(getattr(one, key), getattr(three, key)), key
+    assert one.calls.tobytes() == three.calls.tobytes() and (one.calls["status"] == 0).sum() > 60
+    a1, b1, v1, lo1, n1 = one.joint_units
+    a3, b3, v3, lo3, n3 = three.joint_units
+    assert np.array_equal(n1, n3) and n1.sum() > 500
+    for u in range(b.n_units):         # (the entries of a unit arrive in any order: compare them sorted)
+        k1 = sorted(zip(a1[lo1[u]:lo1[u] + n1[u]].tolist(), b1[lo1[u]:lo1[u] + n1[u]].tolist(), v1[lo1[u]:lo1[u] + n1[u]].tolist()))
+        k3 = sorted(zip(a3[lo3[u]:lo3[u] + n3[u]].tolist(), b3[lo3[u]:lo3[u] + n3[u]].tolist(), v3[lo3[u]:lo3[u] + n3[u]].tolist()))
+        assert k1 == k3, u
+    eng.close()

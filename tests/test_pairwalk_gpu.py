@@ -471,11 +471,12 @@ def test_dense_fetch_hands_over_the_same_blocks(synthetic):
     addr, off = inf.fetch_dense(need)
     size = np.diff(off)
     want = np.diff(ooff[:n_all + 1])
-    assert ((size == want) | (size == 0)).all() and (size[need != 0] == want[need != 0]).all()
-    assert need.sum() < size.astype(bool).sum() + 1 and off[-1] < 0.6 * ooff[n_all]      # (gaps are few; most bytes stay behind)
+    # (a block that was not copied is empty, or as long as the padding that puts the run behind it on a 16-byte boundary)
+    assert ((size == want) | (size < 16)).all() and (size[need != 0] == want[need != 0]).all()
+    assert off[-1] < 0.6 * ooff[n_all]                                      # (most bytes stay behind)
     dense = np.ctypeslib.as_array(ctypes.cast(addr, ctypes.POINTER(ctypes.c_uint8)), shape=(int(off[-1]),))
     for k, data in enumerate(_zlib_blocks(handles, plans)):
-        if size[k]:
+        if size[k] == want[k] and want[k]:
             assert dense[off[k]:off[k + 1]].tobytes() == data, k
     t0 = a0 = 0
     for f, (path, repo, names), sites, regions, rl, first, nt, na, coff in zip(handles, cases, sites_of, regions_of, readlens, firsts, n_tasks,

@@ -7,16 +7,16 @@ usage: python tools/prof_e2e.py [synthetic BAMs = 96] [scan threads = 3] [pair w
 """
 import cProfile, pstats, os, sys, tempfile, time, io, glob, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-torch.cuda.init()
 from tredparse_amd import shard, synth_bam, tred
-from tredparse_amd.engine import Engine
 from tredparse_amd.meta import TREDsRepo
 root = tempfile.mkdtemp(prefix="prof_e2e_")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 walk = (sys.argv[3] if len(sys.argv) > 3 else "1") == "1"
-made = synth_bam.make_bams(root, n, seed=7, workers=shard.usable_cpus())
+made = synth_bam.make_bams(root, n, seed=7, workers=shard.usable_cpus())   # (process pool FIRST: a process that holds a HIP context must not fork)
+import torch
+torch.cuda.init()
+from tredparse_amd.engine import Engine
 bams = sorted(glob.glob(os.path.join(root, "*.bam")))
 repo = TREDsRepo("hg38", sites=os.path.join(root, "no_sites"))
 names = [l["name"] for l in synth_bam.bench_loci()]
@@ -38,7 +38,7 @@ wprof = cProfile.Profile()
 pr = cProfile.Profile()
 t0, c0, p0 = time.perf_counter(), time.thread_time(), time.process_time()
 pr.enable()
-tred.run_many(tasks, engine, batch=16, sink=sink, threads=threads, lazy_details=True, background_sink=True, inflate_device=0, gpu_walk=walk)
+tred.run_many(tasks, engine, batch=16, sink=sink, threads=threads, lazy_details=True, background_sink=2, inflate_device=0, gpu_walk=walk)
 pr.disable()
 dt = time.perf_counter() - t0
 print("gpu_walk", walk, "seconds", dt, "samples", len(tasks), "ms/sample wall", 1e3 * dt / len(tasks), "driver thread cpu ms/sample", 1e3 * (time.thread_time() - c0) / len(tasks),

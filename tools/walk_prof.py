@@ -1,15 +1,11 @@
 #!/usr/bin/env python3
-"""Where the pair walk's cycles go (GPU box): runs tredgpu_inflate_walk of a -DWALK_PROF build of the library on m
-synthetic 30x samples and prints the mean cycles per region of each phase of the record loop.
+"""The front-end call alone (GPU box): tredgpu_inflate_walk -- decode, pair walks (chain / parse / resolve), alternative-locus
+walks -- on m synthetic 30x samples, three times; prints the regions walked and the device time of the pair walk's
+launches.  `rocprofv3 --kernel-trace --stats -- python3 tools/walk_prof.py 16 tredparse_amd/libtredgpu.so <dir>` is how the
+kernels' rocprofv3 summaries under profiles/ are taken (tools/profile_all.sh; the BAMs made beforehand with
+`python tools/walk_prof.py make <dir>`: a process under the profiler must not fork the workers that write them).
 
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DWALK_PROF -shared -o tools/_ab/libtredgpu_walkprof.so \\
-        tredparse_amd/csrc/{capi,sw_ladder,grid,inflate}.hip
-  python tools/walk_prof.py [samples = 16] [library = tools/_ab/libtredgpu_walkprof.so] [directory of BAMs made before]
-
-With the production library as second argument the phase columns are meaningless but the launch is the production one:
-`rocprofv3 --kernel-trace --stats -- python3 tools/walk_prof.py 56 tredparse_amd/libtredgpu.so <dir>` is how the kernel's
-rocprofv3 summary under profiles/ is taken (the BAMs made beforehand with `python tools/walk_prof.py make <dir>`: a
-process under the profiler must not fork the workers that write them).
+  python tools/walk_prof.py [samples = 16] [library = tredparse_amd/libtredgpu.so] [directory of BAMs made before]
 """
 import glob
 import json
@@ -30,7 +26,8 @@ def main():
         return
     from tredparse_amd import _lib
     m = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    _lib.LIB_PATH = os.path.abspath(sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(__file__), "_ab", "libtredgpu_walkprof.so"))
+    if len(sys.argv) > 2:
+        _lib.LIB_PATH = os.path.abspath(sys.argv[2])
     from tredparse_amd import bam_parser, synth_bam
     from tredparse_amd.meta import TREDsRepo
     if len(sys.argv) > 3:
@@ -68,12 +65,10 @@ def main():
     for _ in range(3):
         status, crc, res, gp, tp, ares, _ = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, pairs_per_task=8192, alt_tasks=atasks, alt_chunks=achunks)
     ok = res["status"] == 0
-    phases = {"chain (length words, block bookkeeping, window refills)": res["global_first"][ok], "parse (a lane per record)": res["target_first"][ok],
-              "resolve (ballots, pair table, stores)": res["win_vbeg"][ok].astype(np.int64), "finish (name checks, lists)": res["win_vend"][ok].astype(np.int64)}
-    total = sum(float(v.mean()) for v in phases.values())
-    print(json.dumps({"library": _lib.version(), "samples": m, "regions": int(ok.sum()), "alt_regions": int((atasks["n_chunks"] >= 0).sum()), "alt_records": int(ares["n"].sum()), "records_per_region": float(res["n_window"][ok].mean()),
-                      "walk_kernel_ms": inf.walk_ms(), "mean_cycles_per_region": {k: round(float(v.mean())) for k, v in phases.items()},
-                      "total_cycles": round(total), "note": "shader clock cycles (s_memtime), ~2.2 GHz"}))
+    print(json.dumps({"library": _lib.version(), "samples": m, "regions": int(ok.sum()), "regions_declined": int((~ok).sum()),
+                      "alt_regions": int((atasks["n_chunks"] >= 0).sum()), "alt_records": int(ares["n"].sum()),
+                      "records_per_region_window": float(res["n_window"][ok].mean()), "pairs": int(len(gp) + len(tp)),
+                      "pair_walk_ms (chain + parse + resolve launches)": inf.walk_ms()}))
 
 
 if __name__ == "__main__":

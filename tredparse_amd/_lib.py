@@ -55,7 +55,7 @@ assert CALL_DTYPE.itemsize == C.sizeof(Call) == 56
 EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_sync", "tredgpu_get_stream",
            "tredgpu_version", "tredgpu_set_ladders", "tredgpu_set_model", "tredgpu_pack_reads",
            "tredgpu_sw_classify", "tredgpu_tally", "tredgpu_likelihood_grid", "tredgpu_likelihood_grid_joint",
-           "tredgpu_genotype_batch",
+           "tredgpu_genotype_batch", "tredgpu_genotype_batch_joint",
            "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing", "tredgpu_get_sw_counters",
            "tredgpu_inflater_create", "tredgpu_inflater_destroy", "tredgpu_inflater_last_error",
            "tredgpu_inflater_reserve", "tredgpu_inflate_blocks", "tredgpu_inflate_blocks_crc", "tredgpu_inflater_timing",
@@ -99,6 +99,8 @@ def load():
     lib.tredgpu_genotype_batch.argtypes = [vp, C.c_int, vp, vp, vp, i64, vp, vp, vp, i32,
                                            C.POINTER(SwParams), vp, vp, i64, vp, i64, vp, vp, vp, i32,
                                            vp, vp, vp, vp]
+    lib.tredgpu_genotype_batch_joint.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, C.POINTER(SwParams), vp, vp, i64, vp, i64,
+                                                 vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.tredgpu_pe_kde.argtypes = [vp, C.c_int, vp, i32, vp, i64, vp, vp]
     lib.tredgpu_reset_timing.argtypes = [vp]
     lib.tredgpu_get_timing.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
@@ -282,6 +284,19 @@ class Context:
                                                   hist_stride, _ptr(full_cnt), _ptr(pref_cnt), _ptr(rept_cnt),
                                                   _ptr(calls)), "tredgpu_genotype_batch")
 
+    def genotype_batch_joint(self, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, units, n_units, params,
+                             read_pair_id, global_lens, n_global_total, target_lens, n_target_total, out_tag, out_h, out_score,
+                             hist_stride, rept_cnt, calls, marg, marg_stride, joint_off, joint, joint_n, joint_total):
+        """tredgpu_genotype_batch_joint: SW + tagging -> histograms -> grid with marginals and sparse joint, host arrays,
+        one wait."""
+        self._chk(self.lib.tredgpu_genotype_batch_joint(self.h, _ptr(packed), _ptr(read_off), _ptr(read_len), n_reads,
+                                                        _ptr(unit_read_off), _ptr(unit_ladder), _ptr(units), n_units,
+                                                        C.byref(params), _ptr(read_pair_id), _ptr(global_lens), n_global_total,
+                                                        _ptr(target_lens), n_target_total, _ptr(out_tag), _ptr(out_h),
+                                                        _ptr(out_score), hist_stride, _ptr(rept_cnt), _ptr(calls), _ptr(marg),
+                                                        marg_stride, _ptr(joint_off), _ptr(joint), _ptr(joint_n),
+                                                        _ptr(joint_total)), "tredgpu_genotype_batch_joint")
+
     def reset_timing(self):
         self._chk(self.lib.tredgpu_reset_timing(self.h), "tredgpu_reset_timing")
 
@@ -335,14 +350,15 @@ MIN_PAIR_BYTES = 2 * (36 + 2 + 4 + 18)    # two BAM records of a pair at their s
 
 
 def walk_pool_pairs(tasks, out_off):
-    """Upper bound of the pair lengths the tasks of one walk call can produce: every pair needs two records among the
-    inflated bytes of its task's blocks (out_off: the call's block offsets), and a record of a read of >= 36 bases cannot
-    be smaller than MIN_PAIR_BYTES / 2.  Real 30-40x WGS regions sit near a quarter of this bound."""
+    """Upper bound of the pair lengths one walk call can produce -- the room its pools are given, shared by all tasks:
+    every pair needs two records among the call's inflated bytes (out_off: the call's block offsets; a record of a read
+    of >= 36 bases cannot be smaller than MIN_PAIR_BYTES / 2), and a byte belongs to the regions of at most two loci
+    (FXS / FXTAS and SBMA / AR share their coordinates; loci further apart than +-10 kb share nothing).  30x samples
+    sit near a tenth of this bound; a locus list with three or more loci on one spot could exceed it -- those regions
+    then come back with status 6 and the host walks them."""
     if len(tasks) == 0:
         return 0
-    off = np.asarray(out_off, np.int64)
-    nbytes = off[np.clip(tasks["block_end"], 0, len(off) - 1)] - off[np.clip(tasks["block_first"], 0, len(off) - 1)]
-    return int(np.maximum(nbytes, 0).sum() // MIN_PAIR_BYTES) + 64 * len(tasks)
+    return 2 * int(np.asarray(out_off, np.int64)[-1]) // MIN_PAIR_BYTES + 64 * len(tasks)
 
 
 class Inflater:

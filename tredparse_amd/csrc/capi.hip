@@ -40,7 +40,7 @@ struct tredgpu_ctx {
     Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class, ws_gdesc, ws_gtile, ws_gctr, ws_ucnt, ws_bins, ws_kde;
     int* h_pin = nullptr;  // pinned word for small read-backs
     size_t grid_pool_bytes = GRID_POOL_BYTES;   // TREDGPU_GRID_POOL_MB overrides (tuning / tests of the multi-pass path)
-    Buf st[24];  // staging for HOST-memory calls
+    Buf st[32];  // staging for HOST-memory calls
     // pinned arena of the HOST-memory calls: copies from / to the caller's pageable arrays go through it, so that they are
     // truly asynchronous (a hipMemcpyAsync on pageable memory is staged and waited for by the runtime, one by one -- with
     // several driver processes on the device each of those waits queues behind the others' work: 25 per batch)
@@ -880,6 +880,98 @@ int tredgpu_pe_kde(tredgpu_ctx* c, int mem, const tredgpu_unit_params* units, in
     HIPCHK(c, launch_pe_kde(a, c->stream));
     if ((rc = copy_back(c, pdf_out, (const double*)d_pdf, (size_t)n_units * TREDGPU_SPAN))) return rc;
     if ((rc = copy_back(c, status_out, (const int32_t*)d_st, (size_t)n_units))) return rc;
+    HIPCHK(c, stream_sync(c));
+    return 0;
+}
+
+// The whole path for a batch in HOST memory with everything the product's writers print, in ONE call with ONE wait:
+// tredgpu_sw_classify -> tredgpu_tally -> tredgpu_likelihood_grid_joint composed on the device -- tags, histograms and
+// calls never leave it between the stages (the three separate calls cost a driver three waits and two copies of the
+// per-read arrays in each direction: 20 ms per batch of 16 samples, most of it waiting among other processes' work).
+int tredgpu_genotype_batch_joint(tredgpu_ctx* c, const uint32_t* packed, const int64_t* read_off, const int32_t* read_len,
+                                 int64_t n_reads, const int32_t* unit_read_off, const int32_t* unit_ladder,
+                                 const tredgpu_unit_params* units, int32_t n_units, const tredgpu_sw_params* params,
+                                 const int32_t* read_pair_id, const int32_t* global_lens, int64_t n_global_total,
+                                 const int32_t* target_lens, int64_t n_target_total, uint8_t* out_tag, int16_t* out_h,
+                                 int16_t* out_score, int32_t hist_stride, int32_t* rept_cnt, tredgpu_call* calls, double* marg,
+                                 int32_t marg_stride, const int64_t* joint_off, double* joint, int32_t* joint_n,
+                                 double* joint_total) {
+    if (!c) return -2;
+    int rc;
+    if ((rc = check_sw_params(c, params))) return rc;
+    if ((rc = check_grid_common(c, units, n_units))) return rc;
+    if (c->h_ladders.empty()) return fail(c, -4, "no ladders registered (tredgpu_set_ladders)");
+    if (hist_stride <= c->max_ladder_units) return fail(c, -2, "hist_stride %d must exceed the largest max_units %d", hist_stride, c->max_ladder_units);
+    if (n_reads < 0 || n_units <= 0) return fail(c, -2, "bad sizes");
+    if (!unit_read_off || !unit_ladder || !calls || !marg || !joint_off || !joint || !joint_n || !joint_total || marg_stride <= 0)
+        return fail(c, -2, "NULL array argument");
+    if (n_reads > 0 && (!packed || !read_off || !read_len || !out_tag || !out_h || !out_score)) return fail(c, -2, "NULL array argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    // validate the host metadata (as the separate host-memory calls do)
+    if (unit_read_off[0] != 0 || unit_read_off[n_units] != n_reads) return fail(c, -2, "unit_read_off must span [0,n_reads]");
+    int limits[2] = {0, 0};
+    for (int g = 0; g < n_units; ++g) {
+        if (unit_read_off[g + 1] < unit_read_off[g]) return fail(c, -2, "unit_read_off not monotone at %d", g);
+        if (unit_ladder[g] < 0 || unit_ladder[g] >= (int)c->h_ladders.size()) return fail(c, -2, "unit %d: ladder %d not registered", g, unit_ladder[g]);
+        const tredgpu_unit_params& u = units[g];
+        limits[0] = std::max(limits[0], u.maxinsert);
+        limits[1] = std::max(limits[1], u.n_target);
+        if (u.n_global < 0 || u.n_target < 0 || u.pe_off < 0 || u.tl_off < 0 || (int64_t)u.pe_off + u.n_global > n_global_total ||
+            (int64_t)u.tl_off + u.n_target > n_target_total)
+            return fail(c, -2, "unit %d: paired-end slices out of range", g);
+        if (marg_stride <= std::max(u.maxinsert, hist_stride)) return fail(c, -2, "marg_stride must exceed max(maxinsert, hist_stride)");
+    }
+    int seen = 0;
+    for (int64_t r = 0; r < n_reads; ++r) seen = std::max(seen, read_len[r]);
+    if (seen > TREDGPU_MAX_READ_LEN) return fail(c, -5, "read of %d bp exceeds TREDGPU_MAX_READ_LEN=%d", seen, TREDGPU_MAX_READ_LEN);
+    const int max_len = params->max_read_len > 0 ? params->max_read_len : std::max(seen, 1);
+    const uint32_t* d_packed = nullptr; const int64_t* d_off = nullptr; const int32_t* d_len = nullptr;
+    const int32_t *d_uoff, *d_ulad, *d_pid = nullptr, *d_gl = nullptr, *d_tl = nullptr;
+    const tredgpu_unit_params* d_units; const int64_t* d_joff;
+    uint8_t* d_tag; int16_t *d_h, *d_score; int32_t *d_f, *d_p, *d_r; tredgpu_call* d_calls; double *d_marg, *d_joint, *d_jt; int32_t* d_jn;
+    const size_t words = n_reads > 0 ? (size_t)read_off[n_reads] : 0, hn = (size_t)n_units * hist_stride;
+    const size_t marg_n = (size_t)n_units * 2 * marg_stride, joint_len = (size_t)joint_off[n_units] * 3;
+    if ((rc = stage_in(c, c->st[0], packed, words, &d_packed))) return rc;
+    if ((rc = stage_in(c, c->st[1], read_off, n_reads > 0 ? (size_t)n_reads + 1 : 0, &d_off))) return rc;
+    if ((rc = stage_in(c, c->st[2], read_len, (size_t)n_reads, &d_len))) return rc;
+    if ((rc = stage_in(c, c->st[3], unit_read_off, (size_t)n_units + 1, &d_uoff))) return rc;
+    if ((rc = stage_in(c, c->st[4], unit_ladder, (size_t)n_units, &d_ulad))) return rc;
+    if ((rc = stage_out(c, c->st[5], (size_t)n_reads, &d_tag))) return rc;
+    if ((rc = stage_out(c, c->st[6], (size_t)n_reads, &d_h))) return rc;
+    if ((rc = stage_out(c, c->st[7], (size_t)n_reads, &d_score))) return rc;
+    if (read_pair_id && (rc = stage_in(c, c->st[8], read_pair_id, (size_t)n_reads, &d_pid))) return rc;
+    if (read_pair_id && (rc = ensure(c, c->ws_drop, (size_t)n_reads))) return rc;
+    if ((rc = stage_out(c, c->st[14], hn, &d_f))) return rc;
+    if ((rc = stage_out(c, c->st[15], hn, &d_p))) return rc;
+    if ((rc = stage_out(c, c->st[16], hn, &d_r))) return rc;
+    if ((rc = stage_in(c, c->st[17], units, (size_t)n_units, &d_units))) return rc;
+    if ((rc = stage_in(c, c->st[18], global_lens, (size_t)n_global_total, &d_gl))) return rc;
+    if ((rc = stage_in(c, c->st[19], target_lens, (size_t)n_target_total, &d_tl))) return rc;
+    if ((rc = stage_out(c, c->st[20], (size_t)n_units, &d_calls))) return rc;
+    if ((rc = stage_out(c, c->st[21], marg_n, &d_marg))) return rc;
+    if ((rc = stage_in(c, c->st[22], joint_off, (size_t)n_units + 1, &d_joff))) return rc;
+    if ((rc = stage_out(c, c->st[23], joint_len, &d_joint))) return rc;
+    if ((rc = stage_out(c, c->st[24], (size_t)n_units, &d_jn))) return rc;
+    if ((rc = stage_out(c, c->st[25], (size_t)n_units, &d_jt))) return rc;
+    if (n_reads > 0 && (rc = run_sw_device(c, d_packed, d_off, d_len, n_reads, d_uoff, d_ulad, n_units, params, max_len, d_tag, d_h,
+                                           d_score, nullptr, 0)))
+        return rc;
+    {
+        ScopedTimer tm(c, TREDGPU_KERNEL_TALLY);
+        HIPCHK(c, launch_tally(d_tag, d_h, n_reads, d_uoff, n_units, d_pid, hist_stride, d_f, d_p, d_r, (uint8_t*)c->ws_drop.p, c->stream));
+    }
+    if ((rc = run_grid_device(c, d_units, n_units, hist_stride, d_f, d_p, d_r, d_gl, d_tl, d_calls, nullptr, nullptr, d_marg,
+                              marg_stride, limits, d_joff, d_joint, d_jn, d_jt)))
+        return rc;
+    if ((rc = copy_back(c, out_tag, (const uint8_t*)d_tag, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, out_h, (const int16_t*)d_h, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, out_score, (const int16_t*)d_score, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, rept_cnt, (const int32_t*)d_r, rept_cnt ? hn : 0))) return rc;
+    if ((rc = copy_back(c, joint, (const double*)d_joint, joint_len))) return rc;
+    if ((rc = copy_back(c, joint_n, (const int32_t*)d_jn, (size_t)n_units))) return rc;
+    if ((rc = copy_back(c, joint_total, (const double*)d_jt, (size_t)n_units))) return rc;
+    if ((rc = copy_back(c, calls, (const tredgpu_call*)d_calls, (size_t)n_units))) return rc;
+    if ((rc = copy_back(c, marg, (const double*)d_marg, marg_n))) return rc;
     HIPCHK(c, stream_sync(c));
     return 0;
 }

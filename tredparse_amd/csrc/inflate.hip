@@ -32,6 +32,9 @@
 // returns bytes plus a status per block; gzip framing and ISIZE stay with the host library (libtredbam).
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <ctime>
+#include <cstdlib>
+#include <cstdio>
 #include <stdint.h>
 #include <unistd.h>
 
@@ -873,6 +876,45 @@ __global__ void __launch_bounds__(LANES) walk_chain_kernel(WalkView v, const tre
             int64_t my_a0 = 0;
             uint64_t my_at = 0, my_after = 0;
             while (nb < CHAIN_BATCH) {
+                // ---- the fast path: records whose length word, contig and position lie in this block AND in the window, and
+                //      that end inside the block -- 32-bit arithmetic on (offset in the block, offset in the window) only, one
+                //      LDS access per record (~40 instructions; a lone wavefront issues one every ~5 cycles, and the general
+                //      step below, 64-bit throughout, took ~250 of them: 2.7 ms per region of 4 000 records) ----
+                {
+                    const int bsz = (int)cur.size;
+                    int up = (int)cur.upos;
+                    int wo = (int)walk_uniform((uint32_t)((cur.first + cur.upos) - rd.base));     // (garbage when far outside: checked below)
+                    const bool near = cur.first + cur.upos >= rd.base && cur.first + cur.upos < rd.base + WALK_WINDOW;
+                    // where in this block tell() reaches the chunk's end (tell() = here | upos inside a block)
+                    const uint64_t endv = ch.end_voffset;
+                    const int up_end = (endv >> 16) == (uint64_t)cur.coff ? (int)(endv & 0xFFFFu) : (endv > cur.here ? 0x7FFFFFFF : 0);
+                    bool stop = false;
+                    if (near) {
+                        while (nb < CHAIN_BATCH && up + 12 <= bsz && up < up_end && wo + 16 <= WALK_WINDOW) {
+                            const lds_u32* p = (const lds_u32*)(S.window + (wo & ~3));
+                            const uint32_t x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+                            const uint32_t by = (uint32_t)(wo & 3);
+                            const int32_t size = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x1, x0, by));
+                            const int32_t rtid = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x2, x1, by));
+                            const int32_t rpos = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x3, x2, by));
+                            const int nxt = up + 4 + size;
+                            if (size < 32 || nxt > bsz) break;                    // (the general step decides: a bad record, or one that crosses into the next block)
+                            if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { stop = true; break; }
+                            if (lane == nb) {
+                                my_a0 = cur.first + up;
+                                my_at = cur.here | (uint64_t)(uint32_t)up;
+                                my_after = nxt >= bsz ? cur.next : cur.here | (uint64_t)(uint32_t)nxt;
+                            }
+                            up = nxt;
+                            wo += 4 + size;
+                            ++nb;
+                        }
+                        cur.upos = up;
+                    }
+                    if (stop) { chunk_done = true; break; }
+                    if (nb >= CHAIN_BATCH) break;
+                }
+                // ---- the general step: one record, wherever it lies ----
                 const uint64_t at = cur.tell();
                 if (at >= ch.end_voffset) { chunk_done = true; break; }
                 int64_t a0, r;
@@ -966,11 +1008,15 @@ __device__ int walk_region_resolve(const tredgpu_walk_task& T, WalkLds& S, const
                                    WalkPair* pairs, WalkRepeat* repeats, int* n_pairs, int* n_repeats, tredgpu_walk_result& R, int lane) {
     int np = 0, nrep = 0, nwin = 0;
     uint64_t vbeg = 0, vend = 0;
+    // (the batch after this one is loaded while this one goes through the table: a lone wavefront hides nothing by itself)
+    WalkFields Fn = {};
+    WalkRec men = {};
+    if (lane < n) { Fn = fields[lane]; men = recs[lane]; }
     for (int i0 = 0; i0 < n; i0 += LANES) {
         const bool mine = i0 + lane < n;
-        WalkFields F = {};
-        WalkRec me = {};
-        if (mine) { F = fields[i0 + lane]; me = recs[i0 + lane]; }
+        const WalkFields F = Fn;
+        const WalkRec me = men;
+        if (i0 + LANES + lane < n) { Fn = fields[i0 + LANES + lane]; men = recs[i0 + LANES + lane]; }
         const int32_t rtid = F.rtid, rpos = F.rpos, rend = F.rend;
         const uint32_t flag = F.flag, h = F.h;
         const bool off_region = mine && (rtid != T.tid || rpos >= T.end);       // (rtid < T.tid: the chain ends at the others)
@@ -1255,6 +1301,25 @@ __global__ void __launch_bounds__(LANES) alt_walk_kernel(WalkView v, const tredg
     if (lane == 0) results[t] = out;
 }
 
+// ---- the fetch as a kernel ---------------------------------------------------------------------------------------------
+// The blocks the host wants, copied from the decoder's output straight into pinned host memory by the GPU's own stores (the
+// pinned buffer is mapped into the device's address space): ONE launch and one wait per call where the copy engines
+// were handed ~660 copies of ~160 KB (two thirds of a call's time went there once three driver processes shared them).
+// piece p: `len` bytes from out + src to host + dst, dst a multiple of 16; 256 lanes, 16 bytes each per step.
+struct FetchPiece { int64_t src, dst; int32_t len, pad; };
+__global__ void __launch_bounds__(256) fetch_gather_kernel(const uint8_t* __restrict__ out, uint8_t* __restrict__ host, const FetchPiece* pieces) {
+    const FetchPiece P = pieces[blockIdx.x];
+    const uint8_t* s = out + P.src;
+    uint8_t* d = host + P.dst;
+    const int whole = P.len & ~15;
+    for (int o = threadIdx.x * 16; o < whole; o += 256 * 16) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4 __attribute__((aligned(1))) u32x4_any;
+        *reinterpret_cast<u32x4*>(d + o) = *reinterpret_cast<const u32x4_any*>(s + o);
+    }
+    if ((int)threadIdx.x < P.len - whole) d[whole + threadIdx.x] = s[whole + threadIdx.x];
+}
+
 }  // namespace
 
 // ---- C ABI (include/tredgpu.h) ------------------------------------------------------------------------------------
@@ -1273,6 +1338,7 @@ struct tredgpu_inflater {
     bool host_out = true;                             // false (tredgpu_inflater_host_out): no pinned room for the whole output --
                                                       // the blocks the host wants come through tredgpu_inflater_fetch_dense
     uint8_t* h_dense = nullptr; size_t cap_dense = 0; // pinned: the fetched blocks, one after the other
+    uint8_t *h_pieces = nullptr, *d_pieces = nullptr; size_t cap_pieces = 0;   // the fetch kernel's copy table (FetchPiece)
     int64_t *h_off = nullptr;                         // pinned: comp_off[n+1] then out_off[n+1]
     int32_t* h_status = nullptr;                      // pinned: status[n] then crc[n]
     size_t cap_comp = 0, cap_out = 0, cap_blocks = 0;
@@ -1302,6 +1368,16 @@ struct tredgpu_inflater {
 namespace {
 thread_local std::string g_inflate_error;
 
+// TREDGPU_TRACE=1: host-side timestamps of a call's phases on stderr (milliseconds since the call began)
+struct CallTrace {
+    bool on; const char* what; double t0; std::string line;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    explicit CallTrace(const char* w) : on(getenv("TREDGPU_TRACE") != nullptr), what(w), t0(on ? now() : 0) {}
+    void mark(const char* k) { if (on) { char b[64]; snprintf(b, sizeof b, " %s=%.2f", k, now() - t0); line += b; } }
+    ~CallTrace() { if (on) fprintf(stderr, "[tredgpu %d] %s:%s\n", (int)getpid(), what, line.c_str()); }
+};
+
+
 int ifail(tredgpu_inflater* f, int code, const char* what, hipError_t e = hipSuccess) {
     std::string m = what;
     if (e != hipSuccess) { m += ": "; m += hipGetErrorString(e); }
@@ -1320,6 +1396,9 @@ void release(tredgpu_inflater* f) {
     if (f->h_out) (void)hipHostFree(f->h_out);
     if (f->h_dense) (void)hipHostFree(f->h_dense);
     f->h_dense = nullptr; f->cap_dense = 0;
+    if (f->h_pieces) (void)hipHostFree(f->h_pieces);
+    if (f->d_pieces) (void)hipFree(f->d_pieces);
+    f->h_pieces = f->d_pieces = nullptr; f->cap_pieces = 0;
     if (f->h_off) (void)hipHostFree(f->h_off);
     if (f->h_status) (void)hipHostFree(f->h_status);
     for (void* p : {(void*)f->d_comp, (void*)f->d_out, (void*)f->d_off, (void*)f->d_status})
@@ -1472,6 +1551,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
     if (n_blocks < 0 || (size_t)n_blocks + 1 > f->cap_blocks || (n_blocks > 0 && !status)) return ifail(f, -2, "bad arguments (reserve first)");
     if (n_blocks == 0) return 0;
     if (copy_out && !f->h_out) return ifail(f, -2, "this inflater keeps no host copy of the output (tredgpu_inflater_host_out): walk and fetch");
+    CallTrace tr(w ? "inflate_walk" : "inflate");
     const int64_t* coff = f->h_off;
     const int64_t* ooff = f->h_off + f->cap_blocks;
     for (int32_t k = 0; k < n_blocks; ++k) {
@@ -1529,14 +1609,22 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         const size_t rb_at = n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk);
         static_assert(sizeof(tredgpu_walk_task) % 8 == 0 && sizeof(tredgpu_walk_chunk) % 8 == 0, "rec_base stays 8-byte aligned");
         if (grow_pair(f, &f->h_wtask, &f->d_wtask, &f->cap_wtask, rb_at + (n_tasks + 1) * sizeof(int64_t) + 64)) return -10;
-        // room for every region's record list: a record is never smaller than 64 bytes here (36 fixed bytes, a name, 36
-        // bases and their qualities: 100 and more) -- a region that has more is the host's (status 4)
+        // room for every region's record list: the blocks its chunks span (a task's block_first .. block_end is its whole
+        // FILE), at no less than 64 bytes per record (36 fixed bytes, a name, 36 bases and their qualities: 100 and more) --
+        // a region that has more records than that is the host's (status 4)
         int64_t* rec_base = (int64_t*)(f->h_wtask + rb_at);
         rec_base[0] = 0;
         for (size_t t = 0; t < n_tasks; ++t) {
             const tredgpu_walk_task& T = w->tasks[t];
-            const int64_t bytes = T.n_chunks >= 0 ? ooff[T.block_end] - ooff[T.block_first] : 0;
-            rec_base[t + 1] = rec_base[t] + (T.n_chunks >= 0 ? bytes / 64 + 64 : 0);
+            int64_t bytes = 0;
+            for (int32_t q = 0; q < T.n_chunks; ++q) {
+                const tredgpu_walk_chunk& ch = w->chunks[T.chunk_first + q];
+                if (ch.begin_block < T.block_first || ch.begin_block >= T.block_end) continue;
+                const int64_t* lo = w->blk_coffset + ch.begin_block;
+                const int64_t* hi = std::upper_bound(lo, w->blk_coffset + T.block_end, (int64_t)(ch.end_voffset >> 16));
+                bytes += ooff[ch.begin_block + (hi - lo)] - ooff[ch.begin_block];
+            }
+            rec_base[t + 1] = rec_base[t] + (T.n_chunks > 0 ? bytes / 64 + 64 : 0);
         }
         total_recs = (size_t)rec_base[n_tasks];
         if (total_recs > f->cap_wrecs) {
@@ -1576,6 +1664,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         ICHK(f, hipMemcpyAsync(f->d_wtask, f->h_wtask, rb_at + (n_tasks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->wstream));
         ICHK(f, hipMemsetAsync(f->d_wres + n_tasks * sizeof(tredgpu_walk_result), 0, 16, f->wstream));
     }
+    tr.mark("walk_inputs");
     // the two streams never wait for each other: each copies the offsets in for itself (both write the same values)
     for (int s = 0; s < nstreams; ++s) {
         ICHK(f, hipEventRecord(f->t0[s], f->stream[s]));
@@ -1668,13 +1757,18 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         ICHK(f, hipEventRecord(f->t1[s], f->stream[s]));
         ICHK(f, hipEventRecord(f->done[s], f->stream[s]));
     }
+    tr.mark("enqueued");
     for (int s = 0; s < nstreams; ++s)
         if (wait_asleep(f, f->done[s])) return -10;
+    tr.mark("decoded");
     int bad = 0;
     for (int32_t k = 0; k < n_blocks; ++k) { status[k] = f->h_status[k]; bad += status[k] != 0; }
     if (crc) for (int32_t k = 0; k < n_blocks; ++k) crc[k] = (uint32_t)f->h_status[f->cap_blocks + k];
     if (w) {
-        if (wait_asleep(f, f->wdone) || wait_asleep(f, f->adone)) return -10;
+        if (wait_asleep(f, f->wdone)) return -10;
+        tr.mark("pair_walk");
+        if (wait_asleep(f, f->adone)) return -10;
+        tr.mark("alt_walk");
         unsigned long long used[2];
         memcpy(used, f->h_wres + n_tasks * sizeof(tredgpu_walk_result), 16);
         memcpy(w->results, f->h_wres, n_tasks * sizeof(tredgpu_walk_result));
@@ -1693,6 +1787,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         if (nt) memcpy(w->target_pool, f->h_tpool, nt * 4);
         w->n_global = (int64_t)ng;
         w->n_target = (int64_t)nt;
+        tr.mark("pools");
     }
     return bad;
 }
@@ -1769,6 +1864,7 @@ int tredgpu_inflater_host_out(tredgpu_inflater* f, int enabled) {
 int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const uint8_t* need, uint8_t** host, int64_t* dense_off) {
     if (!f) return -2;
     if (n_blocks < 0 || (size_t)n_blocks + 1 > f->cap_blocks || !host || !dense_off || (n_blocks > 0 && !need)) return ifail(f, -2, "bad arguments");
+    CallTrace tr("fetch_dense");
     const int64_t* ooff = f->h_off + f->cap_blocks;
     constexpr int64_t GAP = 128 * 1024;           // a copy costs the host ~5 us: less than these bytes cost the bus
     // the runs: a wanted block, and on to the next wanted one while the blocks in between are fewer bytes than GAP
@@ -1782,6 +1878,8 @@ int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const ui
         int32_t last = k;
         for (int32_t j = k + 1; j < n_blocks && ooff[j] - ooff[last + 1] <= GAP; ++j)
             if (need[j]) last = j;
+        total = (total + 15) & ~(int64_t)15;       // (a run starts on a 16-byte boundary of the dense buffer: the kernel's stores)
+        dense_off[k] = total;                      // (an empty block in front of the run ends where the run starts: still empty)
         for (int32_t j = k; j <= last; ++j) { total += ooff[j + 1] - ooff[j]; dense_off[j + 1] = total; }
         runs.push_back(Run{k, last});
         k = last + 1;
@@ -1794,17 +1892,50 @@ int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const ui
         ICHK(f, hipHostMalloc((void**)&f->h_dense, c, hipHostMallocDefault));
         f->cap_dense = c;
     }
+    tr.mark("room");
     *host = f->h_dense;
     int copies = 0;
-    for (const Run& r : runs) {
-        ICHK(f, hipMemcpyAsync(f->h_dense + dense_off[r.first], f->d_out + ooff[r.first], (size_t)(ooff[r.last + 1] - ooff[r.first]),
-                               hipMemcpyDeviceToHost, f->stream[copies & 1]));
-        ++copies;
+    static const bool by_dma = getenv("TREDGPU_FETCH_DMA") != nullptr;     // (A/B: the copy engines, one copy per run)
+    if (by_dma) {
+        for (const Run& r : runs) {
+            ICHK(f, hipMemcpyAsync(f->h_dense + dense_off[r.first], f->d_out + ooff[r.first], (size_t)(ooff[r.last + 1] - ooff[r.first]),
+                                   hipMemcpyDeviceToHost, f->stream[copies & 1]));
+            ++copies;
+        }
+        tr.mark("enqueued");
+        for (int s = 0; s < 2; ++s) {
+            ICHK(f, hipEventRecord(f->done[s], f->stream[s]));
+            if (wait_asleep(f, f->done[s])) return -10;
+        }
+    } else if (!runs.empty()) {
+        constexpr int64_t PIECE = 32 * 1024;       // bytes per workgroup: ~3 300 workgroups for a 16-sample call
+        size_t n_pieces = 0;
+        for (const Run& r : runs) n_pieces += (size_t)((ooff[r.last + 1] - ooff[r.first] + PIECE - 1) / PIECE);
+        if (n_pieces > f->cap_pieces) {
+            const size_t c = std::max(n_pieces, f->cap_pieces + f->cap_pieces / 2);
+            if (f->h_pieces) (void)hipHostFree(f->h_pieces);
+            if (f->d_pieces) (void)hipFree(f->d_pieces);
+            f->h_pieces = f->d_pieces = nullptr; f->cap_pieces = 0;
+            ICHK(f, hipHostMalloc((void**)&f->h_pieces, c * sizeof(FetchPiece), hipHostMallocDefault));
+            ICHK(f, hipMalloc((void**)&f->d_pieces, c * sizeof(FetchPiece)));
+            f->cap_pieces = c;
+        }
+        FetchPiece* P = (FetchPiece*)f->h_pieces;
+        size_t p = 0;
+        for (const Run& r : runs) {
+            const int64_t bytes = ooff[r.last + 1] - ooff[r.first];
+            for (int64_t o = 0; o < bytes; o += PIECE) P[p++] = FetchPiece{ooff[r.first] + o, dense_off[r.first] + o, (int32_t)std::min(PIECE, bytes - o), 0};
+        }
+        ICHK(f, hipMemcpyAsync(f->d_pieces, f->h_pieces, n_pieces * sizeof(FetchPiece), hipMemcpyHostToDevice, f->stream[0]));
+        fetch_gather_kernel<<<(unsigned)n_pieces, 256, 0, f->stream[0]>>>(f->d_out, f->h_dense, (const FetchPiece*)f->d_pieces);
+        ICHK(f, hipGetLastError());
+        copies = (int)n_pieces;
+        tr.mark("enqueued");
+        ICHK(f, hipEventRecord(f->done[0], f->stream[0]));
+        if (wait_asleep(f, f->done[0])) return -10;
     }
-    for (int s = 0; s < 2; ++s) {
-        ICHK(f, hipEventRecord(f->done[s], f->stream[s]));
-        if (wait_asleep(f, f->done[s])) return -10;
-    }
+    tr.mark("copied");
+    if (tr.on) { char b[64]; snprintf(b, sizeof b, " copies=%d MB=%.1f", copies, total / 1e6); tr.line += b; }
     return copies;
 }
 

@@ -233,8 +233,49 @@ class Engine(object):
         return tag[:n], h[:n], sc[:n]
 
     def genotype_packed(self, b, dense=False):
-        """The whole path for a PackedUnits batch -> BatchResult (sparse joint distribution included).  dense: also the
-        four terms of every (h1, h2) pair (a second grid call with the dump; what --log DEBUG prints)."""
+        """The whole path for a PackedUnits batch -> BatchResult (sparse joint distribution included): one fused call
+        (tredgpu_genotype_batch_joint: tags, histograms and calls stay on the device between the stages; one wait).
+        dense: also the four terms of every (h1, h2) pair (a second grid call with the dump; what --log DEBUG prints) --
+        that path goes through the three separate calls, which hand the histograms back."""
+        if dense or b.n_units == 0:
+            return self._genotype_packed_stepwise(b, dense)
+        r = BatchResult()
+        r.batch = b
+        r.grid = r.grid_off = None
+        g, n = b.n_units, b.n_reads
+        hs = b.max_units + 2
+        ms = max(int(b.params["maxinsert"].max()), hs) + 2
+        r.tag, r.h, r.score = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.int16), np.zeros(max(n, 1), np.int16)
+        r.full = r.pref = None
+        r.rept = np.zeros((g, hs), np.int32)
+        lad = self._register(b.ladder_keys)
+        gl = b.global_lens if len(b.global_lens) else np.zeros(1, np.int32)
+        tl = b.target_lens if len(b.target_lens) else np.zeros(1, np.int32)
+        params = _lib.default_sw_params(clip=b.clip)
+        r.calls = np.zeros(g, _lib.CALL_DTYPE)
+        r.marg = np.zeros((g, 2, ms), np.float64)
+        cap = np.full(g, JOINT_CAP, np.int64)
+        while True:
+            joff = np.zeros(g + 1, np.int64)
+            joff[1:] = np.cumsum(cap)
+            trip = np.zeros((int(joff[-1]), 3), np.float64)
+            jn, jt = np.zeros(g, np.int32), np.zeros(g, np.float64)
+            self.ctx.genotype_batch_joint(b.packed, b.read_off, b.read_len, n, b.unit_read_off, lad, b.params, g, params,
+                                          b.pair_id if n else None, gl, len(b.global_lens), tl, len(b.target_lens),
+                                          r.tag, r.h, r.score, hs, r.rept, r.calls, r.marg, ms, joff, trip, jn, jt)
+            if (jn <= cap).all():
+                break
+            cap = np.maximum(cap, jn)         # a flat likelihood surface: ask again with room for every entry
+        r.tag, r.h, r.score = r.tag[:n], r.h[:n], r.score[:n]
+        r.joint = [(trip[joff[i]:joff[i] + jn[i]], float(jt[i])) for i in range(g)]
+        per = np.repeat(b.params["period"].astype(np.int64), cap)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r.joint_units = (trip[:, 0].astype(np.int64) // per, trip[:, 1].astype(np.int64) // per, trip[:, 2] / np.repeat(jt, cap),
+                             joff[:-1], jn)
+        return r
+
+    def _genotype_packed_stepwise(self, b, dense=False):
+        """genotype_packed through the three separate calls (SW, tally, grid)."""
         r = BatchResult()
         r.batch = b
         r.grid = r.grid_off = None

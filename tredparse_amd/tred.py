@@ -42,7 +42,7 @@ logger = logging.getLogger(__name__)
 # the writer thread's time in the sink (JSON / VCF text and files)
 TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
           "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0, "walk_regions": 0, "walk_declined": 0,
-          "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0}
+          "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0, "walk_call": 0.0, "walk_fetch": 0.0}
 _TIMING_LOCK = threading.Lock()
 
 
@@ -418,22 +418,26 @@ class _InflateFeeder(object):
         from .bam_parser import walk_need
         w = job["walk"]
         from ._lib import walk_pool_pairs
+        t0 = time.perf_counter()
         status, crc, res, gp, tp, ares, alt_need = inf.run_walk(job["n_all"], w["coffset"], w["clen"], w["crc"], w["tasks"], w["chunks"],
                                                                 alt_tasks=w["alt_tasks"], alt_chunks=w["alt_chunks"],
                                                                 pool_pairs=walk_pool_pairs(w["tasks"], job["ooff"]))
         full = int((res["status"] == 6).sum())
         if full:                           # (WALK_POOL_FULL: cannot happen with the bound above; a wrong plan would show here)
             logging.getLogger("tredparse_amd").warning("pair walk: %d of %d regions found the pair pool full and are walked on the host", full, len(res))
+        t1 = time.perf_counter()
         need = np.zeros(job["n_all"], np.uint8)
         for p in job["live"]:
             a = p["first"]
             need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])],
                                            alt_need[a:a + p["n"]])
+        t2 = time.perf_counter()
         if getattr(inf, "host_out", True):
             inf.fetch(need)
             out_addr, out_off = inf.out_addr, job["ooff"]
         else:
             out_addr, out_off = inf.fetch_dense(need)
+        timing_add(walk_call=t1 - t0, walk_fetch=time.perf_counter() - t2)
         walkable = w["alt_tasks"]["n_chunks"] >= 0
         timing_add(walk_regions=len(res), walk_declined=int((res["status"] != 0).sum()), walk_blocks_fetched=int(need.sum()),
                    walk_alt_regions=int(walkable.sum()), walk_alt_declined=int((ares["status"][walkable] != 0).sum()),
