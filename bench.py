@@ -618,7 +618,8 @@ def e2e_main(args):
     rec = {"rank": rank, "device": os.environ.get("TRED_RANK_DEVICE", "0"), "t_process": t_proc, "t_begin": t0, "t_end": t1,
            "files": len(mine), "host_threads": threads, "first_chunk": min(args.e2e_batch, threads, max(1, len(mine))),
            "driver_seconds": {k: round(v, 4) for k, v in tred.TIMING.items()},
-           "bam_bytes": sum(os.path.getsize(b) for b in bams[lo:hi]), "digests": _output_digests(work)}
+           "bam_bytes": sum(os.path.getsize(b) for b in bams[lo:hi]), "digests": _output_digests(work),
+           "pinned_MB": round(tred.pinned_bytes() / 1e6, 1)}
     with open(os.path.join(out_dir, "e2e_rank{}.json".format(rank)), "w") as fp:
         json.dump(rec, fp)
     if dist is not None:
@@ -767,6 +768,7 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None)
                 leg["per_driver"] = [{"seconds": round(r["t_end"] - r["t_begin"], 3), "device": r.get("device", "0"),
                                       **r["driver_seconds"]} for r in ranks]
                 leg["bam_MB"] = sum(r["bam_bytes"] for r in ranks) / 1e6
+                leg["pinned_MB_per_gpu"] = round(sum(r.get("pinned_MB", 0.0) for r in ranks) / max(1, n_devices), 1)
                 legs.append(leg)
             good = [l for l in legs if "value" in l]
             plan = [l for l in good if l["role"] == "plan"]
@@ -884,7 +886,7 @@ def compact_line(out):
     if e:
         line["end_to_end"] = {k: _r(e[k], 3) for k in ("value", "unit", "first_pass_value", "whole_run_value", "startup_s", "drivers",
                                                        "devices", "host_threads_per_driver", "gpu_inflate", "gpu_walk", "seconds", "samples",
-                                                       "files", "outputs_identical", "error") if k in e}
+                                                       "files", "pinned_MB_per_gpu", "outputs_identical", "error") if k in e}
         h = e.get("host_only_one_driver_per_gpu")
         if h:
             line["end_to_end"]["host_only_one_driver_per_gpu"] = {k: _r(h[k], 3) for k in ("value", "first_pass_value", "seconds")}

@@ -392,6 +392,8 @@ int tredgpu_inflater_fetch(tredgpu_inflater* inf, int32_t n_blocks, const uint8_
  */
 int tredgpu_inflater_host_out(tredgpu_inflater* inf, int enabled);
 int tredgpu_inflater_fetch_dense(tredgpu_inflater* inf, int32_t n_blocks, const uint8_t* need, uint8_t** host, int64_t* dense_off);
+/* page-locked host memory the inflater holds at the moment, in bytes (its staging grows with the largest call it has seen) */
+int64_t tredgpu_inflater_pinned_bytes(const tredgpu_inflater* inf);
 /* device time of the last call's walk launch in milliseconds */
 int tredgpu_inflater_walk_ms(tredgpu_inflater* inf, double* walk_ms);
 

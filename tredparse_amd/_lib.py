@@ -60,7 +60,7 @@ EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_s
            "tredgpu_inflater_create", "tredgpu_inflater_destroy", "tredgpu_inflater_last_error",
            "tredgpu_inflater_reserve", "tredgpu_inflate_blocks", "tredgpu_inflate_blocks_crc", "tredgpu_inflater_timing",
            "tredgpu_inflate_walk", "tredgpu_inflater_fetch", "tredgpu_inflater_walk_ms", "tredgpu_inflater_host_out",
-           "tredgpu_inflater_fetch_dense")
+           "tredgpu_inflater_fetch_dense", "tredgpu_inflater_pinned_bytes")
 
 _lib = None
 
@@ -118,6 +118,8 @@ def load():
     lib.tredgpu_inflater_fetch.argtypes = [vp, i32, vp]
     lib.tredgpu_inflater_walk_ms.argtypes = [vp, C.POINTER(C.c_double)]
     lib.tredgpu_inflater_host_out.argtypes = [vp, C.c_int]
+    lib.tredgpu_inflater_pinned_bytes.argtypes = [vp]
+    lib.tredgpu_inflater_pinned_bytes.restype = i64
     lib.tredgpu_inflater_fetch_dense.argtypes = [vp, i32, vp, C.POINTER(vp), vp]
     _lib = lib
     return lib
@@ -466,8 +468,12 @@ class Inflater:
         off = np.zeros(len(need) + 1, np.int64)
         host = C.c_void_p()
         self._check(self._lib.tredgpu_inflater_fetch_dense(self._h, len(need), need.ctypes.data, C.byref(host), off.ctypes.data),
-                    "tredgpu_inflater_fetch_dense")
+                    "tredgpu_inflater_fetch_dense", "tredgpu_inflater_pinned_bytes")
         return host.value or 0, off
+
+    def pinned_bytes(self):
+        """Page-locked host memory this inflater holds, in bytes."""
+        return int(self._lib.tredgpu_inflater_pinned_bytes(self._h)) if self._h else 0
 
     def walk_ms(self):
         a = C.c_double()

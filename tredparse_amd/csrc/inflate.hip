@@ -1939,6 +1939,13 @@ int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const ui
     return copies;
 }
 
+int64_t tredgpu_inflater_pinned_bytes(const tredgpu_inflater* f) {
+    if (!f) return -2;
+    size_t n = f->cap_comp + (f->h_out ? f->cap_out : 0) + f->cap_blocks * (2 * sizeof(int64_t) + 2 * sizeof(int32_t)) + f->cap_dense +
+               f->cap_pieces * sizeof(FetchPiece) + f->cap_wblk + f->cap_wtask + f->cap_wres + f->cap_gpool + f->cap_tpool + f->cap_atask + f->cap_ares;
+    return (int64_t)n;
+}
+
 int tredgpu_inflater_walk_ms(tredgpu_inflater* f, double* walk_ms) {
     if (!f || !walk_ms) return -2;
     *walk_ms = 0.0;

@@ -257,6 +257,12 @@ def _return_inflaters(device, infs):
             _INFLATERS.setdefault((device, getattr(inf, "host_out", True)), []).append(inf)
 
 
+def pinned_bytes():
+    """Page-locked host memory of the process's pooled inflaters (those a running feeder has borrowed are not counted)."""
+    with _INFLATERS_LOCK:
+        return sum(inf.pinned_bytes() for v in _INFLATERS.values() for inf in v if hasattr(inf, "pinned_bytes"))
+
+
 def release_inflaters():
     """Frees the pooled inflaters (their pinned and device buffers)."""
     with _INFLATERS_LOCK:
