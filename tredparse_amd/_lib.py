@@ -468,7 +468,7 @@ class Inflater:
         off = np.zeros(len(need) + 1, np.int64)
         host = C.c_void_p()
         self._check(self._lib.tredgpu_inflater_fetch_dense(self._h, len(need), need.ctypes.data, C.byref(host), off.ctypes.data),
-                    "tredgpu_inflater_fetch_dense", "tredgpu_inflater_pinned_bytes")
+                    "tredgpu_inflater_fetch_dense")
         return host.value or 0, off
 
     def pinned_bytes(self):

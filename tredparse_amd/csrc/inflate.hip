@@ -1031,15 +1031,21 @@ __device__ int walk_region_resolve(const tredgpu_walk_task& T, WalkLds& S, const
             vend = walk_lane64(me.after, wl);
             nwin += __popcll(win_mask);
         }
-        // PairTable::add, in file order
+        // PairTable::add, in file order.  Serial is only the table itself: one probe and one update per record, on values
+        // every lane holds alike; which pair a record belongs to (and as its how-manieth record) is noted in the record's
+        // own lane, and the pair entries are written behind the loop by all lanes at once (one after the other, each from
+        // the owning lane inside the loop, they were a third of the loop's instructions -- and a lone wavefront issues one
+        // every ~5 cycles).
         uint64_t todo = __ballot(keep && (flag & 0x1) && !(flag & 0x4) && !(flag & 0x400));
+        uint32_t tag_v = h >> 15;
+        if (tag_v == 0) tag_v = 1;
+        const uint32_t slot_v = h & S.mask;
+        int my_idx = -1, my_seen = 0, my_rep = 0;
         while (todo) {
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
-            uint32_t tag = hj >> 15;
-            if (tag == 0) tag = 1;
-            uint32_t slot = hj & S.mask;
+            const uint32_t tag = (uint32_t)__builtin_amdgcn_readlane((int)tag_v, j);
+            uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)slot_v, j);
             int idx = -1, seen = 0;
             for (;; slot = (slot + 1) & S.mask) {
                 const uint32_t entry = walk_uniform(S.table[slot]);
@@ -1051,22 +1057,28 @@ __device__ int walk_region_resolve(const tredgpu_walk_task& T, WalkLds& S, const
                 idx = np++;
             }
             if (seen >= 2 && nrep >= WALK_REPEAT_CAP) return WALK_TABLE_FULL;
-            if (lane == j) {
-                if (seen < 3) S.table[slot] = (tag << 15) | ((uint32_t)(seen + 1) << 13) | (uint32_t)idx;
-                if (seen == 0) {
-                    WalkPair& P = pairs[idx];
-                    P.name_at = me.a0 + 36; P.name_len = F.nlen;
-                    P.a_pos = rpos; P.a_lead = F.lead; P.a_rev = (flag & 0x10) ? 1 : 0; P.complete = 0;
-                } else if (seen == 1) {
-                    WalkPair& P = pairs[idx];
-                    P.name2_at = me.a0 + 36;
-                    P.b_end = rend; P.b_trail = F.trail; P.b_rev = (flag & 0x10) ? 1 : 0; P.complete = 1;
-                } else {                                                // the pair is complete: only the name matters
-                    repeats[nrep].pair = idx; repeats[nrep].name_at = me.a0 + 36;
-                }
-            }
+            if (seen < 3) S.table[slot] = (tag << 15) | ((uint32_t)(seen + 1) << 13) | (uint32_t)idx;   // (every lane the same value)
+            const bool me_now = lane == j;
+            my_idx = me_now ? idx : my_idx;
+            my_seen = me_now ? seen : my_seen;
+            my_rep = me_now ? nrep : my_rep;
             if (seen >= 2) ++nrep;
             walk_lds_order();
+        }
+        if (my_idx >= 0) {
+            if (my_seen == 0) {
+                WalkPair& P = pairs[my_idx];
+                P.name_at = me.a0 + 36; P.name_len = F.nlen;
+                P.a_pos = rpos; P.a_lead = F.lead; P.a_rev = (flag & 0x10) ? 1 : 0; P.complete = 0;
+            }
+        }
+        if (my_idx >= 0 && my_seen == 1) {                          // (behind the first records' stores: `complete` ends up set)
+            WalkPair& P = pairs[my_idx];
+            P.name2_at = me.a0 + 36;
+            P.b_end = rend; P.b_trail = F.trail; P.b_rev = (flag & 0x10) ? 1 : 0; P.complete = 1;
+        }
+        if (my_idx >= 0 && my_seen >= 2) {                          // the pair is complete: only the name matters
+            repeats[my_rep].pair = my_idx; repeats[my_rep].name_at = me.a0 + 36;
         }
         if (bad_mask) return WALK_BAD_RECORD;
     }
