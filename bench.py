@@ -1026,7 +1026,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="only --gpus ranks, no 1/2/4/8 sweep")
     ap.add_argument("--rank-timeout", type=float, default=1500.0)
     ap.add_argument("--stub", action="store_true", help="launcher self-test: ranks do no GPU work")
-    ap.add_argument("--e2e-samples", type=int, default=2048,
+    ap.add_argument("--e2e-samples", type=int, default=4096,
                     help="BAM files per GPU of the end-to-end legs (0: skip them): the same number at every device count")
     ap.add_argument("--e2e-distinct", type=int, default=512,
                     help="distinct synthetic BAMs made; a larger cohort gets the rest as hard links under their own sample keys")

@@ -3,4 +3,4 @@
 Only what the path needs lives here: csrc/ (HIP kernels + C ABI -> libtredgpu.so), the ctypes
 binding, and the host-side mirrors of the reference's operator interfaces for this path.
 """
-__version__ = "0.1.0"
+__version__ = "0.5.0"

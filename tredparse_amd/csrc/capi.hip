@@ -259,7 +259,7 @@ extern "C" {
 #ifndef TREDGPU_SRC_HASH
 #define TREDGPU_SRC_HASH "unknown"
 #endif
-const char* tredgpu_version(void) { return "tredgpu 0.3 (gfx950) src " TREDGPU_SRC_HASH; }
+const char* tredgpu_version(void) { return "tredgpu 0.5 (gfx950) src " TREDGPU_SRC_HASH; }
 
 int tredgpu_create(int device_id, tredgpu_ctx** out) {
     if (!out) return fail(nullptr, -2, "out is NULL");
@@ -272,7 +272,14 @@ int tredgpu_create(int device_id, tredgpu_ctx** out) {
     if (device_id < 0 || device_id >= n) return fail(nullptr, -2, "device %d out of range [0,%d)", device_id, n);
     tredgpu_ctx* c = new tredgpu_ctx();
     c->device = device_id;
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+    // TREDGPU_CTX_PRIORITY=high: the context's stream above the inflaters' (which are created at the lowest priority): a
+    // genotyping call is a dozen short launches, and among other processes' 4 ms decode launches each of them queued
+    int lo_prio = 0, hi_prio = 0;
+    const char* want = getenv("TREDGPU_CTX_PRIORITY");
+    const bool high = want && strcmp(want, "high") == 0;
+    if ((e = hipSetDevice(device_id)) != hipSuccess ||
+        (e = high && hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) == hipSuccess
+                 ? hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi_prio) : hipStreamCreate(&c->stream)) != hipSuccess) {
         delete c;
         return fail(nullptr, -10, "cannot initialise device %d: %s", device_id, hipGetErrorString(e));
     }

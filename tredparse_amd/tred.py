@@ -42,7 +42,7 @@ logger = logging.getLogger(__name__)
 # the writer thread's time in the sink (JSON / VCF text and files)
 TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
           "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0, "walk_regions": 0, "walk_declined": 0,
-          "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0, "walk_call": 0.0, "walk_fetch": 0.0}
+          "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0, "walk_call": 0.0, "walk_fetch": 0.0, "pack": 0.0}
 _TIMING_LOCK = threading.Lock()
 
 
@@ -568,7 +568,9 @@ def _genotype(engine, picks, o):
     out = {}
 
     def attempt(sub):
+        t0 = time.perf_counter()
         batch = PackedUnits.from_scans([(s, ks) for _, s, ks in sub], **kw)
+        timing_add(pack=time.perf_counter() - t0)
         if batch.n_units == 0:
             return
         br = engine.genotype_packed(batch, dense=True) if o["log"] == "DEBUG" else engine.genotype_packed(batch)
