@@ -132,3 +132,32 @@ def test_walk_need_marks_the_windows_blocks_and_what_the_flags_say():
     assert walk_need(coff, host, res[:1], alt_need).tolist() == [1, 1, 1, 1, 0, 1]
     none = np.zeros(0, bamio.WALK_RESULT_DTYPE)
     assert walk_need(coff, host, none, np.zeros(6, np.uint8)).tolist() == [0, 0, 0, 1, 0, 1]
+
+
+def test_pool_bound_covers_any_coverage():
+    """the pair pools were 2 048 entries per task and overflowed silently from ~32x on.  The bound now comes
+    from the call's inflated bytes: two records of at least MIN_PAIR_BYTES / 2 per pair, a byte in the regions of at most
+    two loci -- whatever the coverage."""
+    from tredparse_amd import _lib
+    tasks = np.zeros(60, _lib.WALK_TASK_DTYPE)
+    for cov in (30, 40, 100, 300):
+        reads = int(20000 * cov / 150) * 60                     # 150 bp reads over 60 regions of +-10 kb
+        out_bytes = reads * 290                                 # (a record of such a read: ~290 bytes)
+        off = np.array([0, out_bytes], np.int64)
+        assert _lib.walk_pool_pairs(tasks, off) >= reads // 2    # every read paired: the most pairs there can be
+    assert _lib.walk_pool_pairs(tasks[:0], np.zeros(1, np.int64)) == 0
+
+
+def test_plan_drivers_follows_the_rule_and_the_cohort_size():
+    import argparse
+    from tredparse_amd import shard
+    a = argparse.Namespace(gpus=1, drivers="auto", cpus=None, gpu_inflate=True)
+    assert t.plan_drivers(a, 5000, 16) == shard.driver_plan(16, 1) == (3, 5)
+    assert t.plan_drivers(a, 2, 16) == (1, 16)                  # a handful of samples: one process, all the threads
+    assert t.plan_drivers(a, 70, 16) == (2, 8)                  # never more drivers than blocks of 32 samples
+    a.gpu_inflate = False
+    assert t.plan_drivers(a, 5000, 16) == (3, 5)                # host decoding: a driver per five CPUs
+    a.drivers, a.cpus = "2", 6
+    assert t.plan_drivers(a, 5000, 16) == (2, 6)
+    a8 = argparse.Namespace(gpus=8, drivers="auto", cpus=None, gpu_inflate=True)
+    assert t.plan_drivers(a8, 8000, 128) == (3, 5)

@@ -908,7 +908,6 @@ int tredgpu_genotype_batch_joint(tredgpu_ctx* c, const uint32_t* packed, const i
     if ((rc = check_sw_params(c, params))) return rc;
     if ((rc = check_grid_common(c, units, n_units))) return rc;
     if (c->h_ladders.empty()) return fail(c, -4, "no ladders registered (tredgpu_set_ladders)");
-    if (hist_stride <= c->max_ladder_units) return fail(c, -2, "hist_stride %d must exceed the largest max_units %d", hist_stride, c->max_ladder_units);
     if (n_reads < 0 || n_units <= 0) return fail(c, -2, "bad sizes");
     if (!unit_read_off || !unit_ladder || !calls || !marg || !joint_off || !joint || !joint_n || !joint_total || marg_stride <= 0)
         return fail(c, -2, "NULL array argument");
@@ -920,6 +919,9 @@ int tredgpu_genotype_batch_joint(tredgpu_ctx* c, const uint32_t* packed, const i
     for (int g = 0; g < n_units; ++g) {
         if (unit_read_off[g + 1] < unit_read_off[g]) return fail(c, -2, "unit_read_off not monotone at %d", g);
         if (unit_ladder[g] < 0 || unit_ladder[g] >= (int)c->h_ladders.size()) return fail(c, -2, "unit %d: ladder %d not registered", g, unit_ladder[g]);
+        // (the histograms must hold the repeat counts of THIS batch's ladders; the context may know longer ones)
+        if (hist_stride <= c->h_ladders[unit_ladder[g]].max_units)
+            return fail(c, -2, "hist_stride %d must exceed the max_units %d of unit %d's ladder", hist_stride, c->h_ladders[unit_ladder[g]].max_units, g);
         const tredgpu_unit_params& u = units[g];
         limits[0] = std::max(limits[0], u.maxinsert);
         limits[1] = std::max(limits[1], u.n_target);

@@ -1373,7 +1373,8 @@ struct tredgpu_inflater {
     uint8_t* d_atask = nullptr; uint8_t* h_atask = nullptr; size_t cap_atask = 0;   // the alternative loci's tasks then chunks
     uint8_t* d_ares = nullptr;  uint8_t* h_ares = nullptr;  size_t cap_ares = 0;    // their results, then the blocks' need flags
     int32_t *d_gpool = nullptr, *d_tpool = nullptr, *h_gpool = nullptr, *h_tpool = nullptr;
-    size_t cap_gpool = 0, cap_tpool = 0;
+    size_t cap_gpool = 0, cap_tpool = 0;          // (device pools: the call's bound)
+    size_t cap_hgpool = 0, cap_htpool = 0;        // (pinned host pools: what the walks really produced, an eighth more)
     std::string err;
 };
 
@@ -1430,6 +1431,7 @@ void release_walk(tredgpu_inflater* f) {
     f->d_wblk = f->d_wtask = f->d_wres = f->d_atask = f->d_ares = nullptr; f->d_wrepeats = nullptr; f->d_wpairs = nullptr; f->d_gpool = f->d_tpool = nullptr;
     f->d_wrecs = nullptr; f->d_wfields = nullptr; f->d_wchained = nullptr; f->cap_wrecs = f->cap_wchained = 0;
     f->cap_wblk = f->cap_wtask = f->cap_wres = f->cap_wscratch = f->cap_gpool = f->cap_tpool = f->cap_atask = f->cap_ares = 0;
+    f->cap_hgpool = f->cap_htpool = 0;
 }
 
 // grow-only pairs of pinned host / device buffers for the walk's small arrays
@@ -1521,7 +1523,9 @@ int tredgpu_inflater_reserve(tredgpu_inflater* f, int64_t comp_bytes, int64_t ou
     const size_t need_c = (size_t)comp_bytes + 64, need_o = (size_t)out_bytes + 64, need_b = (size_t)n_blocks + 1;
     if (need_c > f->cap_comp || need_o > f->cap_out || need_b > f->cap_blocks) {
         for (hipStream_t st : f->stream) ICHK(f, hipStreamSynchronize(st));
-        const size_t cc = std::max(need_c, f->cap_comp + f->cap_comp / 2), co = std::max(need_o, f->cap_out + f->cap_out / 2),
+        // (page-locked staging grows by an eighth past the largest call seen: a chunk's size varies by a few per cent, and every
+        //  spare byte here is pinned three times per driver process)
+        const size_t cc = std::max(need_c, f->cap_comp + f->cap_comp / 8), co = std::max(need_o, f->cap_out + f->cap_out / 8),
                      cb = std::max(need_b, f->cap_blocks + f->cap_blocks / 2);
         release(f);
         ICHK(f, hipHostMalloc((void**)&f->h_comp, cc, hipHostMallocDefault));
@@ -1665,8 +1669,20 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
             ICHK(f, hipMalloc((void**)&f->d_wpairs, c * WALK_PAIR_CAP * sizeof(WalkPair)));
             f->cap_wscratch = c;
         }
-        if (grow_pair(f, (uint8_t**)&f->h_gpool, (uint8_t**)&f->d_gpool, &f->cap_gpool, ((size_t)w->cap_global + 16) * 4)) return -10;
-        if (grow_pair(f, (uint8_t**)&f->h_tpool, (uint8_t**)&f->d_tpool, &f->cap_tpool, ((size_t)w->cap_target + 16) * 4)) return -10;
+        // (the pools on the device hold the call's BOUND -- a tenth of it is used at 30x --, their pinned host copies are
+        //  sized behind the walks, from what was really produced)
+        for (int which = 0; which < 2; ++which) {
+            int32_t** d = which ? &f->d_tpool : &f->d_gpool;
+            size_t* cap = which ? &f->cap_tpool : &f->cap_gpool;
+            const size_t need = ((size_t)(which ? w->cap_target : w->cap_global) + 16) * 4;
+            if (need > *cap) {
+                const size_t c = std::max(need, *cap + *cap / 2);
+                if (*d) (void)hipFree(*d);
+                *d = nullptr; *cap = 0;
+                ICHK(f, hipMalloc((void**)d, c));
+                *cap = c;
+            }
+        }
         memcpy(f->h_wblk, w->blk_coffset, nb * 8);
         memcpy(f->h_wblk + nb * 8, w->blk_clen, nb * 4);
         memcpy(f->h_wblk + nb * 12, w->blk_crc, nb * 4);
@@ -1791,6 +1807,18 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         // (a task that found its pool full took its room all the same: the counters can exceed the capacities)
         const size_t ng = (size_t)std::min<unsigned long long>(used[0], (unsigned long long)w->cap_global),
                      nt = (size_t)std::min<unsigned long long>(used[1], (unsigned long long)w->cap_target);
+        for (int which = 0; which < 2; ++which) {
+            int32_t** h = which ? &f->h_tpool : &f->h_gpool;
+            size_t* cap = which ? &f->cap_htpool : &f->cap_hgpool;
+            const size_t need = ((which ? nt : ng) + 16) * 4;
+            if (need > *cap) {
+                const size_t c = std::max(need, *cap + *cap / 8);
+                if (*h) (void)hipHostFree(*h);
+                *h = nullptr; *cap = 0;
+                ICHK(f, hipHostMalloc((void**)h, c, hipHostMallocDefault));
+                *cap = c;
+            }
+        }
         if (ng) ICHK(f, hipMemcpyAsync(f->h_gpool, f->d_gpool, ng * 4, hipMemcpyDeviceToHost, f->wstream));
         if (nt) ICHK(f, hipMemcpyAsync(f->h_tpool, f->d_tpool, nt * 4, hipMemcpyDeviceToHost, f->wstream));
         ICHK(f, hipEventRecord(f->wdone, f->wstream));
@@ -1898,7 +1926,7 @@ int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const ui
     }
     ICHK(f, hipSetDevice(f->device));
     if ((size_t)total + 64 > f->cap_dense) {
-        const size_t c = std::max((size_t)total + 64, f->cap_dense + f->cap_dense / 2);
+        const size_t c = std::max((size_t)total + 64, f->cap_dense + f->cap_dense / 8);
         if (f->h_dense) (void)hipHostFree(f->h_dense);
         f->h_dense = nullptr; f->cap_dense = 0;
         ICHK(f, hipHostMalloc((void**)&f->h_dense, c, hipHostMallocDefault));
@@ -1954,7 +1982,7 @@ int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const ui
 int64_t tredgpu_inflater_pinned_bytes(const tredgpu_inflater* f) {
     if (!f) return -2;
     size_t n = f->cap_comp + (f->h_out ? f->cap_out : 0) + f->cap_blocks * (2 * sizeof(int64_t) + 2 * sizeof(int32_t)) + f->cap_dense +
-               f->cap_pieces * sizeof(FetchPiece) + f->cap_wblk + f->cap_wtask + f->cap_wres + f->cap_gpool + f->cap_tpool + f->cap_atask + f->cap_ares;
+               f->cap_pieces * sizeof(FetchPiece) + f->cap_wblk + f->cap_wtask + f->cap_wres + f->cap_hgpool + f->cap_htpool + f->cap_atask + f->cap_ares;
     return (int64_t)n;
 }
 
