@@ -1,0 +1,23 @@
+# tools/gpu_final.sh -- the round's evidence in one GPU call, all on the tree's build:
+#   every rocprofv3 summary (tools/profile_all.sh), the randomised campaigns, the product CLI's rate, the concurrency probe,
+#   the default bench (as the driver runs it) and the GPU test suite.  Everything lands under gpurun_out/ and profiles/.
+cd $GRAFT_REPO_ROOT
+R=${1:-r05}
+mkdir -p gpurun_out
+O=gpurun_out/${R}_final.txt; : > $O
+python -c "from tredparse_amd import _lib; print(_lib.version())" >> $O
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/${R}_gputest.log 2>&1; tail -3 gpurun_out/${R}_gputest.log >> $O
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err; cp bench_detail.json gpurun_out/${R}_bench_detail.json; cat gpurun_out/${R}_bench.json >> $O
+timeout 600 python tools/cli_rate.py 12288 512 > gpurun_out/${R}_cli_rate.json 2> gpurun_out/cli_rate.err; cat gpurun_out/${R}_cli_rate.json >> $O; tail -2 gpurun_out/cli_rate.err >> $O
+timeout 400 python tools/fuzz_walk.py 250 5 > gpurun_out/${R}_fuzz_walk.json 2>> $O
+timeout 200 python tools/fuzz_inflate.py 120 20281001 > gpurun_out/${R}_fuzz_inflate.json 2>> $O
+timeout 400 python tools/fuzz_parity.py 120 20291001 > gpurun_out/${R}_fuzz_parity.json 2>> $O
+timeout 300 python tools/fuzz_selfcheck.py 100 3 > gpurun_out/${R}_fuzz_selfcheck.json 2>> $O
+timeout 300 python tools/fuzz_grid.py 20 3 > gpurun_out/${R}_fuzz_grid.json 2>> $O
+timeout 300 python tools/fuzz_hist.py 1000 3 > gpurun_out/${R}_fuzz_hist.json 2>> $O
+for f in walk inflate parity selfcheck grid hist; do echo "fuzz_$f: $(head -c 400 gpurun_out/${R}_fuzz_$f.json)" >> $O; done
+python tools/conc_probe.py make /tmp/cp_bams > /dev/null 2>&1
+timeout 600 python tools/conc_probe.py sweep /tmp/cp_bams 2> gpurun_out/conc_err.txt | tail -1 > gpurun_out/${R}_conc_probe.json; head -c 1500 gpurun_out/${R}_conc_probe.json >> $O
+timeout 2400 bash tools/profile_all.sh $R >> $O 2>&1
+ls profiles | grep "^${R}_" | head -80 >> $O
+tail -c 6000 $O

@@ -103,7 +103,8 @@ def set_argparse():
                    help="driver processes per GPU, each with --cpus scan threads and its share of the samples (auto: from "
                         "the usable CPUs and --gpus by shard.driver_plan, never more than one per 32 samples)")
     g.add_argument("--gpu", type=int, default=0, help="device index when --gpus is 1")
-    g.add_argument("--batch-samples", type=int, default=64, help="samples per GPU batch")
+    g.add_argument("--batch-samples", type=int, default=None,
+                   help="samples per GPU batch (default: 64; 12 with --gpu-inflate, where a batch is also one decode + walk call)")
     g.add_argument("--gpu-inflate", action="store_true",
                    help="inflate the BAMs' BGZF blocks on the GPU, --batch-samples samples per launch (needs --cpus > 1; "
                         "pays when several driver processes share the host's cores: see DESIGN.md 4.4)")
@@ -1194,6 +1195,8 @@ def main(args, quiet=False):
         args.cpus = default_cpus(int(os.environ.get("WORLD_SIZE", "1")), pinned, usable)
     elif args.cpus is not None and pinned:
         args.cpus = max(1, min(args.cpus, len(pinned)))         # never more scan threads than this rank's CPU set holds
+    if args.batch_samples is None:
+        args.batch_samples = 12 if args.gpu_inflate else 64
     logger.setLevel(getattr(logging, args.log))
     logging.getLogger("tredparse_amd.bam").setLevel(getattr(logging, args.log))
     t0 = time.time()
