@@ -13,16 +13,21 @@ How it runs
   * started directly: this process is a launcher that NEVER touches a GPU.  For every rank count n of the sweep
     (1, 2, 4, 8 up to the GPUs visible, and --gpus itself) it starts n child ranks (tredparse_amd.shard.spawn_ranks:
     HIP_VISIBLE_DEVICES = one device per child, rank r on device r mod visible), collects their per-rank records,
-    then times the CPU baseline on 1 core and on all host cores, and prints ONE JSON line: the record of
-    n = --gpus with `scaling` (one entry per n), `cpu_baseline` (all cores) and `cpu_baseline_1core`.
-    On a 1-GPU box the sweep adds n = 2 with both ranks on the one GPU (marked oversubscribed: a check of the
-    launcher, not a scaling point).
+    runs the end-to-end legs from BAM files (run_e2e: the host-only leg and THE plan of shard.driver_plan, steady state),
+    the extra one-GPU legs (streamed, configs[4], 100 / 250 bp), and times the CPU baseline on 1 core and on all
+    host cores.
+
+Output: the LAST stdout line is one compact JSON object (< 4 KB, compact_line): the contract's keys, `roofline`,
+`cpu_baseline`, `end_to_end`, one small object per leg.  The full record -- per-rank and per-driver detail, counters,
+notes, every plan of an --e2e-sweep -- goes to bench_detail.json next to this script (and to stderr).
 
 Roofline of the dominant kernel (sw_cont_kernel, integer VALU bound; HIP-event timed on the context's own stream):
 `achieved` = DP cells the kernel really swept (read rows x columns, padding rows and empty quad slots excluded) per
-second, `peak` = int32 VALU lane-ops/s / 10 ops per cell.  The brute-force cell count of SURVEY 8(d) over the same
-time is `effective_TCUPS` (it exceeds the hardware peak because of the exact shortcuts; it is not a hardware rate).
-`traffic` = HBM bytes per launch from the rocprofv3 PMC passes summarised in profiles/ (FETCH_SIZE + WRITE_SIZE).
+second, `peak` = int32 VALU lane-ops/s / 10 ops per cell, `mix_ceiling_frac` = what the kernel's instruction mix can
+reach of that peak on gfx950 (mix_ceiling).  The brute-force cell count of SURVEY 8(d) over the same time is
+`effective_TCUPS` (it exceeds the hardware peak because of the exact shortcuts; it is not a hardware rate).
+`traffic` = HBM bytes per launch from the rocprofv3 PMC passes summarised in profiles/ (FETCH_SIZE + WRITE_SIZE), cited
+only when the summary was taken on THIS build.
 """
 import argparse
 import json

@@ -162,3 +162,26 @@ def test_log_debug_prints_the_references_diagnostics(engine, caplog):
         got = [float(x) for x in f[3:]]
         assert len(got) == 5 and max(abs(a - b) for a, b in zip(got, w[2:])) <= 1e-6
     assert tred._py2_str(-61.0) == "-61.0" and tred._py2_str(1e-05) == "1e-05" and tred._py2_str(-0.020661398520546232) == "-0.0206613985205"
+
+
+def test_high_coverage_samples_stay_on_the_device_walk(engine, tmp_path):
+    """the pair pools of the device walk were sized for ~30x and from ~32x on regions fell back to the host
+    without a word.  60x and 100x samples (4 000 and 7 000 pair lengths per +-10 kb region) through
+    run_many(inflate_device=0, gpu_walk=True): no region declined for want of room, byte-identical results."""
+    from tredparse_amd import synth, synth_bam
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1", "FRDA", "SCA10", "ULD")]
+    names = [l["name"] for l in loci]
+    repo = TREDsRepo()
+    args = []
+    for cov, seed in ((60, 5), (100, 6)):
+        made = synth_bam.make_bams(str(tmp_path / "c{}".format(cov)), 2, seed=seed, loci=loci, p=synth.SynthParams(coverage=cov), prefix="c{}_".format(cov))
+        args += [(key, path, repo, names, 300, False, False, True, True, "ERROR") for key, path, _ in made]
+    plain = tredmod.run_many(args, engine, batch=4, threads=3)
+    for k in tredmod.TIMING:
+        tredmod.TIMING[k] = 0
+    walked = tredmod.run_many(args, engine, batch=4, threads=3, inflate_device=0, gpu_walk=True)
+    for a, b in zip(walked, plain):
+        assert tredmod.dumps_result(a) == tredmod.dumps_result(b)
+    t = tredmod.TIMING
+    assert t["walk_regions"] == len(args) * len(names) and t["walk_declined"] == 0 and t["inflate_failed"] == 0
+    assert all(r["tredCalls"][n + ".PEDP"] > 20 for r in walked for n in names)        # (spanning pairs at that depth)
