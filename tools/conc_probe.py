@@ -68,13 +68,13 @@ def one_call(inf, w):
     for at, n, coffset, hostflags, nt in w["host"]:
         need[at:at + n] = walk_need(coffset, hostflags, res[t0:t0 + nt], alt_need[at:at + n])
         t0 += nt
-    inf.fetch(need)
+    inf.fetch_dense(need)
     return int((res["status"] != 0).sum())
 
 
 def run(root, m, threads, seconds):
     from tredparse_amd import _lib
-    infs = [_lib.Inflater(0) for _ in range(threads)]
+    infs = [_lib.Inflater(0, host_out=False) for _ in range(threads)]      # (as the product's feeder uses them: dense fetch by kernel)
     work = [prepare(root, m, inf) for inf in infs]
     for inf, w in zip(infs, work):
         one_call(inf, w)                      # warm: allocations, pinned staging
@@ -125,7 +125,7 @@ def main():
                      "ms_per_call": round(float(np.mean([o["ms_per_call"] for o in outs])), 2)})
         print(json.dumps(rows[-1]), flush=True)
     from tredparse_amd import _lib
-    print(json.dumps({"library": _lib.version(), "what": "tredgpu_inflate_walk + fetch of the wanted blocks, 30x samples, "
+    print(json.dumps({"library": _lib.version(), "what": "tredgpu_inflate_walk + tredgpu_inflater_fetch_dense of the wanted blocks, 30x samples, "
                       "callers looping for 4 s", "rows": rows}))
 
 
