@@ -222,6 +222,9 @@ int64_t tredbam_plan_blocks(tredbam* b, int64_t* coffset, int32_t* clen, uint32_
 int tredbam_scan_pe(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
                     const tredbam_scan_opts* opts, const tredbam_walk_result* pe, const int32_t* pe_global,
                     const int32_t* pe_target, tredbam_unit* units);
+/* how many entries pe_global / pe_target of the next tredbam_scan_pe / tredbam_scan_walked hold: every pe[i] slice is then
+ * checked against them (-2 on a slice outside; negative: unknown, the slices are trusted as the caller's) */
+int tredbam_pe_pool_sizes(tredbam* b, int64_t n_global, int64_t n_target);
 
 /* The JSON text of one locus' `details` list exactly as the driver prints it inside a sample's file (what
  * json.dumps(list, sort_keys=True, indent=4, separators=(',', ': ')) yields for the list at nesting depth 2:

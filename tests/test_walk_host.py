@@ -161,3 +161,34 @@ def test_plan_drivers_follows_the_rule_and_the_cohort_size():
     assert t.plan_drivers(a, 5000, 16) == (2, 6)
     a8 = argparse.Namespace(gpus=8, drivers="auto", cpus=None, gpu_inflate=True)
     assert t.plan_drivers(a8, 8000, 128) == (3, 5)
+
+
+def test_native_scan_checks_the_pair_length_slices_itself():
+    """tredbam_scan_pe read pe_global + global_first without knowing how long the pool is; only the Python
+    wrapper checked.  tredbam_pe_pool_sizes hands the lengths over and the library refuses a slice outside them."""
+    import ctypes as C
+    from tredparse_amd.bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays
+    from tredparse_amd.meta import TREDsRepo
+    repo = TREDsRepo("hg38", sites=os.path.join(GOLD, "no_sites"))
+    f = bamio.AlignmentFile(os.path.join(GOLD, "bam", "t001.bam"))
+    if not hasattr(f, "plan_walks"):
+        pytest.skip("no native BAM layer")
+    names = ["HD"]
+    sites, regions = _site_arrays(repo, names, [repo[n] for n in names], f)
+    res = np.zeros(1, bamio.WALK_RESULT_DTYPE)
+    res[0] = (0, 5, 2, 0, 0, 0, 0, 0)                           # five global and two target lengths, "from elsewhere"
+    gp, tp = np.arange(5, dtype=np.int32) + 300, np.arange(2, dtype=np.int32) + 400
+    units, pools = f.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(res, gp, tp))
+    assert pools["global_lens"].tolist() == gp.tolist() and pools["target_lens"].tolist() == tp.tolist()
+    # the same call straight at the library with pools declared SHORTER than the slices: refused, nothing read
+    o = bamio.ScanOpts(150, SPAN, FLANKMATCH, DNAPE_ELONGATE, SPAN, 1, 1, 1)
+    out = np.zeros(1, bamio.SCAN_UNIT_DTYPE)
+    alts = regions if len(regions) else np.zeros(1, bamio.REGION_DTYPE)
+    assert f._lib.tredbam_pe_pool_sizes(f._h, 4, 2) == 0
+    rc = f._lib.tredbam_scan_pe(f._h, sites.ctypes.data, 1, alts.ctypes.data, C.byref(o), res.ctypes.data, gp.ctypes.data, tp.ctypes.data,
+                                out.ctypes.data)
+    assert rc == -2 and "outside the pools" in f._err()
+    assert f._lib.tredbam_pe_pool_sizes(f._h, 5, 2) == 0
+    assert f._lib.tredbam_scan_pe(f._h, sites.ctypes.data, 1, alts.ctypes.data, C.byref(o), res.ctypes.data, gp.ctypes.data, tp.ctypes.data,
+                                  out.ctypes.data) == 0
+    f.close()

@@ -385,6 +385,8 @@ def _native():
             lib.tredbam_scan_walked.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             lib.tredbam_scan_walked.restype = C.c_int
+            lib.tredbam_pe_pool_sizes.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+            lib.tredbam_pe_pool_sizes.restype = C.c_int
             lib.tredbam_details_json.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_int64]
             lib.tredbam_details_json.restype = C.c_int64
             lib.tredbam_sparse_json.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64]
@@ -791,6 +793,7 @@ class NativeAlignmentFile(object):
                              or (res["global_first"][ok] + res["n_global"][ok]).max() > len(pe[1])
                              or (res["target_first"][ok] + res["n_target"][ok]).max() > len(pe[2])):
                 raise ValueError("walk results point outside their pools")
+            self._lib.tredbam_pe_pool_sizes(self._h, len(pe[1]), len(pe[2]))      # (the library checks every slice again)
             if alt is not None:
                 ar = np.ascontiguousarray(alt, ALT_RESULT_DTYPE)
                 if len(ar) < int((sites["alt_first"] + sites["n_alt"]).max() if len(sites) else 0):

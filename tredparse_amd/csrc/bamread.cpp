@@ -97,6 +97,7 @@ struct tredbam {
     std::vector<Planned> plan;
     std::unordered_map<int64_t, Preloaded> preloaded;
     int64_t preload_hits = 0, preload_misses = 0;
+    int64_t pe_pool_global = -1, pe_pool_target = -1;   // lengths of the pools tredbam_scan_pe / _walked index (tredbam_pe_pool_sizes)
     tredbam_inflate::Tables inflate_tables;        // decoding tables of the block decoder (inflate_block.h)
     // header
     std::vector<std::string> ref_names;
@@ -1171,6 +1172,10 @@ int scan_impl(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tred
                                                        o->span, b->sc_global, b->sc_target);
             else if (hinted) {
                 rc = n < 0 ? (int)n : 0;                                    // computed elsewhere, in the same order
+                if (rc == 0 && (pe[i].global_first < 0 || pe[i].target_first < 0 || pe[i].n_global < 0 || pe[i].n_target < 0 ||
+                                (b->pe_pool_global >= 0 && pe[i].global_first + pe[i].n_global > b->pe_pool_global) ||
+                                (b->pe_pool_target >= 0 && pe[i].target_first + pe[i].n_target > b->pe_pool_target)))
+                    return fail(b, -2, "pair-length slices of site %d lie outside the pools handed in", (int)i);
                 if (rc == 0) {
                     b->sc_global.insert(b->sc_global.end(), pe_global + pe[i].global_first, pe_global + pe[i].global_first + pe[i].n_global);
                     b->sc_target.insert(b->sc_target.end(), pe_target + pe[i].target_first, pe_target + pe[i].target_first + pe[i].n_target);
@@ -1193,6 +1198,13 @@ extern "C" {
 int tredbam_scan(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
                  const tredbam_scan_opts* o, tredbam_unit* units) {
     return scan_impl(b, sites, n_sites, alts, o, units, nullptr, nullptr, nullptr, nullptr);
+}
+
+int tredbam_pe_pool_sizes(tredbam* b, int64_t n_global, int64_t n_target) {
+    if (!b) return -2;
+    b->pe_pool_global = n_global;
+    b->pe_pool_target = n_target;
+    return 0;
 }
 
 int tredbam_scan_pe(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
