@@ -712,7 +712,6 @@ constexpr int WALK_PAIR_CAP_SMALL = 4096;         // ... and what a launch whose
                                                   // find LDS on the CUs a walk occupies (two walks of 70 KB nearly fill a CU's 160 KB)
 constexpr int WALK_REPEAT_CAP = 2048;
 constexpr int WALK_WINDOW = 6144;                 // bytes of the block stream in LDS
-constexpr int WALK_HEAD = 512;                    // a record's head (fixed fields, name, CIGAR) should lie in the window
 enum { WALK_OK = 0, WALK_NOT_PLANNED = 1, WALK_BAD_BLOCK = 2, WALK_BAD_RECORD = 3, WALK_TABLE_FULL = 4, WALK_NO_END = 5, WALK_POOL_FULL = 6,
        WALK_TAG_CLASH = 7 };
 
@@ -848,7 +847,75 @@ static_assert(sizeof(WalkRec) == 24 && sizeof(WalkFields) == 32, "record tuples"
 struct WalkChained { int32_t status, n; };                       // per region: how the chain ended, records listed
 
 constexpr int CHAIN_BATCH = 64;
-constexpr int WALK_BATCH = 32;                    // (records per step of the alternative loci's walk)
+
+// The next (up to) CHAIN_BATCH records of chunk `ch` from the cursor on: lane j ends up with record j's place (where its
+// length word lies in `out`, its virtual offset, the virtual offset of what follows it).  chunk_done: the chunk's end or the
+// first record beyond the region was reached (that record is not listed); status: why the walk cannot go on.
+__device__ __forceinline__ int chain_batch(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk& ch, WalkCursor& cur,
+                                           WalkReader& rd, WalkLds& S, int lane, int64_t& my_a0, uint64_t& my_at, uint64_t& my_after,
+                                           bool& chunk_done, int& status) {
+    int nb = 0, rc;
+    while (nb < CHAIN_BATCH) {
+        // ---- the fast path: records whose length word, contig and position lie in this block AND in the window, and
+        //      that end inside the block -- 32-bit arithmetic on (offset in the block, offset in the window) only, one
+        //      LDS access per record (~40 instructions; a lone wavefront issues one every ~5 cycles, and the general
+        //      step below, 64-bit throughout, took ~250 of them: 2.7 ms per region of 4 000 records) ----
+        {
+            const int bsz = (int)cur.size;
+            int up = (int)cur.upos;
+            int wo = (int)walk_uniform((uint32_t)((cur.first + cur.upos) - rd.base));     // (garbage when far outside: checked below)
+            const bool near = cur.first + cur.upos >= rd.base && cur.first + cur.upos < rd.base + WALK_WINDOW;
+            // where in this block tell() reaches the chunk's end (tell() = here | upos inside a block)
+            const uint64_t endv = ch.end_voffset;
+            const int up_end = (endv >> 16) == (uint64_t)cur.coff ? (int)(endv & 0xFFFFu) : (endv > cur.here ? 0x7FFFFFFF : 0);
+            bool stop = false;
+            if (near) {
+                while (nb < CHAIN_BATCH && up + 12 <= bsz && up < up_end && wo + 16 <= WALK_WINDOW) {
+                    const lds_u32* p = (const lds_u32*)(S.window + (wo & ~3));
+                    const uint32_t x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+                    const uint32_t by = (uint32_t)(wo & 3);
+                    const int32_t size = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x1, x0, by));
+                    const int32_t rtid = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x2, x1, by));
+                    const int32_t rpos = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x3, x2, by));
+                    const int nxt = up + 4 + size;
+                    if (size < 32 || nxt > bsz) break;                    // (the general step decides: a bad record, or one that crosses into the next block)
+                    if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { stop = true; break; }
+                    if (lane == nb) {
+                        my_a0 = cur.first + up;
+                        my_at = cur.here | (uint64_t)(uint32_t)up;
+                        my_after = nxt >= bsz ? cur.next : cur.here | (uint64_t)(uint32_t)nxt;
+                    }
+                    up = nxt;
+                    wo += 4 + size;
+                    ++nb;
+                }
+                cur.upos = up;
+            }
+            if (stop) { chunk_done = true; break; }
+            if (nb >= CHAIN_BATCH) break;
+        }
+        // ---- the general step: one record, wherever it lies ----
+        const uint64_t at = cur.tell();
+        if (at >= ch.end_voffset) { chunk_done = true; break; }
+        int64_t a0, r;
+        if (cur.upos + 4 <= cur.size) { a0 = cur.first + cur.upos; cur.upos += 4; }       // (nearly always)
+        else if ((rc = cur.take(v, T, 4, &a0)) != 0) { status = rc; break; }
+        if (!rd.inside(a0, 16)) {
+            if (rd.ahead_base <= a0 && a0 + 16 <= rd.ahead_base + WALK_WINDOW) rd.commit(); else rd.fill(a0);
+            rd.prefetch(rd.base + WALK_WINDOW - 16);       // (the window after this one, while this one is walked)
+        }
+        const int32_t size = (int32_t)rd.u32(a0);
+        if (size < 32) { status = WALK_BAD_RECORD; break; }
+        if (cur.upos + size <= cur.size) cur.upos += size;
+        else if ((rc = cur.take(v, T, size, &r)) != 0) { status = rc; break; }
+        const int32_t rtid = (int32_t)rd.u32(a0 + 4), rpos = (int32_t)rd.u32(a0 + 8);
+        if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { chunk_done = true; break; }   // beyond the region: the walk over this chunk ends
+        if (lane == nb) { my_a0 = a0; my_at = at; my_after = cur.tell(); }
+        ++nb;
+    }
+    return nb;
+}
+
 __global__ void __launch_bounds__(LANES) walk_chain_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
                                                            const int64_t* rec_base, WalkRec* recs, WalkChained* chained) {
     __shared__ __attribute__((aligned(16))) uint8_t window[WALK_WINDOW];
@@ -872,67 +939,9 @@ __global__ void __launch_bounds__(LANES) walk_chain_kernel(WalkView v, const tre
         cur.upos = ch.begin_upos;
         bool chunk_done = false;
         while (!chunk_done && status == WALK_OK) {
-            int nb = 0;
             int64_t my_a0 = 0;
             uint64_t my_at = 0, my_after = 0;
-            while (nb < CHAIN_BATCH) {
-                // ---- the fast path: records whose length word, contig and position lie in this block AND in the window, and
-                //      that end inside the block -- 32-bit arithmetic on (offset in the block, offset in the window) only, one
-                //      LDS access per record (~40 instructions; a lone wavefront issues one every ~5 cycles, and the general
-                //      step below, 64-bit throughout, took ~250 of them: 2.7 ms per region of 4 000 records) ----
-                {
-                    const int bsz = (int)cur.size;
-                    int up = (int)cur.upos;
-                    int wo = (int)walk_uniform((uint32_t)((cur.first + cur.upos) - rd.base));     // (garbage when far outside: checked below)
-                    const bool near = cur.first + cur.upos >= rd.base && cur.first + cur.upos < rd.base + WALK_WINDOW;
-                    // where in this block tell() reaches the chunk's end (tell() = here | upos inside a block)
-                    const uint64_t endv = ch.end_voffset;
-                    const int up_end = (endv >> 16) == (uint64_t)cur.coff ? (int)(endv & 0xFFFFu) : (endv > cur.here ? 0x7FFFFFFF : 0);
-                    bool stop = false;
-                    if (near) {
-                        while (nb < CHAIN_BATCH && up + 12 <= bsz && up < up_end && wo + 16 <= WALK_WINDOW) {
-                            const lds_u32* p = (const lds_u32*)(S.window + (wo & ~3));
-                            const uint32_t x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
-                            const uint32_t by = (uint32_t)(wo & 3);
-                            const int32_t size = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x1, x0, by));
-                            const int32_t rtid = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x2, x1, by));
-                            const int32_t rpos = (int32_t)walk_uniform(__builtin_amdgcn_alignbyte(x3, x2, by));
-                            const int nxt = up + 4 + size;
-                            if (size < 32 || nxt > bsz) break;                    // (the general step decides: a bad record, or one that crosses into the next block)
-                            if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { stop = true; break; }
-                            if (lane == nb) {
-                                my_a0 = cur.first + up;
-                                my_at = cur.here | (uint64_t)(uint32_t)up;
-                                my_after = nxt >= bsz ? cur.next : cur.here | (uint64_t)(uint32_t)nxt;
-                            }
-                            up = nxt;
-                            wo += 4 + size;
-                            ++nb;
-                        }
-                        cur.upos = up;
-                    }
-                    if (stop) { chunk_done = true; break; }
-                    if (nb >= CHAIN_BATCH) break;
-                }
-                // ---- the general step: one record, wherever it lies ----
-                const uint64_t at = cur.tell();
-                if (at >= ch.end_voffset) { chunk_done = true; break; }
-                int64_t a0, r;
-                if (cur.upos + 4 <= cur.size) { a0 = cur.first + cur.upos; cur.upos += 4; }       // (nearly always)
-                else if ((rc = cur.take(v, T, 4, &a0)) != 0) { status = rc; break; }
-                if (!rd.inside(a0, 16)) {
-                    if (rd.ahead_base <= a0 && a0 + 16 <= rd.ahead_base + WALK_WINDOW) rd.commit(); else rd.fill(a0);
-                    rd.prefetch(rd.base + WALK_WINDOW - 16);       // (the window after this one, while this one is walked)
-                }
-                const int32_t size = (int32_t)rd.u32(a0);
-                if (size < 32) { status = WALK_BAD_RECORD; break; }
-                if (cur.upos + size <= cur.size) cur.upos += size;
-                else if ((rc = cur.take(v, T, size, &r)) != 0) { status = rc; break; }
-                const int32_t rtid = (int32_t)rd.u32(a0 + 4), rpos = (int32_t)rd.u32(a0 + 8);
-                if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { chunk_done = true; break; }   // beyond the region: the walk over this chunk ends
-                if (lane == nb) { my_a0 = a0; my_at = at; my_after = cur.tell(); }
-                ++nb;
-            }
+            const int nb = chain_batch(v, T, ch, cur, rd, S, lane, my_a0, my_at, my_after, chunk_done, status);
             if (n + nb > cap) { status = WALK_TABLE_FULL; break; }
             if (lane < nb) mine[n + lane] = WalkRec{my_a0, my_at, my_after};
             n += nb;
@@ -1199,9 +1208,19 @@ __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tred
 // go into the region's result (at most six: the region is the host's otherwise) and the blocks they lie in are marked
 // for the copy back.
 constexpr int ALT_MATCH_CAP = 6;
-__device__ int walk_alt_records(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk* chunks, WalkReader& rd,
+// the block of [lo, hi) that holds byte `addr` of `out` (the last one that begins at or before it: empty blocks hold nothing)
+__device__ inline int walk_block_of(const WalkView& v, int lo, int hi, int64_t addr) {
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (v.ooff[mid] <= addr) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ int walk_alt_records(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk* chunks, WalkReader& rd, WalkLds& S,
                                 tredgpu_alt_result& R, uint8_t* need, int lane) {
     if (T.n_chunks < 0) return WALK_NOT_PLANNED;
+    const uint8_t* out = v.out;
     int found = 0;
     for (int c = 0; c < T.n_chunks; ++c) {
         const tredgpu_walk_chunk ch = chunks[T.chunk_first + c];
@@ -1212,58 +1231,40 @@ __device__ int walk_alt_records(const WalkView& v, const tredgpu_walk_task& T, c
         cur.upos = ch.begin_upos;
         bool chunk_done = false;
         while (!chunk_done) {
-            int nb = 0, err = WALK_OK;
+            // the chain as the pair walk has it (chain_batch: the records up to the first one beyond the region), then every
+            // lane reads the fields of ONE of the records found, from where the decoder wrote them
+            int err = WALK_OK;
             int64_t my_a0 = 0;
-            uint64_t my_at = 0;
-            int32_t my_size = 0, my_kb = 0, my_ka = 0;
-            while (nb < WALK_BATCH) {
-                const uint64_t at = cur.tell();
-                if (at >= ch.end_voffset) { chunk_done = true; break; }
-                int64_t a0, r;
-                const bool word_here = cur.upos + 4 <= cur.size;
-                const WalkCursor before = cur;
-                const int kb = cur.upos < cur.size ? cur.k : cur.k + 1;   // the block the record starts in
-                if (word_here) { a0 = cur.first + cur.upos; cur.upos += 4; }
-                else if ((rc = cur.take(v, T, 4, &a0)) != 0) { err = rc; break; }
-                if (!rd.inside(a0, WALK_HEAD)) {
-                    if (nb > 0) { cur = before; break; }
-                    rd.fill(a0);
-                }
-                const int32_t size = (int32_t)rd.u32(a0);
-                if (size < 32) { err = WALK_BAD_RECORD; break; }
-                if (cur.upos + size <= cur.size) cur.upos += size;
-                else if ((rc = cur.take(v, T, size, &r)) != 0) { err = rc; break; }
-                if (lane == nb) { my_a0 = a0; my_at = at; my_size = size; my_kb = kb; my_ka = cur.k; }
-                ++nb;
-            }
+            uint64_t my_at = 0, my_after = 0;
+            const int nb = chain_batch(v, T, ch, cur, rd, S, lane, my_a0, my_at, my_after, chunk_done, err);
             if (err != WALK_OK) chunk_done = true;
             const bool mine = lane < nb;
-            int32_t rtid = 0, rpos = 0, rend = -1, mtid = -1, mpos = -1;
+            int32_t rtid = 0, rpos = 0, rend = -1, mtid = -1, mpos = -1, my_size = 0;
             bool bad = false;
             if (mine) {
                 const int64_t r = my_a0 + 4;
-                rtid = (int32_t)rd.vu32(r);
-                rpos = (int32_t)rd.vu32(r + 4);
-                const uint32_t l_name = rd.vu8(r + 8), n_cigar = rd.vu16(r + 12), flag = rd.vu16(r + 14);
-                const int32_t l_seq = (int32_t)rd.vu32(r + 16);
-                mtid = (int32_t)rd.vu32(r + 20);
-                mpos = (int32_t)rd.vu32(r + 24);
+                my_size = (int32_t)g_u32(out, my_a0);
+                rtid = (int32_t)g_u32(out, r);
+                rpos = (int32_t)g_u32(out, r + 4);
+                const uint32_t l_name = g_u8(out, r + 8), n_cigar = g_u16(out, r + 12), flag = g_u16(out, r + 14);
+                const int32_t l_seq = (int32_t)g_u32(out, r + 16);
+                mtid = (int32_t)g_u32(out, r + 20);
+                mpos = (int32_t)g_u32(out, r + 24);
                 bad = l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)my_size;
-                if (!bad && !(flag & 0x4) && n_cigar > 0 && rtid == T.tid && rpos < T.end) {
+                // (the CIGAR only of the few records whose mate lies in the window: the others cannot count whatever their end)
+                if (!bad && !(flag & 0x4) && n_cigar > 0 && rtid == T.tid && rpos < T.end && mtid == T.tstart && mpos >= T.win_lo && mpos <= T.win_hi) {
                     const int64_t cig = r + 32 + l_name;
                     int64_t e = rpos;
                     for (uint32_t q = 0; q < n_cigar; ++q) {
-                        const uint32_t op = rd.vu32(cig + 4 * q);
+                        const uint32_t op = g_u32(out, cig + 4 * q);
                         if ((0x18Du >> (op & 15)) & 1) e += op >> 4;
                     }
                     rend = (int32_t)e;
                 }
             }
-            const bool off_region = mine && (rtid != T.tid || rpos >= T.end);
-            const bool stops = off_region && (rtid > T.tid || (rtid == T.tid && rpos >= T.end));
-            const uint64_t stop_mask = __ballot(stops), bad_mask = __ballot(mine && !off_region && bad);
-            const int first_stop = stop_mask ? __builtin_ctzll(stop_mask) : 64, first_bad = bad_mask ? __builtin_ctzll(bad_mask) : 64;
-            const int limit = first_stop < first_bad ? first_stop : first_bad;
+            const bool off_region = mine && (rtid != T.tid || rpos >= T.end);    // (a contig before the region's: the chain stops at the others)
+            const uint64_t bad_mask = __ballot(mine && !off_region && bad);
+            const int limit = bad_mask ? __builtin_ctzll(bad_mask) : 64;
             const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
             const bool keep = mine && lane < limit && !off_region && e > T.start;
             uint64_t hits = __ballot(keep && mtid == T.tstart && mpos >= T.win_lo && mpos <= T.win_hi);
@@ -1273,12 +1274,13 @@ __device__ int walk_alt_records(const WalkView& v, const tredgpu_walk_task& T, c
                 if (found >= ALT_MATCH_CAP) return WALK_POOL_FULL;
                 if (lane == j) {
                     R.vbeg[found] = my_at;
-                    for (int k = my_kb; k <= my_ka; ++k) need[k] = 1;
+                    const int kb = walk_block_of(v, T.block_first, T.block_end, my_a0);                     // first and last byte
+                    const int ka = walk_block_of(v, T.block_first, T.block_end, my_a0 + 3 + (int64_t)my_size);
+                    for (int k = kb; k <= ka; ++k) need[k] = 1;
                 }
                 ++found;
             }
-            if (first_bad < first_stop) return WALK_BAD_RECORD;
-            if (first_stop < 64) { chunk_done = true; err = WALK_OK; }
+            if (bad_mask) return WALK_BAD_RECORD;
             if (err != WALK_OK) return err;
         }
     }
@@ -1298,7 +1300,7 @@ __global__ void __launch_bounds__(LANES) alt_walk_kernel(WalkView v, const tredg
     rd.out = v.out; rd.out_end = v.out_end; rd.S = &S; rd.base = (int64_t)1 << 60; rd.lane = lane; rd.ahead_base = (int64_t)1 << 60;
     // (every lane holds the result; the lane that owns a record writes that record's offset into ITS copy: gather them)
     tredgpu_alt_result R = {};
-    const int status = walk_alt_records(v, T, chunks, rd, R, need, lane);
+    const int status = walk_alt_records(v, T, chunks, rd, S, R, need, lane);
     tredgpu_alt_result out = {};
     out.status = status;
     if (status == WALK_OK) {
