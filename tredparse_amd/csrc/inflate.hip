@@ -704,13 +704,11 @@ struct WalkView {
 };
 struct WalkPair { int64_t name_at, name2_at; int32_t a_pos, a_lead, b_end, b_trail; uint16_t name_len; uint8_t a_rev, b_rev, complete, pad[3]; };
 static_assert(sizeof(WalkPair) == 40, "WalkPair layout");
-struct WalkRepeat { int32_t pair; int32_t pad; int64_t name_at; };   // a third, fourth ... record under a pair's tag
 constexpr int WALK_PAIR_CAP = 8192;               // names per region at most (a +-10 kb window at 30x holds ~2 100) ...
 constexpr int WALK_PAIR_CAP_SMALL = 4096;         // ... and what a launch whose regions are all short is given: 38 instead of
                                                   // 70 KB of LDS per wavefront, so that other kernels' workgroups -- the
                                                   // decoder's, the genotyping kernels' of the other driver processes -- still
                                                   // find LDS on the CUs a walk occupies (two walks of 70 KB nearly fill a CU's 160 KB)
-constexpr int WALK_REPEAT_CAP = 2048;
 constexpr int WALK_WINDOW = 6144;                 // bytes of the block stream in LDS
 enum { WALK_OK = 0, WALK_NOT_PLANNED = 1, WALK_BAD_BLOCK = 2, WALK_BAD_RECORD = 3, WALK_TABLE_FULL = 4, WALK_NO_END = 5, WALK_POOL_FULL = 6,
        WALK_TAG_CLASH = 7 };
@@ -733,7 +731,7 @@ struct WalkLds {                                  // (views into the launch's dy
     lds_u8* window;                               // WALK_WINDOW bytes, 16-byte aligned
     int cap; uint32_t mask;
 };
-constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 8; }     // (pair_walk_kernel: the table alone; the window is the chain kernel's)
+constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 16; }    // (pair_walk_kernel: the table alone, 2 * cap slots of 64 bits)
 
 // Every lane holds the same value: say so (v_readfirstlane), and what is computed from it is computed once, on the
 // scalar unit, with scalar branches -- not 64 times on the vector unit with the exec mask rebuilt at every `if`.
@@ -844,7 +842,9 @@ struct WalkCursor {
 struct WalkRec { int64_t a0; uint64_t at, after; };             // where the record's length word lies in `out`; the virtual offsets of the record and of what follows it
 struct WalkFields { uint32_t h; int32_t rtid, rpos, rend, lead, trail; uint16_t flag, nlen; uint32_t bad; };
 static_assert(sizeof(WalkRec) == 24 && sizeof(WalkFields) == 32, "record tuples");
-struct WalkChained { int32_t status, n; };                       // per region: how the chain ended, records listed
+struct WalkChained { int32_t status, n, mode, klo, khi, pad; };   // per region: how the chain ended, records listed; mode 1: listed by
+                                                                  // walk_chain_par_kernel (places only: walk_parse_kernel works out the
+                                                                  // virtual offsets, the region's blocks lie in [klo, khi)); 0: by walk_chain_kernel
 
 constexpr int CHAIN_BATCH = 64;
 
@@ -916,10 +916,147 @@ __device__ __forceinline__ int chain_batch(const WalkView& v, const tredgpu_walk
     return nb;
 }
 
+// ---- the chain, 64 lanes at once ------------------------------------------------------------------------------------
+// Where a record starts is written in the one before it -- but WHETHER a place is a record's start can be guessed from the
+// place itself (a length word that covers the fixed fields, the region's contig, a name that ends in NUL where the head
+// says it ends), and a guess can be checked: the chunk's bytes are cut into 64 segments, lane 0 starts at the chunk's
+// first record, every other lane at the first place of its segment that looks like a record, and each follows the length
+// words up to where the next lane started.  A lane that arrives EXACTLY there has proved the next lane's start (lane 0's is
+// true; by induction so are all of them); one that steps over it, meets a length below 32 or leaves the planned blocks has
+// not, and then the region is walked by walk_chain_kernel, one record after the other, as before -- so the result is that
+// kernel's whatever the bytes are.  A region's chain is ~60 dependent loads per lane instead of ~4 000 steps of one
+// wavefront (1.08 ms per launch, a third of the pair walk).  The lanes list only where records lie; their virtual offsets
+// (WalkRec at / after) are worked out by walk_parse_kernel, one lane per record.
+constexpr int PAR_SEG_MIN = 2048;                                  // bytes per lane at least
+__device__ inline uint32_t g_u32(const uint8_t* out, int64_t at);
+__device__ inline uint32_t g_u16(const uint8_t* out, int64_t at);
+__device__ inline uint32_t g_u8(const uint8_t* out, int64_t at);
+
+// the virtual offset bamread.cpp's bg_tell gives at byte `addr` of `out`, blocks [lo, hi) following each other in the file:
+// inside a block its offset | the place in it; at a block's end the offset of the block that follows in the file
+__device__ inline uint64_t walk_voffset(const WalkView& v, int lo, int hi, int64_t addr) {
+    int a = lo, b = hi;                                            // the first k of [lo, hi] with ooff[k] >= addr
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (v.ooff[mid] >= addr) b = mid; else a = mid + 1;
+    }
+    if (v.ooff[a] == addr) return a < hi ? (uint64_t)v.bcoff[a] << 16 : (uint64_t)(v.bcoff[hi - 1] + v.bclen[hi - 1]) << 16;
+    return (uint64_t)v.bcoff[a - 1] << 16 | (uint64_t)(addr - v.ooff[a - 1]);
+}
+
+__global__ void __launch_bounds__(LANES) walk_chain_par_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
+                                                               const int64_t* rec_base, WalkRec* recs, WalkChained* chained) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const tredgpu_walk_task T = tasks[t];
+    const uint8_t* out = v.out;
+    WalkRec* mine = recs + rec_base[t];
+    const int64_t cap = rec_base[t + 1] - rec_base[t];
+    const WalkChained serial = {WALK_OK, 0, 0, 0, 0, 0};          // "walk_chain_kernel's"
+    if (T.n_chunks < 0) {
+        if (lane == 0) chained[t] = WalkChained{WALK_NOT_PLANNED, 0, 1, 0, 0, 0};
+        return;
+    }
+    int64_t n = 0;
+    int klo = T.block_end, khi = T.block_first;
+    bool give_up = false;
+    for (int c = 0; c < T.n_chunks && !give_up; ++c) {
+        const tredgpu_walk_chunk ch = chunks[T.chunk_first + c];
+        const int k0 = ch.begin_block;
+        if (k0 < T.block_first || k0 >= T.block_end) { give_up = true; break; }
+        // the chunk's blocks: k0 .. kend, kend the last planned block that begins at or before the chunk's end; all of them
+        // vouched for by the decoder and one behind the other in the file
+        const int64_t coff_e = (int64_t)(ch.end_voffset >> 16);
+        const int upos_e = (int)(ch.end_voffset & 0xFFFFu);
+        int kend = k0 - 1;
+        bool fine = true;
+        for (int kb = k0; kb < T.block_end; kb += LANES) {
+            const int k = kb + lane;
+            const bool in = k < T.block_end && v.bcoff[k] <= coff_e;
+            kend = max(kend, kb - 1 + (int)__popcll(__ballot(in)));          // (bcoff ascends)
+            if (in) {
+                fine = fine && walk_block_ok(v, k);
+                if (k > k0) fine = fine && v.bcoff[k - 1] + v.bclen[k - 1] == v.bcoff[k];
+            }
+            if (__ballot(k < T.block_end && !in) != 0) break;
+        }
+        if (kend < k0 || __ballot(!fine) != 0) { give_up = true; break; }
+        const int64_t a_lim = v.ooff[kend + 1];                              // what lies behind is not this chunk's
+        const int64_t A0 = v.ooff[k0] + ch.begin_upos;
+        int64_t A1 = a_lim;
+        if (v.bcoff[kend] == coff_e) A1 = min(a_lim, v.ooff[kend] + (int64_t)upos_e);
+        else if ((uint64_t)(v.bcoff[kend] + v.bclen[kend]) << 16 < ch.end_voffset) { give_up = true; break; }   // the chunk goes on where the plan ends
+        klo = min(klo, k0); khi = max(khi, kend + 1);
+        if (A0 >= A1) continue;
+        const int64_t len = A1 - A0;
+        const int nseg = (int)min((int64_t)LANES, max((int64_t)1, len / PAR_SEG_MIN));
+        const int64_t L = (len + nseg - 1) / nseg;
+        // ---- where this lane starts ----
+        const int64_t INF = (int64_t)1 << 60;
+        int64_t s = INF;
+        if (lane == 0) s = A0;
+        else if (lane < nseg) {
+            const int64_t p_end = min(A0 + (lane + 1) * L, A1);
+            for (int64_t p = A0 + lane * L; p < p_end && p + 36 <= a_lim; ++p) {
+                const int32_t size = (int32_t)g_u32(out, p);
+                if (size < 36 || size > (1 << 24) || (int32_t)g_u32(out, p + 4) != T.tid) continue;
+                const int32_t rpos = (int32_t)g_u32(out, p + 8), l_seq = (int32_t)g_u32(out, p + 20);
+                const int64_t l_name = g_u8(out, p + 12), n_cigar = g_u16(out, p + 16);
+                if (rpos < 0 || l_seq < 0 || l_name < 1 || 32 + l_name + 4 * n_cigar + ((int64_t)l_seq + 1) / 2 + l_seq > size) continue;
+                if (p + 4 + size > a_lim || g_u8(out, p + 36 + l_name - 1) != 0) continue;
+                s = p;
+                break;
+            }
+        }
+        // the next lane that has a start (or the chunk's end)
+        const uint64_t have = __ballot(s != INF);
+        const uint64_t above = lane < 63 ? have >> (lane + 1) : 0;
+        const int nextl = above ? lane + 1 + __builtin_ctzll(above) : lane;
+        int64_t target = (int64_t)__shfl((unsigned long long)s, nextl, LANES);
+        const bool is_last = above == 0;
+        if (is_last) target = A1;
+        // ---- count: follow the length words from s to target ----
+        enum { CLEAN = 0, STOPPED = 1, ANOMALY = 2 };
+        int outcome = CLEAN, cnt = 0;
+        if (s != INF) {
+            int64_t p = s;
+            while (p < target) {
+                if (p + 12 > a_lim) { outcome = ANOMALY; break; }
+                const int32_t size = (int32_t)g_u32(out, p);
+                const int32_t rtid = (int32_t)g_u32(out, p + 4), rpos = (int32_t)g_u32(out, p + 8);
+                if (size < 32 || p + 4 + (int64_t)size > a_lim) { outcome = ANOMALY; break; }   // (walk_chain_kernel says what it is)
+                if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { outcome = STOPPED; break; }
+                ++cnt;
+                p += 4 + (int64_t)size;
+            }
+            if (outcome == CLEAN && p != target && !is_last) outcome = ANOMALY;     // stepped over the next lane's start: a wrong guess
+        }
+        // the first lane that did not arrive: up to it the chain is the file's
+        const uint64_t not_clean = __ballot(outcome != CLEAN);
+        const int J = not_clean ? __builtin_ctzll(not_clean) : LANES - 1;
+        if (not_clean && __shfl(outcome, J, LANES) == ANOMALY) { give_up = true; break; }
+        const int mycnt = lane <= J ? cnt : 0;
+        const int incl = wave_incl_scan(mycnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (n + total > cap) { give_up = true; break; }              // (WALK_TABLE_FULL: the other kernel's to say)
+        // ---- list: the same steps again (the bytes are in the cache now) ----
+        if (mycnt > 0) {
+            int64_t p = s;
+            WalkRec* o = mine + n + (incl - mycnt);
+            for (int q = 0; q < mycnt; ++q) {
+                o[q].a0 = p;
+                p += 4 + (int64_t)(int32_t)g_u32(out, p);
+            }
+        }
+        n += total;
+    }
+    if (lane == 0) chained[t] = give_up ? serial : WalkChained{WALK_OK, (int32_t)n, 1, klo, khi, 0};
+}
+
 __global__ void __launch_bounds__(LANES) walk_chain_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
                                                            const int64_t* rec_base, WalkRec* recs, WalkChained* chained) {
     __shared__ __attribute__((aligned(16))) uint8_t window[WALK_WINDOW];
     const int t = blockIdx.x, lane = threadIdx.x;
+    if (walk_uniform((uint32_t)chained[t].mode) == 1u) return;      // (walk_chain_par_kernel listed this region)
     const tredgpu_walk_task T = tasks[t];
     WalkLds S;
     S.cap = 0; S.mask = 0; S.table = nullptr;
@@ -947,7 +1084,7 @@ __global__ void __launch_bounds__(LANES) walk_chain_kernel(WalkView v, const tre
             n += nb;
         }
     }
-    if (lane == 0) chained[t] = WalkChained{status, (int32_t)n};
+    if (lane == 0) chained[t] = WalkChained{status, (int32_t)n, 0, 0, 0, 0};
 }
 
 __device__ inline uint32_t g_u8(const uint8_t* out, int64_t at) { return out[at]; }
@@ -956,7 +1093,7 @@ __device__ inline uint32_t g_u32(const uint8_t* out, int64_t at) { uint32_t x; _
 
 // one lane per record of the call: slot g of the records' pool belongs to the region whose [rec_base[t], rec_base[t+1])
 // holds it (binary search), and is record g - rec_base[t] of it -- when that region's chain listed that many
-__global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks, const int64_t* rec_base, const WalkRec* recs,
+__global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks, const int64_t* rec_base, WalkRec* recs,
                                                           const WalkChained* chained, WalkFields* fields) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= rec_base[n_tasks]) return;
@@ -970,6 +1107,10 @@ __global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks
     const uint8_t* out = v.out;
     const int64_t a0 = recs[g].a0, r = a0 + 4;
     const int32_t size = (int32_t)g_u32(out, a0);
+    if (C.mode == 1) {                                     // listed by place only: the virtual offsets of the record and of what follows it
+        recs[g].at = walk_voffset(v, C.klo, C.khi, a0);
+        recs[g].after = walk_voffset(v, C.klo, C.khi, a0 + 4 + (int64_t)size);
+    }
     WalkFields F;
     F.rtid = (int32_t)g_u32(out, r);
     F.rpos = (int32_t)g_u32(out, r + 4);
@@ -1012,88 +1153,36 @@ __global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks
     fields[g] = F;
 }
 
-// resolve: the listed records of the region, 64 at a time (lane j: record j of the batch)
-__device__ int walk_region_resolve(const tredgpu_walk_task& T, WalkLds& S, const WalkRec* recs, const WalkFields* fields, int n,
-                                   WalkPair* pairs, WalkRepeat* repeats, int* n_pairs, int* n_repeats, tredgpu_walk_result& R, int lane) {
-    int np = 0, nrep = 0, nwin = 0;
-    uint64_t vbeg = 0, vend = 0;
-    // (the batch after this one is loaded while this one goes through the table: a lone wavefront hides nothing by itself)
-    WalkFields Fn = {};
-    WalkRec men = {};
-    if (lane < n) { Fn = fields[lane]; men = recs[lane]; }
-    for (int i0 = 0; i0 < n; i0 += LANES) {
-        const bool mine = i0 + lane < n;
-        const WalkFields F = Fn;
-        const WalkRec me = men;
-        if (i0 + LANES + lane < n) { Fn = fields[i0 + LANES + lane]; men = recs[i0 + LANES + lane]; }
-        const int32_t rtid = F.rtid, rpos = F.rpos, rend = F.rend;
-        const uint32_t flag = F.flag, h = F.h;
-        const bool off_region = mine && (rtid != T.tid || rpos >= T.end);       // (rtid < T.tid: the chain ends at the others)
-        const uint64_t bad_mask = __ballot(mine && !off_region && F.bad != 0);
-        const int limit = bad_mask ? __builtin_ctzll(bad_mask) : 64;             // records [0, limit) of the batch count
-        const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
-        const bool keep = mine && lane < limit && !off_region && e > T.start;
-        const uint64_t win_mask = __ballot(keep && rpos < T.win_hi && e > T.win_lo);
-        if (win_mask) {                                                // records of the scan's own window
-            const int wf = __builtin_ctzll(win_mask), wl = 63 - __builtin_clzll(win_mask);
-            if (nwin == 0) vbeg = walk_lane64(me.at, wf);
-            vend = walk_lane64(me.after, wl);
-            nwin += __popcll(win_mask);
-        }
-        // PairTable::add, in file order.  Serial is only the table itself: one probe and one update per record, on values
-        // every lane holds alike; which pair a record belongs to (and as its how-manieth record) is noted in the record's
-        // own lane, and the pair entries are written behind the loop by all lanes at once (one after the other, each from
-        // the owning lane inside the loop, they were a third of the loop's instructions -- and a lone wavefront issues one
-        // every ~5 cycles).
-        uint64_t todo = __ballot(keep && (flag & 0x1) && !(flag & 0x4) && !(flag & 0x400));
-        uint32_t tag_v = h >> 15;
-        if (tag_v == 0) tag_v = 1;
-        const uint32_t slot_v = h & S.mask;
-        int my_idx = -1, my_seen = 0, my_rep = 0;
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t tag = (uint32_t)__builtin_amdgcn_readlane((int)tag_v, j);
-            uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)slot_v, j);
-            int idx = -1, seen = 0;
-            for (;; slot = (slot + 1) & S.mask) {
-                const uint32_t entry = walk_uniform(S.table[slot]);
-                if (entry == 0) break;
-                if ((entry >> 15) == tag) { idx = (int)(entry & (WALK_PAIR_CAP - 1)); seen = (int)((entry >> 13) & 3); break; }
-            }
-            if (idx < 0) {
-                if (np >= S.cap) return WALK_TABLE_FULL;
-                idx = np++;
-            }
-            if (seen >= 2 && nrep >= WALK_REPEAT_CAP) return WALK_TABLE_FULL;
-            if (seen < 3) S.table[slot] = (tag << 15) | ((uint32_t)(seen + 1) << 13) | (uint32_t)idx;   // (every lane the same value)
-            const bool me_now = lane == j;
-            my_idx = me_now ? idx : my_idx;
-            my_seen = me_now ? seen : my_seen;
-            my_rep = me_now ? nrep : my_rep;
-            if (seen >= 2) ++nrep;
-            walk_lds_order();
-        }
-        if (my_idx >= 0) {
-            if (my_seen == 0) {
-                WalkPair& P = pairs[my_idx];
-                P.name_at = me.a0 + 36; P.name_len = F.nlen;
-                P.a_pos = rpos; P.a_lead = F.lead; P.a_rev = (flag & 0x10) ? 1 : 0; P.complete = 0;
-            }
-        }
-        if (my_idx >= 0 && my_seen == 1) {                          // (behind the first records' stores: `complete` ends up set)
-            WalkPair& P = pairs[my_idx];
-            P.name2_at = me.a0 + 36;
-            P.b_end = rend; P.b_trail = F.trail; P.b_rev = (flag & 0x10) ? 1 : 0; P.complete = 1;
-        }
-        if (my_idx >= 0 && my_seen >= 2) {                          // the pair is complete: only the name matters
-            repeats[my_rep].pair = my_idx; repeats[my_rep].name_at = me.a0 + 36;
-        }
-        if (bad_mask) return WALK_BAD_RECORD;
+// resolve: PairTable::add for the listed records of the region, 64 at a time (lane j: record j of the batch), every step of it
+// by all lanes at once.  (Round 5's first version took the records of a batch through the table one after the other, on the
+// scalar unit: ~80 instructions and an LDS round trip per record, 1.3 of the kernel's 1.5 ms.)  What PairTable::add
+// computes is, per name, its first and its second record in file order, and the names in order of their first record; none
+// of that needs the records one at a time:
+//   pass 1  every record puts (hash << 32 | its number) into the name's slot with an LDS atomic MIN (slots are found by
+//           compare-and-swap on the hash: linear probing, insert only): the slot ends up holding the name's FIRST record;
+//   pass 2  the records that find their own number there are the first ones: a ballot and a prefix count give the pair its
+//           index (order of first appearance, as the serial table had it); the slot becomes hash << 32 | 1 << 31 |
+//           index << 18 | all ones, and the name's other records put their number into the low 18 bits, again with an
+//           atomic MIN: the SECOND record;
+//   pass 3  the second records write their side of the pair; a third, fourth ... record only has to bear the pair's name
+//           (a hash is not a name: what it does not prove is checked byte for byte, here and in finish).
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+constexpr int RESOLVE_MAX_RECORDS = 32768;         // (the first-record bitmap; 2 x WALK_PAIR_CAP names' worth of records)
+constexpr uint32_t SECOND_NONE = 0x3FFFFu;
+
+__device__ inline bool walk_todo(const tredgpu_walk_task& T, const WalkFields& F, bool mine) {
+    const bool off_region = F.rtid != T.tid || F.rpos >= T.end;             // (rtid < T.tid: the chain ends at the others)
+    const int64_t e = (F.rend < 0 || F.rend <= F.rpos) ? (int64_t)F.rpos + 1 : (int64_t)F.rend;
+    return mine && !off_region && e > T.start && (F.flag & 0x1) && !(F.flag & 0x4) && !(F.flag & 0x400);
+}
+// the slot of a name that is in the table
+__device__ inline uint32_t walk_slot_of(const lds_u64* tab, uint32_t mask, uint32_t h, uint64_t* cur) {
+    uint32_t slot = h & mask;
+    for (uint32_t tries = 0; tries <= mask; ++tries, slot = (slot + 1) & mask) {
+        *cur = tab[slot];
+        if ((uint32_t)(*cur >> 32) == h) break;
     }
-    *n_pairs = np; *n_repeats = nrep;
-    R.n_window = nwin; R.win_vbeg = vbeg; R.win_vend = vend;
-    return WALK_OK;
+    return slot;
 }
 
 __device__ inline bool walk_same_name(const uint8_t* out, int64_t a, int64_t b, uint32_t len) {
@@ -1109,41 +1198,141 @@ __device__ inline bool walk_same_name(const uint8_t* out, int64_t a, int64_t b, 
     return diff == 0;
 }
 
+__device__ int walk_region_resolve(const WalkView& v, const tredgpu_walk_task& T, lds_u64* tab, uint32_t mask, int cap, uint64_t* first_bits,
+                                   const WalkRec* recs, const WalkFields* fields, int n, WalkPair* pairs, int* n_pairs, bool* clash_out,
+                                   tredgpu_walk_result& R, int lane) {
+    if (n > RESOLVE_MAX_RECORDS) return WALK_TABLE_FULL;
+    int nwin = 0, inserted = 0;
+    uint64_t vbeg = 0, vend = 0;
+    // ---- pass 1: the window's records; every name's first record ----
+    {
+        // (the batch after this one is loaded while this one goes through the table: a lone wavefront hides nothing by itself)
+        WalkFields Fn = {};
+        WalkRec men = {};
+        if (lane < n) { Fn = fields[lane]; men = recs[lane]; }
+        for (int i0 = 0; i0 < n; i0 += LANES) {
+            const bool mine = i0 + lane < n;
+            const WalkFields F = Fn;
+            const WalkRec me = men;
+            if (i0 + LANES + lane < n) { Fn = fields[i0 + LANES + lane]; men = recs[i0 + LANES + lane]; }
+            const int32_t rtid = F.rtid, rpos = F.rpos, rend = F.rend;
+            const bool off_region = mine && (rtid != T.tid || rpos >= T.end);
+            if (__ballot(mine && !off_region && F.bad != 0) != 0) return WALK_BAD_RECORD;
+            const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
+            const bool keep = mine && !off_region && e > T.start;
+            const uint64_t win_mask = __ballot(keep && rpos < T.win_hi && e > T.win_lo);
+            if (win_mask) {                                                // records of the scan's own window
+                const int wf = __builtin_ctzll(win_mask), wl = 63 - __builtin_clzll(win_mask);
+                if (nwin == 0) vbeg = walk_lane64(me.at, wf);
+                vend = walk_lane64(me.after, wl);
+                nwin += __popcll(win_mask);
+            }
+            bool fresh = false;
+            if (walk_todo(T, F, mine)) {
+                const uint32_t h = F.h ? F.h : 1u;
+                const uint64_t mine64 = (uint64_t)h << 32 | (uint32_t)(i0 + lane);
+                uint32_t slot = h & mask;
+                for (;; slot = (slot + 1) & mask) {
+                    uint64_t cur = tab[slot];
+                    if (cur == 0) {
+                        unsigned long long expect = 0;
+                        if (__hip_atomic_compare_exchange_strong(tab + slot, &expect, (unsigned long long)mine64, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) { fresh = true; break; }
+                        cur = expect;
+                    }
+                    if ((uint32_t)(cur >> 32) == h) {
+                        __hip_atomic_fetch_min(tab + slot, (unsigned long long)mine64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        break;
+                    }
+                }
+            }
+            inserted += __popcll(__ballot(fresh));
+            if (inserted > cap) return WALK_TABLE_FULL;                    // (2 * cap slots: the probes above always end)
+            walk_lds_order();
+        }
+    }
+    // ---- pass 2: the pairs in order of their first record; every name's second record ----
+    int np = 0;
+    for (int i0 = 0; i0 < n; i0 += LANES) {
+        const int r = i0 + lane;
+        const bool mine = r < n;
+        WalkFields F = {};
+        if (mine) F = fields[r];
+        const bool todo = walk_todo(T, F, mine);
+        const uint32_t h = F.h ? F.h : 1u;
+        uint64_t cur = 0;
+        uint32_t slot = 0;
+        if (todo) slot = walk_slot_of(tab, mask, h, &cur);
+        const bool is_first = todo && (uint32_t)cur == (uint32_t)r;        // (bit 31 clear: nobody has taken the slot over yet)
+        const uint64_t fm = __ballot(is_first);
+        const int idx = np + __popcll(fm & (((uint64_t)1 << lane) - 1));
+        if (lane == 0) first_bits[i0 / LANES] = fm;
+        if (is_first) {
+            tab[slot] = (uint64_t)h << 32 | 0x80000000u | (uint32_t)idx << 18 | SECOND_NONE;
+            WalkPair& P = pairs[idx];
+            P.name_at = recs[r].a0 + 36; P.name_len = F.nlen;
+            P.a_pos = F.rpos; P.a_lead = F.lead; P.a_rev = (F.flag & 0x10) ? 1 : 0; P.complete = 0;
+        }
+        np += __popcll(fm);
+        walk_lds_order();                                                  // (the first records' slots are taken over before the others read them)
+        if (todo && !is_first) {
+            const uint64_t now = tab[slot];
+            __hip_atomic_fetch_min(tab + slot, (unsigned long long)((now & ~(uint64_t)SECOND_NONE) | (uint32_t)r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        walk_lds_order();
+    }
+    // ---- pass 3: the second records' side of the pairs; further records under a pair's hash must bear its name ----
+    bool clash = false;
+    for (int i0 = 0; i0 < n; i0 += LANES) {
+        const int r = i0 + lane;
+        const bool mine = r < n;
+        WalkFields F = {};
+        if (mine) F = fields[r];
+        const bool is_first = (first_bits[i0 / LANES] >> lane) & 1;
+        if (walk_todo(T, F, mine) && !is_first) {
+            const uint32_t h = F.h ? F.h : 1u;
+            uint64_t cur;
+            walk_slot_of(tab, mask, h, &cur);
+            WalkPair& P = pairs[((uint32_t)cur >> 18) & (WALK_PAIR_CAP - 1)];
+            const int64_t name_at = recs[r].a0 + 36;
+            if (((uint32_t)cur & SECOND_NONE) == (uint32_t)r) {
+                P.name2_at = name_at;
+                P.b_end = F.rend; P.b_trail = F.trail; P.b_rev = (F.flag & 0x10) ? 1 : 0; P.complete = 1;
+            } else clash |= !walk_same_name(v.out, P.name_at, name_at, P.name_len);
+        }
+    }
+    *n_pairs = np;
+    *clash_out = clash;
+    R.n_window = nwin; R.win_vbeg = vbeg; R.win_vend = vend;
+    return WALK_OK;
+}
+
 __global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tredgpu_walk_task* tasks, const int64_t* rec_base,
                                                           const WalkRec* recs_all, const WalkFields* fields_all, const WalkChained* chained,
-                                                          tredgpu_walk_result* results, WalkPair* pairs_all, WalkRepeat* repeats_all, int32_t* gpool,
+                                                          tredgpu_walk_result* results, WalkPair* pairs_all, int32_t* gpool,
                                                           int64_t cap_g, int32_t* tpool, int64_t cap_t, unsigned long long* counters,
                                                           int table_cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t walk_lds[];
     __shared__ int64_t firsts[2];
+    __shared__ uint64_t first_bits[RESOLVE_MAX_RECORDS / LANES];
     const int t = blockIdx.x, lane = threadIdx.x;
-    WalkLds S;
-    S.cap = table_cap;
-    S.mask = 2u * (uint32_t)table_cap - 1;
-    S.window = nullptr;
-    S.table = (lds_u32*)walk_lds;
-    for (int k = lane; k < 2 * table_cap; k += LANES) S.table[k] = 0;
+    lds_u64* tab = (lds_u64*)walk_lds;                     // 2 * table_cap slots, open addressing at a load below one half
+    const uint32_t mask = 2u * (uint32_t)table_cap - 1;
+    for (int k = lane; k < 2 * table_cap; k += LANES) tab[k] = 0;
     WalkPair* pairs = pairs_all + (size_t)t * WALK_PAIR_CAP;
-    WalkRepeat* repeats = repeats_all + (size_t)t * WALK_REPEAT_CAP;
     const tredgpu_walk_task T = tasks[t];
     tredgpu_walk_result R = {};
-    int np = 0, nrep = 0;
+    int np = 0;
+    bool clash = false;
     __syncthreads();
     const WalkChained C = chained[t];
     int status = C.status;
-    if (status == WALK_OK) status = walk_region_resolve(T, S, recs_all + rec_base[t], fields_all + rec_base[t], C.n, pairs, repeats, &np, &nrep, R, lane);
-    __syncthreads();                                       // lane 0's pair entries are visible to the wavefront
-    // ---- PairTable::finish, 64 pairs at a time: are the names under one tag equal? which list does the pair go to? ----
+    if (status == WALK_OK) status = walk_region_resolve(v, T, tab, mask, table_cap, first_bits, recs_all + rec_base[t], fields_all + rec_base[t], C.n, pairs, &np, &clash, R, lane);
+    __syncthreads();                                       // the pair entries are visible to the wavefront
+    // ---- PairTable::finish, 64 pairs at a time: are the names under one hash equal? which list does the pair go to? ----
     int ng = 0, nt = 0;
     if (status == WALK_OK) {
-        bool clash = false, no_end = false;
-        for (int q0 = 0; q0 < nrep; q0 += LANES) {
-            const int q = q0 + lane;
-            if (q < nrep) {
-                const WalkPair& P = pairs[repeats[q].pair];
-                clash |= !walk_same_name(v.out, P.name_at, repeats[q].name_at, P.name_len);
-            }
-        }
+        bool no_end = false;
         for (int q0 = 0; q0 < np; q0 += LANES) {
             const int q = q0 + lane;
             int cls = 0;                                   // 1 global, 2 target
@@ -1369,7 +1558,7 @@ struct tredgpu_inflater {
     uint8_t* h_wblk = nullptr;                               // pinned, same layout
     uint8_t* d_wtask = nullptr; uint8_t* h_wtask = nullptr; size_t cap_wtask = 0;   // tasks then chunks
     uint8_t* d_wres = nullptr;  uint8_t* h_wres = nullptr;  size_t cap_wres = 0;    // results then the two counters
-    WalkRepeat* d_wrepeats = nullptr; WalkPair* d_wpairs = nullptr; size_t cap_wscratch = 0;   // in tasks
+    WalkPair* d_wpairs = nullptr; size_t cap_wscratch = 0;   // in tasks
     WalkRec* d_wrecs = nullptr; WalkFields* d_wfields = nullptr; size_t cap_wrecs = 0;          // in records: the chain's list, the parsed fields
     WalkChained* d_wchained = nullptr; size_t cap_wchained = 0;
     uint8_t* d_atask = nullptr; uint8_t* h_atask = nullptr; size_t cap_atask = 0;   // the alternative loci's tasks then chunks
@@ -1426,11 +1615,11 @@ void release(tredgpu_inflater* f) {
 void release_walk(tredgpu_inflater* f) {
     for (void* p : {(void*)f->h_wblk, (void*)f->h_wtask, (void*)f->h_wres, (void*)f->h_gpool, (void*)f->h_tpool, (void*)f->h_atask, (void*)f->h_ares})
         if (p) (void)hipHostFree(p);
-    for (void* p : {(void*)f->d_wblk, (void*)f->d_wtask, (void*)f->d_wres, (void*)f->d_wrepeats, (void*)f->d_wpairs, (void*)f->d_gpool, (void*)f->d_tpool, (void*)f->d_atask, (void*)f->d_ares,
+    for (void* p : {(void*)f->d_wblk, (void*)f->d_wtask, (void*)f->d_wres, (void*)f->d_wpairs, (void*)f->d_gpool, (void*)f->d_tpool, (void*)f->d_atask, (void*)f->d_ares,
                     (void*)f->d_wrecs, (void*)f->d_wfields, (void*)f->d_wchained})
         if (p) (void)hipFree(p);
     f->h_wblk = f->h_wtask = f->h_wres = f->h_atask = f->h_ares = nullptr; f->h_gpool = f->h_tpool = nullptr;
-    f->d_wblk = f->d_wtask = f->d_wres = f->d_atask = f->d_ares = nullptr; f->d_wrepeats = nullptr; f->d_wpairs = nullptr; f->d_gpool = f->d_tpool = nullptr;
+    f->d_wblk = f->d_wtask = f->d_wres = f->d_atask = f->d_ares = nullptr; f->d_wpairs = nullptr; f->d_gpool = f->d_tpool = nullptr;
     f->d_wrecs = nullptr; f->d_wfields = nullptr; f->d_wchained = nullptr; f->cap_wrecs = f->cap_wchained = 0;
     f->cap_wblk = f->cap_wtask = f->cap_wres = f->cap_wscratch = f->cap_gpool = f->cap_tpool = f->cap_atask = f->cap_ares = 0;
     f->cap_hgpool = f->cap_htpool = 0;
@@ -1664,10 +1853,8 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         if (grow_pair(f, &f->h_wres, &f->d_wres, &f->cap_wres, n_tasks * sizeof(tredgpu_walk_result) + 64)) return -10;
         if (n_tasks > f->cap_wscratch) {
             const size_t c = std::max(n_tasks, f->cap_wscratch + f->cap_wscratch / 2);
-            if (f->d_wrepeats) (void)hipFree(f->d_wrepeats);
             if (f->d_wpairs) (void)hipFree(f->d_wpairs);
-            f->d_wrepeats = nullptr; f->d_wpairs = nullptr; f->cap_wscratch = 0;
-            ICHK(f, hipMalloc((void**)&f->d_wrepeats, c * WALK_REPEAT_CAP * sizeof(WalkRepeat)));
+            f->d_wpairs = nullptr; f->cap_wscratch = 0;
             ICHK(f, hipMalloc((void**)&f->d_wpairs, c * WALK_PAIR_CAP * sizeof(WalkPair)));
             f->cap_wscratch = c;
         }
@@ -1754,6 +1941,9 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
             const tredgpu_walk_task* d_tasks = (const tredgpu_walk_task*)f->d_wtask;
             const tredgpu_walk_chunk* d_chunks = (const tredgpu_walk_chunk*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task));
             const int64_t* d_rec_base = (const int64_t*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk));
+            walk_chain_par_kernel<<<(unsigned)n_tasks, LANES, 0, f->wstream>>>(v, d_tasks, d_chunks, d_rec_base, f->d_wrecs, f->d_wchained);
+            if (getenv("TREDGPU_WALK_SERIAL") != nullptr)       // (A/B and tests: every region through the serial chain)
+                ICHK(f, hipMemsetAsync(f->d_wchained, 0, n_tasks * sizeof(WalkChained), f->wstream));
             walk_chain_kernel<<<(unsigned)n_tasks, LANES, 0, f->wstream>>>(v, d_tasks, d_chunks, d_rec_base, f->d_wrecs, f->d_wchained);
             ICHK(f, hipGetLastError());
             if (total_recs > 0) {
@@ -1762,7 +1952,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
             }
             pair_walk_kernel<<<(unsigned)n_tasks, LANES, walk_lds_bytes(table_cap), f->wstream>>>(v, d_tasks, d_rec_base, f->d_wrecs, f->d_wfields,
                 f->d_wchained, (tredgpu_walk_result*)f->d_wres, f->d_wpairs,
-                f->d_wrepeats, f->d_gpool, w->cap_global, f->d_tpool, w->cap_target, (unsigned long long*)(f->d_wres + n_tasks * sizeof(tredgpu_walk_result)),
+                f->d_gpool, w->cap_global, f->d_tpool, w->cap_target, (unsigned long long*)(f->d_wres + n_tasks * sizeof(tredgpu_walk_result)),
                 table_cap);
             ICHK(f, hipGetLastError());
         }
