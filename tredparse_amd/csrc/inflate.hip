@@ -1153,22 +1153,28 @@ __global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks
     fields[g] = F;
 }
 
-// resolve: PairTable::add for the listed records of the region, 64 at a time (lane j: record j of the batch), every step of it
-// by all lanes at once.  (Round 5's first version took the records of a batch through the table one after the other, on the
-// scalar unit: ~80 instructions and an LDS round trip per record, 1.3 of the kernel's 1.5 ms.)  What PairTable::add
-// computes is, per name, its first and its second record in file order, and the names in order of their first record; none
-// of that needs the records one at a time:
-//   pass 1  every record puts (hash << 32 | its number) into the name's slot with an LDS atomic MIN (slots are found by
-//           compare-and-swap on the hash: linear probing, insert only): the slot ends up holding the name's FIRST record;
-//   pass 2  the records that find their own number there are the first ones: a ballot and a prefix count give the pair its
-//           index (order of first appearance, as the serial table had it); the slot becomes hash << 32 | 1 << 31 |
-//           index << 18 | all ones, and the name's other records put their number into the low 18 bits, again with an
-//           atomic MIN: the SECOND record;
-//   pass 3  the second records write their side of the pair; a third, fourth ... record only has to bear the pair's name
-//           (a hash is not a name: what it does not prove is checked byte for byte, here and in finish).
+// resolve: PairTable::add and PairTable::finish for the listed records of a region -- a workgroup of PW_WAVES wavefronts per
+// region, every step by all lanes at once.  (Round 5's first version took the records through the table one after the
+// other on the scalar unit of ONE wavefront: ~80 instructions and an LDS round trip per record, 1.3 of the kernel's 1.5 ms;
+// then one wavefront with the passes below: 0.63 ms, all of it waiting for its own loads.)  What PairTable::add computes is,
+// per name, its first and its second record in file order, and the names in order of their first record; none of that
+// needs the records one at a time.  A slot of the table is 64 bits: hash bits 6..31 | first record | second record
+// (19 bits each, all ones = none), found by compare-and-swap on the hash (linear probing, insert only):
+//   pass 1  every record of a pair-forming read puts (hash | its number | none) into its name's slot with an atomic MIN:
+//           the slot ends up with the name's FIRST record; the window's records are counted on the way;
+//   pass 2  the records that find their own number there are the first ones: their ballot per batch of 64 is kept, a prefix
+//           sum over the batches turns it into the pair's index (order of first appearance, as the serial table had it);
+//           the others put their number into the low bits, again with an atomic MIN: the name's SECOND record;
+//   pass 3  first and second records write their side of the pair; a third, fourth ... record only has to bear the pair's
+//           name (a hash is not a name: what it does not prove is checked byte for byte, here and in finish);
+//   finish  as before -- names equal? orientation, length, which list -- with the lists' places from a prefix sum over the
+//           batches of pairs.
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-constexpr int RESOLVE_MAX_RECORDS = 32768;         // (the first-record bitmap; 2 x WALK_PAIR_CAP names' worth of records)
-constexpr uint32_t SECOND_NONE = 0x3FFFFu;
+constexpr int PW_WAVES = 8, PW_THREADS = PW_WAVES * LANES;
+constexpr int RESOLVE_MAX_RECORDS = 32768;         // (the per-batch arrays below; 2 x WALK_PAIR_CAP names' worth of records)
+constexpr int RESOLVE_MAX_BATCHES = RESOLVE_MAX_RECORDS / LANES, PAIR_MAX_BATCHES = WALK_PAIR_CAP / LANES;
+constexpr uint32_t REC_NONE = 0x7FFFFu;
+constexpr int REC_BITS = 19;
 
 __device__ inline bool walk_todo(const tredgpu_walk_task& T, const WalkFields& F, bool mine) {
     const bool off_region = F.rtid != T.tid || F.rpos >= T.end;             // (rtid < T.tid: the chain ends at the others)
@@ -1180,7 +1186,7 @@ __device__ inline uint32_t walk_slot_of(const lds_u64* tab, uint32_t mask, uint3
     uint32_t slot = h & mask;
     for (uint32_t tries = 0; tries <= mask; ++tries, slot = (slot + 1) & mask) {
         *cur = tab[slot];
-        if ((uint32_t)(*cur >> 32) == h) break;
+        if ((uint32_t)(*cur >> (2 * REC_BITS)) == h >> 6) break;
     }
     return slot;
 }
@@ -1198,40 +1204,83 @@ __device__ inline bool walk_same_name(const uint8_t* out, int64_t a, int64_t b, 
     return diff == 0;
 }
 
-__device__ int walk_region_resolve(const WalkView& v, const tredgpu_walk_task& T, lds_u64* tab, uint32_t mask, int cap, uint64_t* first_bits,
-                                   const WalkRec* recs, const WalkFields* fields, int n, WalkPair* pairs, int* n_pairs, bool* clash_out,
-                                   tredgpu_walk_result& R, int lane) {
-    if (n > RESOLVE_MAX_RECORDS) return WALK_TABLE_FULL;
-    int nwin = 0, inserted = 0;
-    uint64_t vbeg = 0, vend = 0;
+struct PairShared {
+    uint64_t first_bits[RESOLVE_MAX_BATCHES];      // per batch of records: which of them are a name's first record
+    int32_t first_base[RESOLVE_MAX_BATCHES];       // first records per batch, then (exclusive prefix) the first pair index of the batch
+    int32_t cg[PAIR_MAX_BATCHES], ct[PAIR_MAX_BATCHES];   // per batch of pairs: lengths for the global / the target list, then their places
+    uint64_t wvbeg[PW_WAVES], wvend[PW_WAVES];     // per wavefront: the window's records it saw (first / last batch, offsets, count)
+    int32_t wfirst[PW_WAVES], wlast[PW_WAVES], wn[PW_WAVES];
+    int64_t firsts[2];
+    int32_t status, inserted, np, ng, nt, clash, no_end;
+};
+
+// exclusive prefix sum of a[0 .. m) in place, by one wavefront; returns the total
+__device__ inline int walk_scan_lds(int32_t* a, int m, int lane) {
+    int carry = 0;
+    for (int base = 0; base < m; base += LANES) {
+        const int val = base + lane < m ? a[base + lane] : 0;
+        const int incl = wave_incl_scan(val);
+        if (base + lane < m) a[base + lane] = carry + incl - val;
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    }
+    return carry;
+}
+
+__global__ void __launch_bounds__(PW_THREADS) pair_walk_kernel(WalkView v, const tredgpu_walk_task* tasks, const int64_t* rec_base,
+                                                               const WalkRec* recs_all, const WalkFields* fields_all, const WalkChained* chained,
+                                                               tredgpu_walk_result* results, WalkPair* pairs_all, int32_t* gpool,
+                                                               int64_t cap_g, int32_t* tpool, int64_t cap_t, unsigned long long* counters,
+                                                               int table_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t walk_lds[];
+    __shared__ PairShared sh;
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & (LANES - 1), w = tid / LANES;
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    lds_u64* tab = (lds_u64*)walk_lds;                     // 2 * table_cap slots, open addressing at a load below one half
+    const uint32_t mask = 2u * (uint32_t)table_cap - 1;
+    for (int k = tid; k < 2 * table_cap; k += PW_THREADS) tab[k] = 0;
+    WalkPair* pairs = pairs_all + (size_t)t * WALK_PAIR_CAP;
+    const tredgpu_walk_task T = tasks[t];
+    const WalkChained C = chained[t];
+    const WalkRec* recs = recs_all + rec_base[t];
+    const WalkFields* fields = fields_all + rec_base[t];
+    const int n = C.n, nb = (n + LANES - 1) / LANES;
+    if (tid == 0) {
+        sh.status = C.status != WALK_OK ? C.status : (n > RESOLVE_MAX_RECORDS ? (int)WALK_TABLE_FULL : (int)WALK_OK);
+        sh.inserted = 0; sh.np = 0; sh.ng = 0; sh.nt = 0; sh.clash = 0; sh.no_end = 0;
+    }
+    __syncthreads();
+    int status = sh.status;
     // ---- pass 1: the window's records; every name's first record ----
-    {
-        // (the batch after this one is loaded while this one goes through the table: a lone wavefront hides nothing by itself)
+    if (status == WALK_OK) {
+        int nwin = 0, bfirst = -1, blast = -1;
+        uint64_t vbeg = 0, vend = 0;
+        // (the wavefront's next batch is loaded while this one goes through the table)
         WalkFields Fn = {};
         WalkRec men = {};
-        if (lane < n) { Fn = fields[lane]; men = recs[lane]; }
-        for (int i0 = 0; i0 < n; i0 += LANES) {
-            const bool mine = i0 + lane < n;
+        if (w * LANES + lane < n) { Fn = fields[w * LANES + lane]; men = recs[w * LANES + lane]; }
+        for (int b = w; b < nb; b += PW_WAVES) {
+            const int r = b * LANES + lane;
+            const bool mine = r < n;
             const WalkFields F = Fn;
             const WalkRec me = men;
-            if (i0 + LANES + lane < n) { Fn = fields[i0 + LANES + lane]; men = recs[i0 + LANES + lane]; }
+            if (r + PW_THREADS < n) { Fn = fields[r + PW_THREADS]; men = recs[r + PW_THREADS]; }
             const int32_t rtid = F.rtid, rpos = F.rpos, rend = F.rend;
             const bool off_region = mine && (rtid != T.tid || rpos >= T.end);
-            if (__ballot(mine && !off_region && F.bad != 0) != 0) return WALK_BAD_RECORD;
+            if (__ballot(mine && !off_region && F.bad != 0) != 0) { if (lane == 0) sh.status = WALK_BAD_RECORD; break; }
             const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
             const bool keep = mine && !off_region && e > T.start;
             const uint64_t win_mask = __ballot(keep && rpos < T.win_hi && e > T.win_lo);
             if (win_mask) {                                                // records of the scan's own window
                 const int wf = __builtin_ctzll(win_mask), wl = 63 - __builtin_clzll(win_mask);
-                if (nwin == 0) vbeg = walk_lane64(me.at, wf);
-                vend = walk_lane64(me.after, wl);
+                if (nwin == 0) { vbeg = walk_lane64(me.at, wf); bfirst = b; }
+                vend = walk_lane64(me.after, wl); blast = b;
                 nwin += __popcll(win_mask);
             }
             bool fresh = false;
             if (walk_todo(T, F, mine)) {
-                const uint32_t h = F.h ? F.h : 1u;
-                const uint64_t mine64 = (uint64_t)h << 32 | (uint32_t)(i0 + lane);
-                uint32_t slot = h & mask;
+                const uint64_t key = (uint64_t)(F.h >> 6) << (2 * REC_BITS);
+                const uint64_t mine64 = key | (uint64_t)(uint32_t)r << REC_BITS | REC_NONE;
+                uint32_t slot = F.h & mask;
                 for (;; slot = (slot + 1) & mask) {
                     uint64_t cur = tab[slot];
                     if (cur == 0) {
@@ -1240,148 +1289,140 @@ __device__ int walk_region_resolve(const WalkView& v, const tredgpu_walk_task& T
                                                                  __HIP_MEMORY_SCOPE_WORKGROUP)) { fresh = true; break; }
                         cur = expect;
                     }
-                    if ((uint32_t)(cur >> 32) == h) {
+                    if ((cur >> (2 * REC_BITS)) == (key >> (2 * REC_BITS))) {
                         __hip_atomic_fetch_min(tab + slot, (unsigned long long)mine64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         break;
                     }
                 }
             }
-            inserted += __popcll(__ballot(fresh));
-            if (inserted > cap) return WALK_TABLE_FULL;                    // (2 * cap slots: the probes above always end)
-            walk_lds_order();
-        }
-    }
-    // ---- pass 2: the pairs in order of their first record; every name's second record ----
-    int np = 0;
-    for (int i0 = 0; i0 < n; i0 += LANES) {
-        const int r = i0 + lane;
-        const bool mine = r < n;
-        WalkFields F = {};
-        if (mine) F = fields[r];
-        const bool todo = walk_todo(T, F, mine);
-        const uint32_t h = F.h ? F.h : 1u;
-        uint64_t cur = 0;
-        uint32_t slot = 0;
-        if (todo) slot = walk_slot_of(tab, mask, h, &cur);
-        const bool is_first = todo && (uint32_t)cur == (uint32_t)r;        // (bit 31 clear: nobody has taken the slot over yet)
-        const uint64_t fm = __ballot(is_first);
-        const int idx = np + __popcll(fm & (((uint64_t)1 << lane) - 1));
-        if (lane == 0) first_bits[i0 / LANES] = fm;
-        if (is_first) {
-            tab[slot] = (uint64_t)h << 32 | 0x80000000u | (uint32_t)idx << 18 | SECOND_NONE;
-            WalkPair& P = pairs[idx];
-            P.name_at = recs[r].a0 + 36; P.name_len = F.nlen;
-            P.a_pos = F.rpos; P.a_lead = F.lead; P.a_rev = (F.flag & 0x10) ? 1 : 0; P.complete = 0;
-        }
-        np += __popcll(fm);
-        walk_lds_order();                                                  // (the first records' slots are taken over before the others read them)
-        if (todo && !is_first) {
-            const uint64_t now = tab[slot];
-            __hip_atomic_fetch_min(tab + slot, (unsigned long long)((now & ~(uint64_t)SECOND_NONE) | (uint32_t)r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        walk_lds_order();
-    }
-    // ---- pass 3: the second records' side of the pairs; further records under a pair's hash must bear its name ----
-    bool clash = false;
-    for (int i0 = 0; i0 < n; i0 += LANES) {
-        const int r = i0 + lane;
-        const bool mine = r < n;
-        WalkFields F = {};
-        if (mine) F = fields[r];
-        const bool is_first = (first_bits[i0 / LANES] >> lane) & 1;
-        if (walk_todo(T, F, mine) && !is_first) {
-            const uint32_t h = F.h ? F.h : 1u;
-            uint64_t cur;
-            walk_slot_of(tab, mask, h, &cur);
-            WalkPair& P = pairs[((uint32_t)cur >> 18) & (WALK_PAIR_CAP - 1)];
-            const int64_t name_at = recs[r].a0 + 36;
-            if (((uint32_t)cur & SECOND_NONE) == (uint32_t)r) {
-                P.name2_at = name_at;
-                P.b_end = F.rend; P.b_trail = F.trail; P.b_rev = (F.flag & 0x10) ? 1 : 0; P.complete = 1;
-            } else clash |= !walk_same_name(v.out, P.name_at, name_at, P.name_len);
-        }
-    }
-    *n_pairs = np;
-    *clash_out = clash;
-    R.n_window = nwin; R.win_vbeg = vbeg; R.win_vend = vend;
-    return WALK_OK;
-}
-
-__global__ void __launch_bounds__(LANES) pair_walk_kernel(WalkView v, const tredgpu_walk_task* tasks, const int64_t* rec_base,
-                                                          const WalkRec* recs_all, const WalkFields* fields_all, const WalkChained* chained,
-                                                          tredgpu_walk_result* results, WalkPair* pairs_all, int32_t* gpool,
-                                                          int64_t cap_g, int32_t* tpool, int64_t cap_t, unsigned long long* counters,
-                                                          int table_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t walk_lds[];
-    __shared__ int64_t firsts[2];
-    __shared__ uint64_t first_bits[RESOLVE_MAX_RECORDS / LANES];
-    const int t = blockIdx.x, lane = threadIdx.x;
-    lds_u64* tab = (lds_u64*)walk_lds;                     // 2 * table_cap slots, open addressing at a load below one half
-    const uint32_t mask = 2u * (uint32_t)table_cap - 1;
-    for (int k = lane; k < 2 * table_cap; k += LANES) tab[k] = 0;
-    WalkPair* pairs = pairs_all + (size_t)t * WALK_PAIR_CAP;
-    const tredgpu_walk_task T = tasks[t];
-    tredgpu_walk_result R = {};
-    int np = 0;
-    bool clash = false;
-    __syncthreads();
-    const WalkChained C = chained[t];
-    int status = C.status;
-    if (status == WALK_OK) status = walk_region_resolve(v, T, tab, mask, table_cap, first_bits, recs_all + rec_base[t], fields_all + rec_base[t], C.n, pairs, &np, &clash, R, lane);
-    __syncthreads();                                       // the pair entries are visible to the wavefront
-    // ---- PairTable::finish, 64 pairs at a time: are the names under one hash equal? which list does the pair go to? ----
-    int ng = 0, nt = 0;
-    if (status == WALK_OK) {
-        bool no_end = false;
-        for (int q0 = 0; q0 < np; q0 += LANES) {
-            const int q = q0 + lane;
-            int cls = 0;                                   // 1 global, 2 target
-            if (q < np && pairs[q].complete) {
-                const WalkPair P = pairs[q];
-                clash |= !walk_same_name(v.out, P.name_at, P.name2_at, P.name_len);
-                if (!P.a_rev && P.b_rev) {                 // mapped in +, - orientation
-                    if (P.b_end < 0) no_end = true;        // (the reference dies here: the host reports it)
-                    const int64_t tlen = ((int64_t)P.b_end + P.b_trail) - ((int64_t)P.a_pos - P.a_lead);
-                    if (tlen < T.span) cls = (P.a_pos < T.tstart && P.b_end > T.tend) ? 2 : 1;
-                }
+            // (2 * cap slots, names counted before the table can fill: the probes above always end)
+            const int add = __popcll(__ballot(fresh));
+            int seen = 0;
+            if (lane == 0) {
+                seen = add ? atomicAdd(&sh.inserted, add) + add : sh.inserted;
+                if (seen > table_cap) sh.status = WALK_TABLE_FULL;
             }
-            ng += __popcll(__ballot(cls == 1));
-            nt += __popcll(__ballot(cls == 2));
+            if (__builtin_amdgcn_readfirstlane(seen) > table_cap) break;
         }
-        if (__ballot(clash) != 0) status = WALK_TAG_CLASH;
-        else if (__ballot(no_end) != 0) status = WALK_NO_END;
+        if (lane == 0) { sh.wfirst[w] = bfirst; sh.wlast[w] = blast; sh.wn[w] = nwin; sh.wvbeg[w] = vbeg; sh.wvend[w] = vend; }
     }
+    __syncthreads();
+    status = sh.status;
+    // ---- pass 2: which records are first ones; every name's second record ----
     if (status == WALK_OK) {
-        if (lane == 0) {
-            firsts[0] = (int64_t)atomicAdd(&counters[0], (unsigned long long)ng);
-            firsts[1] = (int64_t)atomicAdd(&counters[1], (unsigned long long)nt);
+        for (int b = w; b < nb; b += PW_WAVES) {
+            const int r = b * LANES + lane;
+            const bool mine = r < n;
+            WalkFields F = {};
+            if (mine) F = fields[r];
+            const bool todo = walk_todo(T, F, mine);
+            uint64_t cur = 0;
+            uint32_t slot = 0;
+            if (todo) slot = walk_slot_of(tab, mask, F.h, &cur);
+            const bool is_first = todo && ((uint32_t)(cur >> REC_BITS) & REC_NONE) == (uint32_t)r;
+            const uint64_t fm = __ballot(is_first);
+            if (lane == 0) { sh.first_bits[b] = fm; sh.first_base[b] = __popcll(fm); }
+            if (todo && !is_first)
+                __hip_atomic_fetch_min(tab + slot, (unsigned long long)((cur & ~(uint64_t)REC_NONE) | (uint32_t)r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();
-        const int64_t gf = firsts[0], tf = firsts[1];
+    }
+    __syncthreads();
+    if (status == WALK_OK && w == 0) {
+        const int total = walk_scan_lds(sh.first_base, nb, lane);
+        if (lane == 0) sh.np = total;
+    }
+    __syncthreads();
+    const int np = sh.np;
+    // ---- pass 3: both sides of every pair; further records under a pair's hash must bear its name ----
+    if (status == WALK_OK) {
+        bool clash = false;
+        for (int b = w; b < nb; b += PW_WAVES) {
+            const int r = b * LANES + lane;
+            const bool mine = r < n;
+            WalkFields F = {};
+            if (mine) F = fields[r];
+            if (walk_todo(T, F, mine)) {
+                uint64_t cur;
+                walk_slot_of(tab, mask, F.h, &cur);
+                const uint32_t first = (uint32_t)(cur >> REC_BITS) & REC_NONE, second = (uint32_t)cur & REC_NONE;
+                const int fb = (int)(first / LANES), fl = (int)(first % LANES);
+                WalkPair& P = pairs[sh.first_base[fb] + __popcll(sh.first_bits[fb] & (((uint64_t)1 << fl) - 1))];
+                const int64_t name_at = recs[r].a0 + 36;
+                if ((uint32_t)r == first) {
+                    P.name_at = name_at; P.name_len = F.nlen;
+                    P.a_pos = F.rpos; P.a_lead = F.lead; P.a_rev = (F.flag & 0x10) ? 1 : 0; P.complete = second != REC_NONE ? 1 : 0;
+                } else if ((uint32_t)r == second) {
+                    P.name2_at = name_at;
+                    P.b_end = F.rend; P.b_trail = F.trail; P.b_rev = (F.flag & 0x10) ? 1 : 0;
+                } else clash |= fields[first].nlen != F.nlen || !walk_same_name(v.out, recs[first].a0 + 36, name_at, F.nlen);
+            }
+        }
+        if (__ballot(clash) != 0 && lane == 0) sh.clash = 1;
+    }
+    __syncthreads();                                       // the pair entries are visible to the workgroup
+    // ---- PairTable::finish, 64 pairs at a time: are the names under one hash equal? which list does the pair go to? ----
+    auto classify = [&](int q, int32_t& len32, bool& clash, bool& no_end) {
+        int cls = 0;                                       // 1 global, 2 target
+        if (q < np && pairs[q].complete) {
+            const WalkPair P = pairs[q];
+            clash |= !walk_same_name(v.out, P.name_at, P.name2_at, P.name_len);
+            if (!P.a_rev && P.b_rev) {                     // mapped in +, - orientation
+                if (P.b_end < 0) no_end = true;            // (the reference dies here: the host reports it)
+                const int64_t tlen = ((int64_t)P.b_end + P.b_trail) - ((int64_t)P.a_pos - P.a_lead);
+                if (tlen < T.span) { cls = (P.a_pos < T.tstart && P.b_end > T.tend) ? 2 : 1; len32 = (int32_t)tlen; }
+            }
+        }
+        return cls;
+    };
+    const int npb = (np + LANES - 1) / LANES;
+    if (status == WALK_OK) {
+        bool clash = false, no_end = false;
+        for (int pb = w; pb < npb; pb += PW_WAVES) {
+            int32_t len32 = 0;
+            const int cls = classify(pb * LANES + lane, len32, clash, no_end);
+            const int g = __popcll(__ballot(cls == 1)), tt = __popcll(__ballot(cls == 2));
+            if (lane == 0) { sh.cg[pb] = g; sh.ct[pb] = tt; }
+        }
+        if (__ballot(clash) != 0 && lane == 0) sh.clash = 1;
+        if (__ballot(no_end) != 0 && lane == 0) sh.no_end = 1;
+    }
+    __syncthreads();
+    if (status == WALK_OK) status = sh.clash ? (int)WALK_TAG_CLASH : (sh.no_end ? (int)WALK_NO_END : (int)WALK_OK);
+    if (status == WALK_OK && w == 0) {
+        const int ng = walk_scan_lds(sh.cg, npb, lane), nt = walk_scan_lds(sh.ct, npb, lane);
+        if (lane == 0) {
+            sh.ng = ng; sh.nt = nt;
+            sh.firsts[0] = (int64_t)atomicAdd(&counters[0], (unsigned long long)ng);
+            sh.firsts[1] = (int64_t)atomicAdd(&counters[1], (unsigned long long)nt);
+        }
+    }
+    __syncthreads();
+    tredgpu_walk_result R = {};
+    if (status == WALK_OK) {
+        const int64_t gf = sh.firsts[0], tf = sh.firsts[1];
+        const int ng = sh.ng, nt = sh.nt;
         if (gf + ng > cap_g || tf + nt > cap_t) status = WALK_POOL_FULL;
         else {
-            int go = 0, to = 0;
-            for (int q0 = 0; q0 < np; q0 += LANES) {
-                const int q = q0 + lane;
-                int cls = 0;
+            for (int pb = w; pb < npb; pb += PW_WAVES) {
                 int32_t len32 = 0;
-                if (q < np && pairs[q].complete) {
-                    const WalkPair P = pairs[q];
-                    if (!P.a_rev && P.b_rev) {
-                        const int64_t tlen = ((int64_t)P.b_end + P.b_trail) - ((int64_t)P.a_pos - P.a_lead);
-                        if (tlen < T.span) { cls = (P.a_pos < T.tstart && P.b_end > T.tend) ? 2 : 1; len32 = (int32_t)tlen; }
-                    }
-                }
-                const uint64_t mg = __ballot(cls == 1), mt = __ballot(cls == 2), below = ((uint64_t)1 << lane) - 1;
-                if (cls == 1) gpool[gf + go + __popcll(mg & below)] = len32;
-                if (cls == 2) tpool[tf + to + __popcll(mt & below)] = len32;
-                go += __popcll(mg);
-                to += __popcll(mt);
+                bool c1 = false, c2 = false;
+                const int cls = classify(pb * LANES + lane, len32, c1, c2);
+                const uint64_t mg = __ballot(cls == 1), mt = __ballot(cls == 2);
+                if (cls == 1) gpool[gf + sh.cg[pb] + __popcll(mg & below)] = len32;
+                if (cls == 2) tpool[tf + sh.ct[pb] + __popcll(mt & below)] = len32;
             }
             R.n_global = ng; R.n_target = nt; R.global_first = gf; R.target_first = tf;
+            // the window's records: the count of all wavefronts, the first one's and the last one's offsets
+            int nwin = 0, bf = 1 << 30, bl = -1;
+            for (int k = 0; k < PW_WAVES; ++k) {
+                nwin += sh.wn[k];
+                if (sh.wn[k] > 0 && sh.wfirst[k] < bf) { bf = sh.wfirst[k]; R.win_vbeg = sh.wvbeg[k]; }
+                if (sh.wn[k] > 0 && sh.wlast[k] > bl) { bl = sh.wlast[k]; R.win_vend = sh.wvend[k]; }
+            }
+            R.n_window = nwin;
         }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         R.status = status;
         if (status != WALK_OK) { R.n_global = R.n_target = R.n_window = 0; R.global_first = R.target_first = 0; R.win_vbeg = R.win_vend = 0; }
         results[t] = R;
@@ -1950,7 +1991,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
                 walk_parse_kernel<<<(unsigned)((total_recs + 255) / 256), 256, 0, f->wstream>>>(v, (int)n_tasks, d_rec_base, f->d_wrecs, f->d_wchained, f->d_wfields);
                 ICHK(f, hipGetLastError());
             }
-            pair_walk_kernel<<<(unsigned)n_tasks, LANES, walk_lds_bytes(table_cap), f->wstream>>>(v, d_tasks, d_rec_base, f->d_wrecs, f->d_wfields,
+            pair_walk_kernel<<<(unsigned)n_tasks, PW_THREADS, walk_lds_bytes(table_cap), f->wstream>>>(v, d_tasks, d_rec_base, f->d_wrecs, f->d_wfields,
                 f->d_wchained, (tredgpu_walk_result*)f->d_wres, f->d_wpairs,
                 f->d_gpool, w->cap_global, f->d_tpool, w->cap_target, (unsigned long long*)(f->d_wres + n_tasks * sizeof(tredgpu_walk_result)),
                 table_cap);
