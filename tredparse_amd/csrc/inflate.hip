@@ -944,6 +944,94 @@ __device__ inline uint64_t walk_voffset(const WalkView& v, int lo, int hi, int64
     return (uint64_t)v.bcoff[a - 1] << 16 | (uint64_t)(addr - v.ooff[a - 1]);
 }
 
+// One chunk of a region by all lanes.  false: not this way (see above).  Else lane j has `cnt` records from address `s` on
+// (0 for the lanes behind the one that met the region's end), `first` = how many records the lanes before it have, `total`
+// all of them; [klo, khi) grows to hold the chunk's blocks.
+struct ParChunk { int64_t s; int cnt, first, total; };
+__device__ bool chain_par_chunk(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk& ch, int lane, int min_bytes,
+                                ParChunk& out_c, int& klo, int& khi) {
+    const uint8_t* out = v.out;
+    out_c = ParChunk{0, 0, 0, 0};
+    const int k0 = ch.begin_block;
+    if (k0 < T.block_first || k0 >= T.block_end) return false;
+    // the chunk's blocks: k0 .. kend, kend the last planned block that begins at or before the chunk's end; all of them
+    // vouched for by the decoder and one behind the other in the file
+    const int64_t coff_e = (int64_t)(ch.end_voffset >> 16);
+    const int upos_e = (int)(ch.end_voffset & 0xFFFFu);
+    int kend = k0 - 1;
+    bool fine = true;
+    for (int kb = k0; kb < T.block_end; kb += LANES) {
+        const int k = kb + lane;
+        const bool in = k < T.block_end && v.bcoff[k] <= coff_e;
+        kend = max(kend, kb - 1 + (int)__popcll(__ballot(in)));          // (bcoff ascends)
+        if (in) {
+            fine = fine && walk_block_ok(v, k);
+            if (k > k0) fine = fine && v.bcoff[k - 1] + v.bclen[k - 1] == v.bcoff[k];
+        }
+        if (__ballot(k < T.block_end && !in) != 0) break;
+    }
+    if (kend < k0 || __ballot(!fine) != 0) return false;
+    const int64_t a_lim = v.ooff[kend + 1];                              // what lies behind is not this chunk's
+    const int64_t A0 = v.ooff[k0] + ch.begin_upos;
+    int64_t A1 = a_lim;
+    if (v.bcoff[kend] == coff_e) A1 = min(a_lim, v.ooff[kend] + (int64_t)upos_e);
+    else if ((uint64_t)(v.bcoff[kend] + v.bclen[kend]) << 16 < ch.end_voffset) return false;   // the chunk goes on where the plan ends
+    klo = min(klo, k0); khi = max(khi, kend + 1);
+    if (A0 >= A1) return true;
+    const int64_t len = A1 - A0;
+    if (len < min_bytes) return false;                                   // (a few records: the window in LDS is the faster way)
+    const int nseg = (int)min((int64_t)LANES, max((int64_t)1, len / PAR_SEG_MIN));
+    const int64_t L = (len + nseg - 1) / nseg;
+    // ---- where this lane starts ----
+    const int64_t INF = (int64_t)1 << 60;
+    int64_t s = INF;
+    if (lane == 0) s = A0;
+    else if (lane < nseg) {
+        const int64_t p_end = min(A0 + (lane + 1) * L, A1);
+        for (int64_t p = A0 + lane * L; p < p_end && p + 36 <= a_lim; ++p) {
+            const int32_t size = (int32_t)g_u32(out, p);
+            if (size < 36 || size > (1 << 24) || (int32_t)g_u32(out, p + 4) != T.tid) continue;
+            const int32_t rpos = (int32_t)g_u32(out, p + 8), l_seq = (int32_t)g_u32(out, p + 20);
+            const int64_t l_name = g_u8(out, p + 12), n_cigar = g_u16(out, p + 16);
+            if (rpos < 0 || l_seq < 0 || l_name < 1 || 32 + l_name + 4 * n_cigar + ((int64_t)l_seq + 1) / 2 + l_seq > size) continue;
+            if (p + 4 + size > a_lim || g_u8(out, p + 36 + l_name - 1) != 0) continue;
+            s = p;
+            break;
+        }
+    }
+    // the next lane that has a start (or the chunk's end)
+    const uint64_t have = __ballot(s != INF);
+    const uint64_t above = lane < 63 ? have >> (lane + 1) : 0;
+    const int nextl = above ? lane + 1 + __builtin_ctzll(above) : lane;
+    int64_t target = (int64_t)__shfl((unsigned long long)s, nextl, LANES);
+    const bool is_last = above == 0;
+    if (is_last) target = A1;
+    // ---- count: follow the length words from s to target ----
+    enum { CLEAN = 0, STOPPED = 1, ANOMALY = 2 };
+    int outcome = CLEAN, cnt = 0;
+    if (s != INF) {
+        int64_t p = s;
+        while (p < target) {
+            if (p + 12 > a_lim) { outcome = ANOMALY; break; }
+            const int32_t size = (int32_t)g_u32(out, p);
+            const int32_t rtid = (int32_t)g_u32(out, p + 4), rpos = (int32_t)g_u32(out, p + 8);
+            if (size < 32 || p + 4 + (int64_t)size > a_lim) { outcome = ANOMALY; break; }   // (the serial chain says what it is)
+            if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { outcome = STOPPED; break; }
+            ++cnt;
+            p += 4 + (int64_t)size;
+        }
+        if (outcome == CLEAN && p != target && !is_last) outcome = ANOMALY;     // stepped over the next lane's start: a wrong guess
+    }
+    // the first lane that did not arrive: up to it the chain is the file's
+    const uint64_t not_clean = __ballot(outcome != CLEAN);
+    const int J = not_clean ? __builtin_ctzll(not_clean) : LANES - 1;
+    if (not_clean && __shfl(outcome, J, LANES) == ANOMALY) return false;
+    const int mycnt = lane <= J ? cnt : 0;
+    const int incl = wave_incl_scan(mycnt);
+    out_c = ParChunk{s, mycnt, incl - mycnt, __builtin_amdgcn_readlane(incl, 63)};
+    return true;
+}
+
 __global__ void __launch_bounds__(LANES) walk_chain_par_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
                                                                const int64_t* rec_base, WalkRec* recs, WalkChained* chained) {
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -960,94 +1048,16 @@ __global__ void __launch_bounds__(LANES) walk_chain_par_kernel(WalkView v, const
     int klo = T.block_end, khi = T.block_first;
     bool give_up = false;
     for (int c = 0; c < T.n_chunks && !give_up; ++c) {
-        const tredgpu_walk_chunk ch = chunks[T.chunk_first + c];
-        const int k0 = ch.begin_block;
-        if (k0 < T.block_first || k0 >= T.block_end) { give_up = true; break; }
-        // the chunk's blocks: k0 .. kend, kend the last planned block that begins at or before the chunk's end; all of them
-        // vouched for by the decoder and one behind the other in the file
-        const int64_t coff_e = (int64_t)(ch.end_voffset >> 16);
-        const int upos_e = (int)(ch.end_voffset & 0xFFFFu);
-        int kend = k0 - 1;
-        bool fine = true;
-        for (int kb = k0; kb < T.block_end; kb += LANES) {
-            const int k = kb + lane;
-            const bool in = k < T.block_end && v.bcoff[k] <= coff_e;
-            kend = max(kend, kb - 1 + (int)__popcll(__ballot(in)));          // (bcoff ascends)
-            if (in) {
-                fine = fine && walk_block_ok(v, k);
-                if (k > k0) fine = fine && v.bcoff[k - 1] + v.bclen[k - 1] == v.bcoff[k];
-            }
-            if (__ballot(k < T.block_end && !in) != 0) break;
-        }
-        if (kend < k0 || __ballot(!fine) != 0) { give_up = true; break; }
-        const int64_t a_lim = v.ooff[kend + 1];                              // what lies behind is not this chunk's
-        const int64_t A0 = v.ooff[k0] + ch.begin_upos;
-        int64_t A1 = a_lim;
-        if (v.bcoff[kend] == coff_e) A1 = min(a_lim, v.ooff[kend] + (int64_t)upos_e);
-        else if ((uint64_t)(v.bcoff[kend] + v.bclen[kend]) << 16 < ch.end_voffset) { give_up = true; break; }   // the chunk goes on where the plan ends
-        klo = min(klo, k0); khi = max(khi, kend + 1);
-        if (A0 >= A1) continue;
-        const int64_t len = A1 - A0;
-        const int nseg = (int)min((int64_t)LANES, max((int64_t)1, len / PAR_SEG_MIN));
-        const int64_t L = (len + nseg - 1) / nseg;
-        // ---- where this lane starts ----
-        const int64_t INF = (int64_t)1 << 60;
-        int64_t s = INF;
-        if (lane == 0) s = A0;
-        else if (lane < nseg) {
-            const int64_t p_end = min(A0 + (lane + 1) * L, A1);
-            for (int64_t p = A0 + lane * L; p < p_end && p + 36 <= a_lim; ++p) {
-                const int32_t size = (int32_t)g_u32(out, p);
-                if (size < 36 || size > (1 << 24) || (int32_t)g_u32(out, p + 4) != T.tid) continue;
-                const int32_t rpos = (int32_t)g_u32(out, p + 8), l_seq = (int32_t)g_u32(out, p + 20);
-                const int64_t l_name = g_u8(out, p + 12), n_cigar = g_u16(out, p + 16);
-                if (rpos < 0 || l_seq < 0 || l_name < 1 || 32 + l_name + 4 * n_cigar + ((int64_t)l_seq + 1) / 2 + l_seq > size) continue;
-                if (p + 4 + size > a_lim || g_u8(out, p + 36 + l_name - 1) != 0) continue;
-                s = p;
-                break;
-            }
-        }
-        // the next lane that has a start (or the chunk's end)
-        const uint64_t have = __ballot(s != INF);
-        const uint64_t above = lane < 63 ? have >> (lane + 1) : 0;
-        const int nextl = above ? lane + 1 + __builtin_ctzll(above) : lane;
-        int64_t target = (int64_t)__shfl((unsigned long long)s, nextl, LANES);
-        const bool is_last = above == 0;
-        if (is_last) target = A1;
-        // ---- count: follow the length words from s to target ----
-        enum { CLEAN = 0, STOPPED = 1, ANOMALY = 2 };
-        int outcome = CLEAN, cnt = 0;
-        if (s != INF) {
-            int64_t p = s;
-            while (p < target) {
-                if (p + 12 > a_lim) { outcome = ANOMALY; break; }
-                const int32_t size = (int32_t)g_u32(out, p);
-                const int32_t rtid = (int32_t)g_u32(out, p + 4), rpos = (int32_t)g_u32(out, p + 8);
-                if (size < 32 || p + 4 + (int64_t)size > a_lim) { outcome = ANOMALY; break; }   // (walk_chain_kernel says what it is)
-                if (rtid > T.tid || (rtid == T.tid && rpos >= T.end)) { outcome = STOPPED; break; }
-                ++cnt;
-                p += 4 + (int64_t)size;
-            }
-            if (outcome == CLEAN && p != target && !is_last) outcome = ANOMALY;     // stepped over the next lane's start: a wrong guess
-        }
-        // the first lane that did not arrive: up to it the chain is the file's
-        const uint64_t not_clean = __ballot(outcome != CLEAN);
-        const int J = not_clean ? __builtin_ctzll(not_clean) : LANES - 1;
-        if (not_clean && __shfl(outcome, J, LANES) == ANOMALY) { give_up = true; break; }
-        const int mycnt = lane <= J ? cnt : 0;
-        const int incl = wave_incl_scan(mycnt);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (n + total > cap) { give_up = true; break; }              // (WALK_TABLE_FULL: the other kernel's to say)
+        ParChunk pc;
+        if (!chain_par_chunk(v, T, chunks[T.chunk_first + c], lane, 0, pc, klo, khi) || n + pc.total > cap) { give_up = true; break; }
         // ---- list: the same steps again (the bytes are in the cache now) ----
-        if (mycnt > 0) {
-            int64_t p = s;
-            WalkRec* o = mine + n + (incl - mycnt);
-            for (int q = 0; q < mycnt; ++q) {
-                o[q].a0 = p;
-                p += 4 + (int64_t)(int32_t)g_u32(out, p);
-            }
+        int64_t p = pc.s;
+        WalkRec* o = mine + n + pc.first;
+        for (int q = 0; q < pc.cnt; ++q) {
+            o[q].a0 = p;
+            p += 4 + (int64_t)(int32_t)g_u32(out, p);
         }
-        n += total;
+        n += pc.total;
     }
     if (lane == 0) chained[t] = give_up ? serial : WalkChained{WALK_OK, (int32_t)n, 1, klo, khi, 0};
 }
@@ -1447,71 +1457,125 @@ __device__ inline int walk_block_of(const WalkView& v, int lo, int hi, int64_t a
     return lo;
 }
 
+// what a record of an alternative locus' region is asked: does it count (its mate lies in the locus' window), is it sound
+struct AltRecord { bool bad, hit; int32_t size; };
+__device__ inline AltRecord walk_alt_record(const uint8_t* out, const tredgpu_walk_task& T, int64_t a0) {
+    AltRecord A;
+    const int64_t r = a0 + 4;
+    A.size = (int32_t)g_u32(out, a0);
+    const int32_t rtid = (int32_t)g_u32(out, r), rpos = (int32_t)g_u32(out, r + 4);
+    const uint32_t l_name = g_u8(out, r + 8), n_cigar = g_u16(out, r + 12), flag = g_u16(out, r + 14);
+    const int32_t l_seq = (int32_t)g_u32(out, r + 16), mtid = (int32_t)g_u32(out, r + 20), mpos = (int32_t)g_u32(out, r + 24);
+    const bool off_region = rtid != T.tid || rpos >= T.end;               // (a contig before the region's: the chain stops at the others)
+    A.bad = !off_region && (l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)A.size);
+    A.hit = false;
+    if (!A.bad && !off_region && mtid == T.tstart && mpos >= T.win_lo && mpos <= T.win_hi) {
+        // (the CIGAR only of the few records whose mate lies in the window: the others cannot count whatever their end)
+        int64_t e = (int64_t)rpos + 1;
+        if (!(flag & 0x4) && n_cigar > 0) {
+            const int64_t cig = r + 32 + l_name;
+            int64_t end = rpos;
+            for (uint32_t q = 0; q < n_cigar; ++q) {
+                const uint32_t op = g_u32(out, cig + 4 * q);
+                if ((0x18Du >> (op & 15)) & 1) end += op >> 4;
+            }
+            if ((int32_t)end > rpos) e = (int32_t)end;
+        }
+        A.hit = e > T.start;
+    }
+    return A;
+}
+// a record that counts: its virtual offset into the region's result (R of the owning lane), its blocks marked for the copy back
+__device__ inline void walk_alt_hit(const WalkView& v, int lo, int hi, tredgpu_alt_result& R, int idx, uint64_t at, int64_t a0, int32_t size, uint8_t* need) {
+    for (int m = 0; m < ALT_MATCH_CAP; ++m) if (m == idx) R.vbeg[m] = at;
+    const int kb = walk_block_of(v, lo, hi, a0), ka = walk_block_of(v, lo, hi, a0 + 3 + (int64_t)size);   // first and last byte
+    for (int k = kb; k <= ka; ++k) need[k] = 1;
+}
+
+// one chunk, the records one batch after the other (chain_batch: the window in LDS)
+__device__ int walk_alt_chunk_serial(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk& ch, WalkReader& rd, WalkLds& S,
+                                     tredgpu_alt_result& R, int& found, uint8_t* need, int lane) {
+    const uint8_t* out = v.out;
+    WalkCursor cur;
+    int rc = cur.enter(v, ch.begin_block);
+    if (rc) return rc;
+    cur.upos = ch.begin_upos;
+    bool chunk_done = false;
+    while (!chunk_done) {
+        int err = WALK_OK;
+        int64_t my_a0 = 0;
+        uint64_t my_at = 0, my_after = 0;
+        const int nb = chain_batch(v, T, ch, cur, rd, S, lane, my_a0, my_at, my_after, chunk_done, err);
+        if (err != WALK_OK) chunk_done = true;
+        AltRecord A = {false, false, 0};
+        if (lane < nb) A = walk_alt_record(out, T, my_a0);
+        const uint64_t bad_mask = __ballot(A.bad);
+        const int limit = bad_mask ? __builtin_ctzll(bad_mask) : 64;
+        uint64_t hits = __ballot(A.hit && lane < limit);
+        while (hits) {
+            const int j = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            if (found >= ALT_MATCH_CAP) return WALK_POOL_FULL;
+            if (lane == j) walk_alt_hit(v, T.block_first, T.block_end, R, found, my_at, my_a0, A.size, need);
+            ++found;
+        }
+        if (bad_mask) return WALK_BAD_RECORD;
+        if (err != WALK_OK) return err;
+    }
+    return WALK_OK;
+}
+
+// one chunk, every lane the records chain_par_chunk gave it
+__device__ int walk_alt_chunk_par(const WalkView& v, const tredgpu_walk_task& T, const ParChunk& pc, int klo, int khi,
+                                  tredgpu_alt_result& R, int& found, uint8_t* need, int lane) {
+    const uint8_t* out = v.out;
+    int nh = 0;
+    bool bad = false;
+    int64_t hit_a0[ALT_MATCH_CAP];
+    int32_t hit_size[ALT_MATCH_CAP];
+    int64_t p = pc.s;
+    for (int q = 0; q < pc.cnt; ++q) {
+        const AltRecord A = walk_alt_record(out, T, p);
+        bad |= A.bad;
+        if (A.hit) {
+            for (int m = 0; m < ALT_MATCH_CAP; ++m) if (m == nh) { hit_a0[m] = p; hit_size[m] = A.size; }
+            ++nh;
+        }
+        p += 4 + (int64_t)A.size;
+    }
+    if (__ballot(bad) != 0) return WALK_BAD_RECORD;
+    const int incl = wave_incl_scan(nh);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (found + total > ALT_MATCH_CAP) return WALK_POOL_FULL;
+    for (int m = 0; m < ALT_MATCH_CAP; ++m)
+        if (m < nh) walk_alt_hit(v, klo, khi, R, found + incl - nh + m, walk_voffset(v, klo, khi, hit_a0[m]), hit_a0[m], hit_size[m], need);
+    found += total;
+    return WALK_OK;
+}
+
+constexpr int64_t ALT_PAR_MIN_COMP = 8192;        // compressed bytes of a chunk from which the lanes share it (~150 records)
 __device__ int walk_alt_records(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk* chunks, WalkReader& rd, WalkLds& S,
                                 tredgpu_alt_result& R, uint8_t* need, int lane) {
     if (T.n_chunks < 0) return WALK_NOT_PLANNED;
-    const uint8_t* out = v.out;
     int found = 0;
     for (int c = 0; c < T.n_chunks; ++c) {
         const tredgpu_walk_chunk ch = chunks[T.chunk_first + c];
         if (ch.begin_block < T.block_first || ch.begin_block >= T.block_end) return WALK_NOT_PLANNED;
-        WalkCursor cur;
-        int rc = cur.enter(v, ch.begin_block);
-        if (rc) return rc;
-        cur.upos = ch.begin_upos;
-        bool chunk_done = false;
-        while (!chunk_done) {
-            // the chain as the pair walk has it (chain_batch: the records up to the first one beyond the region), then every
-            // lane reads the fields of ONE of the records found, from where the decoder wrote them
-            int err = WALK_OK;
-            int64_t my_a0 = 0;
-            uint64_t my_at = 0, my_after = 0;
-            const int nb = chain_batch(v, T, ch, cur, rd, S, lane, my_a0, my_at, my_after, chunk_done, err);
-            if (err != WALK_OK) chunk_done = true;
-            const bool mine = lane < nb;
-            int32_t rtid = 0, rpos = 0, rend = -1, mtid = -1, mpos = -1, my_size = 0;
-            bool bad = false;
-            if (mine) {
-                const int64_t r = my_a0 + 4;
-                my_size = (int32_t)g_u32(out, my_a0);
-                rtid = (int32_t)g_u32(out, r);
-                rpos = (int32_t)g_u32(out, r + 4);
-                const uint32_t l_name = g_u8(out, r + 8), n_cigar = g_u16(out, r + 12), flag = g_u16(out, r + 14);
-                const int32_t l_seq = (int32_t)g_u32(out, r + 16);
-                mtid = (int32_t)g_u32(out, r + 20);
-                mpos = (int32_t)g_u32(out, r + 24);
-                bad = l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cigar + ((int64_t)l_seq + 1) / 2 > (int64_t)my_size;
-                // (the CIGAR only of the few records whose mate lies in the window: the others cannot count whatever their end)
-                if (!bad && !(flag & 0x4) && n_cigar > 0 && rtid == T.tid && rpos < T.end && mtid == T.tstart && mpos >= T.win_lo && mpos <= T.win_hi) {
-                    const int64_t cig = r + 32 + l_name;
-                    int64_t e = rpos;
-                    for (uint32_t q = 0; q < n_cigar; ++q) {
-                        const uint32_t op = g_u32(out, cig + 4 * q);
-                        if ((0x18Du >> (op & 15)) & 1) e += op >> 4;
-                    }
-                    rend = (int32_t)e;
-                }
+        // A region's walk starts where its 16 kb bin starts: a few records as a rule, thousands when the bin lies in a covered
+        // stretch -- those few regions were what a launch waited for (1.2 of its 1.4 ms).
+        bool done = false;
+        if ((int64_t)(ch.end_voffset >> 16) - walk_uniform64(v.bcoff[ch.begin_block]) >= ALT_PAR_MIN_COMP) {
+            ParChunk pc;
+            int klo = T.block_end, khi = T.block_first;
+            if (chain_par_chunk(v, T, ch, lane, 0, pc, klo, khi)) {
+                const int rc = walk_alt_chunk_par(v, T, pc, klo, khi, R, found, need, lane);
+                if (rc) return rc;
+                done = true;
             }
-            const bool off_region = mine && (rtid != T.tid || rpos >= T.end);    // (a contig before the region's: the chain stops at the others)
-            const uint64_t bad_mask = __ballot(mine && !off_region && bad);
-            const int limit = bad_mask ? __builtin_ctzll(bad_mask) : 64;
-            const int64_t e = (rend < 0 || rend <= rpos) ? (int64_t)rpos + 1 : (int64_t)rend;
-            const bool keep = mine && lane < limit && !off_region && e > T.start;
-            uint64_t hits = __ballot(keep && mtid == T.tstart && mpos >= T.win_lo && mpos <= T.win_hi);
-            while (hits) {
-                const int j = __builtin_ctzll(hits);
-                hits &= hits - 1;
-                if (found >= ALT_MATCH_CAP) return WALK_POOL_FULL;
-                if (lane == j) {
-                    R.vbeg[found] = my_at;
-                    const int kb = walk_block_of(v, T.block_first, T.block_end, my_a0);                     // first and last byte
-                    const int ka = walk_block_of(v, T.block_first, T.block_end, my_a0 + 3 + (int64_t)my_size);
-                    for (int k = kb; k <= ka; ++k) need[k] = 1;
-                }
-                ++found;
-            }
-            if (bad_mask) return WALK_BAD_RECORD;
-            if (err != WALK_OK) return err;
+        }
+        if (!done) {
+            const int rc = walk_alt_chunk_serial(v, T, ch, rd, S, R, found, need, lane);
+            if (rc) return rc;
         }
     }
     R.n = found;
