@@ -394,6 +394,10 @@ int tredgpu_inflater_host_out(tredgpu_inflater* inf, int enabled);
 int tredgpu_inflater_fetch_dense(tredgpu_inflater* inf, int32_t n_blocks, const uint8_t* need, uint8_t** host, int64_t* dense_off);
 /* page-locked host memory the inflater holds at the moment, in bytes (its staging grows with the largest call it has seen) */
 int64_t tredgpu_inflater_pinned_bytes(const tredgpu_inflater* inf);
+/* of the last tredgpu_inflate_walk call: the regions whose records were listed by the serial chain (walk_chain_kernel) --
+ * those the lane-parallel chain handed back: a guessed record start that was none, a record across the end of the planned
+ * blocks, a block the decoder does not vouch for.  The results are the same either way (tests, diagnostics). */
+int64_t tredgpu_inflater_walk_serial_regions(tredgpu_inflater* inf);
 /* device time of the last call's walk launch in milliseconds */
 int tredgpu_inflater_walk_ms(tredgpu_inflater* inf, double* walk_ms);
 

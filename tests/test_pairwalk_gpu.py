@@ -278,7 +278,7 @@ def test_a_short_random_campaign(capsys, monkeypatch):
     assert out["mismatching_regions"] == 0 and out["mismatching_scans"] == 0
 
 
-def _odd_bam(path, rng, block, no_end=False):
+def _odd_bam(path, rng, block, no_end=False, decoys=False):
     """A BAM around the HD locus whose records have heads of every size: names of 1-250 characters, CIGARs of 1-220
     operations (soft / hard clips at the ends, M I D N = X inside), secondary / supplementary copies under the same name,
     duplicates, unmapped mates -- in blocks of `block` bytes cut without regard to records."""
@@ -335,7 +335,13 @@ def _odd_bam(path, rng, block, no_end=False):
         body = struct.pack("<iiBBHHHiiii", rtid, p, len(name) + 1, 0 if flag & 4 else 60, int(synth_bam._reg2bin(np.array([p]), np.array([end]))[0]),
                            len(ops), flag, l_seq, mtid, mpos, 0)
         body += name.encode() + b"\0" + b"".join(struct.pack("<I", n << 4 | op) for op, n in ops)
-        body += bytes((l_seq + 1) // 2) + b"\xff" * l_seq
+        qual = b"\xff" * l_seq
+        if decoys and l_seq >= 48:
+            # base qualities that read as the head of a record of the region's contig: a length word that covers the fixed
+            # fields, the contig, a position, a two-byte name that ends in NUL, no CIGAR, no bases -- what follows them is not
+            fake = struct.pack("<iiiBBHHHiiii", 40, rtid, 5, 2, 0, 0, 0, 0, 0, -1, -1, 0) + b"a\0"
+            qual = b"\xff" * 4 + fake + b"\xff" * (l_seq - 4 - len(fake))
+        body += bytes((l_seq + 1) // 2) + qual
         offs.append(len(blob))
         blob += struct.pack("<i", len(body)) + body
         ends.append(end)
@@ -403,6 +409,76 @@ def test_heads_longer_than_the_window_and_names_seen_three_times(inf, tmp_path, 
     for key in pools:
         assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
     f.close(); g.close()
+
+
+def test_record_starts_guessed_wrong_are_found_out(inf, tmp_path):
+    """walk_chain_par_kernel guesses where records start from what the bytes look like, and proves every guess by the
+    chain that arrives there.  Here most reads carry base qualities that look like a record's head: lanes that start
+    inside such a read guess wrong, their neighbours step over the guess, and the region goes to the serial chain --
+    lists, offsets and scan as the host computes them, and the library says that the serial chain was used."""
+    path = str(tmp_path / "decoy.bam")
+    assert _odd_bam(path, np.random.default_rng(11), 6000, decoys=True) > 1000
+    repo, names = TREDsRepo(), ["HD"]
+    f = bamio.AlignmentFile(path)
+    sites, regions = _site_arrays(repo, names, [repo["HD"]], f)
+    plan = f.plan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, [f], [plan])
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, _ = _walk_inputs([f], [sites], [150], firsts)
+    alt_tasks, alt_chunks, _ = _alt_inputs([f], [sites], [regions], [150], firsts)
+    status, crc, res, gp, tp, ares, alt_need = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=alt_tasks, alt_chunks=alt_chunks)
+    assert (status == 0).all() and res["status"][0] == 0, res
+    assert inf.walk_serial_regions() == 1                   # (the one region of the call)
+    t = repo["HD"]
+    g = bamio.AlignmentFile(path)
+    eg, et = g.pe_lengths(t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE, t.repeat_start - FLANKMATCH,
+                          t.repeat_end + FLANKMATCH, SPAN)
+    assert list(gp[res["global_first"][0]:][:res["n_global"][0]]) == eg and list(tp[res["target_first"][0]:][:res["n_target"][0]]) == et
+    n, vbeg, vend = _window_span(path, t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE, t.repeat_start - SPAN, t.repeat_end + SPAN)
+    assert (int(res["n_window"][0]), int(res["win_vbeg"][0]), int(res["win_vend"][0])) == (n, vbeg, vend) and n > 30
+    need = walk_need(coff_of[0], host_of[0], res, alt_need)
+    inf.fetch(need)
+    f.preload(inf.out_addr, ooff[:n_all + 1], np.where(need != 0, status, 1).astype(np.int32), crc)
+    u2, p2 = f.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(res, gp, tp), alt=ares)
+    f.preload_clear()
+    units, pools = g.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    for key in units.dtype.names:
+        assert (units[key] == u2[key]).all(), key
+    for key in pools:
+        assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
+    f.close(); g.close()
+
+
+def test_the_serial_chain_and_the_lanes_list_the_same_records(inf, synthetic, monkeypatch):
+    """TREDGPU_WALK_SERIAL=1 sends every region through walk_chain_kernel (one record after the other, the way every
+    region went before the lanes shared the chain): the results of a call are the same numbers either way, and without
+    the switch no region of these files needs the serial chain."""
+    cases = _cases(synthetic)
+    handles = [bamio.AlignmentFile(p) for p, _, _ in cases]
+    sites_of, regions_of, readlens, plans = [], [], [], []
+    for f, (path, repo, names) in zip(handles, cases):
+        sites, regions = _site_arrays(repo, names, [repo[n] for n in names], f)
+        rl = f.max_read_len(101)
+        plans.append(f.plan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN))
+        sites_of.append(sites); regions_of.append(regions); readlens.append(rl)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, handles, plans)
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, _ = _walk_inputs(handles, sites_of, readlens, firsts)
+    alt_tasks, alt_chunks, _ = _alt_inputs(handles, sites_of, regions_of, readlens, firsts)
+    a = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=alt_tasks, alt_chunks=alt_chunks)
+    assert inf.walk_serial_regions() <= int((a[2]["status"] != 0).sum())     # (only what the lanes hand back: regions the plan does not hold)
+    monkeypatch.setenv("TREDGPU_WALK_SERIAL", "1")
+    b = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, alt_tasks=alt_tasks, alt_chunks=alt_chunks)
+    assert inf.walk_serial_regions() == int((tasks["n_chunks"] >= 0).sum())
+    res_a, res_b = a[2], b[2]
+    walked = res_a["status"] == 0
+    assert walked.sum() > 20 and np.array_equal(res_a["status"], res_b["status"])
+    for key in ("n_global", "n_target", "n_window", "win_vbeg", "win_vend"):
+        assert np.array_equal(res_a[key][walked], res_b[key][walked]), key
+    for k in np.flatnonzero(walked):                        # (the pools are filled in the order the regions finish)
+        for pool, first, count in ((3, "global_first", "n_global"), (4, "target_first", "n_target")):
+            assert np.array_equal(a[pool][res_a[first][k]:][:res_a[count][k]], b[pool][res_b[first][k]:][:res_b[count][k]])
+    assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])     # the alternative loci's results and wanted blocks
+    for f in handles:
+        f.close()
 
 
 def test_a_pair_without_alignment_end_is_the_hosts_to_report(inf, tmp_path):

@@ -31,7 +31,7 @@ def main():
     root = tempfile.mkdtemp(prefix="tred_fuzzwalk_")
     inf = _lib.Inflater(0)
     out = {"rounds": rounds, "samples": 0, "regions": 0, "regions_walked": 0, "declined": {}, "pairs": 0, "window_records": 0, "blocks": 0,
-           "blocks_fetched": 0, "mismatching_regions": 0, "mismatching_scans": 0, "alt_regions": 0, "alt_regions_declined": 0, "alt_records": 0, "scans_that_inflated_blocks": 0, "block_sizes": []}
+           "blocks_fetched": 0, "mismatching_regions": 0, "mismatching_scans": 0, "alt_regions": 0, "alt_regions_declined": 0, "alt_records": 0, "scans_that_inflated_blocks": 0, "regions_chained_serially": 0, "block_sizes": []}
     t0 = time.time()
     for rnd in range(rounds):
         loci = [all_loci[i] for i in sorted(rng.choice(len(all_loci), size=int(rng.integers(2, 7)), replace=False))]
@@ -78,6 +78,7 @@ def main():
         walkable = np.concatenate(atasks)["n_chunks"] >= 0
         out["alt_regions"] += int(walkable.sum())
         out["alt_regions_declined"] += int((ares["status"][walkable] != 0).sum())
+        out["regions_chained_serially"] += inf.walk_serial_regions()
         out["alt_records"] += int(ares["n"][ares["status"] == 0].sum())
         assert (status == 0).all() and (crc == bcrc).all()
         out["blocks"] += n_all

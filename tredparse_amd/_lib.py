@@ -60,7 +60,7 @@ EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_s
            "tredgpu_inflater_create", "tredgpu_inflater_destroy", "tredgpu_inflater_last_error",
            "tredgpu_inflater_reserve", "tredgpu_inflate_blocks", "tredgpu_inflate_blocks_crc", "tredgpu_inflater_timing",
            "tredgpu_inflate_walk", "tredgpu_inflater_fetch", "tredgpu_inflater_walk_ms", "tredgpu_inflater_host_out",
-           "tredgpu_inflater_fetch_dense", "tredgpu_inflater_pinned_bytes")
+           "tredgpu_inflater_fetch_dense", "tredgpu_inflater_pinned_bytes", "tredgpu_inflater_walk_serial_regions")
 
 _lib = None
 
@@ -120,6 +120,8 @@ def load():
     lib.tredgpu_inflater_host_out.argtypes = [vp, C.c_int]
     lib.tredgpu_inflater_pinned_bytes.argtypes = [vp]
     lib.tredgpu_inflater_pinned_bytes.restype = i64
+    lib.tredgpu_inflater_walk_serial_regions.argtypes = [vp]
+    lib.tredgpu_inflater_walk_serial_regions.restype = i64
     lib.tredgpu_inflater_fetch_dense.argtypes = [vp, i32, vp, C.POINTER(vp), vp]
     _lib = lib
     return lib
@@ -474,6 +476,10 @@ class Inflater:
     def pinned_bytes(self):
         """Page-locked host memory this inflater holds, in bytes."""
         return int(self._lib.tredgpu_inflater_pinned_bytes(self._h)) if self._h else 0
+
+    def walk_serial_regions(self):
+        """Regions of the last run_walk whose records the serial chain listed (the lane-parallel one handed them back)."""
+        return int(self._lib.tredgpu_inflater_walk_serial_regions(self._h))
 
     def walk_ms(self):
         a = C.c_double()

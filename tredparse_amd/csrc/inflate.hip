@@ -949,11 +949,12 @@ __device__ inline uint64_t walk_voffset(const WalkView& v, int lo, int hi, int64
 // all of them; [klo, khi) grows to hold the chunk's blocks.
 struct ParChunk { int64_t s; int cnt, first, total; };
 __device__ bool chain_par_chunk(const WalkView& v, const tredgpu_walk_task& T, const tredgpu_walk_chunk& ch, int lane, int min_bytes,
-                                ParChunk& out_c, int& klo, int& khi) {
+                                ParChunk& out_c, int& klo, int& khi, int* why = nullptr) {
+#define PAR_NO(code) do { if (why) *why = (code); return false; } while (0)
     const uint8_t* out = v.out;
     out_c = ParChunk{0, 0, 0, 0};
     const int k0 = ch.begin_block;
-    if (k0 < T.block_first || k0 >= T.block_end) return false;
+    if (k0 < T.block_first || k0 >= T.block_end) PAR_NO(1);
     // the chunk's blocks: k0 .. kend, kend the last planned block that begins at or before the chunk's end; all of them
     // vouched for by the decoder and one behind the other in the file
     const int64_t coff_e = (int64_t)(ch.end_voffset >> 16);
@@ -970,16 +971,19 @@ __device__ bool chain_par_chunk(const WalkView& v, const tredgpu_walk_task& T, c
         }
         if (__ballot(k < T.block_end && !in) != 0) break;
     }
-    if (kend < k0 || __ballot(!fine) != 0) return false;
+    if (kend < k0) PAR_NO(2);
+    if (__ballot(!fine) != 0) PAR_NO(3);
     const int64_t a_lim = v.ooff[kend + 1];                              // what lies behind is not this chunk's
     const int64_t A0 = v.ooff[k0] + ch.begin_upos;
     int64_t A1 = a_lim;
     if (v.bcoff[kend] == coff_e) A1 = min(a_lim, v.ooff[kend] + (int64_t)upos_e);
-    else if ((uint64_t)(v.bcoff[kend] + v.bclen[kend]) << 16 < ch.end_voffset) return false;   // the chunk goes on where the plan ends
+    // (the chunk goes on where the plan ends: fine when the region's last record comes first -- the plan holds the blocks up
+    //  to there --, not when the chain runs off the end)
+    const bool open_end = v.bcoff[kend] != coff_e && (uint64_t)(v.bcoff[kend] + v.bclen[kend]) << 16 < ch.end_voffset;
     klo = min(klo, k0); khi = max(khi, kend + 1);
-    if (A0 >= A1) return true;
+    if (A0 >= A1) { if (open_end) PAR_NO(4); return true; }
     const int64_t len = A1 - A0;
-    if (len < min_bytes) return false;                                   // (a few records: the window in LDS is the faster way)
+    if (len < min_bytes) PAR_NO(5);                                      // (a few records: the window in LDS is the faster way)
     const int nseg = (int)min((int64_t)LANES, max((int64_t)1, len / PAR_SEG_MIN));
     const int64_t L = (len + nseg - 1) / nseg;
     // ---- where this lane starts ----
@@ -1025,11 +1029,13 @@ __device__ bool chain_par_chunk(const WalkView& v, const tredgpu_walk_task& T, c
     // the first lane that did not arrive: up to it the chain is the file's
     const uint64_t not_clean = __ballot(outcome != CLEAN);
     const int J = not_clean ? __builtin_ctzll(not_clean) : LANES - 1;
-    if (not_clean && __shfl(outcome, J, LANES) == ANOMALY) return false;
+    if (not_clean && __shfl(outcome, J, LANES) == ANOMALY) PAR_NO(6);
+    if (!not_clean && open_end) PAR_NO(4);
     const int mycnt = lane <= J ? cnt : 0;
     const int incl = wave_incl_scan(mycnt);
     out_c = ParChunk{s, mycnt, incl - mycnt, __builtin_amdgcn_readlane(incl, 63)};
     return true;
+#undef PAR_NO
 }
 
 __global__ void __launch_bounds__(LANES) walk_chain_par_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
@@ -1039,17 +1045,16 @@ __global__ void __launch_bounds__(LANES) walk_chain_par_kernel(WalkView v, const
     const uint8_t* out = v.out;
     WalkRec* mine = recs + rec_base[t];
     const int64_t cap = rec_base[t + 1] - rec_base[t];
-    const WalkChained serial = {WALK_OK, 0, 0, 0, 0, 0};          // "walk_chain_kernel's"
     if (T.n_chunks < 0) {
         if (lane == 0) chained[t] = WalkChained{WALK_NOT_PLANNED, 0, 1, 0, 0, 0};
         return;
     }
     int64_t n = 0;
-    int klo = T.block_end, khi = T.block_first;
+    int klo = T.block_end, khi = T.block_first, why = 7;      // (why a region is left to the serial chain: WalkChained.pad)
     bool give_up = false;
     for (int c = 0; c < T.n_chunks && !give_up; ++c) {
         ParChunk pc;
-        if (!chain_par_chunk(v, T, chunks[T.chunk_first + c], lane, 0, pc, klo, khi) || n + pc.total > cap) { give_up = true; break; }
+        if (!chain_par_chunk(v, T, chunks[T.chunk_first + c], lane, 0, pc, klo, khi, &why) || n + pc.total > cap) { give_up = true; break; }
         // ---- list: the same steps again (the bytes are in the cache now) ----
         int64_t p = pc.s;
         WalkRec* o = mine + n + pc.first;
@@ -1059,7 +1064,7 @@ __global__ void __launch_bounds__(LANES) walk_chain_par_kernel(WalkView v, const
         }
         n += pc.total;
     }
-    if (lane == 0) chained[t] = give_up ? serial : WalkChained{WALK_OK, (int32_t)n, 1, klo, khi, 0};
+    if (lane == 0) chained[t] = give_up ? WalkChained{WALK_OK, 0, 0, 0, 0, why} : WalkChained{WALK_OK, (int32_t)n, 1, klo, khi, 0};
 }
 
 __global__ void __launch_bounds__(LANES) walk_chain_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
@@ -1094,7 +1099,7 @@ __global__ void __launch_bounds__(LANES) walk_chain_kernel(WalkView v, const tre
             n += nb;
         }
     }
-    if (lane == 0) chained[t] = WalkChained{status, (int32_t)n, 0, 0, 0, 0};
+    if (lane == 0) chained[t] = WalkChained{status, (int32_t)n, 0, 0, 0, chained[t].pad};
 }
 
 __device__ inline uint32_t g_u8(const uint8_t* out, int64_t at) { return out[at]; }
@@ -1659,6 +1664,7 @@ struct tredgpu_inflater {
     hipEvent_t wdone = nullptr, w0 = nullptr, w1 = nullptr, decoded[2] = {nullptr, nullptr};
     bool walk_timed = false, big_lds_allowed = false;
     int walk_table_cap = 0;
+    size_t last_walk_tasks = 0;                       // regions of the last walk call (tredgpu_inflater_walk_serial_regions)
     uint8_t* d_wblk = nullptr;  size_t cap_wblk = 0;        // bcoff[n] int64, then bclen[n] int32, then xcrc[n] uint32
     uint8_t* h_wblk = nullptr;                               // pinned, same layout
     uint8_t* d_wtask = nullptr; uint8_t* h_wtask = nullptr; size_t cap_wtask = 0;   // tasks then chunks
@@ -2043,6 +2049,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
                 f->big_lds_allowed = true;
             }
             f->walk_table_cap = table_cap;
+            f->last_walk_tasks = n_tasks;
             const tredgpu_walk_task* d_tasks = (const tredgpu_walk_task*)f->d_wtask;
             const tredgpu_walk_chunk* d_chunks = (const tredgpu_walk_chunk*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task));
             const int64_t* d_rec_base = (const int64_t*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk));
@@ -2281,6 +2288,20 @@ int64_t tredgpu_inflater_pinned_bytes(const tredgpu_inflater* f) {
     size_t n = f->cap_comp + (f->h_out ? f->cap_out : 0) + f->cap_blocks * (2 * sizeof(int64_t) + 2 * sizeof(int32_t)) + f->cap_dense +
                f->cap_pieces * sizeof(FetchPiece) + f->cap_wblk + f->cap_wtask + f->cap_wres + f->cap_hgpool + f->cap_htpool + f->cap_atask + f->cap_ares;
     return (int64_t)n;
+}
+
+int64_t tredgpu_inflater_walk_serial_regions(tredgpu_inflater* f) {
+    if (!f) return -2;
+    if (f->last_walk_tasks == 0 || !f->d_wchained) return 0;
+    ICHK(f, hipSetDevice(f->device));
+    std::vector<WalkChained> c(f->last_walk_tasks);
+    ICHK(f, hipMemcpy(c.data(), f->d_wchained, c.size() * sizeof(WalkChained), hipMemcpyDeviceToHost));
+    int64_t n = 0;
+    for (const WalkChained& w : c) n += w.mode == 0;
+    if (getenv("TREDGPU_TRACE") != nullptr)
+        for (size_t t = 0; t < c.size(); ++t)
+            if (c[t].mode == 0) fprintf(stderr, "tredgpu: region %zu chained serially (reason %d), %d records, status %d\n", t, c[t].pad, c[t].n, c[t].status);
+    return n;
 }
 
 int tredgpu_inflater_walk_ms(tredgpu_inflater* f, double* walk_ms) {
