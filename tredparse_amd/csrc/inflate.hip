@@ -843,8 +843,8 @@ struct WalkRec { int64_t a0; uint64_t at, after; };             // where the rec
 struct WalkFields { uint32_t h; int32_t rtid, rpos, rend, lead, trail; uint16_t flag, nlen; uint32_t bad; };
 static_assert(sizeof(WalkRec) == 24 && sizeof(WalkFields) == 32, "record tuples");
 struct WalkChained { int32_t status, n, mode, klo, khi, pad; };   // per region: how the chain ended, records listed; mode 1: listed by
-                                                                  // walk_chain_par_kernel (places only: walk_parse_kernel works out the
-                                                                  // virtual offsets, the region's blocks lie in [klo, khi)); 0: by walk_chain_kernel
+                                                                  // walk_chain_par_kernel (the region's blocks lie in [klo, khi)), 0: by
+                                                                  // walk_chain_kernel (pad: why the lanes handed the region back)
 
 constexpr int CHAIN_BATCH = 64;
 
@@ -925,8 +925,7 @@ __device__ __forceinline__ int chain_batch(const WalkView& v, const tredgpu_walk
 // true; by induction so are all of them); one that steps over it, meets a length below 32 or leaves the planned blocks has
 // not, and then the region is walked by walk_chain_kernel, one record after the other, as before -- so the result is that
 // kernel's whatever the bytes are.  A region's chain is ~60 dependent loads per lane instead of ~4 000 steps of one
-// wavefront (1.08 ms per launch, a third of the pair walk).  The lanes list only where records lie; their virtual offsets
-// (WalkRec at / after) are worked out by walk_parse_kernel, one lane per record.
+// wavefront (1.08 ms per launch, a third of the pair walk).
 constexpr int PAR_SEG_MIN = 2048;                                  // bytes per lane at least
 __device__ inline uint32_t g_u32(const uint8_t* out, int64_t at);
 __device__ inline uint32_t g_u16(const uint8_t* out, int64_t at);
@@ -1038,6 +1037,33 @@ __device__ bool chain_par_chunk(const WalkView& v, const tredgpu_walk_task& T, c
 #undef PAR_NO
 }
 
+// the same for places that only go up: k = the first block of [lo, hi] that begins at or behind the place, its edges kept
+struct VoffCursor {
+    int k, lo, hi;
+    int64_t edge, before;                              // ooff[k], ooff[k - 1]
+    uint64_t vk, vbefore;                              // the virtual offsets of block k's and block k - 1's first byte
+    __device__ void load(const WalkView& v) {
+        edge = v.ooff[k];
+        vk = k < hi ? (uint64_t)v.bcoff[k] << 16 : (uint64_t)(v.bcoff[hi - 1] + v.bclen[hi - 1]) << 16;
+        before = k > lo ? v.ooff[k - 1] : 0;
+        vbefore = k > lo ? (uint64_t)v.bcoff[k - 1] << 16 : 0;
+    }
+    __device__ void start(const WalkView& v, int lo_, int hi_, int64_t addr) {
+        lo = lo_; hi = hi_;
+        int a = lo, b = hi;
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (v.ooff[mid] >= addr) b = mid; else a = mid + 1;
+        }
+        k = a;
+        load(v);
+    }
+    __device__ uint64_t at(const WalkView& v, int64_t addr) {
+        while (k < hi && edge < addr) { ++k; load(v); }
+        return edge == addr ? vk : vbefore | (uint64_t)(addr - before);
+    }
+};
+
 __global__ void __launch_bounds__(LANES) walk_chain_par_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks,
                                                                const int64_t* rec_base, WalkRec* recs, WalkChained* chained) {
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -1054,13 +1080,24 @@ __global__ void __launch_bounds__(LANES) walk_chain_par_kernel(WalkView v, const
     bool give_up = false;
     for (int c = 0; c < T.n_chunks && !give_up; ++c) {
         ParChunk pc;
-        if (!chain_par_chunk(v, T, chunks[T.chunk_first + c], lane, 0, pc, klo, khi, &why) || n + pc.total > cap) { give_up = true; break; }
-        // ---- list: the same steps again (the bytes are in the cache now) ----
-        int64_t p = pc.s;
-        WalkRec* o = mine + n + pc.first;
-        for (int q = 0; q < pc.cnt; ++q) {
-            o[q].a0 = p;
-            p += 4 + (int64_t)(int32_t)g_u32(out, p);
+        int clo = T.block_end, chi = T.block_first;          // this chunk's blocks
+        if (!chain_par_chunk(v, T, chunks[T.chunk_first + c], lane, 0, pc, clo, chi, &why) || n + pc.total > cap) { give_up = true; break; }
+        klo = min(klo, clo); khi = max(khi, chi);
+        // ---- list: the same steps again (the bytes are in the cache now), every record with its virtual offsets: the
+        //      places only go up, so the block a place lies in is found by stepping on from the one before ----
+        if (pc.cnt > 0) {
+            int64_t p = pc.s;
+            WalkRec* o = mine + n + pc.first;
+            VoffCursor vc;
+            vc.start(v, clo, chi, p);
+            uint64_t at = vc.at(v, p);
+            for (int q = 0; q < pc.cnt; ++q) {
+                const int64_t nxt = p + 4 + (int64_t)(int32_t)g_u32(out, p);
+                const uint64_t after = vc.at(v, nxt);
+                o[q] = WalkRec{p, at, after};
+                p = nxt;
+                at = after;
+            }
         }
         n += pc.total;
     }
@@ -1108,7 +1145,7 @@ __device__ inline uint32_t g_u32(const uint8_t* out, int64_t at) { uint32_t x; _
 
 // one lane per record of the call: slot g of the records' pool belongs to the region whose [rec_base[t], rec_base[t+1])
 // holds it (binary search), and is record g - rec_base[t] of it -- when that region's chain listed that many
-__global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks, const int64_t* rec_base, WalkRec* recs,
+__global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks, const int64_t* rec_base, const WalkRec* recs,
                                                           const WalkChained* chained, WalkFields* fields) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= rec_base[n_tasks]) return;
@@ -1122,10 +1159,6 @@ __global__ void __launch_bounds__(256) walk_parse_kernel(WalkView v, int n_tasks
     const uint8_t* out = v.out;
     const int64_t a0 = recs[g].a0, r = a0 + 4;
     const int32_t size = (int32_t)g_u32(out, a0);
-    if (C.mode == 1) {                                     // listed by place only: the virtual offsets of the record and of what follows it
-        recs[g].at = walk_voffset(v, C.klo, C.khi, a0);
-        recs[g].after = walk_voffset(v, C.klo, C.khi, a0 + 4 + (int64_t)size);
-    }
     WalkFields F;
     F.rtid = (int32_t)g_u32(out, r);
     F.rpos = (int32_t)g_u32(out, r + 4);
