@@ -481,6 +481,38 @@ def test_the_serial_chain_and_the_lanes_list_the_same_records(inf, synthetic, mo
         f.close()
 
 
+def test_a_fetched_block_that_is_not_what_the_decoder_wrote_is_found_out(inf, synthetic):
+    """The decoder's CRC vouches for the bytes on the device; the scan reads their copy in host memory.  One block in
+    sixteen (by its place in the file) is checked again on the host at first use: damage exactly those in the fetched
+    copy -- the scan drops them, inflates them itself and gives the plain scan's numbers."""
+    import ctypes
+    path, repo, names = synthetic[0]
+    f, g = bamio.AlignmentFile(path), bamio.AlignmentFile(path)
+    sites, regions = _site_arrays(repo, names, [repo[n] for n in names], f)
+    rl = f.max_read_len(101)
+    plan = f.plan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, [f], [plan])
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, _ = _walk_inputs([f], [sites], [rl], firsts)
+    status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks)
+    need = walk_need(coff_of[0], host_of[0], res)
+    inf.fetch(need)
+    sampled = ((((np.asarray(coff_of[0]).astype(np.uint64) >> np.uint64(4)) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(60)) == 0) & (need != 0)
+    assert sampled.sum() >= 1, "no block of the sample falls into the checked sixteenth: pick another seed"
+    host = np.ctypeslib.as_array((ctypes.c_uint8 * int(ooff[n_all])).from_address(inf.out_addr))
+    for k in np.flatnonzero(sampled):
+        host[ooff[k] + 40] ^= 0x55
+    f.preload(inf.out_addr, ooff[:n_all + 1], np.where(need != 0, status, 1).astype(np.int32), crc)
+    u2, p2 = f.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(res, gp, tp))
+    hits, misses = f.preload_clear()
+    units, pools = g.scan(sites, regions, rl, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    assert misses >= 1 and hits > 0
+    for key in units.dtype.names:
+        assert (units[key] == u2[key]).all(), key
+    for key in pools:
+        assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
+    f.close(); g.close()
+
+
 def test_a_pair_without_alignment_end_is_the_hosts_to_report(inf, tmp_path):
     """The reference dies in get_target_length when the second read of a +/- pair has no alignment end (`None - int`); the
     kernel ends that region with status 5, the scan walks it itself and reports what the plain scan reports (pe_status

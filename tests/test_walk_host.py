@@ -87,6 +87,34 @@ def test_feeder_with_walked_pair_lengths_gives_the_plain_scans(cohort, monkeypat
     assert sum(m.walks for m in ModelInflater.made) == 4                 # (the chunk with the missing file has nothing to decode)
 
 
+def test_decoded_chunks_that_pile_up_share_a_genotyping_call(cohort, monkeypatch):
+    """A driver whose genotyping call is slower than its decoder takes every chunk whose scans are already in along in the
+    next call (run_many, MERGED_BATCH): fewer calls, every sample once, in cohort order -- and it never waits for a chunk
+    to do so (with a fast engine nothing is merged)."""
+    import time
+    from tests.fake_engine import FakeEngine
+    if not hasattr(bamio.AlignmentFile(cohort[0][1]), "plan_walks"):
+        pytest.skip("no native BAM layer")
+    monkeypatch.setattr("tredparse_amd._lib.Inflater", ModelInflater)
+
+    class Slow(FakeEngine):
+        def genotype_packed(self, b, dense=False):
+            time.sleep(0.6)
+            return FakeEngine.genotype_packed(self, b, dense)
+    tasks = [a for a in cohort if a[0] != "missing"] * 2
+    for engine, expect_merge in ((Slow(seed=3), True), (FakeEngine(seed=3), None)):
+        t.release_inflaters()
+        for k in t.TIMING:
+            t.TIMING[k] = 0
+        seen = []
+        t.run_many(tasks, engine, batch=2, threads=2, lazy_details=True, sink=lambda r: seen.append(r["samplekey"]),
+                   inflate_device=0, gpu_walk=True)
+        assert seen == [a[0] for a in tasks]
+        if expect_merge:
+            assert t.TIMING["merged_chunks"] >= 2
+    t.release_inflaters()
+
+
 def test_regions_the_walker_declines_are_walked_by_the_scan(cohort, monkeypatch):
     """Every region comes back with a status (here: the model pretends a damaged block in each): the scans compute the
     pair lengths themselves, inflating what was not fetched, and nothing changes in the result."""

@@ -1434,7 +1434,11 @@ int tredbam_preload_crc(tredbam* b, const uint8_t* out, const int64_t* out_off, 
         const tredbam::Planned& p = b->plan[k];
         if (status[k] != 0 || out_off[k + 1] - out_off[k] != (int64_t)p.isize) continue;
         if (crc && crc[k] != p.crc) continue;          // the decoder's checksum of its own output is not the trailer's
-        b->preloaded[p.coffset] = tredbam::Preloaded{out + out_off[k], p.isize, p.clen, p.crc, crc != nullptr};
+        // the decoder's CRC vouches for the bytes on the DEVICE; what the scan reads is their copy in host memory (a fetch
+        // behind the walks).  One block in sixteen -- chosen by its place in the file -- is therefore checked again here at
+        // first use (load_block): a stale or partial fetch does not pass unnoticed for long, at 1/16 of the CRC's cost.
+        const bool sampled = (((uint64_t)p.coffset >> 4) * 0x9E3779B97F4A7C15ull >> 60) == 0;
+        b->preloaded[p.coffset] = tredbam::Preloaded{out + out_off[k], p.isize, p.clen, p.crc, crc != nullptr && !sampled};
         ++n;
     }
     // blocks of an earlier scan in the handle's own cache stay valid; the current block pointer may not

@@ -42,7 +42,8 @@ logger = logging.getLogger(__name__)
 # the writer thread's time in the sink (JSON / VCF text and files)
 TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
           "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0, "walk_regions": 0, "walk_declined": 0,
-          "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0, "walk_call": 0.0, "walk_fetch": 0.0, "pack": 0.0}
+          "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0, "walk_call": 0.0, "walk_fetch": 0.0, "pack": 0.0,
+          "merged_chunks": 0}
 _TIMING_LOCK = threading.Lock()
 
 
@@ -481,6 +482,15 @@ class _InflateFeeder(object):
             raise item
         return item
 
+    def next_if_scanned(self):
+        """The next chunk if it is waiting AND all of its scans have finished, else None (the end of the cohort and errors
+        stay where they are, for next())."""
+        with self.q.mutex:
+            head = self.q.queue[0] if self.q.queue else None
+            if not isinstance(head, tuple) or not all(f.done() for f in head[1]):
+                return None
+        return self.q.get()       # (one consumer: what was at the head still is)
+
     def close(self):
         import queue
         self.stop.set()
@@ -856,6 +866,9 @@ class _Writer(object):
             raise self.error
 
 
+MERGED_BATCH = 48        # samples per genotyping call at most when decoded chunks pile up (run_many)
+
+
 def _chunked(task_args, first, batch):
     """Lists of `first`, then `batch` tasks, taken lazily from any iterable."""
     it = iter(task_args)
@@ -914,6 +927,17 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
                 t0 = time.perf_counter()
                 scans = [f.result() for f in futs]
                 timing_add(scan_wait=time.perf_counter() - t0)
+                # Chunks whose scans are already in ride along in the same genotyping call.  A call's time is mostly per
+                # CALL once the decoder's wavefronts fill the device (a dozen launches that each wait for room: 21 ms for
+                # 12 samples against 21 ms for 1 000 on an idle device), so a driver that has fallen behind its decoder
+                # catches up by taking two or three chunks at once -- and never waits for one to do so.
+                while len(chunk) + batch <= max(batch, MERGED_BATCH):
+                    more = feeder.next_if_scanned()
+                    if more is None:
+                        break
+                    chunk = chunk + more[0]
+                    scans = scans + [f.result() for f in more[1]]
+                    timing_add(merged_chunks=1)
                 yield chunk, scans
         elif ex is not None:
             ahead = deque()
