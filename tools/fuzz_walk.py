@@ -46,7 +46,9 @@ def main():
             recs.flag[rng.random(n) < 0.05] ^= 0x10                        # strand flipped
             block = int(rng.choice([200, 333, 1000, 4096, 20000, 0xff00]))
             path = os.path.join(root, "r{}_{}.bam".format(rnd, k))
-            synth_bam.write_bam(path, recs, sample="f{}_{}".format(rnd, k), block=block, split_records=True)
+            # every fifth round: base qualities that look like record heads (the lanes' guesses go wrong, the serial chain takes over)
+            synth_bam.write_bam(path, recs, sample="f{}_{}".format(rnd, k), block=block, split_records=True,
+                                decoys=0.5 if rnd % 5 == 4 else 0.0, decoy_seed=rnd)
             cases.append(path)
             out["block_sizes"].append(block)
         handles = [bamio.AlignmentFile(p) for p in cases]

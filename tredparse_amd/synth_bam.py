@@ -245,10 +245,11 @@ def _bgzf_block(data, level):
 _EOF_BLOCK = _bgzf_block(b"", 6)
 
 
-def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False):
+def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False, decoys=0.0, decoy_seed=1):
     """Write `recs` (sorted) as <path> and <path>.bai.  Returns the number of uncompressed bytes.  split_records: cut the
     record stream into blocks of `block` bytes wherever that falls (records then straddle blocks, as in files written by
-    samtools) instead of at record boundaries."""
+    samtools) instead of at record boundaries.  decoys: that share of the reads gets base qualities that read as the
+    head of a BAM record of the read's contig (tests of the device walk's guessed record starts: DESIGN 4.5)."""
     n = len(recs)
     L = recs.codes.shape[1]
     names = recs.names(sample)
@@ -292,6 +293,15 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False
     flat[idx] = seq
     idx = (off[:-1] + seq_at + seq.shape[1])[:, None] + np.arange(L)[None, :]
     flat[idx] = 0xff                                                        # no base qualities
+    if decoys > 0 and L >= 48 and n:
+        fake = np.zeros(1, fixed.dtype)
+        fake["bs"], fake["pos"], fake["l_name"], fake["mtid"], fake["mpos"] = 40, 5, 2, -1, -1
+        sel = np.nonzero(np.random.default_rng(decoy_seed).random(n) < decoys)[0]
+        rows = np.repeat(fake, len(sel))
+        rows["tid"] = recs.tid[sel]
+        body = np.concatenate([rows.view(np.uint8).reshape(len(sel), 36), np.tile(np.frombuffer(b"a\0", np.uint8), (len(sel), 1))], axis=1)
+        at = (off[sel] + seq_at[sel] + seq.shape[1] + 4)[:, None] + np.arange(38)[None, :]
+        flat[at] = body
     header = b"BAM\x01"
     text = "@HD\tVN:1.5\tSO:coordinate\n" + "".join("@SQ\tSN:{}\tLN:{}\n".format(c, CONTIG_LEN) for c in CONTIGS)
     header += struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(CONTIGS))
