@@ -342,9 +342,11 @@ int tredgpu_inflater_timing(tredgpu_inflater* inf, double* total_ms, double* ker
  * their places in the pinned output.  include/tredbam.h (tredbam_plan_walks, tredbam_plan_blocks, tredbam_scan_pe) is the
  * host's half; the structs have the layouts of tredbam_walk_task / _chunk / _result.
  *   results[t].status  0: walked.  1 a block the walk needs is not among the sample's (or the file ends), 2 a block the
- *                      decoder rejected or whose CRC-32 is not blk_crc, 3 a record that makes no sense, 4 more than 8 192
- *                      query names in the region, 5 a pair whose second read has no alignment end (the reference dies
- *                      there), 6 the pools are full: the host walks that region itself (tredbam_scan_pe does).
+ *                      decoder rejected or whose CRC-32 is not blk_crc, 3 a record that makes no sense, 4 more query
+ *                      names than the region's table holds (4 096, or 8 192 when a region of the call spans more
+ *                      than 40 blocks) or more than 32 768 records, 5 a pair whose second read has no alignment end
+ *                      (the reference dies there), 6 the pools are full, 7 two names under one hash: the host walks
+ *                      that region itself (tredbam_scan_pe does).
  */
 typedef struct tredgpu_walk_task {
     int32_t tid, start, end;        /* records of contig tid overlapping [start, end)                                     */

@@ -513,6 +513,31 @@ def test_a_fetched_block_that_is_not_what_the_decoder_wrote_is_found_out(inf, sy
     f.close(); g.close()
 
 
+def test_regions_at_100x_use_the_large_name_table(inf, tmp_path):
+    """A +-10 kb region at 100x holds ~13 000 records in ~65 blocks and ~6 500 names: the launch takes the 8 192-name table
+    (128 KB of LDS per workgroup) -- lists and window as the host computes them, nothing declined."""
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1")]
+    made = synth_bam.make_bams(str(tmp_path), 1, seed=17, loci=loci, p=synth.SynthParams(coverage=100, expanded_max=120, expanded_frac=0.3))
+    path, repo, names = made[0][1], TREDsRepo(), [l["name"] for l in loci]
+    f, g = bamio.AlignmentFile(path), bamio.AlignmentFile(path)
+    sites, regions = _site_arrays(repo, names, [repo[n] for n in names], f)
+    plan = f.plan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, [f], [plan])
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, _ = _walk_inputs([f], [sites], [150], firsts)
+    status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks, pool_pairs=_lib.walk_pool_pairs(tasks, ooff))
+    assert (status == 0).all() and (res["status"] == 0).all(), res["status"]
+    assert inf.walk_serial_regions() == 0
+    for k, name in enumerate(names):
+        t = repo[name]
+        eg, et = g.pe_lengths(t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE, t.repeat_start - FLANKMATCH,
+                              t.repeat_end + FLANKMATCH, SPAN)
+        assert list(gp[res["global_first"][k]:][:res["n_global"][k]]) == eg and list(tp[res["target_first"][k]:][:res["n_target"][k]]) == et
+        assert len(eg) + len(et) > 5000
+        n, vbeg, vend = _window_span(path, t.chr, t.repeat_start - DNAPE_ELONGATE, t.repeat_end + DNAPE_ELONGATE, t.repeat_start - SPAN, t.repeat_end + SPAN)
+        assert (int(res["n_window"][k]), int(res["win_vbeg"][k]), int(res["win_vend"][k])) == (n, vbeg, vend)
+    f.close(); g.close()
+
+
 def test_a_pair_without_alignment_end_is_the_hosts_to_report(inf, tmp_path):
     """The reference dies in get_target_length when the second read of a +/- pair has no alignment end (`None - int`); the
     kernel ends that region with status 5, the scan walks it itself and reports what the plain scan reports (pe_status

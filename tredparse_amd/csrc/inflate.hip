@@ -684,18 +684,15 @@ __global__ __launch_bounds__(LANES, 7) void inflate_kernel(const uint32_t* __res
 // appearance; of every name seen twice the first two records must map +/-; tlen from the soft-clipped ends; a pair that
 // spans the tract goes to the target list, any other to the global one.
 //
-// One region = one wavefront.  Where the next record starts is written in this one, so the walk is a chain -- but a chain
-// through LDS, not through HBM: the wavefront copies 6 KB of the block stream at a time into LDS (one coalesced load for
-// ~16 records; a lane walking the records in global memory paid a miss of 1-2 us for each, and several per record: 24 ms
-// for a region of 4 000 records), follows the length words there, and then every lane parses ONE of the records found
-// (walk_region_records).  The name table lives in LDS as well (slots of tag << 15 | records seen under the tag << 13 | pair
-// index: one LDS read finds a record's mate AND says whether it is the pair's second record), so finding a record's mate
-// costs no memory access either; what a tag match does NOT
-// prove -- that the two names are equal byte for byte -- is checked for all pairs at the end by the 64 lanes in parallel,
-// and a single mismatch there gives the region back to the host, as does anything else out of the ordinary: a block the
-// plan does not hold or the decoder rejected or whose CRC-32 is not its trailer's, a record that makes no sense, more names
-// than the table holds.  The host then walks that region itself, as it does without this kernel, and reports what is wrong
-// with the file.
+// Four launches per call (walk_chain_par_kernel -> walk_chain_kernel for what that one hands back -> walk_parse_kernel ->
+// pair_walk_kernel; the comments at each say what it does and why).  Nothing here reads HBM a record at a time: a lane
+// walking the records of a region in global memory paid a miss of 1-2 us for each, and several per record (24 ms for a
+// region of 4 000 records) -- the serial chain goes through a 6 KB window in LDS, the parallel one gives every lane ~60
+// records, the name table lives in LDS.  What a hash match in that table does NOT prove -- that two names are equal byte
+// for byte -- is checked for all pairs at the end by all lanes, and a single mismatch there gives the region back to the
+// host, as does anything else out of the ordinary: a block the plan does not hold or the decoder rejected or whose CRC-32
+// is not its trailer's, a record that makes no sense, more names than the table holds.  The host then walks that region
+// itself, as it does without these kernels, and reports what is wrong with the file.
 struct WalkView {
     const uint8_t* out; const int64_t* ooff;          // the decoder's output and its block offsets
     const int32_t* bstatus; const uint32_t* bcrc;     // what the decoder said about each block
@@ -827,18 +824,16 @@ struct WalkCursor {
     }
 };
 
-// The region's walk in three launches (round 5; one wavefront walked, parsed and paired a region's ~4 000 records batch by
-// batch before: 4.06 ms for the 480 regions of 16 samples, on half of the chip's SIMDs, every step waiting for the one
-// before):
-//   chain    walk_chain_kernel, one wavefront per region: all that is serial about a BAM -- from the region's first record
-//            follow the length words through the LDS window, up to the first record beyond the region -- and NOTHING else:
-//            where every record lies (WalkRec), a batch of 64 per coalesced store;
+// The region's walk, taken apart (round 4: one wavefront walked, parsed and paired a region's ~4 000 records batch by
+// batch: 4.06 ms for the 480 regions of 16 samples, on half of the chip's SIMDs, every step waiting for the one before):
+//   chain    where every record lies (WalkRec).  walk_chain_par_kernel: 64 lanes per region, each from a guessed record
+//            start that the lane before it proves; walk_chain_kernel, one wavefront following the length words through
+//            the LDS window, for the regions the lanes hand back;
 //   parse    walk_parse_kernel, one LANE per record, every record of every region of the call side by side (~2 million of
 //            them for 16 samples: the chip is full): fields, CIGAR (end on the reference, soft clips), name hash ->
 //            WalkFields, 32 bytes per record;
-//   resolve  pair_walk_kernel, one wavefront per region: 64 WalkFields per coalesced load, ballots say which records count
-//            for the window and which enter the pair table; only those go through the table one after the other (probe in
-//            LDS, the owning lane writes its fields out); then PairTable::finish as before.
+//   resolve  pair_walk_kernel, eight wavefronts per region: PairTable::add by LDS atomics (first and second record per
+//            name, pairs ranked by ballot and prefix sum), then PairTable::finish.
 struct WalkRec { int64_t a0; uint64_t at, after; };             // where the record's length word lies in `out`; the virtual offsets of the record and of what follows it
 struct WalkFields { uint32_t h; int32_t rtid, rpos, rend, lead, trail; uint16_t flag, nlen; uint32_t bad; };
 static_assert(sizeof(WalkRec) == 24 && sizeof(WalkFields) == 32, "record tuples");
