@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_inflate.sh TAG [samples per call] -- run ON THE GPU BOX (through gpurun): the rocprofv3 evidence for
-# inflate_kernel.  The profiled program is tools/_ab/inflate_prof (tools/inflate_prof.hip built by the
-# caller: a plain binary, directly after `--`), decoding the BGZF blocks of a synthetic 30x BAM of the bench.
+# inflate_kernel.  The profiled program is tools/inflate_prof.hip, built here into /tmp (a plain binary,
+# directly after `--`), decoding the BGZF blocks of a synthetic 30x BAM of the bench (made here as well, by a plain process).
 #   gpurun_out/prof_TAG/kernel_stats.csv   --kernel-trace --stats
 #   gpurun_out/prof_TAG/pmc_*              one counter pass each (never combined with a trace option other than --kernel-trace)
 #   gpurun_out/prof_TAG/pmc_summary.json   tools/pmc_to_json.py
@@ -11,8 +11,12 @@ M=${2:-8}     # (counter passes serialise the dispatches: 56 samples per call di
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-BIN=$ROOT/tools/_ab/inflate_prof
-BAM=$ROOT/tools/_ab/syn0000.bam
+WORK=/tmp/profile_inflate_$$
+mkdir -p $WORK
+BIN=$WORK/inflate_prof
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $BIN $ROOT/tools/inflate_prof.hip 2> $OUT/build.err || { tail -5 $OUT/build.err; exit 1; }
+python3 $ROOT/tools/walk_prof.py make $WORK > /dev/null 2>&1
+BAM=$(ls $WORK/*.bam | head -1)
 cd /tmp && export TMPDIR=/tmp
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BIN $BAM $M 6 1 > "$OUT/run_stats.json" 2> "$OUT/stats.err"
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
