@@ -309,8 +309,11 @@ int tredgpu_get_sw_counters(tredgpu_ctx* ctx, uint64_t out[8]);
  *                             stay valid until the next reserve that has to grow, or destroy.
  *   tredgpu_inflate_blocks    copies in, decodes, copies out (in slices: the copy-out of one slice runs beside the
  *                             decoding of the next), waits.  status[k]: 0, -1 invalid stream (or it runs
- *                             past its payload), -2 the stream ends before out_off[k+1]-out_off[k] bytes.  Returns
- *                             the number of blocks with a non-zero status, or <0.
+ *                             past its payload), -2 the stream ends before out_off[k+1]-out_off[k] bytes, -3 Huffman
+ *                             codes that need more second-level table entries than the decoder holds (a guard: the
+ *                             worst complete codes fit; the caller inflates such a block itself, like any other it
+ *                             gets no bytes for).
+ *                             Returns the number of blocks with a non-zero status, or <0.
  */
 typedef struct tredgpu_inflater tredgpu_inflater;
 int tredgpu_inflater_create(int device_id, tredgpu_inflater** out);

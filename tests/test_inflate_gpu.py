@@ -201,3 +201,114 @@ def test_device_crc_matches_zlib(inf):
     assert (status == 0).all() and [int(c) for c in sums] == [b[1] for b in blocks]
     total, kernel = inf.timing()
     assert 0 < kernel <= total
+
+
+# ---- hand-made dynamic blocks: code length sets that need the deepest second-level tables ------------------------------------
+class _Bits(object):
+    def __init__(self):
+        self.out, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, value, nbits):                 # value's low bit first (header fields, extra bits)
+        self.acc |= (value & ((1 << nbits) - 1)) << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, code, nbits):                 # a Huffman code: its first (most significant) bit first
+        for i in range(nbits - 1, -1, -1):
+            self.put((code >> i) & 1, 1)
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 255)
+        return bytes(self.out)
+
+
+def _canonical(lens):
+    count = [0] * 17
+    for l in lens:
+        count[l] += 1
+    count[0] = 0
+    nxt, code = [0] * 17, 0
+    for l in range(1, 16):
+        code = (code + count[l - 1]) << 1
+        nxt[l] = code
+    codes = []
+    for l in lens:
+        codes.append(nxt[l] if l else 0)
+        nxt[l] += 1 if l else 0
+    return codes
+
+
+LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+LEN_EXTRA = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+DIST_BASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+DIST_EXTRA = [0, 0, 0, 0] + [k // 2 for k in range(2, 28)]
+
+
+def _dynamic_block(l_lens, d_lens, symbols):
+    """One final dynamic block with the given code lengths (286 + 30, each sent as a plain 4-bit code-length code) and
+    symbols: an int = a literal, (length code 0..28, its extra bits, distance code 0..29, its extra bits) = a match."""
+    b = _Bits()
+    b.put(1, 1); b.put(2, 2)
+    b.put(len(l_lens) - 257, 5); b.put(len(d_lens) - 1, 5); b.put(19 - 4, 4)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    for s in order:
+        b.put(4 if s < 16 else 0, 3)             # code lengths 0..15 as themselves: sixteen 4-bit codes, complete
+    for l in list(l_lens) + list(d_lens):
+        b.code(l, 4)
+    lc, dc = _canonical(l_lens), _canonical(d_lens)
+    for s in symbols:
+        if isinstance(s, int):
+            b.code(lc[s], l_lens[s])
+        else:
+            c, cx, d, dx = s
+            b.code(lc[257 + c], l_lens[257 + c]); b.put(cx, LEN_EXTRA[c])
+            b.code(dc[d], d_lens[d]); b.put(dx, DIST_EXTRA[d])
+    b.code(lc[256], l_lens[256])
+    return b.done()
+
+
+# the code length sets that need the most second-level table entries behind a 9-bit / 7-bit root (a hill climb over all
+# complete codes of 286 / 30 symbols up to 15 bits: 338 and 272 entries of the decoder's 640)
+WORST_L = [1, 2, 3, 4, 7] + [10] * 11 + [11] * 41 + [12] * 49 + [13] * 49 + [14] * 65 + [15] * 66
+WORST_D = [1, 2, 3, 4, 5, 8] + [9] * 9 + [10] * 9 + [11, 12, 13, 14, 15, 15]
+
+
+def _complete(lens):
+    return sum(2 ** (15 - l) for l in lens) == 2 ** 15
+
+
+@pytest.mark.parametrize("shuffle", [0, 1, 2])
+def test_codes_that_need_the_deepest_second_level_tables(inf, shuffle):
+    """Every code longer than the root tables' 9 / 7 bits is found through a link to a second-level table; here the
+    literal / length and the distance code are the complete codes that need the most of them, every symbol of both is
+    used, and zlib has to read the same bytes."""
+    rng = np.random.default_rng(40 + shuffle)
+    l_lens, d_lens = list(WORST_L), list(WORST_D)
+    assert len(l_lens) == 286 and len(d_lens) == 30 and _complete(l_lens) and _complete(d_lens)
+    if shuffle:
+        rng.shuffle(l_lens); rng.shuffle(d_lens)
+    symbols = [int(x) for x in rng.permutation(256)] * 3                    # 768 bytes first: room for every short distance
+    produced = len(symbols)
+    for c in rng.permutation(29):
+        for d in rng.permutation(30):
+            dx = int(rng.integers(1 << DIST_EXTRA[d])) if DIST_EXTRA[d] else 0
+            if DIST_BASE[d] + dx > produced:
+                continue
+            cx = int(rng.integers(1 << LEN_EXTRA[c])) if LEN_EXTRA[c] else 0
+            symbols.append((int(c), cx, int(d), dx))
+            produced += LEN_BASE[c] + cx
+            symbols.append(int(rng.integers(256)))
+            produced += 1
+            if produced > 60000:
+                break
+        if produced > 60000:
+            break
+    stream = _dynamic_block(l_lens, d_lens, symbols)
+    want = zlib.decompressobj(-15).decompress(stream)
+    assert len(want) == produced
+    status, got = _inflate(inf, [stream, _raw(want)], [len(want), len(want)])
+    assert list(status) == [0, 0] and got[0] == want and got[1] == want

@@ -9,11 +9,11 @@
 //
 //   * What is serial is only WHERE the next symbol starts.  What a symbol IS, given its start, is not: so every lane
 //     decodes the complete symbol that would start at ITS bit offset of a 64-bit window of the stream -- literal /
-//     length code through a direct table in LDS (11 bits; longer codes canonically from the length counts), the
-//     length's extra bits, the distance code (9-bit direct table) and its extra bits, all from the lane's own 57-bit
-//     view of the stream (15 + 5 + 15 + 13 = 48 bits at most) -- and packs (bits consumed, kind, length or literal,
-//     distance) into one dword.  63 of the 64 answers are for offsets no symbol starts at; they cost nothing but the
-//     VALU slots of a wavefront that would otherwise idle behind a serial chain.
+//     length code through a 9-bit root table in LDS and, for longer codes, a second-level table behind a link (four
+//     look-ups per lane at most, no branches), the length's extra bits, the distance code (7-bit root) and its extra
+//     bits, all from the lane's own 57-bit view of the stream (15 + 5 + 15 + 13 = 48 bits at most) -- and packs (bits
+//     consumed, kind, length or literal, distance) into one dword.  Most of the 64 answers are for offsets no symbol
+//     starts at: they are what lets the serial part be as short as it is.
 //   * The serial chain is then a walk over lanes on the scalar unit: v_readlane the dword at the current offset, set
 //     the offset's bit in a 64-bit mask of symbol starts, add the symbol's bit count to the offset -- no table look-up,
 //     no memory access, four instructions and a branch per symbol; the windows' look-ups do not depend on it.  The
@@ -24,9 +24,11 @@
 //     long matches and the few whose source reaches into the batch are copied one after the other by all 64 lanes,
 //     64 bytes per step (period handling for distances below 64).  Destinations of a batch are consecutive, so the
 //     stores of a batch fall into a handful of cache lines.
-//   * Tables are built by the wavefront together: code-length histogram by LDS atomics, symbols ranked within their
-//     length by ballot + prefix popcount, direct-table entries decoded canonically entry-parallel.
-//   * LDS: 5.8 KB per wavefront and at most 72 VGPRs: 28 wavefronts per CU instead of one -- a wavefront is a chain of
+//   * Tables are built by the wavefront together: code-length histogram by LDS atomics, every symbol its own canonical
+//     code (rank within its length by ballot + prefix popcount) and the entries that decode to it; the second-level
+//     tables of both alphabets share 640 entries (the worst cases of complete codes need 340 + 272; a block that asked
+//     for more would get status -3 and be inflated by the host like any block the decoder does not vouch for).
+//   * LDS: 5.6 KB per wavefront and 72 VGPRs: 28 wavefronts per CU instead of one -- a wavefront is a chain of
 //     short dependent steps, what fills the CU is how many are resident; no per-block workspace in global memory.
 // Nothing here knows BAM: the C ABI (include/tredgpu.h, tredgpu_inflate_*) takes payload offsets and sizes and
 // returns bytes plus a status per block; gzip framing and ISIZE stay with the host library (libtredbam).
@@ -49,20 +51,20 @@ namespace {
 constexpr int LANES = 64;
 constexpr int MAXBITS = 15, MAXL = 288, MAXD = 32;
 #ifndef ROOTL_BITS
-#define ROOTL_BITS 10
+#define ROOTL_BITS 9
 #define ROOTD_BITS 7
 #endif
 constexpr int ROOTL = ROOTL_BITS, ROOTD = ROOTD_BITS;
+constexpr int SUB_CAP = 640;       // entries of second-level tables, both alphabets together: complete codes of 286 / 30 symbols
+                                   // and at most 15 bits need 340 behind a 9-bit root (zlib's ENOUGH_LENS 852 - 512) and 272
+                                   // behind a 7-bit one at the worst (exhaustive hill climbing over code length sets)
 
-// one wavefront's tables (one block in flight per wavefront).  5.8 KB: 28 wavefronts per CU -- the decoder is a chain
+// one wavefront's tables (one block in flight per wavefront).  5.6 KB: 28 wavefronts per CU -- the decoder is a chain
 // of short dependent steps per wavefront, and what fills the CU is how many of them are resident
 struct WaveLds {
-    uint32_t fastL[1 << ROOTL];   // direct tables on the next ROOTL / ROOTD bits of the stream (entries: see entry_L / entry_D)
-    uint32_t fastD[1 << ROOTD];
-    uint16_t symL[MAXL];          // symbols sorted by (code length, symbol): canonical decoding of the longer codes
-    uint16_t symD[MAXD];
-    int32_t longL[2 + MAXBITS - ROOTL], longD[2 + MAXBITS - ROOTD];   // canonical decoding of the longer codes: first code and
-                                                                      // symbol index at length ROOT + 1, codes per length
+    uint32_t rootL[1 << ROOTL];   // direct tables on the next ROOTL / ROOTD bits of the stream (entries: see entry_L / entry_D);
+    uint32_t rootD[1 << ROOTD];   // a code longer than that: a LINK to its second-level table in sub[]
+    uint32_t sub[SUB_CAP];        // second-level tables of both alphabets, on the bits behind the root's
     union {
         uint32_t queue[2 * LANES];    // decoded symbols in stream order, waiting to be executed 64 at a time
         struct {                      // what only the block header needs (the queue is empty then)
@@ -132,18 +134,19 @@ struct UBits {
     __device__ __forceinline__ int pos() const { return idx * 32 - cnt; }
 };
 
-// Direct-table entries (one dword) carry everything a lane needs, so that the window's look-ups are a handful of
+// Table entries (one dword) carry everything a lane needs, so that the window's look-ups are a handful of
 // instructions per lane:
 //   literal / length table:  literal      -> the packed symbol itself
 //                            end of block -> the packed symbol itself
 //                            length code  -> [31:25] code length + extra bits, [24:23] K_MATCH, [22:20] extra bits,
 //                                            [19:16] code length, [7:0] base length - 3
 //   distance table:          [31:25] code length + extra bits, [23:20] extra bits, [19:16] code length, [14:0] base - 1
-//   both:                    SLOW_SYMBOL = the code is longer than the table's ROOT bits, or there is none: the walk asks
-//                            for the canonical decoding only if it gets there (4-5 % of the real symbols; most windows
-//                            never do);  BAD_SYMBOL = a symbol no stream may use.  Both read as "64 bits consumed, kind
-//                            K_BAD": no valid entry has its top bit set, and the walk stops at them by itself.
-constexpr uint32_t SLOW_SYMBOL = BAD_SYMBOL | 1u;
+//   both:                    LINK | bits << 16 | first: the code is longer than the root table's bits -- its entry is
+//                            sub[first + the next `bits` bits of the stream] (round 4 decoded such codes canonically,
+//                            only where a symbol really started with one: 4-5 % of the symbols, a third of the kernel's
+//                            vector instructions);  BAD_SYMBOL = a symbol no stream may use, a code that is none.
+//                            No valid entry has its top bit set: the walk stops at BAD by itself; LINK has the top two.
+constexpr uint32_t LINK = 0xC0000000u;
 
 __device__ __forceinline__ uint32_t entry_L(int sym, int clen) {
     if (sym < 256) return (uint32_t)clen << P_BITS | K_LIT << P_KIND | (uint32_t)sym;
@@ -161,14 +164,19 @@ __device__ __forceinline__ uint32_t entry_D(int sym, int clen) {
     return (uint32_t)(clen + extra) << P_BITS | (uint32_t)extra << 20 | (uint32_t)clen << 16 | (uint32_t)(base - 1);
 }
 
-// count[] / sorted symbols / direct table of a canonical code from n code lengths in LDS, by the whole wavefront.
-// Returns <0 for an over-subscribed set, >0 for an incomplete one, 0 for a complete one (puff's `left`); zeros = the
-// number of unused symbols.
+// Root table and second-level tables of a canonical code from n code lengths in LDS, by the whole wavefront: every
+// symbol works out its own code (first code of its length + its rank among the symbols of that length: a ballot and a
+// prefix popcount) and writes the entries that decode to it.  Returns <0 for an over-subscribed set, >0 for an incomplete
+// one, 0 for a complete one (puff's `left`); TABLES_FULL when sub[] cannot hold the block's second-level tables (the
+// block is then the host's, like any block the decoder does not vouch for); zeros = the number of unused symbols.
+// depth: 1 << ROOT bytes of scratch (how many bits each root prefix's second-level table takes).
+constexpr int TABLES_FULL = -1000;
 template <int ROOT, bool DIST>
-__device__ int build_tables(WaveLds& S, const uint8_t* lens, int n, uint16_t* sym, uint32_t* fast, int32_t* longc, int& zeros, int lane) {
+__device__ int build_tables(WaveLds& S, const uint8_t* lens, int n, uint32_t* root, uint8_t* depth, int& sub_used, int& zeros, int lane) {
     if (lane < 16) S.hdr.cnt[lane] = 0;
     __syncthreads();
     for (int s = lane; s < n; s += LANES) atomicAdd(&S.hdr.cnt[lens[s]], 1u);
+    for (int t = lane; t < (1 << ROOT); t += LANES) { root[t] = BAD_SYMBOL; depth[t] = 0; }
     __syncthreads();
     int c[MAXBITS + 1];
 #pragma unroll
@@ -181,74 +189,94 @@ __device__ int build_tables(WaveLds& S, const uint8_t* lens, int n, uint16_t* sy
         left -= c[l];
         if (left < 0) return left;
     }
-    // symbols sorted by (length, symbol): the rank inside a length is a ballot and a prefix popcount per 64 symbols
-    int off[MAXBITS + 1];
-    off[1] = 0;
+    int first[MAXBITS + 2];                                // the first code of every length
+    first[1] = 0;
 #pragma unroll
-    for (int l = 1; l < MAXBITS; ++l) off[l + 1] = off[l] + c[l];
-    for (int s0 = 0; s0 < n; s0 += LANES) {
-        const int s = s0 + lane;
-        const int l = s < n ? (int)lens[s] : 0;
+    for (int l = 1; l <= MAXBITS; ++l) first[l + 1] = (first[l] + c[l]) << 1;
+    // the symbol's code, its bits in the order the stream has them (bit 0 first)
+    auto code_of = [&](int l, int (&seen)[MAXBITS + 1]) {
+        int code = 0;
 #pragma unroll
         for (int L = 1; L <= MAXBITS; ++L) {
             if (c[L] == 0) continue;
             const uint64_t m = __builtin_amdgcn_ballot_w64(l == L);
-            if (l == L) sym[off[L] + lanes_below(m)] = (uint16_t)s;
-            off[L] += (int)__popcll(m);
+            if (l == L) code = first[L] + seen[L] + lanes_below(m);
+            seen[L] += (int)__popcll(m);
+        }
+        return l > 0 ? (int)(__builtin_bitreverse32((uint32_t)code) >> (32 - l)) : 0;
+    };
+    // pass 1: codes of at most ROOT bits fill the root table; longer ones say how deep their prefix's table has to be
+    // (a length at a time: the lanes that store to one prefix's depth in one instruction store the same value)
+    int seen[MAXBITS + 1];
+#pragma unroll
+    for (int l = 0; l <= MAXBITS; ++l) seen[l] = 0;
+    for (int s0 = 0; s0 < n; s0 += LANES) {
+        const int s = s0 + lane;
+        const int l = s < n ? (int)lens[s] : 0;
+        const int rev = code_of(l, seen);
+        if (l > 0 && l <= ROOT) {
+            const uint32_t e = DIST ? entry_D(s, l) : entry_L(s, l);
+            for (int i = rev; i < (1 << ROOT); i += 1 << l) root[i] = e;
+        }
+#pragma unroll
+        for (int L = ROOT + 1; L <= MAXBITS; ++L) {
+            if (c[L] == 0) continue;
+            if (l == L) {
+                uint8_t& d = depth[rev & ((1 << ROOT) - 1)];
+                d = (uint8_t)max((int)d, L - ROOT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (one wavefront: its LDS operations are carried out in order)
         }
     }
     __syncthreads();
-    // the direct table, entry by entry: the entry's low bits in stream order are a code of at most ROOT bits (decoded
-    // canonically, as the stream's bits would be) or the head of a longer one (0)
-    for (int t = lane; t < (1 << ROOT); t += LANES) {
-        int code = 0, first = 0, index = 0, found = -1, flen = 0;
+    // the second-level tables one behind the other in sub[]
+    constexpr int PER_LANE = ((1 << ROOT) + LANES - 1) / LANES;
+    int mine = 0;
 #pragma unroll
-        for (int len = 1; len <= ROOT; ++len) {
-            code |= (t >> (len - 1)) & 1;
-            const int count = c[len];
-            if (found < 0 && code - count < first) { found = index + (code - first); flen = len; }
-            index += count;
-            first += count;
-            first <<= 1;
-            code <<= 1;
+    for (int k = 0; k < PER_LANE; ++k) {
+        const int r = lane * PER_LANE + k;
+        if (r < (1 << ROOT) && depth[r] != 0) mine += 1 << depth[r];
+    }
+    const int incl = wave_incl_scan(mine);
+    const int total = __builtin_amdgcn_readlane(incl, LANES - 1);
+    if (sub_used + total > SUB_CAP) return TABLES_FULL;
+    int at = sub_used + incl - mine;
+#pragma unroll
+    for (int k = 0; k < PER_LANE; ++k) {
+        const int r = lane * PER_LANE + k;
+        if (r < (1 << ROOT) && depth[r] != 0) {
+            root[r] = LINK | (uint32_t)depth[r] << 16 | (uint32_t)at;
+            at += 1 << depth[r];
         }
-        uint32_t e = SLOW_SYMBOL;
-        if (found >= 0) e = DIST ? entry_D((int)sym[found], flen) : entry_L((int)sym[found], flen);
-        fast[t] = e;
     }
-    int first = 0, index = 0;
+    for (int t = lane; t < total; t += LANES) S.sub[sub_used + t] = BAD_SYMBOL;
+    __syncthreads();
+    // pass 2: the long codes' entries
+    if (total > 0) {
 #pragma unroll
-    for (int l = 1; l <= ROOT; ++l) { index += c[l]; first = (first + c[l]) << 1; }
-    if (lane == 0) {
-        longc[0] = first;
-        longc[1] = index;
-#pragma unroll
-        for (int l = ROOT + 1; l <= MAXBITS; ++l) longc[2 + l - ROOT - 1] = c[l];
+        for (int l = 0; l <= MAXBITS; ++l) seen[l] = 0;
+        for (int s0 = 0; s0 < n; s0 += LANES) {
+            const int s = s0 + lane;
+            const int l = s < n ? (int)lens[s] : 0;
+            const int rev = code_of(l, seen);
+            if (l > ROOT) {
+                const uint32_t link = root[rev & ((1 << ROOT) - 1)];
+                const int bits = (int)((link >> 16) & 15u), base = (int)(link & 0xFFFFu);
+                const uint32_t e = DIST ? entry_D(s, l) : entry_L(s, l);
+                for (int i = rev >> ROOT; i < (1 << bits); i += 1 << (l - ROOT)) S.sub[base + i] = e;
+            }
+        }
     }
+    sub_used += total;
     __syncthreads();
     return zeros == n ? 0 : left;        // no codes at all: complete, nothing decodes (as puff and zlib have it)
 }
 
-// a code longer than ROOT bits, canonically from the length counts; -1: no such code
-template <int ROOT>
-__device__ __forceinline__ int decode_long(uint32_t bits, const uint16_t* sym, const int32_t* longc, int& clen) {
-    int code = (int)(__builtin_bitreverse32(bits) >> (32 - ROOT)) << 1;   // the first ROOT bits as a code, room for the next
-    int first = longc[0], index = longc[1];
-    uint32_t rest = bits >> ROOT;
-    int found = -1, flen = 0;
-#pragma unroll
-    for (int len = ROOT + 1; len <= MAXBITS; ++len) {
-        code |= (int)(rest & 1u);
-        rest >>= 1;
-        const int count = longc[2 + len - ROOT - 1];
-        if (found < 0 && code - count < first) { found = index + (code - first); flen = len; }
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
-    }
-    clen = flen;
-    return found < 0 ? -1 : (int)sym[found];
+// an entry with its LINK followed: `behind` = the stream's bits behind the root's
+__device__ __forceinline__ uint32_t follow_link(const WaveLds& S, uint32_t e, uint32_t behind) {
+    const uint32_t at = (e & 0xFFFFu) + (behind & ~(~0u << ((e >> 16) & 15u)));
+    const uint32_t e2 = S.sub[min(at, (uint32_t)(SUB_CAP - 1))];       // (every lane looks: the ones without a link anywhere in range)
+    return (e >> 30) == 3u ? e2 : e;
 }
 
 // a match from its two entries: length's extra bits, distance's extra bits, everything packed
@@ -259,36 +287,16 @@ __device__ __forceinline__ uint32_t pack_match(uint64_t view, uint32_t eL, uint3
     return ((eL & 0xFF8000FFu) + lx) + (eD & 0xFE000000u) + (((eD & 0x7FFFu) + dx) << P_DIST);
 }
 
-// the complete symbol that starts at this lane's bit of the stream (57 valid bits in view), packed; SLOW_SYMBOL where a
-// code is longer than its direct table.  No branches: every lane makes both look-ups (the second with whatever bits
-// its first entry says follow -- in range by construction) and selects.
+// the complete symbol that starts at this lane's bit of the stream (57 valid bits in view), packed.  No branches: every
+// lane makes all four look-ups (the later ones with whatever bits its earlier entries say follow -- in range by
+// construction) and selects.
 __device__ __forceinline__ uint32_t symbol_at(uint64_t view, const WaveLds& S) {
-    const uint32_t eL = S.fastL[(uint32_t)view & ((1u << ROOTL) - 1u)];
-    const uint32_t eD = S.fastD[(uint32_t)(view >> ((eL >> P_BITS) & 63u)) & ((1u << ROOTD) - 1u)];
+    const uint32_t eL = follow_link(S, S.rootL[(uint32_t)view & ((1u << ROOTL) - 1u)], (uint32_t)(view >> ROOTL));
+    const uint64_t v2 = view >> ((eL >> P_BITS) & 63u);
+    const uint32_t eD = follow_link(S, S.rootD[(uint32_t)v2 & ((1u << ROOTD) - 1u)], (uint32_t)(v2 >> ROOTD));
     const uint32_t m = pack_match(view, eL, eD);
     const bool is_match = ((eL >> P_KIND) & 3u) == K_MATCH;
-    return is_match ? ((int32_t)eD < 0 ? eD : m) : eL;        // (SLOW / BAD entries of either table pass through as they are)
-}
-
-// the same with the long codes resolved (only the lanes that reported SLOW_SYMBOL come here)
-__device__ uint32_t symbol_slow(uint64_t view, const WaveLds& S) {
-    uint32_t eL = S.fastL[(uint32_t)view & ((1u << ROOTL) - 1u)];
-    if (eL == SLOW_SYMBOL) {
-        int clen;
-        const int sym = decode_long<ROOTL>((uint32_t)view, S.symL, S.longL, clen);
-        if (sym < 0) return BAD_SYMBOL;
-        eL = entry_L(sym, clen);
-    }
-    if (((eL >> P_KIND) & 3u) != K_MATCH) return eL;
-    const uint64_t v2 = view >> (eL >> P_BITS);
-    uint32_t eD = S.fastD[(uint32_t)v2 & ((1u << ROOTD) - 1u)];
-    if (eD == SLOW_SYMBOL) {
-        int dlen;
-        const int ds = decode_long<ROOTD>((uint32_t)v2, S.symD, S.longD, dlen);
-        if (ds < 0) return BAD_SYMBOL;
-        eD = entry_D(ds, dlen);
-    }
-    return (int32_t)eD < 0 ? eD : pack_match(view, eL, eD);
+    return is_match ? ((int32_t)eD < 0 ? BAD_SYMBOL : m) : eL;        // (BAD entries of either table pass through)
 }
 
 // Executes the queue: lane k holds symbol k (k < nsym).  Returns 0, or -1 when the output or a distance is out of range.
@@ -395,8 +403,8 @@ __device__ __forceinline__ uint32_t crc_word(const uint32_t* T, uint32_t crc, ui
 
 __device__ uint32_t block_crc(WaveLds& S, const uint8_t* o, int olen, int lane) {
     if (olen == 0) return 0u;
-    uint32_t* T = reinterpret_cast<uint32_t*>(S.fastL);      // (the direct table of the literal/length code is dead by now)
-    static_assert(sizeof(S.fastL) >= 4 * 256 * sizeof(uint32_t), "the CRC tables go where the direct table was");
+    uint32_t* T = reinterpret_cast<uint32_t*>(S.rootL);      // (the Huffman tables are dead by now: rootL, rootD and sub lie one behind the other)
+    static_assert(offsetof(WaveLds, queue) >= 4 * 256 * sizeof(uint32_t), "the CRC tables go where the Huffman tables were");
     __syncthreads();
     for (int k = lane; k < 1024; k += LANES) T[k] = CRC.t[k >> 8][k & 255];
     __syncthreads();
@@ -478,36 +486,27 @@ SYMBOLS_FN SymbolsEnd decode_symbols(WaveLds& S, const uint8_t* p8_, int nbytes,
         const uint64_t view = raw >> ((bit0 + lane) & 7);
         raw = raw1;
         raw1 = *reinterpret_cast<const U64*>(p8 + ((bit0 + 2 * LANES + lane) >> 3));   // the window after the next, early
-        uint32_t sp = symbol_at(view, S);
+        const uint32_t sp = symbol_at(view, S);
         P.mark(1);
         // the walk: from symbol start to symbol start, on the scalar unit
         uint64_t starts = 0;
         uint32_t e;
+        // (four steps per trip of the loop: a taken branch costs a lone wavefront as much as the step itself)
+#define WALK_STEP                                                    \
+            e = (uint32_t)__builtin_amdgcn_readlane((int)sp, pos);   \
+            asm("s_bitset1_b64 %0, %1" : "+s"(starts) : "s"(pos));   \
+            pos += (int)(e >> P_BITS);
         for (;;) {
-            // (four steps per trip of the loop: a taken branch costs a lone wavefront as much as the step itself)
-#define WALK_STEP                                                        \
-                e = (uint32_t)__builtin_amdgcn_readlane((int)sp, pos);   \
-                asm("s_bitset1_b64 %0, %1" : "+s"(starts) : "s"(pos));   \
-                pos += (int)(e >> P_BITS);
-            for (;;) {
-                WALK_STEP
-                if (pos >= LANES) break;
-                WALK_STEP
-                if (pos >= LANES) break;
-                WALK_STEP
-                if (pos >= LANES) break;
-                WALK_STEP
-                if (pos >= LANES) break;
-            }
-#undef WALK_STEP
-            if (e != SLOW_SYMBOL) break;
-            pos -= LANES;                                  // a long code at a real symbol start: resolve those, walk on
-            if (sp == SLOW_SYMBOL) {
-                uint64_t again = view;
-                asm volatile("" : "+v"(again));            // (keeps the canonical decoding in here: hoisted, every window paid for it)
-                sp = symbol_slow(again, S);
-            }
+            WALK_STEP
+            if (pos >= LANES) break;
+            WALK_STEP
+            if (pos >= LANES) break;
+            WALK_STEP
+            if (pos >= LANES) break;
+            WALK_STEP
+            if (pos >= LANES) break;
         }
+#undef WALK_STEP
         P.mark(2);
         P.count(6, 1);
         const uint32_t kind = (e >> P_KIND) & 3u;
@@ -540,7 +539,10 @@ SYMBOLS_FN SymbolsEnd decode_symbols(WaveLds& S, const uint8_t* p8_, int nbytes,
     return SymbolsEnd{rc, opos, bit};
 }
 
-__global__ __launch_bounds__(LANES, 7) void inflate_kernel(const uint32_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
+#ifndef INFLATE_WAVES
+#define INFLATE_WAVES 7
+#endif
+__global__ __launch_bounds__(LANES, INFLATE_WAVES) void inflate_kernel(const uint32_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
                                                         uint8_t* out, const int64_t* __restrict__ out_off, int first_block,
                                                         int32_t* __restrict__ status, uint32_t* __restrict__ crc_out) {
     __shared__ WaveLds S;
@@ -651,10 +653,15 @@ __global__ __launch_bounds__(LANES, 7) void inflate_kernel(const uint32_t* __res
         }
         bit = b.pos();
         __syncthreads();
-        int zeros;
-        int err = build_tables<ROOTL, false>(S, S.hdr.lens, nlen, S.symL, S.fastL, S.longL, zeros, lane);
+        // (scratch for the tables' construction: the distance table's room while the literal / length code is built, the
+        //  literal / length code's lengths -- done with by then -- while the distance code is)
+        int zeros, sub_used = 0;
+        int err = build_tables<ROOTL, false>(S, S.hdr.lens, nlen, S.rootL, reinterpret_cast<uint8_t*>(S.rootD), sub_used, zeros, lane);
+        static_assert(sizeof(S.rootD) >= (1 << ROOTL) && MAXL >= (1 << ROOTD), "scratch for build_tables");
+        if (err == TABLES_FULL) { rc = -3; break; }
         if (err < 0 || (err > 0 && nlen - zeros != 1)) { rc = -1; break; }
-        err = build_tables<ROOTD, true>(S, S.hdr.lens + MAXL, ndist, S.symD, S.fastD, S.longD, zeros, lane);
+        err = build_tables<ROOTD, true>(S, S.hdr.lens + MAXL, ndist, S.rootD, S.hdr.lens, sub_used, zeros, lane);
+        if (err == TABLES_FULL) { rc = -3; break; }
         if (err < 0 || (err > 0 && ndist - zeros != 1)) { rc = -1; break; }
 
         P.mark(0);
