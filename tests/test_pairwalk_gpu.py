@@ -278,7 +278,7 @@ def test_a_short_random_campaign(capsys, monkeypatch):
     assert out["mismatching_regions"] == 0 and out["mismatching_scans"] == 0
 
 
-def _odd_bam(path, rng, block, no_end=False, decoys=False):
+def _odd_bam(path, rng, block, no_end=False, decoys=False, bad_record=False):
     """A BAM around the HD locus whose records have heads of every size: names of 1-250 characters, CIGARs of 1-220
     operations (soft / hard clips at the ends, M I D N = X inside), secondary / supplementary copies under the same name,
     duplicates, unmapped mates -- in blocks of `block` bytes cut without regard to records."""
@@ -342,6 +342,10 @@ def _odd_bam(path, rng, block, no_end=False, decoys=False):
             fake = struct.pack("<iiiBBHHHiiii", 40, rtid, 5, 2, 0, 0, 0, 0, 0, -1, -1, 0) + b"a\0"
             qual = b"\xff" * 4 + fake + b"\xff" * (l_seq - 4 - len(fake))
         body += bytes((l_seq + 1) // 2) + qual
+        if bad_record and len(offs) == len(recs) // 2:
+            # a record whose fixed fields promise more bases than the record holds (its length word is right: the chain
+            # goes on behind it)
+            body = body[:16] + struct.pack("<i", 1 << 20) + body[20:]
         offs.append(len(blob))
         blob += struct.pack("<i", len(body)) + body
         ends.append(end)
@@ -564,6 +568,43 @@ def test_a_pair_without_alignment_end_is_the_hosts_to_report(inf, tmp_path):
         assert (units[key] == u2[key]).all(), key
     for key in pools:
         assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
+    f.close(); g.close()
+
+
+def test_a_record_that_makes_no_sense_is_the_hosts_to_report(inf, tmp_path):
+    """One record in the middle of the region says it has a million bases in 300 bytes: the kernel ends that region with
+    status 3, the scan walks it itself and says what the plain scan says about the file."""
+    path = str(tmp_path / "bad.bam")
+    _odd_bam(path, np.random.default_rng(5), 6000, bad_record=True)
+    repo, names = TREDsRepo(), ["HD"]
+    f = bamio.AlignmentFile(path)
+    sites, regions = _site_arrays(repo, names, [repo["HD"]], f)
+    plan = f.plan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    n_all, comp, _, ooff, firsts = _lay_out(inf, [f], [plan])
+    bcoff, bclen, bcrc, host_of, coff_of, tasks, chunks, _ = _walk_inputs([f], [sites], [150], firsts)
+    status, crc, res, gp, tp = inf.run_walk(n_all, bcoff, bclen, bcrc, tasks, chunks)
+    assert (status == 0).all() and res["status"][0] == 3, res
+    need = walk_need(coff_of[0], host_of[0], res)
+    inf.fetch(need)
+    f.preload(inf.out_addr, ooff[:n_all + 1], np.where(need != 0, status, 1).astype(np.int32), crc)
+    g = bamio.AlignmentFile(path)
+    try:
+        want = g.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
+    except Exception as e:
+        want = e
+    try:
+        got = f.scan(sites, regions, 150, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN, pe=(res, gp, tp))
+    except Exception as e:
+        got = e
+    f.preload_clear()
+    if isinstance(want, Exception):
+        assert type(got) is type(want) and str(got) == str(want)
+    else:
+        (units, pools), (u2, p2) = want, got
+        for key in units.dtype.names:
+            assert (units[key] == u2[key]).all(), key
+        for key in pools:
+            assert (pools[key] == p2[key]) if isinstance(pools[key], bytes) else np.array_equal(pools[key], p2[key]), key
     f.close(); g.close()
 
 
