@@ -49,7 +49,8 @@ extern "C" {
 #define TREDGPU_TAG_HANG 5
 #define TREDGPU_TAG_INVALID 255 /* read longer than the instantiated kernel handles */
 
-#define TREDGPU_MAX_READ_LEN 320   /* rows per alignment the kernels are instantiated for */
+#define TREDGPU_MAX_READ_LEN 480   /* longest read the kernels are instantiated for (512 rows: the packed values' nine row bits) */
+#define TREDGPU_ASSUMED_READ_LEN 320 /* the bound a call in DEVICE memory gets when it names none (max_read_len 0) */
 #define TREDGPU_MAX_TEMPLATE_LEN 511
 #define TREDGPU_SPAN 1000          /* SPAN, bam_parser.py:29 / models.py pdf length */
 
@@ -58,8 +59,8 @@ typedef struct tredgpu_ctx tredgpu_ctx;
 /* scoring + tagging constants: bam_parser.py:95-98 (1/5/7/2), :30 (FLANKMATCH 9), :154-155 (clip).
  * Accepted range: match 1..8, mismatch 0..16, 1 <= gap_extend <= gap_open <= 16, and -- because a DP value is
  * (score + (row + col) * gap_extend) << 18 | start cell in one int32 --
- *     (rows + 511) * gap_extend + max_read_len * match < 8192,   rows = 64 / 112 / 160 / 256 / 320 for
- * max_read_len (0 counts as 320).  Anything else is refused with status -2; 1/5/7/2 needs 1 790. */
+ *     (rows + 511) * gap_extend + max_read_len * match < 8192,   rows = 64 / 112 / 160 / 256 / 320 / 512 for
+ * max_read_len (0 counts as 320).  Anything else is refused with status -2; 1/5/7/2 needs 1 790 (2 526 at 480 bp). */
 typedef struct tredgpu_sw_params {
     int32_t match;      /* +match on the diagonal                (ssw_wrap.py:154-167) */
     int32_t mismatch;   /* -mismatch off the diagonal, N scores 0                       */
@@ -68,8 +69,8 @@ typedef struct tredgpu_sw_params {
     int32_t flank;      /* FLANKMATCH                                                   */
     int32_t clip;       /* --useclippedreads: REPT cut-off from the read's own length   */
     int32_t max_read_len; /* upper bound of read_len[] in the call (selects the kernel
-                             instantiation: 64/112/160/256/320 rows); 0 = scan read_len (HOST
-                             memory) or assume TREDGPU_MAX_READ_LEN (DEVICE memory).  A read
+                             instantiation: 64/112/160/256/320/512 rows); 0 = scan read_len (HOST
+                             memory) or assume TREDGPU_ASSUMED_READ_LEN (DEVICE memory).  A read
                              longer than the bound gets out_tag TREDGPU_TAG_INVALID.      */
     int32_t reserved;
 } tredgpu_sw_params;

@@ -233,3 +233,24 @@ def test_high_coverage_samples_stay_on_the_device_walk(engine, tmp_path, caplog)
     assert t["walk_regions"] == len(args) * len(names) and t["walk_declined"] <= 2 and t["inflate_failed"] == 0
     assert "pair pool full" not in caplog.text
     assert sum(r["tredCalls"][n + ".PEDP"] for r in walked for n in names) > 500      # (spanning pairs at that depth)
+
+
+def test_400bp_reads_through_the_product_path(engine, tmp_path):
+    """Reads of 321-480 bp (merged pairs, long runs) used to cost their unit; now the batch takes sw_cont_kernel<32, 1>.
+    Synthetic 30x BAMs of 400 bp reads with known alleles through run_many (host scan, then the GPU-inflated / walked
+    front end): no unit dropped, the shorter allele found exactly at nearly every locus, both routes the same bytes."""
+    from tredparse_amd import synth, synth_bam
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1", "SCA3", "AR", "DRPLA")]
+    made = synth_bam.make_bams(str(tmp_path), 2, seed=400, loci=loci, p=synth.SynthParams(coverage=30, readlen=400, max_units=60))
+    repo, names = TREDsRepo(), [l["name"] for l in loci]
+    args = [(key, path, repo, names, 300, False, False, True, True, "ERROR") for key, path, _ in made]
+    plain = tredmod.run_many(args, engine, batch=2, threads=2)
+    walked = tredmod.run_many(args, engine, batch=2, threads=2, inflate_device=0, gpu_walk=True)
+    assert json.dumps(plain, sort_keys=True, default=str) == json.dumps(walked, sort_keys=True, default=str)
+    hits = total = 0
+    for r, (_, _, h_true) in zip(plain, made):
+        for k, n in enumerate(names):
+            assert n + ".1" in r["tredCalls"], (r["samplekey"], n)           # (no unit dropped for its reads' length)
+            total += 1
+            hits += r["tredCalls"][n + ".1"] == int(min(h_true[k]))
+    assert hits >= total - 2, (hits, total)

@@ -201,7 +201,7 @@ def test_error_reporting(ctx):
 def test_300bp_reads_take_the_20_rows_per_lane_instantiation(ctx):
     """2 x 300 bp runs (the reference has no length limit, ssw.c:780-871 / bam_parser.py:73): reads up to 320 bp are
     held by sw_cont_kernel<20, 2>.  Per-template records against the oracle field by field, tags of a synthetic 300 bp
-    batch over loci of every period against the oracle, and reads beyond 320 bp flagged, not truncated."""
+    batch over loci of every period against the oracle, and reads beyond the limit (480 bp) refused, not truncated."""
     rng = np.random.default_rng(300)
     mu = -(-300 // 3)
     lad = (HD[0], "CAG", HD[2], mu)
@@ -232,9 +232,45 @@ def test_300bp_reads_take_the_20_rows_per_lane_instantiation(ctx):
     c2 = po.classify(rs, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), po.LocusSet(b.ladders), threads=0)
     assert np.array_equal(t2, c2[:, 0]) and np.array_equal(h2, c2[:, 1]) and np.array_equal(s2, c2[:, 2])
     assert (t2 == _lib.TAG_FULL).sum() > 20 and (t2 == _lib.TAG_REPT).sum() > 0
-    # beyond 320 bp: refused by the call (host memory: the lengths are looked at), never truncated
+    # beyond 480 bp: refused by the call (host memory: the lengths are looked at), never truncated
     with pytest.raises(_lib.TredGpuError, match="TREDGPU_MAX_READ_LEN"):
-        _classify(ctx, [lad], [reads[0], (reads[0] * 2)[:330]], [0, 2], [0])
+        _classify(ctx, [lad], [reads[0], (reads[0] * 2)[:490]], [0, 2], [0])
+
+
+def test_reads_of_321_to_470_bp_take_the_32_rows_per_lane_instantiation(ctx):
+    """Merged pairs / long runs: reads beyond 320 bp are held by sw_cont_kernel<32, 1> (16 lanes x 32 rows: the nine row
+    bits of the packed DP values; ladders stay below 512 columns).  Per-template records against the oracle field by
+    field, and a synthetic 400 bp batch over loci of several periods through the production path."""
+    rng = np.random.default_rng(400)
+    flank = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    for readlen in (330, 400, 470):
+        mu = -(-readlen // 3)
+        lad = (HD[0], "CAG", HD[2], mu)
+        reads = [(flank(60) + HD[0] + "CAG" * 70 + HD[2] + flank(400))[:readlen],          # spanning
+                 po.rc((flank(10) + HD[0] + "CAG" * 150 + HD[2] + flank(50))[:readlen]),   # prefix read, other strand
+                 ("CAG" * 160)[:readlen], ("AGC" * 160)[1:readlen - 1], "N" * readlen,      # inside the repeat; all N
+                 (flank(200) + "CAG" * 20 + HD[2] + flank(400))[:readlen],                 # suffix read
+                 flank(readlen), (HD[0] + "CAG" * 160)[:321]]                              # the shortest read of the instantiation
+        tag, h, sc, dump = _classify(ctx, [lad], reads, [0, len(reads)], [0], dump=True)
+        ls = po.LocusSet([lad])
+        cls = po.classify(reads, np.zeros(len(reads), np.int32), ls)
+        assert np.array_equal(tag, cls[:, 0]) and np.array_equal(h, cls[:, 1]) and np.array_equal(sc, cls[:, 2]), readlen
+        assert set(tag.tolist()) >= {_lib.TAG_FULL, _lib.TAG_REPT, _lib.TAG_NONE}
+        nt = 2 * mu
+        for r, read in enumerate(reads):
+            want = po.sw_pairs([read], ls.templates, [0] * nt, list(range(nt)))
+            assert np.array_equal(dump[r, :, :5].astype(np.int32), want), (readlen, r)
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM2", "SCA10", "SCA36", "ULD")]
+    b = synth.build_batch(401, loci, 2, synth.SynthParams(coverage=20, readlen=400, max_units=120))
+    ctx.set_ladders(b.ladders)
+    n = b.n_reads
+    t2 = np.zeros(n, np.uint8); h2 = np.zeros(n, np.int16); s2 = np.zeros(n, np.int16)
+    ctx.sw_classify(_lib.MEM_HOST, b.packed, b.read_off, b.read_len, n, b.unit_read_off, b.unit_ladder, b.n_units,
+                    _lib.default_sw_params(max_read_len=400), t2, h2, s2)
+    rs = [synth.decode(x) for x in b.codes]
+    c2 = po.classify(rs, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), po.LocusSet(b.ladders), threads=0)
+    assert np.array_equal(t2, c2[:, 0]) and np.array_equal(h2, c2[:, 1]) and np.array_equal(s2, c2[:, 2])
+    assert (t2 == _lib.TAG_FULL).sum() > 20 and (t2 == _lib.TAG_REPT).sum() > 0
 
 
 @pytest.mark.parametrize("repeatpairs", [True, False])

@@ -23,7 +23,7 @@ from . import _lib, bamio
 SPAN = 1000                 # half width of the fetch window around the tract, and the pair-length cap
 FLANKMATCH = 9              # bases of flank an alignment must reach to count as anchored
 DNAPE_ELONGATE = 10 * SPAN  # pairs are collected this far on either side of the tract
-MAX_READ_LEN = 320          # longest read the SW kernel holds (include/tredgpu.h)
+MAX_READ_LEN = 480          # longest read the SW kernel holds (include/tredgpu.h)
 MAX_TEMPLATE_LEN = 511      # longest template (prefix + repeat * max_units + suffix)
 _Y_SKIP = frozenset((1, 4, 6, 7, 10, 11, 13, 16, 18, 19))   # rows of the chrY table that still attract reads
 _PKG = os.path.dirname(os.path.abspath(__file__))

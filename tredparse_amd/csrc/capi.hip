@@ -202,7 +202,8 @@ int rows_for(int max_len) {
     if (max_len <= 112) return 7;
     if (max_len <= 160) return 10;
     if (max_len <= 256) return 16;
-    return 20;
+    if (max_len <= 320) return 20;
+    return 32;                          // 16 lanes x 32 rows: the nine row bits of the packed values
 }
 
 // Every DP value is (score + (row + col) * gap_extend) << 18 | payload in an int32: the scaled score must stay
@@ -210,7 +211,7 @@ int rows_for(int max_len) {
 // for reads up to params.max_read_len, TREDGPU_MAX_READ_LEN when that is 0).  The default 1/5/7/2 scoring needs
 // 1 790 of the 8 192.
 int check_sw_range(tredgpu_ctx* c, const tredgpu_sw_params* p) {
-    const int L = p->max_read_len > 0 && p->max_read_len < TREDGPU_MAX_READ_LEN ? p->max_read_len : TREDGPU_MAX_READ_LEN;
+    const int L = p->max_read_len > 0 ? std::min(p->max_read_len, TREDGPU_MAX_READ_LEN) : TREDGPU_ASSUMED_READ_LEN;
     const int need = (16 * rows_for(L) + 511) * p->gap_extend + L * p->match;
     if (need >= 8192)
         return fail(c, -2, "scoring too large for the packed DP values: (rows + 511) * gap_extend + max_read_len * "
@@ -575,7 +576,7 @@ int tredgpu_sw_classify(tredgpu_ctx* c, int mem, const uint32_t* packed, const i
     HIPCHK(c, hipSetDevice(c->device));
     int max_len = params->max_read_len;
     if (mem == TREDGPU_MEM_DEVICE) {
-        if (max_len <= 0) max_len = TREDGPU_MAX_READ_LEN;
+        if (max_len <= 0) max_len = TREDGPU_ASSUMED_READ_LEN;
         if (out_dump) HIPCHK(c, hipMemsetAsync(out_dump, 0xFF, (size_t)n_reads * dump_templates * 6 * sizeof(int16_t), c->stream));
         return run_sw_device(c, packed, read_off, read_len, n_reads, unit_read_off, unit_ladder, n_units, params,
                              max_len, out_tag, out_h, out_score, out_dump, dump_templates);
@@ -1004,7 +1005,7 @@ int tredgpu_genotype_batch(tredgpu_ctx* c, int mem, const uint32_t* packed, cons
     if (n_reads > 0 && (!packed || !read_off || !read_len || !out_tag || !out_h || !out_score)) return fail(c, -2, "NULL array argument");
     HIPCHK(c, hipSetDevice(c->device));
     if (mem == TREDGPU_MEM_DEVICE) {
-        int max_len = params->max_read_len > 0 ? params->max_read_len : TREDGPU_MAX_READ_LEN;
+        int max_len = params->max_read_len > 0 ? params->max_read_len : TREDGPU_ASSUMED_READ_LEN;
         int limits[2] = {0, 0};
         if (n_units > 0 && (rc = query_max_insert(c, units, n_units, limits))) return rc;
         if (read_pair_id && (rc = ensure(c, c->ws_drop, (size_t)n_reads))) return rc;

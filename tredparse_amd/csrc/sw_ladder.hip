@@ -358,7 +358,8 @@ __device__ __forceinline__ void pair_step_lex(int& k, int& s) {
 // worth); nmask: bit k = row i_lo+k is N.  Rows >= L hold garbage (the caller pads them).
 template <int R>
 __device__ __forceinline__ void load_rows(const SwArgs& a, int64_t off, int L, int i_lo, uint64_t& code2, uint32_t& nmask) {
-    static_assert(R <= 24, "three code words cover 33 rows from any offset, the mask window 33");
+    // (R = 32: a lane's rows start at a multiple of 32 -- two code words and one mask word, nothing to shift)
+    static_assert(R <= 24 || R == 32, "three code words cover 33 rows from any offset, the mask window 33");
     const int nb = (L + 15) >> 4, nm = (L + 31) >> 5;
     const int wl = max(nb - 1, 0), ml = max(nm - 1, 0);
     const int wi = i_lo >> 4, mi = i_lo >> 5;
@@ -1081,6 +1082,8 @@ hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, bool generic, in
         case 33: sw_cont_kernel<16, 2, true><<<blocks, 64, 0, s>>>(a); break;
         case 40: sw_cont_kernel<20, 2, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 320 bp (2 x 300 bp runs)
         case 41: sw_cont_kernel<20, 2, true><<<blocks, 64, 0, s>>>(a); break;
+        case 64: sw_cont_kernel<32, 1, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 480 bp (512 rows: the packed values' nine row bits)
+        case 65: sw_cont_kernel<32, 1, true><<<blocks, 64, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
