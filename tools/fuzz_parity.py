@@ -18,9 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+import os
+# TREDGPU_FUZZ_READLENS=330,400,460: the campaign at other read lengths (e.g. the 32-rows-per-lane instantiation's)
+LONG_READS = [int(x) for x in os.environ.get("TREDGPU_FUZZ_READLENS", "").split(",") if x]
+
+
 def draw_round(rng, loci, synth, po, samples=(1, 4)):
     """One random batch: (batch, reads, unit_read_off, unit_ladder, clip, scoring, readlen)."""
-    readlen = int(rng.choice([36, 75, 100, 125, 150, 150, 150, 250, 300]))
+    readlen = int(rng.choice(LONG_READS if LONG_READS else [36, 75, 100, 125, 150, 150, 150, 250, 300]))
     p = synth.SynthParams(coverage=float(rng.choice([10, 30, 60])), readlen=readlen,
                           sub=float(rng.choice([0.0, 0.01, 0.03])), indel=float(rng.choice([0.0, 0.001, 0.01])),
                           nrate=float(rng.choice([0.0, 0.005, 0.05])), min_units=int(rng.integers(1, 8)),
