@@ -60,7 +60,20 @@ def visible_gpus():
     fork workers nor be replaced)."""
     import subprocess
     import sys
-    code = "import torch; print(torch.cuda.device_count())"
+    # hipGetDeviceCount through ctypes: a child that imports torch for the same number costs 1.5-2.5 s of every
+    # command's start (torch is only asked when the HIP runtime cannot be loaded by name)
+    code = ("import ctypes\n"
+            "n = ctypes.c_int(0)\n"
+            "for name in ('libamdhip64.so', '/opt/rocm/lib/libamdhip64.so'):\n"
+            "    try:\n"
+            "        lib = ctypes.CDLL(name)\n"
+            "    except OSError:\n"
+            "        continue\n"
+            "    print(n.value if lib.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0)\n"
+            "    break\n"
+            "else:\n"
+            "    import torch\n"
+            "    print(torch.cuda.device_count())\n")
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
         return max(0, int(out.stdout.strip().splitlines()[-1]))
