@@ -2,7 +2,7 @@
 # tools/profile_all.sh [ROUND = r05] -- run ON THE GPU BOX (through gpurun): every rocprofv3 summary of the round, taken on
 # ONE build (the tree's libtredgpu.so), in one go:
 #   headline (config3, 150 bp, 1 000 samples), 100 bp, 250 bp, configs[4]     tools/profile_round.sh: kernel stats + PMC passes
-#   front end: inflate + pair walk + alternative-locus walk at 16 and 48 samples per call
+#   front end: inflate + pair walk + alternative-locus walk at 16 and 48 samples per call; inflate_kernel alone
 #                                                                              rocprofv3 ... -- python3 tools/walk_prof.py
 # Results land in gpurun_out/prof_<ROUND>_*/; tools/collect_profiles.py copies the summaries into profiles/ under the
 # round's names and checks that all of them carry the same library_version (tests/test_profiles.py checks it again on CPU).
@@ -36,4 +36,6 @@ for M in 16 48; do
     find "$OUT" -name '*counter_collection.csv' -size +4M -delete
 done
 cd "$ROOT"
+# ---- the decoder alone (tools/inflate_prof.hip, built on the box)
+bash tools/profile_inflate.sh ${R}_inflate 8 > gpurun_out/prof_${R}_inflate.log 2>&1
 python3 tools/collect_profiles.py $R
