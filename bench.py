@@ -596,7 +596,9 @@ def e2e_main(args):
     if args.e2e_python_writer:
         kw.update(sink=sink, background_sink=2 if gpu_inflate else 1)
     else:
-        emit = kw["emit"] = tred.Emitter("hg38", repo, names, workers=2, on_sample=on_sample)
+        # (never more results in flight than the block has files: a driver goes over its block again and again, and two
+        #  writer threads must not meet in one <key>.json -- ADVICE r5)
+        emit = kw["emit"] = tred.Emitter("hg38", repo, names, workers=2, on_sample=on_sample, depth=max(1, min(96, len(mine))))
     try:
         # warm-up: HIP context, ladders, caches -- and, for the GPU-inflate legs, one full chunk through each inflater, whose
         # pinned staging (45 MB per sample of a chunk, three inflaters) stays with the process for the timed cohort
@@ -640,6 +642,11 @@ def steady_state(ranks, logs):
       startup_s        from the common start (the barrier) to the window's start
       whole_run_value  all units over (last finish - common start): fill and drain included
       first_pass_value the units of every driver's first pass over its files, over the time the slowest driver took"""
+    # (a driver that was given no file -- more drivers than files -- has an empty log: it takes no part in the rates)
+    live = [(r, l) for r, l in zip(ranks, logs) if len(l)]
+    if not live:
+        return {"error": "no driver finished a sample"}
+    ranks, logs = [r for r, _ in live], [l for _, l in live]
     t0 = min(r["t_begin"] for r in ranks)
     w0 = max(float(l[min(r["first_chunk"], len(l)) - 1, 0]) for r, l in zip(ranks, logs))
     w1 = min(float(l[-1, 0]) for l in logs)

@@ -60,7 +60,7 @@ typedef struct tredgpu_ctx tredgpu_ctx;
  * Accepted range: match 1..8, mismatch 0..16, 1 <= gap_extend <= gap_open <= 16, and -- because a DP value is
  * (score + (row + col) * gap_extend) << 18 | start cell in one int32 --
  *     (rows + 511) * gap_extend + max_read_len * match < 8192,   rows = 64 / 112 / 160 / 256 / 320 / 512 for
- * max_read_len (0 counts as 320).  Anything else is refused with status -2; 1/5/7/2 needs 1 790 (2 526 at 480 bp). */
+ * max_read_len (0: 320 for DEVICE memory, the longest read of the call for HOST memory).  Anything else is refused with status -2; 1/5/7/2 needs 1 790 (2 526 at 480 bp). */
 typedef struct tredgpu_sw_params {
     int32_t match;      /* +match on the diagonal                (ssw_wrap.py:154-167) */
     int32_t mismatch;   /* -mismatch off the diagonal, N scores 0                       */

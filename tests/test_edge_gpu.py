@@ -177,6 +177,15 @@ def test_scoring_bound_of_the_packed_values(ctx):
     over2 = _lib.SwParams(8, 9, 9, 9, 9, 0, 0, 0)            # 767 * 9 + 2048 = 8951
     with pytest.raises(_lib.TredGpuError, match="packed DP values"):
         _classify(ctx, [lad], reads, [0, len(reads)], [0], params=over2)
+    # no max_read_len named and a 400 bp read in HOST memory: the call resolves the 512-row instantiation, and the bound is
+    # checked for THAT one ((512 + 511) * 5 + 400 * 8 = 8315), not for the 320 bp assumed before the reads were seen
+    # ((320 + 511) * 5 + 320 * 8 = 6715, which passes) -- ADVICE r5
+    long_tmpl = HD[0] + "CAG" * 130 + HD[2]
+    tall = _lib.SwParams(8, 9, 5, 5, 9, 0, 0, 0)
+    _classify(ctx, [lad], reads, [0, len(reads)], [0], params=tall)                  # 90-99 bp reads: fine
+    with pytest.raises(_lib.TredGpuError, match="packed DP values") as e:
+        _classify(ctx, [lad], reads + [long_tmpl[:400]], [0, len(reads) + 1], [0], params=tall)
+    assert "(-2)" in str(e.value)
 
 
 def test_error_reporting(ctx):

@@ -68,3 +68,56 @@ def test_kernels_replay_the_depth_sweep(ctx):
     ctx.likelihood_grid(_lib.MEM_HOST, units, n, hs, full, pref, rept, gl, len(gl), tl, len(tl), calls, None, None, None, 0)
     for (depth, alleles), c in zip(SWEEP, calls):
         assert c["status"] == 0 and sorted([c["h1"] // u["period"], c["h2"] // u["period"]]) == alleles, depth
+
+
+# ---- tools/pin_pysam_live.py: the one-command check for a maintainer who has pysam ---------------
+def _live():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pin_pysam_live", os.path.join(ROOT, "tools", "pin_pysam_live.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_live_pysam_check_skips_cleanly_without_pysam(tmp_path, capsys):
+    live = _live()
+    if live.import_pysam() is not None:
+        pytest.skip("pysam is installed here: run tools/pin_pysam_live.py itself")
+    out = str(tmp_path / "rec.json")
+    assert live.main(["--json", out]) == 0
+    assert "skipped" in capsys.readouterr().out and json.load(open(out))["skipped"] is True
+    assert live.main(["--require"]) == 2
+
+
+def test_live_pysam_check_compares_what_it_says(monkeypatch, capsys):
+    """The comparison itself, with a stand-in pysam module built on this repository's pure-Python reader: identical as it
+    is, and a fetch that drops the placed-unmapped reads / a pileup that truncates to the window are both found out."""
+    import types
+    from tredparse_amd import bamio
+    live = _live()
+
+    class Col(object):
+        def __init__(self, pos, n):
+            self.reference_pos, self.n = pos, n
+
+    def make(drop_unmapped=False, truncate=False):
+        class AlignmentFile(bamio.PyAlignmentFile):
+            def fetch(self, *a, **k):
+                for r in bamio.PyAlignmentFile.fetch(self, *a, **k):
+                    if not (drop_unmapped and a and r.is_unmapped):
+                        yield r
+
+            def pileup(self, chrom, start, end):
+                cols = live.column_sums(bamio.PyAlignmentFile.fetch(self, chrom, start, end), start, end)
+                return [Col(c, n) for c, n in sorted(cols.items()) if not truncate or start <= c < end]
+        mod = types.ModuleType("pysam")
+        mod.AlignmentFile, mod.__version__ = AlignmentFile, "stand-in"
+        return mod
+
+    bam = os.path.join(GOLD, "bam", "t002.bam")
+    monkeypatch.setattr(live, "import_pysam", lambda: make())
+    assert live.main([bam]) == 0 and "identical" in capsys.readouterr().out
+    monkeypatch.setattr(live, "import_pysam", lambda: make(drop_unmapped=True))
+    assert live.main([bam]) == 1 and '"kind": "fetch/window"' in capsys.readouterr().out
+    monkeypatch.setattr(live, "import_pysam", lambda: make(truncate=True))
+    assert live.main([bam]) == 1 and '"kind": "pileup/sum"' in capsys.readouterr().out

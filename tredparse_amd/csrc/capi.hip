@@ -185,7 +185,7 @@ std::vector<int8_t> revcomp(const std::vector<int8_t>& v) {
     return o;
 }
 
-int check_sw_range(tredgpu_ctx* c, const tredgpu_sw_params* p);
+int check_sw_range(tredgpu_ctx* c, const tredgpu_sw_params* p, int max_len = 0);
 
 int check_sw_params(tredgpu_ctx* c, const tredgpu_sw_params* p) {
     if (!p) return fail(c, -2, "params is NULL");
@@ -209,9 +209,11 @@ int rows_for(int max_len) {
 // Every DP value is (score + (row + col) * gap_extend) << 18 | payload in an int32: the scaled score must stay
 // below 2^13 on the longest template (511 columns) for every row the kernel instantiation holds (16 lanes x R rows
 // for reads up to params.max_read_len, TREDGPU_MAX_READ_LEN when that is 0).  The default 1/5/7/2 scoring needs
-// 1 790 of the 8 192.
-int check_sw_range(tredgpu_ctx* c, const tredgpu_sw_params* p) {
-    const int L = p->max_read_len > 0 ? std::min(p->max_read_len, TREDGPU_MAX_READ_LEN) : TREDGPU_ASSUMED_READ_LEN;
+// 1 790 of the 8 192.  max_len > 0: the bound the call resolved (the longest read a HOST-memory call has seen: it may
+// select a larger instantiation than the one the arguments alone were checked for).
+int check_sw_range(tredgpu_ctx* c, const tredgpu_sw_params* p, int max_len) {
+    const int named = max_len > 0 ? max_len : p->max_read_len;
+    const int L = named > 0 ? std::min(named, TREDGPU_MAX_READ_LEN) : TREDGPU_ASSUMED_READ_LEN;
     const int need = (16 * rows_for(L) + 511) * p->gap_extend + L * p->match;
     if (need >= 8192)
         return fail(c, -2, "scoring too large for the packed DP values: (rows + 511) * gap_extend + max_read_len * "
@@ -593,6 +595,7 @@ int tredgpu_sw_classify(tredgpu_ctx* c, int mem, const uint32_t* packed, const i
     for (int64_t r = 0; r < n_reads; ++r) seen = std::max(seen, read_len[r]);
     if (max_len <= 0) max_len = seen;
     if (seen > TREDGPU_MAX_READ_LEN) return fail(c, -5, "read of %d bp exceeds TREDGPU_MAX_READ_LEN=%d", seen, TREDGPU_MAX_READ_LEN);
+    if ((rc = check_sw_range(c, params, std::max(max_len, 1)))) return rc;     // the instantiation these reads select
     const uint32_t* d_packed; const int64_t* d_off; const int32_t* d_len; const int32_t* d_uoff; const int32_t* d_ulad;
     uint8_t* d_tag; int16_t* d_h; int16_t* d_score; int16_t* d_dump = nullptr;
     const size_t words = (size_t)read_off[n_reads];
@@ -935,6 +938,7 @@ int tredgpu_genotype_batch_joint(tredgpu_ctx* c, const uint32_t* packed, const i
     for (int64_t r = 0; r < n_reads; ++r) seen = std::max(seen, read_len[r]);
     if (seen > TREDGPU_MAX_READ_LEN) return fail(c, -5, "read of %d bp exceeds TREDGPU_MAX_READ_LEN=%d", seen, TREDGPU_MAX_READ_LEN);
     const int max_len = params->max_read_len > 0 ? params->max_read_len : std::max(seen, 1);
+    if ((rc = check_sw_range(c, params, max_len))) return rc;                  // the instantiation these reads select
     const uint32_t* d_packed = nullptr; const int64_t* d_off = nullptr; const int32_t* d_len = nullptr;
     const int32_t *d_uoff, *d_ulad, *d_pid = nullptr, *d_gl = nullptr, *d_tl = nullptr;
     const tredgpu_unit_params* d_units; const int64_t* d_joff;

@@ -1653,19 +1653,24 @@ __global__ void __launch_bounds__(LANES) alt_walk_kernel(WalkView v, const tredg
 // The blocks the host wants, copied from the decoder's output straight into pinned host memory by the GPU's own stores (the
 // pinned buffer is mapped into the device's address space): ONE launch and one wait per call where the copy engines
 // were handed ~660 copies of ~160 KB (two thirds of a call's time went there once three driver processes shared them).
-// piece p: `len` bytes from out + src to host + dst, dst a multiple of 16; 256 lanes, 16 bytes each per step.
+// piece p: `len` bytes from out + src to host + dst; 256 lanes, 16 bytes each per step.  dst is any address: the bytes up to
+// its next 16-byte boundary go one by one, the stores behind them are aligned (the loads never had to be) -- the runs lie in
+// the dense buffer without padding, so that every block's length can be read off dense_off.
 struct FetchPiece { int64_t src, dst; int32_t len, pad; };
 __global__ void __launch_bounds__(256) fetch_gather_kernel(const uint8_t* __restrict__ out, uint8_t* __restrict__ host, const FetchPiece* pieces) {
     const FetchPiece P = pieces[blockIdx.x];
     const uint8_t* s = out + P.src;
     uint8_t* d = host + P.dst;
-    const int whole = P.len & ~15;
-    for (int o = threadIdx.x * 16; o < whole; o += 256 * 16) {
+    const int head = min(P.len, (int)((16 - (P.dst & 15)) & 15));
+    if ((int)threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+    const int whole = (P.len - head) & ~15;
+    for (int o = head + threadIdx.x * 16; o < head + whole; o += 256 * 16) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef u32x4 __attribute__((aligned(1))) u32x4_any;
         *reinterpret_cast<u32x4*>(d + o) = *reinterpret_cast<const u32x4_any*>(s + o);
     }
-    if ((int)threadIdx.x < P.len - whole) d[whole + threadIdx.x] = s[whole + threadIdx.x];
+    const int tail = head + whole + (int)threadIdx.x;
+    if (tail < P.len) d[tail] = s[tail];
 }
 
 }  // namespace
@@ -2257,8 +2262,6 @@ int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const ui
         int32_t last = k;
         for (int32_t j = k + 1; j < n_blocks && ooff[j] - ooff[last + 1] <= GAP; ++j)
             if (need[j]) last = j;
-        total = (total + 15) & ~(int64_t)15;       // (a run starts on a 16-byte boundary of the dense buffer: the kernel's stores)
-        dense_off[k] = total;                      // (an empty block in front of the run ends where the run starts: still empty)
         for (int32_t j = k; j <= last; ++j) { total += ooff[j + 1] - ooff[j]; dense_off[j + 1] = total; }
         runs.push_back(Run{k, last});
         k = last + 1;

@@ -758,6 +758,13 @@ class Emitter(object):
         if table is None or (self.no_output and self.on_sample is None):
             if not (self.no_output and self.on_sample is None and o["log"] != "DEBUG"):
                 self._python_path(arg, scan, pieces)
+            else:                # nothing to print: the loci the grid refused are still reported, as the Python path does
+                from .models import STATUS_ERRORS
+                for br, i0, ks in pieces:
+                    st = br.calls["status"][i0:i0 + len(ks)]
+                    for j in np.nonzero(st < 0)[0].tolist():
+                        logger.error("Exception on `%s` %s (%s)", o["bam"], scan.names[ks[j]],
+                                     STATUS_ERRORS.get(int(st[j]), "status {}".format(int(st[j]))))
             return
         br, i0, ks = pieces[0]
         eb = getattr(br, "_emit", None)
@@ -791,8 +798,14 @@ class Emitter(object):
         if rc == 1:
             return self._python_path(arg, scan, pieces)
         if rc < 0:
-            print("Error writing: {} ({})".format(o["samplekey"], self.lib.tredbam_emit_last_error().decode("utf-8", "replace") or rc),
-                  file=sys.stderr)
+            why = self.lib.tredbam_emit_last_error().decode("utf-8", "replace") or str(rc)
+            print("Error writing: {} ({})".format(o["samplekey"], why), file=sys.stderr)
+            if rc != -5:         # not an I/O error of this one sample's files (the reference prints and goes on there, tred.py:
+                # 290-293): the arrays handed over do not fit together -- every later sample of the run would be wrong as well
+                raise RuntimeError("native writer refused `{}`: {} (rc={})".format(o["samplekey"], why, rc))
+            if self.on_sample is not None:
+                self.on_sample({"samplekey": o["samplekey"], "names": scan.names, "printed": [False] * len(scan.names),
+                                "first_allele": [-1] * len(scan.names)})
             return
         from .models import STATUS_ERRORS
         for k in np.nonzero(status[:len(scan.names)] < 0)[0].tolist():
@@ -973,6 +986,8 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
                 for si, (arg, scan) in enumerate(zip(chunk, scans)):
                     emit.submit(arg, scan, parts.get(si, []))
                 timing_add(format=time.perf_counter() - t0)
+                if emit.error is not None:        # a writer thread failed: stop scanning and genotyping the rest of the cohort
+                    raise emit.error
                 continue
             for r in finish_batch(engine, chunk, scans, lazy_details=lazy_details):
                 if sink is not None:
