@@ -1,4 +1,4 @@
-"""The pair walk on the device (csrc/inflate.hip pair_walk_kernel, tredgpu_inflate_walk) against the host's file layer:
+"""The pair walk on the device (csrc/walk.hip pair_walk_kernel, tredgpu_inflate_walk) against the host's file layer:
 per locus the two pair-length lists in PEextractor's order (tredparse/bam_parser.py:316-369, restated by
 bamread.cpp's PairTable and checked against the reference's own numbers in test_host_frontend.py), the virtual offsets
 between which the locus' window lies against a walk through the package's pure-Python BAM layer, and the whole scan with

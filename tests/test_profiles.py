@@ -7,13 +7,14 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r05"
+ROUND = "r06"
 
 
 def tree_hash():
     csrc = os.path.join(ROOT, "tredparse_amd", "csrc")
     h = hashlib.sha256()
-    for name in ("capi.hip", "sw_ladder.hip", "grid.hip", "inflate.hip", "tredgpu_internal.h"):
+    for name in ("capi.hip", "sw_ladder.hip", "grid.hip", "inflate_decode.hip", "walk.hip", "inflater_api.hip", "tredgpu_internal.h",
+                 "inflater_internal.h"):
         with open(os.path.join(csrc, name), "rb") as fp:
             h.update(fp.read())
     with open(os.path.join(ROOT, "include", "tredgpu.h"), "rb") as fp:
@@ -23,7 +24,8 @@ def tree_hash():
 
 def test_makefile_hashes_the_files_this_test_hashes():
     mk = open(os.path.join(ROOT, "tredparse_amd", "csrc", "Makefile")).read()
-    assert "SRCS := capi.hip sw_ladder.hip grid.hip inflate.hip" in mk and "HDRS := tredgpu_internal.h ../../include/tredgpu.h" in mk
+    assert "SRCS := capi.hip sw_ladder.hip grid.hip inflate_decode.hip walk.hip inflater_api.hip" in mk
+    assert "HDRS := tredgpu_internal.h inflater_internal.h ../../include/tredgpu.h" in mk
     assert "cat $(SRCS) $(HDRS) | sha256sum | cut -c1-16" in mk
 
 

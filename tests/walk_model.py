@@ -1,5 +1,5 @@
 """Test infrastructure: a stand-in for _lib.Inflater on machines without a GPU -- zlib for the blocks and a plain Python
-walk over the inflated bytes that follows the task / chunk tables the way csrc/inflate.hip's pair_walk_kernel does
+walk over the inflated bytes that follows the task / chunk tables the way csrc/walk.hip's pair_walk_kernel does
 (bamread.cpp walk_region + PairTable: tredparse/bam_parser.py:316-369).  Only tests use it: the host-side plumbing of
 run_many(gpu_walk=True) is exercised here, the kernel itself in test_pairwalk_gpu.py."""
 import struct

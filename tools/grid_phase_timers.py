@@ -93,7 +93,7 @@ def build(which):
     open(os.path.join(SRC, "_exp_grid_prof.hip"), "w").write(s)
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                            "-Wno-unused-function", "-shared", "-o", os.path.join(ROOT, "tredparse_amd", "libtredgpu_prof.so"),
-                           "capi.hip", "sw_ladder.hip", "inflate.hip", "_exp_grid_prof.hip"], cwd=SRC)
+                           "capi.hip", "sw_ladder.hip", "inflate_decode.hip", "walk.hip", "inflater_api.hip", "_exp_grid_prof.hip"], cwd=SRC)
 
 
 def run(which):

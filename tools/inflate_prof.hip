@@ -4,7 +4,9 @@
 // the call's device time, the decode launches' time and -- profiled build -- the mean cycles per block and phase.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DINFLATE_PROF] -o inflate_prof tools/inflate_prof.hip
 //   ./inflate_prof file.bam [samples per call = 1] [calls = 5] [crc = 1]
-#include "../tredparse_amd/csrc/inflate.hip"
+#include "../tredparse_amd/csrc/inflate_decode.hip"
+#include "../tredparse_amd/csrc/walk.hip"
+#include "../tredparse_amd/csrc/inflater_api.hip"
 
 #include <cstdio>
 #include <cstdlib>

@@ -1,0 +1,77 @@
+// inflater_internal.h -- what the three translation units of the front end share (inflate_decode.hip: the DEFLATE decoder;
+// walk.hip: the record walks and the fetch kernel over its output; inflater_api.hip: the C ABI of include/tredgpu.h section 4):
+// the walk's views and tuples, and one launcher per kernel -- kernels stay local to their file, as in sw_ladder.hip / grid.hip.
+#ifndef TREDGPU_INFLATER_INTERNAL_H
+#define TREDGPU_INFLATER_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/tredgpu.h"
+
+namespace tredgpu_front {
+
+constexpr int LANES = 64;
+
+__device__ __forceinline__ int wave_incl_scan(int v) {   // all 64 lanes active
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr 1, 2, 4, 8: prefix inside a 16-lane row
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast 15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast 31 into rows 2 and 3
+    return v;
+}
+
+struct WalkView {
+    const uint8_t* out; const int64_t* ooff;          // the decoder's output and its block offsets
+    const int32_t* bstatus; const uint32_t* bcrc;     // what the decoder said about each block
+    const uint32_t* xcrc; const int64_t* bcoff; const int32_t* bclen;   // from the file: trailer CRC, compressed offset / length
+    int64_t out_end;                                  // bytes of `out` that may be read
+};
+struct WalkPair { int64_t name_at, name2_at; int32_t a_pos, a_lead, b_end, b_trail; uint16_t name_len; uint8_t a_rev, b_rev, complete, pad[3]; };
+static_assert(sizeof(WalkPair) == 40, "WalkPair layout");
+constexpr int WALK_PAIR_CAP = 8192;               // names per region at most (a +-10 kb window at 30x holds ~2 100) ...
+constexpr int WALK_PAIR_CAP_SMALL = 4096;         // ... and what a launch whose regions are all short is given: 38 instead of
+                                                  // 70 KB of LDS per wavefront, so that other kernels' workgroups -- the
+                                                  // decoder's, the genotyping kernels' of the other driver processes -- still
+                                                  // find LDS on the CUs a walk occupies (two walks of 70 KB nearly fill a CU's 160 KB)
+constexpr int WALK_WINDOW = 6144;                 // bytes of the block stream in LDS
+enum { WALK_OK = 0, WALK_NOT_PLANNED = 1, WALK_BAD_BLOCK = 2, WALK_BAD_RECORD = 3, WALK_TABLE_FULL = 4, WALK_NO_END = 5, WALK_POOL_FULL = 6,
+       WALK_TAG_CLASH = 7 };
+
+struct WalkRec { int64_t a0; uint64_t at, after; };             // where the record's length word lies in `out`; the virtual offsets of the record and of what follows it
+struct WalkFields { uint32_t h; int32_t rtid, rpos, rend, lead, trail; uint16_t flag, nlen; uint32_t bad; };
+static_assert(sizeof(WalkRec) == 24 && sizeof(WalkFields) == 32, "record tuples");
+struct WalkChained { int32_t status, n, mode, klo, khi, pad; };   // per region: how the chain ended, records listed; mode 1: listed by
+                                                                  // walk_chain_par_kernel (the region's blocks lie in [klo, khi)), 0: by
+                                                                  // walk_chain_kernel (pad: why the lanes handed the region back)
+
+struct FetchPiece { int64_t src, dst; int32_t len, pad; };
+
+constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 16; }    // (pair_walk_kernel: the table alone, 2 * cap slots of 64 bits)
+
+constexpr int PW_WAVES = 8, PW_THREADS = PW_WAVES * LANES;      // pair_walk_kernel: a workgroup of 8 wavefronts per region
+
+// ---- launchers (each enqueues on `st` and returns hipGetLastError()) ----------------------------------------------------
+// inflate_decode.hip: blocks [first_block, first_block + n_blocks) of the call, one wavefront each
+hipError_t launch_inflate(const uint32_t* comp, const int64_t* comp_off, uint8_t* out, const int64_t* out_off, int first_block, int n_blocks,
+                          int32_t* status, uint32_t* crc_out, hipStream_t st);
+// walk.hip
+hipError_t launch_walk_chain_par(const WalkView& v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks, const int64_t* rec_base,
+                                 WalkRec* recs, WalkChained* chained, int n_tasks, hipStream_t st);
+hipError_t launch_walk_chain(const WalkView& v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks, const int64_t* rec_base,
+                             WalkRec* recs, WalkChained* chained, int n_tasks, hipStream_t st);
+hipError_t launch_walk_parse(const WalkView& v, int n_tasks, const int64_t* rec_base, const WalkRec* recs, const WalkChained* chained,
+                             WalkFields* fields, size_t total_recs, hipStream_t st);
+hipError_t allow_pair_walk_lds();        // once per device: the large table's dynamic LDS
+hipError_t launch_pair_walk(const WalkView& v, const tredgpu_walk_task* tasks, const int64_t* rec_base, const WalkRec* recs, const WalkFields* fields,
+                            const WalkChained* chained, tredgpu_walk_result* results, WalkPair* pairs, int32_t* gpool, int64_t cap_g, int32_t* tpool,
+                            int64_t cap_t, unsigned long long* counters, int table_cap, int n_tasks, hipStream_t st);
+hipError_t launch_alt_walk(const WalkView& v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks, tredgpu_alt_result* results,
+                           uint8_t* need, int n_tasks, hipStream_t st);
+hipError_t launch_fetch_gather(const uint8_t* out, uint8_t* host, const FetchPiece* pieces, size_t n_pieces, hipStream_t st);
+
+}  // namespace tredgpu_front
+#endif

@@ -38,21 +38,10 @@ from .models import GridError, SparseDist, format_call, pair_summaries
 
 logging.basicConfig()
 logger = logging.getLogger(__name__)
-# seconds accumulated over run_many calls: the driver thread's waits for scans, its GPU calls and its formatting; and
-# the writer thread's time in the sink (JSON / VCF text and files)
-TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
-          "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0, "walk_regions": 0, "walk_declined": 0,
-          "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0, "walk_call": 0.0, "walk_fetch": 0.0, "pack": 0.0,
-          "merged_chunks": 0}
-_TIMING_LOCK = threading.Lock()
-
-
-def timing_add(**kw):
-    """TIMING[key] += value for every keyword, under a lock: the scan pool, the feeder and the writer thread all
-    report here while the driver thread does too (a lost update would show up in bench.py's driver_seconds)."""
-    with _TIMING_LOCK:
-        for k, v in kw.items():
-            TIMING[k] += v
+from .runtime import TIMING, _options, collect_sample, timing_add                      # noqa: F401  (shared with feeder.py / emit.py)
+from .feeder import (_InflateFeeder, _plan_sample, _scan_planned, pinned_bytes,                # noqa: F401
+                     release_inflaters)
+from .emit import Emitter                                                                  # noqa: F401
 
 
 # (ID, Number, Type, Description) of the VCF meta lines, in file order
@@ -169,346 +158,6 @@ def counter_s(counts):
 
 
 # ---- one sample: scan -> units -> calls ---------------------------------------------------------------------------
-def _options(arg):
-    """The reference's run() argument tuple, named."""
-    samplekey, bam, repo, names, maxinsert, fullsearch, clip, alts, repeatpairs, log = arg
-    return dict(samplekey=samplekey, bam=bam, repo=repo, names=list(names), maxinsert=maxinsert,
-                fullsearch=fullsearch, clip=clip, alts=alts, repeatpairs=repeatpairs, log=log)
-
-
-def collect_sample(arg):
-    """Host half of a sample (thread-safe, no GPU): the native scan of its BAM."""
-    o = _options(arg)
-    return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"])
-
-
-# ---- scans over GPU-inflated blocks -----------------------------------------------------------------------------------
-# Two thirds of a scan's host time is DEFLATE decoding of ~550 BGZF blocks per 30x sample, and the host's cores, not
-# the GPU, bound the from-BAM rate.  With `inflate_device` set, run_many plans every sample's blocks from its index
-# (bamio plan), has the GPU decode a whole chunk of samples in ONE launch (_lib.Inflater: one lane per block; kernels of
-# different streams do not overlap on this GPU, so the batch is what fills it) and lets the scans take the blocks from
-# the inflater's pinned output (bamio preload).  Blocks a plan misses, or the decoder rejects, are inflated by the scan
-# itself as before: the results cannot differ.
-def _plan_sample(arg, walk=False):
-    """Thread: open the BAM and list the blocks its scan will read -- with walk, also the pair-length regions as tasks
-    for the device's walk (bamio plan_walks / plan_blocks).  None: no GPU help for this sample."""
-    from .bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays, open_bam, y_regions
-    o = _options(arg)
-    try:
-        f = open_bam(o["bam"])
-    except (IOError, ValueError):
-        return None                                    # scan_sample reports the file
-    try:
-        if not hasattr(f, "plan"):
-            raise ValueError("no native BAM layer")
-        readlen = f.max_read_len(101)
-        loci = [o["repo"][n] for n in o["names"]]
-        sites, regions = _site_arrays(o["repo"], o["names"], loci, f)
-        sexed = any(t.is_xlinked for t in loci)          # scan_sample then asks for the chrY depth windows too
-        n, cbytes, obytes = f.plan(sites, regions, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN,
-                                   use_alts=o["alts"] and not o["clip"], extra=y_regions(o["repo"].ref) if sexed else ())
-        p = {"handle": f, "readlen": readlen, "n": n, "cbytes": cbytes, "obytes": obytes}
-        if walk and n > 0:
-            p["tasks"], p["chunks"] = f.plan_walks(sites, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE, span=SPAN)
-            p["alt_tasks"], p["alt_chunks"] = f.plan_alt_walks(sites, regions, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE,
-                                                               span=SPAN, use_alts=o["alts"] and not o["clip"])
-            p["coffset"], p["clen"], p["crc"], p["host"] = f.plan_blocks()
-        return p
-    except Exception:
-        f.close()
-        return None
-
-
-def _scan_planned(arg, plan, out_addr, out_off, status, crc=None, pe=None, alt=None):
-    """Thread: the sample's scan with its planned blocks preloaded from the inflater's output (crc: the decoder's
-    checksums of those blocks -- the scan then does not walk the bytes for the BGZF CRC again; pe: the pair walks'
-    results from the device, see scan_sample)."""
-    o = _options(arg)
-    f = plan["handle"]
-    try:
-        if status is not None:
-            f.preload(out_addr, out_off, status, crc)
-        return scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"], readlen=plan["readlen"], handle=f,
-                           pe=pe, alt=alt)
-    finally:
-        if status is not None:
-            hits, misses = f.preload_clear()
-            timing_add(inflate_hits=hits, inflate_misses=misses)
-        f.close()
-
-
-# Inflaters are kept between run_many calls of a process (their pinned staging is ~45 MB per sample of a chunk, and
-# page-locking it costs about a second per gigabyte): a feeder borrows three and gives them back.
-_INFLATERS = {}
-_INFLATERS_LOCK = threading.Lock()
-
-
-def _borrow_inflaters(device, n, host_out=True):
-    from ._lib import Inflater
-    with _INFLATERS_LOCK:
-        have = _INFLATERS.setdefault((device, host_out), [])
-        out = [have.pop() for _ in range(min(n, len(have)))]
-    while len(out) < n:
-        out.append(Inflater(device, host_out=host_out))
-    return out
-
-
-def _return_inflaters(device, infs):
-    with _INFLATERS_LOCK:
-        for inf in infs:
-            _INFLATERS.setdefault((device, getattr(inf, "host_out", True)), []).append(inf)
-
-
-def pinned_bytes():
-    """Page-locked host memory of the process's pooled inflaters (those a running feeder has borrowed are not counted)."""
-    with _INFLATERS_LOCK:
-        return sum(inf.pinned_bytes() for v in _INFLATERS.values() for inf in v if hasattr(inf, "pinned_bytes"))
-
-
-def release_inflaters():
-    """Frees the pooled inflaters (their pinned and device buffers)."""
-    with _INFLATERS_LOCK:
-        infs = [i for v in _INFLATERS.values() for i in v]
-        _INFLATERS.clear()
-    for inf in infs:
-        inf.close()
-
-
-atexit.register(release_inflaters)
-
-
-class _InflateFeeder(object):
-    """Feeds run_many's chunks through plan -> GPU inflate -> scan, ahead of the consumer: next() returns the next
-    (chunk, its scan futures), None behind the last one.  Three stages overlap: while the GPU decodes chunk k (a thread of its own makes the call,
-    which sleeps through it), the feeder thread plans and fills chunk k + 1 into another inflater's staging, and the scan
-    pool still reads chunk k - 1's blocks out of a third -- so there are three inflaters, each reused only when every
-    scan that reads its output has finished.  close() can be called at any time -- also while the consumer is unwinding
-    from an error: the threads are told to stop, whatever was planned but never handed to a scan is closed, and the
-    inflaters go only after every scan that reads their buffers has ended."""
-    SLOTS = 3
-
-    def __init__(self, chunks, ex, device, walk=False):
-        import queue
-        self.chunks, self.ex, self.device, self.walk = chunks, ex, device, walk
-        # plans and fills have threads of their own: queued behind a chunk's 28 scans in the scan pool they started only
-        # when those were done, and the pool then idled through the next chunk's decode
-        self.prep = ThreadPoolExecutor(max_workers=2)
-        self.gpu = ThreadPoolExecutor(max_workers=1)       # the decode calls, one after the other, in chunk order
-        # (with the walks on the device only a fifth of the blocks come back: those inflaters keep no pinned copy of the whole
-        #  output -- 45 MB per sample of a chunk -- and hand the wanted blocks over densely packed)
-        self.inflaters = _borrow_inflaters(device, self.SLOTS, host_out=not walk)
-        self.busy = [[] for _ in range(self.SLOTS)]
-        self.decoding = [None] * self.SLOTS            # the slot's last decode job (it sets busy[slot] when it hands the scans out)
-        self.q = queue.Queue(maxsize=2)
-        self.stop = threading.Event()
-        self.thread = threading.Thread(target=self._run, name="tred-inflate", daemon=True)
-        self.thread.start()
-
-    @staticmethod
-    def _close_plans(plans):
-        for p in plans:
-            if p is not None:
-                try:
-                    p["handle"].close()
-                except Exception:
-                    pass
-
-    def _prepare(self, ci, chunk):
-        """Feeder thread: the chunk's plans, and their payloads in the staging of inflater ci % SLOTS."""
-        slot = ci % self.SLOTS
-        inf = self.inflaters[slot]
-        if self.decoding[slot] is not None:
-            self.decoding[slot].exception()            # chunk ci - SLOTS has been decoded and its scans are known ...
-        for fut in self.busy[slot]:
-            fut.exception()                            # ... and have ended (waits; the consumer sees the error itself)
-        plans = [fut.result() for fut in [self.prep.submit(_plan_sample, a, self.walk) for a in chunk]]
-        live = [p for p in plans if p is not None and p["n"] > 0]
-        t0 = time.perf_counter()
-        job = {"plans": plans, "live": live, "inf": inf, "slot": slot, "ooff": None, "n_all": 0}
-        if live and not self.stop.is_set():
-            try:
-                n_all = sum(p["n"] for p in live)
-                comp, out, coff, ooff = inf.reserve(sum(p["cbytes"] for p in live), sum(p["obytes"] for p in live), n_all)
-                at = cb = ob = 0
-                fills = []
-                for p in live:
-                    p["first"] = at
-                    fills.append(self.prep.submit(p["handle"].plan_fill, inf.comp_addr, cb, ob, coff[at:at + p["n"] + 1],
-                                                ooff[at:at + p["n"] + 1]))
-                    at, cb, ob = at + p["n"], cb + p["cbytes"], ob + p["obytes"]
-                for fut in fills:
-                    fut.result()
-                # (every sample wrote its own end as entry n: the next sample's first entry is the same number)
-                job["ooff"], job["n_all"] = ooff, n_all
-                if self.walk:
-                    job["walk"] = self._walk_tables(live)
-            except Exception as e:     # no GPU help for this chunk: the scans inflate for themselves
-                logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
-        timing_add(inflate=time.perf_counter() - t0)
-        return job
-
-    @staticmethod
-    def _walk_tables(live):
-        """The chunk's pair-walk tasks: every sample's tables (bamio plan_walks / plan_blocks) moved to the sample's
-        place among the call's blocks and chunks."""
-        import numpy as np
-        def moved(key_t, key_c, first_key):
-            tasks, chunks, c0, t0 = [], [], 0, 0
-            for p in live:
-                t, c = p[key_t].copy(), p[key_c].copy()
-                t["chunk_first"] += c0
-                t["block_first"] += p["first"]
-                t["block_end"] += p["first"]
-                c["begin_block"][c["begin_block"] >= 0] += p["first"]
-                p[first_key] = t0
-                tasks.append(t)
-                chunks.append(c)
-                c0, t0 = c0 + len(c), t0 + len(t)
-            return np.concatenate(tasks), np.concatenate(chunks)
-        tasks, chunks = moved("tasks", "chunks", "task_first")
-        alt_tasks, alt_chunks = moved("alt_tasks", "alt_chunks", "alt_first")
-        return {"coffset": np.concatenate([p["coffset"] for p in live]), "clen": np.concatenate([p["clen"] for p in live]),
-                "crc": np.concatenate([p["crc"] for p in live]), "tasks": tasks, "chunks": chunks, "alt_tasks": alt_tasks,
-                "alt_chunks": alt_chunks}
-
-    def _decode_and_scan(self, chunk, job):
-        """Decode thread: one launch for the chunk, then its scans go to the pool and their futures to the consumer."""
-        plans, inf, handed, futs = job["plans"], job["inf"], 0, []
-        try:
-            if self.stop.is_set():
-                return
-            status = crc = walked = None
-            out_addr, out_off = inf.out_addr, job["ooff"]
-            if job["ooff"] is not None:
-                t0 = time.perf_counter()
-                try:
-                    if job.get("walk") is not None:
-                        status, crc, walked, out_addr, out_off = self._run_walk(inf, job)
-                    else:
-                        status, crc = inf.run(job["n_all"], crc=True)
-                        timing_add(inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
-                except Exception as e:
-                    logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
-                    status = crc = None
-                timing_add(inflate_gpu=time.perf_counter() - t0)
-            if self.stop.is_set():
-                return
-            for a, p in zip(chunk, plans):
-                if p is None:
-                    futs.append(self.ex.submit(collect_sample, a))
-                elif status is None or p["n"] == 0:
-                    futs.append(self.ex.submit(_scan_planned, a, p, 0, None, None))
-                else:
-                    k = p["first"]
-                    pe = alt = None
-                    if walked is not None:
-                        res, gp, tp, ares = walked
-                        pe = (res[p["task_first"]:p["task_first"] + len(p["tasks"])], gp, tp)
-                        alt = ares[p["alt_first"]:p["alt_first"] + len(p["alt_tasks"])]
-                    futs.append(self.ex.submit(_scan_planned, a, p, out_addr, out_off[k:k + p["n"] + 1], status[k:k + p["n"]],
-                                               crc[k:k + p["n"]], pe, alt))
-                handed += 1                                # (that scan closes its own handle)
-            self.busy[job["slot"]] = futs
-            self._put((chunk, futs))
-        except BaseException as e:     # hand the failure to the consumer instead of leaving it waiting
-            self.busy[job["slot"]] = futs         # (scans already running read the slot's buffers: close() waits for them)
-            self._put(e)
-        finally:
-            # only the plans no scan was given are closed here: a handle a running scan still uses must not be freed under it
-            self._close_plans(plans[handed:])
-
-    @staticmethod
-    def _run_walk(inf, job):
-        """Decode, walk the pair-length regions on the device, fetch the blocks the scans still read.  Returns the
-        statuses as the scans should see them (a block that was not fetched counts as not delivered), the checksums and
-        the walk's (results, global pool, target pool), and where the fetched blocks lie (address, offsets per block)."""
-        import numpy as np
-        from .bam_parser import walk_need
-        w = job["walk"]
-        from ._lib import walk_pool_pairs
-        t0 = time.perf_counter()
-        status, crc, res, gp, tp, ares, alt_need = inf.run_walk(job["n_all"], w["coffset"], w["clen"], w["crc"], w["tasks"], w["chunks"],
-                                                                alt_tasks=w["alt_tasks"], alt_chunks=w["alt_chunks"],
-                                                                pool_pairs=walk_pool_pairs(w["tasks"], job["ooff"]))
-        full = int((res["status"] == 6).sum())
-        if full:                           # (WALK_POOL_FULL: cannot happen with the bound above; a wrong plan would show here)
-            logging.getLogger("tredparse_amd").warning("pair walk: %d of %d regions found the pair pool full and are walked on the host", full, len(res))
-        t1 = time.perf_counter()
-        need = np.zeros(job["n_all"], np.uint8)
-        for p in job["live"]:
-            a = p["first"]
-            need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])],
-                                           alt_need[a:a + p["n"]])
-        t2 = time.perf_counter()
-        if getattr(inf, "host_out", True):
-            inf.fetch(need)
-            out_addr, out_off = inf.out_addr, job["ooff"]
-        else:
-            out_addr, out_off = inf.fetch_dense(need)
-        timing_add(walk_call=t1 - t0, walk_fetch=time.perf_counter() - t2)
-        walkable = w["alt_tasks"]["n_chunks"] >= 0
-        timing_add(walk_regions=len(res), walk_declined=int((res["status"] != 0).sum()), walk_blocks_fetched=int(need.sum()),
-                   walk_alt_regions=int(walkable.sum()), walk_alt_declined=int((ares["status"][walkable] != 0).sum()),
-                   inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
-        return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp, ares), out_addr, out_off
-
-    def _put(self, item):
-        import queue
-        while not self.stop.is_set():
-            try:
-                self.q.put(item, timeout=0.1)
-                return True
-            except queue.Full:
-                continue
-        return False
-
-    def _run(self):
-        try:
-            for ci, chunk in enumerate(self.chunks):
-                if self.stop.is_set():
-                    return
-                job = self._prepare(ci, chunk)
-                if self.stop.is_set():
-                    self._close_plans(job["plans"])
-                    return
-                self.decoding[job["slot"]] = self.gpu.submit(self._decode_and_scan, chunk, job)
-            self.gpu.submit(self._put, None)           # the end of the cohort, behind the last chunk's scans
-        except BaseException as e:
-            self._put(e)
-
-    def next(self):
-        item = self.q.get()
-        if isinstance(item, BaseException):
-            raise item
-        return item
-
-    def next_if_scanned(self):
-        """The next chunk if it is waiting AND all of its scans have finished, else None (the end of the cohort and errors
-        stay where they are, for next())."""
-        with self.q.mutex:
-            head = self.q.queue[0] if self.q.queue else None
-            if not isinstance(head, tuple) or not all(f.done() for f in head[1]):
-                return None
-        return self.q.get()       # (one consumer: what was at the head still is)
-
-    def close(self):
-        import queue
-        self.stop.set()
-        while True:                                        # make room: a put in progress returns at once
-            try:
-                self.q.get_nowait()
-            except queue.Empty:
-                break
-        self.thread.join()                                 # (bounded: the threads check the flag between every two steps)
-        self.gpu.shutdown(wait=True)
-        for slot in self.busy:
-            for fut in slot:
-                fut.exception()                            # scans still reading the staging buffers: let them end
-        self.prep.shutdown()
-        _return_inflaters(self.device, self.inflaters)     # (kept for the process's next cohort; release_inflaters frees them)
-        self.inflaters = []
-
-
 def _skeleton(o, scan):
     calls = {"inferredGender": scan.gender, "depthY": scan.ydepth}
     if scan.opened:
@@ -679,165 +328,6 @@ def run(arg, engine=None):
     {'samplekey', 'bam', 'tredCalls'}."""
     from .engine import Engine
     return finish_batch(engine or Engine(), [arg], [collect_sample(arg)])[0]
-
-
-NATIVE_EMIT = True        # (tools/prof_host.py and the tests switch the native writer off to time / compare the Python path)
-
-
-class Emitter(object):
-    """Writes the samples' <key>.json and <key>.tred.vcf.gz straight from a batch's result arrays and the scans' pools,
-    natively (libtredbam.so tredbam_emit_sample_files, include/tredbam.h) on `workers` threads that run WITHOUT the
-    interpreter lock -- instead of building every sample's tredCalls dict (format_scans) and printing it (to_json,
-    to_vcf) in Python, which was what bounded a driver process.  The text is byte for byte the Python path's
-    (tests/test_emit_native.py).  A sample the native printers do not cover -- --log DEBUG, a BAM that did not open, a
-    batch the retries cut into single units, names outside ASCII -- goes through the Python path on the same thread.
-      echo      print each JSON on stdout as to_json does (one worker then: the order of the samples is kept)
-      on_sample called with {'samplekey', 'names', 'printed' (bool per locus), 'first_allele' (units, per locus)} after a
-                sample's files are written (bench.py checks the calls against the simulated alleles with it)"""
-
-    def __init__(self, ref, repo, treds, no_output=False, echo=False, workers=2, on_sample=None, depth=96):
-        from . import bamio
-        self.ref, self.repo, self.treds, self.no_output, self.echo, self.on_sample = ref, repo, list(treds), no_output, echo, on_sample
-        self.lib = bamio._native() if NATIVE_EMIT else None
-        self.tables = {}
-        self.error = None
-        self.pool = ThreadPoolExecutor(max_workers=1 if echo else max(1, workers), thread_name_prefix="tred-emit")
-        self.depth = depth
-        self.room = threading.BoundedSemaphore(depth)          # results in flight (each holds its scan and batch arrays)
-        self.meta = INFO.encode("utf-8")
-        self.source = __file__.encode("utf-8")
-
-    def _table(self, names):
-        from . import bamio
-        key = tuple(names)
-        if key not in self.tables:
-            ok = self.lib is not None and all(isinstance(self.repo[n].cutoff_risk, int) and isinstance(self.repo[n].cutoff_prerisk, int)
-                                              for n in names)
-            self.tables[key] = bamio.emit_locus_table(self.repo, names) if ok else None
-        return self.tables[key]
-
-    def submit(self, arg, scan, pieces):
-        """One sample of a genotyped batch (pieces: genotype_scans' parts for it)."""
-        self.room.acquire()
-        try:
-            self.pool.submit(self._run, arg, scan, pieces)
-        except BaseException:
-            self.room.release()
-            raise
-
-    def _run(self, arg, scan, pieces):
-        t0 = time.perf_counter()
-        try:
-            if self.error is None:
-                self._emit(arg, scan, pieces)
-        except BaseException as e:
-            self.error = e
-        finally:
-            self.room.release()
-            timing_add(write=time.perf_counter() - t0)
-
-    def _python_path(self, arg, scan, pieces):
-        """The sample through format_scans and the Python writers (what the native path must equal)."""
-        picks = [(0, scan, [k for _, _, ks in pieces for k in ks])]
-        result = format_scans([arg], [scan], picks, unit_results({0: pieces}), lazy_details=True)[0]
-        if not self.no_output:
-            write_vcf_json(result, self.ref, self.repo, self.treds, quiet=not self.echo)
-        if self.on_sample is not None:
-            calls = result["tredCalls"]
-            self.on_sample({"samplekey": result["samplekey"], "names": scan.names,
-                            "printed": [n + ".1" in calls for n in scan.names],
-                            "first_allele": [calls.get(n + ".1", -1) for n in scan.names]})
-
-    def _emit(self, arg, scan, pieces):
-        import ctypes as C
-        import numpy as np
-        from . import bamio
-        o = _options(arg)
-        native = scan.opened and len(pieces) == 1 and o["log"] != "DEBUG" and getattr(pieces[0][0], "joint_units", None) is not None
-        table = self._table(scan.names) if native else None
-        if table is None or (self.no_output and self.on_sample is None):
-            if not (self.no_output and self.on_sample is None and o["log"] != "DEBUG"):
-                self._python_path(arg, scan, pieces)
-            else:                # nothing to print: the loci the grid refused are still reported, as the Python path does
-                from .models import STATUS_ERRORS
-                for br, i0, ks in pieces:
-                    st = br.calls["status"][i0:i0 + len(ks)]
-                    for j in np.nonzero(st < 0)[0].tolist():
-                        logger.error("Exception on `%s` %s (%s)", o["bam"], scan.names[ks[j]],
-                                     STATUS_ERRORS.get(int(st[j]), "status {}".format(int(st[j]))))
-            return
-        br, i0, ks = pieces[0]
-        eb = getattr(br, "_emit", None)
-        if eb is None:                       # the batch's arrays, once per batch (whichever sample's thread gets there first)
-            a, b, v, lo, n = br.joint_units
-            keep = [np.ascontiguousarray(x) for x in (br.tag, br.h, br.batch.unit_read_off, br.calls, br.marg, a, b, v, lo, n)]
-            eb = bamio.EmitBatch(*[x.ctypes.data for x in keep[:5]], br.marg.shape[2], *[x.ctypes.data for x in keep[5:]],
-                                 int(bool(br.repeatpairs)), 0)
-            eb.keep = keep
-            br._emit = eb
-        index = np.full(len(scan.names), -1, np.int32)
-        index[ks] = np.arange(i0, i0 + len(ks), dtype=np.int32)
-        depth = np.ascontiguousarray(scan.depth, np.float64)
-        key, bam = o["samplekey"].encode("utf-8"), o["bam"].encode("utf-8")
-        ydepth = float(scan.ydepth) if isinstance(scan.ydepth, float) else -1.0
-        es = bamio.EmitSample(key, bam, scan.gender.encode("utf-8"), ydepth, 1, int(scan.readlen),
-                              scan.seq4.ctypes.data, scan.seq4_off.ctypes.data, scan.read_len.ctypes.data,
-                              scan.name_blob if isinstance(scan.name_blob, int) else C.cast(C.c_char_p(scan.name_blob), C.c_void_p).value,
-                              scan.name_off.ctypes.data, scan.name_id.ctypes.data,
-                              scan.global_lens.ctypes.data, scan.target_lens.ctypes.data, scan.unit.ctypes.data, depth.ctypes.data,
-                              index.ctypes.data)
-        today = date.today()
-        eo = bamio.EmitOpts(self.ref.encode("utf-8"), self.source, "{}{:02d}{:02d}".format(today.year, today.month, today.day).encode(),
-                            self.meta, 0 if self.no_output else 1, 0 if self.no_output else 1, 6, 0)
-        status = np.zeros(max(1, len(scan.names)), np.int32)
-        cap = (1 << 22) if self.echo else 0
-        text = C.create_string_buffer(cap) if cap else None
-        got = C.c_int64(-1)
-        rc = self.lib.tredbam_emit_sample_files(C.addressof(table), len(scan.names), C.addressof(eb), C.addressof(es), C.addressof(eo),
-                                                status.ctypes.data, text, cap, C.byref(got))
-        if rc == 1:
-            return self._python_path(arg, scan, pieces)
-        if rc < 0:
-            why = self.lib.tredbam_emit_last_error().decode("utf-8", "replace") or str(rc)
-            print("Error writing: {} ({})".format(o["samplekey"], why), file=sys.stderr)
-            if rc != -5:         # not an I/O error of this one sample's files (the reference prints and goes on there, tred.py:
-                # 290-293): the arrays handed over do not fit together -- every later sample of the run would be wrong as well
-                raise RuntimeError("native writer refused `{}`: {} (rc={})".format(o["samplekey"], why, rc))
-            if self.on_sample is not None:
-                self.on_sample({"samplekey": o["samplekey"], "names": scan.names, "printed": [False] * len(scan.names),
-                                "first_allele": [-1] * len(scan.names)})
-            return
-        from .models import STATUS_ERRORS
-        for k in np.nonzero(status[:len(scan.names)] < 0)[0].tolist():
-            st = int(status[k])
-            logger.error("Exception on `%s` %s (%s)", o["bam"], scan.names[k], STATUS_ERRORS.get(st, "status {}".format(st)))
-        if self.echo and not self.no_output:
-            if got.value >= 0:
-                print(text.raw[:got.value].decode("ascii"))
-            else:
-                with open(o["samplekey"] + ".json") as fp:
-                    sys.stdout.write(fp.read())
-        if self.on_sample is not None:
-            c = br.calls[i0:i0 + len(ks)]
-            per = np.array([len(scan.loci[k].repeat) for k in ks], np.int64)
-            first = np.full(len(scan.names), -1, np.int64)
-            first[ks] = np.where(c["status"] == 0, np.minimum(c["h1"], c["h2"]) // per, -1)
-            self.on_sample({"samplekey": o["samplekey"], "names": scan.names, "printed": (status[:len(scan.names)] == 0).tolist(),
-                            "first_allele": first.tolist()})
-
-    def drain(self):
-        """Waits until every submitted sample is written (a sample holds one of the `depth` places until it is)."""
-        for _ in range(self.depth):
-            self.room.acquire()
-        for _ in range(self.depth):
-            self.room.release()
-        if self.error is not None:
-            raise self.error
-
-    def close(self):
-        self.pool.shutdown(wait=True)
-        if self.error is not None:
-            raise self.error
 
 
 class _Writer(object):
