@@ -219,6 +219,12 @@ int tredbam_scan_walked(tredbam* b, const tredbam_site* sites, int32_t n_sites, 
                         const tredbam_scan_opts* opts, const tredbam_walk_result* pe, const int32_t* pe_global,
                         const int32_t* pe_target, const tredbam_alt_result* alt_results, tredbam_unit* units);
 int64_t tredbam_plan_blocks(tredbam* b, int64_t* coffset, int32_t* clen, uint32_t* crc, uint8_t* host);
+/* Plain regions as tasks of the same walker (after tredbam_plan with the regions among its `extra`): task k = the records
+ * overlapping regions[k], the window is the region, span 0 -- no pairs; for the chrY windows of the sex inference
+ * (BamDepth.get_Y_depth, bam_parser.py:413-429), whose pile-up sums the device's read selection (include/tredgpu.h section 5)
+ * returns.  Returns the number of chunks written, -3 when cap_chunks is too small; n_chunks < 0: not walkable. */
+int64_t tredbam_plan_region_walks(tredbam* b, const tredbam_region* regions, int32_t n_regions, tredbam_walk_task* tasks,
+                                  tredbam_walk_chunk* chunks, int64_t cap_chunks);
 int tredbam_scan_pe(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tredbam_region* alts,
                     const tredbam_scan_opts* opts, const tredbam_walk_result* pe, const int32_t* pe_global,
                     const int32_t* pe_target, tredbam_unit* units);

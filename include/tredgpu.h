@@ -382,6 +382,9 @@ typedef struct tredgpu_walk_args {
     const tredgpu_walk_chunk* alt_chunks; int32_t n_alt_chunks;
     struct tredgpu_alt_result* alt_results; /* out: n_alt_tasks                                                            */
     uint8_t* need;                          /* out: n_blocks                                                               */
+    /* the read selection where the records already are (section 5 below; select == NULL: none): one entry per task          */
+    const struct tredgpu_select_task* select;
+    struct tredgpu_select_result* selected; /* out: n_tasks                                                                */
 } tredgpu_walk_args;
 typedef struct tredgpu_alt_result { int32_t status, n; uint64_t vbeg[6]; } tredgpu_alt_result;
 int tredgpu_inflate_walk(tredgpu_inflater* inf, int32_t n_blocks, int32_t* status, uint32_t* crc, tredgpu_walk_args* walk);
@@ -406,6 +409,55 @@ int64_t tredgpu_inflater_pinned_bytes(const tredgpu_inflater* inf);
 int64_t tredgpu_inflater_walk_serial_regions(tredgpu_inflater* inf);
 /* device time of the last call's walk launch in milliseconds */
 int tredgpu_inflater_walk_ms(tredgpu_inflater* inf, double* walk_ms);
+
+/* ---- (5) read selection, depth and 2-bit packing on the device ----------------------------------------------------------- */
+/*
+ * BamParser.parse's read selection (tredparse/bam_parser.py:199-243: of the window's records the unmapped ones -- placed at
+ * their mate -- and those that start within one READLEN of the tract; then, from the alternative loci, the records whose
+ * mate lies in the window), BamDepth.region_depth (:404-411: the pile-up of the window's records without truncation, summed)
+ * and Aligner._DNA_to_int_mat (ssw_wrap.py:229-244) over the records tredgpu_inflate_walk has just listed: the inflated
+ * blocks never leave the device -- what the host still reads of a sample are its calls, the tags and, for the JSON's
+ * `details`, the selected reads' names and 4-bit sequences (~0.3 MB instead of ~7 MB of blocks per 30x sample).
+ *
+ *   tredgpu_select_task    one per task of the walk, in its order.  n_alt >= 0: a locus -- reads of the task's window
+ *                          [win_lo, win_hi) that are unmapped or start within [pos_lo, pos_hi] are selected, in file order,
+ *                          then the hits of the alternative regions alt_first .. alt_first + n_alt of the call's alt_tasks, region
+ *                          by region (a region with n_chunks < 0 -- its contig is not in the file -- is skipped as the
+ *                          reference's fetch skips it); depth_sum = sum over the window's records that are mapped, primary, not
+ *                          QC-failed and not duplicates of (reference_end - reference_start).  n_alt < 0: a plain region (the
+ *                          chrY windows of the sex inference, bam_parser.py:413-429): depth_sum only, nothing is selected; give
+ *                          such a task span <= 0 and the pair walk leaves it alone.
+ *   tredgpu_select_result  status 0, or: the pair walk's / an alternative region's status (1-7: the host scans the unit's sample
+ *                          as before), 8 more than 4 096 reads, 9 a read beyond TREDGPU_MAX_READ_LEN.  n_words / seq4_bytes /
+ *                          name_bytes: the room the unit's reads take in the packed layout (tredgpu_pack_reads), as 4-bit
+ *                          sequences ((L + 1) / 2 bytes each) and as names (not terminated).
+ */
+typedef struct tredgpu_select_task { int32_t pos_lo, pos_hi, alt_first, n_alt; } tredgpu_select_task;
+typedef struct tredgpu_select_result {
+    int32_t status, n_reads, n_words, seq4_bytes, name_bytes, max_len;
+    int64_t depth_sum;
+} tredgpu_select_result;
+#define TREDGPU_SELECT_CAP 4096            /* reads per unit the selection holds */
+/*
+ * tredgpu_genotype_batch_joint over reads that are still on the device: the units are tasks of inflaters' last
+ * tredgpu_inflate_walk calls with a selection (segment s: n_units units, tasks task[.] of inflater inf, in batch order; the
+ * inflaters' buffers must stay untouched until the call returns).  The reads are packed into the context's buffers by a
+ * kernel, SW + tagging -> histograms -> grid run as in tredgpu_genotype_batch_joint, and ONE wait brings back what that call
+ * returns plus the selected reads for the writers:
+ *   unit_read_off[n_units + 1]: running sum of the units' n_reads; unit_word_off / unit_seq4_off / unit_name_off
+ *   [n_units + 1] (int64): running sums of n_words / seq4_bytes / name_bytes (the caller has them from the select results);
+ *   read_len[n_reads], seq4_off[n_reads + 1] + seq4[unit_seq4_off[n_units]], name_off[n_reads + 1] +
+ *   names[unit_name_off[n_units]]: out, host.  params->max_read_len must name the longest selected read (max_len).
+ */
+typedef struct tredgpu_selected_units { tredgpu_inflater* inf; int32_t n_units; int32_t pad; const int32_t* task; } tredgpu_selected_units;
+int tredgpu_genotype_selected(tredgpu_ctx* ctx, const tredgpu_selected_units* segs, int32_t n_segs, const int32_t* unit_read_off,
+                              const int64_t* unit_word_off, const int64_t* unit_seq4_off, const int64_t* unit_name_off,
+                              const int32_t* unit_ladder, const tredgpu_unit_params* units, int32_t n_units,
+                              const tredgpu_sw_params* params, const int32_t* global_lens, int64_t n_global_total,
+                              const int32_t* target_lens, int64_t n_target_total, uint8_t* out_tag, int16_t* out_h,
+                              int16_t* out_score, int32_t hist_stride, int32_t* rept_cnt, tredgpu_call* calls, double* marg,
+                              int32_t marg_stride, const int64_t* joint_off, double* joint, int32_t* joint_n, double* joint_total,
+                              int32_t* read_len, int64_t* seq4_off, uint8_t* seq4, int64_t* name_off, char* names);
 
 #ifdef __cplusplus
 }

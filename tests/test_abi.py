@@ -37,7 +37,7 @@ def test_bam_layer_header_symbols_all_exported():
     src = open(os.path.join(ROOT, "include", "tredbam.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(tredbam_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) == 36 and {"tredbam_emit_sample_files", "tredbam_emit_last_error", "tredbam_pairwise_sum", "tredbam_pe_pool_sizes"} <= set(names) and {"tredbam_plan_walks", "tredbam_plan_blocks", "tredbam_scan_pe", "tredbam_plan_alt_walks", "tredbam_scan_walked"} <= set(names) and {"tredbam_plan", "tredbam_plan_fill", "tredbam_preload", "tredbam_preload_crc", "tredbam_preload_clear"} <= set(names) and "tredbam_pair_stats" in names and "tredbam_sparse_json_many" in names and "tredbam_crc32" in names and "tredbam_details_json" in names and "tredbam_sparse_json" in names and "tredbam_scan" in names and "tredbam_max_read_len" in names and "tredbam_inflate_raw" in names
+    assert len(names) == 37 and "tredbam_plan_region_walks" in names and {"tredbam_emit_sample_files", "tredbam_emit_last_error", "tredbam_pairwise_sum", "tredbam_pe_pool_sizes"} <= set(names) and {"tredbam_plan_walks", "tredbam_plan_blocks", "tredbam_scan_pe", "tredbam_plan_alt_walks", "tredbam_scan_walked"} <= set(names) and {"tredbam_plan", "tredbam_plan_fill", "tredbam_preload", "tredbam_preload_crc", "tredbam_preload_clear"} <= set(names) and "tredbam_pair_stats" in names and "tredbam_sparse_json_many" in names and "tredbam_crc32" in names and "tredbam_details_json" in names and "tredbam_sparse_json" in names and "tredbam_scan" in names and "tredbam_max_read_len" in names and "tredbam_inflate_raw" in names
     out = subprocess.check_output(["nm", "-D", "--defined-only", bamio._LIB_PATH]).decode()
     assert set(re.findall(r" T (tredbam_[a-z0-9_]+)", out)) == set(names)
     assert ctypes.sizeof(ctypes.c_int32) * 10 + 4 == bamio._REC.size == 44      # tredbam_rec

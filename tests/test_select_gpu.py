@@ -1,0 +1,166 @@
+"""GPU: read selection, depth and 2-bit packing on the device (include/tredgpu.h section 5: select_kernel, pack_selected_kernel,
+tredgpu_genotype_selected) against the host's scan (bamread.cpp scan_impl, which restates BamParser.parse's selection,
+BamDepth and BamReadLen: tredparse/bam_parser.py:184-257, 372-411, and is itself pinned against the reference in
+test_host_frontend.py / test_e2e_gpu.py): per sample the same sex, depth, reads in the same order with the same names and
+sequences, the same pair-length slices -- and through the kernels the same tags, calls, marginals and joint entries,
+bit for bit.  Then the product path: run_many with gpu_select against run_many on the host, result dict for result dict."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from tredparse_amd import _lib, synth, synth_bam, tred as t
+from tredparse_amd.bam_parser import scan_sample
+from tredparse_amd.engine import Engine, PackedUnits
+from tredparse_amd.feeder import _InflateFeeder
+from tredparse_amd.meta import TREDsRepo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def cohort(tmp_path_factory):
+    root = tmp_path_factory.mktemp("select")
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1", "AR", "FXS", "FRDA", "SCA17")]
+    made = synth_bam.make_bams(str(root), 3, seed=77, loci=loci, p=synth.SynthParams(coverage=30, expanded_max=120, expanded_frac=0.3))
+    repo = TREDsRepo(ref="hg38", sites=os.path.join(GOLD, "no_sites"))
+    srepo = TREDsRepo()
+    names = [l["name"] for l in loci]
+    args = [(s, os.path.join(GOLD, "bam", s + ".bam"), repo, sorted(repo.names), 300, False, False, True, True, "ERROR") for s in ("t001", "t002")]
+    args += [(key, path, srepo, names, 300, False, False, True, True, "ERROR") for key, path, _ in made]
+    # blocks cut without regard to records (every record straddles the 300-byte ones), odd flags
+    recs, _ = synth_bam.simulate_sample(78, loci[:4], synth.SynthParams(coverage=20, expanded_max=120, expanded_frac=0.3))
+    rng = np.random.default_rng(78)
+    recs.flag[rng.random(len(recs.flag)) < 0.03] |= 0x400
+    recs.flag[rng.random(len(recs.flag)) < 0.02] |= 0x100
+    recs.flag[rng.random(len(recs.flag)) < 0.02] |= 0x200
+    recs.flag[rng.random(len(recs.flag)) < 0.05] ^= 0x10
+    for block in (300, 20000):
+        path = os.path.join(str(root), "cut{}.bam".format(block))
+        synth_bam.write_bam(path, recs, sample="cut", block=block, split_records=True)
+        args.append(("cut{}".format(block), path, srepo, names[:4], 300, False, False, True, True, "ERROR"))
+    args.append(("noalts", os.path.join(GOLD, "bam", "t001.bam"), repo, ["HD", "DM1", "AR"], 300, False, False, False, True, "ERROR"))
+    args.append(("clip", made[0][1], srepo, names, 300, False, True, True, True, "ERROR"))
+    args.append(("full", made[1][1], srepo, names[:3], 60, True, False, True, True, "ERROR"))
+    return args
+
+
+def _device_scans(args, engine, batch):
+    """The feeder with the selection on, a chunk at a time: [(arg, scan, pieces)] in task order."""
+    chunks = [args[i:i + batch] for i in range(0, len(args), batch)]
+    ex = ThreadPoolExecutor(max_workers=2)
+    feeder = _InflateFeeder(chunks, ex, 0, walk=True, select=True)
+    out = []
+    try:
+        for _ in chunks:
+            chunk, futs = feeder.next()
+            scans = [f.result() for f in futs]
+            picks, parts = t.genotype_scans(engine, chunk, scans)
+            out += [(a, s, parts.get(si, [])) for si, (a, s) in enumerate(zip(chunk, scans))]
+    finally:
+        feeder.close()
+        ex.shutdown()
+        t.release_inflaters()
+    return out
+
+
+def test_selection_on_the_device_equals_the_host_scan(cohort, engine):
+    for k in t.TIMING:
+        t.TIMING[k] = 0
+    got = _device_scans(cohort, engine, batch=4)
+    assert t.TIMING["select_samples"] == len(cohort) and t.TIMING["select_declined"] == 0 and t.TIMING["walk_blocks_fetched"] == 0
+    reads = units = 0
+    for a, s, pieces in got:
+        o = t._options(a)
+        assert getattr(s, "device", None) is not None, o["samplekey"]
+        h = scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"])
+        assert (s.gender, s.ydepth, s.readlen, s.opened, s.dropped) == (h.gender, h.ydepth, h.readlen, h.opened, h.dropped), o["samplekey"]
+        for key in ("n_reads", "read_first", "depth_sum", "depth_status", "pe_status", "n_global", "n_target", "status"):
+            assert (s.unit[key] == h.unit[key]).all(), (o["samplekey"], key)
+        assert np.array_equal(s.depth, h.depth) and np.array_equal(s.ploidy, h.ploidy)
+        for k in range(len(s.names)):
+            for x, y in zip(s.pair_lengths(k), h.pair_lengths(k)):
+                assert np.array_equal(x, y), (o["samplekey"], s.names[k])
+        assert np.array_equal(s.read_len, h.read_len) and np.array_equal(s.seq4_off, h.seq4_off) and np.array_equal(s.seq4, h.seq4)
+        assert np.array_equal(s.name_off, h.name_off) and s.name_blob == h.name_blob, o["samplekey"]
+        # the kernels over the device-packed reads against the kernels over the host-packed ones
+        ks = list(range(len(h.names)))
+        hb = engine.genotype_packed(PackedUnits.from_scans([(h, ks)], maxinsert=o["maxinsert"], fullsearch=o["fullsearch"], clip=o["clip"]))
+        (br, i0, dks), = pieces
+        assert dks == ks
+        lo, hi = int(br.batch.unit_read_off[i0]), int(br.batch.unit_read_off[i0 + len(ks)])
+        assert hi - lo == hb.batch.n_reads
+        assert np.array_equal(br.tag[lo:hi], hb.tag) and np.array_equal(br.h[lo:hi], hb.h) and np.array_equal(br.score[lo:hi], hb.score)
+        for key in (k for k in br.calls.dtype.names if k != "pad"):
+            x, y = br.calls[key][i0:i0 + len(ks)], hb.calls[key]
+            assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), (o["samplekey"], key)
+        m = min(br.marg.shape[2], hb.marg.shape[2])
+        assert np.array_equal(br.marg[i0:i0 + len(ks), :, :m], hb.marg[:, :, :m])
+        assert np.array_equal(br.rept[i0:i0 + len(ks)].sum(1), hb.rept.sum(1))
+        for j in range(len(ks)):
+            (ta, tot_a), (tb, tot_b) = br.joint[i0 + j], hb.joint[j]
+            assert tot_a == tot_b and sorted(map(tuple, ta.tolist())) == sorted(map(tuple, tb.tolist())), (o["samplekey"], j)
+        reads += hi - lo
+        units += len(ks)
+    assert reads > 2500 and units > 80
+
+
+def test_what_the_device_cannot_serve_goes_to_the_host_scan(cohort, engine):
+    """--norepeatpairs and --log DEBUG need more than the device path returns; a missing file, a file without the locus'
+    contig: those samples are scanned on the host in the same chunk, the others stay on the device."""
+    a0 = cohort[2]
+    mixed = [cohort[2], cohort[2][:8] + (False, "ERROR"), cohort[3], cohort[3][:9] + ("DEBUG",),
+             ("missing", os.path.join(os.path.dirname(cohort[2][1]), "no_such.bam")) + a0[2:]]
+    got = _device_scans(mixed, engine, batch=5)
+    where = [getattr(s, "device", None) is not None for _, s, _ in got]
+    assert where == [True, False, True, False, False]
+    assert got[4][1].opened is False
+    (b0, i0, k0), = got[0][2]
+    (b1, i1, k1), = got[1][2]
+    n = len(k0)
+    assert np.array_equal(b0.calls["h1"][i0:i0 + n], b1.calls["h1"][i1:i1 + n]) and np.array_equal(b0.calls["h2"][i0:i0 + n], b1.calls["h2"][i1:i1 + n])
+
+
+@pytest.mark.parametrize("emit", [False, True])
+def test_run_many_with_the_selection_on_the_device_gives_the_host_runs_results(cohort, engine, tmp_path, emit):
+    """The product path: result dicts (and, with the native writer, the files' bytes) of run_many(gpu_select=True) against
+    the host-only run_many, chunks of three so that chunks merge and inflaters rotate."""
+    import hashlib
+    args = list(cohort) + list(cohort[2:5])
+    args = [(("s%02d_" % i) + a[0],) + a[1:] for i, a in enumerate(args)]
+    if not emit:
+        want = t.run_many(args, engine, batch=64, threads=2, lazy_details=False)
+        got = t.run_many(args, engine, batch=3, threads=2, lazy_details=False, inflate_device=0, gpu_walk=True, gpu_select=True)
+        assert len(got) == len(want) == len(args)
+        for g, w in zip(got, want):
+            assert g == w, g["samplekey"]
+        return
+    digests = []
+    cwd = os.getcwd()
+    for mode in ("host", "device"):
+        work = tmp_path / mode
+        work.mkdir()
+        os.chdir(str(work))
+        try:
+            em = t.Emitter("hg38", args[2][2], args[2][3], workers=2)
+            kw = dict(inflate_device=0, gpu_walk=True, gpu_select=True) if mode == "device" else {}
+            # (one locus list per Emitter: the synthetic samples)
+            t.run_many([a for a in args if a[3] == args[2][3]], engine, batch=3, threads=2, lazy_details=True, emit=em, **kw)
+            em.close()
+        finally:
+            os.chdir(cwd)
+        d = {}
+        for name in sorted(os.listdir(str(work))):
+            if name.endswith(".json"):
+                d[name] = hashlib.sha256(open(str(work / name), "rb").read()).hexdigest()
+        digests.append(d)
+    assert len(digests[0]) >= 4 and digests[0] == digests[1]

@@ -55,7 +55,7 @@ assert CALL_DTYPE.itemsize == C.sizeof(Call) == 56
 EXPORTS = ("tredgpu_create", "tredgpu_destroy", "tredgpu_last_error", "tredgpu_sync", "tredgpu_get_stream",
            "tredgpu_version", "tredgpu_set_ladders", "tredgpu_set_model", "tredgpu_pack_reads",
            "tredgpu_sw_classify", "tredgpu_tally", "tredgpu_likelihood_grid", "tredgpu_likelihood_grid_joint",
-           "tredgpu_genotype_batch", "tredgpu_genotype_batch_joint",
+           "tredgpu_genotype_batch", "tredgpu_genotype_batch_joint", "tredgpu_genotype_selected",
            "tredgpu_pe_kde", "tredgpu_reset_timing", "tredgpu_get_timing", "tredgpu_get_sw_counters",
            "tredgpu_inflater_create", "tredgpu_inflater_destroy", "tredgpu_inflater_last_error",
            "tredgpu_inflater_reserve", "tredgpu_inflate_blocks", "tredgpu_inflate_blocks_crc", "tredgpu_inflater_timing",
@@ -101,6 +101,8 @@ def load():
                                            vp, vp, vp, vp]
     lib.tredgpu_genotype_batch_joint.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, C.POINTER(SwParams), vp, vp, i64, vp, i64,
                                                  vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.tredgpu_genotype_selected.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(SwParams), vp, i64, vp, i64,
+                                              vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tredgpu_pe_kde.argtypes = [vp, C.c_int, vp, i32, vp, i64, vp, vp]
     lib.tredgpu_reset_timing.argtypes = [vp]
     lib.tredgpu_get_timing.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(C.c_double)]
@@ -301,6 +303,25 @@ class Context:
                                                         marg_stride, _ptr(joint_off), _ptr(joint), _ptr(joint_n),
                                                         _ptr(joint_total)), "tredgpu_genotype_batch_joint")
 
+    def genotype_selected(self, segs, unit_read_off, unit_word_off, unit_seq4_off, unit_name_off, unit_ladder, units, n_units, params,
+                          global_lens, n_global_total, target_lens, n_target_total, out_tag, out_h, out_score, hist_stride, rept_cnt,
+                          calls, marg, marg_stride, joint_off, joint, joint_n, joint_total, read_len, seq4_off, seq4, name_off, names):
+        """tredgpu_genotype_selected: genotype_batch_joint over reads the inflaters' selections left on the device.
+        segs: [(Inflater, int32 array of its tasks in batch order)]."""
+        arr = (SelectedUnits * max(len(segs), 1))()
+        keep = []
+        for k, (inf, task) in enumerate(segs):
+            task = np.ascontiguousarray(task, np.int32)
+            keep.append(task)
+            arr[k] = SelectedUnits(inf._h, len(task), 0, task.ctypes.data if len(task) else None)
+        self._chk(self.lib.tredgpu_genotype_selected(self.h, arr, len(segs), _ptr(unit_read_off), _ptr(unit_word_off), _ptr(unit_seq4_off),
+                                                     _ptr(unit_name_off), _ptr(unit_ladder), _ptr(units), n_units, C.byref(params),
+                                                     _ptr(global_lens), n_global_total, _ptr(target_lens), n_target_total, _ptr(out_tag),
+                                                     _ptr(out_h), _ptr(out_score), hist_stride, _ptr(rept_cnt), _ptr(calls), _ptr(marg),
+                                                     marg_stride, _ptr(joint_off), _ptr(joint), _ptr(joint_n), _ptr(joint_total),
+                                                     _ptr(read_len), _ptr(seq4_off), _ptr(seq4), _ptr(name_off), _ptr(names)),
+                  "tredgpu_genotype_selected")
+
     def reset_timing(self):
         self._chk(self.lib.tredgpu_reset_timing(self.h), "tredgpu_reset_timing")
 
@@ -338,7 +359,12 @@ class WalkArgs(C.Structure):
                 ("results", C.c_void_p), ("global_pool", C.c_void_p), ("cap_global", C.c_int64),
                 ("target_pool", C.c_void_p), ("cap_target", C.c_int64), ("n_global", C.c_int64), ("n_target", C.c_int64),
                 ("alt_tasks", C.c_void_p), ("n_alt_tasks", C.c_int32), ("alt_chunks", C.c_void_p), ("n_alt_chunks", C.c_int32),
-                ("alt_results", C.c_void_p), ("need", C.c_void_p)]
+                ("alt_results", C.c_void_p), ("need", C.c_void_p), ("select", C.c_void_p), ("selected", C.c_void_p)]
+
+
+class SelectedUnits(C.Structure):
+    """tredgpu_selected_units (include/tredgpu.h section 5)."""
+    _fields_ = [("inf", C.c_void_p), ("n_units", C.c_int32), ("pad", C.c_int32), ("task", C.c_void_p)]
 
 
 # layouts of tredgpu_walk_task / _chunk / _result (the same as bamio.WALK_*_DTYPE: tredbam.h's structs)
@@ -348,6 +374,12 @@ WALK_CHUNK_DTYPE = np.dtype([("begin_block", "<i4"), ("begin_upos", "<i4"), ("en
 WALK_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"), ("n_window", "<i4"),
                               ("global_first", "<i8"), ("target_first", "<i8"), ("win_vbeg", "<u8"), ("win_vend", "<u8")])
 ALT_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n", "<i4"), ("vbeg", "<u8", (6,))])
+# tredgpu_select_task / tredgpu_select_result (section 5: the read selection on the device)
+SELECT_TASK_DTYPE = np.dtype([("pos_lo", "<i4"), ("pos_hi", "<i4"), ("alt_first", "<i4"), ("n_alt", "<i4")])
+SELECT_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_reads", "<i4"), ("n_words", "<i4"), ("seq4_bytes", "<i4"), ("name_bytes", "<i4"),
+                                ("max_len", "<i4"), ("depth_sum", "<i8")])
+assert SELECT_TASK_DTYPE.itemsize == 16 and SELECT_RESULT_DTYPE.itemsize == 32
+SELECT_CAP = 4096
 
 
 MIN_PAIR_BYTES = 2 * (36 + 2 + 4 + 18)    # two BAM records of a pair at their smallest: fixed fields, name, one CIGAR op, 36 bases
@@ -425,13 +457,16 @@ class Inflater:
         return status[:n_blocks], sums[:n_blocks]
 
     def run_walk(self, n_blocks, blk_coffset, blk_clen, blk_crc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None,
-                 pool_pairs=None):
+                 pool_pairs=None, select=None):
         """tredgpu_inflate_walk: decodes the blocks laid out in the reserved buffers and walks the pair-length regions
         (tasks WALK_TASK_DTYPE, chunks WALK_CHUNK_DTYPE) over them on the device.  No block is copied back (fetch does
         that).  Returns (status, crc, results WALK_RESULT_DTYPE, global pool, target pool) -- with alt_tasks / alt_chunks
         (the alternative loci's walks) also (results ALT_RESULT_DTYPE, uint8 flags of the blocks that hold their records).
         pool_pairs: room in the global pool for the whole call (walk_pool_pairs: a bound from the planned bytes, so that
-        no coverage makes a region fall back to the host for want of room); without it pairs_per_task per task."""
+        no coverage makes a region fall back to the host for want of room); without it pairs_per_task per task.
+        select (SELECT_TASK_DTYPE, one per task): the read selection, depth sums and sizes where the records are (tredgpu.h
+        section 5) -- the results (SELECT_RESULT_DTYPE) are appended to the returned tuple, the selected records stay on the
+        device for Context.genotype_selected."""
         status, sums = np.zeros(max(n_blocks, 1), np.int32), np.zeros(max(n_blocks, 1), np.uint32)
         coff = np.ascontiguousarray(blk_coffset, np.int64)
         clen = np.ascontiguousarray(blk_clen, np.int32)
@@ -449,13 +484,22 @@ class Inflater:
         ac = np.ascontiguousarray(alt_chunks if (n_alt and len(alt_chunks)) else np.zeros(1, WALK_CHUNK_DTYPE), WALK_CHUNK_DTYPE)
         ares = np.zeros(max(n_alt, 1), ALT_RESULT_DTYPE)
         need = np.zeros(max(n_blocks, 1), np.uint8)
+        sel = selres = None
+        if select is not None:
+            sel = np.ascontiguousarray(select, SELECT_TASK_DTYPE)
+            if len(sel) != len(tasks):
+                raise ValueError("one select task per walk task")
+            selres = np.zeros(max(len(tasks), 1), SELECT_RESULT_DTYPE)
         a = WalkArgs(coff.ctypes.data, clen.ctypes.data, xcrc.ctypes.data, tasks.ctypes.data, len(tasks), chunks.ctypes.data,
                      len(chunks), res.ctypes.data, gp.ctypes.data, len(gp), tp.ctypes.data, len(tp), 0, 0,
-                     at.ctypes.data, n_alt, ac.ctypes.data, len(alt_chunks) if n_alt else 0, ares.ctypes.data, need.ctypes.data)
+                     at.ctypes.data, n_alt, ac.ctypes.data, len(alt_chunks) if n_alt else 0, ares.ctypes.data, need.ctypes.data,
+                     sel.ctypes.data if sel is not None and len(sel) else None, selres.ctypes.data if sel is not None and len(sel) else None)
         self._check(self._lib.tredgpu_inflate_walk(self._h, n_blocks, status.ctypes.data, sums.ctypes.data, C.byref(a)),
                     "tredgpu_inflate_walk")
         out = (status[:n_blocks], sums[:n_blocks], res[:len(tasks)], gp[:a.n_global], tp[:a.n_target])
-        return out if alt_tasks is None else out + (ares[:n_alt], need[:n_blocks])
+        if alt_tasks is not None:
+            out = out + (ares[:n_alt], need[:n_blocks])
+        return out if select is None else out + (selres[:len(tasks)],)
 
     def fetch(self, need):
         """tredgpu_inflater_fetch: the blocks with need[k] != 0 of the last run_walk, to their places in ``out``."""

@@ -63,7 +63,7 @@ class SampleScan(object):
     """
     __slots__ = ("path", "names", "loci", "readlen", "gender", "ydepth", "unit", "depth", "ploidy", "dropped",
                  "packed", "word_off", "read_len", "seq4", "seq4_off", "name_blob", "name_off", "name_id",
-                 "global_lens", "target_lens", "opened", "_text")
+                 "global_lens", "target_lens", "opened", "_text", "device")
 
     def reads_of(self, k):
         u = self.unit[k]

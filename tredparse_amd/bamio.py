@@ -374,6 +374,8 @@ def _native():
             lib.tredbam_plan_walks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(ScanOpts), C.c_void_p, C.c_void_p,
                                                C.c_int64]
             lib.tredbam_plan_walks.restype = C.c_int64
+            lib.tredbam_plan_region_walks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+            lib.tredbam_plan_region_walks.restype = C.c_int64
             lib.tredbam_plan_blocks.argtypes = [C.c_void_p] * 5
             lib.tredbam_plan_blocks.restype = C.c_int64
             lib.tredbam_scan_pe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ScanOpts), C.c_void_p,
@@ -877,6 +879,24 @@ class NativeAlignmentFile(object):
             if n < 0:
                 raise ValueError(self._err())
             return tasks[:n_alts], chunks[:n]
+
+    def plan_region_walks(self, regions):
+        """tredbam_plan_region_walks (after plan() with the regions among its `extra`): (tasks WALK_TASK_DTYPE, chunks) of plain
+        region walks -- regions: [(contig, start, end)]; a task's window is its region and it forms no pairs (span 0)."""
+        rg = np.zeros(max(len(regions), 1), REGION_DTYPE)
+        for k, (contig, lo, hi) in enumerate(regions):
+            rg[k] = (self._tid.get(contig, -1), lo, hi)
+        tasks = np.zeros(max(len(regions), 1), WALK_TASK_DTYPE)
+        cap = 8 * len(regions) + 16
+        while True:
+            chunks = np.zeros(cap, WALK_CHUNK_DTYPE)
+            n = self._lib.tredbam_plan_region_walks(self._h, rg.ctypes.data, len(regions), tasks.ctypes.data, chunks.ctypes.data, cap)
+            if n == -3:
+                cap *= 4
+                continue
+            if n < 0:
+                raise ValueError(self._err())
+            return tasks[:len(regions)], chunks[:n]
 
     def plan_blocks(self):
         """tredbam_plan_blocks: (compressed offset, compressed length, trailer CRC-32, read-by-the-scan-itself flag) of

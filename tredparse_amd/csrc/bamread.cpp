@@ -1311,6 +1311,43 @@ int64_t tredbam_plan_walks(tredbam* b, const tredbam_site* sites, int32_t n_site
     return nc;
 }
 
+// Plain regions as tasks for the same walker: task k = the records overlapping regions[k] = [start, end) of contig tid, its
+// window the region itself, span 0 (the pair walk leaves it alone) -- the chrY windows of the sex inference (BamDepth.
+// get_Y_depth, bam_parser.py:413-429), whose pile-up sums the device's read selection returns with the loci's.  Call after
+// tredbam_plan with the regions among its `extra`.  n_chunks < 0: not walkable (the contig is not in the file, no index).
+int64_t tredbam_plan_region_walks(tredbam* b, const tredbam_region* regions, int32_t n_regions, tredbam_walk_task* tasks,
+                                  tredbam_walk_chunk* chunks, int64_t cap_chunks) {
+    if (!b || n_regions < 0 || (n_regions > 0 && (!regions || !tasks)) || cap_chunks < 0 || (cap_chunks > 0 && !chunks)) return -2;
+    std::unordered_map<int64_t, int32_t> index_of;
+    index_of.reserve(b->plan.size() * 2);
+    for (size_t k = 0; k < b->plan.size(); ++k) index_of[b->plan[k].coffset] = (int32_t)k;
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    int64_t nc = 0;
+    for (int32_t i = 0; i < n_regions; ++i) {
+        const tredbam_region& rg = regions[i];
+        tredbam_walk_task& t = tasks[i];
+        memset(&t, 0, sizeof t);
+        t.tid = rg.tid;
+        t.chunk_first = (int32_t)nc;
+        t.n_chunks = -1;
+        t.block_end = (int32_t)b->plan.size();
+        int64_t start = rg.start, end = rg.end;
+        if (rg.tid < 0 || region_chunks(b, rg.tid, start, end, merged) != 0 || end > INT32_MAX) continue;
+        if ((int64_t)merged.size() > cap_chunks - nc) return -3;
+        t.start = t.win_lo = (int32_t)start;
+        t.end = t.win_hi = (int32_t)end;
+        for (const auto& ch : merged) {
+            tredbam_walk_chunk& c = chunks[nc++];
+            const auto at = index_of.find((int64_t)(ch.first >> 16));
+            c.begin_block = at == index_of.end() ? -1 : at->second;
+            c.begin_upos = (int32_t)(ch.first & 0xFFFF);
+            c.end_voffset = ch.second;
+        }
+        t.n_chunks = (int32_t)merged.size();
+    }
+    return nc;
+}
+
 // Per planned block, in the plan's (file) order: where it starts in the file, how long it is there, the CRC-32 its
 // trailer promises, and whether the scan reads it in any case (alternative loci, extra regions) when the pair lengths
 // and the windows' offsets come from elsewhere (tredbam_scan_pe).

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "tredgpu_internal.h"
+#include "inflater_internal.h"
 
 using namespace tredgpu;
 
@@ -40,7 +41,7 @@ struct tredgpu_ctx {
     Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class, ws_gdesc, ws_gtile, ws_gctr, ws_ucnt, ws_bins, ws_kde;
     int* h_pin = nullptr;  // pinned word for small read-backs
     size_t grid_pool_bytes = GRID_POOL_BYTES;   // TREDGPU_GRID_POOL_MB overrides (tuning / tests of the multi-pass path)
-    Buf st[32];  // staging for HOST-memory calls
+    Buf st[40];  // staging for HOST-memory calls
     // pinned arena of the HOST-memory calls: copies from / to the caller's pageable arrays go through it, so that they are
     // truly asynchronous (a hipMemcpyAsync on pageable memory is staged and waited for by the runtime, one by one -- with
     // several driver processes on the device each of those waits queues behind the others' work: 25 per batch)
@@ -986,6 +987,135 @@ int tredgpu_genotype_batch_joint(tredgpu_ctx* c, const uint32_t* packed, const i
     if ((rc = copy_back(c, joint_total, (const double*)d_jt, (size_t)n_units))) return rc;
     if ((rc = copy_back(c, calls, (const tredgpu_call*)d_calls, (size_t)n_units))) return rc;
     if ((rc = copy_back(c, marg, (const double*)d_marg, marg_n))) return rc;
+    HIPCHK(c, stream_sync(c));
+    return 0;
+}
+
+// tredgpu_genotype_batch_joint over reads that never left the device (include/tredgpu.h section 5): the units are tasks of
+// inflaters' selections; pack_selected_kernel writes them into this context's buffers in the layout the SW kernel reads, and
+// the selected reads' lengths, 4-bit sequences and names come back with the results -- one wait for all of it.
+int tredgpu_genotype_selected(tredgpu_ctx* c, const tredgpu_selected_units* segs, int32_t n_segs, const int32_t* unit_read_off,
+                              const int64_t* unit_word_off, const int64_t* unit_seq4_off, const int64_t* unit_name_off,
+                              const int32_t* unit_ladder, const tredgpu_unit_params* units, int32_t n_units,
+                              const tredgpu_sw_params* params, const int32_t* global_lens, int64_t n_global_total,
+                              const int32_t* target_lens, int64_t n_target_total, uint8_t* out_tag, int16_t* out_h,
+                              int16_t* out_score, int32_t hist_stride, int32_t* rept_cnt, tredgpu_call* calls, double* marg,
+                              int32_t marg_stride, const int64_t* joint_off, double* joint, int32_t* joint_n, double* joint_total,
+                              int32_t* read_len, int64_t* seq4_off, uint8_t* seq4, int64_t* name_off, char* names) {
+    if (!c) return -2;
+    int rc;
+    if ((rc = check_sw_params(c, params))) return rc;
+    if ((rc = check_grid_common(c, units, n_units))) return rc;
+    if (c->h_ladders.empty()) return fail(c, -4, "no ladders registered (tredgpu_set_ladders)");
+    if (n_units <= 0 || n_segs <= 0 || !segs) return fail(c, -2, "bad sizes");
+    if (!unit_read_off || !unit_word_off || !unit_seq4_off || !unit_name_off || !unit_ladder || !calls || !marg || !joint_off || !joint || !joint_n ||
+        !joint_total || marg_stride <= 0)
+        return fail(c, -2, "NULL array argument");
+    if (params->max_read_len <= 0 || params->max_read_len > TREDGPU_MAX_READ_LEN) return fail(c, -2, "params.max_read_len must name the longest selected read");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n_reads = unit_read_off[n_units];
+    if (unit_read_off[0] != 0 || unit_word_off[0] != 0 || unit_seq4_off[0] != 0 || unit_name_off[0] != 0 || n_reads < 0) return fail(c, -2, "unit offsets must start at 0");
+    if (n_reads > 0 && (!out_tag || !out_h || !out_score || !read_len || !seq4_off || !seq4 || !name_off || !names)) return fail(c, -2, "NULL array argument");
+    // the units against the inflaters' own records of what they selected
+    std::vector<int32_t> unit_task((size_t)n_units);
+    std::vector<tredgpu_front::SelectedView> views((size_t)n_segs);
+    int limits[2] = {0, 0};
+    int g = 0;
+    for (int32_t sgi = 0; sgi < n_segs; ++sgi) {
+        const tredgpu_selected_units& sg = segs[sgi];
+        if (!sg.inf || sg.n_units < 0 || (sg.n_units > 0 && !sg.task) || g + sg.n_units > n_units) return fail(c, -2, "segment %d: bad unit list", (int)sgi);
+        if (tredgpu_front::inflater_selected(sg.inf, &views[sgi]) != 0) return fail(c, -2, "segment %d: the inflater's last call carried no read selection", (int)sgi);
+        if (views[sgi].device != c->device) return fail(c, -2, "segment %d: the inflater lives on another device", (int)sgi);
+        for (int32_t k = 0; k < sg.n_units; ++k, ++g) {
+            const int32_t t = sg.task[k];
+            if (t < 0 || t >= views[sgi].n_tasks) return fail(c, -2, "unit %d: task %d is none of the inflater's", g, (int)t);
+            const tredgpu_select_result& R = views[sgi].results[t];
+            if (R.status != 0) return fail(c, -2, "unit %d: its selection was declined (status %d)", g, (int)R.status);
+            if (unit_read_off[g + 1] - unit_read_off[g] != R.n_reads || unit_word_off[g + 1] - unit_word_off[g] != R.n_words ||
+                unit_seq4_off[g + 1] - unit_seq4_off[g] != R.seq4_bytes || unit_name_off[g + 1] - unit_name_off[g] != R.name_bytes)
+                return fail(c, -2, "unit %d: offsets do not match what was selected", g);
+            if (R.max_len > params->max_read_len) return fail(c, -5, "unit %d: a read of %d bp exceeds params.max_read_len", g, (int)R.max_len);
+            unit_task[(size_t)g] = t;
+        }
+    }
+    if (g != n_units) return fail(c, -2, "the segments hold %d units, the batch %d", g, (int)n_units);
+    for (int u = 0; u < n_units; ++u) {
+        if (unit_ladder[u] < 0 || unit_ladder[u] >= (int)c->h_ladders.size()) return fail(c, -2, "unit %d: ladder %d not registered", u, unit_ladder[u]);
+        if (hist_stride <= c->h_ladders[unit_ladder[u]].max_units)
+            return fail(c, -2, "hist_stride %d must exceed the max_units %d of unit %d's ladder", hist_stride, c->h_ladders[unit_ladder[u]].max_units, u);
+        const tredgpu_unit_params& up = units[u];
+        limits[0] = std::max(limits[0], up.maxinsert);
+        limits[1] = std::max(limits[1], up.n_target);
+        if (up.n_global < 0 || up.n_target < 0 || up.pe_off < 0 || up.tl_off < 0 || (int64_t)up.pe_off + up.n_global > n_global_total ||
+            (int64_t)up.tl_off + up.n_target > n_target_total)
+            return fail(c, -2, "unit %d: paired-end slices out of range", u);
+        if (marg_stride <= std::max(up.maxinsert, hist_stride)) return fail(c, -2, "marg_stride must exceed max(maxinsert, hist_stride)");
+    }
+    const int max_len = params->max_read_len;
+    const size_t words = (size_t)unit_word_off[n_units], s4_bytes = (size_t)unit_seq4_off[n_units], nm_bytes = (size_t)unit_name_off[n_units];
+    const size_t hn = (size_t)n_units * hist_stride, marg_n = (size_t)n_units * 2 * marg_stride, joint_len = (size_t)joint_off[n_units] * 3;
+    uint32_t* d_packed; int64_t* d_off; int32_t* d_len; uint8_t* d_seq4; int64_t* d_s4off; uint8_t* d_names; int64_t* d_nmoff;
+    const int32_t *d_uoff, *d_ulad, *d_task, *d_gl = nullptr, *d_tl = nullptr;
+    const int64_t *d_uw, *d_us, *d_un, *d_joff;
+    const tredgpu_unit_params* d_units;
+    uint8_t* d_tag; int16_t *d_h, *d_score; int32_t *d_f, *d_p, *d_r; tredgpu_call* d_calls; double *d_marg, *d_joint, *d_jt; int32_t* d_jn;
+    if ((rc = stage_out(c, c->st[0], words, &d_packed))) return rc;
+    if ((rc = stage_out(c, c->st[1], (size_t)n_reads + 1, &d_off))) return rc;
+    if ((rc = stage_out(c, c->st[2], (size_t)n_reads, &d_len))) return rc;
+    if ((rc = stage_in(c, c->st[3], unit_read_off, (size_t)n_units + 1, &d_uoff))) return rc;
+    if ((rc = stage_in(c, c->st[4], unit_ladder, (size_t)n_units, &d_ulad))) return rc;
+    if ((rc = stage_out(c, c->st[5], (size_t)n_reads, &d_tag))) return rc;
+    if ((rc = stage_out(c, c->st[6], (size_t)n_reads, &d_h))) return rc;
+    if ((rc = stage_out(c, c->st[7], (size_t)n_reads, &d_score))) return rc;
+    if ((rc = stage_out(c, c->st[14], hn, &d_f))) return rc;
+    if ((rc = stage_out(c, c->st[15], hn, &d_p))) return rc;
+    if ((rc = stage_out(c, c->st[16], hn, &d_r))) return rc;
+    if ((rc = stage_in(c, c->st[17], units, (size_t)n_units, &d_units))) return rc;
+    if ((rc = stage_in(c, c->st[18], global_lens, (size_t)n_global_total, &d_gl))) return rc;
+    if ((rc = stage_in(c, c->st[19], target_lens, (size_t)n_target_total, &d_tl))) return rc;
+    if ((rc = stage_out(c, c->st[20], (size_t)n_units, &d_calls))) return rc;
+    if ((rc = stage_out(c, c->st[21], marg_n, &d_marg))) return rc;
+    if ((rc = stage_in(c, c->st[22], joint_off, (size_t)n_units + 1, &d_joff))) return rc;
+    if ((rc = stage_out(c, c->st[23], joint_len, &d_joint))) return rc;
+    if ((rc = stage_out(c, c->st[24], (size_t)n_units, &d_jn))) return rc;
+    if ((rc = stage_out(c, c->st[25], (size_t)n_units, &d_jt))) return rc;
+    if ((rc = stage_in(c, c->st[26], (const int32_t*)unit_task.data(), (size_t)n_units, &d_task))) return rc;
+    if ((rc = stage_in(c, c->st[27], unit_word_off, (size_t)n_units + 1, &d_uw))) return rc;
+    if ((rc = stage_in(c, c->st[28], unit_seq4_off, (size_t)n_units + 1, &d_us))) return rc;
+    if ((rc = stage_in(c, c->st[29], unit_name_off, (size_t)n_units + 1, &d_un))) return rc;
+    if ((rc = stage_out(c, c->st[30], s4_bytes, &d_seq4))) return rc;
+    if ((rc = stage_out(c, c->st[31], (size_t)n_reads + 1, &d_s4off))) return rc;
+    if ((rc = stage_out(c, c->st[32], nm_bytes, &d_names))) return rc;
+    if ((rc = stage_out(c, c->st[33], (size_t)n_reads + 1, &d_nmoff))) return rc;
+    g = 0;
+    for (int32_t sgi = 0; sgi < n_segs; ++sgi) {
+        HIPCHK(c, tredgpu_front::launch_pack_selected(views[sgi].out, views[sgi].sel_list, d_task, d_uoff, d_uw, d_us, d_un, g, segs[sgi].n_units, d_packed,
+                                                      d_off, d_len, d_seq4, d_s4off, d_names, d_nmoff, c->stream));
+        g += segs[sgi].n_units;
+    }
+    if (n_reads > 0 && (rc = run_sw_device(c, d_packed, d_off, d_len, n_reads, d_uoff, d_ulad, n_units, params, max_len, d_tag, d_h, d_score, nullptr, 0)))
+        return rc;
+    {
+        ScopedTimer tm(c, TREDGPU_KERNEL_TALLY);
+        HIPCHK(c, launch_tally(d_tag, d_h, n_reads, d_uoff, n_units, nullptr, hist_stride, d_f, d_p, d_r, (uint8_t*)c->ws_drop.p, c->stream));
+    }
+    if ((rc = run_grid_device(c, d_units, n_units, hist_stride, d_f, d_p, d_r, d_gl, d_tl, d_calls, nullptr, nullptr, d_marg, marg_stride, limits, d_joff,
+                              d_joint, d_jn, d_jt)))
+        return rc;
+    if ((rc = copy_back(c, out_tag, (const uint8_t*)d_tag, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, out_h, (const int16_t*)d_h, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, out_score, (const int16_t*)d_score, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, rept_cnt, (const int32_t*)d_r, rept_cnt ? hn : 0))) return rc;
+    if ((rc = copy_back(c, joint, (const double*)d_joint, joint_len))) return rc;
+    if ((rc = copy_back(c, joint_n, (const int32_t*)d_jn, (size_t)n_units))) return rc;
+    if ((rc = copy_back(c, joint_total, (const double*)d_jt, (size_t)n_units))) return rc;
+    if ((rc = copy_back(c, calls, (const tredgpu_call*)d_calls, (size_t)n_units))) return rc;
+    if ((rc = copy_back(c, marg, (const double*)d_marg, marg_n))) return rc;
+    if ((rc = copy_back(c, read_len, (const int32_t*)d_len, (size_t)n_reads))) return rc;
+    if ((rc = copy_back(c, seq4_off, (const int64_t*)d_s4off, n_reads > 0 ? (size_t)n_reads + 1 : 0))) return rc;
+    if ((rc = copy_back(c, seq4, (const uint8_t*)d_seq4, s4_bytes))) return rc;
+    if ((rc = copy_back(c, name_off, (const int64_t*)d_nmoff, n_reads > 0 ? (size_t)n_reads + 1 : 0))) return rc;
+    if ((rc = copy_back(c, (uint8_t*)names, (const uint8_t*)d_names, nm_bytes))) return rc;
     HIPCHK(c, stream_sync(c));
     return 0;
 }

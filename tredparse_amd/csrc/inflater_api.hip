@@ -56,6 +56,11 @@ struct tredgpu_inflater {
     WalkChained* d_wchained = nullptr; size_t cap_wchained = 0;
     uint8_t* d_atask = nullptr; uint8_t* h_atask = nullptr; size_t cap_atask = 0;   // the alternative loci's tasks then chunks
     uint8_t* d_ares = nullptr;  uint8_t* h_ares = nullptr;  size_t cap_ares = 0;    // their results, then the blocks' need flags
+    // the read selection (tredgpu.h section 5): per task its parameters and result, and TREDGPU_SELECT_CAP record places
+    uint8_t* d_sel = nullptr; uint8_t* h_sel = nullptr; size_t cap_sel = 0;        // tasks' tredgpu_select_task, then their results
+    int64_t* d_sel_list = nullptr; size_t cap_sel_list = 0;                        // in tasks
+    int sel_tasks = 0;                                                             // tasks of the last walk with a selection (0: none)
+    hipEvent_t aready = nullptr;                                                   // the alternative loci's walk has run (the selection reads its hits)
     int32_t *d_gpool = nullptr, *d_tpool = nullptr, *h_gpool = nullptr, *h_tpool = nullptr;
     size_t cap_gpool = 0, cap_tpool = 0;          // (device pools: the call's bound)
     size_t cap_hgpool = 0, cap_htpool = 0;        // (pinned host pools: what the walks really produced, an eighth more)
@@ -106,8 +111,11 @@ void release(tredgpu_inflater* f) {
 }
 
 void release_walk(tredgpu_inflater* f) {
-    for (void* p : {(void*)f->h_wblk, (void*)f->h_wtask, (void*)f->h_wres, (void*)f->h_gpool, (void*)f->h_tpool, (void*)f->h_atask, (void*)f->h_ares})
+    for (void* p : {(void*)f->h_wblk, (void*)f->h_wtask, (void*)f->h_wres, (void*)f->h_gpool, (void*)f->h_tpool, (void*)f->h_atask, (void*)f->h_ares, (void*)f->h_sel})
         if (p) (void)hipHostFree(p);
+    for (void* p : {(void*)f->d_sel, (void*)f->d_sel_list})
+        if (p) (void)hipFree(p);
+    f->h_sel = f->d_sel = nullptr; f->d_sel_list = nullptr; f->cap_sel = f->cap_sel_list = 0; f->sel_tasks = 0;
     for (void* p : {(void*)f->d_wblk, (void*)f->d_wtask, (void*)f->d_wres, (void*)f->d_wpairs, (void*)f->d_gpool, (void*)f->d_tpool, (void*)f->d_atask, (void*)f->d_ares,
                     (void*)f->d_wrecs, (void*)f->d_wfields, (void*)f->d_wchained})
         if (p) (void)hipFree(p);
@@ -139,6 +147,7 @@ void destroy_handles(tredgpu_inflater* f) {
     if (f->wstream) (void)hipStreamDestroy(f->wstream);
     if (f->astream) (void)hipStreamDestroy(f->astream);
     if (f->adone) (void)hipEventDestroy(f->adone);
+    if (f->aready) (void)hipEventDestroy(f->aready);
 }
 }  // namespace
 
@@ -171,6 +180,7 @@ int tredgpu_inflater_create(int device_id, tredgpu_inflater** out) {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&f->wstream, hipStreamNonBlocking, lo_prio);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&f->astream, hipStreamNonBlocking, lo_prio);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->adone, hipEventBlockingSync | hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->aready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->wdone, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&f->w0);
     if (e == hipSuccess) e = hipEventCreate(&f->w1);
@@ -295,6 +305,23 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         }
         for (size_t q = 0; q < n_alt_chunks; ++q)
             if (w->alt_chunks[q].begin_upos < 0 || w->alt_chunks[q].begin_upos > 65536) return ifail(f, -2, "walk chunk starts outside a block");
+        if ((w->select != nullptr) != (w->selected != nullptr)) return ifail(f, -2, "select and selected go together");
+        if (w->select) {
+            for (size_t t = 0; t < n_tasks; ++t) {
+                const tredgpu_select_task& S = w->select[t];
+                if (S.n_alt > 0 && (S.alt_first < 0 || (size_t)S.alt_first + (size_t)S.n_alt > n_alt)) return ifail(f, -2, "select task outside the alternative loci's tasks");
+            }
+            if (grow_pair(f, &f->h_sel, &f->d_sel, &f->cap_sel, n_tasks * (sizeof(tredgpu_select_task) + sizeof(tredgpu_select_result)) + 64)) return -10;
+            if (n_tasks > f->cap_sel_list) {
+                const size_t c = std::max(n_tasks, f->cap_sel_list + f->cap_sel_list / 2);
+                if (f->d_sel_list) (void)hipFree(f->d_sel_list);
+                f->d_sel_list = nullptr; f->cap_sel_list = 0;
+                ICHK(f, hipMalloc((void**)&f->d_sel_list, c * TREDGPU_SELECT_CAP * sizeof(int64_t)));
+                f->cap_sel_list = c;
+            }
+            memcpy(f->h_sel, w->select, n_tasks * sizeof(tredgpu_select_task));
+        }
+        f->sel_tasks = 0;
         const size_t nb = (size_t)n_blocks;
         if (n_alt > 0) {
             if (grow_pair(f, &f->h_atask, &f->d_atask, &f->cap_atask, n_alt * sizeof(tredgpu_walk_task) + n_alt_chunks * sizeof(tredgpu_walk_chunk) + 64)) return -10;
@@ -373,6 +400,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         ICHK(f, hipMemcpyAsync(f->d_wblk, f->h_wblk, nb * 16, hipMemcpyHostToDevice, f->wstream));
         ICHK(f, hipMemcpyAsync(f->d_wtask, f->h_wtask, rb_at + (n_tasks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, f->wstream));
         ICHK(f, hipMemsetAsync(f->d_wres + n_tasks * sizeof(tredgpu_walk_result), 0, 16, f->wstream));
+        if (w->select && n_tasks > 0) ICHK(f, hipMemcpyAsync(f->d_sel, f->h_sel, n_tasks * sizeof(tredgpu_select_task), hipMemcpyHostToDevice, f->wstream));
     }
     tr.mark("walk_inputs");
     // the two streams never wait for each other: each copies the offsets in for itself (both write the same values)
@@ -396,6 +424,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
     f->last_slices = slices;
     f->last_streams = nstreams;
     f->walk_timed = false;
+    if (!w) f->sel_tasks = 0;                      // (the output a selection pointed into is being overwritten)
     if (w) {
         // the walk reads every slice's blocks: its stream waits for the last launch of both decode streams
         for (int s = 0; s < nstreams; ++s) {
@@ -443,7 +472,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
                                      f->d_gpool, w->cap_global, f->d_tpool, w->cap_target,
                                      (unsigned long long*)(f->d_wres + n_tasks * sizeof(tredgpu_walk_result)), table_cap, (int)n_tasks, f->wstream));
         }
-        ICHK(f, hipEventRecord(f->w1, f->wstream));
+        if (!(w->select && n_tasks > 0)) ICHK(f, hipEventRecord(f->w1, f->wstream));
         f->walk_timed = true;
         ICHK(f, hipMemcpyAsync(f->h_wres, f->d_wres, n_tasks * sizeof(tredgpu_walk_result) + 16, hipMemcpyDeviceToHost, f->wstream));
         // the alternative loci's walks on a stream of their own, beside the pair walks: 480 pair-walk wavefronts leave half
@@ -453,9 +482,21 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
             ICHK(f, hipStreamWaitEvent(f->astream, f->w0, 0));
             ICHK(f, launch_alt_walk(v, (const tredgpu_walk_task*)f->d_atask, (const tredgpu_walk_chunk*)(f->d_atask + n_alt * sizeof(tredgpu_walk_task)),
                                     (tredgpu_alt_result*)f->d_ares, f->d_ares + n_alt * sizeof(tredgpu_alt_result), (int)n_alt, f->astream));
+            ICHK(f, hipEventRecord(f->aready, f->astream));
             ICHK(f, hipMemcpyAsync(f->h_ares, f->d_ares, n_alt * sizeof(tredgpu_alt_result) + nb, hipMemcpyDeviceToHost, f->astream));
         }
         ICHK(f, hipEventRecord(f->adone, f->astream));
+        if (w->select && n_tasks > 0) {
+            // the selection reads the pair walk's record lists (this stream) and the alternative loci's hits (the other one)
+            if (n_alt > 0) ICHK(f, hipStreamWaitEvent(f->wstream, f->aready, 0));
+            tredgpu_select_result* d_selres = (tredgpu_select_result*)(f->d_sel + n_tasks * sizeof(tredgpu_select_task));
+            ICHK(f, launch_select(v, (const tredgpu_walk_task*)f->d_wtask, (const tredgpu_select_task*)f->d_sel,
+                                  (const int64_t*)(f->d_wtask + n_tasks * sizeof(tredgpu_walk_task) + n_chunks * sizeof(tredgpu_walk_chunk)), f->d_wrecs,
+                                  f->d_wfields, f->d_wchained, (const tredgpu_walk_result*)f->d_wres, (const tredgpu_walk_task*)f->d_atask,
+                                  (const tredgpu_alt_result*)f->d_ares, (int)n_alt, f->d_sel_list, d_selres, (int)n_tasks, f->wstream));
+            ICHK(f, hipEventRecord(f->w1, f->wstream));
+            ICHK(f, hipMemcpyAsync(f->h_sel + n_tasks * sizeof(tredgpu_select_task), d_selres, n_tasks * sizeof(tredgpu_select_result), hipMemcpyDeviceToHost, f->wstream));
+        }
         ICHK(f, hipEventRecord(f->wdone, f->wstream));
     }
     for (int s = 0; s < nstreams; ++s) {
@@ -477,6 +518,10 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         unsigned long long used[2];
         memcpy(used, f->h_wres + n_tasks * sizeof(tredgpu_walk_result), 16);
         memcpy(w->results, f->h_wres, n_tasks * sizeof(tredgpu_walk_result));
+        if (w->select && n_tasks > 0) {
+            memcpy(w->selected, f->h_sel + n_tasks * sizeof(tredgpu_select_task), n_tasks * sizeof(tredgpu_select_result));
+            f->sel_tasks = (int)n_tasks;
+        }
         if (n_alt > 0) {
             memcpy(w->alt_results, f->h_ares, n_alt * sizeof(tredgpu_alt_result));
             memcpy(w->need, f->h_ares + n_alt * sizeof(tredgpu_alt_result), (size_t)n_blocks);
@@ -656,7 +701,8 @@ int tredgpu_inflater_fetch_dense(tredgpu_inflater* f, int32_t n_blocks, const ui
 int64_t tredgpu_inflater_pinned_bytes(const tredgpu_inflater* f) {
     if (!f) return -2;
     size_t n = f->cap_comp + (f->h_out ? f->cap_out : 0) + f->cap_blocks * (2 * sizeof(int64_t) + 2 * sizeof(int32_t)) + f->cap_dense +
-               f->cap_pieces * sizeof(FetchPiece) + f->cap_wblk + f->cap_wtask + f->cap_wres + f->cap_hgpool + f->cap_htpool + f->cap_atask + f->cap_ares;
+               f->cap_pieces * sizeof(FetchPiece) + f->cap_wblk + f->cap_wtask + f->cap_wres + f->cap_hgpool + f->cap_htpool + f->cap_atask + f->cap_ares +
+               f->cap_sel;
     return (int64_t)n;
 }
 
@@ -686,3 +732,16 @@ int tredgpu_inflater_walk_ms(tredgpu_inflater* f, double* walk_ms) {
 }
 
 }  // extern "C"
+
+// what tredgpu_genotype_selected (capi.hip) reads of an inflater: the decoder's output, the selected records' places and the
+// host copy of the select results of its last walk
+int tredgpu_front::inflater_selected(tredgpu_inflater* f, SelectedView* view) {
+    if (!f || !view) return -2;
+    if (f->sel_tasks <= 0 || !f->d_sel_list || !f->d_out) return ifail(f, -2, "the inflater's last call carried no read selection");
+    view->device = f->device;
+    view->out = f->d_out;
+    view->sel_list = f->d_sel_list;
+    view->n_tasks = f->sel_tasks;
+    view->results = (const tredgpu_select_result*)(f->h_sel + (size_t)f->sel_tasks * sizeof(tredgpu_select_task));
+    return 0;
+}

@@ -72,6 +72,20 @@ hipError_t launch_pair_walk(const WalkView& v, const tredgpu_walk_task* tasks, c
 hipError_t launch_alt_walk(const WalkView& v, const tredgpu_walk_task* tasks, const tredgpu_walk_chunk* chunks, tredgpu_alt_result* results,
                            uint8_t* need, int n_tasks, hipStream_t st);
 hipError_t launch_fetch_gather(const uint8_t* out, uint8_t* host, const FetchPiece* pieces, size_t n_pieces, hipStream_t st);
+// the read selection over the record lists of the pair walk (tredgpu.h section 5); sel_list: TREDGPU_SELECT_CAP places per task
+hipError_t launch_select(const WalkView& v, const tredgpu_walk_task* tasks, const tredgpu_select_task* sel, const int64_t* rec_base,
+                         const WalkRec* recs, const WalkFields* fields, const WalkChained* chained, const tredgpu_walk_result* results,
+                         const tredgpu_walk_task* alt_tasks, const tredgpu_alt_result* alt_results, int n_alt_tasks, int64_t* sel_list,
+                         tredgpu_select_result* out, int n_tasks, hipStream_t st);
+// units [u0, u0 + n_units) of a batch (unit_* arrays indexed by batch unit) from one inflater's selection into the batch's arrays
+hipError_t launch_pack_selected(const uint8_t* out, const int64_t* sel_list, const int32_t* unit_task, const int32_t* unit_read_off,
+                                const int64_t* unit_word_off, const int64_t* unit_seq4_off, const int64_t* unit_name_off, int u0, int n_units,
+                                uint32_t* packed, int64_t* read_off, int32_t* read_len, uint8_t* seq4, int64_t* seq4_off, uint8_t* names,
+                                int64_t* name_off, hipStream_t st);
+
+// inflater_api.hip: what tredgpu_genotype_selected (capi.hip) reads of an inflater whose last walk carried a selection
+struct SelectedView { int device; const uint8_t* out; const int64_t* sel_list; int n_tasks; const tredgpu_select_result* results; };
+int inflater_selected(tredgpu_inflater* inf, SelectedView* view);    // 0, or -2 when the last call had no selection
 
 }  // namespace tredgpu_front
 #endif

@@ -528,7 +528,8 @@ constexpr int REC_BITS = 19;
 __device__ inline bool walk_todo(const tredgpu_walk_task& T, const WalkFields& F, bool mine) {
     const bool off_region = F.rtid != T.tid || F.rpos >= T.end;             // (rtid < T.tid: the chain ends at the others)
     const int64_t e = (F.rend < 0 || F.rend <= F.rpos) ? (int64_t)F.rpos + 1 : (int64_t)F.rend;
-    return mine && !off_region && e > T.start && (F.flag & 0x1) && !(F.flag & 0x4) && !(F.flag & 0x400);
+    // (T.span <= 0: a plain region whose records are only counted -- tredgpu_select_task with n_alt < 0 --, no pairs)
+    return mine && T.span > 0 && !off_region && e > T.start && (F.flag & 0x1) && !(F.flag & 0x4) && !(F.flag & 0x400);
 }
 // the slot of a name that is in the table
 __device__ inline uint32_t walk_slot_of(const lds_u64* tab, uint32_t mask, uint32_t h, uint64_t* cur) {
@@ -971,6 +972,193 @@ __global__ void __launch_bounds__(256) fetch_gather_kernel(const uint8_t* __rest
     if (tail < P.len) d[tail] = s[tail];
 }
 
+// ---- read selection, depth and packing where the records are (include/tredgpu.h section 5) -----------------------------------
+// BamParser.parse's selection and BamDepth's pile-up sum as bamread.cpp's scan_impl restates them (tredparse/bam_parser.py:
+// 199-243, 404-411), over the record list the chain and parse kernels made for the pair walk: one wavefront per locus goes
+// through the region's parsed fields 64 records at a time -- a ballot and a prefix popcount keep the file's order --, then
+// appends the alternative regions' hits (their virtual offsets, turned back into places of `out`), region by region as the
+// host does.  What comes out per locus: where each selected record lies, how many there are and what room they take, the
+// depth sum.  Anything the pair walk or an alternative region's walk declined is declined here too (the status is passed on:
+// the host then scans that sample itself).
+constexpr int SEL_CAP = TREDGPU_SELECT_CAP;
+enum { SEL_FULL = 8, SEL_LONG_READ = 9 };
+
+__device__ inline long long wave_sum64(long long x) {
+    for (int d = 32; d >= 1; d >>= 1) x += (long long)__shfl_xor((unsigned long long)x, d, LANES);
+    return x;
+}
+__device__ inline int wave_sum32(int x) {
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, LANES);
+    return x;
+}
+__device__ inline int wave_max32(int x) {
+    for (int d = 32; d >= 1; d >>= 1) x = max(x, __shfl_xor(x, d, LANES));
+    return x;
+}
+
+__global__ void __launch_bounds__(LANES) select_kernel(WalkView v, const tredgpu_walk_task* tasks, const tredgpu_select_task* sel,
+                                                       const int64_t* rec_base, const WalkRec* recs_all, const WalkFields* fields_all,
+                                                       const WalkChained* chained, const tredgpu_walk_result* results,
+                                                       const tredgpu_walk_task* alt_tasks, const tredgpu_alt_result* alt_results, int n_alt_tasks,
+                                                       int64_t* sel_list, tredgpu_select_result* out) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const tredgpu_walk_task T = tasks[t];
+    const tredgpu_select_task S = sel[t];
+    const WalkChained C = chained[t];
+    const uint8_t* o = v.out;
+    int64_t* list = sel_list + (size_t)t * SEL_CAP;
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    int status = results[t].status;
+    int cnt = 0;
+    long long depth = 0;                               // (per-lane partial sums: added up at the end)
+    int words = 0, s4 = 0, nmb = 0, maxlen = 0;
+    auto take = [&](int64_t a0, int idx) {
+        const int64_t r = a0 + 4;
+        const int l_name = (int)g_u8(o, r + 8), L = (int)g_u32(o, r + 16);
+        if (idx < SEL_CAP) list[idx] = a0;
+        words += ((L + 15) >> 4) + ((L + 31) >> 5);
+        s4 += (L + 1) >> 1;
+        nmb += max(l_name - 1, 0);
+        maxlen = max(maxlen, L);
+    };
+    if (status == WALK_OK) {
+        const WalkRec* recs = recs_all + rec_base[t];
+        const WalkFields* fields = fields_all + rec_base[t];
+        const int n = C.n;
+        for (int b = 0; b * LANES < n; ++b) {
+            const int r = b * LANES + lane;
+            const bool mine = r < n;
+            WalkFields F = {};
+            if (mine) F = fields[r];
+            const bool off_region = F.rtid != T.tid || F.rpos >= T.end;
+            const int64_t e = (F.rend < 0 || F.rend <= F.rpos) ? (int64_t)F.rpos + 1 : (int64_t)F.rend;
+            const bool inwin = mine && !off_region && e > T.start && F.rpos < T.win_hi && e > T.win_lo;   // the window's query returns it
+            if (inwin && !(F.flag & (0x4 | 0x100 | 0x200 | 0x400)) && F.rend >= 0) depth += (long long)F.rend - F.rpos;
+            const bool pick = inwin && S.n_alt >= 0 && ((F.flag & 0x4) != 0 || (F.rpos >= S.pos_lo && F.rpos <= S.pos_hi));
+            const uint64_t m = __ballot(pick);
+            if (pick) take(recs[r].a0, cnt + __popcll(m & below));
+            cnt += __popcll(m);
+        }
+        // the alternative regions' hits, region by region (scan_impl: pool_walked), every lane one hit
+        for (int k = 0; k < S.n_alt && status == WALK_OK; ++k) {
+            const int q = S.alt_first + k;
+            if (q < 0 || q >= n_alt_tasks) { status = WALK_NOT_PLANNED; break; }
+            const tredgpu_walk_task AT = alt_tasks[q];
+            if (AT.n_chunks < 0) continue;             // (its contig is not in this file)
+            const tredgpu_alt_result AR = alt_results[q];
+            if (AR.status != WALK_OK || AR.n < 0 || AR.n > 6) { status = AR.status != WALK_OK ? AR.status : (int)WALK_POOL_FULL; break; }
+            bool lost = false;
+            if (lane < AR.n) {
+                uint64_t at = 0;
+                for (int m = 0; m < 6; ++m) if (m == lane) at = AR.vbeg[m];
+                const int64_t coff = (int64_t)(at >> 16);
+                int lo = AT.block_first, hi = AT.block_end;          // the block of the sample's that starts at coff
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (v.bcoff[mid] < coff) lo = mid + 1; else hi = mid;
+                }
+                if (lo >= AT.block_end || v.bcoff[lo] != coff) lost = true;
+                else take(v.ooff[lo] + (int64_t)(at & 0xFFFFu), cnt + lane);
+            }
+            if (__ballot(lost) != 0) { status = WALK_NOT_PLANNED; break; }
+            cnt += AR.n;
+        }
+    }
+    depth = wave_sum64(depth);
+    words = wave_sum32(words); s4 = wave_sum32(s4); nmb = wave_sum32(nmb); maxlen = wave_max32(maxlen);
+    if (status == WALK_OK && cnt > SEL_CAP) status = SEL_FULL;
+    if (status == WALK_OK && maxlen > TREDGPU_MAX_READ_LEN) status = SEL_LONG_READ;
+    if (lane == 0) {
+        tredgpu_select_result R = {};
+        R.status = status;
+        if (status == WALK_OK) { R.n_reads = cnt; R.n_words = words; R.seq4_bytes = s4; R.name_bytes = nmb; R.max_len = maxlen; R.depth_sum = depth; }
+        out[t] = R;
+    }
+}
+
+// The selected reads of a unit into libtredgpu's read layout (tredgpu_pack_reads: ceil(L/16) words of 2-bit codes, then
+// ceil(L/32) words of N flags; bamread.cpp pool_read) and, for the writers, their 4-bit sequences and names one after the
+// other.  A workgroup of four wavefronts per unit: first every read's place (a block-wide running sum over the reads' sizes,
+// from the unit's bases the caller summed up from the select results), then a wavefront per read: a lane per output word.
+__global__ void __launch_bounds__(256) pack_selected_kernel(const uint8_t* __restrict__ o, const int64_t* __restrict__ sel_list,
+                                                            const int32_t* __restrict__ unit_task, const int32_t* __restrict__ unit_read_off,
+                                                            const int64_t* __restrict__ unit_word_off, const int64_t* __restrict__ unit_seq4_off,
+                                                            const int64_t* __restrict__ unit_name_off, int u0, uint32_t* packed, int64_t* read_off,
+                                                            int32_t* read_len, uint8_t* seq4, int64_t* seq4_off, uint8_t* names, int64_t* name_off) {
+    __shared__ int wsum[3][4];
+    const int u = u0 + blockIdx.x, tid = threadIdx.x, lane = tid & (LANES - 1), w = tid / LANES;
+    const int64_t* list = sel_list + (size_t)unit_task[u] * SEL_CAP;
+    const int r0 = unit_read_off[u], n = unit_read_off[u + 1] - r0;
+    long long base_w = unit_word_off[u], base_s = unit_seq4_off[u], base_n = unit_name_off[u];
+    for (int c = 0; c < n; c += 256) {
+        const int i = c + tid;
+        int lw = 0, ls = 0, ln = 0, L = 0;
+        if (i < n) {
+            const int64_t r = list[i] + 4;
+            const int l_name = (int)g_u8(o, r + 8);
+            L = (int)g_u32(o, r + 16);
+            lw = ((L + 15) >> 4) + ((L + 31) >> 5);
+            ls = (L + 1) >> 1;
+            ln = max(l_name - 1, 0);
+        }
+        const int iw = wave_incl_scan(lw), is = wave_incl_scan(ls), in = wave_incl_scan(ln);
+        if (lane == LANES - 1) { wsum[0][w] = iw; wsum[1][w] = is; wsum[2][w] = in; }
+        __syncthreads();
+        int pw = 0, ps = 0, pn = 0, tw = 0, ts = 0, tn = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (k < w) { pw += wsum[0][k]; ps += wsum[1][k]; pn += wsum[2][k]; }
+            tw += wsum[0][k]; ts += wsum[1][k]; tn += wsum[2][k];
+        }
+        if (i < n) {
+            read_off[r0 + i] = base_w + pw + iw - lw;
+            read_len[r0 + i] = L;
+            seq4_off[r0 + i] = base_s + ps + is - ls;
+            name_off[r0 + i] = base_n + pn + in - ln;
+        }
+        base_w += tw; base_s += ts; base_n += tn;
+        __syncthreads();
+    }
+    // (the entry behind the unit's last read is the next unit's first -- the same number -- or the arrays' end)
+    if (tid == 0) { read_off[r0 + n] = unit_word_off[u + 1]; seq4_off[r0 + n] = unit_seq4_off[u + 1]; name_off[r0 + n] = unit_name_off[u + 1]; }
+    __syncthreads();
+    for (int i = w; i < n; i += 4) {
+        const int64_t r = list[i] + 4;
+        const int l_name = (int)g_u8(o, r + 8), n_cigar = (int)g_u16(o, r + 12), L = (int)g_u32(o, r + 16);
+        const int64_t seq = r + 32 + l_name + 4 * (int64_t)n_cigar;
+        const int nb = (L + 15) >> 4, nm = (L + 31) >> 5;
+        uint32_t* rec = packed + read_off[r0 + i];
+        // "=ACMGRSVTWYHKDBN": A C G T are the codes 0..3, every other letter is an N (code 4)
+        constexpr unsigned long long CODE = 0x4444444344424104ull;
+        for (int j = lane; j < nb + nm; j += LANES) {
+            uint32_t word = 0;
+            if (j < nb) {
+                for (int q = 0; q < 16; ++q) {
+                    const int b = 16 * j + q;
+                    if (b < L) {
+                        const uint32_t byte = g_u8(o, seq + (b >> 1));
+                        const uint32_t code = (uint32_t)(CODE >> (4 * ((b & 1) ? (byte & 15u) : (byte >> 4)))) & 15u;
+                        if (code < 4) word |= code << (2 * q);
+                    }
+                }
+            } else {
+                for (int q = 0; q < 32; ++q) {
+                    const int b = 32 * (j - nb) + q;
+                    if (b < L) {
+                        const uint32_t byte = g_u8(o, seq + (b >> 1));
+                        const uint32_t code = (uint32_t)(CODE >> (4 * ((b & 1) ? (byte & 15u) : (byte >> 4)))) & 15u;
+                        if (code == 4) word |= 1u << q;
+                    }
+                }
+            }
+            rec[j] = word;
+        }
+        uint8_t* s4 = seq4 + seq4_off[r0 + i];
+        for (int j = lane; j < ((L + 1) >> 1); j += LANES) s4[j] = (uint8_t)g_u8(o, seq + j);
+        uint8_t* nm_out = names + name_off[r0 + i];
+        for (int j = lane; j < l_name - 1; j += LANES) nm_out[j] = (uint8_t)g_u8(o, r + 32 + j);
+    }
+}
+
 }  // namespace
 
 namespace tredgpu_front {
@@ -1012,6 +1200,24 @@ hipError_t launch_alt_walk(const WalkView& v, const tredgpu_walk_task* tasks, co
 hipError_t launch_fetch_gather(const uint8_t* out, uint8_t* host, const FetchPiece* pieces, size_t n_pieces, hipStream_t st) {
     if (n_pieces == 0) return hipSuccess;
     fetch_gather_kernel<<<(unsigned)n_pieces, 256, 0, st>>>(out, host, pieces);
+    return hipGetLastError();
+}
+hipError_t launch_select(const WalkView& v, const tredgpu_walk_task* tasks, const tredgpu_select_task* sel, const int64_t* rec_base,
+                         const WalkRec* recs, const WalkFields* fields, const WalkChained* chained, const tredgpu_walk_result* results,
+                         const tredgpu_walk_task* alt_tasks, const tredgpu_alt_result* alt_results, int n_alt_tasks, int64_t* sel_list,
+                         tredgpu_select_result* out, int n_tasks, hipStream_t st) {
+    if (n_tasks <= 0) return hipSuccess;
+    select_kernel<<<(unsigned)n_tasks, LANES, 0, st>>>(v, tasks, sel, rec_base, recs, fields, chained, results, alt_tasks, alt_results, n_alt_tasks,
+                                                       sel_list, out);
+    return hipGetLastError();
+}
+hipError_t launch_pack_selected(const uint8_t* out, const int64_t* sel_list, const int32_t* unit_task, const int32_t* unit_read_off,
+                                const int64_t* unit_word_off, const int64_t* unit_seq4_off, const int64_t* unit_name_off, int u0, int n_units,
+                                uint32_t* packed, int64_t* read_off, int32_t* read_len, uint8_t* seq4, int64_t* seq4_off, uint8_t* names,
+                                int64_t* name_off, hipStream_t st) {
+    if (n_units <= 0) return hipSuccess;
+    pack_selected_kernel<<<(unsigned)n_units, 256, 0, st>>>(out, sel_list, unit_task, unit_read_off, unit_word_off, unit_seq4_off, unit_name_off, u0,
+                                                            packed, read_off, read_len, seq4, seq4_off, names, name_off);
     return hipGetLastError();
 }
 }  // namespace tredgpu_front

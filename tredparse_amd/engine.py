@@ -163,6 +163,11 @@ def _static(scan):
 _STATIC = {}
 
 
+class _SelectedBatch(object):
+    """What a BatchResult's users read of its batch, for units whose reads were packed on the device (genotype_selected)."""
+    __slots__ = ("unit_read_off", "n_units", "n_reads", "params", "clip", "ladder_keys", "pair_id", "max_units")
+
+
 class BatchResult(object):
     """Arrays of one genotyped PackedUnits batch; unit(i) gives the per-unit view the callers format."""
     __slots__ = ("batch", "tag", "h", "score", "full", "pref", "rept", "calls", "marg", "joint", "grid", "grid_off",
@@ -272,6 +277,104 @@ class Engine(object):
         with np.errstate(divide="ignore", invalid="ignore"):
             r.joint_units = (trip[:, 0].astype(np.int64) // per, trip[:, 1].astype(np.int64) // per, trip[:, 2] / np.repeat(jt, cap),
                              joff[:-1], jn)
+        return r
+
+    def genotype_selected(self, scans, maxinsert=300, fullsearch=False, clip=False):
+        """genotype_packed for samples whose reads the device selected and still holds (feeder._device_scan: SampleScans with
+        `.device` = (DeviceChunk, first task, select results)): one tredgpu_genotype_selected call -- pack on the device, SW +
+        tagging -> histograms -> grid, one wait -- which also brings back the selected reads' lengths, 4-bit sequences and
+        names; they are filled into the scans (per-sample views), so that the writers find what scan_sample would have
+        left there.  Every locus of every scan is a unit, in order.  Returns the BatchResult (units in scan order)."""
+        import ctypes as C
+        r = BatchResult()
+        r.grid = r.grid_off = r.full = r.pref = None
+        segs, rows, keys, pools, sels = [], [], [], {}, []
+        g_all, t_all, n_gl, n_tl = [], [], 0, 0
+        for s in scans:
+            dev, t0, sel = s.device
+            n = len(s.names)
+            if dev not in pools:
+                pools[dev] = (n_gl, n_tl)
+                g_all.append(dev.gp)
+                t_all.append(dev.tp)
+                n_gl, n_tl = n_gl + len(dev.gp), n_tl + len(dev.tp)
+            gb, tb = pools[dev]
+            tasks = np.arange(t0, t0 + n, dtype=np.int32)
+            if segs and segs[-1][0] is dev.inf:
+                segs[-1][1].append(tasks)
+            else:
+                segs.append((dev.inf, [tasks]))
+            st, u = _static(s), s.unit
+            row = np.zeros(n, _lib.UNIT_DTYPE)
+            row["period"], row["readlen"], row["ploidy"] = st["period"], s.readlen, s.ploidy
+            row["maxinsert"], row["fullsearch"] = maxinsert, int(fullsearch)
+            row["ref_len"], row["minpe"] = st["span"] + 1, st["span"] + 20
+            row["cutoff_risk"], row["is_expansion"], row["is_recessive"] = st["cutoff_risk"], st["is_expansion"], st["is_recessive"]
+            row["pe_off"], row["n_global"] = gb + u["global_first"], u["n_global"]
+            row["tl_off"], row["n_target"] = tb + u["target_first"], u["n_target"]
+            row["half_depth"] = np.asarray(s.depth, np.float64) / 2
+            rows.append(row)
+            sels.append(sel)
+            k = st["ladder"].get(s.readlen)
+            if k is None:
+                k = st["ladder"][s.readlen] = [(x.prefix, x.repeat, x.suffix, -(-s.readlen // len(x.repeat))) for x in s.loci]
+            keys += k
+        params = np.concatenate(rows)
+        sel = np.concatenate(sels)
+        g = len(params)
+        uro = np.zeros(g + 1, np.int32)
+        uwo, uso, uno = (np.zeros(g + 1, np.int64) for _ in range(3))
+        np.cumsum(sel["n_reads"], out=uro[1:])
+        np.cumsum(sel["n_words"], out=uwo[1:])
+        np.cumsum(sel["seq4_bytes"], out=uso[1:])
+        np.cumsum(sel["name_bytes"], out=uno[1:])
+        n = int(uro[-1])
+        b = r.batch = _SelectedBatch()
+        b.unit_read_off, b.n_units, b.n_reads, b.params, b.clip, b.ladder_keys, b.pair_id = uro, g, n, params, bool(clip), keys, None
+        b.max_units = max([k[3] for k in keys] + [1])
+        hs = b.max_units + 2
+        ms = max(int(params["maxinsert"].max()), hs) + 2
+        r.tag, r.h, r.score = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.int16), np.zeros(max(n, 1), np.int16)
+        r.rept = np.zeros((g, hs), np.int32)
+        lad = self._register(keys)
+        gl = np.ascontiguousarray(np.concatenate(g_all), np.int32) if n_gl else np.zeros(1, np.int32)
+        tl = np.ascontiguousarray(np.concatenate(t_all), np.int32) if n_tl else np.zeros(1, np.int32)
+        sw = _lib.default_sw_params(clip=clip, max_read_len=max(int(sel["max_len"].max()), 1))
+        r.calls = np.zeros(g, _lib.CALL_DTYPE)
+        r.marg = np.zeros((g, 2, ms), np.float64)
+        read_len = np.zeros(max(n, 1), np.int32)
+        s4off, nmoff = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        seq4, names = np.zeros(max(int(uso[-1]), 1), np.uint8), np.zeros(max(int(uno[-1]), 1), np.uint8)
+        seg_arg = [(inf, np.concatenate(t)) for inf, t in segs]
+        cap = np.full(g, JOINT_CAP, np.int64)
+        while True:
+            joff = np.zeros(g + 1, np.int64)
+            joff[1:] = np.cumsum(cap)
+            trip = np.zeros((int(joff[-1]), 3), np.float64)
+            jn, jt = np.zeros(g, np.int32), np.zeros(g, np.float64)
+            self.ctx.genotype_selected(seg_arg, uro, uwo, uso, uno, lad, params, g, sw, gl, n_gl, tl, n_tl, r.tag, r.h, r.score, hs,
+                                       r.rept, r.calls, r.marg, ms, joff, trip, jn, jt, read_len, s4off, seq4, nmoff, names)
+            if (jn <= cap).all():
+                break
+            cap = np.maximum(cap, jn)
+        r.tag, r.h, r.score = r.tag[:n], r.h[:n], r.score[:n]
+        r.joint = [(trip[joff[i]:joff[i] + jn[i]], float(jt[i])) for i in range(g)]
+        per = np.repeat(params["period"].astype(np.int64), cap)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r.joint_units = (trip[:, 0].astype(np.int64) // per, trip[:, 1].astype(np.int64) // per, trip[:, 2] / np.repeat(jt, cap),
+                             joff[:-1], jn)
+        # the reads' arrays, a sample at a time, as scan_sample leaves them (offsets from the sample's first read)
+        u0 = 0
+        for s in scans:
+            m = len(s.names)
+            a, e = int(uro[u0]), int(uro[u0 + m])
+            s.read_len = read_len[a:e]
+            s.seq4_off = s4off[a:e + 1] - s4off[a]
+            s.seq4 = seq4[int(s4off[a]):int(s4off[e])] if e > a else np.zeros(0, np.uint8)
+            s.name_off = nmoff[a:e + 1] - nmoff[a]
+            s.name_blob = names[int(nmoff[a]):int(nmoff[e])].tobytes() if e > a else b""
+            s.name_id = np.zeros(e - a, np.int32)          # (read only under --norepeatpairs, which the device path does not take)
+            u0 += m
         return r
 
     def _genotype_packed_stepwise(self, b, dense=False):

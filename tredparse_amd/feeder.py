@@ -5,7 +5,7 @@ import atexit
 import logging
 import threading
 import time
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import Future, ThreadPoolExecutor
 
 from .bam_parser import scan_sample
 from .runtime import _options, collect_sample, timing_add
@@ -18,9 +18,10 @@ from .runtime import _options, collect_sample, timing_add
 # different streams do not overlap on this GPU, so the batch is what fills it) and lets the scans take the blocks from
 # the inflater's pinned output (bamio preload).  Blocks a plan misses, or the decoder rejects, are inflated by the scan
 # itself as before: the results cannot differ.
-def _plan_sample(arg, walk=False):
+def _plan_sample(arg, walk=False, select=False):
     """Thread: open the BAM and list the blocks its scan will read -- with walk, also the pair-length regions as tasks
-    for the device's walk (bamio plan_walks / plan_blocks).  None: no GPU help for this sample."""
+    for the device's walk (bamio plan_walks / plan_blocks); with select, also what the device's read selection needs
+    (_select_plan).  None: no GPU help for this sample."""
     from .bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays, open_bam, y_regions
     o = _options(arg)
     try:
@@ -42,10 +43,46 @@ def _plan_sample(arg, walk=False):
             p["alt_tasks"], p["alt_chunks"] = f.plan_alt_walks(sites, regions, readlen, pad=SPAN, flank=FLANKMATCH, pe_reach=DNAPE_ELONGATE,
                                                                span=SPAN, use_alts=o["alts"] and not o["clip"])
             p["coffset"], p["clen"], p["crc"], p["host"] = f.plan_blocks()
+            p["select"] = _select_plan(o, f, loci, sites, regions, readlen, sexed, p) if select else None
         return p
     except Exception:
         f.close()
         return None
+
+
+def _select_plan(o, f, loci, sites, regions, readlen, sexed, p):
+    """What the read selection on the device (include/tredgpu.h section 5) needs of one sample beside its walk tables: a
+    tredgpu_select_task per locus (the position range of bam_parser.py:209-213, the locus' alternative regions) and -- when
+    a locus is X-linked -- one plain region task per chrY window of the sex inference, whose pile-up sums come back with
+    the loci's.  None when this sample must go through the host's scan: options whose outputs need more than the device
+    path returns (--log DEBUG prints every pair of the grid, --norepeatpairs needs the reads' name ids before the tally), a
+    locus the file or the kernels cannot serve (its contig is missing, its template ladder or the reads are too long)."""
+    import numpy as np
+    from ._lib import SELECT_TASK_DTYPE
+    from .bam_parser import MAX_READ_LEN, MAX_TEMPLATE_LEN, y_regions
+    if o["log"] == "DEBUG" or not (o["repeatpairs"] or o["clip"]):
+        return None
+    if len(sites) == 0 or (sites["tid"] < 0).any() or (p["tasks"]["n_chunks"] < 0).any() or readlen > MAX_READ_LEN:
+        return None
+    if any(len(t.prefix) + t.period * -(-readlen // t.period) + len(t.suffix) > MAX_TEMPLATE_LEN for t in loci):
+        return None
+    use_alts = o["alts"] and not o["clip"]
+    if use_alts and len(regions) and ((p["alt_tasks"]["n_chunks"] < 0) & (regions["tid"][:len(p["alt_tasks"])] >= 0)).any():
+        return None                                    # (a region of a contig the file HAS that cannot be walked from the plan)
+    sel = np.zeros(len(sites), SELECT_TASK_DTYPE)
+    sel["pos_lo"] = np.maximum(sites["repeat_start"].astype(np.int64) - readlen, 0)
+    sel["pos_hi"] = sites["repeat_end"].astype(np.int64) + readlen
+    sel["alt_first"], sel["n_alt"] = sites["alt_first"], (sites["n_alt"] if use_alts else 0)
+    out = {"sel": sel, "ytasks": None, "ychunks": None, "ywidth": None, "sexed": sexed}
+    if sexed:
+        ys = y_regions(o["repo"].ref)
+        if all(f.tid(c) >= 0 for c, _, _ in ys):        # (a file without these contigs: the sex stays unknown, as in scan_sample)
+            yt, yc = f.plan_region_walks(ys)
+            if (yt["n_chunks"] < 0).any():
+                return None
+            out["ytasks"], out["ychunks"] = yt, yc
+            out["ywidth"] = np.array([hi - lo + 1 for _, lo, hi in ys], np.float64)
+    return out
 
 
 def _scan_planned(arg, plan, out_addr, out_off, status, crc=None, pe=None, alt=None):
@@ -106,6 +143,54 @@ def release_inflaters():
 atexit.register(release_inflaters)
 
 
+class DeviceChunk(object):
+    """The samples of one decode call whose reads were selected on the device: the inflater that holds them (its buffers must
+    stay as they are until the genotyping call has packed the reads: `done()` gives it back to the feeder) and the call's two
+    pair-length pools, which the samples' units index."""
+    __slots__ = ("inf", "gp", "tp", "release")
+
+    def __init__(self, inf, gp, tp):
+        self.inf, self.gp, self.tp, self.release = inf, gp, tp, Future()
+
+    def done(self):
+        if not self.release.done():
+            self.release.set_result(None)
+
+
+def _device_scan(arg, p, dev, res, selres):
+    """The SampleScan of a sample whose reads the device selected (what scan_sample returns, without the per-read arrays:
+    engine.genotype_selected fills those in from the genotyping call): sex from the chrY regions' depth sums, per locus the
+    depth, the read count and the slices of the call's pair-length pools."""
+    import numpy as np
+    from . import bamio
+    from .bam_parser import SPAN, SampleScan
+    o = _options(arg)
+    sp = p["select"]
+    s = SampleScan()
+    s.path, s.names, s.loci = o["bam"], list(o["names"]), [o["repo"][n] for n in o["names"]]
+    s.gender, s.ydepth, s.readlen, s.opened = "Unknown", -1, int(p["readlen"]), True
+    if sp["sexed"] and sp["ytasks"] is not None:
+        y = p["ytask_first"]
+        s.ydepth = float(np.median(selres["depth_sum"][y:y + len(sp["ytasks"])] / sp["ywidth"]))
+        s.gender = "Male" if s.ydepth > 1 else "Female"
+    t, n = p["task_first"], len(p["tasks"])
+    sel, r = selres[t:t + n], res[t:t + n]
+    u = s.unit = np.zeros(n, bamio.SCAN_UNIT_DTYPE)
+    u["n_reads"] = sel["n_reads"]
+    u["read_first"] = np.cumsum(sel["n_reads"], dtype=np.int64) - sel["n_reads"]
+    u["depth_sum"] = sel["depth_sum"]
+    u["n_global"], u["n_target"] = r["n_global"], r["n_target"]
+    u["global_first"], u["target_first"] = r["global_first"], r["target_first"]
+    s.global_lens, s.target_lens = dev.gp, dev.tp
+    window = np.array([x.repeat_end + SPAN - max(0, x.repeat_start - SPAN) + 1 for x in s.loci], np.float64)
+    s.depth = u["depth_sum"] / window
+    s.ploidy = np.array([1 if (s.gender == "Male" and x.is_xlinked) else x.ploidy for x in s.loci], np.int32)
+    s.packed = s.word_off = s.read_len = s.seq4 = s.seq4_off = s.name_blob = s.name_off = s.name_id = None
+    s.dropped = {}
+    s.device = (dev, t, sel)
+    return s
+
+
 class _InflateFeeder(object):
     """Feeds run_many's chunks through plan -> GPU inflate -> scan, ahead of the consumer: next() returns the next
     (chunk, its scan futures), None behind the last one.  Three stages overlap: while the GPU decodes chunk k (a thread of its own makes the call,
@@ -116,9 +201,10 @@ class _InflateFeeder(object):
     inflaters go only after every scan that reads their buffers has ended."""
     SLOTS = 3
 
-    def __init__(self, chunks, ex, device, walk=False):
+    def __init__(self, chunks, ex, device, walk=False, select=False):
         import queue
-        self.chunks, self.ex, self.device, self.walk = chunks, ex, device, walk
+        self.chunks, self.ex, self.device, self.walk, self.select = chunks, ex, device, walk, bool(select and walk)
+        self.on_device = []                            # DeviceChunks handed out and not yet released by the consumer
         # plans and fills have threads of their own: queued behind a chunk's 28 scans in the scan pool they started only
         # when those were done, and the pool then idled through the next chunk's decode
         self.prep = ThreadPoolExecutor(max_workers=2)
@@ -150,7 +236,7 @@ class _InflateFeeder(object):
             self.decoding[slot].exception()            # chunk ci - SLOTS has been decoded and its scans are known ...
         for fut in self.busy[slot]:
             fut.exception()                            # ... and have ended (waits; the consumer sees the error itself)
-        plans = [fut.result() for fut in [self.prep.submit(_plan_sample, a, self.walk) for a in chunk]]
+        plans = [fut.result() for fut in [self.prep.submit(_plan_sample, a, self.walk, self.select) for a in chunk]]
         live = [p for p in plans if p is not None and p["n"] > 0]
         t0 = time.perf_counter()
         job = {"plans": plans, "live": live, "inf": inf, "slot": slot, "ooff": None, "n_all": 0}
@@ -179,26 +265,60 @@ class _InflateFeeder(object):
     @staticmethod
     def _walk_tables(live):
         """The chunk's pair-walk tasks: every sample's tables (bamio plan_walks / plan_blocks) moved to the sample's
-        place among the call's blocks and chunks."""
+        place among the call's blocks and chunks.  A sample with a select plan brings its chrY region tasks along, behind
+        its loci's (`task_first` .. + len(tasks) are the loci, `ytask_first` the first region task), and the chunk then also
+        has one tredgpu_select_task per task of the call."""
         import numpy as np
-        def moved(key_t, key_c, first_key):
-            tasks, chunks, c0, t0 = [], [], 0, 0
+        from ._lib import SELECT_TASK_DTYPE
+
+        def place(t, c, p, c0):
+            t, c = t.copy(), c.copy()
+            t["chunk_first"] += c0
+            t["block_first"] += p["first"]
+            t["block_end"] += p["first"]
+            c["begin_block"][c["begin_block"] >= 0] += p["first"]
+            return t, c
+        tasks, chunks, sels, c0, t0 = [], [], [], 0, 0
+        any_select = any(p.get("select") is not None for p in live)
+        for p in live:
+            t, c = place(p["tasks"], p["chunks"], p, c0)
+            p["task_first"] = t0
+            tasks.append(t)
+            chunks.append(c)
+            c0, t0 = c0 + len(c), t0 + len(t)
+            sp = p.get("select")
+            if any_select:
+                sel = np.zeros(len(t), SELECT_TASK_DTYPE)
+                sel["n_alt"] = -1                          # (a sample the host scans: its tasks are only walked for the pairs)
+                sels.append(sel if sp is None else sp["sel"].copy())
+            if sp is not None and sp["ytasks"] is not None:
+                yt, yc = place(sp["ytasks"], sp["ychunks"], p, c0)
+                p["ytask_first"] = t0
+                tasks.append(yt)
+                chunks.append(yc)
+                ysel = np.zeros(len(yt), SELECT_TASK_DTYPE)
+                ysel["n_alt"] = -1
+                sels.append(ysel)
+                c0, t0 = c0 + len(yc), t0 + len(yt)
+        alt_tasks, alt_chunks, c0, t0 = [], [], 0, 0
+        for p in live:
+            t, c = place(p["alt_tasks"], p["alt_chunks"], p, c0)
+            p["alt_first"] = t0
+            alt_tasks.append(t)
+            alt_chunks.append(c)
+            c0, t0 = c0 + len(c), t0 + len(t)
+        out = {"coffset": np.concatenate([p["coffset"] for p in live]), "clen": np.concatenate([p["clen"] for p in live]),
+               "crc": np.concatenate([p["crc"] for p in live]), "tasks": np.concatenate(tasks), "chunks": np.concatenate(chunks),
+               "alt_tasks": np.concatenate(alt_tasks), "alt_chunks": np.concatenate(alt_chunks), "select": None}
+        if any_select:
+            sel = np.concatenate(sels)
+            # a locus' alternative regions are entries of the CALL's alt tasks: the sample's first one is added
             for p in live:
-                t, c = p[key_t].copy(), p[key_c].copy()
-                t["chunk_first"] += c0
-                t["block_first"] += p["first"]
-                t["block_end"] += p["first"]
-                c["begin_block"][c["begin_block"] >= 0] += p["first"]
-                p[first_key] = t0
-                tasks.append(t)
-                chunks.append(c)
-                c0, t0 = c0 + len(c), t0 + len(t)
-            return np.concatenate(tasks), np.concatenate(chunks)
-        tasks, chunks = moved("tasks", "chunks", "task_first")
-        alt_tasks, alt_chunks = moved("alt_tasks", "alt_chunks", "alt_first")
-        return {"coffset": np.concatenate([p["coffset"] for p in live]), "clen": np.concatenate([p["clen"] for p in live]),
-                "crc": np.concatenate([p["crc"] for p in live]), "tasks": tasks, "chunks": chunks, "alt_tasks": alt_tasks,
-                "alt_chunks": alt_chunks}
+                if p.get("select") is not None:
+                    a = p["task_first"]
+                    sel["alt_first"][a:a + len(p["tasks"])] += p["alt_first"]
+            out["select"] = sel
+        return out
 
     def _decode_and_scan(self, chunk, job):
         """Decode thread: one launch for the chunk, then its scans go to the pool and their futures to the consumer."""
@@ -222,22 +342,34 @@ class _InflateFeeder(object):
                 timing_add(inflate_gpu=time.perf_counter() - t0)
             if self.stop.is_set():
                 return
+            dev = None
             for a, p in zip(chunk, plans):
                 if p is None:
                     futs.append(self.ex.submit(collect_sample, a))
                 elif status is None or p["n"] == 0:
                     futs.append(self.ex.submit(_scan_planned, a, p, 0, None, None))
+                elif walked is not None and p.get("on_device"):
+                    # its reads were selected where the blocks are: no scan -- a SampleScan without per-read arrays, which the
+                    # genotyping call fills in (engine.genotype_selected), and the inflater stays this chunk's until then
+                    if dev is None:
+                        dev = DeviceChunk(inf, walked[1], walked[2])
+                    done = Future()
+                    done.set_result(_device_scan(a, p, dev, walked[0], walked[4]))
+                    futs.append(done)
+                    self._close_plans([p])
                 else:
                     k = p["first"]
                     pe = alt = None
                     if walked is not None:
-                        res, gp, tp, ares = walked
+                        res, gp, tp, ares = walked[:4]
                         pe = (res[p["task_first"]:p["task_first"] + len(p["tasks"])], gp, tp)
                         alt = ares[p["alt_first"]:p["alt_first"] + len(p["alt_tasks"])]
                     futs.append(self.ex.submit(_scan_planned, a, p, out_addr, out_off[k:k + p["n"] + 1], status[k:k + p["n"]],
                                                crc[k:k + p["n"]], pe, alt))
                 handed += 1                                # (that scan closes its own handle)
-            self.busy[job["slot"]] = futs
+            self.busy[job["slot"]] = futs + ([dev.release] if dev is not None else [])
+            if dev is not None:
+                self.on_device = [d for d in self.on_device if not d.release.done()] + [dev]
             self._put((chunk, futs))
         except BaseException as e:     # hand the failure to the consumer instead of leaving it waiting
             self.busy[job["slot"]] = futs         # (scans already running read the slot's buffers: close() waits for them)
@@ -248,38 +380,55 @@ class _InflateFeeder(object):
 
     @staticmethod
     def _run_walk(inf, job):
-        """Decode, walk the pair-length regions on the device, fetch the blocks the scans still read.  Returns the
+        """Decode, walk the pair-length regions on the device -- and, with a selection, pick the loci's reads there --, fetch
+        the blocks the scans still read (none for a sample whose selection went through: p["on_device"]).  Returns the
         statuses as the scans should see them (a block that was not fetched counts as not delivered), the checksums and
-        the walk's (results, global pool, target pool), and where the fetched blocks lie (address, offsets per block)."""
+        the walk's (results, global pool, target pool, alternative loci's results, select results or None), and where the
+        fetched blocks lie (address, offsets per block)."""
         import numpy as np
         from .bam_parser import walk_need
         w = job["walk"]
         from ._lib import walk_pool_pairs
         t0 = time.perf_counter()
-        status, crc, res, gp, tp, ares, alt_need = inf.run_walk(job["n_all"], w["coffset"], w["clen"], w["crc"], w["tasks"], w["chunks"],
-                                                                alt_tasks=w["alt_tasks"], alt_chunks=w["alt_chunks"],
-                                                                pool_pairs=walk_pool_pairs(w["tasks"], job["ooff"]))
+        out = inf.run_walk(job["n_all"], w["coffset"], w["clen"], w["crc"], w["tasks"], w["chunks"], alt_tasks=w["alt_tasks"],
+                           alt_chunks=w["alt_chunks"], pool_pairs=walk_pool_pairs(w["tasks"], job["ooff"]),
+                           **({"select": w["select"]} if w.get("select") is not None else {}))
+        status, crc, res, gp, tp, ares, alt_need = out[:7]
+        selres = out[7] if len(out) > 7 else None
         full = int((res["status"] == 6).sum())
         if full:                           # (WALK_POOL_FULL: cannot happen with the bound above; a wrong plan would show here)
             logging.getLogger("tredparse_amd").warning("pair walk: %d of %d regions found the pair pool full and are walked on the host", full, len(res))
         t1 = time.perf_counter()
         need = np.zeros(job["n_all"], np.uint8)
+        n_dev = 0
         for p in job["live"]:
-            a = p["first"]
-            need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])],
-                                           alt_need[a:a + p["n"]])
+            a, sp = p["first"], p.get("select")
+            p["on_device"] = False
+            if selres is not None and sp is not None:
+                t = p["task_first"]
+                ok = bool((selres["status"][t:t + len(p["tasks"])] == 0).all())
+                if ok and sp["ytasks"] is not None:
+                    y = p["ytask_first"]
+                    ok = bool((selres["status"][y:y + len(sp["ytasks"])] == 0).all())
+                p["on_device"] = ok
+                n_dev += ok
+            if not p["on_device"]:
+                need[a:a + p["n"]] = walk_need(p["coffset"], p["host"], res[p["task_first"]:p["task_first"] + len(p["tasks"])],
+                                               alt_need[a:a + p["n"]])
         t2 = time.perf_counter()
-        if getattr(inf, "host_out", True):
-            inf.fetch(need)
-            out_addr, out_off = inf.out_addr, job["ooff"]
-        else:
-            out_addr, out_off = inf.fetch_dense(need)
+        out_addr, out_off = inf.out_addr, job["ooff"]
+        if need.any() or n_dev == 0:
+            if getattr(inf, "host_out", True):
+                inf.fetch(need)
+            else:
+                out_addr, out_off = inf.fetch_dense(need)
         timing_add(walk_call=t1 - t0, walk_fetch=time.perf_counter() - t2)
         walkable = w["alt_tasks"]["n_chunks"] >= 0
         timing_add(walk_regions=len(res), walk_declined=int((res["status"] != 0).sum()), walk_blocks_fetched=int(need.sum()),
                    walk_alt_regions=int(walkable.sum()), walk_alt_declined=int((ares["status"][walkable] != 0).sum()),
-                   inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()))
-        return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp, ares), out_addr, out_off
+                   inflate_blocks=job["n_all"], inflate_failed=int((status != 0).sum()), select_samples=n_dev,
+                   select_declined=sum(1 for p in job["live"] if p.get("select") is not None) - n_dev if selres is not None else 0)
+        return np.where(need != 0, status, 1).astype(np.int32), crc, (res, gp, tp, ares, selres), out_addr, out_off
 
     def _put(self, item):
         import queue
@@ -330,6 +479,8 @@ class _InflateFeeder(object):
                 break
         self.thread.join()                                 # (bounded: the threads check the flag between every two steps)
         self.gpu.shutdown(wait=True)
+        for dev in self.on_device:                         # (the consumer -- this thread -- is done with them, whatever it did)
+            dev.done()
         for slot in self.busy:
             for fut in slot:
                 fut.exception()                            # scans still reading the staging buffers: let them end

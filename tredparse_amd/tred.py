@@ -101,6 +101,10 @@ def set_argparse():
     g.add_argument("--gpu-walk", action="store_true",
                    help="with --gpu-inflate: the pair-length walks (PEextractor's +-10 kb regions) run on the GPU over the "
                         "blocks it inflated; only the blocks of the loci's windows and alternative loci come back to the host")
+    g.add_argument("--gpu-select", action="store_true",
+                   help="with --gpu-inflate --gpu-walk: read selection, depth and 2-bit packing run on the GPU as well, over the "
+                        "records the walks listed; no block comes back to the host and no host scan runs for the samples the "
+                        "device can serve (the others are scanned as before)")
     g.add_argument("--maxinsert", type=int, default=300, help="largest allele considered, in repeat units")
     g.add_argument("--fullsearch", action="store_true", help="evaluate every allele pair up to --maxinsert")
     g = p.add_argument_group("I/O options")
@@ -268,13 +272,35 @@ def genotype_scans(engine, task_args, scans):
     groups = {}
     for pick, arg in zip(picks, task_args):
         o = _options(arg)
-        key = (o["maxinsert"], o["fullsearch"], o["clip"], o["repeatpairs"] or o["clip"], o["log"] == "DEBUG")
+        # (a scan whose reads the device selected and still holds -- feeder._device_scan -- goes to the call that packs them there)
+        on_device = getattr(pick[1], "device", None) is not None
+        key = (o["maxinsert"], o["fullsearch"], o["clip"], o["repeatpairs"] or o["clip"], o["log"] == "DEBUG", on_device)
         groups.setdefault(key, (o, []))[1].append(pick)
     parts = {}
-    for o, sub in groups.values():
-        parts.update(_genotype(engine, sub, o))
+    try:
+        for key, (o, sub) in groups.items():
+            parts.update(_genotype_selected(engine, sub, o) if key[-1] else _genotype(engine, sub, o))
+    finally:
+        for _, s, _ in picks:                  # the inflaters that held the device's selections are the feeder's again
+            dev = getattr(s, "device", None)
+            if dev is not None:
+                dev[0].done()
     timing_add(gpu=time.perf_counter() - t0)
     return picks, parts
+
+
+def _genotype_selected(engine, picks, o):
+    """_genotype for scans whose reads are on the device: one engine.genotype_selected call for all of them."""
+    t0 = time.perf_counter()
+    scans = [s for _, s, _ in picks]
+    br = engine.genotype_selected(scans, maxinsert=o["maxinsert"], fullsearch=o["fullsearch"], clip=o["clip"])
+    br.repeatpairs = True
+    timing_add(pack=time.perf_counter() - t0)
+    out, i = {}, 0
+    for si, s, ks in picks:
+        out[si] = [(br, i, list(ks))]
+        i += len(s.names)
+    return out
 
 
 def unit_results(parts, only=None):
@@ -385,7 +411,7 @@ def _chunked(task_args, first, batch):
 
 
 def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_details=False, ahead_batches=2,
-             background_sink=False, inflate_device=None, gpu_walk=False, emit=None):
+             background_sink=False, inflate_device=None, gpu_walk=False, emit=None, gpu_select=False):
     """run() over many samples, `batch` samples per GPU batch.  task_args: a list, or any iterable of run() argument
     tuples (taken lazily, a chunk at a time: a cohort need not be known in advance).  BAMs are scanned by `threads` host
     threads (or the executor given as `pool`), up to `ahead_batches` batches ahead of the GPU (with a single batch in
@@ -397,7 +423,9 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     is built (sink is not called, nothing is returned).
     inflate_device: GPU that inflates the samples' BGZF blocks, a chunk of samples per launch (None: the scans inflate on
     the host); needs scan threads.  gpu_walk: the pair-length walks (PEextractor) run on that GPU too, over the blocks it
-    just inflated; only the blocks of the loci's windows and of the alternative loci come back.
+    just inflated; only the blocks of the loci's windows and of the alternative loci come back.  gpu_select (with gpu_walk):
+    the read selection, the depth and the 2-bit packing happen there as well (include/tredgpu.h section 5) -- no block comes
+    back and no host scan runs for a sample the device could serve; any other is scanned as before.
     (Measured and removed: the GPU half of a batch on a thread of its own beside the formatting of the previous batch --
     the two halves fight over the interpreter lock, 20.1-20.4 k against 20.5 k genotypes/s with five drivers, 23.2 k against
     27.5 k with six --, and several decode chunks per genotyping batch, 14.7 / 11.0 k against 25 k: docs/history.)"""
@@ -415,7 +443,7 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     feeder = None
     if inflate_device is not None and ex is not None:
         try:
-            feeder = _InflateFeeder(chunks, ex, inflate_device, walk=gpu_walk)
+            feeder = _InflateFeeder(chunks, ex, inflate_device, walk=gpu_walk, select=gpu_select)
         except Exception as e:       # no pinned memory, no device ...: the scans inflate for themselves
             logging.getLogger("tredparse_amd").warning("GPU inflate not available (%s): BGZF blocks are inflated on the host", e)
 
@@ -797,7 +825,7 @@ def main(args, quiet=False):
                 try:
                     run_many(tasks, engine, batch=max(1, args.batch_samples), threads=max(1, args.cpus), lazy_details=True,
                              inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None, gpu_walk=args.gpu_walk,
-                             emit=emit)
+                             gpu_select=args.gpu_select, emit=emit)
                 finally:
                     emit.close()
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
