@@ -564,6 +564,7 @@ def e2e_main(args):
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
     gpu_inflate, gpu_walk = args.e2e_gpu_inflate == "1", args.e2e_gpu_walk == "1"
+    gpu_select = gpu_inflate and gpu_walk and args.e2e_gpu_select == "1"
     sink_lock = __import__("threading").Lock()
 
     def on_sample(done):                          # from the native writer's threads: the sample's files are written
@@ -591,14 +592,15 @@ def e2e_main(args):
                     return
                 yield t
             passes += 1
-    kw = dict(lazy_details=True, inflate_device=0 if gpu_inflate else None, gpu_walk=gpu_walk)
+    kw = dict(lazy_details=True, inflate_device=0 if gpu_inflate else None, gpu_walk=gpu_walk, gpu_select=gpu_select)
     emit = None
     if args.e2e_python_writer:
         kw.update(sink=sink, background_sink=2 if gpu_inflate else 1)
     else:
         # (never more results in flight than the block has files: a driver goes over its block again and again, and two
         #  writer threads must not meet in one <key>.json -- ADVICE r5)
-        emit = kw["emit"] = tred.Emitter("hg38", repo, names, workers=2, on_sample=on_sample, depth=max(1, min(96, len(mine))))
+        emit = kw["emit"] = tred.Emitter("hg38", repo, names, workers=3 if gpu_select else 2, on_sample=on_sample,
+                                         depth=max(1, min(96, len(mine))))
     try:
         # warm-up: HIP context, ladders, caches -- and, for the GPU-inflate legs, one full chunk through each inflater, whose
         # pinned staging (45 MB per sample of a chunk, three inflaters) stays with the process for the timed cohort
@@ -738,28 +740,33 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None)
         for n_devices in device_counts:
             n_files = n_devices * per_gpu
             # (ranks, threads, gpu_inflate, gpu_walk, seconds): the continuity leg, then the rule's plan
-            plans = [(n_devices, max(1, (usable - 1) // n_devices), False, False, args.e2e_seconds / 2)]
+            plans = [(n_devices, max(1, (usable - 1) // n_devices), False, False, args.e2e_seconds / 2, False)]
             rule = e2e_rule(n_devices, usable)
             if args.e2e_drivers:
                 rule = (args.e2e_drivers * n_devices, args.e2e_threads or max(1, (usable - 1) // (args.e2e_drivers * n_devices)))
             on = args.e2e_gpu_inflate != "0"
-            plans.append(rule + (on, on and args.e2e_gpu_walk == "1", args.e2e_seconds))
+            walk = on and args.e2e_gpu_walk == "1"
+            select = walk and args.e2e_gpu_select == "1"
+            plans.append(rule + (on, walk, args.e2e_seconds, select))
             if args.e2e_sweep:
-                plans += [(d, t, False, False, args.e2e_seconds / 2) for d, t in e2e_plan(n_devices, usable) if d != n_devices]
-                plans += [(d, t, True, True, args.e2e_seconds / 2) for d, t in e2e_plan(n_devices, usable, dense=True) if (d, t) != rule]
-                plans.append(rule + (True, False, args.e2e_seconds / 2))
+                plans += [(d, t, False, False, args.e2e_seconds / 2, False) for d, t in e2e_plan(n_devices, usable) if d != n_devices]
+                plans += [(d, t, True, True, args.e2e_seconds / 2, select) for d, t in e2e_plan(n_devices, usable, dense=True) if (d, t) != rule]
+                plans.append(rule + (True, False, args.e2e_seconds / 2, False))
+                if select:
+                    plans.append(rule + (True, True, args.e2e_seconds / 2, False))      # (the round-5 plan: the selection on the host)
             legs = []
-            for li, (drivers, threads, gpu_inflate, gpu_walk, seconds) in enumerate(plans):
-                batch = args.e2e_inflate_batch if gpu_inflate else args.e2e_batch
+            for li, (drivers, threads, gpu_inflate, gpu_walk, seconds, gpu_select) in enumerate(plans):
+                batch = (args.e2e_inflate_batch if gpu_select else min(args.e2e_inflate_batch, 12)) if gpu_inflate else args.e2e_batch
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
                         "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
-                        "--e2e-seconds", str(seconds), "--e2e-gpu-walk", "1" if gpu_walk else "0"]
+                        "--e2e-seconds", str(seconds), "--e2e-gpu-walk", "1" if gpu_walk else "0", "--e2e-gpu-select",
+                        "1" if gpu_select else "0"]
                 if getattr(args, "e2e_python_writer", False):
                     argv.append("--e2e-python-writer")
                 out_dir = os.path.join(root, "out{}_{}".format(n_devices, li))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
-                leg = {"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate, "gpu_walk": gpu_walk,
+                leg = {"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate, "gpu_walk": gpu_walk, "gpu_select": gpu_select,
                        "host_threads_per_driver": threads, "samples_per_gpu_batch": batch, "files": n_files,
                        "role": "host_only_one_driver_per_gpu" if li == 0 else "plan" if li == 1 else "sweep"}
                 codes = spawn(argv, drivers, n_devices, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
@@ -897,7 +904,7 @@ def compact_line(out):
     e = out.get("end_to_end")
     if e:
         line["end_to_end"] = {k: _r(e[k], 3) for k in ("value", "unit", "first_pass_value", "whole_run_value", "startup_s", "drivers",
-                                                       "devices", "host_threads_per_driver", "gpu_inflate", "gpu_walk", "seconds", "samples",
+                                                       "devices", "host_threads_per_driver", "gpu_inflate", "gpu_walk", "gpu_select", "seconds", "samples",
                                                        "files", "pinned_MB_per_gpu", "outputs_identical", "error") if k in e}
         h = e.get("host_only_one_driver_per_gpu")
         if h:
@@ -1052,10 +1059,13 @@ def main():
                     help="extra one-GPU legs workload:readlen:samples, comma separated ('' for none)")
     ap.add_argument("--e2e-gpu-inflate", choices=("0", "1"), default="1",
                     help="the planned end-to-end leg has the BAMs' BGZF blocks inflated on the GPU (tred.run_many inflate_device)")
+    ap.add_argument("--e2e-gpu-select", choices=("0", "1"), default="1",
+                    help="GPU-walk legs: read selection, depth and packing run on the GPU too (tred.run_many gpu_select): no block "
+                         "comes back to the host, no host scan runs")
     ap.add_argument("--e2e-gpu-walk", choices=("0", "1"), default="1",
                     help="GPU-inflate legs: the pair-length walks run on the GPU too (tred.run_many gpu_walk), and only the "
                          "blocks of the loci's windows and alternative loci come back")
-    ap.add_argument("--e2e-inflate-batch", type=int, default=12, help="samples per GPU batch (and decode + walk call) in the planned leg: 12 keeps three drivers under 2 GB of pinned memory per GPU (16: +2 % throughput, 2.6 GB)")
+    ap.add_argument("--e2e-inflate-batch", type=int, default=36, help="samples per GPU batch (= per decode + walk + select call) in the planned leg: 36 fills the device (55.8 / 60.6 / 64.0 k genotypes/s at 12 / 24 / 36; 3.8 GB of pinned staging per GPU); legs without the selection on the device keep 12")
     ap.add_argument("--streamed", type=int, default=0,
                     help="also time the step fed from pinned host memory: this many distinct batches, double-buffered "
                          "copy-in beside the kernels (the default run adds it as the `streamed` leg with 4 batches)")

@@ -5,15 +5,13 @@ test_host_frontend.py / test_e2e_gpu.py): per sample the same sex, depth, reads 
 sequences, the same pair-length slices -- and through the kernels the same tags, calls, marginals and joint entries,
 bit for bit.  Then the product path: run_many with gpu_select against run_many on the host, result dict for result dict."""
 import os
-from concurrent.futures import ThreadPoolExecutor
+import sys
 
 import numpy as np
 import pytest
 
-from tredparse_amd import _lib, synth, synth_bam, tred as t
-from tredparse_amd.bam_parser import scan_sample
-from tredparse_amd.engine import Engine, PackedUnits
-from tredparse_amd.feeder import _InflateFeeder
+from tredparse_amd import synth, synth_bam, tred as t
+from tredparse_amd.engine import Engine
 from tredparse_amd.meta import TREDsRepo
 
 pytestmark = pytest.mark.gpu
@@ -54,23 +52,15 @@ def cohort(tmp_path_factory):
     return args
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import fuzz_select  # noqa: E402  (the comparison itself lives with the campaign: tools/fuzz_select.py)
+
+
 def _device_scans(args, engine, batch):
-    """The feeder with the selection on, a chunk at a time: [(arg, scan, pieces)] in task order."""
-    chunks = [args[i:i + batch] for i in range(0, len(args), batch)]
-    ex = ThreadPoolExecutor(max_workers=2)
-    feeder = _InflateFeeder(chunks, ex, 0, walk=True, select=True)
-    out = []
     try:
-        for _ in chunks:
-            chunk, futs = feeder.next()
-            scans = [f.result() for f in futs]
-            picks, parts = t.genotype_scans(engine, chunk, scans)
-            out += [(a, s, parts.get(si, [])) for si, (a, s) in enumerate(zip(chunk, scans))]
+        return fuzz_select.device_scans(args, engine, batch)
     finally:
-        feeder.close()
-        ex.shutdown()
         t.release_inflaters()
-    return out
 
 
 def test_selection_on_the_device_equals_the_host_scan(cohort, engine):
@@ -80,38 +70,23 @@ def test_selection_on_the_device_equals_the_host_scan(cohort, engine):
     assert t.TIMING["select_samples"] == len(cohort) and t.TIMING["select_declined"] == 0 and t.TIMING["walk_blocks_fetched"] == 0
     reads = units = 0
     for a, s, pieces in got:
-        o = t._options(a)
-        assert getattr(s, "device", None) is not None, o["samplekey"]
-        h = scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"])
-        assert (s.gender, s.ydepth, s.readlen, s.opened, s.dropped) == (h.gender, h.ydepth, h.readlen, h.opened, h.dropped), o["samplekey"]
-        for key in ("n_reads", "read_first", "depth_sum", "depth_status", "pe_status", "n_global", "n_target", "status"):
-            assert (s.unit[key] == h.unit[key]).all(), (o["samplekey"], key)
-        assert np.array_equal(s.depth, h.depth) and np.array_equal(s.ploidy, h.ploidy)
-        for k in range(len(s.names)):
-            for x, y in zip(s.pair_lengths(k), h.pair_lengths(k)):
-                assert np.array_equal(x, y), (o["samplekey"], s.names[k])
-        assert np.array_equal(s.read_len, h.read_len) and np.array_equal(s.seq4_off, h.seq4_off) and np.array_equal(s.seq4, h.seq4)
-        assert np.array_equal(s.name_off, h.name_off) and s.name_blob == h.name_blob, o["samplekey"]
-        # the kernels over the device-packed reads against the kernels over the host-packed ones
-        ks = list(range(len(h.names)))
-        hb = engine.genotype_packed(PackedUnits.from_scans([(h, ks)], maxinsert=o["maxinsert"], fullsearch=o["fullsearch"], clip=o["clip"]))
-        (br, i0, dks), = pieces
-        assert dks == ks
-        lo, hi = int(br.batch.unit_read_off[i0]), int(br.batch.unit_read_off[i0 + len(ks)])
-        assert hi - lo == hb.batch.n_reads
-        assert np.array_equal(br.tag[lo:hi], hb.tag) and np.array_equal(br.h[lo:hi], hb.h) and np.array_equal(br.score[lo:hi], hb.score)
-        for key in (k for k in br.calls.dtype.names if k != "pad"):
-            x, y = br.calls[key][i0:i0 + len(ks)], hb.calls[key]
-            assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), (o["samplekey"], key)
-        m = min(br.marg.shape[2], hb.marg.shape[2])
-        assert np.array_equal(br.marg[i0:i0 + len(ks), :, :m], hb.marg[:, :, :m])
-        assert np.array_equal(br.rept[i0:i0 + len(ks)].sum(1), hb.rept.sum(1))
-        for j in range(len(ks)):
-            (ta, tot_a), (tb, tot_b) = br.joint[i0 + j], hb.joint[j]
-            assert tot_a == tot_b and sorted(map(tuple, ta.tolist())) == sorted(map(tuple, tb.tolist())), (o["samplekey"], j)
-        reads += hi - lo
-        units += len(ks)
+        assert getattr(s, "device", None) is not None, a[0]
+        bad, r, u = fuzz_select.compare(a, s, pieces, engine)
+        assert not bad, (a[0], bad)
+        reads += r
+        units += u
     assert reads > 2500 and units > 80
+
+
+def test_a_short_random_campaign(capsys, monkeypatch):
+    """tools/fuzz_select.py, four rounds: random loci / coverage / read length / flags / options, blocks cut at random sizes
+    without regard to records (the long campaign is profiles/r06_fuzz_select.json)."""
+    import json
+    monkeypatch.setattr(sys, "argv", ["fuzz_select.py", "4", "20261004"])
+    fuzz_select.main()
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["samples"] >= 8 and out["on_device"] >= out["samples"] - 1 and out["units"] > 20
+    assert out["mismatching_samples"] == 0, out["what"]
 
 
 def test_what_the_device_cannot_serve_goes_to_the_host_scan(cohort, engine):

@@ -94,7 +94,8 @@ def set_argparse():
                         "the usable CPUs and --gpus by shard.driver_plan, never more than one per 32 samples)")
     g.add_argument("--gpu", type=int, default=0, help="device index when --gpus is 1")
     g.add_argument("--batch-samples", type=int, default=None,
-                   help="samples per GPU batch (default: 64; 12 with --gpu-inflate, where a batch is also one decode + walk call)")
+                   help="samples per GPU batch (default: 64; 12 with --gpu-inflate, where a batch is also one decode + walk call; 36 "
+                        "with --gpu-select)")
     g.add_argument("--gpu-inflate", action="store_true",
                    help="inflate the BAMs' BGZF blocks on the GPU, --batch-samples samples per launch (needs --cpus > 1; "
                         "pays when several driver processes share the host's cores: see DESIGN.md 4.4)")
@@ -762,7 +763,10 @@ def main(args, quiet=False):
     elif args.cpus is not None and pinned:
         args.cpus = max(1, min(args.cpus, len(pinned)))         # never more scan threads than this rank's CPU set holds
     if args.batch_samples is None:
-        args.batch_samples = 12 if args.gpu_inflate else 64
+        # (with the selection on the device a chunk is one decode + walk + select call and one genotyping call, nothing comes
+        #  back but results: 36 samples per call fill the device -- 55.8 / 60.6 / 64.0 k genotypes/s at 12 / 24 / 36 --, at
+        #  1.3 GB of pinned staging per driver)
+        args.batch_samples = (36 if (args.gpu_walk and args.gpu_select) else 12) if args.gpu_inflate else 64
     logger.setLevel(getattr(logging, args.log))
     logging.getLogger("tredparse_amd.bam").setLevel(getattr(logging, args.log))
     t0 = time.time()
@@ -821,7 +825,7 @@ def main(args, quiet=False):
                 # the samples' files are written natively, from the batch's arrays, on threads of their own (Emitter); a
                 # sample the native printers do not cover takes the Python path there
                 emit = Emitter(args.ref, repo, loci, no_output=args.no_output, echo=not quiet,
-                               workers=2 if args.cpus > 1 else 1)
+                               workers=(3 if (args.gpu_inflate and args.gpu_walk and args.gpu_select) else 2) if args.cpus > 1 else 1)
                 try:
                     run_many(tasks, engine, batch=max(1, args.batch_samples), threads=max(1, args.cpus), lazy_details=True,
                              inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None, gpu_walk=args.gpu_walk,
