@@ -46,3 +46,34 @@ class FakeEngine(object):
         r.joint = [None] * g
         r.joint_units = (a, bb, v, np.arange(g, dtype=np.int64) * cap, rng.integers(0, cap + 1, g).astype(np.int32))
         return r
+
+    def genotype_selected(self, scans, maxinsert=300, fullsearch=False, clip=False):
+        """engine.Engine.genotype_selected over tests/walk_model.ModelInflater's selection: the scans' per-read arrays are
+        filled from the model's picks (what tredgpu_genotype_selected brings back), the results are genotype_packed's."""
+        b = eng._SelectedBatch()
+        rows, counts = [], []
+        for s in scans:
+            dev, t0, sel = s.device
+            lens, seqs, names = [], [], []
+            for k in range(len(s.names)):
+                a, q, nm = dev.inf.selected_reads(t0 + k)
+                assert len(a) == sel["n_reads"][k]
+                lens += a; seqs += q; names += nm
+            s.read_len = np.array(lens, np.int32)
+            s.seq4 = np.frombuffer(b"".join(seqs), np.uint8).copy()
+            s.seq4_off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.int64)
+            s.name_blob = b"".join(names)
+            s.name_off = np.concatenate([[0], np.cumsum([len(x) for x in names])]).astype(np.int64)
+            s.name_id = np.zeros(len(lens), np.int32)
+            row = np.zeros(len(s.names), _lib.UNIT_DTYPE)
+            row["period"] = [len(x.repeat) for x in s.loci]
+            rows.append(row)
+            counts.append(sel["n_reads"])
+        b.params = np.concatenate(rows)
+        b.n_units = len(b.params)
+        b.unit_read_off = np.zeros(b.n_units + 1, np.int32)
+        np.cumsum(np.concatenate(counts), out=b.unit_read_off[1:])
+        b.n_reads = int(b.unit_read_off[-1])
+        b.clip, b.pair_id, b.ladder_keys = bool(clip), None, []
+        b.max_units = max(-(-s.readlen // len(x.repeat)) for s in scans for x in s.loci)
+        return self.genotype_packed(b)

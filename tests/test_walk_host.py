@@ -220,3 +220,53 @@ def test_native_scan_checks_the_pair_length_slices_itself():
     assert f._lib.tredbam_scan_pe(f._h, sites.ctypes.data, 1, alts.ctypes.data, C.byref(o), res.ctypes.data, gp.ctypes.data, tp.ctypes.data,
                                   out.ctypes.data) == 0
     f.close()
+
+
+def test_feeder_with_the_selection_on_the_device_gives_the_plain_scans(cohort, monkeypatch):
+    """run_many's gpu_select plumbing without a GPU: tests/walk_model.ModelInflater also models the device's read selection
+    (csrc/walk.hip select_kernel: the window's picks and depth sum, the alternative regions' hits, the chrY region tasks) and
+    the fake engine fills the reads in as tredgpu_genotype_selected does.  Every sample the device may serve comes back as a
+    SampleScan whose sex, depths, read counts, pair-length slices, read lengths, sequences and names are the plain scan's;
+    the others (--useclippedreads runs on the device too; the missing file does not) are scanned on the host, in the same chunk."""
+    from tests.fake_engine import FakeEngine
+    if not hasattr(bamio.AlignmentFile(cohort[0][1]), "plan_walks"):
+        pytest.skip("no native BAM layer")
+    monkeypatch.setattr("tredparse_amd._lib.Inflater", ModelInflater)
+    t.release_inflaters()
+    for k in t.TIMING:
+        t.TIMING[k] = 0
+    tasks = list(cohort) + [cohort[2][:8] + (False, "ERROR")]            # (--norepeatpairs: the host's)
+    chunks = [tasks[:3], tasks[3:6], tasks[6:]]
+    ex = ThreadPoolExecutor(max_workers=2)
+    feeder = t._InflateFeeder(chunks, ex, 0, walk=True, select=True)
+    engine = FakeEngine(seed=5, odd_units=False)
+    got = []
+    try:
+        for _ in chunks:
+            chunk, futs = feeder.next()
+            scans = [f.result() for f in futs]
+            picks, parts = t.genotype_scans(engine, chunk, scans)
+            got += list(zip(chunk, scans))
+            assert sorted(parts) == [si for si, s in enumerate(scans) if s.opened]
+    finally:
+        feeder.close()
+        ex.shutdown()
+        t.release_inflaters()
+    on_device = [getattr(s, "device", None) is not None for _, s in got]
+    assert on_device == [a[0] != "missing" and a[8] for a in tasks]
+    assert t.TIMING["select_samples"] == sum(on_device) and t.TIMING["select_declined"] == 0
+    for (a, s), dev in zip(got, on_device):
+        o = t._options(a)
+        plain = scan_sample(o["bam"], o["repo"], o["names"], clip=o["clip"], alts=o["alts"])
+        if not dev:
+            _same(s, plain)
+            continue
+        assert (s.gender, s.ydepth, s.readlen, s.dropped) == (plain.gender, plain.ydepth, plain.readlen, plain.dropped), a[0]
+        for key in s.unit.dtype.names:
+            assert (s.unit[key] == plain.unit[key]).all() or key in ("global_first", "target_first"), (a[0], key)
+        for key in ("read_len", "seq4", "seq4_off", "name_blob", "name_off", "depth", "ploidy"):
+            x, y = getattr(s, key), getattr(plain, key)
+            assert (x == y) if isinstance(x, bytes) else np.array_equal(x, y), (a[0], key)
+        for k in range(len(s.names)):
+            for x, y in zip(s.pair_lengths(k), plain.pair_lengths(k)):
+                assert np.array_equal(x, y), (a[0], k)

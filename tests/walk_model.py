@@ -48,24 +48,28 @@ class ModelInflater(object):
         self.bufs[1][:len(self.dev) - 64] = self.dev[:-64]
         return (status, sums) if crc else status
 
-    def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None, pool_pairs=None):
+    def run_walk(self, n, bcoff, bclen, xcrc, tasks, chunks, pairs_per_task=2048, alt_tasks=None, alt_chunks=None, pool_pairs=None,
+                 select=None):
         self.walks += 1
         self.pool_pairs = pool_pairs
         status, crc = self._inflate(n)
         ooff = self.bufs[3]
         out = out_bytes = self.dev.tobytes()
+        self.out_bytes = out_bytes
         res = np.zeros(len(tasks), _lib.WALK_RESULT_DTYPE)
         gp, tp = [], []
         ok = lambda k: status[k] == 0 and crc[k] == xcrc[k]     # noqa: E731
+        picked = [None] * len(tasks)                            # per task: (places of the window's selected records, depth sum)
         for t, T in enumerate(tasks):
-            r = _walk(T, chunks, out, ooff, bcoff, bclen, ok)
+            r = _walk(T, chunks, out, ooff, bcoff, bclen, ok, sel=None if select is None else select[t])
             if isinstance(r, int):
                 res["status"][t] = r
                 continue
-            g, tt, nwin, vbeg, vend = r
+            g, tt, nwin, vbeg, vend = r[:5]
             res[t] = (0, len(g), len(tt), nwin, len(gp), len(tp), vbeg, vend)
             gp += g
             tp += tt
+            picked[t] = r[5] if len(r) > 5 else None
         # (tred._run_walk sizes the pools from the planned bytes: the bound must hold for every call)
         assert pool_pairs is None or (len(gp) <= pool_pairs and len(tp) <= max(pool_pairs // 8, 16 * len(tasks)) + 1024), (len(gp), len(tp), pool_pairs)
         out = (status, crc, res, np.array(gp, np.int32), np.array(tp, np.int32))
@@ -85,7 +89,52 @@ class ModelInflater(object):
             for m, (at, kb, ka) in enumerate(r):
                 ares["vbeg"][t][m] = at
                 need[kb:ka + 1] = 1
-        return out + (ares, need)
+        if select is None:
+            return out + (ares, need)
+        # the read selection (csrc/walk.hip select_kernel): the window's picks, then the alternative regions' hits region by region
+        selres = np.zeros(len(tasks), _lib.SELECT_RESULT_DTYPE)
+        self.selected = [None] * len(tasks)
+        coff_to_block = {int(c): k for k, c in enumerate(bcoff)}
+        for t, (T, S) in enumerate(zip(tasks, select)):
+            if res["status"][t] != 0:
+                selres["status"][t] = res["status"][t]
+                continue
+            places, depth = picked[t]
+            places = list(places)
+            st = 0
+            for q in range(int(S["alt_first"]), int(S["alt_first"]) + max(int(S["n_alt"]), 0)):
+                if alt_tasks[q]["n_chunks"] < 0:
+                    continue
+                if ares["status"][q] != 0:
+                    st = int(ares["status"][q])
+                    break
+                for at in ares["vbeg"][q][:ares["n"][q]]:
+                    places.append(int(ooff[coff_to_block[int(at) >> 16]]) + (int(at) & 0xFFFF))
+            if st == 0 and len(places) > _lib.SELECT_CAP:
+                st = 8
+            lens = [struct.unpack_from("<i", out_bytes, a0 + 4 + 16)[0] for a0 in places]
+            if st == 0 and lens and max(lens) > 480:
+                st = 9
+            if st:
+                selres["status"][t] = st
+                continue
+            names = [max(out_bytes[a0 + 4 + 8] - 1, 0) for a0 in places]
+            selres[t] = (0, len(places), sum((L + 15) // 16 + (L + 31) // 32 for L in lens), sum((L + 1) // 2 for L in lens), sum(names),
+                         max(lens + [0]), depth)
+            self.selected[t] = places
+        return out + (ares, need, selres)
+
+    def selected_reads(self, task):
+        """(read_len, 4-bit sequences, names) of the reads the selection of the last run_walk picked for `task`, in order."""
+        out, lens, seqs, names = self.out_bytes, [], [], []
+        for a0 in self.selected[task]:
+            r = a0 + 4
+            l_name, n_cig, L = out[r + 8], struct.unpack_from("<H", out, r + 12)[0], struct.unpack_from("<i", out, r + 16)[0]
+            at = r + 32 + l_name + 4 * n_cig
+            lens.append(L)
+            seqs.append(out[at:at + (L + 1) // 2])
+            names.append(out[r + 32:r + 32 + max(l_name - 1, 0)])
+        return lens, seqs, names
 
     def fetch(self, need):
         assert self.host_out
@@ -113,7 +162,7 @@ class ModelInflater(object):
         pass
 
 
-def _walk(T, chunks, out, ooff, bcoff, bclen, ok, alt=False):
+def _walk(T, chunks, out, ooff, bcoff, bclen, ok, alt=False, sel=None):
     """The pair walk of one region -> (global lens, target lens, window records, vbeg, vend), or -- alt -- the records
     whose mate lies on contig tstart within [win_lo, win_hi] as [(virtual offset, first block, last block)]; an int: the
     status the kernel ends the task with."""
@@ -127,6 +176,7 @@ def _walk(T, chunks, out, ooff, bcoff, bclen, ok, alt=False):
 
     pairs, order = {}, []
     nwin = vbeg = vend = 0
+    picks, depth = [], 0
     for c in range(int(T["chunk_first"]), int(T["chunk_first"]) + int(T["n_chunks"])):
         k, upos, cend = int(chunks["begin_block"][c]), int(chunks["begin_upos"][c]), int(chunks["end_voffset"][c])
         if k < T["block_first"] or k >= T["block_end"]:
@@ -185,7 +235,12 @@ def _walk(T, chunks, out, ooff, bcoff, bclen, ok, alt=False):
                     vbeg = at
                 nwin += 1
                 vend = tell(k, upos)
-            if not (flag & 1) or (flag & 4) or (flag & 0x400):
+                if sel is not None:                   # (select_kernel: the pile-up sum and the window's picks, in file order)
+                    if not (flag & (0x4 | 0x100 | 0x200 | 0x400)) and rend >= 0:
+                        depth += rend - pos
+                    if sel["n_alt"] >= 0 and ((flag & 4) or sel["pos_lo"] <= pos <= sel["pos_hi"]):
+                        picks.append(pieces[0])
+            if T["span"] <= 0 or not (flag & 1) or (flag & 4) or (flag & 0x400):
                 continue
             name = out[r + 32:r + 32 + max(l_name - 1, 0)]
             p = pairs.get(name)
@@ -223,4 +278,4 @@ def _walk(T, chunks, out, ooff, bcoff, bclen, ok, alt=False):
         if tlen >= T["span"]:
             continue
         (t if (a[0] < T["tstart"] and b[1] > T["tend"]) else g).append(tlen)
-    return g, t, nwin, vbeg, vend
+    return (g, t, nwin, vbeg, vend) if sel is None else (g, t, nwin, vbeg, vend, (picks, depth))
