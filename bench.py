@@ -23,8 +23,8 @@ notes, every plan of an --e2e-sweep -- goes to bench_detail.json next to this sc
 
 Roofline of the dominant kernel (sw_cont_kernel, integer VALU bound; HIP-event timed on the context's own stream):
 `achieved` = DP cells the kernel really swept (read rows x columns, padding rows and empty quad slots excluded) per
-second, `peak` = int32 VALU lane-ops/s / 10 ops per cell, `mix_ceiling_frac` = what the kernel's instruction mix can
-reach of that peak on gfx950 (mix_ceiling).  The brute-force cell count of SURVEY 8(d) over the same time is
+second, `peak` = int32 VALU lane-ops/s / 10 ops per cell, `mix_ceiling_frac` = what the column blocks' own instruction
+mix allows of that peak for the columns this launch swept (mix_ceiling: the build's ISA census x the kernel's counters).  The brute-force cell count of SURVEY 8(d) over the same time is
 `effective_TCUPS` (it exceeds the hardware peak because of the exact shortcuts; it is not a hardware rate).
 `traffic` = HBM bytes per launch from the rocprofv3 PMC passes summarised in profiles/ (FETCH_SIZE + WRITE_SIZE), cited
 only when the summary was taken on THIS build.
@@ -335,6 +335,9 @@ def rank_main(args):
         swept = cnt["read_cols"] / launches * batch.readlen
         rpl = rows_per_lane(args.readlen)
         lanes = cols * 4 * 16 * rpl                # cells the wavefronts occupy: 4 read slots x 16 lanes x R rows
+        # (the generic variant runs when a ladder's branch alone can pass the score filter: csrc/capi.hip run_sw_device)
+        generic = any(max(len(k[0]), len(k[2])) >= 30 for k in batch.ladders)
+        ceiling, ceiling_basis = mix_ceiling(load_census(), rpl, generic, cnt, launches, swept)
         alg_bytes = int(batch.packed.nbytes + n * 12 + n * 5)  # packed reads + offsets/lengths in, tag/h/score out
         traffic, traffic_src = (None, "counters of the 1 000-sample 150 bp config3 batch only") \
             if (args.workload, args.readlen, args.samples) != ("config3", 150, 1000) else pmc_traffic("sw_cont_kernel", _lib.version())
@@ -352,7 +355,7 @@ def rank_main(args):
                        "parallelism": "sample-sharded x{} (no collective)".format(world)},
             "roofline": {"kernel": "sw_cont_kernel<{},{}>".format(rpl, {4: 6, 7: 4, 10: 4, 16: 2, 20: 2}[rpl]), "bound": "valu",
                          "achieved": swept / sw_s / 1e12, "peak": PEAK_TCUPS, "unit": "TCUPS",
-                         "frac": swept / sw_s / 1e12 / PEAK_TCUPS, "mix_ceiling_frac": mix_ceiling(),
+                         "frac": swept / sw_s / 1e12 / PEAK_TCUPS, "mix_ceiling_frac": ceiling, "mix_ceiling_basis": ceiling_basis,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                          "note": "achieved = DP cells really swept per launch (read rows x columns of every read; "
@@ -755,7 +758,11 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None)
                 if select:
                     plans.append(rule + (True, True, args.e2e_seconds / 2, False))      # (the round-5 plan: the selection on the host)
             legs = []
-            for li, (drivers, threads, gpu_inflate, gpu_walk, seconds, gpu_select) in enumerate(plans):
+            # the planned leg is run several times over (one 12-s leg cannot tell a 5 % change from the box-to-box
+            # and run-to-run spread of +-12 %): the record's value is the MEDIAN of the repeats, min and max beside it
+            repeats = max(1, int(getattr(args, "e2e_repeats", 1)))
+            runs = [(li, p, rep) for li, p in enumerate(plans) for rep in range(repeats if li == 1 else 1)]
+            for li, (drivers, threads, gpu_inflate, gpu_walk, seconds, gpu_select), rep in runs:
                 batch = (args.e2e_inflate_batch if gpu_select else min(args.e2e_inflate_batch, 12)) if gpu_inflate else args.e2e_batch
                 argv = [sys.executable, os.path.abspath(__file__), "--e2e-child", root, "--e2e-batch", str(batch),
                         "--e2e-threads", str(threads), "--e2e-limit", str(n_files), "--e2e-gpu-inflate", "1" if gpu_inflate else "0",
@@ -763,12 +770,12 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None)
                         "1" if gpu_select else "0"]
                 if getattr(args, "e2e_python_writer", False):
                     argv.append("--e2e-python-writer")
-                out_dir = os.path.join(root, "out{}_{}".format(n_devices, li))
+                out_dir = os.path.join(root, "out{}_{}_{}".format(n_devices, li, rep))
                 os.makedirs(out_dir)
                 env = dict(os.environ, TREDBENCH_OUT=out_dir)
                 leg = {"drivers": drivers, "devices": n_devices, "gpu_inflate": gpu_inflate, "gpu_walk": gpu_walk, "gpu_select": gpu_select,
                        "host_threads_per_driver": threads, "samples_per_gpu_batch": batch, "files": n_files,
-                       "role": "host_only_one_driver_per_gpu" if li == 0 else "plan" if li == 1 else "sweep"}
+                       "role": "host_only_one_driver_per_gpu" if li == 0 else "plan" if li == 1 else "sweep", "repeat": rep}
                 codes = spawn(argv, drivers, n_devices, timeout=args.rank_timeout, env=env, stdout=sys.stderr)
                 if any(codes):
                     leg["error"] = "exit codes {}".format(codes)
@@ -790,9 +797,13 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None)
                 leg["pinned_MB_per_gpu"] = round(sum(r.get("pinned_MB", 0.0) for r in ranks) / max(1, n_devices), 1)
                 legs.append(leg)
             good = [l for l in legs if "value" in l]
-            plan = [l for l in good if l["role"] == "plan"]
-            rec = dict(plan[0]) if plan else {"error": "the planned end-to-end leg did not finish"}
+            plan = sorted([l for l in good if l["role"] == "plan"], key=lambda l: l["value"])
+            rec = dict(plan[(len(plan) - 1) // 2]) if plan else {"error": "the planned end-to-end leg did not finish"}
             rec.pop("per_driver", None)
+            if plan:
+                rec["repeats"] = [round(l["value"], 1) for l in sorted(plan, key=lambda l: l["repeat"])]
+                rec["min"], rec["max"] = plan[0]["value"], plan[-1]["value"]
+                rec["value_is"] = "median of {} repeats of {:g} s".format(len(plan), args.e2e_seconds)
             rec["legs"] = legs
             rec["devices"] = n_devices
             rec["outputs_identical"] = bool(good) and len(set((l["outputs"], l["outputs_sha256"]) for l in good)) == 1 \
@@ -864,16 +875,49 @@ def sweep_counts(n_target, n_devices, sweep):
     return ns
 
 
-MIX_CEILING_FRAC = 0.39     # what sw_cont_kernel's own instruction mix allows of the 10-op/cell peak: see mix_ceiling()
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 
 
-def mix_ceiling():
-    """roofline.mix_ceiling_frac: the fraction of `peak` (2-cycle issue, 10 ops per cell) that the kernel's instruction
-    mix can reach at all on gfx950.  profiles/r04_ubench_valu.txt: v_max_i32 / v_max3_i32 / v_add3_u32 / DPP max / v_cmp
-    issue at 4.1 cycles per wave64, plain add / mov at 2.1; the kernel's mix (r04_pmc_summary.json: 16.0 lane-ops per
-    swept cell, about two thirds of them 4-cycle) averages 3.2 cycles per instruction = 0.31 instr/SIMD-cycle against
-    the 0.5 the peak assumes, and spends 16.0 instead of 10 ops per cell: 0.31 / 0.5 x 10 / 16.0 = 0.39."""
-    return MIX_CEILING_FRAC
+def load_census():
+    """tredparse_amd/data/sw_isa_census.json (tools/isa_census.py, written by the build next to the library): the VALU
+    census of sw_cont_kernel's column blocks per instantiation.  None when it is missing or was not taken from the kernel
+    source this tree holds (then mix_ceiling_frac is null: nothing is typed in its place)."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "tredparse_amd", "data", "sw_isa_census.json")
+    try:
+        with open(path) as fp:
+            rec = json.load(fp)
+        h = hashlib.sha256()
+        for name in ("sw_ladder.hip", "tredgpu_internal.h"):
+            with open(os.path.join(here, "tredparse_amd", "csrc", name), "rb") as fp:
+                h.update(fp.read())
+        return rec if rec.get("source_sha16") == h.hexdigest()[:16] else None
+    except (OSError, ValueError):
+        return None
+
+
+def mix_ceiling(census, rpl, generic, counters, launches, swept_cells_per_launch):
+    """roofline.mix_ceiling_frac: the fraction of `peak` (2-cycle issue, 10 ops per cell) this launch could have reached had
+    the kernel done nothing but sweep the columns it swept, each at the issue cost of its own column block: the kernel's work
+    counters say how many trunk and continuation columns the wavefronts went through (tredgpu_get_sw_counters), the build's
+    census (tools/isa_census.py) what a column of either kind costs a SIMD in issue cycles -- 2- and 4-cycle VALU
+    instructions and the DPP wait states of sw_cont_kernel<R>'s own assembly, at the rates of tools/ubench_valu.hip.
+    Everything outside the column blocks (profiles, template ends, best-cell notes: half of the kernel's VALU at 150 bp,
+    profiles/r05_sw_isa_column.txt) and every stall is what separates `frac` from it.  (null, reason) without a census."""
+    if census is None:
+        return None, "no census of this build's sw_ladder.hip (tools/isa_census.py)"
+    k = census["kernels"].get("{},{},{}".format(rpl, {4: 6, 7: 4, 10: 4, 16: 2, 20: 2, 32: 1}[rpl], int(bool(generic))))
+    if k is None or launches <= 0 or swept_cells_per_launch <= 0:
+        return None, "no census entry for this instantiation"
+    cycles = (counters["trunk_cols"] * k["trunk_cycles_per_column"] + counters["continuation_cols"] * k["free_cycles_per_column"]) / launches
+    if cycles <= 0:
+        return None, "no columns counted"
+    seconds = cycles / (SIMDS * CLOCK_HZ)
+    return swept_cells_per_launch / seconds / 1e12 / PEAK_TCUPS, \
+        "{:.3g} trunk + {:.3g} continuation wave-columns per launch at {:g} / {:g} issue cycles each (census of sw_cont_kernel<{}>)".format(
+            counters["trunk_cols"] / launches, counters["continuation_cols"] / launches, k["trunk_cycles_per_column"],
+            k["free_cycles_per_column"], rpl)
 
 
 def _r(x, nd=4):
@@ -905,12 +949,12 @@ def compact_line(out):
     if e:
         line["end_to_end"] = {k: _r(e[k], 3) for k in ("value", "unit", "first_pass_value", "whole_run_value", "startup_s", "drivers",
                                                        "devices", "host_threads_per_driver", "gpu_inflate", "gpu_walk", "gpu_select", "seconds", "samples",
-                                                       "files", "pinned_MB_per_gpu", "outputs_identical", "error") if k in e}
+                                                       "files", "pinned_MB_per_gpu", "outputs_identical", "repeats", "min", "max", "error") if k in e}
         h = e.get("host_only_one_driver_per_gpu")
         if h:
             line["end_to_end"]["host_only_one_driver_per_gpu"] = {k: _r(h[k], 3) for k in ("value", "first_pass_value", "seconds")}
     if "legs" in out:
-        line["legs"] = [{k: _r(l[k], 4) for k in ("leg", "value", "ms_per_step", "frac", "error") if k in l} for l in out["legs"]]
+        line["legs"] = [{k: _r(l[k], 4) for k in ("leg", "value", "ms_per_step", "frac", "mix_ceiling_frac", "error") if k in l} for l in out["legs"]]
     if "scaling_sweep" in out:
         line["scaling_sweep"] = [dict({k: _r(s_[k], 3) for k in ("n", "value", "ms_per_step", "devices", "oversubscribed") if k in s_},
                                       **({"end_to_end": _r(s_["end_to_end"]["value"], 1)} if "value" in s_.get("end_to_end", {}) else {}))
@@ -1002,7 +1046,8 @@ def launcher_main(args):
                                 "kernels_ms_per_step": line["kernels_ms_per_step"],
                                 "mean_grid_pairs": line["check"]["mean_grid_pairs"],
                                 "max_grid_pairs": line["check"]["max_grid_pairs"], "units_ok": line["check"]["units_ok"],
-                                "roofline": {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                "mix_ceiling_frac": r.get("mix_ceiling_frac"),
+                                "roofline": {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "mix_ceiling_frac",
                                                                "avg_launch_ms", "lane_occupancy", "effective_TCUPS")}})
     if not args.no_cpu_baseline and not args.stub:
         loci, batch = make_batch(args, 0, 1)
@@ -1049,7 +1094,8 @@ def main():
                     help="BAM files per GPU of the end-to-end legs (0: skip them): the same number at every device count")
     ap.add_argument("--e2e-distinct", type=int, default=512,
                     help="distinct synthetic BAMs made; a larger cohort gets the rest as hard links under their own sample keys")
-    ap.add_argument("--e2e-seconds", type=float, default=12.0,
+    ap.add_argument("--e2e-repeats", type=int, default=3, help="how often the planned end-to-end leg is run (value = the median)")
+    ap.add_argument("--e2e-seconds", type=float, default=8.0,
                     help="how long the planned end-to-end leg's drivers keep going over their files (the host-only leg: half)")
     ap.add_argument("--e2e-sweep", action="store_true", help="also run the other driver plans (they go to bench_detail.json)")
     ap.add_argument("--e2e-batch", type=int, default=16, help="samples per GPU batch in the end-to-end leg")

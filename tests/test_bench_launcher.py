@@ -94,13 +94,15 @@ def _fake_e2e(monkeypatch, usable=64):
     def fake_spawn(argv, world, n_devices, timeout=None, env=None, stdout=None, cwd=None):
         get = lambda flag: argv[argv.index(flag) + 1]
         limit, threads, seconds = int(get("--e2e-limit")), int(get("--e2e-threads")), float(get("--e2e-seconds"))
-        spawned.append((world, n_devices, limit, threads, get("--e2e-gpu-inflate"), get("--e2e-gpu-walk"), get("--e2e-batch")))
+        spawned.append((world, n_devices, limit, threads, get("--e2e-gpu-inflate"), get("--e2e-gpu-walk") + get("--e2e-gpu-select"),
+                        get("--e2e-batch")))
         ranks, logs = [], []
         names = sorted(f[:-4] for f in os.listdir(get("--e2e-child")) if f.endswith(".bam"))[:limit]
         for r in range(world):
             lo, hi = shard.shard_range(limit, r, world)
             dev = shard.rank_env(r, world, 1, r % n_devices, base={})["TRED_RANK_DEVICE"]
-            t = 1000.0 + 0.5 + 0.01 * np.arange(1, int(seconds * 100) + 1)
+            # (the k-th leg started is 1 % slower per sample than the one before: repeats of a leg differ a little)
+            t = 1000.0 + 0.5 + 0.01 * (1 + 0.01 * len(legs)) * np.arange(1, int(seconds * 100) + 1)
             logs.append(np.stack([t, np.full(len(t), 30.0), np.full(len(t), 25.0), np.full(len(t), 30.0)], axis=1))
             ranks.append({"rank": r, "device": dev, "t_process": 990.0, "t_begin": 1000.0, "t_end": float(t[-1]), "files": hi - lo,
                           "host_threads": threads, "first_chunk": 3, "driver_seconds": {"gpu": 0.1}, "bam_bytes": 1000 * (hi - lo),
@@ -114,7 +116,8 @@ def _fake_e2e(monkeypatch, usable=64):
 def _e2e_args(**kw):
     import argparse
     base = dict(e2e_samples=128, e2e_distinct=128, seed=1, e2e_drivers=0, e2e_threads=0, e2e_batch=16, rank_timeout=60,
-                e2e_gpu_inflate="1", e2e_gpu_walk="1", e2e_inflate_batch=32, e2e_seconds=12.0, e2e_sweep=False)
+                e2e_gpu_inflate="1", e2e_gpu_walk="1", e2e_gpu_select="1", e2e_inflate_batch=32, e2e_seconds=12.0, e2e_sweep=False,
+                e2e_repeats=3)
     base.update(kw)
     return argparse.Namespace(**base)
 
@@ -133,20 +136,22 @@ def test_end_to_end_legs_spread_over_the_devices(tmp_path, monkeypatch):
     recs = bench.run_e2e(_e2e_args(), [1, 2, 8], spawn=fake_spawn, make_bams=fake_bams, read_leg=read_leg)
     assert made == [128]                                            # the distinct files are made once
     assert sorted(recs) == [1, 2, 8]
-    # (ranks, devices, files, threads per rank, gpu_inflate, gpu_walk, batch): files = devices x 128, always
+    # (ranks, devices, files, threads per rank, gpu_inflate, gpu_walk + gpu_select, batch): files = devices x 128, always; the
+    # planned leg (inflate, walks and read selection on the GPU) three times over
     want = []
     for n in (1, 2, 8):
         d, t = shard.driver_plan(64, n)
-        want += [(n, n, 128 * n, 63 // n, "0", "0", "16"), (d * n, n, 128 * n, t, "1", "1", "32")]
+        want += [(n, n, 128 * n, 63 // n, "0", "00", "16")] + [(d * n, n, 128 * n, t, "1", "11", "32")] * 3
     assert spawned == want
     eight = recs[8]
     assert eight["devices"] == 8 and eight["drivers"] == 8 * per_gpu and eight["files"] == 1024
-    assert eight["gpu_inflate"] and eight["gpu_walk"] and eight["outputs_identical"] is True and eight["outputs"] == 1024
-    assert [l["role"] for l in eight["legs"]] == ["host_only_one_driver_per_gpu", "plan"]
-    # steady state: every driver finishes 100 samples x 30 units a second; the window opens at the slowest driver's
-    # third sample (its first chunk) and closes at the first driver's last
-    assert abs(eight["value"] - 8 * per_gpu * 3000.0) < 1.0 and abs(eight["startup_s"] - 0.53) < 1e-6
-    assert abs(eight["seconds"] - (12.0 - 0.03)) < 1e-6
+    assert eight["gpu_inflate"] and eight["gpu_walk"] and eight["gpu_select"] and eight["outputs_identical"] is True and eight["outputs"] == 1024
+    assert [l["role"] for l in eight["legs"]] == ["host_only_one_driver_per_gpu", "plan", "plan", "plan"]
+    # steady state: every driver finishes ~100 samples x 30 units a second; the window opens at the slowest driver's
+    # third sample (its first chunk) and closes at the first driver's last.  The record is the MEDIAN repeat's, min and max beside it
+    assert len(eight["repeats"]) == 3 and eight["min"] < eight["value"] < eight["max"] and eight["repeat"] == 1
+    assert sorted(eight["repeats"])[1] == round(eight["value"], 1) and eight["repeats"][0] > eight["repeats"][1] > eight["repeats"][2]
+    assert abs(eight["value"] - 8 * per_gpu * 3000.0) < 0.15 * 8 * per_gpu * 3000.0
     assert eight["host_only_one_driver_per_gpu"]["value"] > 0 and "per_driver" not in eight
 
 
@@ -154,7 +159,7 @@ def test_end_to_end_sweep_is_behind_its_flag(tmp_path, monkeypatch):
     bench, made, spawned, fake_bams, fake_spawn, read_leg = _fake_e2e(monkeypatch, usable=16)
     recs = bench.run_e2e(_e2e_args(e2e_sweep=True), [1], spawn=fake_spawn, make_bams=fake_bams, read_leg=read_leg)
     roles = [l["role"] for l in recs[1]["legs"]]
-    assert roles[:2] == ["host_only_one_driver_per_gpu", "plan"] and set(roles[2:]) == {"sweep"} and len(roles) > 4
+    assert roles[:4] == ["host_only_one_driver_per_gpu", "plan", "plan", "plan"] and set(roles[4:]) == {"sweep"} and len(roles) > 6
     assert recs[1]["role"] == "plan"                  # the record is the plan's whatever the sweep finds
     assert bench.e2e_plan(1, 16) == [(1, 15), (2, 7), (3, 5)]
     assert bench.e2e_plan(1, 16, dense=True) == [(1, 15), (2, 7), (3, 5), (4, 3), (5, 3), (6, 3)]
@@ -251,3 +256,27 @@ def test_pmc_traffic_is_only_cited_for_the_build_it_was_taken_from(tmp_path, mon
     assert got == 222.0 and "r03_pmc_summary.json" in src and "src aaaa" in src
     got, src = bench.pmc_traffic("sw_cont_kernel", "tredgpu 0.3 (gfx950) src bbbb")
     assert got is None and "no PMC summary of this build" in src and "r02_pmc_summary.json" in src
+
+
+def test_mix_ceiling_is_computed_from_the_builds_census_and_the_kernels_counters():
+    """roofline.mix_ceiling_frac: no literal -- the build's ISA census of sw_cont_kernel's column blocks
+    (tools/isa_census.py -> tredparse_amd/data/sw_isa_census.json, taken from THIS tree's sw_ladder.hip) times the columns the
+    kernel's counters report; it differs between the instantiations and moves with the counters, and is null without a census."""
+    sys.path.insert(0, ROOT)
+    import bench
+    census = bench.load_census()
+    assert census is not None, "tredparse_amd/data/sw_isa_census.json is missing or stale: make -C tredparse_amd/csrc"
+    assert set(census["kernels"]) >= {"4,6,0", "7,4,0", "10,4,0", "10,4,1", "16,2,0", "20,2,0", "32,1,0"}
+    for k in census["kernels"].values():
+        c = k["trunk_column"]
+        assert k["trunk_cycles_per_column"] >= k["free_cycles_per_column"] > 0 and c["max3"] >= 2 * k["rows_per_lane"]
+        assert c["valu4"] >= 4 * k["rows_per_lane"] and c["valu2"] >= 3 * k["rows_per_lane"]      # 7 VALU per cell, 4 of them slow
+    cnt = {"trunk_cols": 5.0e7, "continuation_cols": 2.5e7}
+    cells = {7: 4 * 100 * 7.5e7, 10: 4 * 150 * 7.5e7, 16: 4 * 250 * 7.5e7}
+    got = {r: bench.mix_ceiling(census, r, False, cnt, 1, cells[r])[0] for r in (7, 10, 16)}
+    assert len(set(round(v, 4) for v in got.values())) == 3 and all(0.3 < v < 1.0 for v in got.values()), got
+    more = bench.mix_ceiling(census, 10, False, {"trunk_cols": 6.0e7, "continuation_cols": 2.5e7}, 1, cells[10])[0]
+    assert more < got[10]
+    assert bench.mix_ceiling(None, 10, False, cnt, 1, cells[10])[0] is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "MIX_CEILING_FRAC" not in src and "0.39" not in src
