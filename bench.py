@@ -929,7 +929,7 @@ def compact_line(out):
     object per leg.  Everything else -- per-driver stage times, counters, prose, every plan of a sweep -- is in
     bench_detail.json next to this script (and on stderr)."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-            "vs_baseline", "dtype", "data", "library", "stub", "gpus_visible")
+            "vs_baseline", "dtype", "data", "library", "stub", "gpus_visible", "virtual_gpus")
     line = {k: _r(out[k]) for k in keep if k in out}
     cfg = out.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "name", "units_per_step_per_gpu", "reads_per_step_per_gpu", "parallelism") if k in cfg}
@@ -949,7 +949,7 @@ def compact_line(out):
     if e:
         line["end_to_end"] = {k: _r(e[k], 3) for k in ("value", "unit", "first_pass_value", "whole_run_value", "startup_s", "drivers",
                                                        "devices", "host_threads_per_driver", "gpu_inflate", "gpu_walk", "gpu_select", "seconds", "samples",
-                                                       "files", "pinned_MB_per_gpu", "outputs_identical", "repeats", "min", "max", "error") if k in e}
+                                                       "files", "pinned_MB_per_gpu", "outputs_identical", "repeats", "min", "max", "oversubscribed", "error") if k in e}
         h = e.get("host_only_one_driver_per_gpu")
         if h:
             line["end_to_end"]["host_only_one_driver_per_gpu"] = {k: _r(h[k], 3) for k in ("value", "first_pass_value", "seconds")}
@@ -985,26 +985,35 @@ def launcher_main(args):
         return
     lines = {}
     scaling = []
+    # TRED_VIRTUAL_GPUS=V (shard.virtual_gpus): the box's devices counted as V -- the rehearsal of an 8-GPU run on one GPU
+    real = 1 if args.stub else shard.real_gpus(n_devices)
     for n in sweep_counts(args.gpus, n_devices, not args.no_sweep):
         line, ranks = run_ranks(args, n, n_devices)
         lines[n] = line
         rec = {"n": n, "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
                "devices": min(n, n_devices), "ranks": [{k: r[k] for k in ("rank", "device", "units", "elapsed_s")}
                                                         for r in ranks]}
-        if n > n_devices:
+        if n > real:
             rec["oversubscribed"] = True     # several ranks per GPU: exercises the launcher, not a scaling point
         scaling.append(rec)
     out = lines[args.gpus]
     out["scaling_sweep"] = scaling
     out["gpus_visible"] = n_devices
+    if real < n_devices:
+        out["virtual_gpus"] = {"counted": n_devices, "physical": real,
+                               "note": "TRED_VIRTUAL_GPUS: every rank and driver is real, the devices are not -- a rehearsal, no scaling point"}
     if args.e2e_samples > 0 and not args.stub:
         # the product path from BAM files at every device count of the sweep that the box really has (a 1-GPU box:
         # n = 1 only); the line's own record is that of --gpus
-        counts = sorted(set(r["n"] for r in scaling if not r.get("oversubscribed")) | {min(args.gpus, n_devices)})
+        counts = sorted(set(r["n"] for r in scaling if not r.get("oversubscribed") or (real < n_devices and r["n"] <= n_devices)) |
+                        {min(args.gpus, n_devices)})
         e2e = run_e2e(args, counts)
         out["end_to_end"] = e2e[min(args.gpus, n_devices)]
+        for n, rec in e2e.items():
+            if n > real:
+                rec["oversubscribed"] = True
         for r in scaling:
-            if r["n"] in e2e and not r.get("oversubscribed"):
+            if r["n"] in e2e and (not r.get("oversubscribed") or real < n_devices):
                 rec = e2e[r["n"]]
                 r["end_to_end"] = {k: rec[k] for k in ("value", "unit", "drivers", "devices", "samples", "seconds",
                                                        "host_threads_per_driver", "outputs_identical") if k in rec}

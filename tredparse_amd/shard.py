@@ -76,9 +76,39 @@ def visible_gpus():
             "    print(torch.cuda.device_count())\n")
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-        return max(0, int(out.stdout.strip().splitlines()[-1]))
+        real = max(0, int(out.stdout.strip().splitlines()[-1]))
     except Exception:
         return 0
+    return virtual_gpus(real)
+
+
+def virtual_gpus(real, env=None):
+    """TRED_VIRTUAL_GPUS=V: the launcher treats the box's `real` devices as V (rank r's device is r mod V, which is physical
+    device (r mod V) mod real) -- the rehearsal of an 8-GPU run on the boxes this was built on, which have one: real
+    ranks, real drivers, real gloo, the real NUMA code on the box's sysfs; every record of such a run says `oversubscribed`.
+    The physical count is left in TRED_REAL_GPUS for device_entry / spawn_ranks (and the children)."""
+    import os
+    env = os.environ if env is None else env
+    try:
+        v = int(env.get("TRED_VIRTUAL_GPUS", "0") or 0)
+    except ValueError:
+        v = 0
+    if v <= 0 or real < 1:
+        env.pop("TRED_REAL_GPUS", None)
+        return real
+    env["TRED_REAL_GPUS"] = str(real)
+    return v
+
+
+def real_gpus(n_devices, env=None):
+    """The physical devices behind n_devices counted ones (TRED_VIRTUAL_GPUS)."""
+    import os
+    env = os.environ if env is None else env
+    try:
+        r = int(env.get("TRED_REAL_GPUS", "0") or 0)
+    except ValueError:
+        r = 0
+    return r if 0 < r < n_devices else n_devices
 
 
 def usable_cpus():
@@ -283,6 +313,12 @@ def device_entry(index, env):
     untouched."""
     mask = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES") or ""
     entries = [e.strip() for e in mask.split(",") if e.strip()]
+    try:
+        real = int(env.get("TRED_REAL_GPUS", "0") or 0)      # (TRED_VIRTUAL_GPUS: counted device k is physical k mod real)
+    except ValueError:
+        real = 0
+    if real > 0:
+        index %= real
     return entries[index % len(entries)] if entries else str(index)
 
 
@@ -323,7 +359,12 @@ def spawn_ranks(argv, world, n_devices, timeout=None, env=None, stdout=None, cwd
     port = free_port()
     procs = []
     if cpusets == "auto":
-        cpusets = rank_cpusets(world, n_devices, visible=_visible_indices(os.environ if env is None else env)) if n_devices > 0 else None
+        e = os.environ if env is None else env
+        visible = _visible_indices(e)
+        real = real_gpus(n_devices, e) if n_devices > 0 else 0
+        if 0 < real < n_devices:               # virtual devices: the NUMA node is that of the physical device behind each
+            visible = [(visible[k % real] if visible and k % real < len(visible) else k % real) for k in range(n_devices)]
+        cpusets = rank_cpusets(world, n_devices, visible=visible) if n_devices > 0 else None
     for r in range(world):
         dev = (r % n_devices) if n_devices > 0 else None
         renv = rank_env(r, world, port, dev, env)

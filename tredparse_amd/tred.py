@@ -431,7 +431,9 @@ def run_many(task_args, engine, pool=None, batch=64, sink=None, threads=1, lazy_
     the two halves fight over the interpreter lock, 20.1-20.4 k against 20.5 k genotypes/s with five drivers, 23.2 k against
     27.5 k with six --, and several decode chunks per genotyping batch, 14.7 / 11.0 k against 25 k: docs/history.)"""
     n_known = len(task_args) if hasattr(task_args, "__len__") else None
-    own = pool is None and threads > 1 and (n_known is None or n_known > 1)
+    # (with the blocks inflated on a GPU the scan pool is wanted even for one thread: the feeder hands it the samples the
+    #  device could not serve -- with gpu_select that is all a scan thread still does)
+    own = pool is None and (threads > 1 or inflate_device is not None) and (n_known is None or n_known > 1)
     # the first GPU batch is only as large as one round of the scan threads: nothing else can start before it is in
     # (only when there is more than one batch anyway: an extra GPU call costs more than it hides on small inputs)
     first = min(batch, max(1, threads)) if (own or pool is not None) and (n_known is None or n_known > batch) else batch
@@ -828,7 +830,8 @@ def main(args, quiet=False):
                                workers=(3 if (args.gpu_inflate and args.gpu_walk and args.gpu_select) else 2) if args.cpus > 1 else 1)
                 try:
                     run_many(tasks, engine, batch=max(1, args.batch_samples), threads=max(1, args.cpus), lazy_details=True,
-                             inflate_device=device if (args.gpu_inflate and args.cpus > 1) else None, gpu_walk=args.gpu_walk,
+                             inflate_device=device if (args.gpu_inflate and (args.cpus > 1 or (args.gpu_walk and args.gpu_select))) else None,
+                             gpu_walk=args.gpu_walk,
                              gpu_select=args.gpu_select, emit=emit)
                 finally:
                     emit.close()
