@@ -828,6 +828,38 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None)
         shutil.rmtree(root, ignore_errors=True)
 
 
+def run_e2e_wgs(args, spawn=None, make_bams=None, read_leg=None):
+    """The whole-genome-shaped leg (a stated second number, not the headline): the same two legs -- host
+    only, and the plan with inflate, walks and selection on the GPU -- over synthetic BAMs that also hold what a whole-genome
+    file makes this path read through: 30x reads over the 16 kb index windows of every alternative region and the chrY depth
+    windows (synth_bam.background_windows: ~570 stretches, 4.7 Mb, ~8 x the blocks of a locus-only sample).  The mate rescue
+    of bam_parser.py:217-243 is free on the locus-only files (every alternative-locus fetch is empty there) and is most of a
+    sample's blocks here.  A few distinct files hard-linked up to a small cohort; 4 samples per decode call (a sample is
+    300 MB inflated)."""
+    import functools
+    from tredparse_amd import shard
+    if make_bams is None:
+        from tredparse_amd import synth_bam
+        make_bams = functools.partial(synth_bam.make_bams, wgs_like=True)
+    a = argparse.Namespace(**vars(args))
+    a.e2e_samples, a.e2e_distinct = args.e2e_wgs_samples, min(args.e2e_wgs_distinct, args.e2e_wgs_samples)
+    a.e2e_repeats, a.e2e_sweep, a.e2e_inflate_batch, a.e2e_batch = 1, False, 4, 4
+
+    def few_workers(root, n, seed=0, workers=1):       # (a worker holds ~1 GB while it writes a file)
+        return make_bams(root, n, seed=seed, workers=max(1, min(workers, 4)))
+    rec = run_e2e(a, [1], spawn=spawn, make_bams=few_workers, read_leg=read_leg)[1]
+    plan = [l for l in rec.get("legs", []) if l.get("role") == "plan" and "value" in l]
+    if plan:
+        d = plan[0].get("per_driver", [])
+        blocks = sum(x.get("inflate_blocks", 0) for x in d)
+        samples = max(1.0, sum(x.get("select_samples", 0) + x.get("select_declined", 0) for x in d) or plan[0].get("samples", 0))
+        rec["blocks_per_sample"] = blocks / samples if blocks else None
+        rec["walk_call_seconds_per_driver"] = [round(x.get("walk_call", 0.0), 3) for x in d]
+    rec["what"] = ("whole-genome-shaped synthetic BAMs (synth_bam.make_bams(wgs_like=True): the 30 loci's +-10.5 kb AND 30x reads over "
+                   "every alternative region's index window and the chrY depth windows); same legs and rule as end_to_end")
+    return rec
+
+
 def _read_leg(out_dir, drivers):
     ranks, logs = [], []
     for r in range(drivers):
@@ -953,6 +985,12 @@ def compact_line(out):
         h = e.get("host_only_one_driver_per_gpu")
         if h:
             line["end_to_end"]["host_only_one_driver_per_gpu"] = {k: _r(h[k], 3) for k in ("value", "first_pass_value", "seconds")}
+    w = out.get("end_to_end_wgs")
+    if w:
+        line["end_to_end_wgs"] = {k: _r(w[k], 3) for k in ("value", "unit", "drivers", "files", "seconds", "samples", "blocks_per_sample",
+                                                           "outputs_identical", "error") if k in w}
+        if "host_only_one_driver_per_gpu" in w:
+            line["end_to_end_wgs"]["host_only"] = _r(w["host_only_one_driver_per_gpu"]["value"], 1)
     if "legs" in out:
         line["legs"] = [{k: _r(l[k], 4) for k in ("leg", "value", "ms_per_step", "frac", "mix_ceiling_frac", "error") if k in l} for l in out["legs"]]
     if "scaling_sweep" in out:
@@ -962,7 +1000,7 @@ def compact_line(out):
     line["detail"] = "bench_detail.json"
     text = json.dumps(line)
     if len(text) > 4000:                  # never let the line grow past what the driver reads: drop the optional parts
-        for key in ("scaling_sweep", "legs", "kernels_ms_per_step", "cpu_baseline_1core"):
+        for key in ("scaling_sweep", "legs", "kernels_ms_per_step", "cpu_baseline_1core", "end_to_end_wgs"):
             line.pop(key, None)
             text = json.dumps(line)
             if len(text) <= 4000:
@@ -1017,6 +1055,11 @@ def launcher_main(args):
                 rec = e2e[r["n"]]
                 r["end_to_end"] = {k: rec[k] for k in ("value", "unit", "drivers", "devices", "samples", "seconds",
                                                        "host_threads_per_driver", "outputs_identical") if k in rec}
+    if args.e2e_samples > 0 and args.e2e_wgs_samples > 0 and not args.stub:
+        try:
+            out["end_to_end_wgs"] = run_e2e_wgs(args)
+        except Exception as e:                  # (a stated second number: its failure must not take the line down)
+            out["end_to_end_wgs"] = {"error": str(e)}
     if args.legs and not args.stub:
         # the configurations that otherwise only have correctness tests, one rank each on device 0: BASELINE
         # configs[4] and the other read lengths (their own sw_cont_kernel instantiations)
@@ -1103,6 +1146,10 @@ def main():
                     help="BAM files per GPU of the end-to-end legs (0: skip them): the same number at every device count")
     ap.add_argument("--e2e-distinct", type=int, default=512,
                     help="distinct synthetic BAMs made; a larger cohort gets the rest as hard links under their own sample keys")
+    ap.add_argument("--e2e-wgs-samples", type=int, default=64,
+                    help="BAM files of the whole-genome-shaped leg (0: skip it): the loci AND 30x background over every alternative "
+                         "region's index window")
+    ap.add_argument("--e2e-wgs-distinct", type=int, default=8, help="distinct files among them (the rest are hard links)")
     ap.add_argument("--e2e-repeats", type=int, default=3, help="how often the planned end-to-end leg is run (value = the median)")
     ap.add_argument("--e2e-seconds", type=float, default=8.0,
                     help="how long the planned end-to-end leg's drivers keep going over their files (the host-only leg: half)")

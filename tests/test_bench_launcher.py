@@ -280,3 +280,21 @@ def test_mix_ceiling_is_computed_from_the_builds_census_and_the_kernels_counters
     assert bench.mix_ceiling(None, 10, False, cnt, 1, cells[10])[0] is None
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "MIX_CEILING_FRAC" not in src and "0.39" not in src
+
+
+def test_whole_genome_shaped_leg_runs_the_same_two_legs_over_its_own_files(tmp_path, monkeypatch):
+    """run_e2e_wgs: a small cohort of wgs_like files (8 distinct ones hard-linked to 64), the host-only leg and the planned leg
+    once, four samples per decode call; blocks per sample from the drivers' counters."""
+    bench, made, spawned, fake_bams, fake_spawn, read_leg = _fake_e2e(monkeypatch, usable=16)
+
+    def leg_with_counters(out_dir, drivers):
+        ranks, logs = read_leg(out_dir, drivers)
+        for r in ranks:
+            r["driver_seconds"] = {"gpu": 0.1, "inflate_blocks": 46000.0, "select_samples": 10.0, "select_declined": 0.0, "walk_call": 1.5}
+        return ranks, logs
+    rec = bench.run_e2e_wgs(_e2e_args(e2e_wgs_samples=64, e2e_wgs_distinct=8), spawn=fake_spawn, make_bams=fake_bams, read_leg=leg_with_counters)
+    assert made == [8] and [w[:3] for w in spawned] == [(1, 1, 64), (3, 1, 64)] and spawned[1][5:] == ("11", "4")
+    assert [l["role"] for l in rec["legs"]] == ["host_only_one_driver_per_gpu", "plan"] and rec["outputs_identical"] is True
+    assert rec["blocks_per_sample"] == 4600.0 and rec["walk_call_seconds_per_driver"] == [1.5, 1.5, 1.5] and rec["value"] > 0
+    line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "end_to_end_wgs": rec}))
+    assert line["end_to_end_wgs"]["blocks_per_sample"] == 4600.0 and line["end_to_end_wgs"]["host_only"] > 0

@@ -107,6 +107,8 @@ SYN_SAMPLES = {
                dict(coverage=10.0, readlen=250, ins_mean=550.0, ins_sd=80.0, max_units=75, expanded_max=150, expanded_frac=0.3), 0.3),
     "syn100x": (["HD", "DM1", "SCA1", "FXS"],
                 dict(coverage=100.0, min_units=42, max_units=60, expanded_max=200, expanded_frac=0.8), 0.4),
+    # whole-genome-shaped: background reads over the alternative regions' index windows and the chrY depth windows
+    "synwgs": (["HD", "DM1", "FXS", "SCA10"], dict(coverage=10.0, expanded_max=120, expanded_frac=0.5, wgs_like=True), 0.4),
 }
 
 
@@ -125,7 +127,9 @@ def test_synthetic_samples_match_reference(engine, tmp_path, name):
     names, kw, alt_rate = SYN_SAMPLES[name]
     loci = synth_bam.bench_loci() if names is None else [l for l in synth.load_loci() if l["name"] in names]
     assert [l["name"] for l in loci] == gold["loci"]
-    recs, h_true = synth_bam.simulate_sample(gold["seed"], loci, synth.SynthParams(**kw), alt_rate=alt_rate)
+    kw = dict(kw)
+    wgs_like = kw.pop("wgs_like", False)
+    recs, h_true = synth_bam.simulate_sample(gold["seed"], loci, synth.SynthParams(**kw), alt_rate=alt_rate, wgs_like=wgs_like)
     h = hashlib.sha256()
     for k in recs.FIELDS:
         h.update(np.ascontiguousarray(getattr(recs, k)).tobytes())

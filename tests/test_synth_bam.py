@@ -87,6 +87,47 @@ def test_native_scan_finds_what_the_rules_say(sample, alts):
     assert n_unmapped > 0 and (n_alt > 0) == alts
 
 
+def test_whole_genome_shaped_sample_keeps_its_rescued_mates(tmp_path):
+    """synth_bam wgs_like: the sample of tests/golden/run_synall.json["synwgs"] -- four loci plus 10x
+    background reads over the 16 kb index windows of their ~300 alternative regions and the chrY depth windows -- regenerated
+    from its seed (digest checked).  The background is most of the file, none of it is ever selected, and the mates the
+    simulation mismapped into the alternative regions are still found behind it: by the rules (expected_scan), by the
+    native scan, and by the reference itself -- the golden's `details` (the reference's run() through tools/gen_golden.py)
+    list exactly the reads the scan selects and the kernels tag, which the GPU test of the same sample compares in full
+    (test_flags_gpu.py::test_synthetic_samples_match_reference[synwgs])."""
+    import hashlib
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "run_synall.json")))["samples"]["synwgs"]
+    loci = [l for l in synth.load_loci() if l["name"] in gold["loci"]]
+    assert [l["name"] for l in loci] == gold["loci"]
+    p = synth.SynthParams(coverage=10.0, expanded_max=120, expanded_frac=0.5)
+    recs, _ = sb.simulate_sample(gold["seed"], loci, p, alt_rate=0.4, wgs_like=True)
+    h = hashlib.sha256()
+    for k in recs.FIELDS:
+        h.update(np.ascontiguousarray(getattr(recs, k)).tobytes())
+    assert h.hexdigest() == gold["records_sha256"]
+    plain, _ = sb.simulate_sample(gold["seed"], loci, p, alt_rate=0.4)
+    background = recs.locus == sb.BACKGROUND_LOCUS
+    assert background.sum() > 4 * len(plain) and len(recs) == len(plain) + background.sum()
+    wins = sb.background_windows(loci)
+    assert len(wins) > 150 and any(sb.CONTIGS[t] == "chrY" for t, _, _ in wins)          # FXS is X-linked
+    path = str(tmp_path / "synwgs.bam")
+    sb.write_bam(path, recs, sample="synwgs")
+    names = recs.names("synwgs")
+    scan = scan_sample(path, TREDsRepo(), gold["loci"])
+    assert scan.opened and not scan.dropped and scan.gender in ("Male", "Female") and scan.ydepth > 1
+    rescued = 0
+    for k, l in enumerate(loci):
+        reads, depth, gl, tl = sb.expected_scan(recs, l, 150)
+        a, b = scan.reads_of(k)
+        got = [scan.name(i) for i in range(a, b)]
+        assert got == [names[i] for i in reads] and scan.depth[k] == depth, l["name"]
+        assert not any(".{:02d}.".format(sb.BACKGROUND_LOCUS) in n for n in got)          # no background read is selected
+        rescued += int((recs.tid[reads] != sb.CONTIGS.index(l["repeat_location"].split(":")[0])).sum())
+        # the reads the reference reported for this locus are among the selected ones
+        assert set(d[0] for d in gold["tredCalls"][l["name"] + ".details"]) <= set(got)
+    assert rescued >= 4
+
+
 @pytest.mark.gpu
 def test_bam_path_equals_packed_path(tmp_path):
     """BAM -> CLI driver (native scan, PackedUnits) against the packed-batch path fed straight from the simulation's

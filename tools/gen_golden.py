@@ -464,6 +464,9 @@ SYN_SAMPLES = {
                dict(coverage=10.0, readlen=250, ins_mean=550.0, ins_sd=80.0, max_units=75, expanded_max=150, expanded_frac=0.3), 0.3),
     "syn100x": (20260780, ["HD", "DM1", "SCA1", "FXS"],
                 dict(coverage=100.0, min_units=42, max_units=60, expanded_max=200, expanded_frac=0.8), 0.4),
+    # whole-genome-shaped (synth_bam wgs_like): background reads over every alternative region's index window and the chrY
+    # depth windows -- the reference's mate rescue has to walk through them to find the mismapped mates
+    "synwgs": (20260781, ["HD", "DM1", "FXS", "SCA10"], dict(coverage=10.0, expanded_max=120, expanded_frac=0.5, wgs_like=True), 0.4),
 }
 
 
@@ -471,7 +474,9 @@ def syn_sample(name):
     from tredparse_amd import synth_bam
     seed, names, kw, alt_rate = SYN_SAMPLES[name]
     loci = synth_bam.bench_loci() if names is None else [l for l in synth.load_loci() if l["name"] in names]
-    recs, h_true = synth_bam.simulate_sample(seed, loci, synth.SynthParams(**kw), alt_rate=alt_rate)
+    kw = dict(kw)
+    wgs_like = kw.pop("wgs_like", False)
+    recs, h_true = synth_bam.simulate_sample(seed, loci, synth.SynthParams(**kw), alt_rate=alt_rate, wgs_like=wgs_like)
     return loci, recs, h_true
 
 
@@ -484,7 +489,7 @@ def records_digest(recs):
     return h.hexdigest()
 
 
-def gen_synall(loci_unused):
+def gen_synall(loci_unused, only=None):
     """The reference's run() with default flags on synthetic samples with reads at every locus listed: all 30 loci at
     150 bp (BASELINE configs[1] asks for all TRED loci; the reference's two mini-BAMs cover one locus each), ten loci at
     100 bp and at 250 bp (READLEN from the file, other ladder lengths), four loci at 100x with alleles up to 200 repeats
@@ -493,7 +498,11 @@ def gen_synall(loci_unused):
     from tredparse_amd import synth_bam
     ref = _load_full_reference()
     out = {}
-    for name in SYN_SAMPLES:
+    path = os.path.join(GOLD, "run_synall.json")
+    if only is not None and os.path.exists(path):         # (the other samples' records stay as they are)
+        with open(path) as fp:
+            out = json.load(fp)["samples"]
+    for name in (SYN_SAMPLES if only is None else only):
         loci, recs, h_true = syn_sample(name)
         cwd = os.getcwd()
         tmp = tempfile.mkdtemp()
@@ -738,6 +747,8 @@ def main():
         gen_report(loci)
     if "synall" in what:
         gen_synall(loci)
+    if "synwgs" in what:
+        gen_synall(loci, only=["synwgs"])
     if "debug" in what:
         gen_debug(loci)
 

@@ -204,9 +204,79 @@ def _locus_records(rng, li, locus, h_pair, p, tid_of, alt_rate):
     return recs
 
 
-def simulate_sample(seed, loci, p=None, h_pairs=None, alt_rate=0.3):
+BACKGROUND_LOCUS = 99          # the `locus` field (and name part) of whole-genome background reads
+
+
+def background_windows(loci):
+    """What a whole-genome BAM holds and the locus-only samples lack, as far as this path ever reads it: the 16 kb index
+    windows the walks over the loci's alternative regions go through (a region query starts parsing at the linear index'
+    offset of the window that holds its start: htslib, and csrc/bamread.cpp region_chunks, read everything from there to the
+    region's end) and, when a locus is X-linked, the five chrY windows of the sex inference (bam_parser.y_regions).
+    [(contig index, start, end)] -- merged, and without what lies within REACH + 2 kb of a locus (those stretches are the
+    loci's own, simulated with their haplotypes)."""
+    from .bam_parser import y_regions
+    tid_of = {c: i for i, c in enumerate(CONTIGS)}
+    spans = []
+    for locus in loci:
+        for a in locus.get("alts", "").split("|"):
+            if a:
+                c, se = a.split(":")
+                lo, hi = (int(x) for x in se.split("-"))
+                if c in tid_of:
+                    spans.append((tid_of[c], (lo >> 14) << 14, hi))
+    if any(str(l.get("inheritance", "")).startswith("X") for l in loci):
+        spans += [(tid_of[c], (lo >> 14) << 14, hi) for c, lo, hi in y_regions("hg38") if c in tid_of]
+    own = []
+    for locus in loci:
+        c, se = locus["repeat_location"].split(":")
+        lo, hi = (int(x) for x in se.split("-"))
+        own.append((tid_of[c], lo - REACH - 2000, hi + REACH + 2000))
+    merged = []
+    for t, lo, hi in sorted(spans):
+        if merged and merged[-1][0] == t and lo <= merged[-1][2]:
+            merged[-1][2] = max(merged[-1][2], hi)
+        else:
+            merged.append([t, lo, hi])
+    out = []
+    for t, lo, hi in merged:                   # cut the loci's own stretches out
+        pieces = [(lo, hi)]
+        for ot, olo, ohi in own:
+            if ot == t:
+                pieces = [q for a, b in pieces for q in ((a, min(b, olo)), (max(a, ohi), b)) if q[1] - q[0] > 0]
+        out += [(t, a, b) for a, b in pieces]
+    return out
+
+
+def background_records(rng, windows, p):
+    """Plain read pairs at p.coverage over `windows` (background_windows): random bases, one M operation, proper pairs
+    whose mates lie next to them -- none points at a locus, so none is ever selected; the walks only have to get past them."""
+    L = p.readlen
+    parts = []
+    frag0 = 0
+    for t, lo, hi in windows:
+        nf = int(rng.poisson(p.coverage * (hi - lo) / (2.0 * L)))
+        if nf == 0:
+            continue
+        ins = np.clip(np.rint(rng.normal(p.ins_mean, p.ins_sd, nf)), L, 999).astype(np.int64)
+        fs = lo + (rng.random(nf) * max(1, hi - lo)).astype(np.int64)
+        frag = frag0 + np.arange(nf, dtype=np.int64)
+        frag0 += nf
+        for mate in range(2):
+            pos = fs if mate == 0 else fs + ins - L
+            other = fs + ins - L if mate == 0 else fs
+            flag = np.full(nf, 0x1 | 0x2 | (FR1 | FMREV if mate == 0 else FR2 | FREV), np.int64)
+            cig = np.zeros((nf, 3), np.int64)
+            cig[:, 0] = (L << 4) | OP_M
+            parts.append(Records(tid=np.full(nf, t, np.int64), pos=pos, flag=flag, mtid=np.full(nf, t, np.int64), mpos=other,
+                                 tlen=np.where(mate == 0, ins, -ins), frag=frag, locus=np.full(nf, BACKGROUND_LOCUS, np.int64),
+                                 n_cig=np.ones(nf, np.int64), cig=cig, codes=rng.integers(0, 4, (nf, L)).astype(np.uint8)))
+    return parts
+
+
+def simulate_sample(seed, loci, p=None, h_pairs=None, alt_rate=0.3, wgs_like=False):
     """Records of one sample over `loci` (entries of data/treds.json), sorted as a coordinate-sorted BAM is.
-    Returns (Records, h_true int[n_loci, 2])."""
+    wgs_like: also background reads over everything else a whole-genome BAM makes this path read through
+    (background_windows).  Returns (Records, h_true int[n_loci, 2])."""
     p = p or SynthParams()
     rng = np.random.default_rng(seed)
     tid_of = {c: i for i, c in enumerate(CONTIGS)}
@@ -217,6 +287,13 @@ def simulate_sample(seed, loci, p=None, h_pairs=None, alt_rate=0.3):
             h_pairs[big, 1] = rng.integers(p.max_units, p.expanded_max + 1, int(big.sum()))
     h_pairs = np.sort(np.asarray(h_pairs, np.int64), axis=1)
     parts = [_locus_records(rng, li, locus, h_pairs[li], p, tid_of, alt_rate) for li, locus in enumerate(loci)]
+    if wgs_like:
+        ref = parts[0]
+        for b in background_records(rng, background_windows(loci), p):
+            for k in Records.FIELDS:           # (same dtypes and CIGAR width as the loci's records)
+                v = getattr(b, k)
+                setattr(b, k, v.astype(getattr(ref, k).dtype) if k != "cig" else v[:, :ref.cig.shape[1]].astype(ref.cig.dtype))
+            parts.append(b)
     recs = Records.concat(parts)
     order = np.lexsort((np.arange(len(recs)), recs.pos, recs.tid))      # stable: mates / copies keep their order
     return recs.take(order), h_pairs.astype(np.int32)
@@ -245,21 +322,30 @@ def _bgzf_block(data, level):
 _EOF_BLOCK = _bgzf_block(b"", 6)
 
 
-def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False, decoys=0.0, decoy_seed=1):
-    """Write `recs` (sorted) as <path> and <path>.bai.  Returns the number of uncompressed bytes.  split_records: cut the
-    record stream into blocks of `block` bytes wherever that falls (records then straddle blocks, as in files written by
-    samtools) instead of at record boundaries.  decoys: that share of the reads gets base qualities that read as the
-    head of a BAM record of the read's contig (tests of the device walk's guessed record starts: DESIGN 4.5)."""
+def _record_sizes(recs, sample):
+    """(bytes of every record without its 4-byte block_size, name length incl. NUL, bytes of a packed sequence)."""
+    n = len(recs)
+    L = recs.codes.shape[1]
+    name_len = len("{}.{:02d}.{:07d}".format(sample, 0, 0)) + 1 if n else 1
+    if n:                                   # (names are fixed-width as long as the counters stay inside their fields)
+        name_len = max(name_len, len("{}.{:02d}.{:07d}".format(sample, int(recs.locus.max()), int(recs.frag.max()))) + 1)
+    seq_len = (L + 1) // 2
+    return 32 + name_len + 4 * recs.n_cig.astype(np.int64) + seq_len + L, name_len, seq_len
+
+
+def _encode_records(recs, sample, name_len, bins, decoy_mask=None):
+    """The BAM bytes of `recs` (block_size word + record, one after the other) and the records' byte offsets in them."""
     n = len(recs)
     L = recs.codes.shape[1]
     names = recs.names(sample)
-    name_len = len(names[0]) + 1 if n else 1
     name_mat = np.zeros((n, name_len), np.uint8)
     if n:
-        name_mat[:, :name_len - 1] = np.frombuffer("".join(names).encode(), np.uint8).reshape(n, name_len - 1)
-    rend = recs.ref_end
-    end_for_bin = np.where(rend > recs.pos, rend, recs.pos + 1)
-    bins = _reg2bin(recs.pos.astype(np.int64), end_for_bin)
+        width = len(names[0])
+        if all(len(x) == width for x in (names[0], names[-1])) and width == name_len - 1:
+            name_mat[:, :width] = np.frombuffer("".join(names).encode(), np.uint8).reshape(n, width)
+        else:
+            for i, x in enumerate(names):
+                name_mat[i, :len(x)] = np.frombuffer(x.encode(), np.uint8)
     nib = _NIB[recs.codes]
     if L % 2:
         nib = np.concatenate([nib, np.zeros((n, 1), np.uint8)], axis=1)
@@ -293,23 +379,45 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False
     flat[idx] = seq
     idx = (off[:-1] + seq_at + seq.shape[1])[:, None] + np.arange(L)[None, :]
     flat[idx] = 0xff                                                        # no base qualities
-    if decoys > 0 and L >= 48 and n:
+    if decoy_mask is not None and L >= 48 and n:
         fake = np.zeros(1, fixed.dtype)
         fake["bs"], fake["pos"], fake["l_name"], fake["mtid"], fake["mpos"] = 40, 5, 2, -1, -1
-        sel = np.nonzero(np.random.default_rng(decoy_seed).random(n) < decoys)[0]
+        sel = np.nonzero(decoy_mask)[0]
         rows = np.repeat(fake, len(sel))
         rows["tid"] = recs.tid[sel]
         body = np.concatenate([rows.view(np.uint8).reshape(len(sel), 36), np.tile(np.frombuffer(b"a\0", np.uint8), (len(sel), 1))], axis=1)
         at = (off[sel] + seq_at[sel] + seq.shape[1] + 4)[:, None] + np.arange(38)[None, :]
         flat[at] = body
+    return flat, off
+
+
+WRITE_SLICE = 150000          # records encoded at a time (the index matrices of the scatter are 8 bytes per record byte)
+
+
+def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False, decoys=0.0, decoy_seed=1):
+    """Write `recs` (sorted) as <path> and <path>.bai.  Returns the number of uncompressed bytes.  split_records: cut the
+    record stream into blocks of `block` bytes wherever that falls (records then straddle blocks, as in files written by
+    samtools) instead of at record boundaries.  decoys: that share of the reads gets base qualities that read as the
+    head of a BAM record of the read's contig (tests of the device walk's guessed record starts: DESIGN 4.5).
+    Whole-genome-shaped samples (two million records) are encoded WRITE_SLICE records at a time; the bytes are the same."""
+    n = len(recs)
+    rend = recs.ref_end
+    end_for_bin = np.where(rend > recs.pos, rend, recs.pos + 1)
+    bins = _reg2bin(recs.pos.astype(np.int64), end_for_bin)
+    size, name_len, _ = _record_sizes(recs, sample)
+    decoy_mask = (np.random.default_rng(decoy_seed).random(n) < decoys) if (decoys > 0 and n) else None
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(size + 4, out=off[1:])
     header = b"BAM\x01"
     text = "@HD\tVN:1.5\tSO:coordinate\n" + "".join("@SQ\tSN:{}\tLN:{}\n".format(c, CONTIG_LEN) for c in CONTIGS)
     header += struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(CONTIGS))
     for c in CONTIGS:
         header += struct.pack("<i", len(c) + 1) + c.encode() + b"\x00" + struct.pack("<i", CONTIG_LEN)
     # blocks: the header alone, then whole records
-    blob = flat.tobytes()
     if split_records:
+        flat, off2 = _encode_records(recs, sample, name_len, bins, decoy_mask)
+        assert np.array_equal(off, off2)
+        blob = flat.tobytes()
         starts = list(range(0, len(blob), block)) or [0]
         voff = np.zeros(n + 1, np.int64)
         with open(path, "wb") as fp:
@@ -334,10 +442,21 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False
     voff = np.zeros(n + 1, np.int64)
     with open(path, "wb") as fp:
         fp.write(_bgzf_block(header, level))
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            co = fp.tell()
-            voff[a:b] = (co << 16) | (off[a:b] - off[a])
-            fp.write(_bgzf_block(blob[off[a]:off[b]], level))
+        bi = 0
+        while bi < len(cuts) - 1:
+            # the blocks that start within the next WRITE_SLICE records (at least one), encoded together
+            bj = bi + 1
+            while bj < len(cuts) - 1 and cuts[bj + 1] - cuts[bi] <= WRITE_SLICE:
+                bj += 1
+            ra, rb = cuts[bi], cuts[bj]
+            flat, off2 = _encode_records(recs.take(slice(ra, rb)), sample, name_len, bins[ra:rb],
+                                         None if decoy_mask is None else decoy_mask[ra:rb])
+            blob = flat.tobytes()
+            for a, b in zip(cuts[bi:bj], cuts[bi + 1:bj + 1]):
+                co = fp.tell()
+                voff[a:b] = (co << 16) | (off[a:b] - off[a])
+                fp.write(_bgzf_block(blob[off[a] - off[ra]:off[b] - off[ra]], level))
+            bi = bj
         voff[n] = fp.tell() << 16
         fp.write(_EOF_BLOCK)
     # a record's end offset: the next record's start, or the next block's start for the last record of a block
@@ -345,7 +464,7 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False
     for b in cuts[1:-1]:
         vend[b - 1] = voff[b]
     _write_bai(path + ".bai", recs.tid, recs.pos.astype(np.int64), end_for_bin, bins, voff[:-1], vend)
-    return len(blob)
+    return int(off[-1])
 
 
 def _write_bai(path, tid, pos, end, bins, vbeg, vend):
@@ -445,11 +564,12 @@ def bench_loci():
     return [l for l in load_loci() if l["name"] not in ("FXTAS", "AR")]
 
 
-def make_bams(outdir, n_samples, seed=20260101, loci=None, p=None, workers=1, prefix="syn"):
-    """n_samples synthetic BAMs (<outdir>/<prefix>NNNN.bam + .bai); returns [(samplekey, path, h_true)]."""
+def make_bams(outdir, n_samples, seed=20260101, loci=None, p=None, workers=1, prefix="syn", wgs_like=False):
+    """n_samples synthetic BAMs (<outdir>/<prefix>NNNN.bam + .bai); returns [(samplekey, path, h_true)].  wgs_like: with the
+    background a whole-genome BAM adds (simulate_sample): ~15 x the records, ~2 GB of memory per worker while a file is made."""
     loci = loci or bench_loci()
     os.makedirs(outdir, exist_ok=True)
-    tasks = [(seed + i, "{}{:04d}".format(prefix, i), outdir, loci, p) for i in range(n_samples)]
+    tasks = [(seed + i, "{}{:04d}".format(prefix, i), outdir, loci, p, wgs_like) for i in range(n_samples)]
     if workers > 1 and n_samples > 1:
         from concurrent.futures import ProcessPoolExecutor
         with ProcessPoolExecutor(max_workers=min(workers, n_samples)) as ex:
@@ -458,8 +578,8 @@ def make_bams(outdir, n_samples, seed=20260101, loci=None, p=None, workers=1, pr
 
 
 def _make_one(task):
-    seed, key, outdir, loci, p = task
-    recs, h_true = simulate_sample(seed, loci, p)
+    seed, key, outdir, loci, p, wgs_like = task
+    recs, h_true = simulate_sample(seed, loci, p, wgs_like=wgs_like)
     path = os.path.join(outdir, key + ".bam")
     write_bam(path, recs, sample=key)
     return key, path, h_true
