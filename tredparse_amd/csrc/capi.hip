@@ -281,8 +281,10 @@ int tredgpu_create(int device_id, tredgpu_ctx** out) {
     int lo_prio = 0, hi_prio = 0;
     const char* want = getenv("TREDGPU_CTX_PRIORITY");
     const bool high = want && strcmp(want, "high") == 0;
+    const char* split = getenv("TREDGPU_CTX_CUS");
     if ((e = hipSetDevice(device_id)) != hipSuccess ||
-        (e = high && hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) == hipSuccess
+        (e = (split && atoi(split) > 0) ? tredgpu_front::create_partitioned_stream(&c->stream, hipStreamDefault, 0, 1, device_id)
+             : high && hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) == hipSuccess
                  ? hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi_prio) : hipStreamCreate(&c->stream)) != hipSuccess) {
         delete c;
         return fail(nullptr, -10, "cannot initialise device %d: %s", device_id, hipGetErrorString(e));

@@ -168,7 +168,7 @@ int tredgpu_inflater_create(int device_id, tredgpu_inflater** out) {
     (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
     e = hipSetDevice(device_id);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-        e = hipStreamCreateWithPriority(&f->stream[k], hipStreamNonBlocking, lo_prio);
+        e = create_partitioned_stream(&f->stream[k], hipStreamNonBlocking, lo_prio, 0, device_id);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f->done[k], hipEventBlockingSync | hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&f->t0[k]);
         if (e == hipSuccess) e = hipEventCreate(&f->t1[k]);
@@ -177,8 +177,8 @@ int tredgpu_inflater_create(int device_id, tredgpu_inflater** out) {
         e = hipEventCreate(&f->k0[k]);
         if (e == hipSuccess) e = hipEventCreate(&f->k1[k]);
     }
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&f->wstream, hipStreamNonBlocking, lo_prio);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&f->astream, hipStreamNonBlocking, lo_prio);
+    if (e == hipSuccess) e = create_partitioned_stream(&f->wstream, hipStreamNonBlocking, lo_prio, 0, device_id);
+    if (e == hipSuccess) e = create_partitioned_stream(&f->astream, hipStreamNonBlocking, lo_prio, 0, device_id);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->adone, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->aready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->wdone, hipEventBlockingSync | hipEventDisableTiming);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "../../include/tredgpu.h"
 
@@ -53,6 +54,27 @@ struct FetchPiece { int64_t src, dst; int32_t len, pad; };
 constexpr size_t walk_lds_bytes(int cap) { return (size_t)cap * 16; }    // (pair_walk_kernel: the table alone, 2 * cap slots of 64 bits)
 
 constexpr int PW_WAVES = 8, PW_THREADS = PW_WAVES * LANES;      // pair_walk_kernel: a workgroup of 8 wavefronts per region
+
+// TREDGPU_CTX_CUS=N (tuning / A-B): the device's compute units are split between the front end's streams
+// (decode, walks: the first CUs - N bits of the CU mask) and the genotyping context's stream (the last N) -- a genotyping
+// call's dozen short launches then never queue behind a device full of decoder wavefronts, at the price of the decoder's
+// share.  Unset or 0: every stream may use every CU (the default: the front end is decode-bound).
+// which: 0 front end, 1 context.  Returns hipSuccess with *st created (plainly, with `flags` and `priority`, when no split is set).
+inline hipError_t create_partitioned_stream(hipStream_t* st, unsigned flags, int priority, int which, int device) {
+    const char* want = getenv("TREDGPU_CTX_CUS");
+    const int n_ctx = want ? atoi(want) : 0;
+    hipDeviceProp_t prop;
+    if (n_ctx > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && n_ctx < prop.multiProcessorCount) {
+        const int cus = prop.multiProcessorCount;
+        uint32_t mask[16] = {};
+        for (int k = 0; k < cus && k < 512; ++k) {
+            const bool ctx_cu = k >= cus - n_ctx;
+            if (ctx_cu == (which == 1)) mask[k >> 5] |= 1u << (k & 31);
+        }
+        return hipExtStreamCreateWithCUMask(st, (uint32_t)((cus + 31) / 32), mask);
+    }
+    return hipStreamCreateWithPriority(st, flags, priority);
+}
 
 // ---- launchers (each enqueues on `st` and returns hipGetLastError()) ----------------------------------------------------
 // inflate_decode.hip: blocks [first_block, first_block + n_blocks) of the call, one wavefront each

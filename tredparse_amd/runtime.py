@@ -10,7 +10,7 @@ from .bam_parser import scan_sample
 TIMING = {"scan_wait": 0.0, "gpu": 0.0, "format": 0.0, "write": 0.0, "inflate": 0.0, "inflate_blocks": 0, "inflate_failed": 0,
           "inflate_hits": 0, "inflate_misses": 0, "inflate_gpu": 0.0, "walk_regions": 0, "walk_declined": 0,
           "walk_blocks_fetched": 0, "walk_alt_regions": 0, "walk_alt_declined": 0, "walk_call": 0.0, "walk_fetch": 0.0, "pack": 0.0,
-          "merged_chunks": 0, "select_samples": 0, "select_declined": 0}
+          "merged_chunks": 0, "select_samples": 0, "select_declined": 0, "gpu_calls": 0}
 _TIMING_LOCK = threading.Lock()
 
 

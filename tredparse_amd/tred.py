@@ -286,7 +286,7 @@ def genotype_scans(engine, task_args, scans):
             dev = getattr(s, "device", None)
             if dev is not None:
                 dev[0].done()
-    timing_add(gpu=time.perf_counter() - t0)
+    timing_add(gpu=time.perf_counter() - t0, gpu_calls=len(groups))
     return picks, parts
 
 
