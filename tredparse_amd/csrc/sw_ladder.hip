@@ -410,6 +410,14 @@ __device__ __forceinline__ int lane_now() {
 // GENERIC = false is the production kernel: no per-template dump, and no sweep of the suffix alone (an alignment
 // inside an 18-base suffix cannot reach the score filter of 30).  The host picks GENERIC = true when a dump is asked
 // for or some registered ladder has a branch long enough to reach the filter on its own (|branch| * match >= 30).
+// waves per SIMD the 112-row and the 256-row instantiations are compiled for (tuning: make EXTRA="-DSW_WAVES_R7=5"; A/B in
+// profiles/r06_sw_waves_ab.txt)
+#ifndef SW_WAVES_R7
+#define SW_WAVES_R7 4
+#endif
+#ifndef SW_WAVES_R16
+#define SW_WAVES_R16 2
+#endif
 template <int R, int W, bool GENERIC>
 __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
     // One wavefront per workgroup: quads differ a lot in length (pruning), and a wave slot freed by a short
@@ -1074,12 +1082,12 @@ hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, bool generic, in
         // second parameter = waves per SIMD the register allocation is held to
         case 8: sw_cont_kernel<4, 6, false><<<blocks, 64, 0, s>>>(a); break;
         case 9: sw_cont_kernel<4, 6, true><<<blocks, 64, 0, s>>>(a); break;
-        case 14: sw_cont_kernel<7, 4, false><<<blocks, 64, 0, s>>>(a); break;
-        case 15: sw_cont_kernel<7, 4, true><<<blocks, 64, 0, s>>>(a); break;
+        case 14: sw_cont_kernel<7, SW_WAVES_R7, false><<<blocks, 64, 0, s>>>(a); break;
+        case 15: sw_cont_kernel<7, SW_WAVES_R7, true><<<blocks, 64, 0, s>>>(a); break;
         case 20: sw_cont_kernel<10, 4, false><<<blocks, 64, 0, s>>>(a); break;
         case 21: sw_cont_kernel<10, 4, true><<<blocks, 64, 0, s>>>(a); break;
-        case 32: sw_cont_kernel<16, 2, false><<<blocks, 64, 0, s>>>(a); break;
-        case 33: sw_cont_kernel<16, 2, true><<<blocks, 64, 0, s>>>(a); break;
+        case 32: sw_cont_kernel<16, SW_WAVES_R16, false><<<blocks, 64, 0, s>>>(a); break;
+        case 33: sw_cont_kernel<16, SW_WAVES_R16, true><<<blocks, 64, 0, s>>>(a); break;
         case 40: sw_cont_kernel<20, 2, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 320 bp (2 x 300 bp runs)
         case 41: sw_cont_kernel<20, 2, true><<<blocks, 64, 0, s>>>(a); break;
         case 64: sw_cont_kernel<32, 1, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 480 bp (512 rows: the packed values' nine row bits)
