@@ -337,7 +337,9 @@ def rank_main(args):
         lanes = cols * 4 * 16 * rpl                # cells the wavefronts occupy: 4 read slots x 16 lanes x R rows
         # (the generic variant runs when a ladder's branch alone can pass the score filter: csrc/capi.hip run_sw_device)
         generic = any(max(len(k[0]), len(k[2])) >= 30 for k in batch.ladders)
-        ceiling, ceiling_basis = mix_ceiling(load_census(), rpl, generic, cnt, launches, swept)
+        census = load_census()
+        ceiling, ceiling_basis = mix_ceiling(census, rpl, generic, cnt, launches, swept)
+        waves = (census_entry(census, rpl, generic) or {}).get("waves_per_simd", "?")
         alg_bytes = int(batch.packed.nbytes + n * 12 + n * 5)  # packed reads + offsets/lengths in, tag/h/score out
         traffic, traffic_src = (None, "counters of the 1 000-sample 150 bp config3 batch only") \
             if (args.workload, args.readlen, args.samples) != ("config3", 150, 1000) else pmc_traffic("sw_cont_kernel", _lib.version())
@@ -353,7 +355,7 @@ def rank_main(args):
                        "units_per_step_per_gpu": g, "reads_per_step_per_gpu": n, "coverage": args.coverage_used,
                        "readlen": args.readlen, "maxinsert": 300, "alleles": WORKLOADS[args.workload]["alleles"],
                        "parallelism": "sample-sharded x{} (no collective)".format(world)},
-            "roofline": {"kernel": "sw_cont_kernel<{},{}>".format(rpl, {4: 6, 7: 4, 10: 4, 16: 2, 20: 2}[rpl]), "bound": "valu",
+            "roofline": {"kernel": "sw_cont_kernel<{},{}>".format(rpl, waves), "bound": "valu",
                          "achieved": swept / sw_s / 1e12, "peak": PEAK_TCUPS, "unit": "TCUPS",
                          "frac": swept / sw_s / 1e12 / PEAK_TCUPS, "mix_ceiling_frac": ceiling, "mix_ceiling_basis": ceiling_basis,
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -929,6 +931,14 @@ def load_census():
         return None
 
 
+def census_entry(census, rpl, generic):
+    """The census of sw_cont_kernel<rpl, W, generic> (W: whatever the build compiled it for)."""
+    for k in (census or {}).get("kernels", {}).values():
+        if k["rows_per_lane"] == rpl and bool(k["generic"]) == bool(generic):
+            return k
+    return None
+
+
 def mix_ceiling(census, rpl, generic, counters, launches, swept_cells_per_launch):
     """roofline.mix_ceiling_frac: the fraction of `peak` (2-cycle issue, 10 ops per cell) this launch could have reached had
     the kernel done nothing but sweep the columns it swept, each at the issue cost of its own column block: the kernel's work
@@ -939,7 +949,7 @@ def mix_ceiling(census, rpl, generic, counters, launches, swept_cells_per_launch
     profiles/r05_sw_isa_column.txt) and every stall is what separates `frac` from it.  (null, reason) without a census."""
     if census is None:
         return None, "no census of this build's sw_ladder.hip (tools/isa_census.py)"
-    k = census["kernels"].get("{},{},{}".format(rpl, {4: 6, 7: 4, 10: 4, 16: 2, 20: 2, 32: 1}[rpl], int(bool(generic))))
+    k = census_entry(census, rpl, generic)
     if k is None or launches <= 0 or swept_cells_per_launch <= 0:
         return None, "no census entry for this instantiation"
     cycles = (counters["trunk_cols"] * k["trunk_cycles_per_column"] + counters["continuation_cols"] * k["free_cycles_per_column"]) / launches

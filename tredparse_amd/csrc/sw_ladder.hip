@@ -410,13 +410,28 @@ __device__ __forceinline__ int lane_now() {
 // GENERIC = false is the production kernel: no per-template dump, and no sweep of the suffix alone (an alignment
 // inside an 18-base suffix cannot reach the score filter of 30).  The host picks GENERIC = true when a dump is asked
 // for or some registered ladder has a branch long enough to reach the filter on its own (|branch| * match >= 30).
-// waves per SIMD the 112-row and the 256-row instantiations are compiled for (tuning: make EXTRA="-DSW_WAVES_R7=5"; A/B in
-// profiles/r06_sw_waves_ab.txt)
+// Waves per SIMD each instantiation is compiled for (make EXTRA="-DSW_WAVES_R10=5" builds a variant; tools/sw_waves_ab.sh).
+// Round 6 (profiles/r06_sw_waves_ab.txt): the 112-row kernel at 6 instead of 4 (80 VGPRs, a few spilled: 12.43 -> 12.06 ms
+// per 500-sample step at 100 bp, frac 0.306 -> 0.334) and the 256-row kernel at 3 instead of 2 (168 VGPRs, 50 spilled to
+// scratch that stays in L1/L2: 19.29 -> 16.74 ms at 250 bp, frac 0.274 -> 0.319) -- the waves hide more of the DPP scan's
+// and the LDS notes' latency than the spills cost; the 160-row kernel loses at 5 and 6 (15.98 -> 16.57 / 18.21 ms) and stays at 4.
+#ifndef SW_WAVES_R4
+#define SW_WAVES_R4 6
+#endif
 #ifndef SW_WAVES_R7
-#define SW_WAVES_R7 4
+#define SW_WAVES_R7 6
+#endif
+#ifndef SW_WAVES_R10
+#define SW_WAVES_R10 4
 #endif
 #ifndef SW_WAVES_R16
-#define SW_WAVES_R16 2
+#define SW_WAVES_R16 3
+#endif
+#ifndef SW_WAVES_R20
+#define SW_WAVES_R20 2
+#endif
+#ifndef SW_WAVES_R32
+#define SW_WAVES_R32 1
 #endif
 template <int R, int W, bool GENERIC>
 __global__ __launch_bounds__(64, W) void sw_cont_kernel(SwArgs a) {
@@ -1080,18 +1095,18 @@ hipError_t launch_sw_ladder(const SwArgs& a, int rows_per_lane, bool generic, in
     generic = generic || a.out_dump != nullptr;
     switch (rows_per_lane * 2 + (generic ? 1 : 0)) {
         // second parameter = waves per SIMD the register allocation is held to
-        case 8: sw_cont_kernel<4, 6, false><<<blocks, 64, 0, s>>>(a); break;
-        case 9: sw_cont_kernel<4, 6, true><<<blocks, 64, 0, s>>>(a); break;
+        case 8: sw_cont_kernel<4, SW_WAVES_R4, false><<<blocks, 64, 0, s>>>(a); break;
+        case 9: sw_cont_kernel<4, SW_WAVES_R4, true><<<blocks, 64, 0, s>>>(a); break;
         case 14: sw_cont_kernel<7, SW_WAVES_R7, false><<<blocks, 64, 0, s>>>(a); break;
         case 15: sw_cont_kernel<7, SW_WAVES_R7, true><<<blocks, 64, 0, s>>>(a); break;
-        case 20: sw_cont_kernel<10, 4, false><<<blocks, 64, 0, s>>>(a); break;
-        case 21: sw_cont_kernel<10, 4, true><<<blocks, 64, 0, s>>>(a); break;
+        case 20: sw_cont_kernel<10, SW_WAVES_R10, false><<<blocks, 64, 0, s>>>(a); break;
+        case 21: sw_cont_kernel<10, SW_WAVES_R10, true><<<blocks, 64, 0, s>>>(a); break;
         case 32: sw_cont_kernel<16, SW_WAVES_R16, false><<<blocks, 64, 0, s>>>(a); break;
         case 33: sw_cont_kernel<16, SW_WAVES_R16, true><<<blocks, 64, 0, s>>>(a); break;
-        case 40: sw_cont_kernel<20, 2, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 320 bp (2 x 300 bp runs)
-        case 41: sw_cont_kernel<20, 2, true><<<blocks, 64, 0, s>>>(a); break;
-        case 64: sw_cont_kernel<32, 1, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 480 bp (512 rows: the packed values' nine row bits)
-        case 65: sw_cont_kernel<32, 1, true><<<blocks, 64, 0, s>>>(a); break;
+        case 40: sw_cont_kernel<20, SW_WAVES_R20, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 320 bp (2 x 300 bp runs)
+        case 41: sw_cont_kernel<20, SW_WAVES_R20, true><<<blocks, 64, 0, s>>>(a); break;
+        case 64: sw_cont_kernel<32, SW_WAVES_R32, false><<<blocks, 64, 0, s>>>(a); break;   // reads up to 480 bp (512 rows: the packed values' nine row bits)
+        case 65: sw_cont_kernel<32, SW_WAVES_R32, true><<<blocks, 64, 0, s>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
