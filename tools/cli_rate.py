@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The product's command line at cohort scale (GPU box): N sample keys over D distinct synthetic 30x BAMs (hard links), then
 
-    python -m tredparse_amd.tred samples.csv --workdir w --gpu-inflate --gpu-walk
+    python -m tredparse_amd.tred samples.csv --workdir w --gpu-inflate --gpu-walk --gpu-select
 
 with NO process or thread count -- `--drivers auto` takes shard.driver_plan -- timed as a whole (start-up of the driver
 processes included) and between the first and the last output file.  VERDICT r4 item 3: within 10 % of bench.py's plan.
@@ -42,7 +42,7 @@ def main():
         fp.write("\n".join(rows) + "\n")
     work = os.path.join(root, "work")
     names = [l["name"] for l in synth_bam.bench_loci()]
-    argv = [sys.executable, "-m", "tredparse_amd.tred", csv, "--workdir", work, "--gpu-inflate", "--gpu-walk"]
+    argv = [sys.executable, "-m", "tredparse_amd.tred", csv, "--workdir", work, "--gpu-inflate", "--gpu-walk", "--gpu-select"]
     for t in names:
         argv += ["--tred", t]
     t0 = time.time()
@@ -56,7 +56,8 @@ def main():
     print(json.dumps({"samples": n, "distinct_bams": len(made), "loci": len(names), "exit_code": out.returncode, "json_files": len(files),
                       "elapsed_s": round(dt, 2), "genotypes_per_s_whole_command": round(len(files) * len(names) / dt, 1),
                       "first_to_last_file_s": round(span, 2), "genotypes_per_s_behind_the_first_tenth": round(steady, 1),
-                      "plan": shard.driver_plan(shard.usable_cpus(), 1), "stderr_tail": out.stderr[-300:]}))
+                      "plan": shard.driver_plan(shard.usable_cpus(), 1), "extra_arguments": extra, "usable_cpus": shard.usable_cpus(),
+                      "stderr_tail": out.stderr[-300:]}))
     shutil.rmtree(root, ignore_errors=True)
 
 

@@ -39,8 +39,20 @@ namespace {
 constexpr int NT = 128;   // threads per workgroup (one unit at a time)
 // waves per SIMD the two per-unit front kernels are compiled for, and the workgroups their launches keep resident
 // (256 CUs x what registers and LDS admit per CU; further units come through the ticket queues)
-constexpr int KDE_WAVES = 3, KDE_BLOCKS = 1536;     // 160 VGPRs: the convolution's window registers
-constexpr int PREP_WAVES = 4, PREP_BLOCKS = 2048;   // 128 VGPRs (3 waves: 1.16 ms per 30 000 units, 4 waves: 1.02)
+#ifndef GRID_KDE_WAVES
+#define GRID_KDE_WAVES 3
+#endif
+#ifndef GRID_PREP_WAVES
+#define GRID_PREP_WAVES 4
+#endif
+#ifndef GRID_PAIRS_WAVES
+#define GRID_PAIRS_WAVES 3
+#endif
+#ifndef GRID_REDUCE_WAVES
+#define GRID_REDUCE_WAVES 4
+#endif
+constexpr int KDE_WAVES = GRID_KDE_WAVES, KDE_BLOCKS = 512 * GRID_KDE_WAVES;     // 160 VGPRs: the convolution's window registers
+constexpr int PREP_WAVES = GRID_PREP_WAVES, PREP_BLOCKS = 512 * GRID_PREP_WAVES;   // 128 VGPRs (3 waves: 1.16 ms per 30 000 units, 4 waves: 1.02)
 constexpr int XPER = (TREDGPU_SPAN + NT - 1) / NT;  // KDE x-values per thread
 constexpr int SPAN = TREDGPU_SPAN;
 constexpr int MAXOBS = 256;  // distinct FULL / PREF sizes per unit
@@ -1061,7 +1073,7 @@ struct RowIn {
     double f1, f2, r1v;
 };
 
-__global__ __launch_bounds__(256) void grid_pairs_kernel(GridArgs a, const UnitDesc* descs, double* pool,
+__global__ __launch_bounds__(256, GRID_PAIRS_WAVES) void grid_pairs_kernel(GridArgs a, const UnitDesc* descs, double* pool,
                                                          const int* item_unit, Best* item_best, int item_region,
                                                          GridCounters* ctr) {
     const int lane = threadIdx.x & 63;
@@ -1269,7 +1281,7 @@ __device__ __forceinline__ double block_sum_r(double v, double* red) {
 }
 
 template <bool JOINT>   // JOINT: also the sparse joint distribution (tredgpu_likelihood_grid_joint)
-__global__ __launch_bounds__(NR, 4) void grid_reduce_kernel(GridArgs a, const UnitDesc* descs, double* pool,
+__global__ __launch_bounds__(NR, GRID_REDUCE_WAVES) void grid_reduce_kernel(GridArgs a, const UnitDesc* descs, double* pool,
                                                          const Best* item_best, GridCounters* ctr) {
     __shared__ ReduceShared S;
     const int tid = threadIdx.x;
