@@ -620,6 +620,7 @@ def e2e_main(args):
         if dist is not None:
             dist.barrier()
         t0 = time.time()
+        cpu0 = time.process_time()
         deadline[0] = t0 + args.e2e_seconds
         tred.run_many(cohort(), engine, batch=args.e2e_batch, threads=threads, **kw)
         if emit is not None:
@@ -629,11 +630,12 @@ def e2e_main(args):
         os.chdir(cwd)
     log.sort()
     np.save(os.path.join(out_dir, "e2e_log{}.npy".format(rank)), np.array(log, np.float64).reshape(-1, 4))
+    cpu_s = time.process_time() - cpu0
     rec = {"rank": rank, "device": os.environ.get("TRED_RANK_DEVICE", "0"), "t_process": t_proc, "t_begin": t0, "t_end": t1,
            "files": len(mine), "host_threads": threads, "first_chunk": min(args.e2e_batch, threads, max(1, len(mine))),
            "driver_seconds": {k: round(v, 4) for k, v in tred.TIMING.items()},
            "bam_bytes": sum(os.path.getsize(b) for b in bams[lo:hi]), "digests": _output_digests(work),
-           "pinned_MB": round(tred.pinned_bytes() / 1e6, 1)}
+           "pinned_MB": round(tred.pinned_bytes() / 1e6, 1), "cpu_seconds": round(cpu_s, 3), "samples_logged": len(log)}
     with open(os.path.join(out_dir, "e2e_rank{}.json".format(rank)), "w") as fp:
         json.dump(rec, fp)
     if dist is not None:
@@ -797,6 +799,8 @@ def run_e2e(args, device_counts=(1,), spawn=None, make_bams=None, read_leg=None)
                                       **r["driver_seconds"]} for r in ranks]
                 leg["bam_MB"] = sum(r["bam_bytes"] for r in ranks) / 1e6
                 leg["pinned_MB_per_gpu"] = round(sum(r.get("pinned_MB", 0.0) for r in ranks) / max(1, n_devices), 1)
+                if all("cpu_seconds" in r for r in ranks):      # process CPU time (all threads, the HIP runtime's included) per sample
+                    leg["host_cpu_ms_per_sample"] = round(1e3 * sum(r["cpu_seconds"] for r in ranks) / max(1, sum(r["samples_logged"] for r in ranks)), 3)
                 legs.append(leg)
             good = [l for l in legs if "value" in l]
             plan = sorted([l for l in good if l["role"] == "plan"], key=lambda l: l["value"])
@@ -991,7 +995,7 @@ def compact_line(out):
     if e:
         line["end_to_end"] = {k: _r(e[k], 3) for k in ("value", "unit", "first_pass_value", "whole_run_value", "startup_s", "drivers",
                                                        "devices", "host_threads_per_driver", "gpu_inflate", "gpu_walk", "gpu_select", "seconds", "samples",
-                                                       "files", "pinned_MB_per_gpu", "outputs_identical", "repeats", "min", "max", "oversubscribed", "error") if k in e}
+                                                       "files", "pinned_MB_per_gpu", "host_cpu_ms_per_sample", "outputs_identical", "repeats", "min", "max", "oversubscribed", "error") if k in e}
         h = e.get("host_only_one_driver_per_gpu")
         if h:
             line["end_to_end"]["host_only_one_driver_per_gpu"] = {k: _r(h[k], 3) for k in ("value", "first_pass_value", "seconds")}

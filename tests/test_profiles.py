@@ -40,3 +40,18 @@ def test_round_summaries_come_from_one_build_the_trees():
             versions[os.path.basename(p)] = json.load(fp).get("library_version", "")
     assert len(set(versions.values())) == 1, versions
     assert all(v.endswith("src " + tree_hash()) for v in versions.values()), (versions, tree_hash())
+
+
+def test_round_campaign_records_name_the_trees_build_too():
+    """the fuzz campaigns, the CLI rate and the rehearsal records of the round carry the library they ran on (their
+    "library" field = tredgpu_version()) -- the same build as the counter summaries, the tree's."""
+    import pytest
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", ROUND + "_fuzz_*.json")) + glob.glob(os.path.join(ROOT, "profiles", ROUND + "_cli_rate*.json")))
+    if not paths:
+        pytest.skip("no {} campaign records under profiles/ yet".format(ROUND))
+    want = "src " + tree_hash()
+    for p in paths:
+        with open(p) as fp:
+            rec = json.load(fp)
+        lib = rec.get("library") or rec.get("library_version") or ""
+        assert lib.endswith(want), (os.path.basename(p), lib, want)

@@ -21,6 +21,13 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 
 
+def _version():
+    """tredgpu_version() of the tree's library, asked in a child (this process stays off the GPU runtime)."""
+    out = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from tredparse_amd import _lib; print(_lib.version())" % ROOT],
+                         capture_output=True, text=True)
+    return out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ""
+
+
 def main():
     from tredparse_amd import shard, synth_bam
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
@@ -56,7 +63,7 @@ def main():
     print(json.dumps({"samples": n, "distinct_bams": len(made), "loci": len(names), "exit_code": out.returncode, "json_files": len(files),
                       "elapsed_s": round(dt, 2), "genotypes_per_s_whole_command": round(len(files) * len(names) / dt, 1),
                       "first_to_last_file_s": round(span, 2), "genotypes_per_s_behind_the_first_tenth": round(steady, 1),
-                      "plan": shard.driver_plan(shard.usable_cpus(), 1), "extra_arguments": extra, "usable_cpus": shard.usable_cpus(),
+                      "plan": shard.driver_plan(shard.usable_cpus(), 1), "library": _version(), "extra_arguments": extra, "usable_cpus": shard.usable_cpus(),
                       "stderr_tail": out.stderr[-300:]}))
     shutil.rmtree(root, ignore_errors=True)
 

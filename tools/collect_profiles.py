@@ -3,7 +3,7 @@
 (<round>_<leg>_pmc_summary.json, <round>_<leg>_kernel_stats.csv; the headline leg also as <round>_pmc_summary.json, the
 name bench.py looks up counter traffic under) and refuses a set taken on more than one build.
 
-  python3 tools/collect_profiles.py r05
+  python3 tools/collect_profiles.py r06
 """
 import glob
 import json
@@ -44,4 +44,4 @@ def main(rnd):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r05")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r06")

@@ -85,6 +85,8 @@ def campaign(rounds=6, seed=1, max_pairs=20000):
 def main():
     a = [int(x) for x in sys.argv[1:4]]
     res = campaign(*a)
+    from tredparse_amd import _lib
+    res["library"] = _lib.version()
     print(json.dumps(res))
     return 1 if res["mismatches"] else 0
 

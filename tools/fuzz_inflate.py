@@ -126,4 +126,7 @@ def campaign(rounds=4, seed=1, per_round=300):
 
 
 if __name__ == "__main__":
-    print(json.dumps(campaign(int(sys.argv[1]) if len(sys.argv) > 1 else 4, int(sys.argv[2]) if len(sys.argv) > 2 else 1)))
+    res = campaign(int(sys.argv[1]) if len(sys.argv) > 1 else 4, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    from tredparse_amd import _lib
+    res["library"] = _lib.version()
+    print(json.dumps(res))

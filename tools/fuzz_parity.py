@@ -169,6 +169,8 @@ def campaign(rounds=12, seed=1):
 
 def main():
     res = campaign(int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    from tredparse_amd import _lib
+    res["library"] = _lib.version()
     print(json.dumps(res))
     return 1 if (res["mismatches"] or res["pair_mismatches"]) else 0
 

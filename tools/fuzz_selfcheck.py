@@ -75,6 +75,8 @@ def campaign(rounds=20, seed=1):
 
 def main():
     res = campaign(*[int(x) for x in sys.argv[1:3]])
+    from tredparse_amd import _lib
+    res["library"] = _lib.version()
     print(json.dumps(res))
     return 1 if res["mismatches"] else 0
 

@@ -2,7 +2,7 @@
 #   every rocprofv3 summary (tools/profile_all.sh), the randomised campaigns, the product CLI's rate, the concurrency probe,
 #   the default bench (as the driver runs it) and the GPU test suite.  Everything lands under gpurun_out/ and profiles/.
 cd $GRAFT_REPO_ROOT
-R=${1:-r05}
+R=${1:-r06}
 mkdir -p gpurun_out
 O=gpurun_out/${R}_final.txt; : > $O
 python -c "from tredparse_amd import _lib; print(_lib.version())" >> $O

@@ -7,7 +7,7 @@
 # Results land in gpurun_out/prof_<ROUND>_*/; tools/collect_profiles.py copies the summaries into profiles/ under the
 # round's names and checks that all of them carry the same library_version (tests/test_profiles.py checks it again on CPU).
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 STEPS=3 bash tools/profile_round.sh ${R}_headline > gpurun_out/prof_${R}_headline.log 2>&1

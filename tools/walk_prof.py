@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""The front-end call alone (GPU box): tredgpu_inflate_walk -- decode, pair walks (chain / parse / resolve), alternative-locus
-walks -- on m synthetic 30x samples, three times; prints the regions walked and the device time of the pair walk's
-launches.  `rocprofv3 --kernel-trace --stats -- python3 tools/walk_prof.py 16 tredparse_amd/libtredgpu.so <dir>` is how the
+"""The front end (GPU box) on m synthetic 30x samples per call, three calls: by default as the product drives it (round 6:
+tred.run_many with gpu_select -- decode, pair walks, alternative-locus walks, read selection, then the genotyping call over
+the reads packed on the device); WALK_PROF_PRODUCT=0: tredgpu_inflate_walk alone as in round 5 -- decode, pair walks (chain /
+parse / resolve), alternative-locus walks --, printing the regions walked and the device time of the pair walk's launches.  `rocprofv3 --kernel-trace --stats -- python3 tools/walk_prof.py 16 tredparse_amd/libtredgpu.so <dir>` is how the
 kernels' rocprofv3 summaries under profiles/ are taken (tools/profile_all.sh; the BAMs made beforehand with
 `python tools/walk_prof.py make <dir>`: a process under the profiler must not fork the workers that write them).
 
@@ -39,6 +40,24 @@ def main():
     repo = TREDsRepo("hg38", sites=os.path.join(root, "no_sites"))
     names = [l["name"] for l in synth_bam.bench_loci()]
     loci = [repo[n] for n in names]
+    if os.environ.get("WALK_PROF_PRODUCT", "1") != "0":
+        # round 6: the product's front end as run_many drives it -- decode, walks, read selection (select_kernel), then the
+        # genotyping call over the reads packed on the device (pack_selected_kernel + the SW / tally / grid kernels at this
+        # batch size) -- three chunks of m samples
+        from tredparse_amd import tred
+        from tredparse_amd.engine import Engine
+        engine = Engine(0)
+        tasks = [("w%04d" % i, bams[i % len(bams)], repo, names, 300, False, False, True, True, "ERROR") for i in range(3 * m)]
+        for k in tred.TIMING:
+            tred.TIMING[k] = 0
+        got = []
+        tred.run_many(tasks, engine, batch=m, threads=2, lazy_details=True, sink=got.append, inflate_device=0, gpu_walk=True, gpu_select=True)
+        print(json.dumps({"library": _lib.version(), "samples": m, "chunks": 3, "results": len(got),
+                          "select_samples": int(tred.TIMING["select_samples"]), "select_declined": int(tred.TIMING["select_declined"]),
+                          "walk_blocks_fetched": int(tred.TIMING["walk_blocks_fetched"]), "regions": int(tred.TIMING["walk_regions"]),
+                          "alt_regions": int(tred.TIMING["walk_alt_regions"]), "blocks": int(tred.TIMING["inflate_blocks"])}))
+        tred.release_inflaters()
+        return
     inf = _lib.Inflater(0)
     hs = [bam_parser.open_bam(bams[k % len(bams)]) for k in range(m)]
     plans, tabs = [], []

@@ -6,8 +6,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
+
+#include <unistd.h>
 
 #include "tredgpu_internal.h"
 #include "inflater_internal.h"
@@ -40,6 +43,7 @@ struct tredgpu_ctx {
     // workspaces (grow-only, reused across calls)
     Buf ws_quads, ws_counter, ws_drop, ws_grid, ws_stats, ws_perm, ws_class, ws_gdesc, ws_gtile, ws_gctr, ws_ucnt, ws_bins, ws_kde;
     int* h_pin = nullptr;  // pinned word for small read-backs
+    hipEvent_t sync_ev = nullptr;  // stream_sync's event
     size_t grid_pool_bytes = GRID_POOL_BYTES;   // TREDGPU_GRID_POOL_MB overrides (tuning / tests of the multi-pass path)
     Buf st[40];  // staging for HOST-memory calls
     // pinned arena of the HOST-memory calls: copies from / to the caller's pageable arrays go through it, so that they are
@@ -132,7 +136,24 @@ void* pin_alloc(tredgpu_ctx* c, size_t bytes) {
 // wait for the context's stream; then hand the read-backs that went through the pinned arena to their arrays and start
 // the arena afresh (nothing of it is in flight any more)
 hipError_t stream_sync(tredgpu_ctx* c) {
-    const hipError_t e = hipStreamSynchronize(c->stream);
+    // hipStreamSynchronize spins: a driver process whose genotyping call shares the device with three processes' decoders
+    // sits in it for 40 ms per call -- a core per driver burnt on a box that is short of cores (8 CPUs: 36 k genotypes/s).
+    // So: a short spin for the calls that are nearly done (the kernel-path benchmark's step ends within microseconds of
+    // its last launch), then the event is polled asleep, as the inflater's calls are (inflater_api.hip wait_asleep).
+    hipError_t e = hipSuccess;
+    if (c->sync_ev == nullptr && hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming) != hipSuccess) c->sync_ev = nullptr;
+    if (c->sync_ev != nullptr && (e = hipEventRecord(c->sync_ev, c->stream)) == hipSuccess) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (;;) {
+            const hipError_t q = hipEventQuery(c->sync_ev);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { e = q; break; }
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) > 300000LL) usleep(100);
+        }
+    } else
+        e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess)
         for (const auto& o : c->pin_out) memcpy(o.host, o.pinned, o.bytes);
     c->pin_out.clear();
@@ -308,6 +329,7 @@ void tredgpu_destroy(tredgpu_ctx* c) {
     for (auto& t : c->timers)
         for (auto& ev : t.pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     for (auto& b : c->pin) (void)hipHostFree(b.p);
     c->pin.clear();
     (void)hipStreamDestroy(c->stream);
