@@ -270,3 +270,28 @@ def test_feeder_with_the_selection_on_the_device_gives_the_plain_scans(cohort, m
         for k in range(len(s.names)):
             for x, y in zip(s.pair_lengths(k), plain.pair_lengths(k)):
                 assert np.array_equal(x, y), (a[0], k)
+
+
+def test_a_failed_call_over_device_selected_reads_falls_back_to_the_host_scan(cohort, monkeypatch):
+    """tredgpu_genotype_selected fails as a whole (here: the engine raises): the chunk's samples are scanned on the host after all
+    and genotyped the host-packed way -- every sample still comes out, with the keys of the host-only run."""
+    from tests.fake_engine import FakeEngine
+    from tredparse_amd import _lib
+    if not hasattr(bamio.AlignmentFile(cohort[0][1]), "plan_walks"):
+        pytest.skip("no native BAM layer")
+    monkeypatch.setattr("tredparse_amd._lib.Inflater", ModelInflater)
+    t.release_inflaters()
+
+    class Failing(FakeEngine):
+        def genotype_selected(self, scans, **kw):
+            raise _lib.TredGpuError("the device call failed")
+    tasks = [a for a in cohort if a[0] != "missing"][:5]
+    got = t.run_many(tasks, Failing(seed=2, odd_units=False), batch=3, threads=2, lazy_details=False, inflate_device=0, gpu_walk=True, gpu_select=True)
+    want = t.run_many(tasks, FakeEngine(seed=2, odd_units=False), batch=3, threads=2, lazy_details=False)
+    t.release_inflaters()
+    assert [g["samplekey"] for g in got] == [a[0] for a in tasks]
+    for g, w in zip(got, want):
+        assert set(g["tredCalls"]) == set(w["tredCalls"]) and g["tredCalls"]["inferredGender"] == w["tredCalls"]["inferredGender"]
+        for k, v in w["tredCalls"].items():
+            if k.endswith((".DP", ".PEDP", ".PEG", ".PET")) or k in ("depthY", "readLen"):
+                assert g["tredCalls"][k] == v, k

@@ -266,6 +266,11 @@ def _genotype(engine, picks, o):
 
 
 def genotype_scans(engine, task_args, scans):
+    from ._lib import TredGpuError
+    return _genotype_scans(engine, task_args, scans, TredGpuError)
+
+
+def _genotype_scans(engine, task_args, scans, TredGpuError):
     """GPU half of a batch: the kernels' results for every unit of the scans, (picks, parts) with parts as _genotype
     returns them (unit_results turns them into per-unit views).
     The kernel-side options of a GPU batch are the batch's: tasks that differ in them go in separate batches (the CLI's
@@ -283,7 +288,24 @@ def genotype_scans(engine, task_args, scans):
     parts = {}
     try:
         for key, (o, sub) in groups.items():
-            parts.update(_genotype_selected(engine, sub, o) if key[-1] else _genotype(engine, sub, o))
+            if not key[-1]:
+                parts.update(_genotype(engine, sub, o))
+                continue
+            try:
+                parts.update(_genotype_selected(engine, sub, o))
+            except TredGpuError as e:
+                # the call over the device-held reads failed as a whole: those samples are scanned on the host after all and
+                # go the host-packed way, whose retries cost a bad unit only itself (scans[] is the caller's list: the
+                # writers find the host's scan there)
+                logger.error("GPU batch over device-selected reads failed (%s); scanning its %d samples on the host", e, len(sub))
+                again = []
+                for si, s, _ in sub:
+                    h = collect_sample(task_args[si])
+                    scans[si] = h
+                    picks[si] = (si, h, [k for k in range(len(h.names)) if k not in h.dropped] if h.opened else [])
+                    again.append(picks[si])
+                    s.device[0].done()
+                parts.update(_genotype(engine, again, o))
     finally:
         for _, s, _ in picks:                  # the inflaters that held the device's selections are the feeder's again
             dev = getattr(s, "device", None)
