@@ -284,7 +284,7 @@ extern "C" {
 #ifndef TREDGPU_SRC_HASH
 #define TREDGPU_SRC_HASH "unknown"
 #endif
-const char* tredgpu_version(void) { return "tredgpu 0.5 (gfx950) src " TREDGPU_SRC_HASH; }
+const char* tredgpu_version(void) { return "tredgpu 0.6 (gfx950) src " TREDGPU_SRC_HASH; }
 
 int tredgpu_create(int device_id, tredgpu_ctx** out) {
     if (!out) return fail(nullptr, -2, "out is NULL");
