@@ -879,7 +879,12 @@ int64_t tredbam_details_json(const uint8_t* seq4, const int64_t* seq4_off, const
         }
         TREDBAM_LIT("\",\n                \"seq\": \"");
         const uint8_t* sq = seq4 + seq4_off[rd];
-        for (int32_t k = 0; k < L; ++k) *p++ = BASES[(sq[k >> 1] >> ((k & 1) ? 0 : 4)) & 15];
+        {   // two bases per byte of the 4-bit sequence: one table look-up and one 2-byte store per pair
+            static const struct Pairs { char t[256][2]; Pairs() { for (int b = 0; b < 256; ++b) { t[b][0] = BASES[b >> 4]; t[b][1] = BASES[b & 15]; } } } PAIRS;
+            const int32_t whole = L >> 1;
+            for (int32_t k = 0; k < whole; ++k, p += 2) memcpy(p, PAIRS.t[sq[k]], 2);
+            if (L & 1) *p++ = BASES[sq[whole] >> 4];
+        }
         TREDBAM_LIT("\",\n                \"tag\": \"");
         put(TAGS[tags[i]], 4);
         TREDBAM_LIT("\"\n            }");
