@@ -36,9 +36,18 @@ uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
 
+// One contig of the .bai: where its bins and its linear index lie in the file's bytes (tredbam::bai).  The bins are parsed
+// into the map when the contig is first queried, the linear index is read in place: a whole-genome .bai is ~8 MB of
+// which a sample's queries touch a few contigs' bins and a handful of linear entries -- copying all of it into maps and
+// vectors per sample was a millisecond of every synthetic sample's plan (1.1 MB .bai) and several of a real one's.
 struct RefIndex {
     std::unordered_map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
-    std::vector<uint64_t> linear;
+    bool bins_parsed = false;
+    size_t bins_at = 0;             // offset of the contig's first bin record
+    int32_t n_bin = 0;
+    const uint8_t* lin = nullptr;   // n_lin little-endian 64-bit entries
+    size_t n_lin = 0;
+    uint64_t linear(size_t k) const { return le64(lin + 8 * k); }
 };
 
 }  // namespace
@@ -106,6 +115,7 @@ struct tredbam {
     uint64_t first_record = 0;
     // index
     bool index_loaded = false;
+    std::vector<uint8_t> bai;            // the .bai file's bytes (RefIndex points into them)
     std::vector<RefIndex> index;
     // output of the last fetch
     std::vector<uint8_t> out;
@@ -410,10 +420,17 @@ int load_index(tredbam* b) {
     for (const std::string& c : cand)
         if ((f = fopen(c.c_str(), "rb")) != nullptr) break;
     if (!f) return fail(b, -4, "no .bai index next to %s", b->path.c_str());
-    std::vector<uint8_t> d;
-    uint8_t tmp[65536];
-    size_t g;
-    while ((g = fread(tmp, 1, sizeof tmp, f)) > 0) d.insert(d.end(), tmp, tmp + g);
+    std::vector<uint8_t>& d = b->bai;
+    d.clear();
+    {
+        struct stat st;
+        if (fstat(fileno(f), &st) == 0 && st.st_size > 0) d.resize((size_t)st.st_size);
+        size_t got = d.empty() ? 0 : fread(d.data(), 1, d.size(), f);
+        d.resize(got);
+        uint8_t tmp[65536];                            // (a file that grew, or whose size is not known: the rest)
+        size_t g;
+        while ((g = fread(tmp, 1, sizeof tmp, f)) > 0) d.insert(d.end(), tmp, tmp + g);
+    }
     fclose(f);
     if (d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) return fail(b, -4, "bad BAI magic");
     const int32_t n_ref = (int32_t)le32(d.data() + 4);
@@ -422,22 +439,43 @@ int load_index(tredbam* b) {
     for (int32_t t = 0; t < n_ref; ++t) {
         if (p + 4 > d.size()) return fail(b, -4, "truncated BAI");
         const int32_t n_bin = (int32_t)le32(d.data() + p); p += 4;
-        for (int32_t k = 0; k < n_bin; ++k) {
+        if (n_bin < 0) return fail(b, -4, "truncated BAI");
+        b->index[t].bins_at = p;
+        b->index[t].n_bin = n_bin;
+        for (int32_t k = 0; k < n_bin; ++k) {          // (only the chunk counts are looked at here)
             if (p + 8 > d.size()) return fail(b, -4, "truncated BAI");
-            const uint32_t bin = le32(d.data() + p);
             const int32_t n_chunk = (int32_t)le32(d.data() + p + 4); p += 8;
             if (n_chunk < 0 || p + 16 * (size_t)n_chunk > d.size()) return fail(b, -4, "truncated BAI");
-            auto& v = b->index[t].bins[bin];
-            for (int32_t c = 0; c < n_chunk; ++c, p += 16) v.emplace_back(le64(d.data() + p), le64(d.data() + p + 8));
+            p += 16 * (size_t)n_chunk;
         }
         if (p + 4 > d.size()) return fail(b, -4, "truncated BAI");
         const int32_t n_intv = (int32_t)le32(d.data() + p); p += 4;
         if (n_intv < 0 || p + 8 * (size_t)n_intv > d.size()) return fail(b, -4, "truncated BAI");
-        b->index[t].linear.resize((size_t)n_intv);
-        for (int32_t k = 0; k < n_intv; ++k, p += 8) b->index[t].linear[k] = le64(d.data() + p);
+        b->index[t].lin = d.data() + p;
+        b->index[t].n_lin = (size_t)n_intv;
+        p += 8 * (size_t)n_intv;
     }
     b->index_loaded = true;
     return 0;
+}
+
+// the bins of one contig, parsed on first use (load_index checked the lengths)
+const RefIndex& contig_index(tredbam* b, int32_t tid) {
+    RefIndex& ix = b->index[(size_t)tid];
+    if (!ix.bins_parsed) {
+        const uint8_t* d = b->bai.data();
+        size_t p = ix.bins_at;
+        ix.bins.reserve((size_t)ix.n_bin * 2);
+        for (int32_t k = 0; k < ix.n_bin; ++k) {
+            const uint32_t bin = le32(d + p);
+            const int32_t n_chunk = (int32_t)le32(d + p + 4); p += 8;
+            auto& v = ix.bins[bin];
+            v.reserve((size_t)n_chunk);
+            for (int32_t c = 0; c < n_chunk; ++c, p += 16) v.emplace_back(le64(d + p), le64(d + p + 8));
+        }
+        ix.bins_parsed = true;
+    }
+    return ix;
 }
 
 // The merged index chunks (virtual offsets) a query of [start, end) on tid reads, like htslib's: reg2bins of the 5-level
@@ -451,9 +489,9 @@ int region_chunks(tredbam* b, int32_t tid, int64_t& start, int64_t& end, std::ve
     if (rc) return rc;
     merged.clear();
     if (tid >= (int32_t)b->index.size()) return 0;
-    const RefIndex& ix = b->index[tid];
+    const RefIndex& ix = contig_index(b, tid);
     uint64_t min_off = 0;
-    if (!ix.linear.empty()) min_off = ix.linear[std::min<size_t>((size_t)(start >> 14), ix.linear.size() - 1)];
+    if (ix.n_lin > 0) min_off = ix.linear(std::min<size_t>((size_t)(start >> 14), ix.n_lin - 1));
     // reg2bins of the 5-level scheme over [start, max(end, start + 1))
     const int64_t e1 = std::max(end, start + 1) - 1;
     std::vector<std::pair<uint64_t, uint64_t>> chunks;
@@ -1388,10 +1426,10 @@ int64_t tredbam_plan(tredbam* b, const tredbam_site* sites, int32_t n_sites, con
         if (region_chunks(b, tid, start, end, merged) != 0) return 0;     // (the scan reports what is wrong with it)
         uint64_t cap = ~0ull;
         if (tid < (int32_t)b->index.size()) {
-            const auto& lin = b->index[tid].linear;
+            const RefIndex& lin = b->index[tid];
             const size_t w = (size_t)((std::max<int64_t>(end, 1) - 1) >> 14) + 2;
             // (an entry equal to its predecessor is a window without a record of its own, filled in from before it)
-            if (w < lin.size() && lin[w] != 0 && lin[w] > lin[w - 1]) cap = lin[w];
+            if (w < lin.n_lin && lin.linear(w) != 0 && lin.linear(w) > lin.linear(w - 1)) cap = lin.linear(w);
         }
         for (const auto& ch : merged) {
             const int64_t last = (int64_t)(std::min(ch.second, cap) >> 16);
