@@ -69,6 +69,17 @@ def test_native_files_equal_the_python_path(cohort, tmp_path, repeatpairs, capsy
     assert sorted(a) == sorted(b) and len(a) == 10                 # five samples: JSON + VCF each; the missing BAM: nothing
     for name in a:
         assert a[name] == b[name], name
+    # the native VCF file: ONE gzip member (RFC 1952) -- its pieces are spliced runs of DEFLATE blocks (emit.cpp gzip_three) --
+    # whose trailer carries the text's CRC-32 and length
+    import struct, zlib
+    for name in (n for n in b if n.endswith(".gz")):
+        with open(os.path.join(str(tmp_path / "na"), name), "rb") as fp:
+            raw = fp.read()
+        assert raw[:4] == b"\x1f\x8b\x08\x00"
+        d = zlib.decompressobj(-15)
+        body = d.decompress(raw[10:])
+        assert d.eof and len(d.unused_data) == 8 and body == b[name]
+        assert struct.unpack("<II", d.unused_data) == (zlib.crc32(body), len(body))
     text = a["syn0000.json"].decode()
     assert '.P_h1h2": {' in text and '.details": [' in text and '"inferredGender"' in text and '.P_h1": ""' in text
     # what bench.py's check reads from the emitter: which loci were printed and the shorter allele, per sample

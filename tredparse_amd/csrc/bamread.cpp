@@ -975,6 +975,19 @@ int tredbam_float_repr(double x, char* out) {
     return (int)(p - out);
 }
 
+namespace {
+inline int key_int(char* out, int32_t v) {                 // decimal text of v (at most 11 bytes), its length
+    char buf[12];
+    char* p = buf + sizeof buf;
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *--p = '-';
+    const int n = (int)(buf + sizeof buf - p);
+    memcpy(out, p, (size_t)n);
+    return n;
+}
+}  // namespace
+
 int64_t tredbam_sparse_json(const int32_t* a, const int32_t* b, const double* values, int64_t n, int32_t depth,
                             char* out, int64_t cap) {
     if (n < 0 || depth < 0 || depth > 16 || !out || cap < 2 || (n > 0 && (!a || !values))) return -2;
@@ -985,7 +998,8 @@ int64_t tredbam_sparse_json(const int32_t* a, const int32_t* b, const double* va
     std::vector<Item> items((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         Item& it = items[(size_t)i];
-        it.klen = b ? snprintf(it.key, sizeof it.key, "%d,%d", (int)a[i], (int)b[i]) : snprintf(it.key, sizeof it.key, "%d", (int)a[i]);
+        it.klen = key_int(it.key, a[i]);
+        if (b) { it.key[it.klen++] = ','; it.klen += key_int(it.key + it.klen, b[i]); }
         it.at = i;
     }
     std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) {
