@@ -115,7 +115,10 @@ struct tredbam {
     uint64_t first_record = 0;
     // index
     bool index_loaded = false;
-    std::vector<uint8_t> bai;            // the .bai file's bytes (RefIndex points into them)
+    std::vector<uint8_t> bai;            // the .bai file's bytes when it could not be mapped
+    const uint8_t* bai_p = nullptr;      // the .bai file's bytes (RefIndex points into them): mapped read-only, so that only the
+    size_t bai_n = 0;                    //   pages a sample's queries touch are ever looked at (1.1 MB - 8 MB per file), or `bai`
+    bool bai_mapped = false;
     std::vector<RefIndex> index;
     // output of the last fetch
     std::vector<uint8_t> out;
@@ -416,22 +419,32 @@ int load_index(tredbam* b) {
     const size_t dot = cand[1].rfind('.');
     if (dot != std::string::npos) cand[1] = cand[1].substr(0, dot);
     cand[1] += ".bai";
-    FILE* f = nullptr;
+    if (b->bai_mapped) { munmap(const_cast<uint8_t*>(b->bai_p), b->bai_n); b->bai_mapped = false; }   // (an earlier, refused index)
+    int fd = -1;
     for (const std::string& c : cand)
-        if ((f = fopen(c.c_str(), "rb")) != nullptr) break;
-    if (!f) return fail(b, -4, "no .bai index next to %s", b->path.c_str());
-    std::vector<uint8_t>& d = b->bai;
-    d.clear();
+        if ((fd = open(c.c_str(), O_RDONLY | O_CLOEXEC)) >= 0) break;
+    if (fd < 0) return fail(b, -4, "no .bai index next to %s", b->path.c_str());
+    struct Bytes { const uint8_t* p; size_t n; const uint8_t* data() const { return p; } size_t size() const { return n; } } d{nullptr, 0};
     {
         struct stat st;
-        if (fstat(fileno(f), &st) == 0 && st.st_size > 0) d.resize((size_t)st.st_size);
-        size_t got = d.empty() ? 0 : fread(d.data(), 1, d.size(), f);
-        d.resize(got);
-        uint8_t tmp[65536];                            // (a file that grew, or whose size is not known: the rest)
-        size_t g;
-        while ((g = fread(tmp, 1, sizeof tmp, f)) > 0) d.insert(d.end(), tmp, tmp + g);
+        void* m = MAP_FAILED;
+        if (fstat(fd, &st) == 0 && st.st_size > 0) m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            b->bai_p = (const uint8_t*)m;
+            b->bai_n = (size_t)st.st_size;
+            b->bai_mapped = true;
+        } else {                                           // (no mapping: the bytes are read)
+            std::vector<uint8_t>& v = b->bai;
+            v.clear();
+            uint8_t tmp[65536];
+            ssize_t g;
+            while ((g = read(fd, tmp, sizeof tmp)) > 0) v.insert(v.end(), tmp, tmp + g);
+            b->bai_p = v.data();
+            b->bai_n = v.size();
+        }
+        d = Bytes{b->bai_p, b->bai_n};
     }
-    fclose(f);
+    close(fd);
     if (d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) return fail(b, -4, "bad BAI magic");
     const int32_t n_ref = (int32_t)le32(d.data() + 4);
     size_t p = 8;
@@ -463,7 +476,7 @@ int load_index(tredbam* b) {
 const RefIndex& contig_index(tredbam* b, int32_t tid) {
     RefIndex& ix = b->index[(size_t)tid];
     if (!ix.bins_parsed) {
-        const uint8_t* d = b->bai.data();
+        const uint8_t* d = b->bai_p;
         size_t p = ix.bins_at;
         ix.bins.reserve((size_t)ix.n_bin * 2);
         for (int32_t k = 0; k < ix.n_bin; ++k) {
@@ -782,6 +795,7 @@ int tredbam_open(const char* path, tredbam** out) {
 void tredbam_close(tredbam* b) {
     if (!b) return;
     if (b->map) munmap(const_cast<uint8_t*>(b->map), b->map_size);
+    if (b->bai_mapped) munmap(const_cast<uint8_t*>(b->bai_p), b->bai_n);
     if (b->fp) fclose(b->fp);
     delete b;
 }
