@@ -69,8 +69,7 @@ def test_native_files_equal_the_python_path(cohort, tmp_path, repeatpairs, capsy
     assert sorted(a) == sorted(b) and len(a) == 10                 # five samples: JSON + VCF each; the missing BAM: nothing
     for name in a:
         assert a[name] == b[name], name
-    # the native VCF file: ONE gzip member (RFC 1952) -- its pieces are spliced runs of DEFLATE blocks (emit.cpp gzip_three) --
-    # whose trailer carries the text's CRC-32 and length
+    # the native VCF file: ONE gzip member (RFC 1952) whose trailer carries the text's CRC-32 and length
     import struct, zlib
     for name in (n for n in b if n.endswith(".gz")):
         with open(os.path.join(str(tmp_path / "na"), name), "rb") as fp:

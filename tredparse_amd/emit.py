@@ -121,7 +121,7 @@ class Emitter(object):
                               index.ctypes.data)
         today = date.today()
         eo = bamio.EmitOpts(self.ref.encode("utf-8"), self.source, "{}{:02d}{:02d}".format(today.year, today.month, today.day).encode(),
-                            self.meta, 0 if self.no_output else 1, 0 if self.no_output else 1, 6, 0)
+                            self.meta, 0 if self.no_output else 1, 0 if self.no_output else 1, 0, 0)     # (gzip level 0: the writer's own, emit.cpp GZIP_LEVEL)
         status = np.zeros(max(1, len(scan.names)), np.int32)
         cap = (1 << 22) if self.echo else 0
         text = C.create_string_buffer(cap) if cap else None

@@ -686,7 +686,7 @@ def to_vcf(results, ref, repo, treds=("HD",), store=None):
     records = sorted(_vcf_line(t, calls, repo.get_info(t)) for t in treds if t + ".1" in calls)
     text = vcfstanza(results["samplekey"], results["bam"], calls, ref) + "\n" + "".join(line + "\n" for _, _, line in records)
     with open(results["samplekey"] + ".tred.vcf.gz", "wb") as fw:   # (one gzip member written in one piece)
-        fw.write(gzip.compress(text.encode("utf-8"), compresslevel=6))
+        fw.write(gzip.compress(text.encode("utf-8"), compresslevel=3))   # (as the native writer: emit.cpp GZIP_LEVEL)
 
 
 def write_vcf_json(results, ref, repo, treds, store=None, quiet=False):
