@@ -10,6 +10,9 @@ class FakeEngine(object):
     def __init__(self, seed=1, odd_units=True):
         self.seed, self.odd_units, self.calls = seed, odd_units, 0
 
+    def close(self):                                   # (engine.Engine.close: the CLI gives its context back before it ends)
+        pass
+
     def genotype_packed(self, b, dense=False):
         rng = np.random.default_rng(self.seed + 1000 * self.calls)
         self.calls += 1

@@ -23,6 +23,9 @@ class NoEvidenceEngine(object):
     def __init__(self, device=0):
         NoEvidenceEngine.made.append(device)
 
+    def close(self):
+        pass
+
     def genotype_packed(self, b):
         r = BatchResult()
         r.batch = b

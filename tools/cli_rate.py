@@ -52,9 +52,20 @@ def main():
     argv = [sys.executable, "-m", "tredparse_amd.tred", csv, "--workdir", work, "--gpu-inflate", "--gpu-walk", "--gpu-select"]
     for t in names:
         argv += ["--tred", t]
+    env = dict(os.environ)
+    timeline = "--timeline" in extra                  # (the drivers' marks, tredparse_amd/runtime.py: seconds since the command began)
+    if timeline:
+        extra.remove("--timeline")
+        env["TRED_TIMELINE"] = root
     t0 = time.time()
-    out = subprocess.run(argv + extra, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    out = subprocess.run(argv + extra, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
     dt = time.time() - t0
+    lines = {}
+    if timeline:
+        for f in sorted(glob.glob(os.path.join(root, "timeline_*.json"))):
+            with open(f) as fp:
+                ev = json.load(fp)
+            lines[os.path.basename(f)] = [[round(t - t0, 3), e, kw] for t, e, kw in ev[:90]] + ["..."] + [[round(t - t0, 3), e, kw] for t, e, kw in ev[-6:]]
     files = glob.glob(os.path.join(work, "*.json"))
     times = sorted(os.path.getmtime(f) for f in files)
     span = times[-1] - times[0] if len(times) > 1 else dt
@@ -62,9 +73,9 @@ def main():
     steady = (len(mid) - 1) * len(names) / max(mid[-1] - mid[0], 1e-9) if len(mid) > 1 else 0.0
     print(json.dumps({"samples": n, "distinct_bams": len(made), "loci": len(names), "exit_code": out.returncode, "json_files": len(files),
                       "elapsed_s": round(dt, 2), "genotypes_per_s_whole_command": round(len(files) * len(names) / dt, 1),
-                      "first_to_last_file_s": round(span, 2), "genotypes_per_s_behind_the_first_tenth": round(steady, 1),
+                      "first_file_after_s": round(times[0] - t0, 2) if times else None, "first_to_last_file_s": round(span, 2), "genotypes_per_s_behind_the_first_tenth": round(steady, 1),
                       "plan": shard.driver_plan(shard.usable_cpus(), 1), "library": _version(), "extra_arguments": extra, "usable_cpus": shard.usable_cpus(),
-                      "stderr_tail": out.stderr[-300:]}))
+                      "stderr_tail": out.stderr[-300:], **({"timeline": lines} if timeline else {})}))
     shutil.rmtree(root, ignore_errors=True)
 
 

@@ -8,7 +8,7 @@ import time
 from concurrent.futures import Future, ThreadPoolExecutor
 
 from .bam_parser import scan_sample
-from .runtime import _options, collect_sample, timing_add
+from .runtime import _options, collect_sample, mark, timing_add
 
 
 # ---- scans over GPU-inflated blocks -----------------------------------------------------------------------------------
@@ -330,6 +330,7 @@ class _InflateFeeder(object):
             out_addr, out_off = inf.out_addr, job["ooff"]
             if job["ooff"] is not None:
                 t0 = time.perf_counter()
+                mark("decode call", n=len(chunk))
                 try:
                     if job.get("walk") is not None:
                         status, crc, walked, out_addr, out_off = self._run_walk(inf, job)
@@ -340,6 +341,7 @@ class _InflateFeeder(object):
                     logging.getLogger("tredparse_amd").warning("GPU inflate skipped for a chunk of %d samples (%s)", len(chunk), e)
                     status = crc = None
                 timing_add(inflate_gpu=time.perf_counter() - t0)
+                mark("decoded", n=len(chunk))
             if self.stop.is_set():
                 return
             dev = None

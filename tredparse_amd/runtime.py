@@ -22,6 +22,28 @@ def timing_add(**kw):
             TIMING[k] += v
 
 
+# A driver's timeline, for tuning: with TRED_TIMELINE=<directory> in the environment every mark(event) is kept with its wall-clock
+# time and the process writes <directory>/timeline_<pid>.json when it ends (tools/cli_rate.py --timeline reads them).  Off: one
+# dictionary look-up per mark.
+_TIMELINE = [] if __import__("os").environ.get("TRED_TIMELINE") else None
+
+
+def mark(event, **kw):
+    if _TIMELINE is not None:
+        import time
+        _TIMELINE.append((time.time(), event, kw))
+
+
+def timeline_dump():
+    if _TIMELINE:
+        import json, os
+        try:
+            with open(os.path.join(os.environ["TRED_TIMELINE"], "timeline_{}.json".format(os.getpid())), "w") as fp:
+                json.dump(_TIMELINE, fp)
+        except OSError:
+            pass
+
+
 def _options(arg):
     """The reference's run() argument tuple, named."""
     samplekey, bam, repo, names, maxinsert, fullsearch, clip, alts, repeatpairs, log = arg
