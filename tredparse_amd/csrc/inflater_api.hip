@@ -129,7 +129,7 @@ void release_walk(tredgpu_inflater* f) {
 // grow-only pairs of pinned host / device buffers for the walk's small arrays
 int grow_pair(tredgpu_inflater* f, uint8_t** host, uint8_t** dev, size_t* cap, size_t need) {
     if (need <= *cap) return 0;
-    const size_t c = std::max(need, *cap + *cap / 2);
+    const size_t c = std::max(need + need / 8, *cap + *cap / 2);     // (an eighth past the call that makes it grow: see tredgpu_inflater_reserve)
     if (*host) (void)hipHostFree(*host);
     if (*dev) (void)hipFree(*dev);
     *host = nullptr; *dev = nullptr; *cap = 0;
@@ -217,10 +217,12 @@ int tredgpu_inflater_reserve(tredgpu_inflater* f, int64_t comp_bytes, int64_t ou
     const size_t need_c = (size_t)comp_bytes + 64, need_o = (size_t)out_bytes + 64, need_b = (size_t)n_blocks + 1;
     if (need_c > f->cap_comp || need_o > f->cap_out || need_b > f->cap_blocks) {
         for (hipStream_t st : f->stream) ICHK(f, hipStreamSynchronize(st));
-        // (page-locked staging grows by an eighth past the largest call seen: a chunk's size varies by a few per cent, and every
-        //  spare byte here is pinned three times per driver process)
-        const size_t cc = std::max(need_c, f->cap_comp + f->cap_comp / 8), co = std::max(need_o, f->cap_out + f->cap_out / 8),
-                     cb = std::max(need_b, f->cap_blocks + f->cap_blocks / 2);
+        // (page-locked staging grows by an eighth past the largest call seen, and a sixteenth past the call that makes it grow:
+        //  a chunk's size varies by a few per cent -- sized exactly, the second and the third chunk of a driver each freed and
+        //  page-locked 0.3 GB again, 0.3-0.4 s of a cohort's first two seconds --, and every spare byte here is pinned three times
+        //  per driver process)
+        const size_t cc = std::max(need_c + need_c / 16, f->cap_comp + f->cap_comp / 8), co = std::max(need_o + need_o / 16, f->cap_out + f->cap_out / 8),
+                     cb = std::max(need_b + need_b / 16, f->cap_blocks + f->cap_blocks / 2);
         release(f);
         ICHK(f, hipHostMalloc((void**)&f->h_comp, cc, hipHostMallocDefault));
         if (f->host_out) ICHK(f, hipHostMalloc((void**)&f->h_out, co, hipHostMallocDefault));
@@ -355,7 +357,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         }
         total_recs = (size_t)rec_base[n_tasks];
         if (total_recs > f->cap_wrecs) {
-            const size_t c = std::max(total_recs, f->cap_wrecs + f->cap_wrecs / 2);
+            const size_t c = std::max(total_recs + total_recs / 8, f->cap_wrecs + f->cap_wrecs / 2);
             if (f->d_wrecs) (void)hipFree(f->d_wrecs);
             if (f->d_wfields) (void)hipFree(f->d_wfields);
             f->d_wrecs = nullptr; f->d_wfields = nullptr; f->cap_wrecs = 0;
@@ -364,7 +366,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
             f->cap_wrecs = c;
         }
         if (n_tasks > f->cap_wchained) {
-            const size_t c = std::max(n_tasks, f->cap_wchained + f->cap_wchained / 2);
+            const size_t c = std::max(n_tasks + n_tasks / 8, f->cap_wchained + f->cap_wchained / 2);
             if (f->d_wchained) (void)hipFree(f->d_wchained);
             f->d_wchained = nullptr; f->cap_wchained = 0;
             ICHK(f, hipMalloc((void**)&f->d_wchained, c * sizeof(WalkChained)));
@@ -372,7 +374,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
         }
         if (grow_pair(f, &f->h_wres, &f->d_wres, &f->cap_wres, n_tasks * sizeof(tredgpu_walk_result) + 64)) return -10;
         if (n_tasks > f->cap_wscratch) {
-            const size_t c = std::max(n_tasks, f->cap_wscratch + f->cap_wscratch / 2);
+            const size_t c = std::max(n_tasks + n_tasks / 8, f->cap_wscratch + f->cap_wscratch / 2);
             if (f->d_wpairs) (void)hipFree(f->d_wpairs);
             f->d_wpairs = nullptr; f->cap_wscratch = 0;
             ICHK(f, hipMalloc((void**)&f->d_wpairs, c * WALK_PAIR_CAP * sizeof(WalkPair)));
@@ -385,7 +387,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
             size_t* cap = which ? &f->cap_tpool : &f->cap_gpool;
             const size_t need = ((size_t)(which ? w->cap_target : w->cap_global) + 16) * 4;
             if (need > *cap) {
-                const size_t c = std::max(need, *cap + *cap / 2);
+                const size_t c = std::max(need + need / 8, *cap + *cap / 2);
                 if (*d) (void)hipFree(*d);
                 *d = nullptr; *cap = 0;
                 ICHK(f, hipMalloc((void**)d, c));
@@ -534,7 +536,7 @@ int run_inflate(tredgpu_inflater* f, int32_t n_blocks, int32_t* status, uint32_t
             size_t* cap = which ? &f->cap_htpool : &f->cap_hgpool;
             const size_t need = ((which ? nt : ng) + 16) * 4;
             if (need > *cap) {
-                const size_t c = std::max(need, *cap + *cap / 8);
+                const size_t c = std::max(need + need / 8, *cap + *cap / 8);
                 if (*h) (void)hipHostFree(*h);
                 *h = nullptr; *cap = 0;
                 ICHK(f, hipHostMalloc((void**)h, c, hipHostMallocDefault));
