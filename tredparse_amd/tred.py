@@ -870,11 +870,13 @@ def main(args, quiet=False):
                     mark("emitter closed")
                     # the pinned staging and the context are given back HERE, in order: left to the interpreter's shutdown
                     # (atexit, finalisers in any order) the same work took 0.85 s of a 12 288-sample command's 9.2 instead of 0.2
-                    from .feeder import release_inflaters
-                    release_inflaters()
-                    mark("inflaters released")
-                    engine.close()
-                    mark("engine closed")
+                    # (a driver process of the fan-out, which ends here; a caller of main() in a longer-lived process keeps both)
+                    if spawned:
+                        from .feeder import release_inflaters
+                        release_inflaters()
+                        mark("inflaters released")
+                        engine.close()
+                        mark("engine closed")
                     timeline_dump()
         print("Elapsed time={}".format(timedelta(seconds=time.time() - t0)), file=sys.stderr)
     finally:
