@@ -1,6 +1,9 @@
 """What the pieces of a driver process share (tred.py the CLI and run_many, feeder.py the GPU-inflate pipeline, emit.py
 the native writer): the stage timers and the named form of run()'s argument tuple."""
+import json
+import os
 import threading
+import time
 
 from .bam_parser import scan_sample
 
@@ -25,18 +28,16 @@ def timing_add(**kw):
 # A driver's timeline, for tuning: with TRED_TIMELINE=<directory> in the environment every mark(event) is kept with its wall-clock
 # time and the process writes <directory>/timeline_<pid>.json when it ends (tools/cli_rate.py --timeline reads them).  Off: one
 # dictionary look-up per mark.
-_TIMELINE = [] if __import__("os").environ.get("TRED_TIMELINE") else None
+_TIMELINE = [] if os.environ.get("TRED_TIMELINE") else None
 
 
 def mark(event, **kw):
     if _TIMELINE is not None:
-        import time
         _TIMELINE.append((time.time(), event, kw))
 
 
 def timeline_dump():
     if _TIMELINE:
-        import json, os
         try:
             with open(os.path.join(os.environ["TRED_TIMELINE"], "timeline_{}.json".format(os.getpid())), "w") as fp:
                 json.dump(_TIMELINE, fp)
