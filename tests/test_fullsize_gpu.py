@@ -171,18 +171,16 @@ def test_device_memory_path_matches_host_path(ctx, loci):
     assert d["calls"].cpu().numpy().tobytes() == ref["calls"].tobytes()
 
 
-def test_config5_high_coverage_expanded_alleles(ctx, loci):
-    """BASELINE configs[4]: 100x coverage, one allele expanded up to 200 repeats -- large (h1,h2) grids
-    (no spanning read for the long allele: extended h2 range, PE mode) and many repeat-only reads."""
-    _model(ctx)
-    sel = [l for l in loci if l["name"] in ("HD", "DM1", "SCA1")]
-    # both alleles beyond what a 150 bp read can span (no FULL read -> both axes extended), one up to 200
+def _config5_against_the_oracle(ctx, sel, seed, samples, expect_big):
+    """A configs[4]-shaped batch (100x, alleles beyond a read, one up to 200 repeats) through the kernels and through the CPU
+    restatement: every read's tag and repeat count, every unit's call, likelihood, CI and pair count."""
     p = synth.SynthParams(coverage=100, min_units=42, max_units=60, expanded_max=200, expanded_frac=0.8)
-    b = synth.build_batch(55, sel, 2, p, maxinsert=300)
+    b = synth.build_batch(seed, sel, samples, p, maxinsert=300)
     ctx.set_ladders(b.ladders)
     r = _run(ctx, b)
     assert (r["calls"]["status"] == 0).all()
-    assert r["calls"]["n_pairs"].max() > 20000 and (r["tag"] == 4).sum() > 50         # big grids, REPT reads
+    if expect_big:
+        assert r["calls"]["n_pairs"].max() > 20000 and (r["tag"] == 4).sum() > 50         # big grids, REPT reads
     ls = po.LocusSet(b.ladders)
     reads = [synth.decode(x) for x in b.codes]
     cls = po.classify(reads, np.repeat(b.unit_ladder, np.diff(b.unit_read_off)), ls, threads=0)
@@ -191,13 +189,32 @@ def test_config5_high_coverage_expanded_alleles(ctx, loci):
         up = b.units[u]
         f = {k: int(v) for k, v in enumerate(r["full"][u]) if v}
         pp = {k: int(v) for k, v in enumerate(r["pref"][u]) if v}
-        res = lo.Caller(int(up["period"]), 150, 2, 2 * float(up["half_depth"]), f, pp, int(r["rept"][u].sum()),
+        res = lo.Caller(int(up["period"]), 150, int(up["ploidy"]), 2 * float(up["half_depth"]), f, pp,
+                        int(r["rept"][u].sum()),
                         b.global_lens[up["pe_off"]:up["pe_off"] + up["n_global"]],
                         b.target_lens[up["tl_off"]:up["tl_off"] + up["n_target"]], int(up["ref_len"]),
                         int(up["minpe"])).evaluate()
         c = r["calls"][u]
         assert (c["h1"], c["h2"]) == tuple(res["alleles"]), u
         assert abs(c["lik"] - res["lik"]) <= 1e-6 and tuple(c["ci"]) == tuple(res["CI"]) and c["n_pairs"] == len(res["mls"])
+    return b.n_units
+
+
+def test_config5_high_coverage_expanded_alleles(ctx, loci):
+    """BASELINE configs[4]: 100x coverage, one allele expanded up to 200 repeats -- large (h1,h2) grids
+    (no spanning read for the long allele: extended h2 range, PE mode) and many repeat-only reads."""
+    _model(ctx)
+    sel = [l for l in loci if l["name"] in ("HD", "DM1", "SCA1")]
+    assert _config5_against_the_oracle(ctx, sel, 55, 2, True) == 6
+
+
+def test_config5_across_all_loci(ctx, loci):
+    """configs[4] again over every locus the bench's 200 x 30 batch holds (motifs of 3, 4, 5, 6 and 12 bp, X-linked and
+    autosomal, either strand's flanks): one 100x sample x 30 loci against the oracle, read by read and call by call
+    (VERDICT r5 weak 1 iii: six units were 'adequate, not generous')."""
+    _model(ctx)
+    sel = [l for l in loci if l["name"] not in ("FXTAS", "AR")]       # (the 30 of bench.py / synth_bam.bench_loci)
+    assert _config5_against_the_oracle(ctx, sel, 77, 1, False) == 30
 
 
 def test_small_scratch_pool_takes_several_passes(loci, monkeypatch):
