@@ -52,7 +52,9 @@ PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9      # int32 VALU lane-ops/s: 256 CU x 4 SI
 OPS_PER_CELL = 10.0                        # minimum VALU ops of one affine-gap local-alignment cell
 PEAK_TCUPS = PEAK_LANE_OPS / OPS_PER_CELL / 1e12
 HBM_PEAK_GBS = 8000.0
-PMC_GLOB = os.path.join(ROOT, "profiles", "r*_pmc_summary.json")
+# (the HEADLINE configuration's summary only -- tools/collect_profiles.py copies it to <round>_pmc_summary.json; the other legs'
+#  files, <round>_<leg>_pmc_summary.json, hold the same kernels over other workloads: walk16 is a 16-sample call)
+PMC_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")
 
 
 def pmc_traffic(kernel, library_version):
@@ -118,7 +120,7 @@ WORKLOADS = {
 
 def rows_per_lane(readlen):
     """The sw_cont_kernel instantiation a maximum read length selects (csrc/capi.hip rows_for)."""
-    return 4 if readlen <= 64 else 7 if readlen <= 112 else 10 if readlen <= 160 else 16 if readlen <= 256 else 20
+    return 4 if readlen <= 64 else 7 if readlen <= 112 else 10 if readlen <= 160 else 16 if readlen <= 256 else 20 if readlen <= 320 else 32
 
 
 def make_batch(args, rank, world):
@@ -1145,8 +1147,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=1000, help="synthetic samples per GPU (x 30 loci)")
     ap.add_argument("--coverage", type=float, default=None, help="override the workload's coverage (30x / 100x)")
-    ap.add_argument("--readlen", type=int, default=150, choices=(100, 150, 250, 300),
-                    help="read length: selects the sw_cont_kernel instantiation (R = 7 / 10 / 16 / 20 rows per lane)")
+    ap.add_argument("--readlen", type=int, default=150, choices=(100, 150, 250, 300, 400),
+                    help="read length: selects the sw_cont_kernel instantiation (R = 7 / 10 / 16 / 20 / 32 rows per lane)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3",
                     help="config3 = BASELINE configs[2] (the headline); config5 = configs[4] (100x, expanded alleles)")
     ap.add_argument("--seed", type=int, default=20260101)

@@ -258,6 +258,20 @@ def test_pmc_traffic_is_only_cited_for_the_build_it_was_taken_from(tmp_path, mon
     assert got is None and "no PMC summary of this build" in src and "r02_pmc_summary.json" in src
 
 
+def test_pmc_traffic_comes_from_the_headline_summary_not_from_another_legs(tmp_path, monkeypatch):
+    """profiles/ holds one summary per profiled leg, all of the same build and all with sw_cont_kernel in them (walk16 is a
+    16-sample call: 8 MB per launch where the headline batch moves 450): only <round>_pmc_summary.json is the headline's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert os.path.basename(bench.PMC_GLOB) == "r[0-9][0-9]_pmc_summary.json"
+    monkeypatch.setattr(bench, "PMC_GLOB", str(tmp_path / os.path.basename(bench.PMC_GLOB)))
+    lib = "tredgpu 0.6 (gfx950) src cccc"
+    for name, b in (("r06_pmc_summary.json", 445e6), ("r06_walk16_pmc_summary.json", 8e6), ("r06_len250_pmc_summary.json", 1.6e9)):
+        (tmp_path / name).write_text(json.dumps({"library_version": lib, "kernels": {"sw_cont_kernel": {"hbm_bytes_per_launch": b}}}))
+    got, src = bench.pmc_traffic("sw_cont_kernel", lib)
+    assert got == 445e6 and "profiles/r06_pmc_summary.json" in src
+
+
 def test_mix_ceiling_is_computed_from_the_builds_census_and_the_kernels_counters():
     """roofline.mix_ceiling_frac: no literal -- the build's ISA census of sw_cont_kernel's column blocks
     (tools/isa_census.py -> tredparse_amd/data/sw_isa_census.json, taken from THIS tree's sw_ladder.hip) times the columns the
