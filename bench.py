@@ -393,6 +393,8 @@ def rank_main(args):
         }
         if streamed is not None:
             out["streamed"] = streamed
+        if n_dev < world:                             # (ranks share devices: a rehearsal or a stub, never a scaling point)
+            out["devices"], out["oversubscribed"] = n_dev, True
         if out_dir:
             with open(os.path.join(out_dir, "line.json"), "w") as fp:
                 json.dump(out, fp)

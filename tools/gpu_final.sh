@@ -1,7 +1,7 @@
 # tools/gpu_final.sh -- the round's evidence in one GPU call, all on the tree's build:
 #   the GPU test suite, the default bench (as the driver runs it), the CLI's rate, the randomised campaigns (SW, grid, decoder,
 #   walks, read selection), the from-BAM leg at 8 CPUs, every rocprofv3 summary (tools/profile_all.sh).  Everything lands under
-#   gpurun_out/ and profiles/.  The A/B records of the round (cu_mask, sw_waves, grid_waves, virtual8) have scripts of their own.
+#   gpurun_out/ and profiles/.  The A/B records of the round (cu_mask, sw_waves, grid_waves, virtual8, grid_fuse_probe, inflate_capacity, h2d_probe) have scripts of their own.
 cd $GRAFT_REPO_ROOT
 R=${1:-r06}
 mkdir -p gpurun_out
