@@ -43,6 +43,10 @@ if "RANK" not in os.environ:
     for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ.setdefault(_v, "1")
 
+# (the host driver of this pool supports dmabuf IPC only: without this RCCL's set-up of a multi-rank job fails in hipIpcGetMemHandle;
+#  the GPU boxes export it already -- a rank started by anything else gets it here, before torch loads)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
