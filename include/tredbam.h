@@ -114,6 +114,8 @@ typedef struct tredbam_scan_opts {
 
 #define TREDBAM_UNIT_NO_FETCH 1   /* unknown contig or no index: no reads (the reference logs and goes on)        */
 #define TREDBAM_UNIT_FAILED 2     /* the file could not be read: the reference's exception drops the locus        */
+#define TREDBAM_UNIT_NO_SEQ 4     /* a selected record holds no sequence (SEQ '*', l_seq 0): pysam's query_sequence is
+                                   * None there and _parseReadSW's len(seq) raises (bam_parser.py:129-133): locus dropped */
 
 typedef struct tredbam_unit {
     int32_t status;               /* TREDBAM_UNIT_* flags                                                           */

@@ -555,3 +555,43 @@ def test_scan_over_blocks_inflated_elsewhere_equals_the_plain_scan():
         for field in ("packed", "read_len", "global_lens", "target_lens", "unit", "depth"):
             assert np.array_equal(getattr(ref, field), getattr(got, field)), (sample, field)
         f.close()
+
+
+def test_a_selected_record_without_a_sequence_is_reported_by_the_scan(tmp_path, caplog):
+    """SEQ '*' (l_seq 0) on a record the selection takes: pysam gives query_sequence None, the reference's len(seq) raises
+    (tredparse/bam_parser.py:129-133) and the locus is lost (tred.py:245-249).  Here: TREDBAM_UNIT_NO_SEQ on that unit,
+    admit() drops it with the reference's kind of log line, the other loci stay; both file layers return None like pysam."""
+    import logging
+    import numpy as np
+    from tredparse_amd import bam_parser, bamio, synth, synth_bam
+    from tredparse_amd.meta import TREDsRepo
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1")]
+    recs, _ = synth_bam.simulate_sample(92, loci, synth.SynthParams(coverage=12))
+    repo = TREDsRepo()
+    t0 = repo["HD"]
+    li = [l["name"] for l in loci].index("HD")
+    inwin = np.nonzero((recs.locus == li) & (recs.pos >= t0.repeat_start - 100) & (recs.pos <= t0.repeat_end + 100) & ((recs.flag & 0x4) == 0))[0]
+    far = np.nonzero((recs.locus == li) & (recs.pos < t0.repeat_start - 2000))[0]      # in the pair-length region only: harmless
+    mask = np.zeros(len(recs), bool)
+    mask[far[0]] = True
+    path = str(tmp_path / "far.bam")
+    synth_bam.write_bam(path, recs, sample="q", no_seq=mask)
+    names = [l["name"] for l in loci]
+    s = bam_parser.scan_sample(path, repo, names)
+    assert s.dropped == {} and not (s.unit["status"] & bamio.UNIT_NO_SEQ).any()
+    mask[inwin[0]] = True
+    path = str(tmp_path / "noseq.bam")
+    synth_bam.write_bam(path, recs, sample="q", no_seq=mask, split_records=True, block=5000)
+    with caplog.at_level(logging.ERROR):
+        s = bam_parser.scan_sample(path, repo, names)
+    k = names.index("HD")
+    assert list(s.dropped) == [k] and "without a sequence" in s.dropped[k]
+    assert [bool(x & bamio.UNIT_NO_SEQ) for x in s.unit["status"]] == [n == "HD" for n in names]
+    assert any("Exception on" in r.getMessage() and " HD " in r.getMessage() for r in caplog.records)
+    a, b = s.reads_of(k)
+    assert int(s.read_len[a:b].min()) == 0 and int((s.read_len[a:b] == 0).sum()) == 1
+    for cls in (bamio.PyAlignmentFile, bamio.NativeAlignmentFile):
+        f = cls(path)
+        seqs = [r.query_sequence for r in f.fetch(t0.chr, t0.repeat_start - 150, t0.repeat_end + 150)]
+        assert seqs.count(None) == 1 and all(x is None or len(x) == 150 for x in seqs)
+        f.close()

@@ -139,3 +139,33 @@ def test_run_many_with_the_selection_on_the_device_gives_the_host_runs_results(c
                 d[name] = hashlib.sha256(open(str(work / name), "rb").read()).hexdigest()
         digests.append(d)
     assert len(digests[0]) >= 4 and digests[0] == digests[1]
+
+
+def test_a_selected_record_without_a_sequence_drops_its_locus_on_either_path(engine, tmp_path):
+    """SEQ '*' (l_seq 0): pysam's query_sequence is None and the reference's _parseReadSW dies in len(seq)
+    (tredparse/bam_parser.py:129-133), which costs the sample that locus (tred.py:245-249).  The host's scan says so
+    (TREDBAM_UNIT_NO_SEQ); the device's selection does not look for it, but the lengths it brings back show it, and such a
+    sample is scanned by the host after all: the same result dicts, the locus missing from both."""
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1", "SCA1", "FRDA")]
+    recs, _ = synth_bam.simulate_sample(91, loci, synth.SynthParams(coverage=20))
+    srepo = TREDsRepo()
+    t0 = srepo["DM1"]
+    inwin = np.nonzero((recs.locus == [l["name"] for l in loci].index("DM1")) & (recs.pos >= t0.repeat_start - 100) & (recs.pos <= t0.repeat_end + 100) &
+                       ((recs.flag & 0x4) == 0))[0]
+    assert len(inwin) > 3
+    mask = np.zeros(len(recs), bool)
+    mask[inwin[1]] = True
+    plain, odd = str(tmp_path / "plain.bam"), str(tmp_path / "noseq.bam")
+    synth_bam.write_bam(plain, recs, sample="p")
+    synth_bam.write_bam(odd, recs, sample="p", no_seq=mask)
+    names = [l["name"] for l in loci]
+    args = [("plain", plain, srepo, names, 300, False, False, True, True, "ERROR"), ("noseq", odd, srepo, names, 300, False, False, True, True, "ERROR")]
+    for k in t.TIMING:
+        t.TIMING[k] = 0
+    want = t.run_many(args, engine, batch=64, threads=2, lazy_details=False)
+    got = t.run_many(args, engine, batch=2, threads=2, lazy_details=False, inflate_device=0, gpu_walk=True, gpu_select=True)
+    t.release_inflaters()
+    assert t.TIMING["select_samples"] == 2                      # (both were selected on the device; one came back to the host)
+    assert got == want
+    assert "DM1.1" in want[0]["tredCalls"] and "DM1.1" not in want[1]["tredCalls"]
+    assert all(n + ".1" in want[1]["tredCalls"] for n in names if n != "DM1")

@@ -216,6 +216,8 @@ def admit(s):
         why = None
         if u["status"] & bamio.UNIT_FAILED:
             why = "the BAM could not be read"
+        elif u["status"] & bamio.UNIT_NO_SEQ:
+            why = "a selected read without a sequence (SEQ '*': len(None) in the reference)"
         elif u["pe_status"] != 0:
             why = "a paired read without an alignment end (pair-length extraction)"
         elif longest > MAX_READ_LEN:

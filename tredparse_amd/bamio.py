@@ -97,6 +97,8 @@ class PyRead(Read):
     @property
     def query_sequence(self):
         raw, n = self._seq_raw, self.l_seq
+        if n == 0:
+            return None                                  # (SEQ '*': pysam's AlignedSegment.query_sequence is None)
         out = []
         for i in range(n):
             b = raw[i >> 1]
@@ -423,7 +425,7 @@ REGION_DTYPE = np.dtype([("tid", "<i4"), ("start", "<i4"), ("end", "<i4")])
 SCAN_UNIT_DTYPE = np.dtype([("status", "<i4"), ("n_reads", "<i4"), ("read_first", "<i8"), ("depth_sum", "<i8"),
                             ("depth_status", "<i4"), ("pe_status", "<i4"), ("n_global", "<i4"), ("n_target", "<i4"),
                             ("global_first", "<i8"), ("target_first", "<i8")])
-UNIT_NO_FETCH, UNIT_FAILED = 1, 2
+UNIT_NO_FETCH, UNIT_FAILED, UNIT_NO_SEQ = 1, 2, 4
 # the pair walks handed to the device (include/tredbam.h; the same layouts as tredgpu.h's tredgpu_walk_*)
 WALK_TASK_DTYPE = np.dtype([(k, "<i4") for k in ("tid", "start", "end", "tstart", "tend", "span", "chunk_first", "n_chunks",
                                                  "block_first", "block_end", "win_lo", "win_hi")])
@@ -649,6 +651,8 @@ class NativeRead(Read):
 
     @property
     def query_sequence(self):
+        if self.l_seq == 0:
+            return None                                  # (as pysam)
         q = self._q + ((self._l_name + 3) & ~3) + 4 * self._n_cig
         return self._d[q:q + self.l_seq].decode()
 

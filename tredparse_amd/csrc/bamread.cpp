@@ -131,6 +131,7 @@ struct tredbam {
     std::vector<int32_t> sc_read_len, sc_name_id, sc_global, sc_target;
     std::vector<uint8_t> sc_seq4;
     std::vector<char> sc_names;
+    bool sc_noseq = false;               // pool_read met a record without a sequence since the flag was last cleared
 };
 
 namespace {
@@ -723,6 +724,7 @@ void pool_read(tredbam* b, const uint8_t* r, std::unordered_map<std::string, int
         if (code == 4) rec[nb + ((size_t)i >> 5)] |= 1u << (i & 31);
         else rec[(size_t)i >> 4] |= (uint32_t)code << ((i & 15) * 2);
     }
+    if (L == 0) b->sc_noseq = true;          // (SEQ '*': pysam's query_sequence is None and the reference's len(seq) raises)
     b->sc_word_off.push_back((int64_t)b->sc_packed.size());
     b->sc_read_len.push_back(L);
     b->sc_seq4.insert(b->sc_seq4.end(), seq, seq + ((size_t)L + 1) / 2);
@@ -1176,6 +1178,7 @@ int scan_impl(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tred
         const tredbam_site& st = sites[i];
         tredbam_unit& u = units[i];
         memset(&u, 0, sizeof u);
+        b->sc_noseq = false;
         u.read_first = (int64_t)b->sc_read_len.size();
         u.global_first = (int64_t)b->sc_global.size();
         u.target_first = (int64_t)b->sc_target.size();
@@ -1235,6 +1238,7 @@ int scan_impl(tredbam* b, const tredbam_site* sites, int32_t n_sites, const tred
             }
         }
         u.n_reads = (int32_t)((int64_t)b->sc_read_len.size() - u.read_first);
+        if (b->sc_noseq) u.status |= TREDBAM_UNIT_NO_SEQ;
         // paired-end lengths around the tract
         if (with_pe && !(u.status & TREDBAM_UNIT_FAILED)) {
             const size_t g0 = b->sc_global.size(), t0 = b->sc_target.size();

@@ -286,6 +286,18 @@ def _genotype_scans(engine, task_args, scans, TredGpuError):
         key = (o["maxinsert"], o["fullsearch"], o["clip"], o["repeatpairs"] or o["clip"], o["log"] == "DEBUG", on_device)
         groups.setdefault(key, (o, []))[1].append(pick)
     parts = {}
+
+    def on_the_host(o, sub):
+        """The samples of `sub` scanned by the host after all and genotyped the host-packed way (scans[] is the caller's list:
+        the writers find the host's scan there)."""
+        again = []
+        for si, s, _ in sub:
+            h = collect_sample(task_args[si])
+            scans[si] = h
+            picks[si] = (si, h, [k for k in range(len(h.names)) if k not in h.dropped] if h.opened else [])
+            again.append(picks[si])
+            s.device[0].done()
+        parts.update(_genotype(engine, again, o))
     try:
         for key, (o, sub) in groups.items():
             if not key[-1]:
@@ -295,17 +307,16 @@ def _genotype_scans(engine, task_args, scans, TredGpuError):
                 parts.update(_genotype_selected(engine, sub, o))
             except TredGpuError as e:
                 # the call over the device-held reads failed as a whole: those samples are scanned on the host after all and
-                # go the host-packed way, whose retries cost a bad unit only itself (scans[] is the caller's list: the
-                # writers find the host's scan there)
+                # go the host-packed way, whose retries cost a bad unit only itself
                 logger.error("GPU batch over device-selected reads failed (%s); scanning its %d samples on the host", e, len(sub))
-                again = []
-                for si, s, _ in sub:
-                    h = collect_sample(task_args[si])
-                    scans[si] = h
-                    picks[si] = (si, h, [k for k in range(len(h.names)) if k not in h.dropped] if h.opened else [])
-                    again.append(picks[si])
-                    s.device[0].done()
-                parts.update(_genotype(engine, again, o))
+                on_the_host(o, sub)
+                continue
+            # A selected record without a sequence (SEQ '*': pysam gives None and the reference's len(seq) raises,
+            # bam_parser.py:129-133) drops its locus in the host's scan (TREDBAM_UNIT_NO_SEQ); the device's selection does not
+            # look for it, but the lengths it brings back show it: such a sample is the host's.
+            odd = [p for p in sub if len(p[1].read_len) and int(p[1].read_len.min()) == 0]
+            if odd:
+                on_the_host(o, odd)
     finally:
         for _, s, _ in picks:                  # the inflaters that held the device's selections are the feeder's again
             dev = getattr(s, "device", None)
