@@ -32,7 +32,6 @@ only when the summary was taken on THIS build.
 import argparse
 import json
 import os
-import subprocess
 import sys
 import tempfile
 import time

@@ -17,7 +17,6 @@ Reference counterparts: flags tred.py:64-113; per-sample driver run() :180-278; 
 ignored) and the HLI-internal "@sample" lookup.
 """
 import argparse
-import atexit
 import gzip
 import json
 import logging
