@@ -8,7 +8,8 @@ the chrY depth windows in), perturbs the records' flags (duplicates, secondary, 
 each as a BAM whose BGZF blocks are cut at a random size WITHOUT regard to record boundaries (200 bytes .. 64 KiB), picks
 the options at random (alternative loci on / off, --useclippedreads, --fullsearch with a small --maxinsert) and sends the
 samples through the product's feeder with the selection on (feeder._InflateFeeder(select=True) -> tred.genotype_scans).
-Compared per sample with scan_sample + the host-packed genotyping call: sex and chrY depth, per locus depth sum, read count
+One sample in seven carries a record without a sequence (SEQ '*'): where the selection takes it, the sample must come back to the
+host's scan and lose that locus, as the reference does.  Compared per sample with scan_sample + the host-packed genotyping call: sex and chrY depth, per locus depth sum, read count
 and pair-length slices; the selected reads' lengths, 4-bit sequences and names in order; tags, repeat counts, scores, calls,
 marginals and joint entries bit for bit.  Prints one JSON line.
 
@@ -51,9 +52,13 @@ def compare(a, s, pieces, engine):
         bad.append("sequences")
     if not (np.array_equal(s.name_off, h.name_off) and s.name_blob == h.name_blob):
         bad.append("names")
-    ks = list(range(len(h.names)))
+    ks = [k for k in range(len(h.names)) if k not in h.dropped]          # (a locus the reference would lose is in no batch)
+    if not ks:
+        return bad + ([] if not pieces else ["units"]), 0, 0
     hb = engine.genotype_packed(PackedUnits.from_scans([(h, ks)], maxinsert=o["maxinsert"], fullsearch=o["fullsearch"], clip=o["clip"]))
     (br, i0, dks), = pieces
+    if dks != ks:
+        return bad + ["units"], 0, 0
     lo, hi = int(br.batch.unit_read_off[i0]), int(br.batch.unit_read_off[i0 + len(ks)])
     if dks != ks or hi - lo != hb.batch.n_reads:
         return bad + ["units"], 0, 0
@@ -105,7 +110,8 @@ def main():
     root = tempfile.mkdtemp(prefix="tred_fuzzsel_")
     engine = Engine(0)
     out = {"rounds": rounds, "samples": 0, "on_device": 0, "declined": 0, "units": 0, "reads": 0, "mismatching_samples": 0, "what": {},
-           "block_sizes": [], "read_lengths": [], "x_linked_samples": 0}
+           "block_sizes": [], "read_lengths": [], "x_linked_samples": 0, "samples_with_a_record_without_sequence": 0,
+           "of_which_lost_a_locus": 0}
     for k in t.TIMING:
         t.TIMING[k] = 0
     t0 = time.time()
@@ -126,8 +132,13 @@ def main():
             recs.flag[rng.random(n) < 0.05] ^= 0x10                        # strand flipped
             block = int(rng.choice([200, 333, 1000, 4096, 20000, 0xff00]))
             path = os.path.join(root, "r{}_{}.bam".format(rnd, k))
+            no_seq = None
+            if rng.random() < 0.15 and n:                                 # one record without its sequence (SEQ '*'), anywhere
+                no_seq = np.zeros(n, bool)
+                no_seq[int(rng.integers(n))] = True
+                out["samples_with_a_record_without_sequence"] += 1
             synth_bam.write_bam(path, recs, sample="f{}_{}".format(rnd, k), block=block, split_records=True,
-                                decoys=0.5 if rnd % 5 == 4 else 0.0, decoy_seed=rnd)
+                                decoys=0.5 if rnd % 5 == 4 else 0.0, decoy_seed=rnd, no_seq=no_seq)
             mode = int(rng.integers(0, 5))            # plain, plain, --noalts, --useclippedreads, --fullsearch --maxinsert 60
             args.append(("f{}_{}".format(rnd, k), path, repo, names, 60 if mode == 4 else 300, mode == 4, mode == 3, mode != 2, True, "ERROR"))
             out["block_sizes"].append(block)
@@ -136,9 +147,10 @@ def main():
         for a, s, pieces in device_scans(args, engine, batch=int(rng.integers(1, 5))):
             out["samples"] += 1
             if getattr(s, "device", None) is None:
-                out["declined"] += 1
-                continue
-            out["on_device"] += 1
+                out["declined"] += 1                     # (or taken back: a record without a sequence among the selected)
+                out["of_which_lost_a_locus"] += int(bool(s.dropped))
+            else:
+                out["on_device"] += 1
             bad, reads, units = compare(a, s, pieces, engine)
             out["reads"] += reads
             out["units"] += units
