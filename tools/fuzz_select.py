@@ -110,7 +110,7 @@ def main():
     root = tempfile.mkdtemp(prefix="tred_fuzzsel_")
     engine = Engine(0)
     out = {"rounds": rounds, "samples": 0, "on_device": 0, "declined": 0, "units": 0, "reads": 0, "mismatching_samples": 0, "what": {},
-           "block_sizes": [], "read_lengths": [], "x_linked_samples": 0, "samples_with_a_record_without_sequence": 0,
+           "block_sizes": [], "read_lengths": [], "x_linked_samples": 0, "samples_with_a_record_without_sequence": 0, "samples_with_a_mapped_record_without_cigar": 0,
            "of_which_lost_a_locus": 0}
     for k in t.TIMING:
         t.TIMING[k] = 0
@@ -130,6 +130,12 @@ def main():
             recs.flag[rng.random(n) < 0.01] |= 0x200                       # QC fail
             recs.flag[rng.random(n) < 0.02] &= ~0x1                        # unpaired
             recs.flag[rng.random(n) < 0.05] ^= 0x10                        # strand flipped
+            if rng.random() < 0.15 and n:                                 # one mapped record without a CIGAR ('*': pysam's
+                i = int(rng.integers(n))                                   # reference_end is None, PEextractor dies on such a mate)
+                if not (recs.flag[i] & 0x4):
+                    recs.n_cig[i] = 0
+                    recs.cig[i] = 0
+                    out["samples_with_a_mapped_record_without_cigar"] += 1
             block = int(rng.choice([200, 333, 1000, 4096, 20000, 0xff00]))
             path = os.path.join(root, "r{}_{}.bam".format(rnd, k))
             no_seq = None
