@@ -130,6 +130,20 @@ def main():
             recs.flag[rng.random(n) < 0.01] |= 0x200                       # QC fail
             recs.flag[rng.random(n) < 0.02] &= ~0x1                        # unpaired
             recs.flag[rng.random(n) < 0.05] ^= 0x10                        # strand flipped
+            # CIGAR forms the simulator does not write: a leading hard clip (no query bases: query_alignment_start skips it), '='
+            # in place of M (consumes the reference all the same)
+            hc = np.nonzero((rng.random(n) < 0.03) & (recs.n_cig <= 2) & (recs.n_cig >= 1))[0]
+            for i in hc.tolist():
+                m = int(recs.n_cig[i])
+                recs.cig[i, 1:m + 1] = recs.cig[i, :m].copy()
+                recs.cig[i, 0] = (5 << 4) | 5
+                recs.n_cig[i] = m + 1
+            eq = np.nonzero(rng.random(n) < 0.03)[0]
+            for i in eq.tolist():
+                for j in range(int(recs.n_cig[i])):
+                    if (int(recs.cig[i, j]) & 15) == 0:
+                        recs.cig[i, j] = (int(recs.cig[i, j]) & ~15) | 7
+                        break
             if rng.random() < 0.15 and n:                                 # one mapped record without a CIGAR ('*': pysam's
                 i = int(rng.integers(n))                                   # reference_end is None, PEextractor dies on such a mate)
                 if not (recs.flag[i] & 0x4):

@@ -58,7 +58,7 @@ class Records(object):
     def ref_end(self):
         """pysam reference_end: pos + reference-consuming CIGAR lengths; -1 for unmapped reads."""
         op, ln = self.cig & 15, self.cig >> 4
-        span = np.where((op == OP_M) | (op == OP_D), ln, 0).sum(axis=1)
+        span = np.where(np.isin(op, (OP_M, OP_D, 3, 7, 8)), ln, 0).sum(axis=1)          # M D N = X consume the reference
         return np.where((self.flag & FUNMAP) != 0, -1, self.pos + span).astype(np.int64)
 
     def names(self, sample):
