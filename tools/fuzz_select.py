@@ -99,6 +99,11 @@ def device_scans(args, engine, batch):
     return out
 
 
+# optional fields as an aligner leaves them behind every record (every third round): the last one an array whose bytes read as a
+# record's head (block_size 40, a contig id, a position) to whoever mistakes them for one
+AUX = b"NMC\x02MDZ75A74\x00ASC\x91RGZgroup1\x00XSC\x13" + b"ZBBC" + (40).to_bytes(4, "little") + bytes([40, 0, 0, 0, 3, 0, 0, 0, 5, 0, 0, 0, 2, 0, 73, 18] + [0] * 24)
+
+
 def main():
     from tredparse_amd import _lib, synth, synth_bam, tred as t
     from tredparse_amd.engine import Engine
@@ -158,7 +163,8 @@ def main():
                 no_seq[int(rng.integers(n))] = True
                 out["samples_with_a_record_without_sequence"] += 1
             synth_bam.write_bam(path, recs, sample="f{}_{}".format(rnd, k), block=block, split_records=True,
-                                decoys=0.5 if rnd % 5 == 4 else 0.0, decoy_seed=rnd, no_seq=no_seq)
+                                decoys=0.5 if rnd % 5 == 4 else 0.0, decoy_seed=rnd, no_seq=no_seq,
+                                aux=AUX if rnd % 3 == 2 else b"")
             mode = int(rng.integers(0, 5))            # plain, plain, --noalts, --useclippedreads, --fullsearch --maxinsert 60
             args.append(("f{}_{}".format(rnd, k), path, repo, names, 60 if mode == 4 else 300, mode == 4, mode == 3, mode != 2, True, "ERROR"))
             out["block_sizes"].append(block)

@@ -20,6 +20,10 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
+# optional fields behind every record of every third round (as aligners leave them); the array's bytes read as a record's head
+AUX = b"NMC\x02MDZ75A74\x00ASC\x91RGZgroup1\x00XSC\x13" + b"ZBBC" + (40).to_bytes(4, "little") + bytes([40, 0, 0, 0, 3, 0, 0, 0, 5, 0, 0, 0, 2, 0, 73, 18] + [0] * 24)
+
+
 def main():
     from tredparse_amd import _lib, bamio, synth, synth_bam
     from tredparse_amd.bam_parser import DNAPE_ELONGATE, FLANKMATCH, SPAN, _site_arrays, walk_need
@@ -48,7 +52,7 @@ def main():
             path = os.path.join(root, "r{}_{}.bam".format(rnd, k))
             # every fifth round: base qualities that look like record heads (the lanes' guesses go wrong, the serial chain takes over)
             synth_bam.write_bam(path, recs, sample="f{}_{}".format(rnd, k), block=block, split_records=True,
-                                decoys=0.5 if rnd % 5 == 4 else 0.0, decoy_seed=rnd)
+                                decoys=0.5 if rnd % 5 == 4 else 0.0, decoy_seed=rnd, aux=AUX if rnd % 3 == 2 else b"")
             cases.append(path)
             out["block_sizes"].append(block)
         handles = [bamio.AlignmentFile(p) for p in cases]

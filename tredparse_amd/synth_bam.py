@@ -322,7 +322,7 @@ def _bgzf_block(data, level):
 _EOF_BLOCK = _bgzf_block(b"", 6)
 
 
-def _record_sizes(recs, sample, no_seq=None):
+def _record_sizes(recs, sample, no_seq=None, aux=b""):
     """(bytes of every record without its 4-byte block_size, name length incl. NUL, bytes of a packed sequence).  no_seq: a mask
     of records written WITHOUT their sequence (SEQ and QUAL '*', l_seq 0: what some aligners leave of secondary alignments)."""
     n = len(recs)
@@ -332,10 +332,10 @@ def _record_sizes(recs, sample, no_seq=None):
         name_len = max(name_len, len("{}.{:02d}.{:07d}".format(sample, int(recs.locus.max()), int(recs.frag.max()))) + 1)
     seq_len = (L + 1) // 2
     body = np.full(n, seq_len + L, np.int64) if no_seq is None else np.where(no_seq, 0, seq_len + L).astype(np.int64)
-    return 32 + name_len + 4 * recs.n_cig.astype(np.int64) + body, name_len, seq_len
+    return 32 + name_len + 4 * recs.n_cig.astype(np.int64) + body + len(aux), name_len, seq_len
 
 
-def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None):
+def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None, aux=b""):
     """The BAM bytes of `recs` (block_size word + record, one after the other) and the records' byte offsets in them."""
     n = len(recs)
     L = recs.codes.shape[1]
@@ -353,7 +353,7 @@ def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None):
         nib = np.concatenate([nib, np.zeros((n, 1), np.uint8)], axis=1)
     seq = (nib[:, 0::2] << 4) | nib[:, 1::2]
     with_seq = np.ones(n, bool) if no_seq is None else ~np.asarray(no_seq, bool)
-    size = 32 + name_len + 4 * recs.n_cig + np.where(with_seq, seq.shape[1] + L, 0)   # without the 4-byte block_size
+    size = 32 + name_len + 4 * recs.n_cig + np.where(with_seq, seq.shape[1] + L, 0) + len(aux)   # without the 4-byte block_size
     off = np.zeros(n + 1, np.int64)
     np.cumsum(size + 4, out=off[1:])
     flat = np.zeros(int(off[-1]), np.uint8)
@@ -383,6 +383,9 @@ def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None):
     flat[idx] = seq[ws]
     idx = (off[ws] + seq_at[ws] + seq.shape[1])[:, None] + np.arange(L)[None, :]
     flat[idx] = 0xff                                                        # no base qualities
+    if len(aux) and n:                                                     # the same optional fields behind every record
+        idx = (off[1:] - len(aux))[:, None] + np.arange(len(aux))[None, :]
+        flat[idx] = np.frombuffer(aux, np.uint8)
     if decoy_mask is not None and L >= 48 and n:
         decoy_mask = decoy_mask & with_seq
         fake = np.zeros(1, fixed.dtype)
@@ -399,19 +402,20 @@ def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None):
 WRITE_SLICE = 150000          # records encoded at a time (the index matrices of the scatter are 8 bytes per record byte)
 
 
-def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False, decoys=0.0, decoy_seed=1, no_seq=None):
+def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False, decoys=0.0, decoy_seed=1, no_seq=None, aux=b""):
     """Write `recs` (sorted) as <path> and <path>.bai.  Returns the number of uncompressed bytes.  split_records: cut the
     record stream into blocks of `block` bytes wherever that falls (records then straddle blocks, as in files written by
     samtools) instead of at record boundaries.  decoys: that share of the reads gets base qualities that read as the
     head of a BAM record of the read's contig (tests of the device walk's guessed record starts: DESIGN 4.5).
     Whole-genome-shaped samples (two million records) are encoded WRITE_SLICE records at a time; the bytes are the same.
-    no_seq: a mask of records written without sequence and qualities (l_seq 0)."""
+    no_seq: a mask of records written without sequence and qualities (l_seq 0).  aux: bytes of optional fields (tag, type,
+    value ...) appended to every record, as aligners leave them (NM, MD, AS, RG ...)."""
     n = len(recs)
     rend = recs.ref_end
     end_for_bin = np.where(rend > recs.pos, rend, recs.pos + 1)
     bins = _reg2bin(recs.pos.astype(np.int64), end_for_bin)
     no_seq = None if no_seq is None else np.asarray(no_seq, bool)
-    size, name_len, _ = _record_sizes(recs, sample, no_seq)
+    size, name_len, _ = _record_sizes(recs, sample, no_seq, aux)
     decoy_mask = (np.random.default_rng(decoy_seed).random(n) < decoys) if (decoys > 0 and n) else None
     off = np.zeros(n + 1, np.int64)
     np.cumsum(size + 4, out=off[1:])
@@ -422,7 +426,7 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False
         header += struct.pack("<i", len(c) + 1) + c.encode() + b"\x00" + struct.pack("<i", CONTIG_LEN)
     # blocks: the header alone, then whole records
     if split_records:
-        flat, off2 = _encode_records(recs, sample, name_len, bins, decoy_mask, no_seq)
+        flat, off2 = _encode_records(recs, sample, name_len, bins, decoy_mask, no_seq, aux)
         assert np.array_equal(off, off2)
         blob = flat.tobytes()
         starts = list(range(0, len(blob), block)) or [0]
@@ -457,7 +461,7 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False
                 bj += 1
             ra, rb = cuts[bi], cuts[bj]
             flat, off2 = _encode_records(recs.take(slice(ra, rb)), sample, name_len, bins[ra:rb],
-                                         None if decoy_mask is None else decoy_mask[ra:rb], None if no_seq is None else no_seq[ra:rb])
+                                         None if decoy_mask is None else decoy_mask[ra:rb], None if no_seq is None else no_seq[ra:rb], aux)
             blob = flat.tobytes()
             for a, b in zip(cuts[bi:bj], cuts[bi + 1:bj + 1]):
                 co = fp.tell()
