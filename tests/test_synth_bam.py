@@ -237,18 +237,16 @@ def test_optional_fields_and_stripped_sequences_do_not_change_what_a_scan_reads(
     """write_bam(aux=, no_seq=): the shapes real files have and the simulator's records lack -- optional fields behind every
     record, a record without its sequence -- leave every other record as it was: the scan of a file with optional fields equals
     the plain file's, field for field."""
-    from tredparse_amd import bam_parser
-    from tredparse_amd.meta import TREDsRepo
     loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1")]
-    recs, _ = synth_bam.simulate_sample(5, loci, synth.SynthParams(coverage=12))
+    recs, _ = sb.simulate_sample(5, loci, synth.SynthParams(coverage=12))
     repo, names = TREDsRepo(), [l["name"] for l in loci]
     aux = b"NMC\x02MDZ75A74\x00ASC\x91RGZgroup1\x00"
     a, b = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
-    na = synth_bam.write_bam(a, recs, sample="x")
-    nb = synth_bam.write_bam(b, recs, sample="x", aux=aux, split_records=True, block=777)
+    na = sb.write_bam(a, recs, sample="x")
+    nb = sb.write_bam(b, recs, sample="x", aux=aux, split_records=True, block=777)
     assert nb == na + len(recs) * len(aux)
-    sa, sb = bam_parser.scan_sample(a, repo, names), bam_parser.scan_sample(b, repo, names)
-    assert np.array_equal(sa.read_len, sb.read_len) and np.array_equal(sa.seq4, sb.seq4) and sa.name_blob == sb.name_blob
-    assert np.array_equal(sa.depth, sb.depth)
+    sa, sc = scan_sample(a, repo, names), scan_sample(b, repo, names)
+    assert np.array_equal(sa.read_len, sc.read_len) and np.array_equal(sa.seq4, sc.seq4) and sa.name_blob == sc.name_blob
+    assert np.array_equal(sa.depth, sc.depth)
     for k in range(len(names)):
-        assert all(np.array_equal(x, y) for x, y in zip(sa.pair_lengths(k), sb.pair_lengths(k)))
+        assert all(np.array_equal(x, y) for x, y in zip(sa.pair_lengths(k), sc.pair_lengths(k)))
