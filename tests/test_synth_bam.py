@@ -250,3 +250,27 @@ def test_optional_fields_and_stripped_sequences_do_not_change_what_a_scan_reads(
     assert np.array_equal(sa.depth, sc.depth)
     for k in range(len(names)):
         assert all(np.array_equal(x, y) for x, y in zip(sa.pair_lengths(k), sc.pair_lengths(k)))
+
+
+def test_trimmed_reads_round_trip_through_both_file_layers(tmp_path):
+    """write_bam(lengths=) + trim_records: reads trimmed before alignment -- every record its own l_seq, its CIGAR's last
+    operation shortened to match -- read back by both file layers: length, bases and query bases of the CIGAR agree."""
+    loci = [l for l in synth.load_loci() if l["name"] in ("HD", "DM1")]
+    recs, _ = sb.simulate_sample(5, loci, synth.SynthParams(coverage=10))
+    rng = np.random.default_rng(3)
+    want = np.where(rng.random(len(recs)) < 0.4, rng.integers(40, 151, len(recs)), 150)
+    cut, ls = sb.trim_records(recs, want)
+    assert (ls <= 150).all() and (ls < 150).sum() > len(recs) // 4 and recs.cig is not cut.cig
+    path = str(tmp_path / "v.bam")
+    sb.write_bam(path, cut, sample="v", lengths=ls, split_records=True, block=1234, aux=b"NMC\x01")
+    for cls in (bamio.PyAlignmentFile, bamio.NativeAlignmentFile):
+        f = cls(path)
+        rows = list(f.fetch())
+        f.close()
+        assert len(rows) == len(recs)
+        for i, r in enumerate(rows):
+            assert r.query_length == ls[i] and r.query_sequence == synth.decode(recs.codes[i])[:ls[i]]
+            assert sum(n for op, n in r.cigartuples if op in (0, 1, 4, 7, 8)) == ls[i]
+    repo = TREDsRepo()
+    s = scan_sample(path, repo, [l["name"] for l in loci])
+    assert s.readlen == 150 and int(s.read_len.min()) < 150 and s.dropped == {}

@@ -115,7 +115,7 @@ def main():
     root = tempfile.mkdtemp(prefix="tred_fuzzsel_")
     engine = Engine(0)
     out = {"rounds": rounds, "samples": 0, "on_device": 0, "declined": 0, "units": 0, "reads": 0, "mismatching_samples": 0, "what": {},
-           "block_sizes": [], "read_lengths": [], "x_linked_samples": 0, "samples_with_a_record_without_sequence": 0, "samples_with_a_mapped_record_without_cigar": 0,
+           "block_sizes": [], "read_lengths": [], "x_linked_samples": 0, "samples_with_a_record_without_sequence": 0, "samples_with_a_mapped_record_without_cigar": 0, "samples_with_trimmed_reads": 0,
            "of_which_lost_a_locus": 0}
     for k in t.TIMING:
         t.TIMING[k] = 0
@@ -162,9 +162,13 @@ def main():
                 no_seq = np.zeros(n, bool)
                 no_seq[int(rng.integers(n))] = True
                 out["samples_with_a_record_without_sequence"] += 1
+            lengths = None
+            if rnd % 4 == 1 and n:                                        # reads trimmed before alignment: two in five shortened
+                recs, lengths = synth_bam.trim_records(recs, np.where(rng.random(n) < 0.4, rng.integers(readlen // 3, readlen + 1, n), readlen))
+                out["samples_with_trimmed_reads"] += 1
             synth_bam.write_bam(path, recs, sample="f{}_{}".format(rnd, k), block=block, split_records=True,
                                 decoys=0.5 if rnd % 5 == 4 else 0.0, decoy_seed=rnd, no_seq=no_seq,
-                                aux=AUX if rnd % 3 == 2 else b"")
+                                aux=AUX if rnd % 3 == 2 else b"", lengths=lengths)
             mode = int(rng.integers(0, 5))            # plain, plain, --noalts, --useclippedreads, --fullsearch --maxinsert 60
             args.append(("f{}_{}".format(rnd, k), path, repo, names, 60 if mode == 4 else 300, mode == 4, mode == 3, mode != 2, True, "ERROR"))
             out["block_sizes"].append(block)

@@ -322,7 +322,7 @@ def _bgzf_block(data, level):
 _EOF_BLOCK = _bgzf_block(b"", 6)
 
 
-def _record_sizes(recs, sample, no_seq=None, aux=b""):
+def _record_sizes(recs, sample, no_seq=None, aux=b"", lengths=None):
     """(bytes of every record without its 4-byte block_size, name length incl. NUL, bytes of a packed sequence).  no_seq: a mask
     of records written WITHOUT their sequence (SEQ and QUAL '*', l_seq 0: what some aligners leave of secondary alignments)."""
     n = len(recs)
@@ -331,11 +331,14 @@ def _record_sizes(recs, sample, no_seq=None, aux=b""):
     if n:                                   # (names are fixed-width as long as the counters stay inside their fields)
         name_len = max(name_len, len("{}.{:02d}.{:07d}".format(sample, int(recs.locus.max()), int(recs.frag.max()))) + 1)
     seq_len = (L + 1) // 2
-    body = np.full(n, seq_len + L, np.int64) if no_seq is None else np.where(no_seq, 0, seq_len + L).astype(np.int64)
+    Ls = np.full(n, L, np.int64) if lengths is None else np.asarray(lengths, np.int64)
+    body = (Ls + 1) // 2 + Ls
+    if no_seq is not None:
+        body = np.where(no_seq, 0, body)
     return 32 + name_len + 4 * recs.n_cig.astype(np.int64) + body + len(aux), name_len, seq_len
 
 
-def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None, aux=b""):
+def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None, aux=b"", lengths=None):
     """The BAM bytes of `recs` (block_size word + record, one after the other) and the records' byte offsets in them."""
     n = len(recs)
     L = recs.codes.shape[1]
@@ -349,11 +352,15 @@ def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None, 
             for i, x in enumerate(names):
                 name_mat[i, :len(x)] = np.frombuffer(x.encode(), np.uint8)
     nib = _NIB[recs.codes]
+    Ls = np.full(n, L, np.int64) if lengths is None else np.asarray(lengths, np.int64)
+    if lengths is not None:
+        nib = np.where(np.arange(L)[None, :] < Ls[:, None], nib, 0).astype(np.uint8)      # (nothing behind a shortened read's last base)
     if L % 2:
         nib = np.concatenate([nib, np.zeros((n, 1), np.uint8)], axis=1)
     seq = (nib[:, 0::2] << 4) | nib[:, 1::2]
+    seqw = (Ls + 1) // 2
     with_seq = np.ones(n, bool) if no_seq is None else ~np.asarray(no_seq, bool)
-    size = 32 + name_len + 4 * recs.n_cig + np.where(with_seq, seq.shape[1] + L, 0) + len(aux)   # without the 4-byte block_size
+    size = 32 + name_len + 4 * recs.n_cig + np.where(with_seq, seqw + Ls, 0) + len(aux)   # without the 4-byte block_size
     off = np.zeros(n + 1, np.int64)
     np.cumsum(size + 4, out=off[1:])
     flat = np.zeros(int(off[-1]), np.uint8)
@@ -362,7 +369,7 @@ def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None, 
                                   ("mpos", "<i4"), ("tlen", "<i4")]))
     fixed["bs"], fixed["tid"], fixed["pos"], fixed["l_name"] = size, recs.tid, recs.pos, name_len
     fixed["mapq"] = np.where((recs.flag & FUNMAP) != 0, 0, 60)
-    fixed["bin"], fixed["n_cig"], fixed["flag"], fixed["l_seq"] = bins, recs.n_cig, recs.flag, np.where(with_seq, L, 0)
+    fixed["bin"], fixed["n_cig"], fixed["flag"], fixed["l_seq"] = bins, recs.n_cig, recs.flag, np.where(with_seq, Ls, 0)
     fixed["mtid"], fixed["mpos"], fixed["tlen"] = recs.mtid, recs.mpos, recs.tlen
 
     def scatter(col0, mat):
@@ -379,15 +386,23 @@ def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None, 
             flat[idx] = cig_bytes[sel, :4 * k]
     seq_at = 36 + name_len + 4 * recs.n_cig
     ws = np.nonzero(with_seq)[0]
-    idx = (off[ws] + seq_at[ws])[:, None] + np.arange(seq.shape[1])[None, :]
-    flat[idx] = seq[ws]
-    idx = (off[ws] + seq_at[ws] + seq.shape[1])[:, None] + np.arange(L)[None, :]
-    flat[idx] = 0xff                                                        # no base qualities
+    if lengths is None:
+        idx = (off[ws] + seq_at[ws])[:, None] + np.arange(seq.shape[1])[None, :]
+        flat[idx] = seq[ws]
+        idx = (off[ws] + seq_at[ws] + seq.shape[1])[:, None] + np.arange(L)[None, :]
+        flat[idx] = 0xff                                                    # no base qualities
+    else:                                                                   # every record its own width
+        idx = (off[ws] + seq_at[ws])[:, None] + np.arange(seq.shape[1])[None, :]
+        keep = np.arange(seq.shape[1])[None, :] < seqw[ws][:, None]
+        flat[idx[keep]] = seq[ws][keep]
+        idx = (off[ws] + seq_at[ws] + seqw[ws])[:, None] + np.arange(L)[None, :]
+        keep = np.arange(L)[None, :] < Ls[ws][:, None]
+        flat[idx[keep]] = 0xff
     if len(aux) and n:                                                     # the same optional fields behind every record
         idx = (off[1:] - len(aux))[:, None] + np.arange(len(aux))[None, :]
         flat[idx] = np.frombuffer(aux, np.uint8)
     if decoy_mask is not None and L >= 48 and n:
-        decoy_mask = decoy_mask & with_seq
+        decoy_mask = decoy_mask & with_seq & (Ls == L)
         fake = np.zeros(1, fixed.dtype)
         fake["bs"], fake["pos"], fake["l_name"], fake["mtid"], fake["mpos"] = 40, 5, 2, -1, -1
         sel = np.nonzero(decoy_mask)[0]
@@ -399,23 +414,43 @@ def _encode_records(recs, sample, name_len, bins, decoy_mask=None, no_seq=None, 
     return flat, off
 
 
+def trim_records(recs, lengths):
+    """`recs` with every record cut to lengths[i] bases at the end of its CIGAR (reads trimmed before alignment): the last
+    operation gives up the bases; a record whose last operation is too short for that keeps its length.  Returns (records --
+    the CIGAR matrix is a copy, the other arrays are shared --, the lengths really applied)."""
+    L = recs.codes.shape[1]
+    want = np.minimum(np.asarray(lengths, np.int64), L)
+    cig = recs.cig.copy()
+    last = np.maximum(recs.n_cig.astype(np.int64) - 1, 0)
+    rows = np.arange(len(recs))
+    op_len = (cig[rows, last] >> 4).astype(np.int64)
+    cut = L - want
+    ok = (recs.n_cig > 0) & (cut > 0) & (op_len > cut)
+    cig[rows[ok], last[ok]] = (((op_len[ok] - cut[ok]) << 4) | (cig[rows[ok], last[ok]] & 15)).astype(cig.dtype)
+    out = Records(**{k: (cig if k == "cig" else getattr(recs, k)) for k in Records.FIELDS})
+    return out, np.where(ok, want, L)
+
+
 WRITE_SLICE = 150000          # records encoded at a time (the index matrices of the scatter are 8 bytes per record byte)
 
 
-def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False, decoys=0.0, decoy_seed=1, no_seq=None, aux=b""):
+def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False, decoys=0.0, decoy_seed=1, no_seq=None, aux=b"",
+              lengths=None):
     """Write `recs` (sorted) as <path> and <path>.bai.  Returns the number of uncompressed bytes.  split_records: cut the
     record stream into blocks of `block` bytes wherever that falls (records then straddle blocks, as in files written by
     samtools) instead of at record boundaries.  decoys: that share of the reads gets base qualities that read as the
     head of a BAM record of the read's contig (tests of the device walk's guessed record starts: DESIGN 4.5).
     Whole-genome-shaped samples (two million records) are encoded WRITE_SLICE records at a time; the bytes are the same.
     no_seq: a mask of records written without sequence and qualities (l_seq 0).  aux: bytes of optional fields (tag, type,
-    value ...) appended to every record, as aligners leave them (NM, MD, AS, RG ...)."""
+    value ...) appended to every record, as aligners leave them (NM, MD, AS, RG ...).  lengths: every record's own sequence
+    length (<= the codes' width; trim_records makes the CIGARs agree): reads trimmed before alignment."""
     n = len(recs)
     rend = recs.ref_end
     end_for_bin = np.where(rend > recs.pos, rend, recs.pos + 1)
     bins = _reg2bin(recs.pos.astype(np.int64), end_for_bin)
     no_seq = None if no_seq is None else np.asarray(no_seq, bool)
-    size, name_len, _ = _record_sizes(recs, sample, no_seq, aux)
+    lengths = None if lengths is None else np.asarray(lengths, np.int64)
+    size, name_len, _ = _record_sizes(recs, sample, no_seq, aux, lengths)
     decoy_mask = (np.random.default_rng(decoy_seed).random(n) < decoys) if (decoys > 0 and n) else None
     off = np.zeros(n + 1, np.int64)
     np.cumsum(size + 4, out=off[1:])
@@ -426,7 +461,7 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False
         header += struct.pack("<i", len(c) + 1) + c.encode() + b"\x00" + struct.pack("<i", CONTIG_LEN)
     # blocks: the header alone, then whole records
     if split_records:
-        flat, off2 = _encode_records(recs, sample, name_len, bins, decoy_mask, no_seq, aux)
+        flat, off2 = _encode_records(recs, sample, name_len, bins, decoy_mask, no_seq, aux, lengths)
         assert np.array_equal(off, off2)
         blob = flat.tobytes()
         starts = list(range(0, len(blob), block)) or [0]
@@ -461,7 +496,8 @@ def write_bam(path, recs, sample="s", level=1, block=0xff00, split_records=False
                 bj += 1
             ra, rb = cuts[bi], cuts[bj]
             flat, off2 = _encode_records(recs.take(slice(ra, rb)), sample, name_len, bins[ra:rb],
-                                         None if decoy_mask is None else decoy_mask[ra:rb], None if no_seq is None else no_seq[ra:rb], aux)
+                                         None if decoy_mask is None else decoy_mask[ra:rb], None if no_seq is None else no_seq[ra:rb], aux,
+                                         None if lengths is None else lengths[ra:rb])
             blob = flat.tobytes()
             for a, b in zip(cuts[bi:bj], cuts[bi + 1:bj + 1]):
                 co = fp.tell()
